@@ -1,0 +1,268 @@
+/*
+ * pbrt_amd.h -- the drop-in boundary of the MI355X wavefront path tracer.
+ *
+ * C ABI of libpbrt_amd.so (hand-written HIP for gfx950 behind extern "C").  It replaces ONE
+ * call of the reference: `integrator->Render(*scene)` (reference src/core/api.cpp:1623), i.e.
+ * SamplerIntegrator::Render -> PathIntegrator::Li (src/core/integrator.cpp:228-339,
+ * src/integrators/path.cpp:64-188) with everything under it.  Everything a reference-side
+ * Integrator subclass can see of a built Scene is passed in as plain-old-data:
+ * pointers + sizes, no C++ types, no torch types.  INTEGRATION.md shows the ~100-line
+ * `WavefrontPathIntegrator : public Integrator` a pbrt-v3 maintainer would add on top of this.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; mi_last_error() gives the message
+ *     (pbrt's own convention is Error()/Warning() + continue, src/core/error.cpp:89-102;
+ *      no exception crosses this boundary).
+ *   - all pointers in mi_scene_desc are HOST pointers; the library owns every device
+ *     allocation.  mi_scene_upload copies; the caller may free its arrays afterwards.
+ *   - one mi_ctx per GPU (one process per GPU in multi-GPU runs); calls on one ctx are
+ *     serialised by the caller, work is enqueued on the ctx stream.
+ *   - Float == IEEE binary32 (src/core/pbrt.h:156), Spectrum == RGB, 3 floats
+ *     (src/core/spectrum.h:429).
+ */
+#ifndef PBRT_AMD_H
+#define PBRT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- geometry ---------- */
+
+/* LinearBVHNode exactly as BVHAccel flattens it (src/accelerators/bvh.cpp:95-104, :640-658):
+ * DFS order, first child = this+1, second child = `offset`; leaf iff n_prims > 0. The shim
+ * collapses this tree to its 128-byte BVH4 device layout; the reference hands its own array. */
+typedef struct mi_bvh2_node {
+    float bmin[3], bmax[3];
+    int32_t offset;   /* primitivesOffset (leaf) | secondChildOffset (interior) */
+    uint16_t n_prims; /* 0 -> interior */
+    uint8_t axis;     /* interior: split axis */
+    uint8_t pad;
+} mi_bvh2_node;
+
+/* per-TriangleMesh flags (src/shapes/triangle.h:51-69) */
+#define MI_MESH_HAS_N 1u  /* per-vertex normals present */
+#define MI_MESH_HAS_UV 2u /* per-vertex uv present (else (0,0),(1,0),(1,1): triangle.h:98-108) */
+#define MI_MESH_HAS_S 4u  /* per-vertex tangents present */
+#define MI_MESH_FLIP 8u   /* reverseOrientation ^ transformSwapsHandedness (triangle.cpp:417-421) */
+
+typedef struct mi_mesh {
+    uint32_t flags;
+    int32_t material; /* index into materials[]; -1 = no material (null BSDF, path.cpp:108) */
+} mi_mesh;
+
+/* ---------------------------------------------------------------- materials --------- */
+
+/* One BxDF of a BSDF (src/core/reflection.h).  Textures are constant in this slice, so the lobe
+ * list Material::ComputeScatteringFunctions would build (src/materials/ *.cpp) is a function of
+ * the material alone and is passed pre-evaluated (clamped, black lobes dropped, roughness
+ * remapped: matte.cpp:54-61, plastic.cpp:52-69, microfacet.h:123-128). */
+enum mi_bxdf_type {
+    MI_BXDF_LAMBERT_R = 0,    /* LambertianReflection     reflection.cpp:178  */
+    MI_BXDF_LAMBERT_T = 1,    /* LambertianTransmission   reflection.cpp:187,391-403 */
+    MI_BXDF_OREN_NAYAR = 2,   /* OrenNayar                reflection.cpp:197-219 */
+    MI_BXDF_SPECULAR_R = 3,   /* SpecularReflection       reflection.cpp:136-143 */
+    MI_BXDF_SPECULAR_T = 4,   /* SpecularTransmission     reflection.cpp:150-166 */
+    MI_BXDF_FRESNEL_SPEC = 5, /* FresnelSpecular          reflection.cpp:477-511 */
+    MI_BXDF_MICROFACET_R = 6, /* MicrofacetReflection     reflection.cpp:226-236,405-423 */
+    MI_BXDF_MICROFACET_T = 7, /* MicrofacetTransmission   reflection.cpp:244-266,425-448 */
+    MI_BXDF_FRESNEL_BLEND = 8 /* FresnelBlend             reflection.cpp:279-298,450-475 */
+};
+enum mi_fresnel_type { MI_FRESNEL_NOOP = 0, MI_FRESNEL_DIELECTRIC = 1, MI_FRESNEL_CONDUCTOR = 2 };
+
+typedef struct mi_bxdf {
+    int32_t type;       /* mi_bxdf_type */
+    int32_t fresnel;    /* mi_fresnel_type (SPECULAR_R / MICROFACET_R only) */
+    int32_t scaled;     /* 1 -> wrapped in ScaledBxDF(scale) (mixmat.cpp:57-63) */
+    int32_t distrib;    /* 0 = TrowbridgeReitz (all stock materials), 1 = Beckmann */
+    float R[3];         /* R | Rd (FresnelBlend) | T for *_T lobes lives in T */
+    float T[3];         /* T | Rs (FresnelBlend) */
+    float scale[3];     /* ScaledBxDF factor */
+    float alphax, alphay;
+    float etaA, etaB;   /* dielectric: FresnelDielectric(etaI=etaA, etaT=etaB) / etaA,etaB of *_T */
+    float eta_c[3];     /* conductor: etaT (etaI = 1) */
+    float k_c[3];       /* conductor: k */
+    float A, B;         /* OrenNayar precomputed (reflection.h:  A = 1 - s2/(2(s2+.33)), B = .45 s2/(s2+.09)) */
+} mi_bxdf;
+
+#define MI_MAX_BXDFS 8 /* reflection.h:199 */
+typedef struct mi_material {
+    int32_t n_bxdfs;
+    float eta; /* BSDF::eta (reflection.h:156; glass.cpp:58, uber.cpp:56-60) */
+    mi_bxdf bxdfs[MI_MAX_BXDFS];
+} mi_material;
+
+/* ---------------------------------------------------------------- lights ------------ */
+
+enum mi_light_type {
+    MI_LIGHT_AREA_TRI = 0, /* DiffuseAreaLight on one Triangle (api.cpp:1357-1366, lights/diffuse.cpp) */
+    MI_LIGHT_POINT = 1,    /* PointLight   lights/point.cpp:44-53  */
+    MI_LIGHT_DISTANT = 2,  /* DistantLight lights/distant.cpp:49-67 */
+    MI_LIGHT_INFINITE = 3  /* InfiniteAreaLight, constant L only (lights/infinite.cpp:92-132) */
+};
+typedef struct mi_light {
+    int32_t type;
+    int32_t tri;       /* AREA_TRI: triangle index in BVH primitive order */
+    int32_t two_sided; /* AREA_TRI: diffuse.h:56-58 */
+    int32_t pad;
+    float L[3];        /* Lemit | I | L */
+    float area;        /* AREA_TRI: Triangle::Area() (triangle.cpp:575-581) */
+    float pos[3];      /* POINT: pLight; DISTANT: wLight (normalised, world) */
+    float world_radius;/* DISTANT/INFINITE: Scene bound radius (Preprocess) */
+    float world_center[3];
+    float pad2;
+} mi_light;
+
+/* ---------------------------------------------------------------- camera/film ------- */
+
+typedef struct mi_camera {     /* PerspectiveCamera, cameras/perspective.cpp:45-67 */
+    float raster_to_camera[16]; /* Transform::m, row major */
+    float camera_to_world[16];  /* CameraToWorld (static; AnimatedTransform start) */
+    float dx_camera[3], dy_camera[3];
+    float lens_radius, focal_distance;
+    float shutter_open, shutter_close;
+} mi_camera;
+
+#define MI_FILTER_TABLE_WIDTH 16 /* film.h:96 */
+typedef struct mi_film {     /* Film, core/film.cpp:45-86 */
+    int32_t full_res[2];
+    int32_t crop_min[2], crop_max[2];     /* croppedPixelBounds */
+    int32_t sample_min[2], sample_max[2]; /* Film::GetSampleBounds() */
+    float filter_radius[2];
+    float filter_table[MI_FILTER_TABLE_WIDTH * MI_FILTER_TABLE_WIDTH];
+    float max_sample_luminance;
+    float scale;
+} mi_film;
+
+typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
+    int32_t max_depth;          /* path.cpp:193, default 5 */
+    float rr_threshold;         /* path.cpp:208, default 1 */
+    int32_t pixel_min[2], pixel_max[2]; /* pixelBounds (path.cpp:195-207) */
+    int32_t spp;                /* RoundUpPow2(pixelsamples) (sobol.h:52) */
+    int32_t sobol_resolution;   /* sobol.h:58-59 */
+    int32_t sobol_log2_resolution;
+} mi_integrator;
+
+/* ---------------------------------------------------------------- the scene --------- */
+
+typedef struct mi_scene_desc {
+    uint32_t abi_version; /* = MI_ABI_VERSION */
+    /* vertices (world space, triangle.cpp:72-74) */
+    uint32_t n_verts;
+    const float *P;  /* 3*n_verts */
+    const float *N;  /* 3*n_verts, zeros where the mesh has none; may be NULL if no mesh has normals */
+    const float *UV; /* 2*n_verts; may be NULL */
+    /* triangles in BVHAccel::primitives order (bvh.cpp:205 `primitives.swap(orderedPrims)`) */
+    uint32_t n_tris;
+    const uint32_t *tri_indices; /* 3*n_tris global vertex indices */
+    const uint32_t *tri_mesh;    /* n_tris -> meshes[] */
+    const int32_t *tri_light;    /* n_tris -> lights[] index or -1 */
+    uint32_t n_meshes;
+    const mi_mesh *meshes;
+    /* acceleration structure */
+    uint32_t n_bvh_nodes;
+    const mi_bvh2_node *bvh_nodes;
+    /* shading */
+    uint32_t n_materials;
+    const mi_material *materials;
+    uint32_t n_lights;
+    const mi_light *lights;
+    /* light-selection distribution (Distribution1D over all lights: uniform/power,
+     * lightdistrib.cpp:56-75); func has n_lights entries, cdf n_lights+1 */
+    const float *light_func;
+    const float *light_cdf;
+    float light_func_int;
+    float pad0;
+    mi_camera camera;
+    mi_film film;
+    mi_integrator integrator;
+} mi_scene_desc;
+
+/* ---------------------------------------------------------------- ABI ---------------- */
+
+typedef struct mi_ctx mi_ctx;
+
+const char *mi_last_error(void);
+int mi_abi_version(void);
+
+/* context: one per GPU. `stream` = a hipStream_t to run on (0 -> library creates its own). */
+int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out);
+void mi_ctx_destroy(mi_ctx *ctx);
+
+/* Scene hand-over: what `Integrator::Render(const Scene&)` receives (integrator.h:53-58).
+ * Builds the BVH4, triangle records and tables in HBM. */
+int mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
+
+/* SamplerIntegrator::Render (integrator.cpp:228-339) over the 16x16 tiles owned by `rank` of
+ * `world` (tile t -> rank t % world; integrator.cpp:235-240 gives the tile grid), samples
+ * [spp_begin, spp_end) of every owned pixel, accumulated into the device film
+ * (FilmTile::AddSample semantics, film.h:121-161).  Asynchronous on the ctx stream. */
+typedef struct mi_render_params {
+    int32_t rank, world;
+    int32_t spp_begin, spp_end; /* spp_end = -1 -> integrator.spp */
+    int32_t count_work;         /* 1 -> maintain nodes-visited / tris-tested counters (slower) */
+    int32_t max_paths_in_flight;/* 0 -> default */
+} mi_render_params;
+int mi_render(mi_ctx *ctx, const mi_render_params *params);
+int mi_sync(mi_ctx *ctx);
+
+/* Film: FilmTilePixel{contribSum rgb, filterWeightSum} = 16 B per cropped pixel
+ * (film.h:52-55) -- the multi-GPU gather payload.  The host Film performs
+ * MergeFilmTile/WriteImage (film.cpp:117-130,168-210) on the downloaded array. */
+int mi_film_clear(mi_ctx *ctx);
+int mi_film_download(mi_ctx *ctx, float *rgbw /* 4 * cropped pixel count */);
+void *mi_film_device_ptr(mi_ctx *ctx); /* float4 per cropped pixel, for RCCL by the caller */
+int64_t mi_film_pixel_count(mi_ctx *ctx);
+
+/* Work counters (names follow the reference's STAT_COUNTERs: integrator.cpp:48,
+ * scene.cpp:40-42, triangle.cpp:45) */
+enum mi_counter {
+    MI_CNT_CAMERA_RAYS = 0,
+    MI_CNT_CLOSEST_RAYS = 1, /* Scene::Intersect calls  */
+    MI_CNT_SHADOW_RAYS = 2,  /* Scene::IntersectP calls */
+    MI_CNT_NODES_CLOSEST = 3,/* BVH4 nodes fetched by closest-hit kernel launches */
+    MI_CNT_TRIS_CLOSEST = 4,
+    MI_CNT_NODES_ANY = 5,
+    MI_CNT_TRIS_ANY = 6,
+    MI_CNT_PATH_SEGMENTS = 7,
+    MI_CNT_COUNT = 16
+};
+int mi_counters(mi_ctx *ctx, uint64_t out[MI_CNT_COUNT]);
+int mi_counters_reset(mi_ctx *ctx);
+
+/* Per-kernel device time (HIP events recorded on the ctx stream around every launch while
+ * enabled).  Kernel ids: */
+enum mi_kernel_id {
+    MI_K_RAYGEN = 0, MI_K_CLOSEST = 1, MI_K_SORT = 2, MI_K_SHADE = 3, MI_K_ANYHIT = 4,
+    MI_K_MIS_CLOSEST = 5, MI_K_FILM = 6, MI_K_COUNT = 8
+};
+int mi_timing_enable(mi_ctx *ctx, int on);
+int mi_timing_get(mi_ctx *ctx, double ms_total[MI_K_COUNT], uint64_t launches[MI_K_COUNT]);
+
+/* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
+
+typedef struct mi_ray { float o[3]; float tmax; float d[3]; float time; } mi_ray;  /* geometry.h:869-890 */
+typedef struct mi_hit { int32_t prim; float t; float b0, b1, b2; float n[3]; } mi_hit; /* prim -1 = miss */
+
+/* BVHAccel::Intersect (bvh.cpp:662-700) + Triangle::Intersect (triangle.cpp:188-425) */
+int mi_intersect(mi_ctx *ctx, const mi_ray *rays, int64_t n, mi_hit *hits);
+/* BVHAccel::IntersectP (bvh.cpp:702-738) */
+int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded);
+/* SobolSampler: GetIndexForSample + SampleDimension (sobol.cpp:42-59) for pixel (px,py),
+ * sample numbers [0,n_samples), dimensions [0,n_dims); out[s*n_dims+d]; index_out[s] */
+int mi_sobol(mi_ctx *ctx, int px, int py, int n_samples, int n_dims, float *out, uint64_t *index_out);
+/* Sampler::GetCameraSample + PerspectiveCamera::GenerateRayDifferential (sampler.cpp:46-52,
+ * perspective.cpp:95-144) for n (pixel, sample) pairs */
+int mi_camera_rays(mi_ctx *ctx, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n,
+                   mi_ray *rays, float *p_film /* 2*n */);
+/* PathIntegrator::Li per camera sample, before the film: radiance rgb for n (pixel,sample) pairs */
+int mi_li(mi_ctx *ctx, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *L_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_AMD_H */

@@ -1,0 +1,272 @@
+"""pbrt-v3-distributed_amd: ctypes binding over the C ABI of include/pbrt_amd.h.
+
+Python here is plumbing only: it loads
+  lib/libpbrt_amd_host.so  (C++ host: .pbrt parser, pbrt API state machine, SAH BVH build, Film)
+  lib/libpbrt_amd.so       (hand-written HIP kernels for gfx950 behind extern "C" mi_* entry points)
+and passes POD pointers between them.  There is no Python or CPU rendering path: every render /
+intersect / sample call goes to the HIP library and raises if it (or a GPU) is unavailable.
+
+Import with:  importlib.import_module("pbrt-v3-distributed_amd")   (the directory name is not an identifier)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HOST_LIB = os.path.join(LIB_DIR, "libpbrt_amd_host.so")
+DEVICE_LIB = os.path.join(LIB_DIR, "libpbrt_amd.so")
+
+MI_CNT_COUNT = 16
+MI_K_COUNT = 8
+COUNTER_NAMES = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any",
+                 "tris_any", "path_segments"]
+KERNEL_NAMES = ["raygen", "closest", "sort", "shade", "anyhit", "mis_closest", "film", "other"]
+
+
+class MiRay(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("tmax", C.c_float), ("d", C.c_float * 3), ("time", C.c_float)]
+
+
+class MiHit(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float),
+                ("n", C.c_float * 3)]
+
+
+class MiRenderParams(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("spp_begin", C.c_int32), ("spp_end", C.c_int32),
+                ("count_work", C.c_int32), ("max_paths_in_flight", C.c_int32)]
+
+
+RAY_DTYPE = np.dtype([("o", np.float32, 3), ("tmax", np.float32), ("d", np.float32, 3), ("time", np.float32)])
+HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32), ("b1", np.float32),
+                      ("b2", np.float32), ("n", np.float32, 3)])
+
+# Every symbol include/pbrt_amd.h declares (checked by tests/test_abi.py against the header text)
+DEVICE_SYMBOLS = [
+    "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
+    "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_pixel_count", "mi_counters",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_camera_rays", "mi_li",
+]
+
+_host = None
+_dev = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("%s missing: run __graft_entry__.build() / make -C pbrt-v3-distributed_amd" % HOST_LIB)
+        L = C.CDLL(HOST_LIB, mode=C.RTLD_GLOBAL)
+        L.pbrt_amd_scene_load.restype = C.c_void_p
+        L.pbrt_amd_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        L.pbrt_amd_scene_free.argtypes = [C.c_void_p]
+        L.pbrt_amd_scene_desc.restype = C.c_void_p
+        L.pbrt_amd_scene_desc.argtypes = [C.c_void_p]
+        L.pbrt_amd_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        for f in ("pbrt_amd_film_merge", "pbrt_amd_film_rgb"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.pbrt_amd_film_clear.argtypes = [C.c_void_p]
+        L.pbrt_amd_film_write.argtypes = [C.c_void_p, C.c_char_p]
+        _host = L
+    return _host
+
+
+def device_lib():
+    """The HIP library.  Fails loudly: there is no fallback path."""
+    global _dev
+    if _dev is None:
+        if not os.path.exists(DEVICE_LIB):
+            raise RuntimeError("%s missing: the HIP extension was not built (hipcc --offload-arch=gfx950)" % DEVICE_LIB)
+        L = C.CDLL(DEVICE_LIB, mode=C.RTLD_GLOBAL)
+        L.mi_last_error.restype = C.c_char_p
+        L.mi_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mi_ctx_destroy.argtypes = [C.c_void_p]
+        L.mi_scene_upload.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_render.argtypes = [C.c_void_p, C.POINTER(MiRenderParams)]
+        L.mi_sync.argtypes = [C.c_void_p]
+        L.mi_film_clear.argtypes = [C.c_void_p]
+        L.mi_film_download.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_film_device_ptr.restype = C.c_void_p
+        L.mi_film_device_ptr.argtypes = [C.c_void_p]
+        L.mi_film_pixel_count.restype = C.c_int64
+        L.mi_film_pixel_count.argtypes = [C.c_void_p]
+        L.mi_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_counters_reset.argtypes = [C.c_void_p]
+        L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
+        L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mi_sobol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mi_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        _dev = L
+    return _dev
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """A parsed .pbrt scene, flattened to the POD mi_scene_desc (host side only; no GPU needed)."""
+
+    INFO_FIELDS = ["n_verts", "n_tris", "n_meshes", "n_bvh_nodes", "n_materials", "n_lights", "xres", "yres",
+                   "crop_x0", "crop_y0", "crop_x1", "crop_y1", "spp", "max_depth", "sobol_resolution",
+                   "sobol_log2_resolution"]
+
+    def __init__(self, filename=None, text=None, quiet=True, outfile=None):
+        L = host_lib()
+        src = text if text is not None else filename
+        self._h = L.pbrt_amd_scene_load(src.encode(), 1 if text is not None else 0, 1 if quiet else 0,
+                                        outfile.encode() if outfile else None)
+        if not self._h:
+            raise RuntimeError("scene load failed: %r" % (filename or "<text>"))
+        self.desc = L.pbrt_amd_scene_desc(self._h)
+        info = (C.c_int64 * len(self.INFO_FIELDS))()
+        L.pbrt_amd_scene_info(self._h, info)
+        self.info = dict(zip(self.INFO_FIELDS, [int(v) for v in info]))
+        self.width = self.info["crop_x1"] - self.info["crop_x0"]
+        self.height = self.info["crop_y1"] - self.info["crop_y0"]
+
+    def close(self):
+        if self._h:
+            host_lib().pbrt_amd_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host Film (MergeFilmTile / WriteImage semantics, reference film.cpp:117-130,168-210)
+    def film_image(self, rgbw):
+        """rgbw: (H, W, 4) float32 {contribSum rgb, filterWeightSum} -> final (H, W, 3) image."""
+        L = host_lib()
+        rgbw = np.ascontiguousarray(rgbw, dtype=np.float32)
+        L.pbrt_amd_film_clear(self._h)
+        L.pbrt_amd_film_merge(self._h, _ptr(rgbw))
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        L.pbrt_amd_film_rgb(self._h, _ptr(out))
+        return out
+
+    def write_image(self, rgbw, filename):
+        self.film_image(rgbw)
+        host_lib().pbrt_amd_film_write(self._h, filename.encode())
+
+
+class Context:
+    """One GPU context of the HIP path tracer with an uploaded scene."""
+
+    def __init__(self, scene, device=0, stream=None):
+        L = device_lib()
+        self.scene = scene
+        self._ctx = C.c_void_p()
+        if L.mi_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._ctx)) != 0:
+            raise RuntimeError("mi_ctx_create: %s" % L.mi_last_error().decode())
+        if L.mi_scene_upload(self._ctx, scene.desc) != 0:
+            raise RuntimeError("mi_scene_upload: %s" % L.mi_last_error().decode())
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, device_lib().mi_last_error().decode()))
+
+    def close(self):
+        if self._ctx:
+            device_lib().mi_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, rank=0, world=1, spp_begin=0, spp_end=-1, count_work=False, max_paths=0, sync=True):
+        p = MiRenderParams(rank, world, spp_begin, spp_end, 1 if count_work else 0, max_paths)
+        self._chk(device_lib().mi_render(self._ctx, C.byref(p)), "mi_render")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._chk(device_lib().mi_sync(self._ctx), "mi_sync")
+
+    def film_clear(self):
+        self._chk(device_lib().mi_film_clear(self._ctx), "mi_film_clear")
+
+    def film(self):
+        out = np.empty((self.scene.height, self.scene.width, 4), dtype=np.float32)
+        self._chk(device_lib().mi_film_download(self._ctx, _ptr(out)), "mi_film_download")
+        return out
+
+    def film_device_ptr(self):
+        return device_lib().mi_film_device_ptr(self._ctx)
+
+    def counters(self):
+        out = np.zeros(MI_CNT_COUNT, dtype=np.uint64)
+        self._chk(device_lib().mi_counters(self._ctx, _ptr(out)), "mi_counters")
+        return dict(zip(COUNTER_NAMES, [int(v) for v in out[:len(COUNTER_NAMES)]]))
+
+    def counters_reset(self):
+        self._chk(device_lib().mi_counters_reset(self._ctx), "mi_counters_reset")
+
+    def timing_enable(self, on=True):
+        self._chk(device_lib().mi_timing_enable(self._ctx, 1 if on else 0), "mi_timing_enable")
+
+    def timing(self):
+        ms = np.zeros(MI_K_COUNT, dtype=np.float64)
+        n = np.zeros(MI_K_COUNT, dtype=np.uint64)
+        self._chk(device_lib().mi_timing_get(self._ctx, _ptr(ms), _ptr(n)), "mi_timing_get")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    # ---- stage-level entry points
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self._chk(device_lib().mi_intersect(self._ctx, _ptr(rays), len(rays), _ptr(hits)), "mi_intersect")
+        return hits
+
+    def intersect_p(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        self._chk(device_lib().mi_intersect_p(self._ctx, _ptr(rays), len(rays), _ptr(occ)), "mi_intersect_p")
+        return occ
+
+    def sobol(self, px, py, n_samples, n_dims):
+        out = np.zeros((n_samples, n_dims), dtype=np.float32)
+        idx = np.zeros(n_samples, dtype=np.uint64)
+        self._chk(device_lib().mi_sobol(self._ctx, px, py, n_samples, n_dims, _ptr(out), _ptr(idx)), "mi_sobol")
+        return out, idx
+
+    def camera_rays(self, pixels_xy, sample_num):
+        pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)
+        sample_num = np.ascontiguousarray(sample_num, dtype=np.int32)
+        n = len(sample_num)
+        rays = np.zeros(n, dtype=RAY_DTYPE)
+        pfilm = np.zeros((n, 2), dtype=np.float32)
+        self._chk(device_lib().mi_camera_rays(self._ctx, _ptr(pixels_xy), _ptr(sample_num), n, _ptr(rays), _ptr(pfilm)),
+                  "mi_camera_rays")
+        return rays, pfilm
+
+    def li(self, pixels_xy, sample_num):
+        pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)
+        sample_num = np.ascontiguousarray(sample_num, dtype=np.int32)
+        n = len(sample_num)
+        out = np.zeros((n, 3), dtype=np.float32)
+        self._chk(device_lib().mi_li(self._ctx, _ptr(pixels_xy), _ptr(sample_num), n, _ptr(out)), "mi_li")
+        return out
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        tag = f.readline().strip()
+        if tag != b"PF":
+            raise ValueError("not a 3-channel PFM: %s" % path)
+        w, h = [int(v) for v in f.readline().split()]
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(w * h * 12), dtype="<f4" if scale < 0 else ">f4").reshape(h, w, 3)
+    return np.ascontiguousarray(data[::-1]).astype(np.float32)

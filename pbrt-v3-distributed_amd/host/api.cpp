@@ -1,0 +1,559 @@
+// Scene-description state machine.  Follows the reference's core/api.cpp: graphics-state and
+// CTM stacks (:353-365, :1124-1192), named coordinate systems (:988-1006), options block vs
+// world block checks (:375-403), defaults (:166-176), pbrtShape creating one area light per
+// emissive triangle (:1333-1424), object instancing (:1524-1592; static instances are flattened
+// here), and pbrtWorldEnd building Scene + Integrator then calling Render once (:1594-1653).
+#include "api.h"
+
+#include <map>
+
+namespace pbrt_amd {
+
+std::string g_imageFileOverride;
+Float g_cropWindow[4] = {0, 1, 0, 1};
+bool g_quickRender = false;
+
+namespace {
+
+enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
+const int MaxTransforms = 2;
+const uint32_t StartTransformBits = 1, EndTransformBits = 2, AllTransformsBits = 3;
+
+struct TransformSet {
+    Transform t[MaxTransforms];
+    Transform &operator[](int i) { return t[i]; }
+    const Transform &operator[](int i) const { return t[i]; }
+    bool IsAnimated() const { return !(t[0] == t[1]); }
+};
+TransformSet InverseSet(const TransformSet &ts) { TransformSet r; for (int i = 0; i < MaxTransforms; ++i) r.t[i] = Inverse(ts.t[i]); return r; }
+
+struct MaterialInstance { std::string name; std::shared_ptr<Material> material; ParamSet params; };
+
+struct GraphicsState {
+    TextureMaps textures;
+    std::map<std::string, std::shared_ptr<MaterialInstance>> namedMaterials;
+    std::shared_ptr<MaterialInstance> currentMaterial;
+    ParamSet areaLightParams;
+    std::string areaLight;
+    bool reverseOrientation = false;
+    GraphicsState() {
+        ParamSet empty;
+        TextureParams tp(empty, empty, textures);
+        currentMaterial = std::make_shared<MaterialInstance>(MaterialInstance{"matte", MakeMaterial("matte", tp, nullptr), ParamSet()});
+    }
+};
+
+struct RenderOptions {   // api.cpp:150-186
+    Float transformStartTime = 0, transformEndTime = 1;
+    std::string FilterName = "box", FilmName = "image", SamplerName = "halton", AcceleratorName = "bvh",
+                IntegratorName = "path", CameraName = "perspective";
+    ParamSet FilterParams, FilmParams, SamplerParams, AcceleratorParams, IntegratorParams, CameraParams;
+    TransformSet CameraToWorld;
+    std::vector<LightEntry> lights;
+    std::vector<GeometricPrimitive> primitives;
+    std::map<std::string, std::vector<GeometricPrimitive>> instances;
+    std::vector<GeometricPrimitive> *currentInstance = nullptr;
+};
+
+APIState currentApiState = APIState::Uninitialized;
+TransformSet curTransform;
+uint32_t activeTransformBits = AllTransformsBits;
+std::map<std::string, TransformSet> namedCoordinateSystems;
+std::unique_ptr<RenderOptions> renderOptions;
+GraphicsState graphicsState;
+std::vector<GraphicsState> pushedGraphicsStates;
+std::vector<TransformSet> pushedTransforms;
+std::vector<uint32_t> pushedActiveTransformBits;
+Options PbrtOptions;
+std::unique_ptr<BuiltScene> builtScene;
+
+#define VERIFY_INITIALIZED(func)                                                        \
+    if (currentApiState == APIState::Uninitialized) {                                   \
+        Error("pbrtInit() must be before calling \"%s()\". Ignoring.", func);           \
+        return;                                                                         \
+    } else
+#define VERIFY_OPTIONS(func)                                                            \
+    VERIFY_INITIALIZED(func);                                                           \
+    if (currentApiState == APIState::WorldBlock) {                                      \
+        Error("Options cannot be set inside world block; \"%s\" not allowed.  Ignoring.", func); \
+        return;                                                                         \
+    } else
+#define VERIFY_WORLD(func)                                                              \
+    VERIFY_INITIALIZED(func);                                                           \
+    if (currentApiState == APIState::OptionsBlock) {                                    \
+        Error("Scene description must be inside world block; \"%s\" not allowed. Ignoring.", func); \
+        return;                                                                         \
+    } else
+#define FOR_ACTIVE_TRANSFORMS(expr) \
+    for (int i = 0; i < MaxTransforms; ++i) if (activeTransformBits & (1 << i)) { expr }
+#define WARN_IF_ANIMATED_TRANSFORM(func)                                                                         \
+    do { if (curTransform.IsAnimated())                                                                          \
+        Warning("Animated transformations set; ignoring for \"%s\" and using the start transform only", func);   \
+    } while (false)
+
+Matrix4x4 fromColumnMajor(const Float tr[16]) {   // api.cpp:922-925
+    return Matrix4x4(tr[0], tr[4], tr[8], tr[12], tr[1], tr[5], tr[9], tr[13], tr[2], tr[6], tr[10], tr[14], tr[3],
+                     tr[7], tr[11], tr[15]);
+}
+
+}  // namespace
+
+void pbrtInit(const Options &opt) {
+    PbrtOptions = opt;
+    g_imageFileOverride = opt.imageFile;
+    g_quickRender = opt.quickRender;
+    g_quiet = opt.quiet;
+    g_cropWindow[0] = opt.cropWindow[0][0]; g_cropWindow[1] = opt.cropWindow[0][1];
+    g_cropWindow[2] = opt.cropWindow[1][0]; g_cropWindow[3] = opt.cropWindow[1][1];
+    if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
+    currentApiState = APIState::OptionsBlock;
+    renderOptions.reset(new RenderOptions);
+    graphicsState = GraphicsState();
+    curTransform = TransformSet();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems.clear();
+    pushedGraphicsStates.clear(); pushedTransforms.clear(); pushedActiveTransformBits.clear();
+}
+
+void pbrtCleanup() {
+    if (currentApiState == APIState::Uninitialized) Error("pbrtCleanup() called without pbrtInit().");
+    else if (currentApiState == APIState::WorldBlock) Error("pbrtCleanup() called while inside world block.");
+    currentApiState = APIState::Uninitialized;
+    renderOptions.reset(nullptr);
+}
+
+void pbrtIdentity() { VERIFY_INITIALIZED("Identity"); FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform();) }
+void pbrtTranslate(Float dx, Float dy, Float dz) {
+    VERIFY_INITIALIZED("Translate");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Translate(Vec3(dx, dy, dz));)
+}
+void pbrtTransform(Float tr[16]) {
+    VERIFY_INITIALIZED("Transform");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform(fromColumnMajor(tr));)
+}
+void pbrtConcatTransform(Float tr[16]) {
+    VERIFY_INITIALIZED("ConcatTransform");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Transform(fromColumnMajor(tr));)
+}
+void pbrtRotate(Float angle, Float dx, Float dy, Float dz) {
+    VERIFY_INITIALIZED("Rotate");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Rotate(angle, Vec3(dx, dy, dz));)
+}
+void pbrtScale(Float sx, Float sy, Float sz) {
+    VERIFY_INITIALIZED("Scale");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Scale(sx, sy, sz);)
+}
+void pbrtLookAt(Float ex, Float ey, Float ez, Float lx, Float ly, Float lz, Float ux, Float uy, Float uz) {
+    VERIFY_INITIALIZED("LookAt");
+    bool ok;
+    Transform lookAt = LookAt(Vec3(ex, ey, ez), Vec3(lx, ly, lz), Vec3(ux, uy, uz), &ok);
+    if (!ok)
+        Error("\"up\" vector (%f, %f, %f) and viewing direction passed to LookAt are pointing in the same direction.  "
+              "Using the identity transformation.", ux, uy, uz);
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * lookAt;)
+}
+void pbrtCoordinateSystem(const std::string &name) { VERIFY_INITIALIZED("CoordinateSystem"); namedCoordinateSystems[name] = curTransform; }
+void pbrtCoordSysTransform(const std::string &name) {
+    VERIFY_INITIALIZED("CoordSysTransform");
+    if (namedCoordinateSystems.find(name) != namedCoordinateSystems.end()) curTransform = namedCoordinateSystems[name];
+    else Warning("Couldn't find named coordinate system \"%s\"", name.c_str());
+}
+void pbrtActiveTransformAll() { activeTransformBits = AllTransformsBits; }
+void pbrtActiveTransformEndTime() { activeTransformBits = EndTransformBits; }
+void pbrtActiveTransformStartTime() { activeTransformBits = StartTransformBits; }
+void pbrtTransformTimes(Float start, Float end) {
+    VERIFY_OPTIONS("TransformTimes");
+    renderOptions->transformStartTime = start; renderOptions->transformEndTime = end;
+}
+void pbrtPixelFilter(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("PixelFilter"); renderOptions->FilterName = name; renderOptions->FilterParams = params;
+}
+void pbrtFilm(const std::string &type, const ParamSet &params) {
+    VERIFY_OPTIONS("Film"); renderOptions->FilmParams = params; renderOptions->FilmName = type;
+}
+void pbrtSampler(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Sampler"); renderOptions->SamplerName = name; renderOptions->SamplerParams = params;
+}
+void pbrtAccelerator(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Accelerator"); renderOptions->AcceleratorName = name; renderOptions->AcceleratorParams = params;
+}
+void pbrtIntegrator(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Integrator"); renderOptions->IntegratorName = name; renderOptions->IntegratorParams = params;
+}
+void pbrtCamera(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Camera");
+    renderOptions->CameraName = name;
+    renderOptions->CameraParams = params;
+    renderOptions->CameraToWorld = InverseSet(curTransform);
+    namedCoordinateSystems["camera"] = renderOptions->CameraToWorld;
+}
+void pbrtMakeNamedMedium(const std::string &name, const ParamSet &) {
+    VERIFY_INITIALIZED("MakeNamedMedium");
+    Warning("Participating media are ignored by the path integrator (path.cpp:122-123); medium \"%s\" dropped.", name.c_str());
+}
+void pbrtMediumInterface(const std::string &, const std::string &) { VERIFY_INITIALIZED("MediumInterface"); }
+
+void pbrtWorldBegin() {
+    VERIFY_OPTIONS("WorldBegin");
+    currentApiState = APIState::WorldBlock;
+    for (int i = 0; i < MaxTransforms; ++i) curTransform[i] = Transform();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems["world"] = curTransform;
+}
+void pbrtAttributeBegin() {
+    VERIFY_WORLD("AttributeBegin");
+    pushedGraphicsStates.push_back(graphicsState);
+    pushedTransforms.push_back(curTransform);
+    pushedActiveTransformBits.push_back(activeTransformBits);
+}
+void pbrtAttributeEnd() {
+    VERIFY_WORLD("AttributeEnd");
+    if (!pushedGraphicsStates.size()) { Error("Unmatched pbrtAttributeEnd() encountered. Ignoring it."); return; }
+    graphicsState = std::move(pushedGraphicsStates.back()); pushedGraphicsStates.pop_back();
+    curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
+    activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
+}
+void pbrtTransformBegin() {
+    VERIFY_WORLD("TransformBegin");
+    pushedTransforms.push_back(curTransform);
+    pushedActiveTransformBits.push_back(activeTransformBits);
+}
+void pbrtTransformEnd() {
+    VERIFY_WORLD("TransformEnd");
+    if (!pushedTransforms.size()) { Error("Unmatched pbrtTransformEnd() encountered. Ignoring it."); return; }
+    curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
+    activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
+}
+
+// MakeFloatTexture / MakeSpectrumTexture (api.cpp:613-731), constant-folded
+void pbrtTexture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &params) {
+    VERIFY_WORLD("Texture");
+    TextureParams tp(params, params, graphicsState.textures);
+    bool isFloat = type == "float", isSpec = type == "color" || type == "spectrum";
+    if (!isFloat && !isSpec) { Error("Texture type \"%s\" unknown.", type.c_str()); return; }
+    if ((isFloat && graphicsState.textures.floats.count(name)) || (isSpec && graphicsState.textures.spectra.count(name)))
+        Warning("Texture \"%s\" being redefined", name.c_str());
+    WARN_IF_ANIMATED_TRANSFORM("Texture");
+    if (texname == "constant") {   // textures/constant.cpp
+        if (isFloat) graphicsState.textures.floats[name] = tp.FindFloat("value", 1.f);
+        else graphicsState.textures.spectra[name] = params.FindOneSpectrum("value", RGB(1.f));
+    } else if (texname == "scale") {   // textures/scale.cpp: tex1 * tex2
+        if (isFloat) graphicsState.textures.floats[name] = tp.GetFloat("tex1", 1.f) * tp.GetFloat("tex2", 1.f);
+        else graphicsState.textures.spectra[name] = tp.GetSpectrum("tex1", RGB(1.f)) * tp.GetSpectrum("tex2", RGB(1.f));
+    } else if (texname == "mix") {     // textures/mix.h: (1 - amt) * t1 + amt * t2
+        Float amt = tp.GetFloat("amount", 0.5f);
+        if (isFloat) graphicsState.textures.floats[name] = (1 - amt) * tp.GetFloat("tex1", 0.f) + amt * tp.GetFloat("tex2", 1.f);
+        else graphicsState.textures.spectra[name] = tp.GetSpectrum("tex1", RGB(0.f)) * (1 - amt) + tp.GetSpectrum("tex2", RGB(1.f)) * amt;
+    } else {
+        Warning("Texture \"%s\" of class \"%s\" is outside this path's scope (image/procedural textures: SURVEY.md s.8 "
+                "row f2); a mid-grey constant is substituted.", name.c_str(), texname.c_str());
+        if (isFloat) graphicsState.textures.floats[name] = 1.f;
+        else graphicsState.textures.spectra[name] = RGB(0.5f);
+        return;
+    }
+    params.ReportUnused();
+}
+
+static std::map<std::string, std::shared_ptr<Material>> namedMaterialMap() {
+    std::map<std::string, std::shared_ptr<Material>> m;
+    for (auto &kv : graphicsState.namedMaterials) m[kv.first] = kv.second->material;
+    return m;
+}
+
+void pbrtMaterial(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("Material");
+    ParamSet empty;
+    TextureParams mp(params, empty, graphicsState.textures);
+    auto named = namedMaterialMap();
+    std::shared_ptr<Material> mtl = MakeMaterial(name, mp, &named);
+    graphicsState.currentMaterial = std::make_shared<MaterialInstance>(MaterialInstance{name, mtl, params});
+}
+void pbrtMakeNamedMaterial(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("MakeNamedMaterial");
+    ParamSet empty;
+    TextureParams mp(params, empty, graphicsState.textures);
+    std::string matName = mp.FindString("type");
+    WARN_IF_ANIMATED_TRANSFORM("MakeNamedMaterial");
+    if (matName == "") Error("No parameter string \"type\" found in MakeNamedMaterial");
+    auto named = namedMaterialMap();
+    std::shared_ptr<Material> mtl = MakeMaterial(matName, mp, &named);
+    if (graphicsState.namedMaterials.count(name)) Warning("Named material \"%s\" redefined.", name.c_str());
+    graphicsState.namedMaterials[name] = std::make_shared<MaterialInstance>(MaterialInstance{matName, mtl, params});
+}
+void pbrtNamedMaterial(const std::string &name) {
+    VERIFY_WORLD("NamedMaterial");
+    auto it = graphicsState.namedMaterials.find(name);
+    if (it == graphicsState.namedMaterials.end()) { Error("NamedMaterial \"%s\" unknown.", name.c_str()); return; }
+    graphicsState.currentMaterial = it->second;
+}
+
+// MakeLight (api.cpp:733-757) for the light types this path carries
+std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, const Transform &l2w) {
+    auto light = std::make_shared<Light>();
+    std::memset(&light->l, 0, sizeof(light->l));
+    light->l.tri = -1;
+    if (name == "point") {   // point.cpp:80-88: pLight = (Translate(from) * light2world)(0,0,0)
+        RGB I = ps.FindOneSpectrum("I", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
+        Vec3 P = ps.FindOnePoint3("from", Vec3(0, 0, 0));
+        Transform t = Translate(Vec3(P.x, P.y, P.z)) * l2w;
+        Vec3 p = t.Point(Vec3(0, 0, 0));
+        RGB Is = I * sc;
+        light->l.type = MI_LIGHT_POINT;
+        for (int i = 0; i < 3; ++i) { light->l.L[i] = Is.c[i]; light->l.pos[i] = p[i]; }
+    } else if (name == "distant") {   // distant.cpp:44-49,94-102
+        RGB L = ps.FindOneSpectrum("L", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
+        Vec3 from = ps.FindOnePoint3("from", Vec3(0, 0, 0)), to = ps.FindOnePoint3("to", Vec3(0, 0, 1));
+        Vec3 w = Normalize(l2w.Vector(from - to));
+        RGB Ls = L * sc;
+        light->l.type = MI_LIGHT_DISTANT;
+        for (int i = 0; i < 3; ++i) { light->l.L[i] = Ls.c[i]; light->l.pos[i] = w[i]; }
+    } else if (name == "infinite" || name == "exinfinite") {   // infinite.cpp: constant radiance only
+        RGB L = ps.FindOneSpectrum("L", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
+        if (ps.FindOneFilename("mapname", "") != "")
+            Warning("infinite light environment maps are outside this path's scope (SURVEY.md s.8 row f1); using constant L");
+        ps.FindOneInt("samples", 1); ps.FindOneInt("nsamples", 1);
+        RGB Ls = L * sc;
+        light->l.type = MI_LIGHT_INFINITE;
+        for (int i = 0; i < 3; ++i) light->l.L[i] = Ls.c[i];
+    } else {
+        Warning("Light \"%s\" is not supported by this path (spot/goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());
+        ps.ReportUnused();
+        return nullptr;
+    }
+    ps.ReportUnused();
+    return light;
+}
+
+void pbrtLightSource(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("LightSource");
+    WARN_IF_ANIMATED_TRANSFORM("LightSource");
+    std::shared_ptr<Light> lt = MakeLight(name, params, curTransform[0]);
+    if (!lt) Error("LightSource: light type \"%s\" unknown.", name.c_str());
+    else renderOptions->lights.push_back(LightEntry{lt, -1});
+}
+void pbrtAreaLightSource(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("AreaLightSource");
+    graphicsState.areaLight = name;
+    graphicsState.areaLightParams = params;
+}
+
+void pbrtShape(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("Shape");
+    if (curTransform.IsAnimated())
+        Warning("Animated shapes (TransformedPrimitive, primitive.cpp:76-96) are outside this path's scope; using the start transform");
+    std::shared_ptr<TriangleMesh> shape = MakeShapes(name, curTransform[0], graphicsState.reverseOrientation, params);
+    if (!shape || shape->nTriangles() == 0) return;
+    // GraphicsState::GetMaterialForShape (api.cpp:1771-1800): shape parameters may override material ones
+    std::shared_ptr<Material> mtl;
+    {
+        bool shapeHasMaterialParams = false;   // shapeMaySetMaterialParameters heuristics, api.cpp:1431-1480
+        for (auto &it : params.items()) {
+            size_t nv = it.type == ParamType::String || it.type == ParamType::Texture ? it.s.size()
+                        : (it.type == ParamType::Int || it.type == ParamType::Bool) ? it.i.size()
+                        : (it.type == ParamType::Float) ? it.f.size()
+                        : (it.type == ParamType::Point2 || it.type == ParamType::Vector2) ? it.f.size() / 2 : it.f.size() / 3;
+            if (it.type == ParamType::Texture) { if (it.name != "alpha" && it.name != "shadowalpha") shapeHasMaterialParams = true; }
+            else if (it.type == ParamType::Float) { if (nv == 1 && it.name != "radius") shapeHasMaterialParams = true; }
+            else if (it.type == ParamType::String) { if (nv == 1 && it.name != "filename" && it.name != "type" && it.name != "scheme") shapeHasMaterialParams = true; }
+            else if (nv == 1) shapeHasMaterialParams = true;
+        }
+        if (shapeHasMaterialParams && graphicsState.currentMaterial->material) {
+            TextureParams mp(params, graphicsState.currentMaterial->params, graphicsState.textures);
+            auto named = namedMaterialMap();
+            mtl = MakeMaterial(graphicsState.currentMaterial->name, mp, &named);
+        } else
+            mtl = graphicsState.currentMaterial->material;
+    }
+    params.ReportUnused();
+    GeometricPrimitive gp;
+    gp.shape = shape;
+    gp.material = mtl;
+    if (graphicsState.areaLight != "") {   // MakeAreaLight api.cpp:759-772, CreateDiffuseAreaLight diffuse.cpp:135-146
+        if (graphicsState.areaLight == "area" || graphicsState.areaLight == "diffuse") {
+            const ParamSet &ap = graphicsState.areaLightParams;
+            RGB L = ap.FindOneSpectrum("L", RGB(1.0)), sc = ap.FindOneSpectrum("scale", RGB(1.0));
+            ap.FindOneInt("samples", ap.FindOneInt("nsamples", 1));
+            bool twoSided = ap.FindOneBool("twosided", false);
+            gp.areaLight = std::make_shared<AreaLightSpec>(AreaLightSpec{L * sc, twoSided});
+            ap.ReportUnused();
+        } else
+            Warning("Area light \"%s\" unknown.", graphicsState.areaLight.c_str());
+    }
+    if (renderOptions->currentInstance) {
+        if (gp.areaLight) Warning("Area lights not supported with object instancing");
+        gp.areaLight = nullptr;
+        renderOptions->currentInstance->push_back(gp);
+    } else {
+        renderOptions->primitives.push_back(gp);
+        if (gp.areaLight) renderOptions->lights.push_back(LightEntry{nullptr, (int)renderOptions->primitives.size() - 1});
+    }
+}
+
+void pbrtReverseOrientation() { VERIFY_WORLD("ReverseOrientation"); graphicsState.reverseOrientation = !graphicsState.reverseOrientation; }
+
+void pbrtObjectBegin(const std::string &name) {
+    VERIFY_WORLD("ObjectBegin");
+    pbrtAttributeBegin();
+    if (renderOptions->currentInstance) Error("ObjectBegin called inside of instance definition");
+    renderOptions->instances[name] = std::vector<GeometricPrimitive>();
+    renderOptions->currentInstance = &renderOptions->instances[name];
+}
+void pbrtObjectEnd() {
+    VERIFY_WORLD("ObjectEnd");
+    if (!renderOptions->currentInstance) Error("ObjectEnd called outside of instance definition");
+    renderOptions->currentInstance = nullptr;
+    pbrtAttributeEnd();
+}
+void pbrtObjectInstance(const std::string &name) {
+    VERIFY_WORLD("ObjectInstance");
+    if (renderOptions->currentInstance) { Error("ObjectInstance can't be called inside instance definition"); return; }
+    auto it = renderOptions->instances.find(name);
+    if (it == renderOptions->instances.end()) { Error("Unable to find instance named \"%s\"", name.c_str()); return; }
+    if (it->second.empty()) return;
+    // Reference: TransformedPrimitive over a shared BVH (api.cpp:1555-1591).  Here static instances are
+    // flattened: a transformed copy of each mesh (documented deviation).
+    const Transform &i2w = curTransform[0];
+    for (const GeometricPrimitive &src : it->second) {
+        GeometricPrimitive gp = src;
+        auto mesh = std::make_shared<TriangleMesh>(*src.shape);
+        for (auto &p : mesh->p) p = i2w.Point(p);
+        for (auto &n : mesh->n) n = i2w.Normal(n);
+        for (auto &s : mesh->s) s = i2w.Vector(s);
+        if (i2w.SwapsHandedness()) mesh->transformSwapsHandedness = !mesh->transformSwapsHandedness;
+        gp.shape = mesh;
+        renderOptions->primitives.push_back(gp);
+    }
+}
+
+// ------------------------------------------------------------------ WorldEnd
+PerspectiveCamera::PerspectiveCamera(const Transform &c2w, const Float sw[4], Float so, Float sc, Float lensr,
+                                     Float focald, Float fov, Film *f)
+    : CameraToWorld(c2w), shutterOpen(so), shutterClose(sc), lensRadius(lensr), focalDistance(focald), film(f) {
+    CameraToScreen = Perspective(fov, 1e-2f, 1000.f);   // perspective.cpp:52
+    // camera.h:101-107 ; sw = {pMin.x, pMax.x, pMin.y, pMax.y}
+    ScreenToRaster = Scale(film->fullResolution[0], film->fullResolution[1], 1) *
+                     Scale(1 / (sw[1] - sw[0]), 1 / (sw[2] - sw[3]), 1) * Translate(Vec3(-sw[0], -sw[3], 0));
+    RasterToScreen = Inverse(ScreenToRaster);
+    RasterToCamera = Inverse(CameraToScreen) * RasterToScreen;
+    dxCamera = RasterToCamera.Point(Vec3(1, 0, 0)) - RasterToCamera.Point(Vec3(0, 0, 0));   // perspective.cpp:56-59
+    dyCamera = RasterToCamera.Point(Vec3(0, 1, 0)) - RasterToCamera.Point(Vec3(0, 0, 0));
+}
+
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &ps, const Transform &cam2world, Film *film) {   // perspective.cpp:228-277
+    Float shutteropen = ps.FindOneFloat("shutteropen", 0.f), shutterclose = ps.FindOneFloat("shutterclose", 1.f);
+    if (shutterclose < shutteropen) {
+        Warning("Shutter close time [%f] < shutter open [%f].  Swapping them.", shutterclose, shutteropen);
+        std::swap(shutterclose, shutteropen);
+    }
+    Float lensradius = ps.FindOneFloat("lensradius", 0.f), focaldistance = ps.FindOneFloat("focaldistance", 1e6);
+    Float frame = ps.FindOneFloat("frameaspectratio", Float(film->fullResolution[0]) / Float(film->fullResolution[1]));
+    Float screen[4];
+    if (frame > 1.f) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.f; screen[3] = 1.f; }
+    else { screen[0] = -1.f; screen[1] = 1.f; screen[2] = -1.f / frame; screen[3] = 1.f / frame; }
+    int swi;
+    const Float *sw = ps.FindFloat("screenwindow", &swi);
+    if (sw) {
+        if (swi == 4) { screen[0] = sw[0]; screen[1] = sw[1]; screen[2] = sw[2]; screen[3] = sw[3]; }
+        else Error("\"screenwindow\" should have four values");
+    }
+    Float fov = ps.FindOneFloat("fov", 90.);
+    Float halffov = ps.FindOneFloat("halffov", -1.f);
+    if (halffov > 0.f) fov = 2.f * halffov;
+    return new PerspectiveCamera(cam2world, screen, shutteropen, shutterclose, lensradius, focaldistance, fov, film);
+}
+
+SobolSampler::SobolSampler(int64_t spp, const int smin[2], const int smax[2]) {   // sobol.h:51-62
+    samplesPerPixel = spp <= 1 ? 1 : (int64_t)RoundUpPow2((int32_t)spp);
+    if (!IsPowerOf2(spp))
+        Warning("Non power-of-two sample count rounded up to %lld for SobolSampler.", (long long)samplesPerPixel);
+    for (int i = 0; i < 2; ++i) { sampleMin[i] = smin[i]; sampleMax[i] = smax[i]; }
+    resolution = RoundUpPow2(std::max(smax[0] - smin[0], smax[1] - smin[1]));
+    log2Resolution = Log2Int((uint32_t)resolution);
+}
+
+Scene::Scene(std::shared_ptr<BVHAccel> agg, std::vector<GeometricPrimitive> prims, std::vector<LightEntry> l)
+    : aggregate(std::move(agg)), primitives(std::move(prims)), lights(std::move(l)) {
+    worldBound = aggregate->WorldBound();   // scene.h:56
+}
+
+void pbrtWorldEnd() {
+    VERIFY_WORLD("WorldEnd");
+    while (pushedGraphicsStates.size()) {
+        Warning("Missing end to pbrtAttributeBegin()");
+        pushedGraphicsStates.pop_back();
+        pushedTransforms.pop_back();
+    }
+    while (pushedTransforms.size()) { Warning("Missing end to pbrtTransformBegin()"); pushedTransforms.pop_back(); }
+
+    // RenderOptions::MakeIntegrator (api.cpp:1666-1718) / MakeCamera (:1720-1731)
+    std::unique_ptr<WavefrontPathIntegrator> integrator;
+    {
+        std::unique_ptr<Filter> filter = MakeFilter(renderOptions->FilterName, renderOptions->FilterParams);
+        Film *film = nullptr;
+        if (filter) {
+            if (renderOptions->FilmName == "image") {
+                film = CreateFilm(renderOptions->FilmParams, std::move(filter));
+                renderOptions->FilmParams.ReportUnused();
+            } else
+                Warning("Film \"%s\" unknown.", renderOptions->FilmName.c_str());
+        }
+        std::shared_ptr<PerspectiveCamera> camera;
+        if (!film) Error("Unable to create film.");
+        else if (renderOptions->CameraName == "perspective") {
+            if (renderOptions->CameraToWorld.IsAnimated())
+                Warning("Animated camera transforms are outside this path's scope; using the start transform");
+            camera.reset(CreatePerspectiveCamera(renderOptions->CameraParams, renderOptions->CameraToWorld[0], film));
+            renderOptions->CameraParams.ReportUnused();
+        } else {
+            Warning("Camera \"%s\" is not supported by this path (perspective only: SURVEY.md s.2 row 26).", renderOptions->CameraName.c_str());
+            delete film;
+        }
+        if (!camera) Error("Unable to create camera");
+        else {
+            int smin[2], smax[2];
+            camera->film->GetSampleBounds(smin, smax);
+            int nsamp = renderOptions->SamplerParams.FindOneInt("pixelsamples", 16);
+            if (PbrtOptions.quickRender) nsamp = 1;
+            if (renderOptions->SamplerName != "sobol")
+                Warning("Sampler \"%s\" is not implemented on the GPU path (north-star names Sobol; halton is a 'next' row); "
+                        "rendering with \"sobol\" at %d spp.", renderOptions->SamplerName.c_str(), nsamp);
+            renderOptions->SamplerParams.ReportUnused();
+            auto sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
+            if (renderOptions->IntegratorName == "path") {
+                integrator.reset(CreatePathIntegrator(renderOptions->IntegratorParams, sampler, camera));
+                integrator->nGpus = PbrtOptions.nGpus;
+                renderOptions->IntegratorParams.ReportUnused();
+            } else
+                Error("Integrator \"%s\" unknown to this path (only \"path\": SURVEY.md s.2 row 7).", renderOptions->IntegratorName.c_str());
+            if (renderOptions->lights.empty()) Warning("No light sources defined in scene; rendering a black image.");
+        }
+    }
+    // RenderOptions::MakeScene (api.cpp:1655-1664)
+    std::unique_ptr<Scene> scene;
+    {
+        std::shared_ptr<BVHAccel> accel;
+        if (renderOptions->AcceleratorName == "bvh") accel = CreateBVHAccelerator(renderOptions->primitives, renderOptions->AcceleratorParams);
+        else {
+            Warning("Accelerator \"%s\" is not on this path; using \"bvh\".", renderOptions->AcceleratorName.c_str());
+            accel = std::make_shared<BVHAccel>(renderOptions->primitives, 4, BVHAccel::SplitMethod::SAH);
+        }
+        renderOptions->AcceleratorParams.ReportUnused();
+        scene.reset(new Scene(accel, std::move(renderOptions->primitives), std::move(renderOptions->lights)));
+    }
+    if (scene && integrator) {
+        if (PbrtOptions.deferRender) {
+            builtScene.reset(new BuiltScene{std::move(scene), std::move(integrator)});
+        } else
+            integrator->Render(*scene);   // api.cpp:1623 -- the drop-in call site
+    }
+    graphicsState = GraphicsState();
+    currentApiState = APIState::OptionsBlock;
+    renderOptions.reset(new RenderOptions);
+    for (int i = 0; i < MaxTransforms; ++i) curTransform[i] = Transform();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems.clear();
+}
+
+std::unique_ptr<BuiltScene> pbrtTakeBuiltScene() { return std::move(builtScene); }
+
+}  // namespace pbrt_amd

@@ -1,0 +1,65 @@
+// C entry points of libpbrt_amd_host.so: scene loading for Python tests / bench (ctypes) and
+// for any other FFI user.  Pure host code: no HIP dependency, usable without a GPU.
+#include "api.h"
+
+using namespace pbrt_amd;
+
+struct pbrt_amd_scene {
+    std::unique_ptr<BuiltScene> built;
+    std::unique_ptr<FlatScene> flat;
+};
+
+extern "C" {
+
+// Parse `filename` (or, if is_text != 0, the scene text itself) up to WorldEnd and flatten the
+// result; returns NULL on failure.  quick/spp/res overrides <= 0 are ignored.
+pbrt_amd_scene *pbrt_amd_scene_load(const char *filename_or_text, int is_text, int quiet, const char *outfile) {
+    Options opt;
+    opt.quiet = quiet != 0;
+    opt.deferRender = true;
+    if (outfile) opt.imageFile = outfile;
+    pbrtInit(opt);
+    if (is_text) pbrtParseString(filename_or_text); else pbrtParseFile(filename_or_text);
+    pbrtCleanup();
+    std::unique_ptr<BuiltScene> built = pbrtTakeBuiltScene();
+    if (!built) return nullptr;
+    pbrt_amd_scene *s = new pbrt_amd_scene;
+    s->flat = built->integrator->Flatten(*built->scene);
+    s->built = std::move(built);
+    return s;
+}
+void pbrt_amd_scene_free(pbrt_amd_scene *s) { delete s; }
+const mi_scene_desc *pbrt_amd_scene_desc(pbrt_amd_scene *s) { return &s->flat->desc; }
+int pbrt_amd_error_count() { return g_errorCount; }
+// n_verts n_tris n_meshes n_bvh_nodes n_materials n_lights xres yres crop(x0 y0 x1 y1) spp max_depth sobol_res log2res
+void pbrt_amd_scene_info(pbrt_amd_scene *s, int64_t *out) {
+    const mi_scene_desc &d = s->flat->desc;
+    int64_t v[16] = {d.n_verts, d.n_tris, d.n_meshes, d.n_bvh_nodes, d.n_materials, d.n_lights, d.film.full_res[0],
+                     d.film.full_res[1], d.film.crop_min[0], d.film.crop_min[1], d.film.crop_max[0], d.film.crop_max[1],
+                     d.integrator.spp, d.integrator.max_depth, d.integrator.sobol_resolution, d.integrator.sobol_log2_resolution};
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+}
+
+// Film: merge a downloaded FilmTilePixel array (4 floats per cropped pixel) and produce the
+// final RGB image exactly as Film::WriteImage would; optionally write it.
+int pbrt_amd_film_merge(pbrt_amd_scene *s, const float *rgbw) { s->built->integrator->camera->film->MergeFilm(rgbw); return 0; }
+int pbrt_amd_film_clear(pbrt_amd_scene *s) { s->built->integrator->camera->film->Clear(); return 0; }
+int pbrt_amd_film_rgb(pbrt_amd_scene *s, float *rgb_out) {
+    std::vector<Float> rgb = s->built->integrator->camera->film->FinalRGB();
+    std::memcpy(rgb_out, rgb.data(), rgb.size() * sizeof(float));
+    return 0;
+}
+int pbrt_amd_film_write(pbrt_amd_scene *s, const char *filename) {
+    Film &f = *s->built->integrator->camera->film;
+    if (filename && filename[0]) f.filename = filename;
+    f.WriteImage();
+    return 0;
+}
+int pbrt_amd_read_pfm(const char *filename, float *rgb, int capacity_floats, int *w, int *h) {
+    std::vector<Float> v;
+    if (!ReadImagePFM(filename, &v, w, h)) return -1;
+    if ((int)v.size() > capacity_floats) return -2;
+    std::memcpy(rgb, v.data(), v.size() * sizeof(float));
+    return 0;
+}
+}

@@ -1,0 +1,278 @@
+// WavefrontPathIntegrator: the Integrator subclass that stands where PathIntegrator does
+// (reference integrators/path.{h,cpp}; created by CreatePathIntegrator path.cpp:190-213).
+// Render(scene) = flatten the Scene to the POD mi_scene_desc, hand it to the HIP library through
+// the C ABI of include/pbrt_amd.h, pull the FilmTilePixel array back and let the host Film do
+// MergeFilmTile / WriteImage (film.cpp:117-130,168-210).  The HIP library is loaded at run time;
+// there is NO CPU fallback: if it (or a GPU) is missing, Render reports an Error and returns.
+#include <dlfcn.h>
+
+#include <chrono>
+
+#include "api.h"
+
+namespace pbrt_amd {
+
+WavefrontPathIntegrator::WavefrontPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera,
+                                                 std::shared_ptr<SobolSampler> sampler, const int pmin[2],
+                                                 const int pmax[2], Float rrThreshold, const std::string &strategy)
+    : maxDepth(maxDepth), camera(std::move(camera)), sampler(std::move(sampler)), rrThreshold(rrThreshold),
+      lightSampleStrategy(strategy) {
+    for (int i = 0; i < 2; ++i) { pixelMin[i] = pmin[i]; pixelMax[i] = pmax[i]; }
+}
+
+WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<SobolSampler> sampler,
+                                              std::shared_ptr<PerspectiveCamera> camera) {   // path.cpp:190-213
+    int maxDepth = ps.FindOneInt("maxdepth", 5);
+    int np;
+    const int *pb = ps.FindInt("pixelbounds", &np);
+    int pmin[2], pmax[2];
+    camera->film->GetSampleBounds(pmin, pmax);
+    if (pb) {
+        if (np != 4) Error("Expected four values for \"pixelbounds\" parameter. Got %d.", np);
+        else {
+            pmin[0] = std::max(pmin[0], pb[0]); pmax[0] = std::min(pmax[0], pb[1]);
+            pmin[1] = std::max(pmin[1], pb[2]); pmax[1] = std::min(pmax[1], pb[3]);
+            if ((pmax[0] - pmin[0]) * (pmax[1] - pmin[1]) == 0) Error("Degenerate \"pixelbounds\" specified.");
+        }
+    }
+    Float rrThreshold = ps.FindOneFloat("rrthreshold", 1.);
+    std::string lightStrategy = ps.FindOneString("lightsamplestrategy", "spatial");
+    return new WavefrontPathIntegrator(maxDepth, camera, sampler, pmin, pmax, rrThreshold, lightStrategy);
+}
+
+static void copyMatrix(float dst[16], const Matrix4x4 &m) { std::memcpy(dst, m.m, 16 * sizeof(float)); }
+
+std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) const {
+    std::unique_ptr<FlatScene> fs(new FlatScene);
+    const BVHAccel &bvh = *scene.aggregate;
+    const auto &prims = scene.primitives;
+    // --- vertices + meshes
+    std::vector<uint32_t> vertexOffset(prims.size()), triOffset(prims.size());
+    size_t nv = 0, nt = 0;
+    bool anyN = false, anyUV = false;
+    for (size_t i = 0; i < prims.size(); ++i) {
+        vertexOffset[i] = (uint32_t)nv; triOffset[i] = (uint32_t)nt;
+        nv += prims[i].shape->p.size(); nt += prims[i].shape->nTriangles();
+        anyN |= !prims[i].shape->n.empty(); anyUV |= !prims[i].shape->uv.empty();
+    }
+    fs->P.resize(3 * nv);
+    if (anyN) fs->N.assign(3 * nv, 0.f);
+    if (anyUV) fs->UV.assign(2 * nv, 0.f);
+    // materials: identical BxDF lists share one slot (sort key of the shading kernels)
+    auto materialIndex = [&](const std::shared_ptr<Material> &m) -> int {
+        if (!m) return -1;
+        for (size_t k = 0; k < fs->materials.size(); ++k)
+            if (std::memcmp(&fs->materials[k], &m->bsdf, sizeof(mi_material)) == 0) return (int)k;
+        fs->materials.push_back(m->bsdf);
+        return (int)fs->materials.size() - 1;
+    };
+    fs->meshes.resize(prims.size());
+    for (size_t i = 0; i < prims.size(); ++i) {
+        const TriangleMesh &mesh = *prims[i].shape;
+        for (size_t v = 0; v < mesh.p.size(); ++v) {
+            size_t g = vertexOffset[i] + v;
+            fs->P[3 * g] = mesh.p[v].x; fs->P[3 * g + 1] = mesh.p[v].y; fs->P[3 * g + 2] = mesh.p[v].z;
+            if (!mesh.n.empty()) { fs->N[3 * g] = mesh.n[v].x; fs->N[3 * g + 1] = mesh.n[v].y; fs->N[3 * g + 2] = mesh.n[v].z; }
+            if (!mesh.uv.empty()) { fs->UV[2 * g] = mesh.uv[2 * v]; fs->UV[2 * g + 1] = mesh.uv[2 * v + 1]; }
+        }
+        uint32_t flags = 0;
+        if (!mesh.n.empty()) flags |= MI_MESH_HAS_N;
+        if (!mesh.uv.empty()) flags |= MI_MESH_HAS_UV;
+        if (!mesh.s.empty()) Warning("per-vertex tangents \"S\" are ignored by this path");
+        if (mesh.reverseOrientation ^ mesh.transformSwapsHandedness) flags |= MI_MESH_FLIP;
+        fs->meshes[i].flags = flags;
+        fs->meshes[i].material = materialIndex(prims[i].material);
+    }
+    // --- triangles in BVH primitive order
+    size_t nTris = bvh.primitives.size();
+    fs->triIndices.resize(3 * nTris);
+    fs->triMesh.resize(nTris);
+    fs->triLight.assign(nTris, -1);
+    std::vector<uint32_t> orderOf(nt);   // (prim, tri) -> position in bvh.primitives
+    for (size_t k = 0; k < nTris; ++k) {
+        const BVHAccel::PrimRef &r = bvh.primitives[k];
+        const TriangleMesh &mesh = *prims[r.prim].shape;
+        for (int c = 0; c < 3; ++c) fs->triIndices[3 * k + c] = vertexOffset[r.prim] + (uint32_t)mesh.indices[3 * r.tri + c];
+        fs->triMesh[k] = r.prim;
+        orderOf[triOffset[r.prim] + r.tri] = (uint32_t)k;
+    }
+    // --- lights, in scene.lights order (api.cpp:1418-1424: appended in file order, one per emissive triangle)
+    Vec3 worldCenter = (scene.WorldBound().pMin + scene.WorldBound().pMax) / 2;   // Bounds3::BoundingSphere geometry.h:808-811
+    Float worldRadius = 0;
+    {
+        const Bounds3 &b = scene.WorldBound();
+        bool inside = worldCenter.x >= b.pMin.x && worldCenter.x <= b.pMax.x && worldCenter.y >= b.pMin.y &&
+                      worldCenter.y <= b.pMax.y && worldCenter.z >= b.pMin.z && worldCenter.z <= b.pMax.z;
+        worldRadius = inside ? (worldCenter - b.pMax).Length() : 0;
+    }
+    std::vector<Float> power;
+    for (const LightEntry &e : scene.lights) {
+        if (e.light) {
+            mi_light l = e.light->l;
+            l.world_radius = worldRadius;
+            for (int i = 0; i < 3; ++i) l.world_center[i] = worldCenter[i];
+            RGB L(l.L[0], l.L[1], l.L[2]);
+            if (l.type == MI_LIGHT_POINT) power.push_back((L * (4 * kPi)).y());                       // point.cpp:56
+            else power.push_back((L * kPi * worldRadius * worldRadius).y());                          // distant.cpp:64-66 / infinite
+            fs->lights.push_back(l);
+        } else {
+            const GeometricPrimitive &gp = prims[e.prim];
+            const TriangleMesh &mesh = *gp.shape;
+            for (int t = 0; t < mesh.nTriangles(); ++t) {
+                mi_light l;
+                std::memset(&l, 0, sizeof(l));
+                l.type = MI_LIGHT_AREA_TRI;
+                l.tri = (int32_t)orderOf[triOffset[e.prim] + t];
+                l.two_sided = gp.areaLight->twoSided;
+                for (int i = 0; i < 3; ++i) l.L[i] = gp.areaLight->Lemit.c[i];
+                const Vec3 &p0 = mesh.p[mesh.indices[3 * t]], &p1 = mesh.p[mesh.indices[3 * t + 1]], &p2 = mesh.p[mesh.indices[3 * t + 2]];
+                l.area = 0.5 * Cross(p1 - p0, p2 - p0).Length();   // Triangle::Area triangle.cpp:575-581
+                fs->triLight[l.tri] = (int32_t)fs->lights.size();
+                RGB pw = gp.areaLight->Lemit * (Float)(l.two_sided ? 2 : 1) * l.area * kPi;   // diffuse.cpp:64-66
+                power.push_back(pw.y());
+                fs->lights.push_back(l);
+            }
+        }
+    }
+    // --- light-selection distribution (lightdistrib.cpp:48-84, sampling.h:55-70)
+    size_t nl = fs->lights.size();
+    std::string strategy = lightSampleStrategy;
+    if (strategy != "uniform" && strategy != "power" && strategy != "spatial") {
+        Error("Light sample distribution type \"%s\" unknown. Using \"spatial\".", strategy.c_str());
+        strategy = "spatial";
+    }
+    if (strategy == "spatial" && nl > 1)
+        Warning("lightsamplestrategy \"spatial\" (lightdistrib.cpp:96-300) is not implemented on the GPU path yet; "
+                "using \"power\" -- images will differ from the reference unless the scene asks for \"uniform\"/\"power\".");
+    bool uniform = strategy == "uniform" || nl == 1;
+    fs->lightFunc.resize(nl);
+    fs->lightCdf.resize(nl + 1);
+    for (size_t i = 0; i < nl; ++i) fs->lightFunc[i] = uniform ? Float(1) : power[i];
+    Float funcInt = 0;
+    if (nl) {
+        int n = (int)nl;
+        fs->lightCdf[0] = 0;
+        for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] = fs->lightCdf[i - 1] + fs->lightFunc[i - 1] / n;
+        funcInt = fs->lightCdf[n];
+        if (funcInt == 0) for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] = Float(i) / Float(n);
+        else for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] /= funcInt;
+    }
+    // --- desc
+    mi_scene_desc &d = fs->desc;
+    std::memset(&d, 0, sizeof(d));
+    d.abi_version = MI_ABI_VERSION;
+    d.n_verts = (uint32_t)nv; d.P = fs->P.data(); d.N = anyN ? fs->N.data() : nullptr; d.UV = anyUV ? fs->UV.data() : nullptr;
+    d.n_tris = (uint32_t)nTris; d.tri_indices = fs->triIndices.data(); d.tri_mesh = fs->triMesh.data(); d.tri_light = fs->triLight.data();
+    d.n_meshes = (uint32_t)fs->meshes.size(); d.meshes = fs->meshes.data();
+    d.n_bvh_nodes = (uint32_t)bvh.nodes.size(); d.bvh_nodes = bvh.nodes.data();
+    d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
+    d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
+    d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
+    copyMatrix(d.camera.raster_to_camera, camera->RasterToCamera.m);
+    copyMatrix(d.camera.camera_to_world, camera->CameraToWorld.m);
+    for (int i = 0; i < 3; ++i) { d.camera.dx_camera[i] = camera->dxCamera[i]; d.camera.dy_camera[i] = camera->dyCamera[i]; }
+    d.camera.lens_radius = camera->lensRadius; d.camera.focal_distance = camera->focalDistance;
+    d.camera.shutter_open = camera->shutterOpen; d.camera.shutter_close = camera->shutterClose;
+    const Film &film = *camera->film;
+    for (int i = 0; i < 2; ++i) {
+        d.film.full_res[i] = film.fullResolution[i];
+        d.film.crop_min[i] = film.cropMin[i]; d.film.crop_max[i] = film.cropMax[i];
+        d.film.sample_min[i] = sampler->sampleMin[i]; d.film.sample_max[i] = sampler->sampleMax[i];
+        d.integrator.pixel_min[i] = pixelMin[i]; d.integrator.pixel_max[i] = pixelMax[i];
+    }
+    d.film.filter_radius[0] = film.filter->rx; d.film.filter_radius[1] = film.filter->ry;
+    std::memcpy(d.film.filter_table, film.filterTable, sizeof(film.filterTable));
+    d.film.max_sample_luminance = film.maxSampleLuminance;
+    d.film.scale = film.scale;
+    d.integrator.max_depth = maxDepth; d.integrator.rr_threshold = rrThreshold;
+    d.integrator.spp = (int32_t)sampler->samplesPerPixel;
+    d.integrator.sobol_resolution = sampler->resolution; d.integrator.sobol_log2_resolution = sampler->log2Resolution;
+    return fs;
+}
+
+// ---- run-time binding to the HIP library -------------------------------------------------
+namespace {
+struct DeviceApi {
+    void *handle = nullptr;
+    const char *(*last_error)() = nullptr;
+    int (*ctx_create)(int, void *, mi_ctx **) = nullptr;
+    void (*ctx_destroy)(mi_ctx *) = nullptr;
+    int (*scene_upload)(mi_ctx *, const mi_scene_desc *) = nullptr;
+    int (*render)(mi_ctx *, const mi_render_params *) = nullptr;
+    int (*sync)(mi_ctx *) = nullptr;
+    int (*film_download)(mi_ctx *, float *) = nullptr;
+    int (*counters)(mi_ctx *, uint64_t *) = nullptr;
+    bool load() {
+        if (handle) return true;
+        const char *names[] = {"libpbrt_amd.so", "./libpbrt_amd.so"};
+        std::string tried;
+        const char *env = std::getenv("PBRT_AMD_LIB");
+        if (env) handle = dlopen(env, RTLD_NOW);
+        for (const char *n : names) { if (handle) break; handle = dlopen(n, RTLD_NOW); }
+        if (!handle) {
+            Dl_info info;   // next to this host library
+            if (dladdr((void *)&CreatePathIntegrator, &info) && info.dli_fname) {
+                std::string p(info.dli_fname);
+                size_t s = p.find_last_of('/');
+                p = (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/libpbrt_amd.so";
+                handle = dlopen(p.c_str(), RTLD_NOW);
+            }
+        }
+        if (!handle) { Error("cannot load libpbrt_amd.so (the HIP path tracer): %s", dlerror()); return false; }
+#define BIND(field, sym) field = (decltype(field))dlsym(handle, sym); if (!field) { Error("libpbrt_amd.so lacks %s", sym); return false; }
+        BIND(last_error, "mi_last_error") BIND(ctx_create, "mi_ctx_create") BIND(ctx_destroy, "mi_ctx_destroy")
+        BIND(scene_upload, "mi_scene_upload") BIND(render, "mi_render") BIND(sync, "mi_sync")
+        BIND(film_download, "mi_film_download") BIND(counters, "mi_counters")
+#undef BIND
+        return true;
+    }
+};
+DeviceApi g_dev;
+}  // namespace
+
+void WavefrontPathIntegrator::Render(const Scene &scene) {
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    std::unique_ptr<FlatScene> fs = Flatten(scene);
+    if (!g_dev.load()) return;
+    int world = std::max(1, nGpus);
+    std::vector<mi_ctx *> ctxs(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        if (g_dev.ctx_create(r, nullptr, &ctxs[r]) != 0 || g_dev.scene_upload(ctxs[r], &fs->desc) != 0) {
+            Error("GPU %d: %s", r, g_dev.last_error());
+            for (mi_ctx *c : ctxs) if (c) g_dev.ctx_destroy(c);
+            return;
+        }
+    }
+    auto t1 = clk::now();
+    // image tiles shard across GPUs (scene replicated); each device renders only its tiles
+    for (int r = 0; r < world; ++r) {
+        mi_render_params rp;
+        std::memset(&rp, 0, sizeof(rp));
+        rp.rank = r; rp.world = world; rp.spp_begin = 0; rp.spp_end = -1;
+        if (g_dev.render(ctxs[r], &rp) != 0) Error("GPU %d render: %s", r, g_dev.last_error());
+    }
+    for (int r = 0; r < world; ++r) g_dev.sync(ctxs[r]);
+    auto t2 = clk::now();
+    Film &film = *camera->film;
+    std::vector<float> rgbw(4 * film.pixels.size());
+    uint64_t total[MI_CNT_COUNT] = {0};
+    for (int r = 0; r < world; ++r) {   // disjoint tiles: merging every rank's film is the gather
+        if (g_dev.film_download(ctxs[r], rgbw.data()) != 0) Error("GPU %d film: %s", r, g_dev.last_error());
+        film.MergeFilm(rgbw.data());
+        uint64_t c[MI_CNT_COUNT];
+        if (g_dev.counters(ctxs[r], c) == 0) for (int i = 0; i < MI_CNT_COUNT; ++i) total[i] += c[i];
+        g_dev.ctx_destroy(ctxs[r]);
+    }
+    film.WriteImage();
+    if (!g_quiet) {
+        double setup = std::chrono::duration<double>(t1 - t0).count(), render = std::chrono::duration<double>(t2 - t1).count();
+        double rays = double(total[MI_CNT_CLOSEST_RAYS] + total[MI_CNT_SHADOW_RAYS]);
+        std::printf("Integrator::Render(): flatten+upload %.3f s, render %.3f s on %d GPU(s)\n", setup, render, world);
+        std::printf("  Camera rays traced %llu (%.2f Msamples/s); Regular + Shadow ray intersection tests %llu + %llu (%.2f Mrays/s)\n",
+                    (unsigned long long)total[MI_CNT_CAMERA_RAYS], total[MI_CNT_CAMERA_RAYS] / render * 1e-6,
+                    (unsigned long long)total[MI_CNT_CLOSEST_RAYS], (unsigned long long)total[MI_CNT_SHADOW_RAYS], rays / render * 1e-6);
+    }
+}
+
+}  // namespace pbrt_amd

@@ -1,0 +1,181 @@
+// Host-side object model: the slice of pbrt-v3's plugin surface the hot path touches.
+// Class / factory names, constructor arguments and defaults follow the reference headers
+// cited at each declaration, so a pbrt-v3 user finds the same handles.  Geometry is kept as
+// whole meshes + index ranges (no per-triangle heap objects: the reference spends ~233 B per
+// triangle on Triangle/GeometricPrimitive/shared_ptr blocks) and the whole
+// Scene flattens to the POD mi_scene_desc of include/pbrt_amd.h.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrt_amd.h"
+#include "geom.h"
+#include "paramset.h"
+
+namespace pbrt_amd {
+
+// ---- Shape: TriangleMesh (shapes/triangle.h:51-69; vertices are world space, triangle.cpp:72-74)
+struct TriangleMesh {
+    std::vector<Vec3> p;        // world space
+    std::vector<Vec3> n;        // world space (ObjectToWorld(Normal)), empty if absent
+    std::vector<Vec3> s;        // tangents, empty if absent
+    std::vector<Float> uv;      // 2 per vertex, empty if absent
+    std::vector<int> indices;   // 3 per triangle
+    bool reverseOrientation = false, transformSwapsHandedness = false;
+    int nTriangles() const { return (int)indices.size() / 3; }
+};
+// CreateTriangleMesh (triangle.cpp:94-110) / CreateTriangleMeshShape (:648-744) / CreatePLYMesh
+// (shapes/plymesh.cpp:157-290) / CreateLoopSubdiv (shapes/loopsubdiv.cpp:149-400)
+std::shared_ptr<TriangleMesh> CreateTriangleMesh(const Transform &o2w, bool reverseOrientation, int nTris,
+                                                 const int *indices, int nVerts, const Vec3 *P, const Vec3 *S,
+                                                 const Vec3 *N, const Float *UV);
+std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool ro, const ParamSet &ps);
+std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const ParamSet &ps);
+std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool ro, const ParamSet &ps);
+std::shared_ptr<TriangleMesh> CreateSphereMesh(const Transform &o2w, bool ro, const ParamSet &ps);
+// MakeShapes (api.cpp:430-539)
+std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps);
+
+// ---- Material (core/material.h:51-61): ComputeScatteringFunctions folded to its constant BxDF list
+struct Material {
+    std::string type;
+    mi_material bsdf;   // what ComputeScatteringFunctions(allowMultipleLobes=true, Radiance) builds
+};
+// MakeMaterial (api.cpp:541-611); returns nullptr for "" / "none"
+std::shared_ptr<Material> MakeMaterial(const std::string &name, const TextureParams &mp,
+                                       const std::map<std::string, std::shared_ptr<Material>> *named);
+
+// ---- Lights (core/light.h:62-112)
+struct AreaLightSpec { RGB Lemit; bool twoSided; };          // CreateDiffuseAreaLight diffuse.cpp:135-146
+struct Light { mi_light l; };                                 // point / distant / infinite
+// one entry of Scene::lights in file order (api.cpp:1418-1424): a LightSource light, or
+// "every triangle of primitive `prim` is a DiffuseAreaLight" (api.cpp:1357-1366)
+struct LightEntry { std::shared_ptr<Light> light; int prim; };
+std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, const Transform &light2world);
+
+// ---- Primitive (core/primitive.h:51-64,119-127)
+struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here
+    std::shared_ptr<TriangleMesh> shape;
+    std::shared_ptr<Material> material;
+    std::shared_ptr<AreaLightSpec> areaLight;
+};
+
+// ---- Aggregate: BVHAccel (accelerators/bvh.h:52-99)
+class BVHAccel {
+  public:
+    enum class SplitMethod { SAH, HLBVH, Middle, EqualCounts };
+    struct PrimRef { uint32_t prim, tri; };   // (GeometricPrimitive index, triangle within its mesh)
+    BVHAccel(const std::vector<GeometricPrimitive> &prims, int maxPrimsInNode, SplitMethod m);
+    Bounds3 WorldBound() const;
+    std::vector<mi_bvh2_node> nodes;      // LinearBVHNode[] (bvh.cpp:95-104)
+    std::vector<PrimRef> primitives;      // ordered primitives (bvh.cpp:205)
+    int maxPrimsInNode;
+    SplitMethod splitMethod;
+};
+std::shared_ptr<BVHAccel> CreateBVHAccelerator(const std::vector<GeometricPrimitive> &prims, const ParamSet &ps);
+
+// ---- Filter (core/filter.h:48-58, filters/*.cpp)
+struct Filter {
+    std::string name;
+    Float rx, ry;
+    Float p0 = 0, p1 = 0;   // gaussian: alpha,(expX) | mitchell: B,C | sinc: tau
+    Float expX = 0, expY = 0;
+    Float Evaluate(Float x, Float y) const;
+};
+std::unique_ptr<Filter> MakeFilter(const std::string &name, const ParamSet &ps);
+
+// ---- Film (core/film.h:58-187)
+class Film {
+  public:
+    Film(int xres, int yres, const Float crop[4], std::unique_ptr<Filter> filt, Float diagonal,
+         const std::string &filename, Float scale, Float maxSampleLuminance);
+    void GetSampleBounds(int mn[2], int mx[2]) const;         // film.cpp:80-86
+    // MergeFilmTile over the whole cropped film from {rgb contribSum, filterWeightSum} records
+    // (film.cpp:117-130): RGB->XYZ then accumulate.
+    void MergeFilm(const float *rgbw);
+    void Clear();
+    void WriteImage(Float splatScale = 1);                    // film.cpp:168-210
+    std::vector<Float> FinalRGB() const;                      // the array WriteImage hands to imageio
+    int fullResolution[2];
+    int cropMin[2], cropMax[2];
+    std::unique_ptr<Filter> filter;
+    std::string filename;
+    Float diagonal, scale, maxSampleLuminance;
+    Float filterTable[MI_FILTER_TABLE_WIDTH * MI_FILTER_TABLE_WIDTH];
+    struct Pixel { Float xyz[3]; Float filterWeightSum; };
+    std::vector<Pixel> pixels;
+};
+Film *CreateFilm(const ParamSet &ps, std::unique_ptr<Filter> filter);
+bool WriteImage(const std::string &name, const Float *rgb, const int cropMin[2], const int cropMax[2],
+                const int fullRes[2]);   // imageio.cpp:81-122: .pfm (float32), .exr (half, uncompressed)
+bool ReadImagePFM(const std::string &name, std::vector<Float> *rgb, int *w, int *h);
+
+// ---- Camera (core/camera.h:50-115, cameras/perspective.cpp)
+struct PerspectiveCamera {
+    PerspectiveCamera(const Transform &cameraToWorld, const Float screenWindow[4], Float shutterOpen,
+                      Float shutterClose, Float lensRadius, Float focalDistance, Float fov, Film *film);
+    Transform CameraToWorld, CameraToScreen, RasterToCamera, ScreenToRaster, RasterToScreen;
+    Float shutterOpen, shutterClose, lensRadius, focalDistance;
+    Vec3 dxCamera, dyCamera;
+    std::unique_ptr<Film> film;   // camera owns the film (camera.cpp:42)
+};
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &ps, const Transform &cam2world, Film *film);
+
+// ---- Sampler: SobolSampler (samplers/sobol.h:48-69)
+struct SobolSampler {
+    SobolSampler(int64_t spp, const int sampleMin[2], const int sampleMax[2]);
+    int64_t samplesPerPixel;
+    int sampleMin[2], sampleMax[2];
+    int resolution, log2Resolution;
+};
+
+// ---- Scene (core/scene.h:50-80)
+class Scene {
+  public:
+    Scene(std::shared_ptr<BVHAccel> aggregate, std::vector<GeometricPrimitive> prims, std::vector<LightEntry> lights);
+    const Bounds3 &WorldBound() const { return worldBound; }
+    std::shared_ptr<BVHAccel> aggregate;
+    std::vector<GeometricPrimitive> primitives;
+    std::vector<LightEntry> lights;   // scene.lights order; area lights expand to one light per triangle
+    Bounds3 worldBound;
+};
+
+// ---- Integrator (core/integrator.h:53-58) and the GPU path integrator
+class Integrator {
+  public:
+    virtual ~Integrator() {}
+    virtual void Render(const Scene &scene) = 0;
+};
+
+// Owns the flattened arrays an mi_scene_desc points into.
+struct FlatScene {
+    mi_scene_desc desc;
+    std::vector<float> P, N, UV, lightFunc, lightCdf;
+    std::vector<uint32_t> triIndices, triMesh;
+    std::vector<int32_t> triLight;
+    std::vector<mi_mesh> meshes;
+    std::vector<mi_material> materials;
+    std::vector<mi_light> lights;
+};
+
+class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)
+  public:
+    WavefrontPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera,
+                            std::shared_ptr<SobolSampler> sampler, const int pixelMin[2], const int pixelMax[2],
+                            Float rrThreshold, const std::string &lightSampleStrategy);
+    void Render(const Scene &scene) override;   // flatten -> mi_scene_upload -> mi_render -> Film
+    // Flatten(scene): everything Render hands to the device, as POD
+    std::unique_ptr<FlatScene> Flatten(const Scene &scene) const;
+    int maxDepth;
+    std::shared_ptr<PerspectiveCamera> camera;
+    std::shared_ptr<SobolSampler> sampler;
+    int pixelMin[2], pixelMax[2];
+    Float rrThreshold;
+    std::string lightSampleStrategy;
+    int nGpus = 1;   // --gpus: tile-sharded over this many devices in-process
+};
+WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<SobolSampler> sampler,
+                                              std::shared_ptr<PerspectiveCamera> camera);
+
+}  // namespace pbrt_amd

@@ -1,0 +1,219 @@
+// Shape factories that end in a TriangleMesh (host, scene-load time).
+// Reference: shapes/triangle.cpp:60-110 (TriangleMesh ctor: vertices/normals/tangents are
+// transformed to world space once), :648-744 (CreateTriangleMeshShape parameter handling),
+// shapes/plymesh.cpp:157-290 (PLY loading; quads split (0,1,2),(3,0,2), :141-147).
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "scene.h"
+
+namespace pbrt_amd {
+
+std::shared_ptr<TriangleMesh> CreateTriangleMesh(const Transform &o2w, bool reverseOrientation, int nTris,
+                                                 const int *indices, int nVerts, const Vec3 *P, const Vec3 *S,
+                                                 const Vec3 *N, const Float *UV) {
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->indices.assign(indices, indices + 3 * nTris);
+    mesh->p.resize(nVerts);
+    for (int i = 0; i < nVerts; ++i) mesh->p[i] = o2w.Point(P[i]);
+    if (UV) mesh->uv.assign(UV, UV + 2 * nVerts);
+    if (N) { mesh->n.resize(nVerts); for (int i = 0; i < nVerts; ++i) mesh->n[i] = o2w.Normal(N[i]); }
+    if (S) { mesh->s.resize(nVerts); for (int i = 0; i < nVerts; ++i) mesh->s[i] = o2w.Vector(S[i]); }
+    mesh->reverseOrientation = reverseOrientation;
+    mesh->transformSwapsHandedness = o2w.SwapsHandedness();   // shape.cpp:47-50
+    return mesh;
+}
+
+static void warnAlpha(const ParamSet &ps) {
+    if (ps.FindTexture("alpha") != "" || ps.FindTexture("shadowalpha") != "")
+        Warning("alpha / shadowalpha textures are not supported by this path (SURVEY.md s.8 row f2); ignored");
+    if (ps.FindOneFloat("alpha", 1.f) == 0.f || ps.FindOneFloat("shadowalpha", 1.f) == 0.f)
+        Warning("constant zero alpha is not supported by this path; shape stays visible");
+}
+
+std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool ro, const ParamSet &ps) {
+    int nvi, npi, nuvi = 0, nsi, nni;
+    const int *vi = ps.FindInt("indices", &nvi);
+    const Float *P = ps.FindPoint3("P", &npi);
+    const Float *uvs = ps.FindPoint2("uv", &nuvi);
+    if (!uvs) uvs = ps.FindPoint2("st", &nuvi);
+    if (!uvs) {
+        uvs = ps.FindFloat("uv", &nuvi);
+        if (!uvs) uvs = ps.FindFloat("st", &nuvi);
+        if (uvs) nuvi /= 2;
+    }
+    if (uvs) {
+        if (nuvi < npi) {
+            Error("Not enough of \"uv\"s for triangle mesh.  Expected %d, found %d.  Discarding.", npi, nuvi);
+            uvs = nullptr;
+        } else if (nuvi > npi)
+            Warning("More \"uv\"s provided than will be used for triangle mesh.  (%d expcted, %d found)", npi, nuvi);
+    }
+    if (!vi) { Error("Vertex indices \"indices\" not provided with triangle mesh shape"); return nullptr; }
+    if (!P) { Error("Vertex positions \"P\" not provided with triangle mesh shape"); return nullptr; }
+    const Float *S = ps.FindVector3("S", &nsi);
+    if (S && nsi != npi) { Error("Number of \"S\"s for triangle mesh must match \"P\"s"); S = nullptr; }
+    const Float *N = ps.FindNormal3("N", &nni);
+    if (N && nni != npi) { Error("Number of \"N\"s for triangle mesh must match \"P\"s"); N = nullptr; }
+    for (int i = 0; i < nvi; ++i)
+        if (vi[i] >= npi || vi[i] < 0) {
+            Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", vi[i], npi);
+            return nullptr;
+        }
+    int nfi;
+    ps.FindInt("faceIndices", &nfi);   // only consumed by ptex textures (not on this path)
+    warnAlpha(ps);
+    return CreateTriangleMesh(o2w, ro, nvi / 3, vi, npi, (const Vec3 *)P, (const Vec3 *)S, (const Vec3 *)N, uvs);
+}
+
+// ---------------------------------------------------------------- PLY
+namespace {
+struct PlyProp { std::string name, type, countType, itemType; bool isList = false; };
+struct PlyElem { std::string name; long count = 0; std::vector<PlyProp> props; };
+int plyTypeSize(const std::string &t) {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+    if (t == "double" || t == "float64") return 8;
+    return 0;
+}
+double plyReadBinary(const unsigned char *&p, const std::string &t, bool swap) {
+    int n = plyTypeSize(t);
+    unsigned char b[8];
+    for (int i = 0; i < n; ++i) b[i] = swap ? p[n - 1 - i] : p[i];
+    p += n;
+    if (t == "char" || t == "int8") return (double)*(int8_t *)b;
+    if (t == "uchar" || t == "uint8") return (double)*(uint8_t *)b;
+    if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, b, 2); return v; }
+    if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, b, 2); return v; }
+    if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, b, 4); return v; }
+    if (t == "uint" || t == "uint32") { uint32_t v; std::memcpy(&v, b, 4); return v; }
+    if (t == "float" || t == "float32") { float v; std::memcpy(&v, b, 4); return v; }
+    double v; std::memcpy(&v, b, 8); return v;
+}
+}  // namespace
+
+std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const ParamSet &ps) {
+    std::string filename = ps.FindOneFilename("filename", "");
+    std::ifstream in(filename, std::ios::binary);
+    if (!in) { Error("Couldn't open PLY file \"%s\"", filename.c_str()); return nullptr; }
+    std::string data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    size_t pos = 0;
+    auto nextLine = [&](std::string *line) {
+        if (pos >= data.size()) return false;
+        size_t e = data.find('\n', pos);
+        if (e == std::string::npos) e = data.size();
+        *line = data.substr(pos, e - pos);
+        if (!line->empty() && line->back() == '\r') line->pop_back();
+        pos = e + 1;
+        return true;
+    };
+    std::string line;
+    if (!nextLine(&line) || line != "ply") { Error("\"%s\" is not a PLY file", filename.c_str()); return nullptr; }
+    std::string format;
+    std::vector<PlyElem> elems;
+    while (nextLine(&line)) {
+        std::istringstream ls(line);
+        std::string tok;
+        ls >> tok;
+        if (tok == "format") ls >> format;
+        else if (tok == "element") { PlyElem e; ls >> e.name >> e.count; elems.push_back(e); }
+        else if (tok == "property") {
+            PlyProp p;
+            ls >> p.type;
+            if (p.type == "list") { p.isList = true; ls >> p.countType >> p.itemType; }
+            ls >> p.name;
+            if (elems.empty()) { Error("PLY property before element in \"%s\"", filename.c_str()); return nullptr; }
+            elems.back().props.push_back(p);
+        } else if (tok == "end_header") break;
+    }
+    bool ascii = format == "ascii", swap = format == "binary_big_endian";
+    if (!ascii && format != "binary_little_endian" && !swap) { Error("Unknown PLY format in \"%s\"", filename.c_str()); return nullptr; }
+
+    long vertexCount = 0, faceCount = 0;
+    for (auto &e : elems) { if (e.name == "vertex") vertexCount = e.count; if (e.name == "face") faceCount = e.count; }
+    if (vertexCount == 0 || faceCount == 0) {
+        Error("PLY file \"%s\" is invalid! No face/vertex elements found!", filename.c_str());
+        return nullptr;
+    }
+    std::vector<Vec3> P(vertexCount), N;
+    std::vector<Float> UV;
+    std::vector<int> indices;
+    indices.reserve(faceCount * 3);
+    bool hasN = false, hasUV = false;
+
+    std::istringstream as;
+    const unsigned char *bp = (const unsigned char *)data.data() + pos;
+    if (ascii) as.str(data.substr(pos));
+    auto readVal = [&](const std::string &type) -> double {
+        if (ascii) { double v = 0; as >> v; return v; }
+        return plyReadBinary(bp, type, swap);
+    };
+    for (auto &e : elems) {
+        if (e.name == "vertex") {
+            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                const std::string &n = e.props[k].name;
+                if (n == "x") ix = k; else if (n == "y") iy = k; else if (n == "z") iz = k;
+                else if (n == "nx") inx = k; else if (n == "ny") iny = k; else if (n == "nz") inz = k;
+                else if (n == "u" || n == "s" || n == "texture_u" || n == "texture_s") iu = k;   // plymesh.cpp:218-231
+                else if (n == "v" || n == "t" || n == "texture_v" || n == "texture_t") iv = k;
+            }
+            if (ix < 0 || iy < 0 || iz < 0) { Error("PLY file \"%s\": Vertex coordinate property not found!", filename.c_str()); return nullptr; }
+            hasN = inx >= 0 && iny >= 0 && inz >= 0;
+            hasUV = iu >= 0 && iv >= 0;
+            if (hasN) N.resize(vertexCount);
+            if (hasUV) UV.resize(2 * vertexCount);
+            for (long i = 0; i < e.count; ++i)
+                for (size_t k = 0; k < e.props.size(); ++k) {
+                    if (e.props[k].isList) { long n = (long)readVal(e.props[k].countType); for (long j = 0; j < n; ++j) readVal(e.props[k].itemType); continue; }
+                    float v = (float)readVal(e.props[k].type);
+                    if ((int)k == ix) P[i].x = v; else if ((int)k == iy) P[i].y = v; else if ((int)k == iz) P[i].z = v;
+                    else if (hasN && (int)k == inx) N[i].x = v; else if (hasN && (int)k == iny) N[i].y = v;
+                    else if (hasN && (int)k == inz) N[i].z = v;
+                    else if (hasUV && (int)k == iu) UV[2 * i] = v; else if (hasUV && (int)k == iv) UV[2 * i + 1] = v;
+                }
+        } else if (e.name == "face") {
+            for (long i = 0; i < e.count; ++i)
+                for (auto &p : e.props) {
+                    if (!p.isList) { readVal(p.type); continue; }
+                    long n = (long)readVal(p.countType);
+                    std::vector<int> face(n);
+                    for (long j = 0; j < n; ++j) face[j] = (int)readVal(p.itemType);
+                    if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
+                    if (n != 3 && n != 4) { Warning("plymesh: Ignoring face with %i vertices (only triangles and quads are supported!)", (int)n); continue; }
+                    for (long j = 0; j < n; ++j)
+                        if (face[j] < 0 || face[j] >= vertexCount) {
+                            Error("plymesh: Vertex reference %i is out of bounds! Valid range is [0..%i)", face[j], (int)vertexCount);
+                            return nullptr;
+                        }
+                    indices.insert(indices.end(), {face[0], face[1], face[2]});
+                    if (n == 4) indices.insert(indices.end(), {face[3], face[0], face[2]});
+                }
+        } else {   // skip unknown elements
+            for (long i = 0; i < e.count; ++i)
+                for (auto &p : e.props) {
+                    if (p.isList) { long n = (long)readVal(p.countType); for (long j = 0; j < n; ++j) readVal(p.itemType); }
+                    else readVal(p.type);
+                }
+        }
+    }
+    warnAlpha(ps);
+    return CreateTriangleMesh(o2w, ro, (int)indices.size() / 3, indices.data(), (int)vertexCount, P.data(), nullptr,
+                              hasN ? N.data() : nullptr, hasUV ? UV.data() : nullptr);
+}
+
+std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &, bool, const ParamSet &);   // loopsubdiv.cpp
+
+std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps) {
+    if (name == "trianglemesh") return CreateTriangleMeshShape(o2w, ro, ps);
+    if (name == "plymesh") return CreatePLYMesh(o2w, ro, ps);
+    if (name == "loopsubdiv") return CreateLoopSubdiv(o2w, ro, ps);
+    // quadrics / curves / nurbs / heightfield: not on the triangle hot path
+    Warning("Shape \"%s\" is not supported by the GPU triangle path (convert with the reference's --toply); skipped.",
+            name.c_str());
+    return nullptr;
+}
+
+}  // namespace pbrt_amd

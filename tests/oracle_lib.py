@@ -1,0 +1,129 @@
+"""ctypes access to oracle/liboracle.so (the CPU restatement) and oracle/_ref/pbrt_ref (the real
+reference, when built).  TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+pa = importlib.import_module("pbrt-v3-distributed_amd")
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+PBRT_REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_sobol_interval_to_index.restype = C.c_uint64
+        L.oracle_sobol_interval_to_index.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+        L.oracle_sobol_sample_float.restype = C.c_float
+        L.oracle_sobol_sample_float.argtypes = [C.c_int64, C.c_int]
+        L.oracle_sobol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.oracle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.oracle_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.oracle_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_render.restype = C.c_double
+        L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def render(scene, spp_begin=0, spp_end=-1, nthreads=0, tiles=None):
+    """-> (rgbw (H,W,4), counters dict, seconds)"""
+    rgbw = np.zeros((scene.height, scene.width, 4), dtype=np.float32)
+    cnt = np.zeros(8, dtype=np.uint64)
+    t = None if tiles is None else np.asarray(tiles, dtype=np.int32)
+    secs = lib().oracle_render(scene.desc, _p(rgbw), spp_begin, spp_end, nthreads, _p(cnt), _p(t) if t is not None else None)
+    names = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any", "tris_any"]
+    return rgbw, dict(zip(names, [int(v) for v in cnt[:7]])), secs
+
+
+def sobol(scene, px, py, n_samples, n_dims):
+    out = np.zeros((n_samples, n_dims), dtype=np.float32)
+    idx = np.zeros(n_samples, dtype=np.uint64)
+    lib().oracle_sobol(scene.desc, px, py, n_samples, n_dims, _p(out), _p(idx))
+    return out, idx
+
+
+def camera_rays(scene, pixels_xy, sample_num):
+    pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)
+    sample_num = np.ascontiguousarray(sample_num, dtype=np.int32)
+    n = len(sample_num)
+    rays = np.zeros(n, dtype=pa.RAY_DTYPE)
+    pf = np.zeros((n, 2), dtype=np.float32)
+    lib().oracle_camera_rays(scene.desc, _p(pixels_xy), _p(sample_num), n, _p(rays), _p(pf))
+    return rays, pf
+
+
+def intersect(scene, rays):
+    rays = np.ascontiguousarray(rays, dtype=pa.RAY_DTYPE)
+    hits = np.zeros(len(rays), dtype=pa.HIT_DTYPE)
+    cnt = np.zeros(2, dtype=np.uint64)
+    lib().oracle_intersect(scene.desc, _p(rays), len(rays), _p(hits), _p(cnt))
+    return hits, cnt
+
+
+def intersect_p(scene, rays):
+    rays = np.ascontiguousarray(rays, dtype=pa.RAY_DTYPE)
+    occ = np.zeros(len(rays), dtype=np.uint8)
+    cnt = np.zeros(2, dtype=np.uint64)
+    lib().oracle_intersect_p(scene.desc, _p(rays), len(rays), _p(occ), _p(cnt))
+    return occ, cnt
+
+
+def li(scene, pixels_xy, sample_num):
+    pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)
+    sample_num = np.ascontiguousarray(sample_num, dtype=np.int32)
+    out = np.zeros((len(sample_num), 3), dtype=np.float32)
+    lib().oracle_li(scene.desc, _p(pixels_xy), _p(sample_num), len(sample_num), _p(out))
+    return out
+
+
+def triangle_intersect(p0, p1, p2, o, d, tmax=np.inf):
+    ray = np.zeros(1, dtype=pa.RAY_DTYPE)
+    ray["o"][0] = o; ray["d"][0] = d; ray["tmax"][0] = tmax
+    t = C.c_float(0)
+    b = np.zeros(3, dtype=np.float32)
+    v = [np.ascontiguousarray(x, dtype=np.float32) for x in (p0, p1, p2)]
+    hit = lib().oracle_triangle_intersect(_p(v[0]), _p(v[1]), _p(v[2]), _p(ray), C.byref(t), _p(b))
+    return bool(hit), t.value, b
+
+
+def have_ref():
+    return os.path.exists(PBRT_REF)
+
+
+def run_ref(scene_file, outfile, nthreads=None, extra=()):
+    """Render with the real reference binary; returns the image (H,W,3)."""
+    cmd = [PBRT_REF, "--quiet", "--outfile", outfile]
+    if nthreads:
+        cmd += ["--nthreads", str(nthreads)]
+    cmd += list(extra) + [scene_file]
+    subprocess.check_call(cmd)
+    return pa.read_pfm(outfile)
+
+
+def image_metrics(img, ref):
+    """per-pixel L2 criterion of SURVEY.md s.8(c): fraction of pixels with |d|_2 <= 1e-3 (1+|ref|_2), and relMSE."""
+    d = np.linalg.norm(img.astype(np.float64) - ref.astype(np.float64), axis=-1)
+    r = np.linalg.norm(ref.astype(np.float64), axis=-1)
+    frac = float(np.mean(d <= 1e-3 * (1 + r)))
+    relmse = float(np.mean(d ** 2) / max(1e-30, np.mean(r ** 2)))
+    return frac, relmse
