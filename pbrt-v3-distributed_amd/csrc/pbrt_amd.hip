@@ -1,0 +1,1167 @@
+// libpbrt_amd.so -- wavefront path tracer for MI355X (gfx950), hand-written HIP behind the C ABI of
+// include/pbrt_amd.h.  One context per GPU.  Reference hot path: SamplerIntegrator::Render
+// (core/integrator.cpp:228-339) -> PathIntegrator::Li (integrators/path.cpp:64-188).
+//
+// Wavefront organisation (per pass over a chunk of (pixel, sample) pairs; all queues live in HBM):
+//   k_raygen     Sobol' index + camera sample + PerspectiveCamera ray           -> extension queue
+//   per bounce:
+//   k_closest    BVH4 closest hit, LDS-resident per-lane stack                  -> hit records + material key counts
+//   k_scan/k_scatter   counting sort of the hit paths by material (wave ballots) -> material-sorted queue
+//   k_shade      emission, BSDF build, UniformSampleOneLight/EstimateDirect, BSDF::Sample_f, RR
+//                                                                               -> shadow / MIS / next extension queues
+//   k_anyhit     BVH4 any-hit for shadow rays, adds the light-sampled term
+//   k_closest<MIS>  closest hit for the BSDF-sampled MIS ray, adds its term
+//   k_film       FilmTile::AddSample into the device film
+// All kernels are persistent grid-stride loops whose trip counts come from device-side queue
+// counters (no host round trips inside a pass) with an XCD-contiguous chunk mapping.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_shade.h"
+#include "sobol_tables.inc"
+
+// ============================================================================ device side
+struct PathState {
+    float4 *ray_o, *ray_d;     // o.xyz,tMax | d.xyz,-
+    uint2 *hit;                // prim (0xffffffff = miss), t bits
+    float4 *beta;              // rgb, etaScale
+    float4 *L;                 // rgb, -
+    uint4 *smp;                // sobol index lo, hi, dimension, bounces | specularBounce << 16
+    float2 *pfilm;
+    uint32_t *pixel;           // film pixel x | y << 16 (sample-space coords), 0xffffffff = inactive
+    float4 *sh_o, *sh_d, *sh_c;   // shadow ray: o.xyz,tMax | d | contribution rgb
+    float4 *mi_o, *mi_d, *mi_c;   // MIS ray: o | d.xyz,lightNum | contribution rgb
+    uint2 *keyrank;
+    uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
+    uint32_t *qcount;          // [0],[1] extension queues, [2] shadow, [3] mis, [4] sorted total
+    uint32_t *keycount, *keyoffset;
+    unsigned long long *counters;
+    uint32_t *spill;
+    int spill_per_thread;
+    uint32_t cap;
+};
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_COUNT = 8 };
+
+struct PassInfo {
+    const uint32_t *tiles;     // owned tile ids (tile = ty * nTilesX + tx)
+    uint32_t n_tiles_x;
+    uint32_t pix0, npix;       // owned-pixel range of this pass (16x16 tile-major pixel numbering)
+    uint32_t s0, ns;           // sample numbers [s0, s0+ns)
+    const int32_t *list_xy;    // explicit (pixel, sample) list mode (mi_li / mi_camera_rays), else null
+    const int32_t *list_s;
+};
+
+#define MISS_PRIM 0xffffffffu
+#define INACTIVE_PIXEL 0xffffffffu
+
+// ---- XCD-aware persistent loop: the queue is cut into 256-item chunks; XCD x (= blockIdx.x % 8, the
+// observed dispatch placement) owns one contiguous eighth of the chunks so that its private 4 MiB L2
+// sees a spatially coherent band of rays; correctness never depends on the placement.
+struct ChunkIter {
+    uint32_t nch, cpx, c, xcd, bpx;
+    PT_DEV ChunkIter(uint32_t n) {
+        nch = (n + PT_BLOCK - 1) / PT_BLOCK;
+        cpx = (nch + 7) / 8;
+        xcd = blockIdx.x & 7;
+        bpx = gridDim.x >> 3;
+        c = blockIdx.x >> 3;
+    }
+    PT_DEV bool more() const { return c < cpx; }
+    PT_DEV uint32_t item() const { return (xcd * cpx + c) * PT_BLOCK + threadIdx.x; }
+    PT_DEV void next() { c += bpx; }
+};
+
+PT_DEV uint32_t lane_id() { return __lane_id(); }
+// wave-aggregated queue append: one atomic per wave (ballot + popcount), order-preserving inside the wave
+PT_DEV uint32_t wave_append(uint32_t *counter, bool active) {
+    unsigned long long mask = __ballot(active);
+    if (mask == 0) return 0;
+    uint32_t lane = lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// wave-aggregated histogram slot: lanes with equal key share one atomic (match-any built from ballots)
+PT_DEV uint32_t wave_key_rank(uint32_t *keycount, uint32_t key, bool active) {
+    uint32_t lane = lane_id();
+    uint32_t rank = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        int first = __ffsll((long long)todo) - 1;
+        uint32_t k0 = __shfl(key, first);
+        unsigned long long same = __ballot(active && key == k0) & todo;
+        if (active && key == k0) {
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(&keycount[k0], (uint32_t)__popcll(same));
+            base = __shfl(base, first);
+            rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return rank;
+}
+PT_DEV void wave_count(unsigned long long *counter, uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
+// ---- camera: Sampler::GetCameraSample (core/sampler.cpp:46-52) + PerspectiveCamera::GenerateRayDifferential
+// main ray (cameras/perspective.cpp:95-144) + Transform::operator()(Ray) (core/transform.h:252-264)
+PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
+    Float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    Float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    Float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    Float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1) return V3(xp, yp, zp);
+    Float inv = (Float)1 / wp;
+    return V3(inv * xp, inv * yp, inv * zp);
+}
+PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy) {
+    Float u0, u1, l0, l1;
+    smp.Get2D(sc, &u0, &u1);
+    Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;
+    Float time = smp.Get1D(sc);
+    (void)time;   // static scene: ray.time is never read on this path
+    smp.Get2D(sc, &l0, &l1);
+    const mi_camera &cam = sc.camera;
+    V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
+    V3 ro(0, 0, 0), rd = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
+    if (cam.lens_radius > 0) {
+        Float dx, dy;
+        ConcentricSampleDisk(l0, l1, &dx, &dy);
+        Float lx = cam.lens_radius * dx, ly = cam.lens_radius * dy;
+        Float ft = cam.focal_distance / rd.z;
+        V3 pFocus = ro + rd * ft;
+        ro = V3(lx, ly, 0);
+        rd = Normalize(pFocus - ro);
+    }
+    const float *m = cam.camera_to_world;
+    V3 wo_ = XfPoint(m, ro);   // w == 1 for the affine camera-to-world matrix; XfPoint handles the general case
+    Float xAbs = (absf(m[0] * ro.x) + absf(m[1] * ro.y) + absf(m[2] * ro.z) + absf(m[3]));
+    Float yAbs = (absf(m[4] * ro.x) + absf(m[5] * ro.y) + absf(m[6] * ro.z) + absf(m[7]));
+    Float zAbs = (absf(m[8] * ro.x) + absf(m[9] * ro.y) + absf(m[10] * ro.z) + absf(m[11]));
+    V3 oError = gamma_n(3) * V3(xAbs, yAbs, zAbs);
+    V3 wd(m[0] * rd.x + m[1] * rd.y + m[2] * rd.z, m[4] * rd.x + m[5] * rd.y + m[6] * rd.z, m[8] * rd.x + m[9] * rd.y + m[10] * rd.z);
+    Float lengthSquared = wd.LengthSquared();
+    Float tm = PT_INFINITY;
+    if (lengthSquared > 0) {
+        Float dt = Dot(Abs(wd), oError) / lengthSquared;
+        wo_ = wo_ + wd * dt;
+        tm -= dt;
+    }
+    *o = wo_; *d = wd; *tMax = tm; *pfx = pFilmX; *pfy = pFilmY;
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, PassInfo pass, uint32_t qout) {
+    uint32_t n = pass.list_xy ? pass.npix : pass.npix * pass.ns;
+    uint32_t ncam = 0;
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        bool active = i < n;
+        int x = 0, y = 0;
+        uint32_t s = 0;
+        if (active) {
+            if (pass.list_xy) { x = pass.list_xy[2 * i]; y = pass.list_xy[2 * i + 1]; s = (uint32_t)pass.list_s[i]; }
+            else {
+                uint32_t p = i % pass.npix;
+                s = pass.s0 + i / pass.npix;
+                uint32_t k = pass.pix0 + p, tile = pass.tiles[k >> 8], w = k & 255;
+                x = sc.sample_min[0] + (int)(tile % pass.n_tiles_x) * 16 + (int)(w & 15);
+                y = sc.sample_min[1] + (int)(tile / pass.n_tiles_x) * 16 + (int)(w >> 4);
+                // tile clipped to the sample bounds (integrator.cpp:251-255) and the pixelBounds test (:273)
+                active = x < sc.sample_max[0] && y < sc.sample_max[1] && x >= sc.pixel_min[0] && x < sc.pixel_max[0] &&
+                         y >= sc.pixel_min[1] && y < sc.pixel_max[1];
+            }
+        }
+        if (i < n) {
+            ps.L[i] = make_float4(0, 0, 0, 0);
+            ps.pixel[i] = active ? ((uint32_t)(x - sc.sample_min[0]) | ((uint32_t)(y - sc.sample_min[1]) << 16)) : INACTIVE_PIXEL;
+        }
+        if (active) {
+            Sampler smp;
+            smp.Start(sc, x, y, s);
+            V3 o, d;
+            Float tMax, pfx, pfy;
+            GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy);
+            ps.ray_o[i] = make_float4(o.x, o.y, o.z, tMax);
+            ps.ray_d[i] = make_float4(d.x, d.y, d.z, 0);
+            ps.beta[i] = make_float4(1, 1, 1, 1);
+            ps.smp[i] = make_uint4((uint32_t)smp.index, (uint32_t)(smp.index >> 32), (uint32_t)smp.dimension, 0);
+            ps.pfilm[i] = make_float2(pfx, pfy);
+            ++ncam;
+        }
+        uint32_t pos = wave_append(&ps.qcount[qout], active);
+        if (active) ps.q_ext[qout][pos] = i;
+    }
+    wave_count(&ps.counters[MI_CNT_CAMERA_RAYS], ncam);
+}
+
+// ---- closest hit over a queue.  MODE 0: path extension rays (writes hit record + material key/rank);
+// MODE 1: MIS rays of EstimateDirect (core/integrator.cpp:167-213): adds f*Li*weight/scatteringPdf.
+template <int MODE, bool COUNT>
+__global__ void __launch_bounds__(PT_BLOCK) k_closest(DevScene sc, PathState ps, uint32_t qin) {
+    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
+    TravStack st;
+    st.lds = &lds_stack[threadIdx.x];
+    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : ps.q_mis;
+    uint32_t n = ps.qcount[MODE == 0 ? qin : QC_MIS];
+    TraceCounters tc = {0, 0};
+    uint32_t nrays = 0;
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        bool active = i < n;
+        uint32_t slot = 0, prim = MISS_PRIM, key = 0;
+        Float t = 0;
+        if (active) {
+            slot = queue[i];
+            float4 o4 = MODE == 0 ? ps.ray_o[slot] : ps.mi_o[slot];
+            float4 d4 = MODE == 0 ? ps.ray_d[slot] : ps.mi_d[slot];
+            V3 o(o4.x, o4.y, o4.z), d(d4.x, d4.y, d4.z);
+            Float tMax = MODE == 0 ? o4.w : PT_INFINITY;
+            bool hit = Traverse<false, COUNT>(sc, o, d, tMax, st, &t, &prim, &tc);
+            if (!hit) prim = MISS_PRIM;
+            ++nrays;
+            if (MODE == 0) {
+                ps.hit[slot] = make_uint2(prim, __float_as_uint(t));
+                if (hit) {
+                    int mat = sc.meshes[sc.tri_mesh[prim]].material;
+                    key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;   // null-BSDF surfaces: own bucket
+                } else
+                    key = sc.n_materials;                                   // escaped rays
+            } else {
+                int lightNum = (int)__float_as_uint(d4.w);
+                const mi_light &light = sc.lights[lightNum];
+                RGB Li(0.f);
+                if (hit) {
+                    if (sc.tri_light[prim] == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                        V3 p0, p1, p2;
+                        uint32_t tf;
+                        LoadTri(sc, prim, &p0, &p1, &p2, &tf);
+                        TriHit th;
+                        TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
+                        Isect li;
+                        BuildIsect(sc, prim, p0, p1, p2, th, d, &li);
+                        Li = AreaL(light, li.n, -d);   // lightIsect.Le(-wi)
+                    }
+                } else if (light.type == MI_LIGHT_INFINITE)
+                    Li = rgb3(light.L);                 // light.Le(ray)
+                if (!Li.IsBlack()) {
+                    float4 c = ps.mi_c[slot], L = ps.L[slot];
+                    L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
+                    ps.L[slot] = L;
+                }
+            }
+        }
+        if (MODE == 0) {
+            uint32_t rank = wave_key_rank(ps.keycount, key, active);
+            if (active) ps.keyrank[slot] = make_uint2(key, rank);
+        }
+    }
+    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], nrays);
+    if (COUNT) { wave_count(&ps.counters[MI_CNT_NODES_CLOSEST], tc.nodes); wave_count(&ps.counters[MI_CNT_TRIS_CLOSEST], tc.tris); }
+}
+
+// ---- shadow rays: VisibilityTester::Unoccluded (core/light.cpp:59-61) -> BVHAccel::IntersectP
+template <bool COUNT>
+__global__ void __launch_bounds__(PT_BLOCK) k_anyhit(DevScene sc, PathState ps) {
+    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
+    TravStack st;
+    st.lds = &lds_stack[threadIdx.x];
+    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    uint32_t n = ps.qcount[QC_SHADOW];
+    TraceCounters tc = {0, 0};
+    uint32_t nrays = 0;
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        if (i < n) {
+            uint32_t slot = ps.q_shadow[i];
+            float4 o4 = ps.sh_o[slot], d4 = ps.sh_d[slot];
+            Float t;
+            uint32_t prim;
+            bool occluded = Traverse<true, COUNT>(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, st, &t, &prim, &tc);
+            ++nrays;
+            if (!occluded) {
+                float4 c = ps.sh_c[slot], L = ps.L[slot];
+                L.x += c.x; L.y += c.y; L.z += c.z;
+                ps.L[slot] = L;
+            }
+        }
+    }
+    wave_count(&ps.counters[MI_CNT_SHADOW_RAYS], nrays);
+    if (COUNT) { wave_count(&ps.counters[MI_CNT_NODES_ANY], tc.nodes); wave_count(&ps.counters[MI_CNT_TRIS_ANY], tc.tris); }
+}
+
+// ---- counting sort by material key
+__global__ void k_scan_keys(PathState ps, uint32_t nkeys) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < nkeys; ++k) { ps.keyoffset[k] = acc; acc += ps.keycount[k]; }
+        ps.qcount[QC_SORTED] = acc;
+    }
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin) {
+    uint32_t n = ps.qcount[qin];
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        if (i < n) {
+            uint32_t slot = ps.q_ext[qin][i];
+            uint2 kr = ps.keyrank[slot];
+            ps.q_sorted[ps.keyoffset[kr.x] + kr.y] = slot;
+        }
+    }
+}
+
+// ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
+__global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, uint32_t qout) {
+    uint32_t n = ps.qcount[QC_SORTED];
+    uint32_t nseg = 0;
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        bool active = i < n;
+        bool cont = false, wantShadow = false, wantMis = false;
+        uint32_t slot = 0;
+        if (active) {
+            slot = ps.q_sorted[i];
+            uint2 hr = ps.hit[slot];
+            float4 o4 = ps.ray_o[slot], d4 = ps.ray_d[slot], b4 = ps.beta[slot], L4 = ps.L[slot];
+            uint4 s4 = ps.smp[slot];
+            V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            RGB beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
+            Float etaScale = b4.w;
+            int bounces = (int)(s4.w & 0xffffu);
+            bool specularBounce = (s4.w >> 16) & 1u;
+            Sampler smp;
+            smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+            smp.dimension = (int)s4.z;
+            smp.px = smp.py = 0;   // only dimensions 0/1 (camera sample) look at the pixel
+            ++nseg;
+            bool found = hr.x != MISS_PRIM;
+            // path.cpp:91-101: emitted light at the vertex / from the environment
+            Isect isect;
+            if (found) {
+                V3 p0, p1, p2;
+                uint32_t tf;
+                LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
+                TriHit th;
+                TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
+                BuildIsect(sc, hr.x, p0, p1, p2, th, rd, &isect);
+            }
+            if (bounces == 0 || specularBounce) {
+                if (found) {
+                    int li = sc.tri_light[hr.x];
+                    if (li >= 0) { RGB Le = AreaL(sc.lights[li], isect.n, -rd); L = L + beta * Le; }
+                } else {
+                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].L);
+                }
+            }
+            if (found && bounces < sc.max_depth) {
+                int matIdx = sc.meshes[sc.tri_mesh[hr.x]].material;
+                if (matIdx < 0) {
+                    // null BSDF: step through the surface, same bounce count, no sampler use (path.cpp:108-113)
+                    V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, rd);
+                    ps.ray_o[slot] = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                    cont = true;
+                } else {
+                    BSDF bsdf(isect, &sc.materials[matIdx]);
+                    // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
+                    if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
+                        Float ul = smp.Get1D(sc);
+                        // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411)
+                        int size = (int)sc.n_lights + 1, first = 0, len = size;
+                        while (len > 0) {
+                            int half = len >> 1, middle = first + half;
+                            if (sc.light_cdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
+                        }
+                        int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+                        Float selPdf = (sc.light_func_int > 0) ? sc.light_func[lightNum] / (sc.light_func_int * (int)sc.n_lights) : 0;
+                        if (selPdf != 0) {
+                            Float uL0, uL1, uS0, uS1;
+                            smp.Get2D(sc, &uL0, &uL1);
+                            smp.Get2D(sc, &uS0, &uS1);
+                            // ---- EstimateDirect (core/integrator.cpp:108-215), handleMedia=false, specular=false
+                            const mi_light &light = sc.lights[lightNum];
+                            const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+                            LightSample ls;
+                            SampleLi(sc, light, isect, uL0, uL1, &ls);
+                            Float lightPdf = ls.pdf, scatteringPdf = 0;
+                            if (lightPdf > 0 && !ls.Li.IsBlack()) {
+                                RGB f = bsdf.f(isect.wo, ls.wi, bsdfFlags) * AbsDot(ls.wi, isect.ns);
+                                scatteringPdf = bsdf.Pdf(isect.wo, ls.wi, bsdfFlags);
+                                if (!f.IsBlack()) {
+                                    RGB Ld;
+                                    if (ls.delta) Ld = f * ls.Li / lightPdf;
+                                    else {
+                                        Float weight = PowerHeuristic(lightPdf, scatteringPdf);
+                                        Ld = f * ls.Li * weight / lightPdf;
+                                    }
+                                    RGB c = beta * (Ld / selPdf);   // added by k_anyhit iff the shadow ray is unoccluded
+                                    ps.sh_o[slot] = make_float4(ls.shadow.o.x, ls.shadow.o.y, ls.shadow.o.z, ls.shadow.tMax);
+                                    ps.sh_d[slot] = make_float4(ls.shadow.d.x, ls.shadow.d.y, ls.shadow.d.z, 0);
+                                    ps.sh_c[slot] = make_float4(c.r, c.g, c.b, 0);
+                                    wantShadow = true;
+                                }
+                            }
+                            if (!ls.delta) {   // BSDF-sampling half of the MIS estimator
+                                V3 wi;
+                                int sampledType;
+                                RGB f = bsdf.Sample_f(isect.wo, &wi, uS0, uS1, &scatteringPdf, bsdfFlags, &sampledType);
+                                f = f * AbsDot(wi, isect.ns);
+                                bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+                                if (!f.IsBlack() && scatteringPdf > 0) {
+                                    Float weight = 1;
+                                    bool ok = true;
+                                    if (!sampledSpecular) {
+                                        lightPdf = PdfLi(sc, light, isect, wi);
+                                        if (lightPdf == 0) ok = false;
+                                        else weight = PowerHeuristic(scatteringPdf, lightPdf);
+                                    }
+                                    if (ok) {
+                                        V3 mo = OffsetRayOrigin(isect.p, isect.pError, isect.n, wi);   // it.SpawnRay(wi)
+                                        RGB c = beta * ((f * weight / scatteringPdf) / selPdf);         // times Li, resolved by k_closest<1>
+                                        ps.mi_o[slot] = make_float4(mo.x, mo.y, mo.z, 0);
+                                        ps.mi_d[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)lightNum));
+                                        ps.mi_c[slot] = make_float4(c.r, c.g, c.b, 0);
+                                        wantMis = true;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // ---- sample the BSDF for the next path segment (path.cpp:131-150)
+                    V3 wo = -rd, wi;
+                    Float pdf, u0, u1;
+                    int flags;
+                    smp.Get2D(sc, &u0, &u1);
+                    RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                    if (!(f.IsBlack() || pdf == 0.f)) {
+                        beta = beta * (f * AbsDot(wi, isect.ns) / pdf);
+                        specularBounce = (flags & BSDF_SPECULAR) != 0;
+                        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                            Float eta = sc.materials[matIdx].eta;
+                            etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                        }
+                        V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, wi);   // isect.SpawnRay(wi)
+                        cont = true;
+                        // Russian roulette (path.cpp:176-184)
+                        RGB rrBeta = beta * etaScale;
+                        if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
+                            Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
+                            if (smp.Get1D(sc) < q) cont = false;
+                            else beta = beta / (1 - q);
+                        }
+                        if (cont) {
+                            ps.ray_o[slot] = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                            ps.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, 0);
+                            ps.beta[slot] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                            ++bounces;
+                        }
+                    }
+                }
+            }
+            ps.L[slot] = make_float4(L.r, L.g, L.b, 0);
+            if (cont) ps.smp[slot] = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16));
+        }
+        uint32_t pos = wave_append(&ps.qcount[qout], cont);
+        if (cont) ps.q_ext[qout][pos] = slot;
+        pos = wave_append(&ps.qcount[QC_SHADOW], wantShadow);
+        if (wantShadow) ps.q_shadow[pos] = slot;
+        pos = wave_append(&ps.qcount[QC_MIS], wantMis);
+        if (wantMis) ps.q_mis[pos] = slot;
+    }
+    wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
+}
+
+// ---- film: the radiance guards of integrator.cpp:294-315 + FilmTile::AddSample (core/film.h:121-161).
+// One lane per owned pixel walks that pixel's samples of the pass in sample order.
+//   SPILL == false: only the lane's own pixel, as a plain running sum continued from the film value -- the
+//                   reference's accumulation order for a pixel's own samples, no atomics;
+//   SPILL == true : every other footprint pixel (wide filters; with the box filter only a sample that lands
+//                   exactly on a pixel edge) through atomicAdd, in a second launch so that it cannot race
+//                   with the plain stores of the first.
+template <bool SPILL>
+__global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, PassInfo pass, float4 *film) {
+    int cw = sc.crop_max[0] - sc.crop_min[0];
+    const int W = MI_FILTER_TABLE_WIDTH;
+    for (ChunkIter it(pass.npix); it.more(); it.next()) {
+        uint32_t p = it.item();
+        if (p >= pass.npix) continue;
+        uint32_t pix = ps.pixel[p];
+        if (pix == INACTIVE_PIXEL) continue;
+        int ownx = sc.sample_min[0] + (int)(pix & 0xffffu), owny = sc.sample_min[1] + (int)(pix >> 16);
+        bool ownInside = ownx >= sc.crop_min[0] && ownx < sc.crop_max[0] && owny >= sc.crop_min[1] && owny < sc.crop_max[1];
+        float4 *own = &film[(size_t)(owny - sc.crop_min[1]) * cw + (ownx - sc.crop_min[0])];
+        float4 acc = (!SPILL && ownInside) ? *own : make_float4(0, 0, 0, 0);
+        for (uint32_t s = 0; s < pass.ns; ++s) {
+            uint32_t slot = s * pass.npix + p;
+            float2 pf = ps.pfilm[slot];
+            Float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+            int p0x = (int)__builtin_ceilf(dx - sc.filter_radius[0]), p0y = (int)__builtin_ceilf(dy - sc.filter_radius[1]);
+            int p1x = (int)__builtin_floorf(dx + sc.filter_radius[0]) + 1, p1y = (int)__builtin_floorf(dy + sc.filter_radius[1]) + 1;
+            p0x = p0x > sc.crop_min[0] ? p0x : sc.crop_min[0]; p0y = p0y > sc.crop_min[1] ? p0y : sc.crop_min[1];
+            p1x = p1x < sc.crop_max[0] ? p1x : sc.crop_max[0]; p1y = p1y < sc.crop_max[1] ? p1y : sc.crop_max[1];
+            if (SPILL && p0x == ownx && p1x == ownx + 1 && p0y == owny && p1y == owny + 1) continue;   // nothing but the own pixel
+            float4 L4 = ps.L[slot];
+            RGB L(L4.x, L4.y, L4.z);
+            if (L.HasNaNs()) L = RGB(0.f);
+            else if ((double)L.y() < -1e-5) L = RGB(0.f);
+            else if (__builtin_isinf(L.y())) L = RGB(0.f);
+            if (L.y() > sc.max_sample_luminance) L = L * (sc.max_sample_luminance / L.y());
+            Float invRx = 1 / sc.filter_radius[0], invRy = 1 / sc.filter_radius[1];
+            for (int y = p0y; y < p1y; ++y) {
+                Float fy = absf((y - dy) * invRy * W);
+                int iy = mni((int)__builtin_floorf(fy), W - 1);
+                for (int x = p0x; x < p1x; ++x) {
+                    bool isOwn = x == ownx && y == owny;
+                    if (isOwn == SPILL) continue;
+                    Float fx = absf((x - dx) * invRx * W);
+                    int ix = mni((int)__builtin_floorf(fx), W - 1);
+                    Float fw = sc.filter_table[iy * W + ix];
+                    RGB c = L * 1.f * fw;   // L * sampleWeight * filterWeight
+                    if (!SPILL) { acc.x += c.r; acc.y += c.g; acc.z += c.b; acc.w += fw; }
+                    else {
+                        float *o = reinterpret_cast<float *>(&film[(size_t)(y - sc.crop_min[1]) * cw + (x - sc.crop_min[0])]);
+                        atomicAdd(o, c.r); atomicAdd(o + 1, c.g); atomicAdd(o + 2, c.b); atomicAdd(o + 3, fw);
+                    }
+                }
+            }
+        }
+        if (!SPILL && ownInside) *own = acc;
+    }
+}
+
+// ---- stage-level kernels (parity tests): one lane per input record
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
+    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
+    TravStack st;
+    st.lds = &lds_stack[threadIdx.x];
+    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    TraceCounters tc = {0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
+        mi_ray r = rays[i];
+        V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
+        Float t;
+        uint32_t prim;
+        if (occluded) {
+            occluded[i] = Traverse<true, false>(sc, o, d, r.tmax, st, &t, &prim, &tc) ? 1 : 0;
+        } else {
+            mi_hit h;
+            h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
+            if (Traverse<false, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
+                V3 p0, p1, p2;
+                uint32_t tf;
+                LoadTri(sc, prim, &p0, &p1, &p2, &tf);
+                TriHit th;
+                TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
+                Isect is;
+                BuildIsect(sc, prim, p0, p1, p2, th, d, &is);
+                h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
+                h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
+            }
+            hits[i] = h;
+        }
+    }
+}
+__global__ void k_stage_sobol(DevScene sc, int px, int py, int n_samples, int n_dims, float *out, unsigned long long *index_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples * n_dims) return;
+    int s = i / n_dims, d = i % n_dims;
+    Sampler smp;
+    smp.Start(sc, px, py, (uint64_t)s);
+    out[i] = smp.SampleDimension(sc, d);
+    if (d == 0 && index_out) index_out[s] = smp.index;
+}
+__global__ void k_stage_export_rays(PathState ps, int64_t n, mi_ray *rays, float *pfilm) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 o = ps.ray_o[i], d = ps.ray_d[i];
+    mi_ray r;
+    r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.tmax = o.w; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z; r.time = 0;
+    rays[i] = r;
+    float2 pf = ps.pfilm[i];
+    pfilm[2 * i] = pf.x; pfilm[2 * i + 1] = pf.y;
+}
+__global__ void k_stage_export_L(PathState ps, int64_t n, float *L_rgb) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 L4 = ps.L[i];
+    RGB L(L4.x, L4.y, L4.z);   // same guards as the film path (integrator.cpp:294-315)
+    if (L.HasNaNs()) L = RGB(0.f);
+    else if ((double)L.y() < -1e-5) L = RGB(0.f);
+    else if (__builtin_isinf(L.y())) L = RGB(0.f);
+    L_rgb[3 * i] = L.r; L_rgb[3 * i + 1] = L.g; L_rgb[3 * i + 2] = L.b;
+}
+
+// ============================================================================ host side
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return -1; }
+#define HIP_TRY(expr)                                                                                    \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int numCUs = 256, gridBlocks = 1024;
+    DevScene sc;
+    bool haveScene = false;
+    std::vector<DevBuf> sceneBufs;
+    DevBuf film, counters, tiles;
+    int64_t filmPixels = 0;
+    // wavefront state
+    PathState ps;
+    std::vector<DevBuf> stateBufs;
+    uint32_t cap = 0;
+    uint32_t nkeys = 0;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int id; };
+    std::vector<Ev> evPool;
+    size_t evUsed = 0;
+    double msTotal[MI_K_COUNT] = {0};
+    uint64_t launches[MI_K_COUNT] = {0};
+};
+
+static int upload(mi_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    if (b.alloc(bytes)) return -1;
+    if (bytes && src) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// ---- BVH2 -> BVH4 collapse (host).  Every BVH4 child box is a reference node box.
+namespace {
+struct B4Builder {
+    const mi_bvh2_node *n2;
+    std::vector<BVH4Node> out;
+    int maxDepth = 0;
+    static float area(const mi_bvh2_node &n) {
+        float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+    static void setChild(BVH4Node &nd, int k, const float bmin[3], const float bmax[3], uint32_t ref) {
+        nd.lox[k] = bmin[0]; nd.loy[k] = bmin[1]; nd.loz[k] = bmin[2];
+        nd.hix[k] = bmax[0]; nd.hiy[k] = bmax[1]; nd.hiz[k] = bmax[2];
+        nd.child[k] = ref;
+    }
+    static void clearNode(BVH4Node &nd) {
+        std::memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 4; ++k) nd.child[k] = BVH4_EMPTY;
+    }
+    // a reference leaf with more than BVH4_LEAF_MAX triangles becomes a small chain of nodes with the leaf's box
+    uint32_t leafRef(const mi_bvh2_node &lf, uint32_t first, uint32_t count, int depth) {
+        if (count <= BVH4_LEAF_MAX) return BVH4_LEAF | ((count - 1) << 27) | first;
+        uint32_t idx = (uint32_t)out.size();
+        out.emplace_back();
+        clearNode(out[idx]);
+        maxDepth = std::max(maxDepth, depth + 1);
+        uint32_t per = (count + 3) / 4;
+        per = ((per + BVH4_LEAF_MAX - 1) / BVH4_LEAF_MAX) * BVH4_LEAF_MAX;
+        for (int k = 0; k < 4 && count > 0; ++k) {
+            uint32_t c = std::min(per, count);
+            uint32_t ref = leafRef(lf, first, c, depth + 1);
+            setChild(out[idx], k, lf.bmin, lf.bmax, ref);
+            first += c; count -= c;
+        }
+        return idx;
+    }
+    uint32_t build(uint32_t i2, int depth) {   // i2: interior reference node
+        uint32_t idx = (uint32_t)out.size();
+        out.emplace_back();
+        clearNode(out[idx]);
+        maxDepth = std::max(maxDepth, depth);
+        uint32_t kids[4];
+        int nk = 2;
+        kids[0] = i2 + 1; kids[1] = (uint32_t)n2[i2].offset;
+        while (nk < 4) {   // open the interior child with the largest surface area
+            int best = -1;
+            float bestA = -1;
+            for (int k = 0; k < nk; ++k)
+                if (n2[kids[k]].n_prims == 0) { float a = area(n2[kids[k]]); if (a > bestA) { bestA = a; best = k; } }
+            if (best < 0) break;
+            uint32_t o = kids[best];
+            for (int k = nk; k > best + 1; --k) kids[k] = kids[k - 1];
+            kids[best] = o + 1; kids[best + 1] = (uint32_t)n2[o].offset;
+            ++nk;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const mi_bvh2_node &c = n2[kids[k]];
+            uint32_t ref = c.n_prims > 0 ? leafRef(c, (uint32_t)c.offset, c.n_prims, depth) : build(kids[k], depth + 1);
+            setChild(out[idx], k, c.bmin, c.bmax, ref);
+        }
+        return idx;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char *mi_last_error(void) { return g_err.c_str(); }
+int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
+    if (!out) return fail("mi_ctx_create: null out");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail("mi_ctx_create: no HIP device available (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail("mi_ctx_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    mi_ctx *c = new mi_ctx;
+    c->device = device_ordinal;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    c->numCUs = prop.multiProcessorCount;
+    c->gridBlocks = ((c->numCUs * 6 + 7) / 8) * 8;   // 6 x 24 KiB LDS stacks per CU; multiple of 8 for the XCD mapping
+    std::memset(&c->sc, 0, sizeof(c->sc));
+    std::memset(&c->ps, 0, sizeof(c->ps));
+    if (c->counters.alloc(MI_CNT_COUNT * sizeof(uint64_t))) { delete c; return -1; }
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, MI_CNT_COUNT * sizeof(uint64_t), c->stream));
+    *out = c;
+    return 0;
+}
+
+void mi_ctx_destroy(mi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->sceneBufs) b.release();
+    for (auto &b : c->stateBufs) b.release();
+    c->film.release(); c->counters.release(); c->tiles.release();
+    for (auto &e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->ownStream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
+    if (!c || !d) return fail("mi_scene_upload: null argument");
+    if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
+    if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
+    if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto &b : c->sceneBufs) b.release();
+    c->sceneBufs.clear();
+    c->sceneBufs.resize(24);
+    int nb = 0;
+    auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
+    DevScene &sc = c->sc;
+    std::memset(&sc, 0, sizeof(sc));
+    // BVH4
+    B4Builder bb;
+    bb.n2 = d->bvh_nodes;
+    if (d->n_bvh_nodes) {
+        if (d->bvh_nodes[0].n_prims > 0) {   // single-leaf tree: wrap it in one BVH4 node
+            bb.out.emplace_back();
+            B4Builder::clearNode(bb.out[0]);
+            uint32_t ref = bb.leafRef(d->bvh_nodes[0], (uint32_t)d->bvh_nodes[0].offset, d->bvh_nodes[0].n_prims, 0);
+            B4Builder::setChild(bb.out[0], 0, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, ref);
+        } else
+            bb.build(0, 0);
+    }
+    { DevBuf &b = next(); if (upload(c, b, bb.out.data(), bb.out.size() * sizeof(BVH4Node))) return -1; sc.nodes = b.as<BVH4Node>(); }
+    sc.n_nodes = (uint32_t)bb.out.size();
+    sc.stack_need = 3 * (bb.maxDepth + 1) + 1;
+    // triangle records
+    std::vector<float4> tv(3 * (size_t)d->n_tris);
+    for (uint32_t t = 0; t < d->n_tris; ++t) {
+        const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        const float *p0 = d->P + 3 * (size_t)v[0], *p1 = d->P + 3 * (size_t)v[1], *p2 = d->P + 3 * (size_t)v[2];
+        // per-triangle rejection of shapes/triangle.cpp:300-315, evaluated with the reference's arithmetic
+        uint32_t mflags = d->meshes[d->tri_mesh[t]].flags;
+        float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+        if (d->UV && (mflags & MI_MESH_HAS_UV)) for (int k = 0; k < 3; ++k) { uv[k][0] = d->UV[2 * (size_t)v[k]]; uv[k][1] = d->UV[2 * (size_t)v[k] + 1]; }
+        float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]}, duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+        float dp02[3], dp12[3];
+        for (int k = 0; k < 3; ++k) { dp02[k] = p0[k] - p2[k]; dp12[k] = p1[k] - p2[k]; }
+        float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+        bool degenerateUV = std::abs(determinant) < 1e-8;
+        auto crossLen2 = [](const float a[3], const float b[3]) {
+            double ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
+            float cx = (float)((ay * bz) - (az * by)), cy = (float)((az * bx) - (ax * bz)), cz = (float)((ax * by) - (ay * bx));
+            return cx * cx + cy * cy + cz * cz;
+        };
+        bool reject = false;
+        bool needNg = degenerateUV;
+        if (!degenerateUV) {
+            float invdet = 1 / determinant, dpdu[3], dpdv[3];
+            for (int k = 0; k < 3; ++k) {
+                dpdu[k] = (duv12[1] * dp02[k] - duv02[1] * dp12[k]) * invdet;
+                dpdv[k] = (-duv12[0] * dp02[k] + duv02[0] * dp12[k]) * invdet;
+            }
+            if (crossLen2(dpdu, dpdv) == 0) needNg = true;
+        }
+        if (needNg) {
+            float a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = p2[k] - p0[k]; b[k] = p1[k] - p0[k]; }
+            if (crossLen2(a, b) == 0) reject = true;
+        }
+        uint32_t fl = reject ? TRI_FLAG_REJECT : 0u;
+        float flf;
+        std::memcpy(&flf, &fl, 4);
+        tv[3 * (size_t)t] = make_float4(p0[0], p0[1], p0[2], flf);
+        tv[3 * (size_t)t + 1] = make_float4(p1[0], p1[1], p1[2], 0);
+        tv[3 * (size_t)t + 2] = make_float4(p2[0], p2[1], p2[2], 0);
+    }
+    { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->tri_indices, 3 * (size_t)d->n_tris * 4)) return -1; sc.tri_indices = b.as<uint32_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->tri_mesh, (size_t)d->n_tris * 4)) return -1; sc.tri_mesh = b.as<uint32_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->tri_light, (size_t)d->n_tris * 4)) return -1; sc.tri_light = b.as<int32_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->meshes, (size_t)d->n_meshes * sizeof(mi_mesh))) return -1; sc.meshes = b.as<mi_mesh>(); }
+    if (d->N) { DevBuf &b = next(); if (upload(c, b, d->N, 3 * (size_t)d->n_verts * 4)) return -1; sc.N = b.as<float>(); }
+    if (d->UV) { DevBuf &b = next(); if (upload(c, b, d->UV, 2 * (size_t)d->n_verts * 4)) return -1; sc.UV = b.as<float>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->lights, (size_t)d->n_lights * sizeof(mi_light))) return -1; sc.lights = b.as<mi_light>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->light_func, (size_t)d->n_lights * 4)) return -1; sc.light_func = b.as<float>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->light_cdf, ((size_t)d->n_lights + 1) * 4)) return -1; sc.light_cdf = b.as<float>(); }
+    { DevBuf &b = next(); if (upload(c, b, d->film.filter_table, sizeof(d->film.filter_table))) return -1; sc.filter_table = b.as<float>(); }
+    std::vector<int32_t> inf;
+    for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == MI_LIGHT_INFINITE) inf.push_back((int32_t)i);
+    { DevBuf &b = next(); if (upload(c, b, inf.data(), inf.size() * 4)) return -1; sc.infinite_lights = b.as<int32_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, kSobolMatrices32, sizeof(kSobolMatrices32))) return -1; sc.sobol32 = b.as<uint32_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, kVdCSobolMatrices, sizeof(kVdCSobolMatrices))) return -1; sc.vdc = b.as<uint64_t>(); }
+    { DevBuf &b = next(); if (upload(c, b, kVdCSobolMatricesInv, sizeof(kVdCSobolMatricesInv))) return -1; sc.vdc_inv = b.as<uint64_t>(); }
+    sc.n_infinite = (uint32_t)inf.size();
+    sc.light_func_int = d->light_func_int;
+    sc.n_tris = d->n_tris; sc.n_lights = d->n_lights; sc.n_materials = d->n_materials;
+    sc.camera = d->camera;
+    for (int i = 0; i < 2; ++i) {
+        sc.full_res[i] = d->film.full_res[i]; sc.crop_min[i] = d->film.crop_min[i]; sc.crop_max[i] = d->film.crop_max[i];
+        sc.sample_min[i] = d->film.sample_min[i]; sc.sample_max[i] = d->film.sample_max[i];
+        sc.pixel_min[i] = d->integrator.pixel_min[i]; sc.pixel_max[i] = d->integrator.pixel_max[i];
+        sc.filter_radius[i] = d->film.filter_radius[i];
+    }
+    sc.max_sample_luminance = d->film.max_sample_luminance;
+    sc.max_depth = d->integrator.max_depth; sc.spp = d->integrator.spp;
+    sc.sobol_resolution = d->integrator.sobol_resolution; sc.sobol_log2_resolution = d->integrator.sobol_log2_resolution;
+    sc.rr_threshold = d->integrator.rr_threshold;
+    if (sc.sobol_log2_resolution > PBRT_AMD_SOBOL_NRES) return fail("mi_scene_upload: image too large for the Sobol' tables");
+    if (sc.sample_max[0] - sc.sample_min[0] > 65535 || sc.sample_max[1] - sc.sample_min[1] > 65535)
+        return fail("mi_scene_upload: sample bounds exceed 65535 pixels per axis");
+    // worst-case Sobol' dimensions: 5 camera + 8 per bounce (the reference LOG(FATAL)s past 1024, sobol.cpp:48-51)
+    if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
+    c->nkeys = d->n_materials + 2;
+    // film
+    c->filmPixels = (int64_t)std::max(0, sc.crop_max[0] - sc.crop_min[0]) * std::max(0, sc.crop_max[1] - sc.crop_min[1]);
+    if (c->film.alloc((size_t)c->filmPixels * sizeof(float4))) return -1;
+    HIP_TRY(hipMemsetAsync(c->film.p, 0, c->film.bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
+    // state depending on the scene is (re)allocated lazily by ensure_state()
+    for (auto &b : c->stateBufs) b.release();
+    c->stateBufs.clear();
+    c->cap = 0;
+    c->haveScene = true;
+    return 0;
+}
+
+}  // extern "C"
+
+static int ensure_state(mi_ctx *c, uint32_t cap) {
+    if (c->cap >= cap && !c->stateBufs.empty()) return 0;
+    for (auto &b : c->stateBufs) b.release();
+    c->stateBufs.clear();
+    c->stateBufs.resize(32);
+    int nb = 0;
+    PathState &ps = c->ps;
+    std::memset(&ps, 0, sizeof(ps));
+    auto A = [&](size_t bytes) -> void * { DevBuf &b = c->stateBufs[nb++]; return b.alloc(bytes) ? nullptr : b.p; };
+#define ALLOC(field, type, count) do { ps.field = (type *)A(sizeof(type) * (size_t)(count)); if (!ps.field) return -1; } while (0)
+    ALLOC(ray_o, float4, cap); ALLOC(ray_d, float4, cap); ALLOC(hit, uint2, cap); ALLOC(beta, float4, cap); ALLOC(L, float4, cap);
+    ALLOC(smp, uint4, cap); ALLOC(pfilm, float2, cap); ALLOC(pixel, uint32_t, cap);
+    ALLOC(sh_o, float4, cap); ALLOC(sh_d, float4, cap); ALLOC(sh_c, float4, cap);
+    ALLOC(mi_o, float4, cap); ALLOC(mi_d, float4, cap); ALLOC(mi_c, float4, cap);
+    ALLOC(keyrank, uint2, cap);
+    ALLOC(q_ext[0], uint32_t, cap); ALLOC(q_ext[1], uint32_t, cap); ALLOC(q_shadow, uint32_t, cap); ALLOC(q_mis, uint32_t, cap);
+    ALLOC(q_sorted, uint32_t, cap);
+    ALLOC(qcount, uint32_t, QC_COUNT);
+    ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys);
+    ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
+    ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * ps.spill_per_thread);
+#undef ALLOC
+    ps.counters = c->counters.as<unsigned long long>();
+    ps.cap = cap;
+    c->cap = cap;
+    return 0;
+}
+
+// ---- launch bookkeeping (per-kernel device time from HIP events on the ctx stream)
+static void tic(mi_ctx *c, int id) {
+    if (!c->timing) return;
+    if (c->evUsed == c->evPool.size()) {
+        mi_ctx::Ev e;
+        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        c->evPool.push_back(e);
+    }
+    c->evPool[c->evUsed].id = id;
+    (void)hipEventRecord(c->evPool[c->evUsed].a, c->stream);
+}
+static void toc(mi_ctx *c) {
+    if (!c->timing) return;
+    (void)hipEventRecord(c->evPool[c->evUsed].b, c->stream);
+    ++c->evUsed;
+}
+static void harvest(mi_ctx *c) {
+    for (size_t i = 0; i < c->evUsed; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->evPool[i].a, c->evPool[i].b) == hipSuccess) { c->msTotal[c->evPool[i].id] += ms; c->launches[c->evPool[i].id]++; }
+    }
+    c->evUsed = 0;
+}
+
+// One pass of the wavefront pipeline over the paths generated by `pass`.
+static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm) {
+    PathState &ps = c->ps;
+    const DevScene &sc = c->sc;
+    hipStream_t st = c->stream;
+    dim3 grid(c->gridBlocks), block(PT_BLOCK);
+    HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_COUNT * sizeof(uint32_t), st));
+    tic(c, MI_K_RAYGEN);
+    hipLaunchKernelGGL(k_raygen, grid, block, 0, st, sc, ps, pass, 0u);
+    toc(c);
+    uint32_t qin = 0;
+    int iter = 0;
+    while (true) {
+        uint32_t qout = qin ^ 1;
+        HIP_TRY(hipMemsetAsync(ps.keycount, 0, c->nkeys * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.qcount + qout, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.qcount + QC_SHADOW, 0, 2 * sizeof(uint32_t), st));   // shadow + mis
+        tic(c, MI_K_CLOSEST);
+        if (countWork) hipLaunchKernelGGL((k_closest<0, true>), grid, block, 0, st, sc, ps, qin);
+        else hipLaunchKernelGGL((k_closest<0, false>), grid, block, 0, st, sc, ps, qin);
+        toc(c);
+        tic(c, MI_K_SORT);
+        hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(64), 0, st, ps, c->nkeys);
+        hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin);
+        toc(c);
+        tic(c, MI_K_SHADE);
+        hipLaunchKernelGGL(k_shade, grid, block, 0, st, sc, ps, qout);
+        toc(c);
+        tic(c, MI_K_ANYHIT);
+        if (countWork) hipLaunchKernelGGL((k_anyhit<true>), grid, block, 0, st, sc, ps);
+        else hipLaunchKernelGGL((k_anyhit<false>), grid, block, 0, st, sc, ps);
+        toc(c);
+        tic(c, MI_K_MIS_CLOSEST);
+        if (countWork) hipLaunchKernelGGL((k_closest<1, true>), grid, block, 0, st, sc, ps, qin);
+        else hipLaunchKernelGGL((k_closest<1, false>), grid, block, 0, st, sc, ps, qin);
+        toc(c);
+        qin = qout;
+        ++iter;
+        if (iter > sc.max_depth) {
+            // every ordinary path is done after max_depth+1 segments; only chains of null-BSDF surfaces
+            // (which do not count as bounces) can still be alive -- check, and keep going if so
+            uint32_t left = 0;
+            HIP_TRY(hipMemcpyAsync(&left, ps.qcount + qin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (left == 0 || iter > sc.max_depth + 4096) break;
+        }
+    }
+    if (toFilm) {
+        tic(c, MI_K_FILM);
+        hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->film.as<float4>());
+        hipLaunchKernelGGL((k_film<true>), grid, block, 0, st, sc, ps, pass, c->film.as<float4>());
+        toc(c);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int mi_render(mi_ctx *c, const mi_render_params *rp) {
+    if (!c || !rp) return fail("mi_render: null argument");
+    if (!c->haveScene) return fail("mi_render: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    const DevScene &sc = c->sc;
+    int world = std::max(1, rp->world), rank = rp->rank;
+    if (rank < 0 || rank >= world) return fail("mi_render: rank out of range");
+    int s0 = std::max(0, rp->spp_begin), s1 = rp->spp_end < 0 ? sc.spp : std::min(rp->spp_end, sc.spp);
+    if (s1 <= s0) return 0;
+    // tile grid of SamplerIntegrator::Render (integrator.cpp:233-237); tile t belongs to rank t % world
+    const int tileSize = 16;
+    int ex = sc.sample_max[0] - sc.sample_min[0], ey = sc.sample_max[1] - sc.sample_min[1];
+    int nTx = (ex + tileSize - 1) / tileSize, nTy = (ey + tileSize - 1) / tileSize;
+    std::vector<uint32_t> tiles;
+    for (int t = rank; t < nTx * nTy; t += world) tiles.push_back((uint32_t)t);
+    if (tiles.empty()) return 0;
+    if (upload(c, c->tiles, tiles.data(), tiles.size() * sizeof(uint32_t))) return -1;
+    uint64_t npixOwned = (uint64_t)tiles.size() * 256;
+    uint32_t cap = rp->max_paths_in_flight > 0 ? (uint32_t)rp->max_paths_in_flight : (1u << 23);
+    cap = std::max(cap, 256u * 64u);
+    uint64_t want = std::min<uint64_t>(cap, npixOwned * (uint64_t)(s1 - s0));
+    if (ensure_state(c, (uint32_t)std::max<uint64_t>(want, 256 * 64))) return -1;
+    cap = c->cap;
+    // chunking: whole pixel range x as many samples as fit, else pixel sub-ranges x 1 sample
+    uint32_t pixPerPass = (uint32_t)std::min<uint64_t>(npixOwned, cap & ~255u);
+    uint32_t sppPerPass = pixPerPass == npixOwned ? std::max<uint32_t>(1, cap / (uint32_t)npixOwned) : 1;
+    for (uint64_t p0 = 0; p0 < npixOwned; p0 += pixPerPass) {
+        uint32_t np = (uint32_t)std::min<uint64_t>(pixPerPass, npixOwned - p0);
+        for (int s = s0; s < s1; s += (int)sppPerPass) {
+            PassInfo pass;
+            pass.tiles = c->tiles.as<uint32_t>();
+            pass.n_tiles_x = (uint32_t)nTx;
+            pass.pix0 = (uint32_t)p0; pass.npix = np;
+            pass.s0 = (uint32_t)s; pass.ns = (uint32_t)std::min<int>((int)sppPerPass, s1 - s);
+            pass.list_xy = nullptr; pass.list_s = nullptr;
+            if (run_pass(c, pass, rp->count_work != 0, true)) return -1;
+        }
+    }
+    return 0;
+}
+
+int mi_sync(mi_ctx *c) {
+    if (!c) return fail("mi_sync: null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harvest(c);
+    return 0;
+}
+
+int mi_film_clear(mi_ctx *c) {
+    if (!c || !c->haveScene) return fail("mi_film_clear: no scene");
+    HIP_TRY(hipMemsetAsync(c->film.p, 0, c->film.bytes, c->stream));
+    return 0;
+}
+int mi_film_download(mi_ctx *c, float *rgbw) {
+    if (!c || !c->haveScene || !rgbw) return fail("mi_film_download: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(rgbw, c->film.p, (size_t)c->filmPixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harvest(c);
+    return 0;
+}
+void *mi_film_device_ptr(mi_ctx *c) { return c ? c->film.p : nullptr; }
+int64_t mi_film_pixel_count(mi_ctx *c) { return c ? c->filmPixels : 0; }
+
+int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
+    if (!c || !out) return fail("mi_counters: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, c->counters.p, MI_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int mi_counters_reset(mi_ctx *c) {
+    if (!c) return fail("mi_counters_reset: null ctx");
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, MI_CNT_COUNT * sizeof(uint64_t), c->stream));
+    return 0;
+}
+int mi_timing_enable(mi_ctx *c, int on) {
+    if (!c) return fail("mi_timing_enable: null ctx");
+    c->timing = on != 0;
+    for (int i = 0; i < MI_K_COUNT; ++i) { c->msTotal[i] = 0; c->launches[i] = 0; }
+    return 0;
+}
+int mi_timing_get(mi_ctx *c, double ms_total[MI_K_COUNT], uint64_t launches[MI_K_COUNT]) {
+    if (!c) return fail("mi_timing_get: null ctx");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harvest(c);
+    for (int i = 0; i < MI_K_COUNT; ++i) { ms_total[i] = c->msTotal[i]; launches[i] = c->launches[i]; }
+    return 0;
+}
+
+// ---- stage-level entry points
+static int stage_common(mi_ctx *c) {
+    if (!c || !c->haveScene) return fail("no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_state(c, std::max<uint32_t>(c->cap, 256 * 64));
+}
+
+int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
+    if (stage_common(c)) return -1;
+    if (n <= 0) return 0;
+    DevBuf dr, dh;
+    if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_hit))) return -1;
+    hipLaunchKernelGGL(k_stage_intersect, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
+    HIP_TRY(hipMemcpyAsync(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dr.release(); dh.release();
+    return 0;
+}
+int mi_intersect_p(mi_ctx *c, const mi_ray *rays, int64_t n, uint8_t *occluded) {
+    if (stage_common(c)) return -1;
+    if (n <= 0) return 0;
+    DevBuf dr, dh;
+    if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n)) return -1;
+    hipLaunchKernelGGL(k_stage_intersect, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
+    HIP_TRY(hipMemcpyAsync(occluded, dh.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dr.release(); dh.release();
+    return 0;
+}
+int mi_sobol(mi_ctx *c, int px, int py, int n_samples, int n_dims, float *out, uint64_t *index_out) {
+    if (stage_common(c)) return -1;
+    int64_t n = (int64_t)n_samples * n_dims;
+    if (n <= 0) return 0;
+    DevBuf d_out, d_idx;
+    if (d_out.alloc((size_t)n * 4) || d_idx.alloc((size_t)n_samples * 8)) return -1;
+    hipLaunchKernelGGL(k_stage_sobol, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, px, py, n_samples, n_dims, d_out.as<float>(), d_idx.as<unsigned long long>());
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (index_out) HIP_TRY(hipMemcpyAsync(index_out, d_idx.p, (size_t)n_samples * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d_out.release(); d_idx.release();
+    return 0;
+}
+static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, int64_t off, uint32_t cnt, bool trace,
+                     DevBuf &dxy, DevBuf &ds) {
+    (void)n;
+    if (upload(c, dxy, pixels_xy + 2 * off, (size_t)cnt * 8) || upload(c, ds, sample_num + off, (size_t)cnt * 4)) return -1;
+    PassInfo pass;
+    std::memset(&pass, 0, sizeof(pass));
+    pass.npix = cnt; pass.ns = 1;
+    pass.list_xy = dxy.as<int32_t>(); pass.list_s = ds.as<int32_t>();
+    if (trace) return run_pass(c, pass, false, false);
+    HIP_TRY(hipMemsetAsync(c->ps.qcount, 0, QC_COUNT * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_raygen, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
+    return 0;
+}
+int mi_camera_rays(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, mi_ray *rays, float *p_film) {
+    if (stage_common(c)) return -1;
+    DevBuf dxy, ds, dr, dp;
+    for (int64_t off = 0; off < n; off += c->cap) {
+        uint32_t cnt = (uint32_t)std::min<int64_t>(c->cap, n - off);
+        if (list_pass(c, pixels_xy, sample_num, n, off, cnt, false, dxy, ds)) return -1;
+        if (dr.alloc((size_t)cnt * sizeof(mi_ray)) || dp.alloc((size_t)cnt * 8)) return -1;
+        hipLaunchKernelGGL(k_stage_export_rays, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->ps, (int64_t)cnt, dr.as<mi_ray>(), dp.as<float>());
+        HIP_TRY(hipMemcpyAsync(rays + off, dr.p, (size_t)cnt * sizeof(mi_ray), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(p_film + 2 * off, dp.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    dxy.release(); ds.release(); dr.release(); dp.release();
+    return 0;
+}
+int mi_li(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *L_rgb) {
+    if (stage_common(c)) return -1;
+    DevBuf dxy, ds, dl;
+    for (int64_t off = 0; off < n; off += c->cap) {
+        uint32_t cnt = (uint32_t)std::min<int64_t>(c->cap, n - off);
+        if (list_pass(c, pixels_xy, sample_num, n, off, cnt, true, dxy, ds)) return -1;
+        if (dl.alloc((size_t)cnt * 12)) return -1;
+        hipLaunchKernelGGL(k_stage_export_L, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->ps, (int64_t)cnt, dl.as<float>());
+        HIP_TRY(hipMemcpyAsync(L_rgb + 3 * off, dl.p, (size_t)cnt * 12, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    dxy.release(); ds.release(); dl.release();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// Device scene layout (HBM) + Sobol' sampler + watertight triangle test + BVH4 traversal.
+#pragma once
+#include "pbrt_amd.h"
+#include "pt_math.h"
+
+// ------------------------------------------------------------------ HBM layout
+// BVH4 node: exactly one 128-byte cache line, fetched by a lane as 8 x global_load_dwordx4.
+// Child bounds are SoA so a lane tests 4 boxes from 6 float4 registers.  Built by collapsing
+// the reference's own BVH2 (LinearBVHNode[], accelerators/bvh.cpp:95-104): every BVH4 child box is
+// a BVH2 node box, so the set of triangles whose ancestors' boxes a ray passes is a superset of
+// what BVHAccel::Intersect visits and the closest hit is identical (SURVEY.md s.7 "BVH topology").
+struct __attribute__((aligned(128))) BVH4Node {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t child[4];   // interior: node index | leaf: BVH4_LEAF | (count-1) << 27 | first triangle | BVH4_EMPTY
+    uint32_t pad[4];
+};
+#define BVH4_LEAF 0x80000000u
+#define BVH4_EMPTY 0xFFFFFFFFu
+#define BVH4_LEAF_MAX 16          /* triangles per leaf reference; bigger reference leaves are chained */
+#define BVH4_FIRST_MASK 0x07ffffffu
+
+// Triangle record: 3 x float4 = 48 B, pre-gathered world-space vertices in BVH primitive order
+// (removes the reference's Primitive -> Shape -> mesh -> index -> vertex pointer chain).
+// v0.w carries flag bits (as uint): bit0 = "always rejected": the triangle is degenerate in the sense of
+// shapes/triangle.cpp:308-315 (decided per triangle, independent of the ray).
+#define TRI_FLAG_REJECT 1u
+
+struct DevScene {
+    const BVH4Node *nodes;
+    const float4 *tri_verts;        // 3 per triangle
+    const uint32_t *tri_indices;    // 3 per triangle (vertex ids for N / UV)
+    const uint32_t *tri_mesh;
+    const int32_t *tri_light;
+    const mi_mesh *meshes;
+    const float *N;                 // may be null
+    const float *UV;                // may be null
+    const mi_material *materials;
+    const mi_light *lights;
+    const float *light_func, *light_cdf;
+    const float *filter_table;
+    const int32_t *infinite_lights; // indices of MI_LIGHT_INFINITE lights
+    const uint32_t *sobol32;        // [1024][52] generator matrices (sobol_tables.inc), L2 resident
+    const uint64_t *vdc, *vdc_inv;  // [26][52] pixel <-> index maps
+    float light_func_int;
+    uint32_t n_tris, n_nodes, n_lights, n_materials, n_infinite;
+    int32_t stack_need;             // 3 * BVH4 depth + 1
+    mi_camera camera;
+    // film / sampler / integrator scalars
+    int32_t full_res[2], crop_min[2], crop_max[2], sample_min[2], sample_max[2], pixel_min[2], pixel_max[2];
+    float filter_radius[2], max_sample_luminance;
+    int32_t max_depth, spp, sobol_resolution, sobol_log2_resolution;
+    float rr_threshold;
+};
+
+// ------------------------------------------------------------------ Sobol' (integer, bit exact)
+#ifndef PBRT_AMD_SOBOL_NDIM
+#define PBRT_AMD_SOBOL_NDIM 1024
+#define PBRT_AMD_SOBOL_NCOL 52
+#define PBRT_AMD_SOBOL_NRES 26
+#endif
+
+PT_DEV uint64_t SobolIntervalToIndex(const DevScene &sc, uint32_t m, uint64_t frame, int px, int py) {   // core/lowdiscrepancy.h:229-249
+    if (m == 0) return 0;
+    const uint32_t m2 = m << 1;
+    uint64_t index = uint64_t(frame) << m2;
+    uint64_t delta = 0;
+    for (int c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= sc.vdc[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= sc.vdc_inv[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    return index;
+}
+PT_DEV Float SobolSampleFloat(const DevScene &sc, uint64_t a, int dimension) {   // core/lowdiscrepancy.h:259-274 (scramble 0)
+    uint32_t v = 0;
+    for (int i = dimension * PBRT_AMD_SOBOL_NCOL; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= sc.sobol32[i];
+    return mn(v * 0x1p-32f, PT_ONE_MINUS_EPS);
+}
+
+struct Sampler {   // GlobalSampler/SobolSampler state per path (core/sampler.cpp:136-195, samplers/sobol.cpp:42-59)
+    uint64_t index;
+    int dimension;
+    int px, py;
+    PT_DEV void Start(const DevScene &sc, int x, int y, uint64_t sampleNum) {
+        px = x; py = y; dimension = 0;
+        index = SobolIntervalToIndex(sc, sc.sobol_log2_resolution, sampleNum, x - sc.sample_min[0], y - sc.sample_min[1]);
+    }
+    PT_DEV Float SampleDimension(const DevScene &sc, int dim) const {   // sobol.cpp:47-59
+        if (dim >= PBRT_AMD_SOBOL_NDIM) dim = PBRT_AMD_SOBOL_NDIM - 1;   // the reference LOG(FATAL)s here; host rejects such depths
+        Float s = SobolSampleFloat(sc, index, dim);
+        if (dim == 0 || dim == 1) {
+            s = s * sc.sobol_resolution + sc.sample_min[dim];
+            s = clampf(s - (dim == 0 ? px : py), (Float)0, PT_ONE_MINUS_EPS);
+        }
+        return s;
+    }
+    PT_DEV Float Get1D(const DevScene &sc) { return SampleDimension(sc, dimension++); }
+    PT_DEV void Get2D(const DevScene &sc, Float *u0, Float *u1) {
+        *u0 = SampleDimension(sc, dimension);
+        *u1 = SampleDimension(sc, dimension + 1);
+        dimension += 2;
+    }
+};
+
+// ------------------------------------------------------------------ triangle
+struct TriHit { Float t, b0, b1, b2; };
+
+// Watertight ray-triangle test: Triangle::Intersect shapes/triangle.cpp:188-291 (through the
+// conservative t > delta_t test).  The per-triangle degeneracy rejection of :308-315 is the
+// TRI_FLAG_REJECT bit.  tMax is the ray's current tMax (accept t == tMax: :258-261).
+PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, const V3 &dir, Float tMax, TriHit *h) {
+    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    // kz = MaxDimension(Abs(d)); kx = kz+1, ky = kx+1 (mod 3)
+    Float ax = absf(dir.x), ay = absf(dir.y), az = absf(dir.z);
+    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    V3 d;
+    if (kz == 0) {   // (kx,ky,kz) = (1,2,0)
+        d = V3(dir.y, dir.z, dir.x);
+        p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x);
+    } else if (kz == 1) {   // (2,0,1)
+        d = V3(dir.z, dir.x, dir.y);
+        p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y);
+    } else {
+        d = dir;
+    }
+    Float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    Float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    Float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    Float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {   // :234-245 fp64 re-evaluation at triangle edges
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    Float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    Float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
+    Float invDet = 1 / det;
+    Float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    Float t = tScaled * invDet;
+    Float maxZt = MaxComponent(Abs(V3(p0t.z, p1t.z, p2t.z)));
+    Float deltaZ = gamma_n(3) * maxZt;
+    Float maxXt = MaxComponent(Abs(V3(p0t.x, p1t.x, p2t.x)));
+    Float maxYt = MaxComponent(Abs(V3(p0t.y, p1t.y, p2t.y)));
+    Float deltaX = gamma_n(5) * (maxXt + maxZt);
+    Float deltaY = gamma_n(5) * (maxYt + maxZt);
+    Float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    Float maxE = MaxComponent(Abs(V3(e0, e1, e2)));
+    Float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absf(invDet);
+    if (t <= deltaT) return false;
+    h->t = t; h->b0 = b0; h->b1 = b1; h->b2 = b2;
+    return true;
+}
+
+PT_DEV void LoadTri(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, uint32_t *flags) {
+    const float4 *tv = sc.tri_verts + 3 * (size_t)prim;
+    float4 a = tv[0], b = tv[1], c = tv[2];
+    *p0 = V3(a.x, a.y, a.z); *p1 = V3(b.x, b.y, b.z); *p2 = V3(c.x, c.y, c.z);
+    *flags = __float_as_uint(a.w);
+}
+
+// ------------------------------------------------------------------ BVH4 traversal
+struct TraceCounters { uint32_t nodes, tris; };
+
+// Robust slab test of Bounds3::IntersectP(ray, invDir, dirIsNeg) core/geometry.h:1412-1438 for one
+// child box; returns entry distance for ordering.
+PT_DEV bool SlabTest(Float lox, Float loy, Float loz, Float hix, Float hiy, Float hiz, const V3 &o, const V3 &invDir,
+                     bool negx, bool negy, bool negz, Float rayTMax, Float *tEntry) {
+    const Float widen = 1 + 2 * gamma_n(3);
+    Float tMin = ((negx ? hix : lox) - o.x) * invDir.x;
+    Float tMax = ((negx ? lox : hix) - o.x) * invDir.x;
+    Float tyMin = ((negy ? hiy : loy) - o.y) * invDir.y;
+    Float tyMax = ((negy ? loy : hiy) - o.y) * invDir.y;
+    tMax *= widen;
+    tyMax *= widen;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    Float tzMin = ((negz ? hiz : loz) - o.z) * invDir.z;
+    Float tzMax = ((negz ? loz : hiz) - o.z) * invDir.z;
+    tzMax *= widen;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    *tEntry = tMin;
+    return (tMin < rayTMax) && (tMax > 0);
+}
+
+// Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][lane] layout: a
+// lane's entries sit in one bank column, so pushes/pops of a whole wave are conflict free whatever
+// the per-lane depth), deeper entries spill to a per-thread slice of an HBM buffer (rare).
+#define PT_LDS_STACK 24
+#define PT_BLOCK 256
+struct TravStack {
+    uint32_t *lds;        // &stack[0][threadIdx.x]
+    uint32_t *spill;      // per-thread spill slice
+    int sp;
+    PT_DEV void push(uint32_t v) {
+        if (sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = v; else spill[sp - PT_LDS_STACK] = v;
+        ++sp;
+    }
+    PT_DEV uint32_t pop() {
+        --sp;
+        return (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK];
+    }
+};
+
+// Closest hit (ANY == false; BVHAccel::Intersect bvh.cpp:662-700) or any hit (ANY == true;
+// BVHAccel::IntersectP :702-738).  Returns hit/occluded; *tHit,*primHit valid for closest hits.
+template <bool ANY, bool COUNT>
+PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit,
+                     TraceCounters *cnt) {
+    if (sc.n_nodes == 0) return false;
+    V3 invDir(1 / d.x, 1 / d.y, 1 / d.z);
+    bool negx = invDir.x < 0, negy = invDir.y < 0, negz = invDir.z < 0;
+    bool hit = false;
+    st.sp = 0;
+    uint32_t cur = 0;   // root is always an interior BVH4 node
+    while (true) {
+        if (!(cur & BVH4_LEAF)) {
+            const BVH4Node *node = sc.nodes + cur;
+            const float4 *n4 = reinterpret_cast<const float4 *>(node);
+            float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5];
+            uint4 ch = *reinterpret_cast<const uint4 *>(node->child);
+            if (COUNT) ++cnt->nodes;
+            Float t0, t1, t2, t3;
+            bool h0 = ch.x != BVH4_EMPTY && SlabTest(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, o, invDir, negx, negy, negz, tMax, &t0);
+            bool h1 = ch.y != BVH4_EMPTY && SlabTest(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, o, invDir, negx, negy, negz, tMax, &t1);
+            bool h2 = ch.z != BVH4_EMPTY && SlabTest(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, o, invDir, negx, negy, negz, tMax, &t2);
+            bool h3 = ch.w != BVH4_EMPTY && SlabTest(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, o, invDir, negx, negy, negz, tMax, &t3);
+            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+            if (!h0) t0 = PT_INFINITY;
+            if (!h1) t1 = PT_INFINITY;
+            if (!h2) t2 = PT_INFINITY;
+            if (!h3) t3 = PT_INFINITY;
+            // sort the (up to four) hits by entry distance: 5-comparator network on (t, c)
+#define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
+            PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+            int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            if (nh == 0) {
+                if (st.sp == 0) break;
+                cur = st.pop();
+                continue;
+            }
+            // far ones first onto the stack, nearest becomes current
+            if (nh > 3) st.push(c3);
+            if (nh > 2) st.push(c2);
+            if (nh > 1) st.push(c1);
+            cur = c0;
+        } else {
+            uint32_t first = cur & BVH4_FIRST_MASK, n = ((cur >> 27) & 0xfu) + 1;
+            for (uint32_t i = 0; i < n; ++i) {
+                V3 p0, p1, p2;
+                uint32_t flags;
+                LoadTri(sc, first + i, &p0, &p1, &p2, &flags);
+                if (COUNT) ++cnt->tris;
+                TriHit th;
+                if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, o, d, tMax, &th)) {
+                    if (ANY) return true;
+                    hit = true;
+                    tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
+                    *tHit = th.t;
+                    *primHit = first + i;
+                }
+            }
+            if (st.sp == 0) break;
+            cur = st.pop();
+        }
+    }
+    return hit;
+}

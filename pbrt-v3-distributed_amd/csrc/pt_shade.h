@@ -1,0 +1,590 @@
+// Surface interaction, BSDF / BxDFs, microfacet distributions and lights for the shading kernels.
+// One lane = one path vertex; a wave is sorted so that its lanes share a material, which makes
+// every switch on mi_bxdf::type below wave-uniform (no divergence) and lets the lobe parameters
+// come through scalar loads.  Each routine cites the reference code it reproduces.
+#pragma once
+#include "pt_scene.h"
+
+// ------------------------------------------------------------------ SurfaceInteraction (core/interaction.h:94-157)
+struct Isect {
+    V3 p, pError, wo, n;   // n = oriented geometric normal
+    V3 ns, dpdus;          // shading.n, shading.dpdu
+    uint32_t prim;
+};
+
+PT_DEV void TriUVs(const DevScene &sc, uint32_t prim, uint32_t meshFlags, Float uv[3][2]) {   // Triangle::GetUVs shapes/triangle.h:98-108
+    if (sc.UV && (meshFlags & MI_MESH_HAS_UV)) {
+        const uint32_t *v = sc.tri_indices + 3 * (size_t)prim;
+        for (int i = 0; i < 3; ++i) { uv[i][0] = sc.UV[2 * (size_t)v[i]]; uv[i][1] = sc.UV[2 * (size_t)v[i] + 1]; }
+    } else {
+        uv[0][0] = 0; uv[0][1] = 0; uv[1][0] = 1; uv[1][1] = 0; uv[2][0] = 1; uv[2][1] = 1;
+    }
+}
+
+// Second half of Triangle::Intersect (shapes/triangle.cpp:293-421): build the interaction from the
+// barycentrics the traversal found.  rayD = direction of the ray that hit.
+PT_DEV void BuildIsect(const DevScene &sc, uint32_t prim, const V3 &p0, const V3 &p1, const V3 &p2, const TriHit &th,
+                       const V3 &rayD, Isect *is) {
+    uint32_t mflags = sc.meshes[sc.tri_mesh[prim]].flags;
+    Float uv[3][2];
+    TriUVs(sc, prim, mflags, uv);
+    Float duv02x = uv[0][0] - uv[2][0], duv02y = uv[0][1] - uv[2][1], duv12x = uv[1][0] - uv[2][0], duv12y = uv[1][1] - uv[2][1];
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    Float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerateUV = absf(determinant) < 1e-8;
+    V3 dpdu, dpdv;
+    if (!degenerateUV) {
+        Float invdet = 1 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * invdet;
+        dpdv = (-duv12x * dp02 + duv02x * dp12) * invdet;
+    }
+    if (degenerateUV || Cross(dpdu, dpdv).LengthSquared() == 0) {
+        V3 ng = Cross(p2 - p0, p1 - p0);   // non-zero: TRI_FLAG_REJECT triangles never get here
+        CoordinateSystem(Normalize(ng), &dpdu, &dpdv);
+    }
+    Float b0 = th.b0, b1 = th.b1, b2 = th.b2;
+    Float xAbsSum = (absf(b0 * p0.x) + absf(b1 * p1.x) + absf(b2 * p2.x));
+    Float yAbsSum = (absf(b0 * p0.y) + absf(b1 * p1.y) + absf(b2 * p2.y));
+    Float zAbsSum = (absf(b0 * p0.z) + absf(b1 * p1.z) + absf(b2 * p2.z));
+    is->pError = gamma_n(7) * V3(xAbsSum, yAbsSum, zAbsSum);
+    is->p = b0 * p0 + b1 * p1 + b2 * p2;
+    is->wo = Normalize(-rayD);   // Interaction ctor: wo(Normalize(wo)), core/interaction.h:60
+    is->prim = prim;
+    is->n = is->ns = Normalize(Cross(dp02, dp12));   // triangle.cpp:346
+    is->dpdus = dpdu;
+    bool flip = (mflags & MI_MESH_FLIP) != 0;
+    if (sc.N && (mflags & MI_MESH_HAS_N)) {   // :347-415
+        const uint32_t *v = sc.tri_indices + 3 * (size_t)prim;
+        V3 n0 = v3(sc.N + 3 * (size_t)v[0]), n1 = v3(sc.N + 3 * (size_t)v[1]), n2 = v3(sc.N + 3 * (size_t)v[2]);
+        V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
+        if (ns.LengthSquared() > 0) ns = Normalize(ns); else ns = is->n;
+        V3 ss = Normalize(dpdu);
+        V3 ts = Cross(ss, ns);
+        if (ts.LengthSquared() > 0.f) { ts = Normalize(ts); ss = Cross(ts, ns); }
+        else CoordinateSystem(ns, &ss, &ts);
+        V3 sn = Normalize(Cross(ss, ts));   // SetShadingGeometry core/interaction.cpp:73-92 (authoritative)
+        if (flip) sn = -sn;
+        is->n = Faceforward(is->n, sn);
+        is->ns = sn;
+        is->dpdus = ss;
+        is->n = Faceforward(is->n, is->ns);   // triangle.cpp:417-419
+    } else if (flip) {
+        is->n = is->ns = -is->n;              // :420-421
+    }
+}
+
+// ------------------------------------------------------------------ BxDFs (core/reflection.{h,cpp})
+#define BSDF_REFLECTION 1
+#define BSDF_TRANSMISSION 2
+#define BSDF_DIFFUSE 4
+#define BSDF_GLOSSY 8
+#define BSDF_SPECULAR 16
+#define BSDF_ALL 31
+
+PT_DEV Float CosTheta(const V3 &w) { return w.z; }
+PT_DEV Float Cos2Theta(const V3 &w) { return w.z * w.z; }
+PT_DEV Float AbsCosTheta(const V3 &w) { return absf(w.z); }
+PT_DEV Float Sin2Theta(const V3 &w) { return mx((Float)0, (Float)1 - Cos2Theta(w)); }
+PT_DEV Float SinTheta(const V3 &w) { return sqrtf_(Sin2Theta(w)); }
+PT_DEV Float TanTheta(const V3 &w) { return SinTheta(w) / CosTheta(w); }
+PT_DEV Float Tan2Theta(const V3 &w) { return Sin2Theta(w) / Cos2Theta(w); }
+PT_DEV Float CosPhi(const V3 &w) { Float s = SinTheta(w); return (s == 0) ? 1 : clampf(w.x / s, -1, 1); }
+PT_DEV Float SinPhi(const V3 &w) { Float s = SinTheta(w); return (s == 0) ? 0 : clampf(w.y / s, -1, 1); }
+PT_DEV Float Cos2Phi(const V3 &w) { return CosPhi(w) * CosPhi(w); }
+PT_DEV Float Sin2Phi(const V3 &w) { return SinPhi(w) * SinPhi(w); }
+PT_DEV V3 Reflect(const V3 &wo, const V3 &n) { return -wo + 2 * Dot(wo, n) * n; }   // reflection.h:91-93
+PT_DEV bool Refract(const V3 &wi, const V3 &n, Float eta, V3 *wt) {                 // reflection.h:95-107
+    Float cosThetaI = Dot(n, wi);
+    Float sin2ThetaI = mx(Float(0), Float(1 - cosThetaI * cosThetaI));
+    Float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    Float cosThetaT = sqrtf_(1 - sin2ThetaT);
+    *wt = eta * -wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+PT_DEV bool SameHemisphere(const V3 &w, const V3 &wp) { return w.z * wp.z > 0; }
+
+PT_DEV Float FrDielectric(Float cosThetaI, Float etaI, Float etaT) {   // reflection.cpp:47-68
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { Float t = etaI; etaI = etaT; etaT = t; cosThetaI = absf(cosThetaI); }
+    Float sinThetaI = sqrtf_(mx((Float)0, 1 - cosThetaI * cosThetaI));
+    Float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    Float cosThetaT = sqrtf_(mx((Float)0, 1 - sinThetaT * sinThetaT));
+    Float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    Float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+PT_DEV RGB FrConductor(Float cosThetaI, const RGB &etai, const RGB &etat, const RGB &k) {   // reflection.cpp:71-94
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    RGB eta = etat / etai, etak = k / etai;
+    Float cosThetaI2 = cosThetaI * cosThetaI;
+    Float sinThetaI2 = (Float)(1. - (double)cosThetaI2);   // `1. - cosThetaI2` is a double expression there
+    RGB eta2 = eta * eta, etak2 = etak * etak;
+    RGB t0 = eta2 - etak2 - RGB(sinThetaI2);
+    RGB a2plusb2 = SqrtRGB(t0 * t0 + 4 * eta2 * etak2);
+    RGB t1 = a2plusb2 + RGB(cosThetaI2);
+    RGB a = SqrtRGB(0.5f * (a2plusb2 + t0));
+    RGB t2 = (Float)2 * cosThetaI * a;
+    RGB Rs = (t1 - t2) / (t1 + t2);
+    RGB t3 = cosThetaI2 * a2plusb2 + RGB(sinThetaI2 * sinThetaI2);
+    RGB t4 = t2 * sinThetaI2;
+    RGB Rp = Rs * (t3 - t4) / (t3 + t4);
+    return 0.5f * (Rp + Rs);   // `0.5 * Spectrum` converts 0.5 to Float
+}
+PT_DEV RGB FresnelEvaluate(const mi_bxdf &b, Float cosThetaI) {   // reflection.cpp:118-130, FresnelNoOp
+    if (b.fresnel == MI_FRESNEL_DIELECTRIC) return RGB(FrDielectric(cosThetaI, b.etaA, b.etaB));
+    if (b.fresnel == MI_FRESNEL_CONDUCTOR) return FrConductor(absf(cosThetaI), RGB(1.f), rgb3(b.eta_c), rgb3(b.k_c));
+    return RGB(1.f);
+}
+
+// MicrofacetDistribution (core/microfacet.{h,cpp}): TrowbridgeReitz (all stock materials) / Beckmann D, Lambda
+struct Distrib {
+    Float ax, ay;
+    int beckmann;
+    PT_DEV Float D(const V3 &wh) const {   // microfacet.cpp:146-163
+        Float tan2Theta = Tan2Theta(wh);
+        if (__builtin_isinf(tan2Theta)) return 0.;
+        const Float cos4Theta = Cos2Theta(wh) * Cos2Theta(wh);
+        if (beckmann)
+            return expf_(-tan2Theta * (Cos2Phi(wh) / (ax * ax) + Sin2Phi(wh) / (ay * ay))) / (PT_PI * ax * ay * cos4Theta);
+        Float e = (Cos2Phi(wh) / (ax * ax) + Sin2Phi(wh) / (ay * ay)) * tan2Theta;
+        return 1 / (PT_PI * ax * ay * cos4Theta * (1 + e) * (1 + e));
+    }
+    PT_DEV Float Lambda(const V3 &w) const {   // microfacet.cpp:165-184
+        Float absTanTheta = absf(TanTheta(w));
+        if (__builtin_isinf(absTanTheta)) return 0.;
+        Float alpha = sqrtf_(Cos2Phi(w) * ax * ax + Sin2Phi(w) * ay * ay);
+        if (beckmann) {
+            Float a = 1 / (alpha * absTanTheta);
+            if (a >= 1.6f) return 0;
+            return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+        }
+        Float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+        return (-1 + sqrtf_(1.f + alpha2Tan2Theta)) / 2;
+    }
+    PT_DEV Float G1(const V3 &w) const { return 1 / (1 + Lambda(w)); }
+    PT_DEV Float G(const V3 &wo, const V3 &wi) const { return 1 / (1 + Lambda(wo) + Lambda(wi)); }
+    PT_DEV Float Pdf(const V3 &wo, const V3 &wh) const { return D(wh) * G1(wo) * AbsDot(wo, wh) / AbsCosTheta(wo); }   // :338-344
+    PT_DEV V3 Sample_wh(const V3 &wo, Float u0, Float u1) const;
+};
+// TrowbridgeReitzSample11 microfacet.cpp:238-282; the unqualified sqrt/cos/sin of its first branch are
+// the double overloads in the reference build -- reproduced with fp64 ops.
+PT_DEV void TrowbridgeReitzSample11(Float cosTheta, Float U1, Float U2, Float *slope_x, Float *slope_y) {
+    if ((double)cosTheta > .9999) {
+        Float r = (Float)sqrt((double)(U1 / (1 - U1)));
+        Float phi = (Float)(6.28318530718 * (double)U2);
+        *slope_x = (Float)((double)r * cos((double)phi));
+        *slope_y = (Float)((double)r * sin((double)phi));
+        return;
+    }
+    Float sinTheta = sqrtf_(mx((Float)0, (Float)1 - cosTheta * cosTheta));
+    Float tanTheta = sinTheta / cosTheta;
+    Float a = 1 / tanTheta;
+    Float G1 = 2 / (1 + sqrtf_(1.f + 1.f / (a * a)));
+    Float A = 2 * U1 / G1 - 1;
+    Float tmp = 1.f / (A * A - 1.f);
+    if ((double)tmp > 1e10) tmp = (Float)1e10;
+    Float B = tanTheta;
+    Float D = sqrtf_(mx(Float(B * B * tmp * tmp - (A * A - B * B) * tmp), Float(0)));
+    Float slope_x_1 = B * tmp - D;
+    Float slope_x_2 = B * tmp + D;
+    *slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+    Float S;
+    if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+    else { S = -1.f; U2 = 2.f * (.5f - U2); }
+    Float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    *slope_y = S * z * sqrtf_(1.f + *slope_x * *slope_x);
+}
+PT_DEV V3 Distrib::Sample_wh(const V3 &wo, Float u0, Float u1) const {   // microfacet.cpp:284-336 (visible-area sampling)
+    bool flip = wo.z < 0;
+    V3 wi = flip ? -wo : wo;
+    V3 wiStretched = Normalize(V3(ax * wi.x, ay * wi.y, wi.z));
+    Float slope_x, slope_y;
+    TrowbridgeReitzSample11(CosTheta(wiStretched), u0, u1, &slope_x, &slope_y);
+    Float tmp = CosPhi(wiStretched) * slope_x - SinPhi(wiStretched) * slope_y;
+    slope_y = SinPhi(wiStretched) * slope_x + CosPhi(wiStretched) * slope_y;
+    slope_x = tmp;
+    slope_x = ax * slope_x;
+    slope_y = ay * slope_y;
+    V3 wh = Normalize(V3(-slope_x, -slope_y, 1.f));
+    if (flip) wh = -wh;
+    return wh;
+}
+
+PT_DEV int BxdfFlags(int type) {
+    switch (type) {
+    case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case MI_BXDF_LAMBERT_T: return BSDF_TRANSMISSION | BSDF_DIFFUSE;
+    case MI_BXDF_SPECULAR_R: return BSDF_REFLECTION | BSDF_SPECULAR;
+    case MI_BXDF_SPECULAR_T: return BSDF_TRANSMISSION | BSDF_SPECULAR;
+    case MI_BXDF_FRESNEL_SPEC: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+    case MI_BXDF_MICROFACET_R: case MI_BXDF_FRESNEL_BLEND: return BSDF_REFLECTION | BSDF_GLOSSY;
+    case MI_BXDF_MICROFACET_T: return BSDF_TRANSMISSION | BSDF_GLOSSY;
+    }
+    return 0;
+}
+PT_DEV bool Matches(int bxdfFlags, int flags) { return (bxdfFlags & flags) == bxdfFlags; }   // reflection.h:215
+
+PT_DEV RGB BxdfF_unscaled(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+    switch (b.type) {
+    case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
+    case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
+    case MI_BXDF_OREN_NAYAR: {                              // :197-219
+        Float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
+        Float maxCos = 0;
+        if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+            Float sinPhiI = SinPhi(wi), cosPhiI = CosPhi(wi), sinPhiO = SinPhi(wo), cosPhiO = CosPhi(wo);
+            Float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+            maxCos = mx((Float)0, dCos);
+        }
+        Float sinAlpha, tanBeta;
+        if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / AbsCosTheta(wi); }
+        else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
+        return rgb3(b.R) * PT_INV_PI * (b.A + b.B * maxCos * sinAlpha * tanBeta);
+    }
+    case MI_BXDF_MICROFACET_R: {                            // :226-236
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
+        V3 wh = wi + wo;
+        if (cosThetaI == 0 || cosThetaO == 0) return RGB(0.f);
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return RGB(0.f);
+        wh = Normalize(wh);
+        RGB F = FresnelEvaluate(b, Dot(wi, wh));
+        return rgb3(b.R) * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    }
+    case MI_BXDF_MICROFACET_T: {                            // :244-266
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        if (SameHemisphere(wo, wi)) return RGB(0.f);
+        Float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) return RGB(0.f);
+        Float eta = CosTheta(wo) > 0 ? (b.etaB / b.etaA) : (b.etaA / b.etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        RGB F(FrDielectric(Dot(wo, wh), b.etaA, b.etaB));
+        Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        Float factor = 1 / eta;   // TransportMode::Radiance
+        return (RGB(1.f) - F) * rgb3(b.T) *
+               absf(dist.D(wh) * dist.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
+                    (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    }
+    case MI_BXDF_FRESNEL_BLEND: {                           // :279-298 (Rd = R, Rs = T)
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        RGB Rd = rgb3(b.R), Rs = rgb3(b.T);
+        Float ci = 1 - .5f * AbsCosTheta(wi), co = 1 - .5f * AbsCosTheta(wo);
+        Float pi5 = (ci * ci) * (ci * ci) * ci, po5 = (co * co) * (co * co) * co;
+        RGB diffuse = (28.f / (23.f * PT_PI)) * Rd * (RGB(1.f) - Rs) * (1 - pi5) * (1 - po5);
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return RGB(0.f);
+        wh = Normalize(wh);
+        Float c = 1 - Dot(wi, wh);
+        Float c5 = (c * c) * (c * c) * c;
+        RGB schlick = Rs + c5 * (RGB(1.f) - Rs);   // reflection.h:485-488
+        RGB specular = dist.D(wh) / (4 * AbsDot(wi, wh) * mx(AbsCosTheta(wi), AbsCosTheta(wo))) * schlick;
+        return diffuse + specular;
+    }
+    default: return RGB(0.f);   // specular lobes evaluate to zero
+    }
+}
+PT_DEV RGB BxdfF(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+    RGB f = BxdfF_unscaled(b, wo, wi);
+    return b.scaled ? rgb3(b.scale) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
+}
+PT_DEV Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+    switch (b.type) {
+    case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
+    case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
+    case MI_BXDF_MICROFACET_R: {                                                                                       // :418-423
+        if (!SameHemisphere(wo, wi)) return 0;
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        V3 wh = Normalize(wo + wi);
+        return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
+    }
+    case MI_BXDF_MICROFACET_T: {                                                                                       // :436-448
+        if (SameHemisphere(wo, wi)) return 0;
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        Float eta = CosTheta(wo) > 0 ? (b.etaB / b.etaA) : (b.etaA / b.etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        Float dwh_dwi = absf((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        return dist.Pdf(wo, wh) * dwh_dwi;
+    }
+    case MI_BXDF_FRESNEL_BLEND: {                                                                                      // :470-475
+        if (!SameHemisphere(wo, wi)) return 0;
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        V3 wh = Normalize(wo + wi);
+        Float pdf_wh = dist.Pdf(wo, wh);
+        return .5f * (AbsCosTheta(wi) * PT_INV_PI + pdf_wh / (4 * Dot(wo, wh)));
+    }
+    default: return 0;
+    }
+}
+// BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
+PT_DEV RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+    RGB f;
+    switch (b.type) {
+    case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
+        *wi = CosineSampleHemisphere(u0, u1);
+        if (wo.z < 0) wi->z *= -1;
+        *pdf = BxdfPdf(b, wo, *wi);
+        f = BxdfF_unscaled(b, wo, *wi);
+        break;
+    case MI_BXDF_LAMBERT_T:                            // :391-398
+        *wi = CosineSampleHemisphere(u0, u1);
+        if (wo.z > 0) wi->z *= -1;
+        *pdf = BxdfPdf(b, wo, *wi);
+        f = BxdfF_unscaled(b, wo, *wi);
+        break;
+    case MI_BXDF_SPECULAR_R:                           // :136-143
+        *wi = V3(-wo.x, -wo.y, wo.z);
+        *pdf = 1;
+        f = FresnelEvaluate(b, CosTheta(*wi)) * rgb3(b.R) / AbsCosTheta(*wi);
+        break;
+    case MI_BXDF_SPECULAR_T: {                         // :150-166
+        bool entering = CosTheta(wo) > 0;
+        Float etaI = entering ? b.etaA : b.etaB, etaT = entering ? b.etaB : b.etaA;
+        if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return RGB(0.f);
+        *pdf = 1;
+        RGB ft = rgb3(b.T) * (RGB(1.f) - RGB(FrDielectric(CosTheta(*wi), b.etaA, b.etaB)));
+        ft = ft * ((etaI * etaI) / (etaT * etaT));
+        f = ft / AbsCosTheta(*wi);
+        break;
+    }
+    case MI_BXDF_FRESNEL_SPEC: {                       // :477-511
+        Float F = FrDielectric(CosTheta(wo), b.etaA, b.etaB);
+        if (u0 < F) {
+            *wi = V3(-wo.x, -wo.y, wo.z);
+            *sampledType = BSDF_SPECULAR | BSDF_REFLECTION;
+            *pdf = F;
+            f = F * rgb3(b.R) / AbsCosTheta(*wi);
+        } else {
+            bool entering = CosTheta(wo) > 0;
+            Float etaI = entering ? b.etaA : b.etaB, etaT = entering ? b.etaB : b.etaA;
+            if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return RGB(0.f);
+            RGB ft = rgb3(b.T) * (1 - F);
+            ft = ft * ((etaI * etaI) / (etaT * etaT));
+            *sampledType = BSDF_SPECULAR | BSDF_TRANSMISSION;
+            *pdf = 1 - F;
+            f = ft / AbsCosTheta(*wi);
+        }
+        break;
+    }
+    case MI_BXDF_MICROFACET_R: {                       // :405-416
+        if (wo.z == 0) return RGB(0.f);
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        V3 wh = dist.Sample_wh(wo, u0, u1);
+        *wi = Reflect(wo, wh);
+        if (!SameHemisphere(wo, *wi)) return RGB(0.f);
+        *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
+        f = BxdfF_unscaled(b, wo, *wi);
+        break;
+    }
+    case MI_BXDF_MICROFACET_T: {                       // :425-434
+        if (wo.z == 0) return RGB(0.f);
+        Distrib dist{b.alphax, b.alphay, b.distrib};
+        V3 wh = dist.Sample_wh(wo, u0, u1);
+        Float eta = CosTheta(wo) > 0 ? (b.etaA / b.etaB) : (b.etaB / b.etaA);
+        if (!Refract(wo, wh, eta, wi)) return RGB(0.f);
+        *pdf = BxdfPdf(b, wo, *wi);
+        f = BxdfF_unscaled(b, wo, *wi);
+        break;
+    }
+    case MI_BXDF_FRESNEL_BLEND: {                      // :450-468
+        if ((double)u0 < .5) {
+            u0 = mn(2 * u0, PT_ONE_MINUS_EPS);
+            *wi = CosineSampleHemisphere(u0, u1);
+            if (wo.z < 0) wi->z *= -1;
+        } else {
+            u0 = mn(2 * (u0 - .5f), PT_ONE_MINUS_EPS);
+            Distrib dist{b.alphax, b.alphay, b.distrib};
+            V3 wh = dist.Sample_wh(wo, u0, u1);
+            *wi = Reflect(wo, wh);
+            if (!SameHemisphere(wo, *wi)) return RGB(0.f);
+        }
+        *pdf = BxdfPdf(b, wo, *wi);
+        f = BxdfF_unscaled(b, wo, *wi);
+        break;
+    }
+    }
+    return b.scaled ? rgb3(b.scale) * f : f;   // ScaledBxDF::Sample_f reflection.cpp:101-106
+}
+
+// ------------------------------------------------------------------ BSDF (core/reflection.h:153-202)
+struct BSDF {
+    const mi_material *m;
+    V3 ns, ng, ss, ts;
+    PT_DEV BSDF(const Isect &si, const mi_material *mat) : m(mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
+    PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
+    PT_DEV V3 LocalToWorld(const V3 &v) const {
+        return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
+    }
+    PT_DEV int NumComponents(int flags) const {
+        int n = 0;
+        for (int i = 0; i < m->n_bxdfs; ++i) if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) ++n;
+        return n;
+    }
+    PT_DEV RGB f(const V3 &woW, const V3 &wiW, int flags) const {   // reflection.cpp:670-683
+        V3 wi = WorldToLocal(wiW), wo = WorldToLocal(woW);
+        if (wo.z == 0) return RGB(0.f);
+        bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
+        RGB f(0.f);
+        for (int i = 0; i < m->n_bxdfs; ++i) {
+            const mi_bxdf &b = m->bxdfs[i];
+            int t = BxdfFlags(b.type);
+            if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
+        }
+        return f;
+    }
+    PT_DEV Float Pdf(const V3 &woW, const V3 &wiW, int flags) const {   // reflection.cpp:770-785
+        if (m->n_bxdfs == 0) return 0.f;
+        V3 wo = WorldToLocal(woW), wi = WorldToLocal(wiW);
+        if (wo.z == 0) return 0.f;
+        Float pdf = 0.f;
+        int matchingComps = 0;
+        for (int i = 0; i < m->n_bxdfs; ++i)
+            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf(m->bxdfs[i], wo, wi); }
+        return matchingComps > 0 ? pdf / matchingComps : 0.f;
+    }
+    PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
+        int matchingComps = NumComponents(type);
+        if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return RGB(0.f); }
+        int comp = mni((int)__builtin_floorf(u0 * matchingComps), matchingComps - 1);
+        int chosen = 0, count = comp;
+        for (int i = 0; i < m->n_bxdfs; ++i)
+            if (Matches(BxdfFlags(m->bxdfs[i].type), type) && count-- == 0) { chosen = i; break; }
+        const mi_bxdf &bxdf = m->bxdfs[chosen];
+        Float ur0 = mn(u0 * matchingComps - comp, PT_ONE_MINUS_EPS);
+        V3 wi, wo = WorldToLocal(woWorld);
+        if (wo.z == 0) return RGB(0.f);
+        *pdf = 0;
+        int bt = BxdfFlags(bxdf.type);
+        *sampledType = bt;
+        RGB f = BxdfSample_f(bxdf, wo, &wi, ur0, u1, pdf, sampledType);
+        if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
+        *wiWorld = LocalToWorld(wi);
+        if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
+            for (int i = 0; i < m->n_bxdfs; ++i)
+                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf(m->bxdfs[i], wo, wi);
+        if (matchingComps > 1) *pdf /= matchingComps;
+        if (!(bt & BSDF_SPECULAR)) {
+            bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
+            f = RGB(0.f);
+            for (int i = 0; i < m->n_bxdfs; ++i) {
+                const mi_bxdf &b = m->bxdfs[i];
+                int t = BxdfFlags(b.type);
+                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
+            }
+        }
+        return f;
+    }
+};
+
+// ------------------------------------------------------------------ lights
+PT_DEV RGB AreaL(const mi_light &l, const V3 &n, const V3 &w) {   // DiffuseAreaLight::L lights/diffuse.h:56-58
+    return (l.two_sided || Dot(n, w) > 0) ? rgb3(l.L) : RGB(0.f);
+}
+
+struct ShadowRay { V3 o, d; Float tMax; };
+// Interaction::SpawnRayTo(const Interaction&) core/interaction.h:72-78
+PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, const V3 &n2) {
+    ShadowRay r;
+    r.o = OffsetRayOrigin(ref.p, ref.pError, ref.n, p2 - ref.p);
+    V3 target = OffsetRayOrigin(p2, p2Error, n2, r.o - p2);
+    r.d = target - r.o;
+    r.tMax = 1 - PT_SHADOW_EPS;
+    return r;
+}
+
+struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
+
+PT_DEV void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Float u0, Float u1, LightSample *ls) {
+    ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
+    if (l.type == MI_LIGHT_AREA_TRI) {
+        // DiffuseAreaLight::Sample_Li lights/diffuse.cpp:68-81 -> Shape::Sample(ref,u) core/shape.cpp:56-70
+        // -> Triangle::Sample(u) shapes/triangle.cpp:583-608
+        Float su0 = sqrtf_(u0);
+        Float b0 = 1 - su0, b1 = u1 * su0;   // UniformSampleTriangle core/sampling.cpp:154-157
+        V3 p0, p1, p2;
+        uint32_t tf;
+        LoadTri(sc, l.tri, &p0, &p1, &p2, &tf);
+        V3 p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+        V3 n = Normalize(Cross(p1 - p0, p2 - p0));
+        uint32_t mflags = sc.meshes[sc.tri_mesh[l.tri]].flags;
+        if (sc.N && (mflags & MI_MESH_HAS_N)) {
+            const uint32_t *v = sc.tri_indices + 3 * (size_t)l.tri;
+            V3 n0 = v3(sc.N + 3 * (size_t)v[0]), n1 = v3(sc.N + 3 * (size_t)v[1]), n2 = v3(sc.N + 3 * (size_t)v[2]);
+            V3 ns = b0 * n0 + b1 * n1 + (1 - b0 - b1) * n2;
+            n = Faceforward(n, ns);
+        } else if (mflags & MI_MESH_FLIP)
+            n = n * -1.f;
+        V3 pAbsSum = Abs(b0 * p0) + Abs(b1 * p1) + Abs((1 - b0 - b1) * p2);
+        V3 pError = gamma_n(6) * pAbsSum;
+        Float pdf = 1 / l.area;
+        V3 wi = p - ref.p;
+        if (wi.LengthSquared() == 0) pdf = 0;
+        else {
+            wi = Normalize(wi);
+            pdf *= DistanceSquared(ref.p, p) / AbsDot(n, -wi);
+            if (__builtin_isinf(pdf)) pdf = 0.f;
+        }
+        if (pdf == 0 || (p - ref.p).LengthSquared() == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return; }
+        ls->wi = Normalize(p - ref.p);
+        ls->pdf = pdf;
+        ls->shadow = SpawnRayTo(ref, p, pError, n);
+        ls->Li = AreaL(l, n, -ls->wi);
+        return;
+    }
+    if (l.type == MI_LIGHT_POINT) {   // lights/point.cpp:44-53
+        V3 pLight = v3(l.pos);
+        ls->wi = Normalize(pLight - ref.p);
+        ls->pdf = 1.f;
+        ls->shadow = SpawnRayTo(ref, pLight, V3(), V3());
+        ls->Li = rgb3(l.L) / DistanceSquared(pLight, ref.p);
+        return;
+    }
+    if (l.type == MI_LIGHT_DISTANT) {   // lights/distant.cpp:49-59
+        V3 wLight = v3(l.pos);
+        ls->wi = wLight;
+        ls->pdf = 1;
+        V3 pOutside = ref.p + wLight * (2 * l.world_radius);
+        ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
+        ls->Li = rgb3(l.L);
+        return;
+    }
+    {   // constant InfiniteAreaLight, lights/infinite.cpp:108-132 with a 1x1 map (uv = u, mapPdf = 1)
+        Float theta = u1 * PT_PI, phi = u0 * 2 * PT_PI;
+        Float cosTheta = cosf_(theta), sinTheta = sinf_(theta);
+        Float sinPhi = sinf_(phi), cosPhi = cosf_(phi);
+        ls->wi = V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+        ls->pdf = 1 / (2 * PT_PI * PT_PI * sinTheta);
+        if (sinTheta == 0) ls->pdf = 0;
+        V3 pOutside = ref.p + ls->wi * (2 * l.world_radius);
+        ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
+        ls->Li = rgb3(l.L);
+    }
+}
+
+// Light::Pdf_Li
+PT_DEV Float PdfLi(const DevScene &sc, const mi_light &l, const Isect &ref, const V3 &wi) {
+    if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
+        V3 o = OffsetRayOrigin(ref.p, ref.pError, ref.n, wi);
+        V3 p0, p1, p2;
+        uint32_t tf;
+        LoadTri(sc, l.tri, &p0, &p1, &p2, &tf);
+        TriHit th;
+        if ((tf & TRI_FLAG_REJECT) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;
+        Isect li;
+        BuildIsect(sc, l.tri, p0, p1, p2, th, wi, &li);
+        Float pdf = DistanceSquared(ref.p, li.p) / (AbsDot(li.n, -wi) * l.area);
+        if (__builtin_isinf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+    if (l.type == MI_LIGHT_INFINITE) {   // lights/infinite.cpp:134-143, constant map
+        Float theta = acosf_(clampf(wi.z, -1, 1));
+        Float sinTheta = sinf_(theta);
+        if (sinTheta == 0) return 0;
+        return 1 / (2 * PT_PI * PT_PI * sinTheta);
+    }
+    return 0;
+}
