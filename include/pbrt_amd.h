@@ -216,6 +216,9 @@ int mi_sync(mi_ctx *ctx);
 int mi_film_clear(mi_ctx *ctx);
 int mi_film_download(mi_ctx *ctx, float *rgbw /* 4 * cropped pixel count */);
 void *mi_film_device_ptr(mi_ctx *ctx); /* float4 per cropped pixel, for RCCL by the caller */
+/* Render into a caller-owned device buffer (e.g. a torch tensor that torch.distributed reduces over RCCL);
+ * NULL switches back to the library's own film. */
+int mi_film_bind(mi_ctx *ctx, void *device_float4_buffer);
 int64_t mi_film_pixel_count(mi_ctx *ctx);
 
 /* Work counters (names follow the reference's STAT_COUNTERs: integrator.cpp:48,
@@ -229,6 +232,9 @@ enum mi_counter {
     MI_CNT_NODES_ANY = 5,
     MI_CNT_TRIS_ANY = 6,
     MI_CNT_PATH_SEGMENTS = 7,
+    MI_CNT_MIS_RAYS = 8,     /* the part of CLOSEST_RAYS traced by the MIS launches (integrator.cpp:202) */
+    MI_CNT_NODES_MIS = 9,
+    MI_CNT_TRIS_MIS = 10,
     MI_CNT_COUNT = 16
 };
 int mi_counters(mi_ctx *ctx, uint64_t out[MI_CNT_COUNT]);

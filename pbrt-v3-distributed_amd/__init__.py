@@ -21,7 +21,7 @@ DEVICE_LIB = os.path.join(LIB_DIR, "libpbrt_amd.so")
 MI_CNT_COUNT = 16
 MI_K_COUNT = 8
 COUNTER_NAMES = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any",
-                 "tris_any", "path_segments"]
+                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis"]
 KERNEL_NAMES = ["raygen", "closest", "sort", "shade", "anyhit", "mis_closest", "film", "other"]
 
 
@@ -46,7 +46,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 # Every symbol include/pbrt_amd.h declares (checked by tests/test_abi.py against the header text)
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
-    "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_pixel_count", "mi_counters",
+    "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
     "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_intersect", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
@@ -92,6 +92,7 @@ def device_lib():
         L.mi_film_download.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_film_device_ptr.restype = C.c_void_p
         L.mi_film_device_ptr.argtypes = [C.c_void_p]
+        L.mi_film_bind.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_film_pixel_count.restype = C.c_int64
         L.mi_film_pixel_count.argtypes = [C.c_void_p]
         L.mi_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -205,6 +206,10 @@ class Context:
 
     def film_device_ptr(self):
         return device_lib().mi_film_device_ptr(self._ctx)
+
+    def film_bind(self, device_ptr):
+        """Render into a caller-owned device buffer of height*width float4 (e.g. a torch tensor's data_ptr())."""
+        self._chk(device_lib().mi_film_bind(self._ctx, C.c_void_p(device_ptr) if device_ptr else None), "mi_film_bind")
 
     def counters(self):
         out = np.zeros(MI_CNT_COUNT, dtype=np.uint64)

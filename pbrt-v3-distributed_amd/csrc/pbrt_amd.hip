@@ -267,7 +267,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_closest(DevScene sc, PathState ps,
         }
     }
     wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], nrays);
-    if (COUNT) { wave_count(&ps.counters[MI_CNT_NODES_CLOSEST], tc.nodes); wave_count(&ps.counters[MI_CNT_TRIS_CLOSEST], tc.tris); }
+    if (MODE == 1) wave_count(&ps.counters[MI_CNT_MIS_RAYS], nrays);
+    if (COUNT) {
+        wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : MI_CNT_NODES_MIS], tc.nodes);
+        wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : MI_CNT_TRIS_MIS], tc.tris);
+    }
 }
 
 // ---- shadow rays: VisibilityTester::Unoccluded (core/light.cpp:59-61) -> BVHAccel::IntersectP
@@ -629,6 +633,7 @@ struct mi_ctx {
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
     DevBuf film, counters, tiles;
+    float4 *filmPtr = nullptr;   // c->film.p or a caller-owned buffer (mi_film_bind)
     int64_t filmPixels = 0;
     // wavefront state
     PathState ps;
@@ -866,6 +871,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     c->filmPixels = (int64_t)std::max(0, sc.crop_max[0] - sc.crop_min[0]) * std::max(0, sc.crop_max[1] - sc.crop_min[1]);
     if (c->film.alloc((size_t)c->filmPixels * sizeof(float4))) return -1;
     HIP_TRY(hipMemsetAsync(c->film.p, 0, c->film.bytes, c->stream));
+    c->filmPtr = c->film.as<float4>();
     HIP_TRY(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
     // state depending on the scene is (re)allocated lazily by ensure_state()
     for (auto &b : c->stateBufs) b.release();
@@ -978,8 +984,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     }
     if (toFilm) {
         tic(c, MI_K_FILM);
-        hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->film.as<float4>());
-        hipLaunchKernelGGL((k_film<true>), grid, block, 0, st, sc, ps, pass, c->film.as<float4>());
+        hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->filmPtr);
+        hipLaunchKernelGGL((k_film<true>), grid, block, 0, st, sc, ps, pass, c->filmPtr);
         toc(c);
     }
     HIP_TRY(hipGetLastError());
@@ -1039,18 +1045,23 @@ int mi_sync(mi_ctx *c) {
 
 int mi_film_clear(mi_ctx *c) {
     if (!c || !c->haveScene) return fail("mi_film_clear: no scene");
-    HIP_TRY(hipMemsetAsync(c->film.p, 0, c->film.bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->filmPtr, 0, (size_t)c->filmPixels * sizeof(float4), c->stream));
+    return 0;
+}
+int mi_film_bind(mi_ctx *c, void *p) {
+    if (!c || !c->haveScene) return fail("mi_film_bind: no scene");
+    c->filmPtr = p ? (float4 *)p : c->film.as<float4>();
     return 0;
 }
 int mi_film_download(mi_ctx *c, float *rgbw) {
     if (!c || !c->haveScene || !rgbw) return fail("mi_film_download: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(rgbw, c->film.p, (size_t)c->filmPixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(rgbw, c->filmPtr, (size_t)c->filmPixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     harvest(c);
     return 0;
 }
-void *mi_film_device_ptr(mi_ctx *c) { return c ? c->film.p : nullptr; }
+void *mi_film_device_ptr(mi_ctx *c) { return c ? (void *)c->filmPtr : nullptr; }
 int64_t mi_film_pixel_count(mi_ctx *c) { return c ? c->filmPixels : 0; }
 
 int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
