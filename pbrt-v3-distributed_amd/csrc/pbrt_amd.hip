@@ -41,6 +41,8 @@ struct PathState {
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
     uint32_t *qcount;          // [0],[1] extension queues, [2] shadow, [3] mis, [4] sorted total
     uint32_t *keycount, *keyoffset;
+    uint32_t *blockhist;       // [gridBlocks][nkeys]
+    uint32_t *cursor;          // [8] per-XCD-segment fetch cursors of k_trace
     unsigned long long *counters;
     uint32_t *spill;
     int spill_per_thread;
@@ -125,12 +127,14 @@ PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
     return V3(inv * xp, inv * yp, inv * zp);
 }
 PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy) {
-    Float u0, u1, l0, l1;
-    smp.Get2D(sc, &u0, &u1);
-    Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;
-    Float time = smp.Get1D(sc);
-    (void)time;   // static scene: ray.time is never read on this path
-    smp.Get2D(sc, &l0, &l1);
+    Float u[5];
+    SobolBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
+    // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57)
+    Float u0 = clampf((u[0] * sc.sobol_resolution + sc.sample_min[0]) - smp.px, (Float)0, PT_ONE_MINUS_EPS);
+    Float u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
+    Float l0 = u[3], l1 = u[4];
+    smp.dimension = 5;
+    Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;   // static scene: the time sample (dim 2) is never read
     const mi_camera &cam = sc.camera;
     V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
     V3 ro(0, 0, 0), rd = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
@@ -204,122 +208,178 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
     wave_count(&ps.counters[MI_CNT_CAMERA_RAYS], ncam);
 }
 
-// ---- closest hit over a queue.  MODE 0: path extension rays (writes hit record + material key/rank);
-// MODE 1: MIS rays of EstimateDirect (core/integrator.cpp:167-213): adds f*Li*weight/scatteringPdf.
+// ---- ray traversal over a queue, persistent lanes with dynamic ray fetch.
+// Incoherent rays take wildly different numbers of BVH steps (measured: a plain one-ray-per-lane loop
+// keeps 9 % of the VALU lanes busy on the 10 M-triangle scene, profiles/r01_a_*).  Here a lane that
+// finishes its ray immediately takes the next one, so a wave only idles at the very end of the queue:
+//   * the queue is cut into 8 XCD segments; a wave pulls batches of TRACE_BATCH rays from the segment of the
+//     XCD it (most likely) runs on -- one atomic per batch -- and steals from the other segments afterwards;
+//   * lanes re-fill when at least TRACE_REFILL of the 64 are idle; between re-fills every lane advances its
+//     own ray: up to TRACE_NODE_STEPS interior-node steps, then one leaf step (while-while traversal).
+// MODE 0: path-extension rays -> hit record.  MODE 1: MIS rays of EstimateDirect (core/integrator.cpp:167-213)
+// -> adds f*Li*weight/scatteringPdf.  MODE 2: shadow rays, VisibilityTester::Unoccluded (core/light.cpp:59-61).
+#define TRACE_BATCH 64u
+#define TRACE_REFILL 16
+#define TRACE_NODE_STEPS 2
 template <int MODE, bool COUNT>
-__global__ void __launch_bounds__(PT_BLOCK) k_closest(DevScene sc, PathState ps, uint32_t qin) {
+__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
     st.lds = &lds_stack[threadIdx.x];
     st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
-    const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : ps.q_mis;
-    uint32_t n = ps.qcount[MODE == 0 ? qin : QC_MIS];
+    const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
+    const uint32_t n = ps.qcount[MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW)];
+    const uint32_t segLen = (((n + 7) / 8) + 63u) & ~63u;
+    const uint32_t lane = lane_id();
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    uint32_t seg = blockIdx.x & 7, segsTried = 0;
+    uint32_t poolNext = 0, poolEnd = 0;   // wave-uniform
+    bool active = false;
+    uint32_t slot = 0, lightNum = 0;
+    TravState ts;
+    ts.cur = TRAV_DONE;
     TraceCounters tc = {0, 0};
     uint32_t nrays = 0;
+    while (true) {
+        unsigned long long idle = __ballot(!active);
+        int nIdle = __popcll(idle);
+        if (nIdle >= TRACE_REFILL && segsTried < 8) {
+            while (segsTried < 8 && nIdle > 0) {
+                if (poolNext >= poolEnd) {   // take the next batch of this segment (one atomic per wave and batch)
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&ps.cursor[seg], TRACE_BATCH);
+                    base = __shfl(base, 0);
+                    uint32_t segBeg = seg * segLen, segEnd = segBeg + segLen < n ? segBeg + segLen : n;
+                    if (segBeg + base >= segEnd || segBeg >= n) { seg = (seg + 1) & 7; ++segsTried; poolNext = poolEnd = 0; continue; }
+                    poolNext = segBeg + base;
+                    poolEnd = poolNext + TRACE_BATCH < segEnd ? poolNext + TRACE_BATCH : segEnd;
+                }
+                uint32_t avail = poolEnd - poolNext;
+                uint32_t rank = (uint32_t)__popcll(idle & ltMask);
+                if (!active && rank < avail) {
+                    slot = queue[poolNext + rank];
+                    float4 o4 = MODE == 0 ? ps.ray_o[slot] : (MODE == 1 ? ps.mi_o[slot] : ps.sh_o[slot]);
+                    float4 d4 = MODE == 0 ? ps.ray_d[slot] : (MODE == 1 ? ps.mi_d[slot] : ps.sh_d[slot]);
+                    if (MODE == 1) lightNum = __float_as_uint(d4.w);
+                    ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    active = true;
+                    ++nrays;
+                }
+                poolNext += (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
+                idle = __ballot(!active);
+                nIdle = __popcll(idle);
+            }
+        }
+        if (!__any(active)) break;
+        const bool mayRefill = segsTried < 8;
+        while (true) {
+#pragma unroll 1
+            for (int k = 0; k < TRACE_NODE_STEPS; ++k)
+                if (active && ts.atNode()) TravNodeStep<COUNT>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT>(sc, ts, st, &tc);
+            if (active && ts.done()) {
+                if (MODE == 0) {
+                    ps.hit[slot] = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                } else if (MODE == 2) {
+                    if (ts.prim == TRAV_MISS) {   // unoccluded: add the light-sampled term
+                        float4 c = ps.sh_c[slot], L = ps.L[slot];
+                        L.x += c.x; L.y += c.y; L.z += c.z;
+                        ps.L[slot] = L;
+                    }
+                } else {
+                    const mi_light &light = sc.lights[lightNum];
+                    RGB Li(0.f);
+                    if (ts.prim != TRAV_MISS) {
+                        if (sc.tri_light[ts.prim] == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                            V3 p0, p1, p2;
+                            uint32_t tf;
+                            LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
+                            TriHit th;
+                            TriangleTest(p0, p1, p2, ts.o, ts.d, PT_INFINITY, &th);
+                            Isect li;
+                            BuildIsect(sc, ts.prim, p0, p1, p2, th, ts.d, &li);
+                            Li = AreaL(light, li.n, -ts.d);   // lightIsect.Le(-wi)
+                        }
+                    } else if (light.type == MI_LIGHT_INFINITE)
+                        Li = rgb3(light.L);                   // light.Le(ray)
+                    if (!Li.IsBlack()) {
+                        float4 c = ps.mi_c[slot], L = ps.L[slot];
+                        L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
+                        ps.L[slot] = L;
+                    }
+                }
+                active = false;
+            }
+            int nAct = __popcll(__ballot(active));
+            if (nAct == 0 || (mayRefill && nAct <= 64 - TRACE_REFILL)) break;
+        }
+    }
+    wave_count(&ps.counters[MODE == 2 ? MI_CNT_SHADOW_RAYS : MI_CNT_CLOSEST_RAYS], nrays);
+    if (MODE == 1) wave_count(&ps.counters[MI_CNT_MIS_RAYS], nrays);
+    if (COUNT) {
+        wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : (MODE == 1 ? MI_CNT_NODES_MIS : MI_CNT_NODES_ANY)], tc.nodes);
+        wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : (MODE == 1 ? MI_CNT_TRIS_MIS : MI_CNT_TRIS_ANY)], tc.tris);
+    }
+}
+
+// ---- counting sort of the traced paths by material key, without global atomics:
+//   k_keycount : every (persistent) block histograms the keys of ITS chunks in LDS -- wave ballots merge equal
+//                keys, so an LDS atomic is issued per (wave, distinct key) -- and records each path's rank inside
+//                the block; the block histogram goes to blockhist[block][key]
+//   k_scan_keys: offsets[block][key] = keyBase[key] + sum of the histograms of lower blocks (one thread per key)
+//   k_scatter  : same chunk->block mapping, so sorted[offsets[block][key] + rank] = path
+__global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps, uint32_t qin, uint32_t nkeys) {
+    extern __shared__ uint32_t lhist[];
+    for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) lhist[k] = 0;
+    __syncthreads();
+    uint32_t n = ps.qcount[qin];
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
         bool active = i < n;
-        uint32_t slot = 0, prim = MISS_PRIM, key = 0;
-        Float t = 0;
+        uint32_t slot = 0, key = 0;
         if (active) {
-            slot = queue[i];
-            float4 o4 = MODE == 0 ? ps.ray_o[slot] : ps.mi_o[slot];
-            float4 d4 = MODE == 0 ? ps.ray_d[slot] : ps.mi_d[slot];
-            V3 o(o4.x, o4.y, o4.z), d(d4.x, d4.y, d4.z);
-            Float tMax = MODE == 0 ? o4.w : PT_INFINITY;
-            bool hit = Traverse<false, COUNT>(sc, o, d, tMax, st, &t, &prim, &tc);
-            if (!hit) prim = MISS_PRIM;
-            ++nrays;
-            if (MODE == 0) {
-                ps.hit[slot] = make_uint2(prim, __float_as_uint(t));
-                if (hit) {
-                    int mat = sc.meshes[sc.tri_mesh[prim]].material;
-                    key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;   // null-BSDF surfaces: own bucket
-                } else
-                    key = sc.n_materials;                                   // escaped rays
-            } else {
-                int lightNum = (int)__float_as_uint(d4.w);
-                const mi_light &light = sc.lights[lightNum];
-                RGB Li(0.f);
-                if (hit) {
-                    if (sc.tri_light[prim] == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
-                        V3 p0, p1, p2;
-                        uint32_t tf;
-                        LoadTri(sc, prim, &p0, &p1, &p2, &tf);
-                        TriHit th;
-                        TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
-                        Isect li;
-                        BuildIsect(sc, prim, p0, p1, p2, th, d, &li);
-                        Li = AreaL(light, li.n, -d);   // lightIsect.Le(-wi)
-                    }
-                } else if (light.type == MI_LIGHT_INFINITE)
-                    Li = rgb3(light.L);                 // light.Le(ray)
-                if (!Li.IsBlack()) {
-                    float4 c = ps.mi_c[slot], L = ps.L[slot];
-                    L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
-                    ps.L[slot] = L;
-                }
-            }
+            slot = ps.q_ext[qin][i];
+            uint32_t prim = ps.hit[slot].x;
+            if (prim != MISS_PRIM) {
+                int mat = sc.meshes[sc.tri_mesh[prim]].material;
+                key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;   // null-BSDF surfaces: own bucket
+            } else
+                key = sc.n_materials;                                   // escaped rays
         }
-        if (MODE == 0) {
-            uint32_t rank = wave_key_rank(ps.keycount, key, active);
-            if (active) ps.keyrank[slot] = make_uint2(key, rank);
+        uint32_t rank = wave_key_rank(lhist, key, active);
+        if (active) ps.keyrank[slot] = make_uint2(key, rank);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) ps.blockhist[(size_t)blockIdx.x * nkeys + k] = lhist[k];
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_scan_keys(PathState ps, uint32_t nkeys, uint32_t nblocks) {
+    __shared__ uint32_t total[PT_BLOCK];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < nkeys; k0 += PT_BLOCK) {   // keys in groups of 256
+        uint32_t k = k0 + threadIdx.x, acc = 0;
+        if (k < nkeys)
+            for (uint32_t b = 0; b < nblocks; ++b) { uint32_t h = ps.blockhist[(size_t)b * nkeys + k]; ps.blockhist[(size_t)b * nkeys + k] = acc; acc += h; }
+        total[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = carry;
+            for (uint32_t j = 0; j < PT_BLOCK && k0 + j < nkeys; ++j) { ps.keyoffset[k0 + j] = run; run += total[j]; }
+            carry = run;
         }
+        __syncthreads();
     }
-    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], nrays);
-    if (MODE == 1) wave_count(&ps.counters[MI_CNT_MIS_RAYS], nrays);
-    if (COUNT) {
-        wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : MI_CNT_NODES_MIS], tc.nodes);
-        wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : MI_CNT_TRIS_MIS], tc.tris);
-    }
+    if (threadIdx.x == 0) ps.qcount[QC_SORTED] = carry;
 }
-
-// ---- shadow rays: VisibilityTester::Unoccluded (core/light.cpp:59-61) -> BVHAccel::IntersectP
-template <bool COUNT>
-__global__ void __launch_bounds__(PT_BLOCK) k_anyhit(DevScene sc, PathState ps) {
-    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
-    TravStack st;
-    st.lds = &lds_stack[threadIdx.x];
-    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
-    uint32_t n = ps.qcount[QC_SHADOW];
-    TraceCounters tc = {0, 0};
-    uint32_t nrays = 0;
-    for (ChunkIter it(n); it.more(); it.next()) {
-        uint32_t i = it.item();
-        if (i < n) {
-            uint32_t slot = ps.q_shadow[i];
-            float4 o4 = ps.sh_o[slot], d4 = ps.sh_d[slot];
-            Float t;
-            uint32_t prim;
-            bool occluded = Traverse<true, COUNT>(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, st, &t, &prim, &tc);
-            ++nrays;
-            if (!occluded) {
-                float4 c = ps.sh_c[slot], L = ps.L[slot];
-                L.x += c.x; L.y += c.y; L.z += c.z;
-                ps.L[slot] = L;
-            }
-        }
-    }
-    wave_count(&ps.counters[MI_CNT_SHADOW_RAYS], nrays);
-    if (COUNT) { wave_count(&ps.counters[MI_CNT_NODES_ANY], tc.nodes); wave_count(&ps.counters[MI_CNT_TRIS_ANY], tc.tris); }
-}
-
-// ---- counting sort by material key
-__global__ void k_scan_keys(PathState ps, uint32_t nkeys) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < nkeys; ++k) { ps.keyoffset[k] = acc; acc += ps.keycount[k]; }
-        ps.qcount[QC_SORTED] = acc;
-    }
-}
-__global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin) {
+__global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin, uint32_t nkeys) {
     uint32_t n = ps.qcount[qin];
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
         if (i < n) {
             uint32_t slot = ps.q_ext[qin][i];
             uint2 kr = ps.keyrank[slot];
-            ps.q_sorted[ps.keyoffset[kr.x] + kr.y] = slot;
+            ps.q_sorted[ps.keyoffset[kr.x] + ps.blockhist[(size_t)blockIdx.x * nkeys + kr.x] + kr.y] = slot;
         }
     }
 }
@@ -347,6 +407,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
             smp.dimension = (int)s4.z;
             smp.px = smp.py = 0;   // only dimensions 0/1 (camera sample) look at the pixel
+            // the (at most) 8 sample dimensions this vertex can consume: light pick, uLight, uScattering, BSDF, RR
+            Float us[8];
+            SobolBatch<8>(sc, smp.index, smp.dimension, us);
+            int ui = 0;
             ++nseg;
             bool found = hr.x != MISS_PRIM;
             // path.cpp:91-101: emitted light at the vertex / from the environment
@@ -378,7 +442,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
                     BSDF bsdf(isect, &sc.materials[matIdx]);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
-                        Float ul = smp.Get1D(sc);
+                        Float ul = us[ui++];
                         // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411)
                         int size = (int)sc.n_lights + 1, first = 0, len = size;
                         while (len > 0) {
@@ -389,8 +453,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
                         Float selPdf = (sc.light_func_int > 0) ? sc.light_func[lightNum] / (sc.light_func_int * (int)sc.n_lights) : 0;
                         if (selPdf != 0) {
                             Float uL0, uL1, uS0, uS1;
-                            smp.Get2D(sc, &uL0, &uL1);
-                            smp.Get2D(sc, &uS0, &uS1);
+                            uL0 = us[ui]; uL1 = us[ui + 1]; uS0 = us[ui + 2]; uS1 = us[ui + 3];
+                            ui += 4;
                             // ---- EstimateDirect (core/integrator.cpp:108-215), handleMedia=false, specular=false
                             const mi_light &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
@@ -444,7 +508,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
                     V3 wo = -rd, wi;
                     Float pdf, u0, u1;
                     int flags;
-                    smp.Get2D(sc, &u0, &u1);
+                    u0 = us[ui]; u1 = us[ui + 1];
+                    ui += 2;
                     RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
                     if (!(f.IsBlack() || pdf == 0.f)) {
                         beta = beta * (f * AbsDot(wi, isect.ns) / pdf);
@@ -459,7 +524,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
                         RGB rrBeta = beta * etaScale;
                         if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
                             Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
-                            if (smp.Get1D(sc) < q) cont = false;
+                            if (us[ui++] < q) cont = false;
                             else beta = beta / (1 - q);
                         }
                         if (cont) {
@@ -472,7 +537,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, u
                 }
             }
             ps.L[slot] = make_float4(L.r, L.g, L.b, 0);
-            if (cont) ps.smp[slot] = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16));
+            if (cont) ps.smp[slot] = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
         }
         uint32_t pos = wave_append(&ps.qcount[qout], cont);
         if (cont) ps.q_ext[qout][pos] = slot;
@@ -845,6 +910,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == MI_LIGHT_INFINITE) inf.push_back((int32_t)i);
     { DevBuf &b = next(); if (upload(c, b, inf.data(), inf.size() * 4)) return -1; sc.infinite_lights = b.as<int32_t>(); }
     { DevBuf &b = next(); if (upload(c, b, kSobolMatrices32, sizeof(kSobolMatrices32))) return -1; sc.sobol32 = b.as<uint32_t>(); }
+    {
+        std::vector<uint32_t> T((size_t)PBRT_AMD_SOBOL_NCOL * PT_SOBOLT_STRIDE, 0u);
+        for (int dmn = 0; dmn < PBRT_AMD_SOBOL_NDIM; ++dmn)
+            for (int i = 0; i < PBRT_AMD_SOBOL_NCOL; ++i) T[(size_t)i * PT_SOBOLT_STRIDE + dmn] = kSobolMatrices32[dmn * PBRT_AMD_SOBOL_NCOL + i];
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_sobolT), T.data(), T.size() * 4));
+    }
     { DevBuf &b = next(); if (upload(c, b, kVdCSobolMatrices, sizeof(kVdCSobolMatrices))) return -1; sc.vdc = b.as<uint64_t>(); }
     { DevBuf &b = next(); if (upload(c, b, kVdCSobolMatricesInv, sizeof(kVdCSobolMatricesInv))) return -1; sc.vdc_inv = b.as<uint64_t>(); }
     sc.n_infinite = (uint32_t)inf.size();
@@ -861,12 +932,18 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.max_depth = d->integrator.max_depth; sc.spp = d->integrator.spp;
     sc.sobol_resolution = d->integrator.sobol_resolution; sc.sobol_log2_resolution = d->integrator.sobol_log2_resolution;
     sc.rr_threshold = d->integrator.rr_threshold;
+    {
+        int sppBits = 0;
+        while ((1 << sppBits) < sc.spp) ++sppBits;
+        sc.sobol_index_bits = std::min(PBRT_AMD_SOBOL_NCOL, 2 * sc.sobol_log2_resolution + sppBits);
+    }
     if (sc.sobol_log2_resolution > PBRT_AMD_SOBOL_NRES) return fail("mi_scene_upload: image too large for the Sobol' tables");
     if (sc.sample_max[0] - sc.sample_min[0] > 65535 || sc.sample_max[1] - sc.sample_min[1] > 65535)
         return fail("mi_scene_upload: sample bounds exceed 65535 pixels per axis");
     // worst-case Sobol' dimensions: 5 camera + 8 per bounce (the reference LOG(FATAL)s past 1024, sobol.cpp:48-51)
     if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
     c->nkeys = d->n_materials + 2;
+    if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
     // film
     c->filmPixels = (int64_t)std::max(0, sc.crop_max[0] - sc.crop_min[0]) * std::max(0, sc.crop_max[1] - sc.crop_min[1]);
     if (c->film.alloc((size_t)c->filmPixels * sizeof(float4))) return -1;
@@ -901,7 +978,8 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(q_ext[0], uint32_t, cap); ALLOC(q_ext[1], uint32_t, cap); ALLOC(q_shadow, uint32_t, cap); ALLOC(q_mis, uint32_t, cap);
     ALLOC(q_sorted, uint32_t, cap);
     ALLOC(qcount, uint32_t, QC_COUNT);
-    ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys);
+    ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, 8);
+    ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * c->nkeys);
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
     ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * ps.spill_per_thread);
 #undef ALLOC
@@ -949,27 +1027,30 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     int iter = 0;
     while (true) {
         uint32_t qout = qin ^ 1;
-        HIP_TRY(hipMemsetAsync(ps.keycount, 0, c->nkeys * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(ps.qcount + qout, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(ps.qcount + QC_SHADOW, 0, 2 * sizeof(uint32_t), st));   // shadow + mis
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_CLOSEST);
-        if (countWork) hipLaunchKernelGGL((k_closest<0, true>), grid, block, 0, st, sc, ps, qin);
-        else hipLaunchKernelGGL((k_closest<0, false>), grid, block, 0, st, sc, ps, qin);
+        if (countWork) hipLaunchKernelGGL((k_trace<0, true>), grid, block, 0, st, sc, ps, qin);
+        else hipLaunchKernelGGL((k_trace<0, false>), grid, block, 0, st, sc, ps, qin);
         toc(c);
         tic(c, MI_K_SORT);
-        hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(64), 0, st, ps, c->nkeys);
-        hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin);
+        hipLaunchKernelGGL(k_keycount, grid, block, c->nkeys * sizeof(uint32_t), st, sc, ps, qin, c->nkeys);
+        hipLaunchKernelGGL(k_scan_keys, dim3(1), block, 0, st, ps, c->nkeys, (uint32_t)c->gridBlocks);
+        hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
         tic(c, MI_K_SHADE);
         hipLaunchKernelGGL(k_shade, grid, block, 0, st, sc, ps, qout);
         toc(c);
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
-        if (countWork) hipLaunchKernelGGL((k_anyhit<true>), grid, block, 0, st, sc, ps);
-        else hipLaunchKernelGGL((k_anyhit<false>), grid, block, 0, st, sc, ps);
+        if (countWork) hipLaunchKernelGGL((k_trace<2, true>), grid, block, 0, st, sc, ps, qin);
+        else hipLaunchKernelGGL((k_trace<2, false>), grid, block, 0, st, sc, ps, qin);
         toc(c);
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_MIS_CLOSEST);
-        if (countWork) hipLaunchKernelGGL((k_closest<1, true>), grid, block, 0, st, sc, ps, qin);
-        else hipLaunchKernelGGL((k_closest<1, false>), grid, block, 0, st, sc, ps, qin);
+        if (countWork) hipLaunchKernelGGL((k_trace<1, true>), grid, block, 0, st, sc, ps, qin);
+        else hipLaunchKernelGGL((k_trace<1, false>), grid, block, 0, st, sc, ps, qin);
         toc(c);
         qin = qout;
         ++iter;

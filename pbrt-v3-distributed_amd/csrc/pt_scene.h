@@ -40,6 +40,7 @@ struct DevScene {
     const float *filter_table;
     const int32_t *infinite_lights; // indices of MI_LIGHT_INFINITE lights
     const uint32_t *sobol32;        // [1024][52] generator matrices (sobol_tables.inc), L2 resident
+    int32_t sobol_index_bits;       // upper bound on the bits of a Sobol' index: 2*log2(resolution) + log2(spp)
     const uint64_t *vdc, *vdc_inv;  // [26][52] pixel <-> index maps
     float light_func_int;
     uint32_t n_tris, n_nodes, n_lights, n_materials, n_infinite;
@@ -76,6 +77,39 @@ PT_DEV Float SobolSampleFloat(const DevScene &sc, uint64_t a, int dimension) {  
     for (int i = dimension * PBRT_AMD_SOBOL_NCOL; a != 0; a >>= 1, i++)
         if (a & 1) v ^= sc.sobol32[i];
     return mn(v * 0x1p-32f, PT_ONE_MINUS_EPS);
+}
+
+// N consecutive dimensions dim0..dim0+N-1 of one Sobol' index in a single sweep over the index bits.
+// Inside a wave all paths normally sit at the same dimension (same bounce history), so the generator words
+// are wave-uniform: one broadcast load per (bit, dimension) instead of 64 divergent dependent ones, and the
+// per-lane work is an AND/XOR.  Values are bit-identical to SobolSampleFloat (same XOR set).
+#define PT_SOBOLT_STRIDE (PBRT_AMD_SOBOL_NDIM + 16)
+// transposed generator matrices [bit][dimension] in the constant address space: with a wave-uniform
+// dimension the words come through the scalar cache (s_load), off the vector memory pipe
+__constant__ uint32_t c_sobolT[PBRT_AMD_SOBOL_NCOL * PT_SOBOLT_STRIDE];
+template <int N>
+PT_DEV void SobolBatch(const DevScene &sc, uint64_t index, int dim0, Float *out) {
+    uint32_t v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0;
+    int d0 = __builtin_amdgcn_readfirstlane(dim0);
+    if (__all(dim0 == d0)) {
+        const uint32_t *row = c_sobolT + d0;
+        for (int i = 0; i < sc.sobol_index_bits; ++i, row += PT_SOBOLT_STRIDE) {
+            uint32_t mask = 0u - ((uint32_t)(index >> i) & 1u);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] ^= row[k] & mask;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            uint64_t a = index;
+            for (int i = (dim0 + k) * PBRT_AMD_SOBOL_NCOL; a != 0; a >>= 1, i++)
+                if (a & 1) v[k] ^= sc.sobol32[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = mn(v[k] * 0x1p-32f, PT_ONE_MINUS_EPS);
 }
 
 struct Sampler {   // GlobalSampler/SobolSampler state per path (core/sampler.cpp:136-195, samplers/sobol.cpp:42-59)
@@ -216,68 +250,90 @@ struct TravStack {
     }
 };
 
-// Closest hit (ANY == false; BVHAccel::Intersect bvh.cpp:662-700) or any hit (ANY == true;
-// BVHAccel::IntersectP :702-738).  Returns hit/occluded; *tHit,*primHit valid for closest hits.
+// Traversal as a per-lane state machine, so that a wave can keep its lanes busy with DIFFERENT rays at
+// different stages (persistent lanes with dynamic ray fetch, see k_trace): `cur` is the next thing to
+// look at -- an interior BVH4 node, a leaf reference, or TRAV_DONE.
+// Closest hit (ANY == false) follows BVHAccel::Intersect (accelerators/bvh.cpp:662-700), any hit
+// (ANY == true) BVHAccel::IntersectP (:702-738); `prim` != MISS marks a hit / an occlusion.
+#define TRAV_DONE 0xFFFFFFFFu
+#define TRAV_MISS 0xFFFFFFFFu
+struct TravState {
+    V3 o, d, invDir;
+    Float tMax, tHit;
+    uint32_t prim, cur;
+    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+        o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
+        invDir = V3(1 / d.x, 1 / d.y, 1 / d.z);
+        st.sp = 0;
+        cur = sc.n_nodes ? 0u : TRAV_DONE;   // the root is always an interior BVH4 node
+    }
+    PT_DEV bool done() const { return cur == TRAV_DONE; }
+    PT_DEV bool atLeaf() const { return cur != TRAV_DONE && (cur & BVH4_LEAF); }
+    PT_DEV bool atNode() const { return !(cur & BVH4_LEAF); }
+};
+
+// one interior-node step: fetch the 128-byte node, test its four boxes, go to the nearest hit child and
+// push the others far-to-near
+template <bool COUNT>
+PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
+    const BVH4Node *node = sc.nodes + ts.cur;
+    const float4 *n4 = reinterpret_cast<const float4 *>(node);
+    float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5];
+    uint4 ch = *reinterpret_cast<const uint4 *>(node->child);
+    if (COUNT) ++cnt->nodes;
+    bool negx = ts.invDir.x < 0, negy = ts.invDir.y < 0, negz = ts.invDir.z < 0;
+    Float t0, t1, t2, t3;
+    bool h0 = ch.x != BVH4_EMPTY && SlabTest(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t0);
+    bool h1 = ch.y != BVH4_EMPTY && SlabTest(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t1);
+    bool h2 = ch.z != BVH4_EMPTY && SlabTest(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t2);
+    bool h3 = ch.w != BVH4_EMPTY && SlabTest(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t3);
+    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    if (!h0) t0 = PT_INFINITY;
+    if (!h1) t1 = PT_INFINITY;
+    if (!h2) t2 = PT_INFINITY;
+    if (!h3) t3 = PT_INFINITY;
+#define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
+    PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+    int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (nh == 0) { ts.cur = st.sp ? st.pop() : TRAV_DONE; return; }
+    if (nh > 3) st.push(c3);
+    if (nh > 2) st.push(c2);
+    if (nh > 1) st.push(c1);
+    ts.cur = c0;
+}
+
+// one leaf step: test the leaf's triangles in primitive order (ties at equal t: the later one wins, as in
+// the reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261)
+template <bool ANY, bool COUNT>
+PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
+    uint32_t first = ts.cur & BVH4_FIRST_MASK, n = ((ts.cur >> 27) & 0xfu) + 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 p0, p1, p2;
+        uint32_t flags;
+        LoadTri(sc, first + i, &p0, &p1, &p2, &flags);
+        if (COUNT) ++cnt->tris;
+        TriHit th;
+        if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.d, ts.tMax, &th)) {
+            ts.prim = first + i;
+            ts.tHit = th.t;
+            if (ANY) { ts.cur = TRAV_DONE; return; }
+            ts.tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
+        }
+    }
+    ts.cur = st.sp ? st.pop() : TRAV_DONE;
+}
+
+// plain per-ray loop (stage-level entry points)
 template <bool ANY, bool COUNT>
 PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit,
                      TraceCounters *cnt) {
-    if (sc.n_nodes == 0) return false;
-    V3 invDir(1 / d.x, 1 / d.y, 1 / d.z);
-    bool negx = invDir.x < 0, negy = invDir.y < 0, negz = invDir.z < 0;
-    bool hit = false;
-    st.sp = 0;
-    uint32_t cur = 0;   // root is always an interior BVH4 node
-    while (true) {
-        if (!(cur & BVH4_LEAF)) {
-            const BVH4Node *node = sc.nodes + cur;
-            const float4 *n4 = reinterpret_cast<const float4 *>(node);
-            float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5];
-            uint4 ch = *reinterpret_cast<const uint4 *>(node->child);
-            if (COUNT) ++cnt->nodes;
-            Float t0, t1, t2, t3;
-            bool h0 = ch.x != BVH4_EMPTY && SlabTest(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, o, invDir, negx, negy, negz, tMax, &t0);
-            bool h1 = ch.y != BVH4_EMPTY && SlabTest(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, o, invDir, negx, negy, negz, tMax, &t1);
-            bool h2 = ch.z != BVH4_EMPTY && SlabTest(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, o, invDir, negx, negy, negz, tMax, &t2);
-            bool h3 = ch.w != BVH4_EMPTY && SlabTest(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, o, invDir, negx, negy, negz, tMax, &t3);
-            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-            if (!h0) t0 = PT_INFINITY;
-            if (!h1) t1 = PT_INFINITY;
-            if (!h2) t2 = PT_INFINITY;
-            if (!h3) t3 = PT_INFINITY;
-            // sort the (up to four) hits by entry distance: 5-comparator network on (t, c)
-#define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
-            PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
-#undef PT_CSWAP
-            int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-            if (nh == 0) {
-                if (st.sp == 0) break;
-                cur = st.pop();
-                continue;
-            }
-            // far ones first onto the stack, nearest becomes current
-            if (nh > 3) st.push(c3);
-            if (nh > 2) st.push(c2);
-            if (nh > 1) st.push(c1);
-            cur = c0;
-        } else {
-            uint32_t first = cur & BVH4_FIRST_MASK, n = ((cur >> 27) & 0xfu) + 1;
-            for (uint32_t i = 0; i < n; ++i) {
-                V3 p0, p1, p2;
-                uint32_t flags;
-                LoadTri(sc, first + i, &p0, &p1, &p2, &flags);
-                if (COUNT) ++cnt->tris;
-                TriHit th;
-                if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, o, d, tMax, &th)) {
-                    if (ANY) return true;
-                    hit = true;
-                    tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
-                    *tHit = th.t;
-                    *primHit = first + i;
-                }
-            }
-            if (st.sp == 0) break;
-            cur = st.pop();
-        }
+    TravState ts;
+    ts.init(sc, o, d, tMax, st);
+    while (!ts.done()) {
+        if (ts.atNode()) TravNodeStep<COUNT>(sc, ts, st, cnt);
+        else TravLeafStep<ANY, COUNT>(sc, ts, st, cnt);
     }
-    return hit;
+    *tHit = ts.tHit; *primHit = ts.prim;
+    return ts.prim != TRAV_MISS;
 }

@@ -5,6 +5,10 @@
 #pragma once
 #include "pt_scene.h"
 
+// big, wave-uniformly-branched routines are real functions (one copy each): keeps the shading kernel's
+// register footprint and code size down compared with inlining them at every BSDF::f/Pdf/Sample_f site
+#define PT_FN __device__ __noinline__
+
 // ------------------------------------------------------------------ SurfaceInteraction (core/interaction.h:94-157)
 struct Isect {
     V3 p, pError, wo, n;   // n = oriented geometric normal
@@ -23,7 +27,7 @@ PT_DEV void TriUVs(const DevScene &sc, uint32_t prim, uint32_t meshFlags, Float 
 
 // Second half of Triangle::Intersect (shapes/triangle.cpp:293-421): build the interaction from the
 // barycentrics the traversal found.  rayD = direction of the ray that hit.
-PT_DEV void BuildIsect(const DevScene &sc, uint32_t prim, const V3 &p0, const V3 &p1, const V3 &p2, const TriHit &th,
+PT_FN void BuildIsect(const DevScene &sc, uint32_t prim, const V3 &p0, const V3 &p1, const V3 &p2, const TriHit &th,
                        const V3 &rayD, Isect *is) {
     uint32_t mflags = sc.meshes[sc.tri_mesh[prim]].flags;
     Float uv[3][2];
@@ -227,7 +231,7 @@ PT_DEV int BxdfFlags(int type) {
 }
 PT_DEV bool Matches(int bxdfFlags, int flags) { return (bxdfFlags & flags) == bxdfFlags; }   // reflection.h:215
 
-PT_DEV RGB BxdfF_unscaled(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+PT_FN RGB BxdfF_unscaled(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
@@ -291,7 +295,7 @@ PT_DEV RGB BxdfF(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     RGB f = BxdfF_unscaled(b, wo, wi);
     return b.scaled ? rgb3(b.scale) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
 }
-PT_DEV Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+PT_FN Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
@@ -321,7 +325,7 @@ PT_DEV Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     }
 }
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
-PT_DEV RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     RGB f;
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
@@ -498,7 +502,7 @@ PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, c
 
 struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
 
-PT_DEV void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Float u0, Float u1, LightSample *ls) {
+PT_FN void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Float u0, Float u1, LightSample *ls) {
     ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
     if (l.type == MI_LIGHT_AREA_TRI) {
         // DiffuseAreaLight::Sample_Li lights/diffuse.cpp:68-81 -> Shape::Sample(ref,u) core/shape.cpp:56-70
@@ -566,7 +570,7 @@ PT_DEV void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Fl
 }
 
 // Light::Pdf_Li
-PT_DEV Float PdfLi(const DevScene &sc, const mi_light &l, const Isect &ref, const V3 &wi) {
+PT_FN Float PdfLi(const DevScene &sc, const mi_light &l, const Isect &ref, const V3 &wi) {
     if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
         V3 o = OffsetRayOrigin(ref.p, ref.pError, ref.n, wi);
         V3 p0, p1, p2;
