@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 HOST_LIB = os.path.join(LIB_DIR, "libpbrt_amd_host.so")
-DEVICE_LIB = os.path.join(LIB_DIR, "libpbrt_amd.so")
+DEVICE_LIB = os.environ.get("PBRT_AMD_DEVICE_LIB", os.path.join(LIB_DIR, "libpbrt_amd.so"))   # env override: kernel-variant A/B runs
 
 MI_CNT_COUNT = 16
 MI_K_COUNT = 8

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -218,11 +219,26 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 //     own ray: up to TRACE_NODE_STEPS interior-node steps, then one leaf step (while-while traversal).
 // MODE 0: path-extension rays -> hit record.  MODE 1: MIS rays of EstimateDirect (core/integrator.cpp:167-213)
 // -> adds f*Li*weight/scatteringPdf.  MODE 2: shadow rays, VisibilityTester::Unoccluded (core/light.cpp:59-61).
+#ifndef TRACE_BATCH
 #define TRACE_BATCH 64u
+#endif
+#ifndef TRACE_REFILL
 #define TRACE_REFILL 16
-#define TRACE_NODE_STEPS 2
+#endif
+#ifndef TRACE_NODE_STEPS
+#define TRACE_NODE_STEPS 8     /* at most this many node steps between two leaf phases */
+#endif
+#ifndef TRACE_LEAF_MIN
+#define TRACE_LEAF_MIN 24      /* run the leaf phase as soon as this many lanes wait at a leaf */
+#endif
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 1   /* __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow */
+#endif
+#ifndef PT_GRID_PER_CU
+#define PT_GRID_PER_CU 6   /* persistent blocks per CU (6 x 24 KiB LDS stacks fit the 160 KiB LDS) */
+#endif
 template <int MODE, bool COUNT>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, PathState ps, uint32_t qin) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
     st.lds = &lds_stack[threadIdx.x];
@@ -273,9 +289,20 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, PathState ps, u
         if (!__any(active)) break;
         const bool mayRefill = segsTried < 8;
         while (true) {
-#pragma unroll 1
-            for (int k = 0; k < TRACE_NODE_STEPS; ++k)
-                if (active && ts.atNode()) TravNodeStep<COUNT>(sc, ts, st, &tc);
+            // node phase: keep stepping through interior nodes while enough lanes still want one (lanes that reached
+            // a leaf or finished wait); then ONE leaf phase for everybody waiting at a leaf.  A leaf step (up to 16
+            // watertight triangle tests) costs several node steps, so it should run with many lanes, not for one.
+            {
+                int guard = 0;
+                while (true) {
+                    bool wantNode = active && ts.atNode();
+                    int nWant = __popcll(__ballot(wantNode));
+                    if (nWant == 0) break;
+                    if (wantNode) TravNodeStep<COUNT>(sc, ts, st, &tc);
+                    int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
+                    if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
+                }
+            }
             if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
@@ -385,7 +412,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin
 }
 
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
-__global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, PathState ps, uint32_t qout) {
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
+#endif
+__global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     uint32_t n = ps.qcount[QC_SORTED];
     uint32_t nseg = 0;
     for (ChunkIter it(n); it.more(); it.next()) {
@@ -737,7 +767,12 @@ struct B4Builder {
     }
     static void clearNode(BVH4Node &nd) {
         std::memset(&nd, 0, sizeof(nd));
-        for (int k = 0; k < 4; ++k) nd.child[k] = BVH4_EMPTY;
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int k = 0; k < 4; ++k) {   // empty slot = inverted infinite box: fails every interval test
+            nd.child[k] = BVH4_EMPTY;
+            nd.lox[k] = nd.loy[k] = nd.loz[k] = inf;
+            nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -inf;
+        }
     }
     // a reference leaf with more than BVH4_LEAF_MAX triangles becomes a small chain of nodes with the leaf's box
     uint32_t leafRef(const mi_bvh2_node &lf, uint32_t first, uint32_t count, int depth) {
@@ -804,7 +839,7 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     c->numCUs = prop.multiProcessorCount;
-    c->gridBlocks = ((c->numCUs * 6 + 7) / 8) * 8;   // 6 x 24 KiB LDS stacks per CU; multiple of 8 for the XCD mapping
+    c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(MI_CNT_COUNT * sizeof(uint64_t))) { delete c; return -1; }

@@ -140,25 +140,31 @@ struct Sampler {   // GlobalSampler/SobolSampler state per path (core/sampler.cp
 // ------------------------------------------------------------------ triangle
 struct TriHit { Float t, b0, b1, b2; };
 
+// Per-ray constants of the watertight test (shapes/triangle.cpp:203-216): the permutation (kz = dimension of
+// largest |d|) and the shear Sx,Sy,Sz depend on the ray only, so a ray computes them once, not per triangle.
+struct RayShear {
+    int kz;
+    Float Sx, Sy, Sz;
+    PT_DEV void init(const V3 &dir) {
+        Float ax = absf(dir.x), ay = absf(dir.y), az = absf(dir.z);
+        kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);   // MaxDimension(Abs(d))
+        Float dx, dy, dz;                                               // Permute(d, kx, ky, kz), kx = kz+1, ky = kx+1 (mod 3)
+        if (kz == 0) { dx = dir.y; dy = dir.z; dz = dir.x; }
+        else if (kz == 1) { dx = dir.z; dy = dir.x; dz = dir.y; }
+        else { dx = dir.x; dy = dir.y; dz = dir.z; }
+        Sx = -dx / dz; Sy = -dy / dz; Sz = 1.f / dz;
+    }
+    PT_DEV V3 permute(const V3 &v) const {
+        return kz == 0 ? V3(v.y, v.z, v.x) : (kz == 1 ? V3(v.z, v.x, v.y) : v);
+    }
+};
+
 // Watertight ray-triangle test: Triangle::Intersect shapes/triangle.cpp:188-291 (through the
 // conservative t > delta_t test).  The per-triangle degeneracy rejection of :308-315 is the
 // TRI_FLAG_REJECT bit.  tMax is the ray's current tMax (accept t == tMax: :258-261).
-PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, const V3 &dir, Float tMax, TriHit *h) {
-    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
-    // kz = MaxDimension(Abs(d)); kx = kz+1, ky = kx+1 (mod 3)
-    Float ax = absf(dir.x), ay = absf(dir.y), az = absf(dir.z);
-    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
-    V3 d;
-    if (kz == 0) {   // (kx,ky,kz) = (1,2,0)
-        d = V3(dir.y, dir.z, dir.x);
-        p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x);
-    } else if (kz == 1) {   // (2,0,1)
-        d = V3(dir.z, dir.x, dir.y);
-        p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y);
-    } else {
-        d = dir;
-    }
-    Float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, const RayShear &rs, Float tMax, TriHit *h) {
+    V3 p0t = rs.permute(p0 - o), p1t = rs.permute(p1 - o), p2t = rs.permute(p2 - o);
+    const Float Sx = rs.Sx, Sy = rs.Sy, Sz = rs.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -196,6 +202,11 @@ PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, 
     h->t = t; h->b0 = b0; h->b1 = b1; h->b2 = b2;
     return true;
 }
+PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, const V3 &dir, Float tMax, TriHit *h) {
+    RayShear rs;
+    rs.init(dir);
+    return TriangleTest(p0, p1, p2, o, rs, tMax, h);
+}
 
 PT_DEV void LoadTri(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, uint32_t *flags) {
     const float4 *tv = sc.tri_verts + 3 * (size_t)prim;
@@ -207,34 +218,34 @@ PT_DEV void LoadTri(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, u
 // ------------------------------------------------------------------ BVH4 traversal
 struct TraceCounters { uint32_t nodes, tris; };
 
-// Robust slab test of Bounds3::IntersectP(ray, invDir, dirIsNeg) core/geometry.h:1412-1438 for one
-// child box; returns entry distance for ordering.
-PT_DEV bool SlabTest(Float lox, Float loy, Float loz, Float hix, Float hiy, Float hiz, const V3 &o, const V3 &invDir,
-                     bool negx, bool negy, bool negz, Float rayTMax, Float *tEntry) {
-    const Float widen = 1 + 2 * gamma_n(3);
-    Float tMin = ((negx ? hix : lox) - o.x) * invDir.x;
-    Float tMax = ((negx ? lox : hix) - o.x) * invDir.x;
-    Float tyMin = ((negy ? hiy : loy) - o.y) * invDir.y;
-    Float tyMax = ((negy ? loy : hiy) - o.y) * invDir.y;
-    tMax *= widen;
-    tyMax *= widen;
-    if (tMin > tyMax || tyMin > tMax) return false;
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    Float tzMin = ((negz ? hiz : loz) - o.z) * invDir.z;
-    Float tzMax = ((negz ? loz : hiz) - o.z) * invDir.z;
-    tzMax *= widen;
-    if (tMin > tzMax || tzMin > tMax) return false;
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
-    *tEntry = tMin;
-    return (tMin < rayTMax) && (tMax > 0);
-}
-
+// Ray-box test.  Reference: Bounds3::IntersectP(ray, invDir, dirIsNeg) core/geometry.h:1412-1438 --
+//   tNear_a = (near_a - o_a) * invDir_a,  tFar_a = ((far_a - o_a) * invDir_a) * (1 + 2 gamma(3)),  accept iff the
+//   three [tNear, tFar] intervals overlap, tEnter < ray.tMax and tExit > 0.
+// The box test only has to be CONSERVATIVE with respect to the reference's (every box the reference enters is
+// entered here; extra boxes cost time, never change the closest hit), so it is evaluated in the cheaper form
+//   tEnter = max3(tNear_x, tNear_y, tNear_z),  tExit = min3(tFar_x, tFar_y, tFar_z),  tFar_a = (far_a - o_a) * invFar_a
+// with invFar_a = invDir_a * (1 + 4 gamma(3)) precomputed per ray: the wider factor covers the one rounding that
+// differs from the reference's two-step product (relative 2^-24 << 2 gamma(3)); max3/min3 ignore a NaN operand
+// (0 * inf on a slab plane) where the reference's comparisons reject, again the conservative side.
+struct RayBox {
+    V3 o, invNear, invFar;
+    uint32_t offNearX, offNearY, offNearZ;   // byte offsets of the near planes inside a BVH4Node (lo or hi array by ray sign)
+    PT_DEV void init(const V3 &o_, const V3 &invDir) {
+        o = o_;
+        invNear = invDir;
+        const Float w = 1 + 4 * gamma_n(3);
+        invFar = V3(invDir.x * w, invDir.y * w, invDir.z * w);
+        offNearX = invDir.x < 0 ? 48u : 0u;
+        offNearY = invDir.y < 0 ? 64u : 16u;
+        offNearZ = invDir.z < 0 ? 80u : 32u;
+    }
+};
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][lane] layout: a
 // lane's entries sit in one bank column, so pushes/pops of a whole wave are conflict free whatever
 // the per-lane depth), deeper entries spill to a per-thread slice of an HBM buffer (rare).
+#ifndef PT_LDS_STACK
 #define PT_LDS_STACK 24
+#endif
 #define PT_BLOCK 256
 struct TravStack {
     uint32_t *lds;        // &stack[0][threadIdx.x]
@@ -258,12 +269,15 @@ struct TravStack {
 #define TRAV_DONE 0xFFFFFFFFu
 #define TRAV_MISS 0xFFFFFFFFu
 struct TravState {
-    V3 o, d, invDir;
+    V3 o, d;
+    RayBox box;
+    RayShear shear;
     Float tMax, tHit;
     uint32_t prim, cur;
     PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
-        invDir = V3(1 / d.x, 1 / d.y, 1 / d.z);
+        box.init(o, V3(1 / d.x, 1 / d.y, 1 / d.z));
+        shear.init(d);
         st.sp = 0;
         cur = sc.n_nodes ? 0u : TRAV_DONE;   // the root is always an interior BVH4 node
     }
@@ -272,26 +286,32 @@ struct TravState {
     PT_DEV bool atNode() const { return !(cur & BVH4_LEAF); }
 };
 
-// one interior-node step: fetch the 128-byte node, test its four boxes, go to the nearest hit child and
-// push the others far-to-near
+// one interior-node step: fetch the 128-byte node (near / far planes picked by address, per ray sign), test its
+// four boxes, go to the nearest hit child and push the others far-to-near.  Empty child slots hold an inverted
+// infinite box, so they fail the interval test without a separate check.
 template <bool COUNT>
 PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
-    const BVH4Node *node = sc.nodes + ts.cur;
-    const float4 *n4 = reinterpret_cast<const float4 *>(node);
-    float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5];
-    uint4 ch = *reinterpret_cast<const uint4 *>(node->child);
+    const char *node = reinterpret_cast<const char *>(sc.nodes + ts.cur);
+    const RayBox &rb = ts.box;
+    float4 nx = *reinterpret_cast<const float4 *>(node + rb.offNearX), fx = *reinterpret_cast<const float4 *>(node + (48u - rb.offNearX));
+    float4 ny = *reinterpret_cast<const float4 *>(node + rb.offNearY), fy = *reinterpret_cast<const float4 *>(node + (80u - rb.offNearY));
+    float4 nz = *reinterpret_cast<const float4 *>(node + rb.offNearZ), fz = *reinterpret_cast<const float4 *>(node + (112u - rb.offNearZ));
+    uint4 ch = *reinterpret_cast<const uint4 *>(node + 96);
     if (COUNT) ++cnt->nodes;
-    bool negx = ts.invDir.x < 0, negy = ts.invDir.y < 0, negz = ts.invDir.z < 0;
     Float t0, t1, t2, t3;
-    bool h0 = ch.x != BVH4_EMPTY && SlabTest(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t0);
-    bool h1 = ch.y != BVH4_EMPTY && SlabTest(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t1);
-    bool h2 = ch.z != BVH4_EMPTY && SlabTest(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t2);
-    bool h3 = ch.w != BVH4_EMPTY && SlabTest(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ts.o, ts.invDir, negx, negy, negz, ts.tMax, &t3);
+    bool h0, h1, h2, h3;
+#define PT_BOX(k, c, tk, hk)                                                                                       \
+    {                                                                                                              \
+        Float e = __builtin_fmaxf(__builtin_fmaxf((nx.c - rb.o.x) * rb.invNear.x, (ny.c - rb.o.y) * rb.invNear.y), \
+                                  (nz.c - rb.o.z) * rb.invNear.z);                                                 \
+        Float x = __builtin_fminf(__builtin_fminf((fx.c - rb.o.x) * rb.invFar.x, (fy.c - rb.o.y) * rb.invFar.y),   \
+                                  (fz.c - rb.o.z) * rb.invFar.z);                                                  \
+        hk = (e <= x) && (e < ts.tMax) && (x > 0);                                                                  \
+        tk = hk ? e : PT_INFINITY;                                                                                 \
+    }
+    PT_BOX(0, x, t0, h0) PT_BOX(1, y, t1, h1) PT_BOX(2, z, t2, h2) PT_BOX(3, w, t3, h3)
+#undef PT_BOX
     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-    if (!h0) t0 = PT_INFINITY;
-    if (!h1) t1 = PT_INFINITY;
-    if (!h2) t2 = PT_INFINITY;
-    if (!h3) t3 = PT_INFINITY;
 #define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
     PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
 #undef PT_CSWAP
@@ -314,7 +334,7 @@ PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
         LoadTri(sc, first + i, &p0, &p1, &p2, &flags);
         if (COUNT) ++cnt->tris;
         TriHit th;
-        if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.d, ts.tMax, &th)) {
+        if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th)) {
             ts.prim = first + i;
             ts.tHit = th.t;
             if (ANY) { ts.cur = TRAV_DONE; return; }
