@@ -83,6 +83,7 @@ def main():
             args.tris, args.res[0], args.res[1], args.spp)
 
     pa = importlib.import_module("pbrt-v3-distributed_amd")
+    par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
     t0 = time.time()
     sc = pa.Scene(scene_file)
     t_load = time.time() - t0
@@ -110,7 +111,7 @@ def main():
         ctx.render(rank=rank, world=world, count_work=count, max_paths=args.max_paths, sync=False)
         if world > 1:
             ctx.sync()   # the ctx stream is not torch's current stream
-            dist.reduce(film_t, dst=0, op=dist.ReduceOp.SUM)
+            par.combine_films(film_t, dst=0)
 
     # ---- one counting pass (deterministic work: node / triangle fetch counts feed the roofline), then warm-up
     ctx.counters_reset()

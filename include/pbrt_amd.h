@@ -256,6 +256,9 @@ typedef struct mi_hit { int32_t prim; float t; float b0, b1, b2; float n[3]; } m
 
 /* BVHAccel::Intersect (bvh.cpp:662-700) + Triangle::Intersect (triangle.cpp:188-425) */
 int mi_intersect(mi_ctx *ctx, const mi_ray *rays, int64_t n, mi_hit *hits);
+/* Triangle::Intersect alone (triangle.cpp:188-425) for n independent (triangle, ray) pairs, no scene needed:
+ * tri9 = 9 floats per triangle (p0 p1 p2); replays the reference's Triangle.* unit-test vectors on the device. */
+int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits);
 /* BVHAccel::IntersectP (bvh.cpp:702-738) */
 int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded);
 /* SobolSampler: GetIndexForSample + SampleDimension (sobol.cpp:42-59) for pixel (px,py),

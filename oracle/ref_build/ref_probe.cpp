@@ -1,0 +1,193 @@
+// ref_probe: links the UNMODIFIED reference objects (oracle/_ref/libpbrt_ref.a) and dumps known-answer
+// vectors from the reference's own classes for tests/golden/ (tools/gen_golden.py runs it).  The ray /
+// triangle sets replay the constructions of the reference's unit tests (src/tests/shapes.cpp
+// Triangle.Watertight :28-129, Triangle.Reintersect :154-205, Triangle.BadCases :544-559; src/tests/sampling.cpp
+// LowDiscrepancy.Sobol :120-136, Distribution1D.Discrete :231-280) with the same RNG seeds.
+// Build infrastructure: includes reference headers from /root/reference, copies nothing into this repo.
+#include <cstdio>
+#include <functional>
+#include <vector>
+
+#include "lowdiscrepancy.h"
+#include "materials/metal.h"
+#include "paramset.h"
+#include "pbrt.h"
+#include "reflection.h"
+#include "rng.h"
+#include "sampling.h"
+#include "samplers/sobol.h"
+#include "shapes/triangle.h"
+#include "sobolmatrices.h"
+
+using namespace pbrt;
+
+static void put(FILE *f, const void *p, size_t n) { fwrite(p, 1, n, f); }
+template <typename T> static void putv(FILE *f, T v) { put(f, &v, sizeof(T)); }
+
+static Float pExp(RNG &rng, Float exp = 8.) {   // tests/shapes.cpp:18-22
+    Float logu = Lerp(rng.UniformFloat(), -exp, exp);
+    return std::pow(10, logu);
+}
+
+// record: p0 p1 p2 (9f) o d (6f) tmax (f) hit (i32) t b0 b1 b2 (4f) n (3f) = 24 words
+static void triRecord(FILE *f, const std::shared_ptr<Shape> &tri, const Point3f v[3], const Ray &r, int32_t *count) {
+    Float tHit = 0;
+    SurfaceInteraction isect;
+    Ray ray(r);
+    bool hit = tri->Intersect(ray, &tHit, &isect, false);
+    for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) putv<float>(f, v[j][k]);
+    for (int k = 0; k < 3; ++k) putv<float>(f, r.o[k]);
+    for (int k = 0; k < 3; ++k) putv<float>(f, r.d[k]);
+    putv<float>(f, r.tMax);
+    putv<int32_t>(f, hit ? 1 : 0);
+    putv<float>(f, hit ? tHit : 0.f);
+    // barycentrics are not exposed; recover them from uv (default uvs (0,0),(1,0),(1,1): u = b1 + b2, v = b2)
+    Float b2 = hit ? isect.uv[1] : 0, b1 = hit ? isect.uv[0] - isect.uv[1] : 0;
+    putv<float>(f, hit ? isect.uv[0] : 0.f); putv<float>(f, hit ? isect.uv[1] : 0.f); putv<float>(f, b1); putv<float>(f, b2);
+    for (int k = 0; k < 3; ++k) putv<float>(f, hit ? isect.n[k] : 0.f);
+    ++*count;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: ref_probe <outdir>\n"); return 1; }
+    std::string dir = argv[1];
+    // ---- Sobol: SobolSampleFloat(i, d) and SobolIntervalToIndex
+    {
+        FILE *f = fopen((dir + "/sobol_samples.bin").c_str(), "wb");
+        const int dims[] = {0, 1, 2, 3, 4, 5, 17, 63, 255, 1023};
+        int32_t n = 0;
+        for (int d : dims)
+            for (int64_t i = 0; i < 2048; i += (d < 2 ? 1 : 7)) { putv<int64_t>(f, i); putv<int32_t>(f, d); putv<float>(f, SobolSampleFloat(i, d, 0)); ++n; }
+        RNG rng(3);
+        for (int k = 0; k < 4000; ++k) {   // big indices
+            int64_t i = (int64_t)(rng.UniformUInt32() & 0x7fffffff) << (rng.UniformUInt32() % 4);
+            int d = rng.UniformUInt32() % 1024;
+            putv<int64_t>(f, i); putv<int32_t>(f, d); putv<float>(f, SobolSampleFloat(i, d, 0)); ++n;
+        }
+        fclose(f);
+        f = fopen((dir + "/sobol_index.bin").c_str(), "wb");
+        for (int k = 0; k < 6000; ++k) {
+            uint32_t m = 1 + rng.UniformUInt32() % 12;
+            uint64_t frame = rng.UniformUInt32() % 4096;
+            int px = rng.UniformUInt32() % (1u << m), py = rng.UniformUInt32() % (1u << m);
+            putv<uint32_t>(f, m); putv<uint64_t>(f, frame); putv<int32_t>(f, px); putv<int32_t>(f, py);
+            putv<uint64_t>(f, SobolIntervalToIndex(m, frame, Point2i(px, py)));
+        }
+        fclose(f);
+        // the sampler class itself: Get1D/Get2D stream for a few pixels (dims 0/1 remapped)
+        f = fopen((dir + "/sobol_sampler.bin").c_str(), "wb");
+        Bounds2i sb(Point2i(0, 0), Point2i(400, 300));
+        SobolSampler s(16, sb);
+        const int px[][2] = {{0, 0}, {1, 0}, {399, 299}, {123, 45}, {256, 256 % 300}};
+        for (auto &p : px) {
+            s.StartPixel(Point2i(p[0], p[1]));
+            int k = 0;
+            do {
+                putv<int32_t>(f, p[0]); putv<int32_t>(f, p[1]); putv<int32_t>(f, k++);
+                for (int d = 0; d < 24; ++d) putv<float>(f, s.Get1D());
+            } while (s.StartNextSample());
+        }
+        fclose(f);
+    }
+    // ---- triangles
+    {
+        FILE *f = fopen((dir + "/triangles.bin").c_str(), "wb");
+        int32_t count = 0;
+        static Transform identity;
+        int indices[3] = {0, 1, 2};
+        // Triangle.BadCases (known answer: miss)
+        {
+            Point3f p[3] = {Point3f(-1113.45459, -79.049614, -56.2431908), Point3f(-1113.45459, -87.0922699, -56.2431908),
+                            Point3f(-1113.45459, -79.2090149, -56.2431908)};
+            auto mesh = CreateTriangleMesh(&identity, &identity, false, 1, indices, 3, p, nullptr, nullptr, nullptr, nullptr, nullptr);
+            Ray ray(Point3f(-1081.47925, 99.9999542, 87.7701111), Vector3f(-32.1072998, -183.355865, -144.607635), 0.9999);
+            triRecord(f, mesh[0], p, ray, &count);
+        }
+        // Triangle.Reintersect-style: random triangles with coordinates 10^+-8, rays toward a sampled point,
+        // then rays spawned from the hit point (expected: no re-intersection)
+        for (int i = 0; i < 1000; ++i) {
+            RNG rng(i);
+            Point3f v[3];
+            for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) v[j][k] = pExp(rng);
+            if ((Cross(v[1] - v[0], v[2] - v[0]).LengthSquared()) < 1e-20) continue;
+            auto triVec = CreateTriangleMesh(&identity, &identity, false, 1, indices, 3, v, nullptr, nullptr, nullptr, nullptr, nullptr);
+            Point2f u(rng.UniformFloat(), rng.UniformFloat());
+            Float pdf;
+            Interaction pTri = triVec[0]->Sample(u, &pdf);
+            Point3f o;
+            for (int j = 0; j < 3; ++j) o[j] = pExp(rng);
+            Ray r(o, pTri.p - o);
+            triRecord(f, triVec[0], v, r, &count);
+            Float tHit;
+            SurfaceInteraction isect;
+            if (!triVec[0]->Intersect(r, &tHit, &isect, false)) continue;
+            for (int j = 0; j < 6; ++j) {
+                Point2f u2(rng.UniformFloat(), rng.UniformFloat());
+                Vector3f w = UniformSampleSphere(u2);
+                Ray rOut = isect.SpawnRay(w);
+                triRecord(f, triVec[0], v, rOut, &count);
+                Point3f p2;
+                for (int k = 0; k < 3; ++k) p2[k] = pExp(rng);
+                rOut = isect.SpawnRayTo(p2);
+                triRecord(f, triVec[0], v, rOut, &count);
+            }
+        }
+        // Watertight-style: rays aimed exactly at vertices / edge midpoints of moderate-size triangles
+        for (int i = 0; i < 1500; ++i) {
+            RNG rng(5000 + i);
+            Point3f v[3];
+            for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) v[j][k] = Lerp(rng.UniformFloat(), -10, 10);
+            if ((Cross(v[1] - v[0], v[2] - v[0]).LengthSquared()) < 1e-20) continue;
+            auto triVec = CreateTriangleMesh(&identity, &identity, false, 1, indices, 3, v, nullptr, nullptr, nullptr, nullptr, nullptr);
+            Point3f o;
+            for (int k = 0; k < 3; ++k) o[k] = Lerp(rng.UniformFloat(), -10, 10);
+            int which = rng.UniformUInt32() % 6;
+            Point3f target = which < 3 ? v[which] : Point3f((v[which - 3] + v[(which - 2) % 3]) * 0.5f);
+            Ray r(o, target - o);
+            triRecord(f, triVec[0], v, r, &count);
+            Ray r2(o, Normalize(target - o));
+            triRecord(f, triVec[0], v, r2, &count);
+        }
+        fclose(f);
+        fprintf(stderr, "ref_probe: %d triangle records\n", count);
+    }
+    // ---- Distribution1D::SampleDiscrete (sampling.h:90-100)
+    {
+        FILE *f = fopen((dir + "/distribution1d.bin").c_str(), "wb");
+        RNG rng(9);
+        for (int trial = 0; trial < 8; ++trial) {
+            int n = 1 + (int)(rng.UniformUInt32() % 40);
+            std::vector<Float> func(n);
+            for (auto &x : func) x = rng.UniformFloat() < 0.2 ? 0.f : rng.UniformFloat() * 10;
+            Distribution1D d(&func[0], n);
+            putv<int32_t>(f, n);
+            for (auto x : func) putv<float>(f, x);
+            for (auto x : d.cdf) putv<float>(f, x);
+            putv<float>(f, d.funcInt);
+            putv<int32_t>(f, 64);
+            for (int k = 0; k < 64; ++k) {
+                Float u = k < 60 ? rng.UniformFloat() : (k - 60) / 4.f;
+                Float pdf;
+                int idx = d.SampleDiscrete(u, &pdf);
+                putv<float>(f, u); putv<int32_t>(f, idx); putv<float>(f, pdf);
+            }
+        }
+        fclose(f);
+    }
+    // ---- default copper eta / k of MetalMaterial as RGB (materials/metal.cpp:81-118)
+    {
+        ParamSet empty;
+        std::map<std::string, std::shared_ptr<Texture<Float>>> ft;
+        std::map<std::string, std::shared_ptr<Texture<Spectrum>>> st;
+        TextureParams tp(empty, empty, ft, st);
+        std::unique_ptr<MetalMaterial> m(CreateMetalMaterial(tp));
+        SurfaceInteraction si(Point3f(0, 0, 0), Vector3f(), Point2f(), Vector3f(0, 0, 1), Vector3f(1, 0, 0), Vector3f(0, 1, 0), Normal3f(),
+                              Normal3f(), 0, nullptr);
+        MemoryArena arena;
+        m->ComputeScatteringFunctions(&si, arena, TransportMode::Radiance, true);
+        FILE *f = fopen((dir + "/copper.txt").c_str(), "w");
+        fprintf(f, "%s\n", si.bsdf->ToString().c_str());
+        fclose(f);
+    }
+    return 0;
+}

@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_intersect", "mi_triangle_intersect", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -101,6 +101,7 @@ def device_lib():
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mi_triangle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_sobol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.mi_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -264,6 +265,17 @@ class Context:
         out = np.zeros((n, 3), dtype=np.float32)
         self._chk(device_lib().mi_li(self._ctx, _ptr(pixels_xy), _ptr(sample_num), n, _ptr(out)), "mi_li")
         return out
+
+
+def triangle_intersect(tri9, rays, device=0):
+    """Device Triangle::Intersect for independent (triangle, ray) pairs (no scene)."""
+    tri9 = np.ascontiguousarray(tri9, dtype=np.float32).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+    hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+    L = device_lib()
+    if L.mi_triangle_intersect(device, _ptr(tri9), _ptr(rays), len(rays), _ptr(hits)) != 0:
+        raise RuntimeError("mi_triangle_intersect: %s" % L.mi_last_error().decode())
+    return hits
 
 
 def read_pfm(path):

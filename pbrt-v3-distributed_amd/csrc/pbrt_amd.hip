@@ -669,6 +669,27 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathS
         }
     }
 }
+__global__ void k_stage_triangles(const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *t = tri9 + 9 * i;
+    V3 p0(t[0], t[1], t[2]), p1(t[3], t[4], t[5]), p2(t[6], t[7], t[8]);
+    mi_ray r = rays[i];
+    V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
+    mi_hit h;
+    h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
+    TriHit th;
+    // + the per-triangle degeneracy rejection (triangle.cpp:308-315; default uvs) the scene path precomputes
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    V3 dpdu = (-1.f * dp02 - -1.f * dp12) * 1.f, dpdv = (-0.f * dp02 + -1.f * dp12) * 1.f;
+    bool reject = Cross(dpdu, dpdv).LengthSquared() == 0 && Cross(p2 - p0, p1 - p0).LengthSquared() == 0;
+    if (!reject && TriangleTest(p0, p1, p2, o, d, r.tmax, &th)) {
+        h.prim = 0; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
+        V3 n = Normalize(Cross(dp02, dp12));
+        h.n[0] = n.x; h.n[1] = n.y; h.n[2] = n.z;
+    }
+    hits[i] = h;
+}
 __global__ void k_stage_sobol(DevScene sc, int px, int py, int n_samples, int n_dims, float *out, unsigned long long *index_out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_samples * n_dims) return;
@@ -1222,6 +1243,20 @@ int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
     HIP_TRY(hipMemcpyAsync(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     dr.release(); dh.release();
+    return 0;
+}
+int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits) {
+    if (n <= 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("mi_triangle_intersect: no HIP device available");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    DevBuf dt, dr, dh;
+    if (dt.alloc((size_t)n * 36) || dr.alloc((size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_hit))) return -1;
+    HIP_TRY(hipMemcpy(dt.p, tri9, (size_t)n * 36, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, rays, (size_t)n * sizeof(mi_ray), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_triangles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dt.as<float>(), dr.as<mi_ray>(), n, dh.as<mi_hit>());
+    HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost));
+    dt.release(); dr.release(); dh.release();
     return 0;
 }
 int mi_intersect_p(mi_ctx *c, const mi_ray *rays, int64_t n, uint8_t *occluded) {

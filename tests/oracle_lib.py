@@ -35,6 +35,11 @@ def lib():
         L.oracle_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_render_sharded.restype = C.c_double
+        L.oracle_render_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.oracle_sample_discrete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p]
+        L.oracle_distribution1d.restype = C.c_float
+        L.oracle_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_render.restype = C.c_double
         L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
@@ -45,12 +50,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def render(scene, spp_begin=0, spp_end=-1, nthreads=0, tiles=None):
-    """-> (rgbw (H,W,4), counters dict, seconds)"""
+def render(scene, spp_begin=0, spp_end=-1, nthreads=0, tiles=None, rank=0, world=1):
+    """-> (rgbw (H,W,4), counters dict, seconds); rank/world: only the tiles mi_render gives that rank"""
     rgbw = np.zeros((scene.height, scene.width, 4), dtype=np.float32)
     cnt = np.zeros(8, dtype=np.uint64)
     t = None if tiles is None else np.asarray(tiles, dtype=np.int32)
-    secs = lib().oracle_render(scene.desc, _p(rgbw), spp_begin, spp_end, nthreads, _p(cnt), _p(t) if t is not None else None)
+    secs = lib().oracle_render_sharded(scene.desc, _p(rgbw), spp_begin, spp_end, nthreads, _p(cnt), _p(t) if t is not None else None, rank, world)
     names = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any", "tris_any"]
     return rgbw, dict(zip(names, [int(v) for v in cnt[:7]])), secs
 
@@ -104,6 +109,20 @@ def triangle_intersect(p0, p1, p2, o, d, tmax=np.inf):
     v = [np.ascontiguousarray(x, dtype=np.float32) for x in (p0, p1, p2)]
     hit = lib().oracle_triangle_intersect(_p(v[0]), _p(v[1]), _p(v[2]), _p(ray), C.byref(t), _p(b))
     return bool(hit), t.value, b
+
+
+def distribution1d(func):
+    func = np.ascontiguousarray(func, dtype=np.float32)
+    cdf = np.zeros(len(func) + 1, dtype=np.float32)
+    fi = lib().oracle_distribution1d(_p(func), len(func), _p(cdf))
+    return cdf, float(fi)
+
+
+def sample_discrete(func, cdf, func_int, u):
+    func = np.ascontiguousarray(func, dtype=np.float32); cdf = np.ascontiguousarray(cdf, dtype=np.float32)
+    pdf = C.c_float(0)
+    idx = lib().oracle_sample_discrete(_p(func), _p(cdf), func_int, len(func), u, C.byref(pdf))
+    return idx, pdf.value
 
 
 def have_ref():

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref/pbrt_ref + ref_probe, built from /root/reference by
+oracle/ref_build/Makefile).  Run here (where /root/reference exists); the fixtures are committed because the reference
+cannot travel to the GPU box.
+
+  golden/ref_vectors.npz    known-answer vectors from the reference's own classes (Sobol, SobolSampler, Triangle::Intersect
+                            on the unit-test ray constructions, Distribution1D::SampleDiscrete)
+  golden/<scene>_<res>_<spp>spp.pfm   reference renders (float32, lossless) of the small parity scenes
+"""
+import os, subprocess, sys, tempfile
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    subprocess.check_call([os.path.join(REF, "ref_probe"), tmp])
+    ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
+    si = np.fromfile(os.path.join(tmp, "sobol_index.bin"), dtype=np.dtype([("m", "<u4"), ("frame", "<u8"), ("px", "<i4"), ("py", "<i4"), ("idx", "<u8")]))
+    sp = np.fromfile(os.path.join(tmp, "sobol_sampler.bin"), dtype=np.dtype([("px", "<i4"), ("py", "<i4"), ("s", "<i4"), ("u", "<f4", 24)]))
+    tri = np.fromfile(os.path.join(tmp, "triangles.bin"), dtype=np.dtype([("p", "<f4", 9), ("o", "<f4", 3), ("d", "<f4", 3), ("tmax", "<f4"), ("hit", "<i4"),
+                                                                           ("t", "<f4"), ("uv", "<f4", 2), ("b1", "<f4"), ("b2", "<f4"), ("n", "<f4", 3)]))
+    keep = np.zeros(len(tri), dtype=bool); keep[0] = True; keep[1::4] = True   # BadCases record + every 4th
+    tri = tri[keep]
+    raw = np.fromfile(os.path.join(tmp, "distribution1d.bin"), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, triangles=tri, distribution1d=raw)
+    print("ref_vectors.npz:", len(ss), "sobol samples,", len(si), "indices,", len(sp), "sampler rows,", len(tri), "triangle records")
+
+    scenes = [("cornell", 64, 64, 1), ("cornell", 64, 64, 8), ("materials", 96, 72, 1), ("materials", 96, 72, 16)]
+    for name, w, h, spp in scenes:
+        text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
+        import re
+        text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
+        text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+        f = os.path.join(tmp, "s.pbrt"); open(f, "w").write(text)
+        out = os.path.join(OUT, "%s_%dx%d_%dspp.pfm" % (name, w, h, spp))
+        subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--outfile", out, f])
+        print("rendered", out)
+
+
+def scene_text(name, w, h, spp):
+    """the same scene edits as above, for the tests"""
+    import re
+    text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
+    text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
+    return re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+
+
+if __name__ == "__main__":
+    main()
