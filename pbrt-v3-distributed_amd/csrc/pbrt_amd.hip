@@ -28,17 +28,32 @@
 #include "sobol_tables.inc"
 
 // ============================================================================ device side
+// Per-path state is array-of-structures, one 128-byte cache line per path (+ one for the two NEE rays): after the
+// material sort a wave's paths are scattered over the slot range, and with a structure-of-arrays layout every 16-byte
+// field access dragged in a full line of which 7/8 went unused (measured: k_shade missed L2 on 68 % of its requests
+// and moved ~4 TB/s for ~0.6 TB/s of payload).  With AoS a lane's loads all land in the one or two lines it owns.
+struct __attribute__((aligned(128))) PathRec {
+    float4 ray_o, ray_d;       // o.xyz,tMax | d.xyz,-
+    float4 beta;               // rgb, etaScale
+    float4 L;                  // rgb, -
+    uint4 smp;                 // sobol index lo, hi, dimension, bounces | specularBounce << 16
+    uint2 hit;                 // prim (0xffffffff = miss), t bits
+    float2 pfilm;
+    uint32_t pixel;            // sample-space pixel x | y << 16, 0xffffffff = inactive
+    uint32_t pad0;
+    uint2 pad1;
+    float4 pad2;
+};
+struct __attribute__((aligned(128))) NeeRec {
+    float4 sh_o, sh_d, sh_c;   // shadow ray: o.xyz,tMax | d | contribution rgb
+    float4 mi_o, mi_d, mi_c;   // MIS ray: o | d.xyz,lightNum | contribution rgb
+    float4 pad[2];
+};
 struct PathState {
-    float4 *ray_o, *ray_d;     // o.xyz,tMax | d.xyz,-
-    uint2 *hit;                // prim (0xffffffff = miss), t bits
-    float4 *beta;              // rgb, etaScale
-    float4 *L;                 // rgb, -
-    uint4 *smp;                // sobol index lo, hi, dimension, bounces | specularBounce << 16
-    float2 *pfilm;
-    uint32_t *pixel;           // film pixel x | y << 16 (sample-space coords), 0xffffffff = inactive
-    float4 *sh_o, *sh_d, *sh_c;   // shadow ray: o.xyz,tMax | d | contribution rgb
-    float4 *mi_o, *mi_d, *mi_c;   // MIS ray: o | d.xyz,lightNum | contribution rgb
-    uint2 *keyrank;
+    PathRec *rec;
+    NeeRec *nee;
+    uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
+    uint2 *keyrank;            // because the sort kernels walk them in queue order, not per path
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
     uint32_t *qcount;          // [0],[1] extension queues, [2] shadow, [3] mis, [4] sorted total
     uint32_t *keycount, *keyoffset;
@@ -187,8 +202,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
             }
         }
         if (i < n) {
-            ps.L[i] = make_float4(0, 0, 0, 0);
-            ps.pixel[i] = active ? ((uint32_t)(x - sc.sample_min[0]) | ((uint32_t)(y - sc.sample_min[1]) << 16)) : INACTIVE_PIXEL;
+            ps.rec[i].L = make_float4(0, 0, 0, 0);
+            ps.rec[i].pixel = active ? ((uint32_t)(x - sc.sample_min[0]) | ((uint32_t)(y - sc.sample_min[1]) << 16)) : INACTIVE_PIXEL;
         }
         if (active) {
             Sampler smp;
@@ -196,11 +211,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
             V3 o, d;
             Float tMax, pfx, pfy;
             GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy);
-            ps.ray_o[i] = make_float4(o.x, o.y, o.z, tMax);
-            ps.ray_d[i] = make_float4(d.x, d.y, d.z, 0);
-            ps.beta[i] = make_float4(1, 1, 1, 1);
-            ps.smp[i] = make_uint4((uint32_t)smp.index, (uint32_t)(smp.index >> 32), (uint32_t)smp.dimension, 0);
-            ps.pfilm[i] = make_float2(pfx, pfy);
+            ps.rec[i].ray_o = make_float4(o.x, o.y, o.z, tMax);
+            ps.rec[i].ray_d = make_float4(d.x, d.y, d.z, 0);
+            ps.rec[i].beta = make_float4(1, 1, 1, 1);
+            ps.rec[i].smp = make_uint4((uint32_t)smp.index, (uint32_t)(smp.index >> 32), (uint32_t)smp.dimension, 0);
+            ps.rec[i].pfilm = make_float2(pfx, pfy);
             ++ncam;
         }
         uint32_t pos = wave_append(&ps.qcount[qout], active);
@@ -274,8 +289,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                 uint32_t rank = (uint32_t)__popcll(idle & ltMask);
                 if (!active && rank < avail) {
                     slot = queue[poolNext + rank];
-                    float4 o4 = MODE == 0 ? ps.ray_o[slot] : (MODE == 1 ? ps.mi_o[slot] : ps.sh_o[slot]);
-                    float4 d4 = MODE == 0 ? ps.ray_d[slot] : (MODE == 1 ? ps.mi_d[slot] : ps.sh_d[slot]);
+                    float4 o4 = MODE == 0 ? ps.rec[slot].ray_o : (MODE == 1 ? ps.nee[slot].mi_o : ps.nee[slot].sh_o);
+                    float4 d4 = MODE == 0 ? ps.rec[slot].ray_d : (MODE == 1 ? ps.nee[slot].mi_d : ps.nee[slot].sh_d);
                     if (MODE == 1) lightNum = __float_as_uint(d4.w);
                     ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
                     active = true;
@@ -306,18 +321,24 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
             if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
-                    ps.hit[slot] = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                    ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                    uint32_t key = sc.n_materials;                                   // escaped rays
+                    if (ts.prim != TRAV_MISS) {
+                        int mat = (int)sc.tri_info[ts.prim].y;
+                        key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;         // null-BSDF surfaces: own bucket
+                    }
+                    ps.key[slot] = key;
                 } else if (MODE == 2) {
                     if (ts.prim == TRAV_MISS) {   // unoccluded: add the light-sampled term
-                        float4 c = ps.sh_c[slot], L = ps.L[slot];
+                        float4 c = ps.nee[slot].sh_c, L = ps.rec[slot].L;
                         L.x += c.x; L.y += c.y; L.z += c.z;
-                        ps.L[slot] = L;
+                        ps.rec[slot].L = L;
                     }
                 } else {
-                    const mi_light &light = sc.lights[lightNum];
+                    const mi_light &light = sc.lights[lightNum].l;
                     RGB Li(0.f);
                     if (ts.prim != TRAV_MISS) {
-                        if (sc.tri_light[ts.prim] == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                        if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
                             V3 p0, p1, p2;
                             uint32_t tf;
                             LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
@@ -330,9 +351,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     } else if (light.type == MI_LIGHT_INFINITE)
                         Li = rgb3(light.L);                   // light.Le(ray)
                     if (!Li.IsBlack()) {
-                        float4 c = ps.mi_c[slot], L = ps.L[slot];
+                        float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
                         L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
-                        ps.L[slot] = L;
+                        ps.rec[slot].L = L;
                     }
                 }
                 active = false;
@@ -366,15 +387,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
         uint32_t slot = 0, key = 0;
         if (active) {
             slot = ps.q_ext[qin][i];
-            uint32_t prim = ps.hit[slot].x;
-            if (prim != MISS_PRIM) {
-                int mat = sc.meshes[sc.tri_mesh[prim]].material;
-                key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;   // null-BSDF surfaces: own bucket
-            } else
-                key = sc.n_materials;                                   // escaped rays
+            key = ps.key[slot];
         }
         uint32_t rank = wave_key_rank(lhist, key, active);
-        if (active) ps.keyrank[slot] = make_uint2(key, rank);
+        if (active) ps.keyrank[i] = make_uint2(key, rank);   // indexed by queue position: k_scatter walks the same chunks
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) ps.blockhist[(size_t)blockIdx.x * nkeys + k] = lhist[k];
@@ -405,17 +421,26 @@ __global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin
         uint32_t i = it.item();
         if (i < n) {
             uint32_t slot = ps.q_ext[qin][i];
-            uint2 kr = ps.keyrank[slot];
+            uint2 kr = ps.keyrank[i];
             ps.q_sorted[ps.keyoffset[kr.x] + ps.blockhist[(size_t)blockIdx.x * nkeys + kr.x] + kr.y] = slot;
         }
     }
 }
 
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
+#ifndef PT_CDF_LDS
+#define PT_CDF_LDS 2048
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
+    // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
+    __shared__ float s_cdf[PT_CDF_LDS];
+    const bool cdfInLds = sc.n_lights + 1 <= PT_CDF_LDS;
+    if (cdfInLds) for (uint32_t k = threadIdx.x; k < sc.n_lights + 1; k += PT_BLOCK) s_cdf[k] = sc.light_cdf[k];
+    __syncthreads();
+    const float *cdf = cdfInLds ? s_cdf : sc.light_cdf;
     uint32_t n = ps.qcount[QC_SORTED];
     uint32_t nseg = 0;
     for (ChunkIter it(n); it.more(); it.next()) {
@@ -425,9 +450,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
         uint32_t slot = 0;
         if (active) {
             slot = ps.q_sorted[i];
-            uint2 hr = ps.hit[slot];
-            float4 o4 = ps.ray_o[slot], d4 = ps.ray_d[slot], b4 = ps.beta[slot], L4 = ps.L[slot];
-            uint4 s4 = ps.smp[slot];
+            uint2 hr = ps.rec[slot].hit;
+            float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
+            uint4 s4 = ps.rec[slot].smp;
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             RGB beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
             Float etaScale = b4.w;
@@ -445,7 +470,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             bool found = hr.x != MISS_PRIM;
             // path.cpp:91-101: emitted light at the vertex / from the environment
             Isect isect;
+            uint4 tinfo = make_uint4(0, 0, 0, 0);
             if (found) {
+                tinfo = sc.tri_info[hr.x];
                 V3 p0, p1, p2;
                 uint32_t tf;
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
@@ -455,18 +482,18 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             }
             if (bounces == 0 || specularBounce) {
                 if (found) {
-                    int li = sc.tri_light[hr.x];
-                    if (li >= 0) { RGB Le = AreaL(sc.lights[li], isect.n, -rd); L = L + beta * Le; }
+                    int li = (int)tinfo.z;
+                    if (li >= 0) { RGB Le = AreaL(sc.lights[li].l, isect.n, -rd); L = L + beta * Le; }
                 } else {
-                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].L);
+                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].l.L);
                 }
             }
             if (found && bounces < sc.max_depth) {
-                int matIdx = sc.meshes[sc.tri_mesh[hr.x]].material;
+                int matIdx = (int)tinfo.y;
                 if (matIdx < 0) {
                     // null BSDF: step through the surface, same bounce count, no sampler use (path.cpp:108-113)
                     V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, rd);
-                    ps.ray_o[slot] = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                    ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                     cont = true;
                 } else {
                     BSDF bsdf(isect, &sc.materials[matIdx]);
@@ -477,7 +504,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                         int size = (int)sc.n_lights + 1, first = 0, len = size;
                         while (len > 0) {
                             int half = len >> 1, middle = first + half;
-                            if (sc.light_cdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
+                            if (cdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
                         }
                         int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
                         Float selPdf = (sc.light_func_int > 0) ? sc.light_func[lightNum] / (sc.light_func_int * (int)sc.n_lights) : 0;
@@ -486,7 +513,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             uL0 = us[ui]; uL1 = us[ui + 1]; uS0 = us[ui + 2]; uS1 = us[ui + 3];
                             ui += 4;
                             // ---- EstimateDirect (core/integrator.cpp:108-215), handleMedia=false, specular=false
-                            const mi_light &light = sc.lights[lightNum];
+                            const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
                             LightSample ls;
                             SampleLi(sc, light, isect, uL0, uL1, &ls);
@@ -502,9 +529,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                                         Ld = f * ls.Li * weight / lightPdf;
                                     }
                                     RGB c = beta * (Ld / selPdf);   // added by k_anyhit iff the shadow ray is unoccluded
-                                    ps.sh_o[slot] = make_float4(ls.shadow.o.x, ls.shadow.o.y, ls.shadow.o.z, ls.shadow.tMax);
-                                    ps.sh_d[slot] = make_float4(ls.shadow.d.x, ls.shadow.d.y, ls.shadow.d.z, 0);
-                                    ps.sh_c[slot] = make_float4(c.r, c.g, c.b, 0);
+                                    ps.nee[slot].sh_o = make_float4(ls.shadow.o.x, ls.shadow.o.y, ls.shadow.o.z, ls.shadow.tMax);
+                                    ps.nee[slot].sh_d = make_float4(ls.shadow.d.x, ls.shadow.d.y, ls.shadow.d.z, 0);
+                                    ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, 0);
                                     wantShadow = true;
                                 }
                             }
@@ -525,9 +552,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                                     if (ok) {
                                         V3 mo = OffsetRayOrigin(isect.p, isect.pError, isect.n, wi);   // it.SpawnRay(wi)
                                         RGB c = beta * ((f * weight / scatteringPdf) / selPdf);         // times Li, resolved by k_closest<1>
-                                        ps.mi_o[slot] = make_float4(mo.x, mo.y, mo.z, 0);
-                                        ps.mi_d[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)lightNum));
-                                        ps.mi_c[slot] = make_float4(c.r, c.g, c.b, 0);
+                                        ps.nee[slot].mi_o = make_float4(mo.x, mo.y, mo.z, 0);
+                                        ps.nee[slot].mi_d = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)lightNum));
+                                        ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
                                         wantMis = true;
                                     }
                                 }
@@ -558,16 +585,16 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             else beta = beta / (1 - q);
                         }
                         if (cont) {
-                            ps.ray_o[slot] = make_float4(no.x, no.y, no.z, PT_INFINITY);
-                            ps.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, 0);
-                            ps.beta[slot] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                            ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                            ps.rec[slot].ray_d = make_float4(wi.x, wi.y, wi.z, 0);
+                            ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
                             ++bounces;
                         }
                     }
                 }
             }
-            ps.L[slot] = make_float4(L.r, L.g, L.b, 0);
-            if (cont) ps.smp[slot] = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
+            ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
+            if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
         }
         uint32_t pos = wave_append(&ps.qcount[qout], cont);
         if (cont) ps.q_ext[qout][pos] = slot;
@@ -593,7 +620,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
     for (ChunkIter it(pass.npix); it.more(); it.next()) {
         uint32_t p = it.item();
         if (p >= pass.npix) continue;
-        uint32_t pix = ps.pixel[p];
+        uint32_t pix = ps.rec[p].pixel;
         if (pix == INACTIVE_PIXEL) continue;
         int ownx = sc.sample_min[0] + (int)(pix & 0xffffu), owny = sc.sample_min[1] + (int)(pix >> 16);
         bool ownInside = ownx >= sc.crop_min[0] && ownx < sc.crop_max[0] && owny >= sc.crop_min[1] && owny < sc.crop_max[1];
@@ -601,14 +628,14 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
         float4 acc = (!SPILL && ownInside) ? *own : make_float4(0, 0, 0, 0);
         for (uint32_t s = 0; s < pass.ns; ++s) {
             uint32_t slot = s * pass.npix + p;
-            float2 pf = ps.pfilm[slot];
+            float2 pf = ps.rec[slot].pfilm;
             Float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
             int p0x = (int)__builtin_ceilf(dx - sc.filter_radius[0]), p0y = (int)__builtin_ceilf(dy - sc.filter_radius[1]);
             int p1x = (int)__builtin_floorf(dx + sc.filter_radius[0]) + 1, p1y = (int)__builtin_floorf(dy + sc.filter_radius[1]) + 1;
             p0x = p0x > sc.crop_min[0] ? p0x : sc.crop_min[0]; p0y = p0y > sc.crop_min[1] ? p0y : sc.crop_min[1];
             p1x = p1x < sc.crop_max[0] ? p1x : sc.crop_max[0]; p1y = p1y < sc.crop_max[1] ? p1y : sc.crop_max[1];
             if (SPILL && p0x == ownx && p1x == ownx + 1 && p0y == owny && p1y == owny + 1) continue;   // nothing but the own pixel
-            float4 L4 = ps.L[slot];
+            float4 L4 = ps.rec[slot].L;
             RGB L(L4.x, L4.y, L4.z);
             if (L.HasNaNs()) L = RGB(0.f);
             else if ((double)L.y() < -1e-5) L = RGB(0.f);
@@ -702,17 +729,17 @@ __global__ void k_stage_sobol(DevScene sc, int px, int py, int n_samples, int n_
 __global__ void k_stage_export_rays(PathState ps, int64_t n, mi_ray *rays, float *pfilm) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 o = ps.ray_o[i], d = ps.ray_d[i];
+    float4 o = ps.rec[i].ray_o, d = ps.rec[i].ray_d;
     mi_ray r;
     r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.tmax = o.w; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z; r.time = 0;
     rays[i] = r;
-    float2 pf = ps.pfilm[i];
+    float2 pf = ps.rec[i].pfilm;
     pfilm[2 * i] = pf.x; pfilm[2 * i + 1] = pf.y;
 }
 __global__ void k_stage_export_L(PathState ps, int64_t n, float *L_rgb) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 L4 = ps.L[i];
+    float4 L4 = ps.rec[i].L;
     RGB L(L4.x, L4.y, L4.z);   // same guards as the film path (integrator.cpp:294-315)
     if (L.HasNaNs()) L = RGB(0.f);
     else if ((double)L.y() < -1e-5) L = RGB(0.f);
@@ -952,13 +979,41 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     }
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
     { DevBuf &b = next(); if (upload(c, b, d->tri_indices, 3 * (size_t)d->n_tris * 4)) return -1; sc.tri_indices = b.as<uint32_t>(); }
-    { DevBuf &b = next(); if (upload(c, b, d->tri_mesh, (size_t)d->n_tris * 4)) return -1; sc.tri_mesh = b.as<uint32_t>(); }
-    { DevBuf &b = next(); if (upload(c, b, d->tri_light, (size_t)d->n_tris * 4)) return -1; sc.tri_light = b.as<int32_t>(); }
-    { DevBuf &b = next(); if (upload(c, b, d->meshes, (size_t)d->n_meshes * sizeof(mi_mesh))) return -1; sc.meshes = b.as<mi_mesh>(); }
+    {
+        std::vector<uint4> ti(d->n_tris);
+        for (uint32_t t = 0; t < d->n_tris; ++t) {
+            const mi_mesh &m = d->meshes[d->tri_mesh[t]];
+            ti[t] = make_uint4(m.flags, (uint32_t)m.material, (uint32_t)d->tri_light[t], d->tri_mesh[t]);
+        }
+        DevBuf &b = next();
+        if (upload(c, b, ti.data(), ti.size() * sizeof(uint4))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        sc.tri_info = b.as<uint4>();
+    }
     if (d->N) { DevBuf &b = next(); if (upload(c, b, d->N, 3 * (size_t)d->n_verts * 4)) return -1; sc.N = b.as<float>(); }
     if (d->UV) { DevBuf &b = next(); if (upload(c, b, d->UV, 2 * (size_t)d->n_verts * 4)) return -1; sc.UV = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
-    { DevBuf &b = next(); if (upload(c, b, d->lights, (size_t)d->n_lights * sizeof(mi_light))) return -1; sc.lights = b.as<mi_light>(); }
+    {
+        std::vector<DevLight> dl(d->n_lights);
+        for (uint32_t i = 0; i < d->n_lights; ++i) {
+            std::memset(&dl[i], 0, sizeof(DevLight));
+            dl[i].l = d->lights[i];
+            if (d->lights[i].type == MI_LIGHT_AREA_TRI) {
+                uint32_t t = (uint32_t)d->lights[i].tri;
+                const float4 *v = &tv[3 * (size_t)t];
+                dl[i].p0[0] = v[0].x; dl[i].p0[1] = v[0].y; dl[i].p0[2] = v[0].z;
+                dl[i].p1[0] = v[1].x; dl[i].p1[1] = v[1].y; dl[i].p1[2] = v[1].z;
+                dl[i].p2[0] = v[2].x; dl[i].p2[1] = v[2].y; dl[i].p2[2] = v[2].z;
+                uint32_t fl;
+                std::memcpy(&fl, &v[0].w, 4);
+                dl[i].mesh_flags = d->meshes[d->tri_mesh[t]].flags | ((fl & TRI_FLAG_REJECT) ? 0x80000000u : 0u);
+            }
+        }
+        DevBuf &b = next();
+        if (upload(c, b, dl.data(), dl.size() * sizeof(DevLight))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        sc.lights = b.as<DevLight>();
+    }
     { DevBuf &b = next(); if (upload(c, b, d->light_func, (size_t)d->n_lights * 4)) return -1; sc.light_func = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->light_cdf, ((size_t)d->n_lights + 1) * 4)) return -1; sc.light_cdf = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->film.filter_table, sizeof(d->film.filter_table))) return -1; sc.filter_table = b.as<float>(); }
@@ -1026,11 +1081,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     std::memset(&ps, 0, sizeof(ps));
     auto A = [&](size_t bytes) -> void * { DevBuf &b = c->stateBufs[nb++]; return b.alloc(bytes) ? nullptr : b.p; };
 #define ALLOC(field, type, count) do { ps.field = (type *)A(sizeof(type) * (size_t)(count)); if (!ps.field) return -1; } while (0)
-    ALLOC(ray_o, float4, cap); ALLOC(ray_d, float4, cap); ALLOC(hit, uint2, cap); ALLOC(beta, float4, cap); ALLOC(L, float4, cap);
-    ALLOC(smp, uint4, cap); ALLOC(pfilm, float2, cap); ALLOC(pixel, uint32_t, cap);
-    ALLOC(sh_o, float4, cap); ALLOC(sh_d, float4, cap); ALLOC(sh_c, float4, cap);
-    ALLOC(mi_o, float4, cap); ALLOC(mi_d, float4, cap); ALLOC(mi_c, float4, cap);
-    ALLOC(keyrank, uint2, cap);
+    ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, cap);
     ALLOC(q_ext[0], uint32_t, cap); ALLOC(q_ext[1], uint32_t, cap); ALLOC(q_shadow, uint32_t, cap); ALLOC(q_mis, uint32_t, cap);
     ALLOC(q_sorted, uint32_t, cap);
     ALLOC(qcount, uint32_t, QC_COUNT);

@@ -33,8 +33,13 @@ PT_DEV Float sqrtf_(Float v) { return __builtin_sqrtf(v); }
 // libm calls: evaluated in double and rounded once.  The reference calls glibc's float routines,
 // which return the correctly rounded result in all but a vanishing fraction of inputs; going
 // through ocml's double versions gets the same value almost always, unlike ocml's 1-2 ulp float paths.
+#ifdef PT_F32_TRIG   /* experiment only: ocml's 1-2 ulp float routines (not the parity build) */
+PT_DEV Float sinf_(Float v) { return sinf(v); }
+PT_DEV Float cosf_(Float v) { return cosf(v); }
+#else
 PT_DEV Float sinf_(Float v) { return (Float)sin((double)v); }
 PT_DEV Float cosf_(Float v) { return (Float)cos((double)v); }
+#endif
 PT_DEV Float acosf_(Float v) { return (Float)acos((double)v); }
 PT_DEV Float expf_(Float v) { return (Float)exp((double)v); }
 

@@ -25,17 +25,22 @@ struct __attribute__((aligned(128))) BVH4Node {
 // shapes/triangle.cpp:308-315 (decided per triangle, independent of the ray).
 #define TRI_FLAG_REJECT 1u
 
+struct DevLight {
+    mi_light l;
+    float p0[3]; uint32_t mesh_flags;
+    float p1[3]; uint32_t pad1;
+    float p2[3]; uint32_t pad2;
+};
+
 struct DevScene {
     const BVH4Node *nodes;
     const float4 *tri_verts;        // 3 per triangle
     const uint32_t *tri_indices;    // 3 per triangle (vertex ids for N / UV)
-    const uint32_t *tri_mesh;
-    const int32_t *tri_light;
-    const mi_mesh *meshes;
+    const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const float *N;                 // may be null
     const float *UV;                // may be null
     const mi_material *materials;
-    const mi_light *lights;
+    const DevLight *lights;         // mi_light + (area lights) the triangle's vertices and mesh flags: no extra hops while sampling
     const float *light_func, *light_cdf;
     const float *filter_table;
     const int32_t *infinite_lights; // indices of MI_LIGHT_INFINITE lights
@@ -323,25 +328,25 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     ts.cur = c0;
 }
 
-// one leaf step: test the leaf's triangles in primitive order (ties at equal t: the later one wins, as in
-// the reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261)
+// one leaf step = ONE triangle of the leaf (in primitive order; ties at equal t: the later one wins, as in the
+// reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261).  A lane stays at the leaf until its triangles are
+// used up, so a leaf phase of the wave costs one watertight test whatever the leaf sizes of its lanes are.
 template <bool ANY, bool COUNT>
 PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
-    uint32_t first = ts.cur & BVH4_FIRST_MASK, n = ((ts.cur >> 27) & 0xfu) + 1;
-    for (uint32_t i = 0; i < n; ++i) {
-        V3 p0, p1, p2;
-        uint32_t flags;
-        LoadTri(sc, first + i, &p0, &p1, &p2, &flags);
-        if (COUNT) ++cnt->tris;
-        TriHit th;
-        if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th)) {
-            ts.prim = first + i;
-            ts.tHit = th.t;
-            if (ANY) { ts.cur = TRAV_DONE; return; }
-            ts.tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
-        }
+    uint32_t first = ts.cur & BVH4_FIRST_MASK, left = (ts.cur >> 27) & 0xfu;   // left = triangles after this one
+    V3 p0, p1, p2;
+    uint32_t flags;
+    LoadTri(sc, first, &p0, &p1, &p2, &flags);
+    if (COUNT) ++cnt->tris;
+    TriHit th;
+    if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th)) {
+        ts.prim = first;
+        ts.tHit = th.t;
+        if (ANY) { ts.cur = TRAV_DONE; return; }
+        ts.tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
     }
-    ts.cur = st.sp ? st.pop() : TRAV_DONE;
+    if (left) ts.cur = BVH4_LEAF | ((left - 1) << 27) | (first + 1);
+    else ts.cur = st.sp ? st.pop() : TRAV_DONE;
 }
 
 // plain per-ray loop (stage-level entry points)

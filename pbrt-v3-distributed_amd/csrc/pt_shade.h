@@ -29,7 +29,7 @@ PT_DEV void TriUVs(const DevScene &sc, uint32_t prim, uint32_t meshFlags, Float 
 // barycentrics the traversal found.  rayD = direction of the ray that hit.
 PT_FN void BuildIsect(const DevScene &sc, uint32_t prim, const V3 &p0, const V3 &p1, const V3 &p2, const TriHit &th,
                        const V3 &rayD, Isect *is) {
-    uint32_t mflags = sc.meshes[sc.tri_mesh[prim]].flags;
+    uint32_t mflags = sc.tri_info[prim].x;
     Float uv[3][2];
     TriUVs(sc, prim, mflags, uv);
     Float duv02x = uv[0][0] - uv[2][0], duv02y = uv[0][1] - uv[2][1], duv12x = uv[1][0] - uv[2][0], duv12y = uv[1][1] - uv[2][1];
@@ -502,19 +502,18 @@ PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, c
 
 struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
 
-PT_FN void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Float u0, Float u1, LightSample *ls) {
+PT_FN void SampleLi(const DevScene &sc, const DevLight &dl, const Isect &ref, Float u0, Float u1, LightSample *ls) {
+    const mi_light &l = dl.l;
     ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
     if (l.type == MI_LIGHT_AREA_TRI) {
         // DiffuseAreaLight::Sample_Li lights/diffuse.cpp:68-81 -> Shape::Sample(ref,u) core/shape.cpp:56-70
         // -> Triangle::Sample(u) shapes/triangle.cpp:583-608
         Float su0 = sqrtf_(u0);
         Float b0 = 1 - su0, b1 = u1 * su0;   // UniformSampleTriangle core/sampling.cpp:154-157
-        V3 p0, p1, p2;
-        uint32_t tf;
-        LoadTri(sc, l.tri, &p0, &p1, &p2, &tf);
+        V3 p0 = v3(dl.p0), p1 = v3(dl.p1), p2 = v3(dl.p2);
         V3 p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
         V3 n = Normalize(Cross(p1 - p0, p2 - p0));
-        uint32_t mflags = sc.meshes[sc.tri_mesh[l.tri]].flags;
+        uint32_t mflags = dl.mesh_flags;
         if (sc.N && (mflags & MI_MESH_HAS_N)) {
             const uint32_t *v = sc.tri_indices + 3 * (size_t)l.tri;
             V3 n0 = v3(sc.N + 3 * (size_t)v[0]), n1 = v3(sc.N + 3 * (size_t)v[1]), n2 = v3(sc.N + 3 * (size_t)v[2]);
@@ -570,14 +569,13 @@ PT_FN void SampleLi(const DevScene &sc, const mi_light &l, const Isect &ref, Flo
 }
 
 // Light::Pdf_Li
-PT_FN Float PdfLi(const DevScene &sc, const mi_light &l, const Isect &ref, const V3 &wi) {
+PT_FN Float PdfLi(const DevScene &sc, const DevLight &dl, const Isect &ref, const V3 &wi) {
+    const mi_light &l = dl.l;
     if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
         V3 o = OffsetRayOrigin(ref.p, ref.pError, ref.n, wi);
-        V3 p0, p1, p2;
-        uint32_t tf;
-        LoadTri(sc, l.tri, &p0, &p1, &p2, &tf);
+        V3 p0 = v3(dl.p0), p1 = v3(dl.p1), p2 = v3(dl.p2);
         TriHit th;
-        if ((tf & TRI_FLAG_REJECT) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;
+        if ((dl.mesh_flags & 0x80000000u) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;   // bit 31: TRI_FLAG_REJECT of that triangle
         Isect li;
         BuildIsect(sc, l.tri, p0, p1, p2, th, wi, &li);
         Float pdf = DistanceSquared(ref.p, li.p) / (AbsDot(li.n, -wi) * l.area);

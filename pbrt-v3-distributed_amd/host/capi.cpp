@@ -55,6 +55,31 @@ int pbrt_amd_film_write(pbrt_amd_scene *s, const char *filename) {
     f.WriteImage();
     return 0;
 }
+// number of GeometricPrimitives (meshes) of the scene, and a binary-little-endian PLY dump of one of them
+// (world-space positions [+ normals]); used by tools/make_killeroo.py to ship subdivided geometry as plymesh
+int pbrt_amd_scene_num_prims(pbrt_amd_scene *s) { return (int)s->built->scene->primitives.size(); }
+int pbrt_amd_scene_write_ply(pbrt_amd_scene *s, int prim, const char *filename) {
+    if (prim < 0 || prim >= (int)s->built->scene->primitives.size()) return -1;
+    const TriangleMesh &m = *s->built->scene->primitives[prim].shape;
+    FILE *f = std::fopen(filename, "wb");
+    if (!f) return -2;
+    bool hasN = !m.n.empty();
+    std::fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\n", m.p.size());
+    if (hasN) std::fprintf(f, "property float nx\nproperty float ny\nproperty float nz\n");
+    std::fprintf(f, "element face %d\nproperty list uchar int vertex_indices\nend_header\n", m.nTriangles());
+    for (size_t i = 0; i < m.p.size(); ++i) {
+        float v[6] = {m.p[i].x, m.p[i].y, m.p[i].z, 0, 0, 0};
+        if (hasN) { v[3] = m.n[i].x; v[4] = m.n[i].y; v[5] = m.n[i].z; }
+        std::fwrite(v, 4, hasN ? 6 : 3, f);
+    }
+    for (int t = 0; t < m.nTriangles(); ++t) {
+        unsigned char n = 3;
+        std::fwrite(&n, 1, 1, f);
+        std::fwrite(&m.indices[3 * t], 4, 3, f);
+    }
+    std::fclose(f);
+    return 0;
+}
 int pbrt_amd_read_pfm(const char *filename, float *rgb, int capacity_floats, int *w, int *h) {
     std::vector<Float> v;
     if (!ReadImagePFM(filename, &v, w, h)) return -1;
