@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--res", type=int, nargs=2, default=[1920, 1080])
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--scene", default=None, help="render this .pbrt instead of the generated stand-in")
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4"],
+                    help="BASELINE.json config: c3 = San-Miguel-class 1080p 64spp (default, the metric's workload); "
+                         "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample (0 = skip)")
     ap.add_argument("--max-paths", type=int, default=0)
     args = ap.parse_args()
@@ -63,12 +66,43 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- scene (generated once per node by local rank 0)
+    bench_dir = os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench")
     if args.scene:
         scene_file = args.scene
         workload = os.path.basename(scene_file)
+    elif args.config == "c2":
+        d = os.path.join(bench_dir, "killeroo_%dx%d" % (args.res[0], args.res[1]))
+        spp = args.spp if args.spp != 64 else 128
+        scene_file = os.path.join(d, "killeroo_%dspp.pbrt" % spp)
+        if local_rank == 0 and not os.path.exists(scene_file):
+            os.makedirs(d, exist_ok=True)
+            text = open(os.path.join(ROOT, "scenes", "killeroo.pbrt")).read()
+            text = text.replace('[700] "integer yresolution" [700]', '[%d] "integer yresolution" [%d]' % (args.res[0], args.res[1]))
+            text = text.replace('"integer pixelsamples" [8]', '"integer pixelsamples" [%d]' % spp)
+            text = text.replace("killeroo_geo/", os.path.join(ROOT, "scenes", "killeroo_geo") + "/")
+            open(scene_file + ".tmp", "w").write(text)
+            os.rename(scene_file + ".tmp", scene_file)
+        while not os.path.exists(scene_file):
+            time.sleep(0.2)
+        workload = "killeroo-simple (sphere light as icosphere mesh, sobol): 67.8 k triangles, %dx%d, %d spp, path maxdepth 5" % (args.res[0], args.res[1], spp)
+    elif args.config == "c4":
+        spp = args.spp if args.spp != 64 else 256
+        tris = args.tris if args.tris != 10_000_000 else 600_000
+        key = "bathroom_synth_%dk_%dx%d_%dspp" % (tris // 1000, args.res[0], args.res[1], spp)
+        d = os.path.join(bench_dir, key)
+        scene_file = os.path.join(d, "bathroom_synth.pbrt")
+        marker = os.path.join(d, ".done")
+        if local_rank == 0 and not os.path.exists(marker):
+            os.makedirs(d, exist_ok=True)
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "bathroom", "--tris", str(tris),
+                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(spp), "--out", scene_file], stdout=sys.stderr)
+            open(marker, "w").write("ok")
+        while not os.path.exists(marker):
+            time.sleep(0.2)
+        workload = "Contemporary-Bathroom-class synthetic stand-in: glass/mirror/metal, %dx%d, %d spp, path maxdepth 30" % (args.res[0], args.res[1], spp)
     else:
         key = "sanmiguel_synth_%dk_%dx%d_%dspp" % (args.tris // 1000, args.res[0], args.res[1], args.spp)
-        d = os.path.join(os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench"), key)
+        d = os.path.join(bench_dir, key)
         scene_file = os.path.join(d, "sanmiguel_synth.pbrt")
         marker = os.path.join(d, ".done")
         if local_rank == 0 and not os.path.exists(marker):
@@ -176,17 +210,16 @@ def main():
             import oracle_lib as ol
             ncores = os.cpu_count() or 1
             ntx, nty = (sc.width + 15) // 16, (sc.height + 15) // 16
-            # probe: 8 centre tiles at 1 spp to size the sample
             cx, cy = ntx // 2, nty // 2
-            _, pc, ps_ = ol.render(sc, 0, 1, ncores, tiles=[cx - 2, cy - 1, cx + 2, cy + 1])
-            rate = pc["camera_rays"] / max(ps_, 1e-6)
-            want = rate * args.cpu_seconds
             spp_cpu = int(min(sc.info["spp"], 8))
-            tiles_needed = max(8, int(want / (256 * spp_cpu)))
-            side = int(np.ceil(np.sqrt(tiles_needed)))
-            bx0, by0 = max(0, cx - side // 2), max(0, cy - side // 2)
-            box = [bx0, by0, min(ntx, bx0 + side), min(nty, by0 + side)]
-            rgbw_cpu, cc, secs = ol.render(sc, 0, spp_cpu, ncores, tiles=box)
+            side = 8   # centre box of side x side tiles, grown until the sample takes long enough
+            while True:
+                bx0, by0 = max(0, cx - side // 2), max(0, cy - side // 2)
+                box = [bx0, by0, min(ntx, bx0 + side), min(nty, by0 + side)]
+                rgbw_cpu, cc, secs = ol.render(sc, 0, spp_cpu, ncores, tiles=box)
+                if secs >= args.cpu_seconds * 0.5 or (box[2] - box[0] >= ntx and box[3] - box[1] >= nty):
+                    break
+                side = int(side * max(1.5, min(4.0, (args.cpu_seconds / max(secs, 1e-3)) ** 0.5)))
             cpu = {"value": round(cc["camera_rays"] / secs * 1e-6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",
                    "mrays_per_s": round((cc["closest_rays"] + cc["shadow_rays"]) / secs * 1e-6, 3),
                    "sample": "oracle/pt_oracle.cpp (CPU restatement, pinned to pbrt_ref) on tiles [%d,%d)x[%d,%d) of the same frame, %d of %d spp, %d threads, %.1f s"
