@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -138,6 +138,13 @@ typedef struct mi_film {     /* Film, core/film.cpp:45-86 */
     float scale;
 } mi_film;
 
+/* Light-selection strategy.  TABLE: one Distribution1D over all lights, passed as light_func / light_cdf
+ * (UniformLightDistribution, PowerLightDistribution, or any scene with a single light).
+ * SPATIAL: SpatialLightDistribution (lightdistrib.cpp:96-300); the library evaluates ComputeDistribution for
+ * every voxel of the grid at upload time (the reference fills its hash table lazily with the same values). */
+#define MI_LIGHT_STRATEGY_TABLE 0
+#define MI_LIGHT_STRATEGY_SPATIAL 1
+
 typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t max_depth;          /* path.cpp:193, default 5 */
     float rr_threshold;         /* path.cpp:208, default 1 */
@@ -145,6 +152,8 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t spp;                /* RoundUpPow2(pixelsamples) (sobol.h:52) */
     int32_t sobol_resolution;   /* sobol.h:58-59 */
     int32_t sobol_log2_resolution;
+    int32_t light_strategy;     /* MI_LIGHT_STRATEGY_*: CreateLightSampleDistribution (lightdistrib.cpp:48-66, path.cpp:72) */
+    int32_t spatial_max_voxels; /* SpatialLightDistribution maxVoxels (lightdistrib.h:92), 64; 0 -> 64 */
 } mi_integrator;
 
 /* ---------------------------------------------------------------- the scene --------- */

@@ -427,6 +427,62 @@ __global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin
     }
 }
 
+// ---- SpatialLightDistribution::ComputeDistribution (core/lightdistrib.cpp:219-300), evaluated for every voxel at upload
+// time.  halton: the 128 x {RadicalInverse(0..4, i)} values (identical for every voxel).  One thread per (voxel, light)
+// keeps the per-light sum over the samples in the reference's order.
+#define PT_SPATIAL_SAMPLES 128
+PT_DEV Float LerpB(Float t, Float a, Float b) { return (1 - t) * a + t * b; }   // pbrt::Lerp via Bounds3::Lerp geometry.h:775-779
+__global__ void __launch_bounds__(PT_BLOCK) k_spatial_contrib(DevScene sc, float *contrib, const float *halton, uint64_t total) {
+    __shared__ float s_h[PT_SPATIAL_SAMPLES * 5];
+    for (uint32_t k = threadIdx.x; k < PT_SPATIAL_SAMPLES * 5; k += PT_BLOCK) s_h[k] = halton[k];
+    __syncthreads();
+    const uint32_t nl = sc.n_lights;
+    for (uint64_t i = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < total; i += (uint64_t)gridDim.x * PT_BLOCK) {
+        uint32_t vox = (uint32_t)(i / nl), j = (uint32_t)(i - (uint64_t)vox * nl);
+        int pi2 = (int)(vox % (uint32_t)sc.sp_nvox[2]);
+        uint32_t r = vox / (uint32_t)sc.sp_nvox[2];
+        int pi1 = (int)(r % (uint32_t)sc.sp_nvox[1]), pi0 = (int)(r / (uint32_t)sc.sp_nvox[1]);
+        V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
+        V3 t0(Float(pi0) / Float(sc.sp_nvox[0]), Float(pi1) / Float(sc.sp_nvox[1]), Float(pi2) / Float(sc.sp_nvox[2]));
+        V3 t1(Float(pi0 + 1) / Float(sc.sp_nvox[0]), Float(pi1 + 1) / Float(sc.sp_nvox[1]), Float(pi2 + 1) / Float(sc.sp_nvox[2]));
+        V3 a(LerpB(t0.x, bmin.x, bmax.x), LerpB(t0.y, bmin.y, bmax.y), LerpB(t0.z, bmin.z, bmax.z));
+        V3 b(LerpB(t1.x, bmin.x, bmax.x), LerpB(t1.y, bmin.y, bmax.y), LerpB(t1.z, bmin.z, bmax.z));
+        V3 vmin(mn(a.x, b.x), mn(a.y, b.y), mn(a.z, b.z)), vmax(mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z));   // Bounds3(p1, p2)
+        const DevLight &light = sc.lights[j];
+        Isect intr;
+        intr.pError = V3(); intr.n = V3(); intr.ns = V3(); intr.wo = V3(1, 0, 0);
+        Float acc = 0;
+        for (int k = 0; k < PT_SPATIAL_SAMPLES; ++k) {
+            const float *h = &s_h[5 * k];
+            intr.p = V3(LerpB(h[0], vmin.x, vmax.x), LerpB(h[1], vmin.y, vmax.y), LerpB(h[2], vmin.z, vmax.z));
+            LightSample ls;
+            ls.pdf = 0; ls.Li = RGB(0.f);
+            SampleLi(sc, light, intr, h[3], h[4], &ls);
+            if (ls.pdf > 0) acc += ls.Li.y() / ls.pdf;
+        }
+        contrib[i] = acc;
+    }
+}
+// second half of ComputeDistribution + the Distribution1D constructor (core/sampling.h:55-70), one thread per voxel
+// (the sums are sequential in the reference; the order is kept)
+__global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_t nl, float *func /* in: contrib */, float *cdf, float *funcInt) {
+    for (uint32_t v = blockIdx.x * PT_BLOCK + threadIdx.x; v < nvox; v += gridDim.x * PT_BLOCK) {
+        float *f = func + (size_t)v * nl, *c = cdf + (size_t)v * (nl + 1);
+        Float sum = 0;
+        for (uint32_t j = 0; j < nl; ++j) sum = sum + f[j];
+        Float avg = sum / (Float)((uint64_t)PT_SPATIAL_SAMPLES * (uint64_t)nl);
+        Float minContrib = (avg > 0) ? (Float)(.001 * (double)avg) : 1;
+        for (uint32_t j = 0; j < nl; ++j) f[j] = mx(f[j], minContrib);
+        int n = (int)nl;
+        c[0] = 0;
+        for (int i = 1; i < n + 1; ++i) c[i] = c[i - 1] + f[i - 1] / n;
+        Float fi = c[n];
+        if (fi == 0) for (int i = 1; i < n + 1; ++i) c[i] = Float(i) / Float(n);
+        else for (int i = 1; i < n + 1; ++i) c[i] /= fi;
+        funcInt[v] = fi;
+    }
+}
+
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
 #ifndef PT_CDF_LDS
 #define PT_CDF_LDS 2048
@@ -499,15 +555,33 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                     BSDF bsdf(isect, &sc.materials[matIdx]);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
+                        // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
+                        const float *vcdf = cdf, *vfunc = sc.light_func;
+                        Float funcInt = sc.light_func_int;
+                        if (sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL) {
+                            V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
+                            V3 off = isect.p - bmin;   // Bounds3::Offset geometry.h:786-792
+                            if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
+                            if (bmax.y > bmin.y) off.y /= bmax.y - bmin.y;
+                            if (bmax.z > bmin.z) off.z /= bmax.z - bmin.z;
+                            int v0 = (int)(off.x * sc.sp_nvox[0]), v1 = (int)(off.y * sc.sp_nvox[1]), v2 = (int)(off.z * sc.sp_nvox[2]);
+                            v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
+                            v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
+                            v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
+                            size_t vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
+                            vcdf = sc.sp_cdf + vox * (sc.n_lights + 1);
+                            vfunc = sc.sp_func + vox * sc.n_lights;
+                            funcInt = sc.sp_func_int[vox];
+                        }
                         Float ul = us[ui++];
                         // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411)
                         int size = (int)sc.n_lights + 1, first = 0, len = size;
                         while (len > 0) {
                             int half = len >> 1, middle = first + half;
-                            if (cdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
+                            if (vcdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
                         }
                         int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
-                        Float selPdf = (sc.light_func_int > 0) ? sc.light_func[lightNum] / (sc.light_func_int * (int)sc.n_lights) : 0;
+                        Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
                         if (selPdf != 0) {
                             Float uL0, uL1, uS0, uS1;
                             uL0 = us[ui]; uL1 = us[ui + 1]; uS0 = us[ui + 2]; uS1 = us[ui + 3];
@@ -916,7 +990,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(24);
+    c->sceneBufs.resize(32);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1016,6 +1090,70 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     }
     { DevBuf &b = next(); if (upload(c, b, d->light_func, (size_t)d->n_lights * 4)) return -1; sc.light_func = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->light_cdf, ((size_t)d->n_lights + 1) * 4)) return -1; sc.light_cdf = b.as<float>(); }
+    // ---- SpatialLightDistribution (lightdistrib.cpp:96-126 sizes the grid; ComputeDistribution for all voxels on the device)
+    sc.light_strategy = MI_LIGHT_STRATEGY_TABLE;
+    if (d->integrator.light_strategy == MI_LIGHT_STRATEGY_SPATIAL && d->n_lights > 1) {
+        const int maxVoxels = d->integrator.spatial_max_voxels > 0 ? d->integrator.spatial_max_voxels : 64;
+        float bmin[3], bmax[3];
+        for (int i = 0; i < 3; ++i) {
+            bmin[i] = d->n_bvh_nodes ? d->bvh_nodes[0].bmin[i] : std::numeric_limits<float>::max();      // Bounds3f() geometry.h:650-655
+            bmax[i] = d->n_bvh_nodes ? d->bvh_nodes[0].bmax[i] : std::numeric_limits<float>::lowest();
+        }
+        float diag[3] = {bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
+        int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);   // Bounds3::MaximumExtent geometry.h:747-755
+        float bm = diag[me];
+        uint64_t nvox = 1;
+        for (int i = 0; i < 3; ++i) {
+            sc.sp_nvox[i] = std::max(1, int(std::round(diag[i] / bm * maxVoxels)));
+            sc.sp_bmin[i] = bmin[i]; sc.sp_bmax[i] = bmax[i];
+            nvox *= (uint64_t)sc.sp_nvox[i];
+        }
+        uint64_t nl = d->n_lights, bytes = nvox * (2 * nl + 2) * 4;
+        if (nvox >= (1ull << 31) || bytes > (64ull << 30))
+            return fail("mi_scene_upload: spatial light distribution table would need " + std::to_string(bytes >> 30) + " GiB");
+        // the Halton points of ComputeDistribution: RadicalInverse(0..4, i) (core/lowdiscrepancy.cpp:389-403, 427-445)
+        std::vector<float> halton(PT_SPATIAL_SAMPLES * 5);
+        {
+            static const int primes[5] = {2, 3, 5, 7, 11};
+            for (int i = 0; i < PT_SPATIAL_SAMPLES; ++i)
+                for (int b = 0; b < 5; ++b) {
+                    uint64_t a = (uint64_t)i;
+                    float v;
+                    if (b == 0) {
+                        uint64_t r = 0;
+                        for (int k = 0; k < 64; ++k) if (a & (1ull << k)) r |= 1ull << (63 - k);   // ReverseBits64
+                        v = (float)((double)r * 0x1p-64);
+                    } else {
+                        const float invBase = 1.f / (float)primes[b];
+                        uint64_t rev = 0;
+                        float invBaseN = 1;
+                        while (a) {
+                            uint64_t nx = a / (uint64_t)primes[b], digit = a - nx * (uint64_t)primes[b];
+                            rev = rev * (uint64_t)primes[b] + digit;
+                            invBaseN *= invBase;
+                            a = nx;
+                        }
+                        v = std::min((float)rev * invBaseN, 0x1.fffffep-1f);
+                    }
+                    halton[5 * i + b] = v;
+                }
+        }
+        DevBuf hbuf;
+        if (upload(c, hbuf, halton.data(), halton.size() * 4)) return -1;
+        DevBuf &bf = next(), &bc = next(), &bi = next();
+        if (bf.alloc(nvox * nl * 4) || bc.alloc(nvox * (nl + 1) * 4) || bi.alloc(nvox * 4)) return -1;
+        sc.sp_func = bf.as<float>(); sc.sp_cdf = bc.as<float>(); sc.sp_func_int = bi.as<float>();
+        sc.n_lights = d->n_lights;   // the kernels below read lights / n_lights / N / tri_indices, all set above
+        uint64_t total = nvox * nl;
+        unsigned gridc = (unsigned)std::min<uint64_t>((total + PT_BLOCK - 1) / PT_BLOCK, 65536);
+        hipLaunchKernelGGL(k_spatial_contrib, dim3(gridc), dim3(PT_BLOCK), 0, c->stream, sc, bf.as<float>(), hbuf.as<float>(), total);
+        unsigned gridv = (unsigned)std::min<uint64_t>((nvox + PT_BLOCK - 1) / PT_BLOCK, 65536);
+        hipLaunchKernelGGL(k_spatial_cdf, dim3(gridv), dim3(PT_BLOCK), 0, c->stream, (uint32_t)nvox, (uint32_t)nl, bf.as<float>(), bc.as<float>(), bi.as<float>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hbuf.release();
+        sc.light_strategy = MI_LIGHT_STRATEGY_SPATIAL;
+    }
     { DevBuf &b = next(); if (upload(c, b, d->film.filter_table, sizeof(d->film.filter_table))) return -1; sc.filter_table = b.as<float>(); }
     std::vector<int32_t> inf;
     for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == MI_LIGHT_INFINITE) inf.push_back((int32_t)i);

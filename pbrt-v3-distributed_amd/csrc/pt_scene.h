@@ -48,6 +48,10 @@ struct DevScene {
     int32_t sobol_index_bits;       // upper bound on the bits of a Sobol' index: 2*log2(resolution) + log2(spp)
     const uint64_t *vdc, *vdc_inv;  // [26][52] pixel <-> index maps
     float light_func_int;
+    // SpatialLightDistribution (core/lightdistrib.cpp:96-300) as a dense table: one Distribution1D per voxel
+    const float *sp_func, *sp_cdf, *sp_func_int;   // [nvox][n_lights], [nvox][n_lights + 1], [nvox]
+    int32_t light_strategy, sp_nvox[3];
+    float sp_bmin[3], sp_bmax[3];                  // scene.WorldBound()
     uint32_t n_tris, n_nodes, n_lights, n_materials, n_infinite;
     int32_t stack_need;             // 3 * BVH4 depth + 1
     mi_camera camera;

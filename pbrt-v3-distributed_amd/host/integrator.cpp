@@ -141,9 +141,9 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         Error("Light sample distribution type \"%s\" unknown. Using \"spatial\".", strategy.c_str());
         strategy = "spatial";
     }
-    if (strategy == "spatial" && nl > 1)
-        Warning("lightsamplestrategy \"spatial\" (lightdistrib.cpp:96-300) is not implemented on the GPU path yet; "
-                "using \"power\" -- images will differ from the reference unless the scene asks for \"uniform\"/\"power\".");
+    // "spatial" (the reference's default) with more than one light: the device library evaluates
+    // SpatialLightDistribution::ComputeDistribution per voxel itself; light_func/light_cdf then only carry the power table.
+    bool spatial = strategy == "spatial" && nl > 1;
     bool uniform = strategy == "uniform" || nl == 1;
     fs->lightFunc.resize(nl);
     fs->lightCdf.resize(nl + 1);
@@ -168,6 +168,8 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
     d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
+    d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
+    d.integrator.spatial_max_voxels = 64;
     copyMatrix(d.camera.raster_to_camera, camera->RasterToCamera.m);
     copyMatrix(d.camera.camera_to_world, camera->CameraToWorld.m);
     for (int i = 0; i < 3; ++i) { d.camera.dx_camera[i] = camera->dxCamera[i]; d.camera.dy_camera[i] = camera->dyCamera[i]; }

@@ -140,18 +140,19 @@ def test_device_triangle_intersect_matches_reference_vectors():
     assert h["prim"][0] == -1    # Triangle.BadCases known answer
 
 
-@pytest.mark.parametrize("name,w,h,spp", [("cornell", 64, 64, 1), ("cornell", 64, 64, 8), ("materials", 96, 72, 1), ("materials", 96, 72, 16)])
-def test_render_vs_reference_fixture(name, w, h, spp):
+@pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
+                                                    ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial")])
+def test_render_vs_reference_fixture(name, w, h, spp, strategy):
     """GPU image vs the REAL reference's render (tests/golden/*.pfm).  Stated tolerance: per-pixel L2 <= 1e-3 (1 + |ref|)
     for >= 99.5 % of the pixels and relMSE <= 1e-4; at 1 spp each pixel is one camera sample's radiance."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tools", "gen_golden.py"))
     gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
-    sc = pa.Scene(text=gg.scene_text(name, w, h, spp))
+    sc = pa.Scene(text=gg.scene_text(name, w, h, spp, strategy))
     ctx = pa.Context(sc)
     ctx.render()
     img = sc.film_image(ctx.film())
-    ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp.pfm" % (name, w, h, spp)))
+    ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else "")))
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     ctx.close()

@@ -104,17 +104,18 @@ def test_distribution1d_matches_reference(vec):
             assert i2 == idx and np.float32(p2) == np.float32(pdf)
 
 
-@pytest.mark.parametrize("name,w,h,spp", [("cornell", 64, 64, 1), ("cornell", 64, 64, 8), ("materials", 96, 72, 1), ("materials", 96, 72, 16)])
-def test_oracle_render_matches_reference_image(built, name, w, h, spp):
+@pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
+                                                    ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial")])
+def test_oracle_render_matches_reference_image(built, name, w, h, spp, strategy):
     """Whole pipeline vs the reference's own render (lossless PFM fixture).  1 spp = per-camera-sample radiance.
     Tolerance: max |d| <= 2e-6 (1 + |ref|): the only differences are last-ulp film-sum / libm effects."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ol.ROOT, "tools", "gen_golden.py"))
     gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
-    sc = pa.Scene(text=gg.scene_text(name, w, h, spp))
+    sc = pa.Scene(text=gg.scene_text(name, w, h, spp, strategy))
     rgbw, cnt, _ = ol.render(sc, nthreads=4)
     img = sc.film_image(rgbw)
-    ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp.pfm" % (name, w, h, spp)))
+    ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else "")))
     assert img.shape == ref.shape
     assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())
     assert cnt["camera_rays"] == w * h * spp

@@ -30,23 +30,24 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, triangles=tri, distribution1d=raw)
     print("ref_vectors.npz:", len(ss), "sobol samples,", len(si), "indices,", len(sp), "sampler rows,", len(tri), "triangle records")
 
-    scenes = [("cornell", 64, 64, 1), ("cornell", 64, 64, 8), ("materials", 96, 72, 1), ("materials", 96, 72, 16)]
-    for name, w, h, spp in scenes:
-        text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
-        import re
-        text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
-        text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+    # strategy None = as the scene file says (cornell: uniform, materials: power); "spatial" = the reference's default
+    scenes = [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
+              ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial")]
+    for name, w, h, spp, strategy in scenes:
+        text = scene_text(name, w, h, spp, strategy)
         f = os.path.join(tmp, "s.pbrt"); open(f, "w").write(text)
-        out = os.path.join(OUT, "%s_%dx%d_%dspp.pfm" % (name, w, h, spp))
+        out = os.path.join(OUT, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else ""))
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--outfile", out, f])
         print("rendered", out)
 
 
-def scene_text(name, w, h, spp):
-    """the same scene edits as above, for the tests"""
+def scene_text(name, w, h, spp, strategy=None):
+    """the scene edits behind each fixture (also used by the tests)"""
     import re
     text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
     text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
+    if strategy:
+        text = re.sub(r'"string lightsamplestrategy" "\w+"', '"string lightsamplestrategy" "%s"' % strategy, text)
     return re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
 
 
