@@ -254,10 +254,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #endif
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
-    st.lds = &lds_stack[threadIdx.x];
-    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    st.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    st.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
     const uint32_t n = ps.qcount[MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW)];
     const uint32_t segLen = (((n + 7) / 8) + 63u) & ~63u;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     bool wantNode = active && ts.atNode();
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
-                    if (wantNode) TravNodeStep<COUNT>(sc, ts, st, &tc);
+                    if (wantNode) TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                             TriHit th;
                             TriangleTest(p0, p1, p2, ts.o, ts.d, PT_INFINITY, &th);
                             Isect li;
-                            BuildIsect(sc, ts.prim, p0, p1, p2, th, ts.d, &li);
+                            BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, ts.d, &li);
                             Li = AreaL(light, li.n, -ts.d);   // lightIsect.Le(-wi)
                         }
                     } else if (light.type == MI_LIGHT_INFINITE)
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_contrib(DevScene sc, float
             intr.p = V3(LerpB(h[0], vmin.x, vmax.x), LerpB(h[1], vmin.y, vmax.y), LerpB(h[2], vmin.z, vmax.z));
             LightSample ls;
             ls.pdf = 0; ls.Li = RGB(0.f);
-            SampleLi(sc, light, intr, h[3], h[4], &ls);
+            SampleLi(GeomTables(sc), light, intr, h[3], h[4], &ls);
             if (ls.pdf > 0) acc += ls.Li.y() / ls.pdf;
         }
         contrib[i] = acc;
@@ -483,6 +483,26 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
     }
 }
 
+#ifndef PT_SHADE_PROF
+#define PT_SHADE_PROF 0
+#endif
+#define PT_CNT_ALLOC 64
+#if PT_SHADE_PROF
+// developer instrumentation: wave time between consecutive probes (all memory drained at each probe)
+#define PROBE(k)                                                                                     \
+    {                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                                               \
+        unsigned long long pm_ = __ballot(1);                                                        \
+        if (lane_id() == (uint32_t)(__ffsll((long long)pm_) - 1)) {                                  \
+            long long now_ = clock64();                                                              \
+            atomicAdd(&ps.counters[16 + (k)], (unsigned long long)(now_ - s_prof[threadIdx.x >> 6])); \
+            atomicAdd(&ps.counters[40 + (k)], 1ull);                                                 \
+            s_prof[threadIdx.x >> 6] = now_;                                                         \
+        }                                                                                            \
+    }
+#else
+#define PROBE(k)
+#endif
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
 #ifndef PT_CDF_LDS
 #define PT_CDF_LDS 2048
@@ -493,6 +513,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
+#if PT_SHADE_PROF
+    __shared__ long long s_prof[PT_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) s_prof[threadIdx.x >> 6] = clock64();
+#endif
     const bool cdfInLds = sc.n_lights + 1 <= PT_CDF_LDS;
     if (cdfInLds) for (uint32_t k = threadIdx.x; k < sc.n_lights + 1; k += PT_BLOCK) s_cdf[k] = sc.light_cdf[k];
     __syncthreads();
@@ -501,6 +525,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
     uint32_t nseg = 0;
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
+        PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = i < n;
         bool cont = false, wantShadow = false, wantMis = false;
         uint32_t slot = 0;
@@ -514,6 +539,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             Float etaScale = b4.w;
             int bounces = (int)(s4.w & 0xffffu);
             bool specularBounce = (s4.w >> 16) & 1u;
+            PROBE(1)   // queue + path record loads
             Sampler smp;
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
             smp.dimension = (int)s4.z;
@@ -521,7 +547,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             // the (at most) 8 sample dimensions this vertex can consume: light pick, uLight, uScattering, BSDF, RR
             Float us[8];
             SobolBatch<8>(sc, smp.index, smp.dimension, us);
-            int ui = 0;
+            PROBE(2)   // Sobol batch
+            int ui = 0;      // sample dimensions consumed by this vertex (added to the path's dimension at the end)
+            int ubase = 0;   // sample dimensions consumed before the BSDF sample: 0, 1 (light pick only) or 5 -- static indices keep us[] in registers
             ++nseg;
             bool found = hr.x != MISS_PRIM;
             // path.cpp:91-101: emitted light at the vertex / from the environment
@@ -534,8 +562,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
                 TriHit th;
                 TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                BuildIsect(sc, hr.x, p0, p1, p2, th, rd, &isect);
+                BuildIsect(GeomTables(sc), hr.x, p0, p1, p2, th, rd, &isect);
             }
+            PROBE(3)   // triangle reload + BuildIsect
             if (bounces == 0 || specularBounce) {
                 if (found) {
                     int li = (int)tinfo.z;
@@ -552,7 +581,17 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                     ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                     cont = true;
                 } else {
-                    BSDF bsdf(isect, &sc.materials[matIdx]);
+                    PROBE(4)   // emission
+                    // Lanes of a wave share a material almost always (sorted queue); at the boundary between two materials
+                    // the block below runs once per distinct material, each time with a WAVE-UNIFORM material pointer:
+                    // lobe counts, types and parameters come through scalar loads and every lobe switch is a scalar branch.
+                    bool matTodo = true;
+                    while (matTodo) {
+                    int matU = UniformInt(matIdx);
+                    if (SameAs(matIdx, matU)) {
+                    matTodo = false;
+                    const mi_material *matPtr = sc.materials + matU;
+                    BSDF bsdf(isect, matPtr);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
@@ -573,7 +612,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             vfunc = sc.sp_func + vox * sc.n_lights;
                             funcInt = sc.sp_func_int[vox];
                         }
-                        Float ul = us[ui++];
+                        PROBE(5)   // BSDF ctor + NumComponents + voxel lookup
+                        Float ul = us[0];
+                        ubase = 1;
                         // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411)
                         int size = (int)sc.n_lights + 1, first = 0, len = size;
                         while (len > 0) {
@@ -584,13 +625,15 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                         Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
                         if (selPdf != 0) {
                             Float uL0, uL1, uS0, uS1;
-                            uL0 = us[ui]; uL1 = us[ui + 1]; uS0 = us[ui + 2]; uS1 = us[ui + 3];
-                            ui += 4;
+                            uL0 = us[1]; uL1 = us[2]; uS0 = us[3]; uS1 = us[4];
+                            ubase = 5;
                             // ---- EstimateDirect (core/integrator.cpp:108-215), handleMedia=false, specular=false
                             const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+                            PROBE(6)   // light pick
                             LightSample ls;
-                            SampleLi(sc, light, isect, uL0, uL1, &ls);
+                            SampleLi(GeomTables(sc), light, isect, uL0, uL1, &ls);
+                            PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
                                 RGB f = bsdf.f(isect.wo, ls.wi, bsdfFlags) * AbsDot(ls.wi, isect.ns);
@@ -609,17 +652,19 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                                     wantShadow = true;
                                 }
                             }
+                            PROBE(8)   // NEE f + Pdf + shadow ray store
                             if (!ls.delta) {   // BSDF-sampling half of the MIS estimator
                                 V3 wi;
                                 int sampledType;
                                 RGB f = bsdf.Sample_f(isect.wo, &wi, uS0, uS1, &scatteringPdf, bsdfFlags, &sampledType);
                                 f = f * AbsDot(wi, isect.ns);
+                                PROBE(9)   // MIS Sample_f
                                 bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
                                 if (!f.IsBlack() && scatteringPdf > 0) {
                                     Float weight = 1;
                                     bool ok = true;
                                     if (!sampledSpecular) {
-                                        lightPdf = PdfLi(sc, light, isect, wi);
+                                        lightPdf = PdfLi(GeomTables(sc), light, isect, wi);
                                         if (lightPdf == 0) ok = false;
                                         else weight = PowerHeuristic(scatteringPdf, lightPdf);
                                     }
@@ -635,18 +680,21 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             }
                         }
                     }
+                    PROBE(10)   // MIS PdfLi + ray store
                     // ---- sample the BSDF for the next path segment (path.cpp:131-150)
                     V3 wo = -rd, wi;
                     Float pdf, u0, u1;
                     int flags;
-                    u0 = us[ui]; u1 = us[ui + 1];
-                    ui += 2;
+                    u0 = ubase == 0 ? us[0] : (ubase == 1 ? us[1] : us[5]);
+                    u1 = ubase == 0 ? us[1] : (ubase == 1 ? us[2] : us[6]);
+                    ui = ubase + 2;
                     RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                    PROBE(11)   // path Sample_f
                     if (!(f.IsBlack() || pdf == 0.f)) {
                         beta = beta * (f * AbsDot(wi, isect.ns) / pdf);
                         specularBounce = (flags & BSDF_SPECULAR) != 0;
                         if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
-                            Float eta = sc.materials[matIdx].eta;
+                            Float eta = bsdf.m->eta;
                             etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
                         }
                         V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, wi);   // isect.SpawnRay(wi)
@@ -655,7 +703,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                         RGB rrBeta = beta * etaScale;
                         if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
                             Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
-                            if (us[ui++] < q) cont = false;
+                            Float urr = ubase == 0 ? us[2] : (ubase == 1 ? us[3] : us[7]);
+                            ++ui;
+                            if (urr < q) cont = false;
                             else beta = beta / (1 - q);
                         }
                         if (cont) {
@@ -665,8 +715,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             ++bounces;
                         }
                     }
+                    }   // matIdx == matU
+                    }   // material waterfall
                 }
             }
+            PROBE(12)   // RR + record stores
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
             if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
         }
@@ -676,6 +729,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
         if (wantShadow) ps.q_shadow[pos] = slot;
         pos = wave_append(&ps.qcount[QC_MIS], wantMis);
         if (wantMis) ps.q_mis[pos] = slot;
+        PROBE(13)   // L store + queue appends
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
 }
@@ -740,10 +794,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
 
 // ---- stage-level kernels (parity tests): one lane per input record
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
-    __shared__ uint32_t lds_stack[PT_LDS_STACK * PT_BLOCK];
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
-    st.lds = &lds_stack[threadIdx.x];
-    st.spill = ps.spill + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    st.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    st.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     TraceCounters tc = {0, 0};
     for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
         mi_ray r = rays[i];
@@ -762,7 +816,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathS
                 TriHit th;
                 TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
                 Isect is;
-                BuildIsect(sc, prim, p0, p1, p2, th, d, &is);
+                BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
                 h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
                 h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
             }
@@ -964,8 +1018,8 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
-    if (c->counters.alloc(MI_CNT_COUNT * sizeof(uint64_t))) { delete c; return -1; }
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, MI_CNT_COUNT * sizeof(uint64_t), c->stream));
+    if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { delete c; return -1; }
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream));
     *out = c;
     return 0;
 }
@@ -1226,7 +1280,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, 8);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * c->nkeys);
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
-    ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * ps.spill_per_thread);
+    ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * ps.spill_per_thread * (sizeof(StackEntry) / 4));
 #undef ALLOC
     ps.counters = c->counters.as<unsigned long long>();
     ps.cap = cap;
@@ -1394,12 +1448,22 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     if (!c || !out) return fail("mi_counters: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(out, c->counters.p, MI_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+#if PT_SHADE_PROF
+    {   // developer build only: per-phase wave cycles of k_shade
+        uint64_t all[PT_CNT_ALLOC];
+        HIP_TRY(hipMemcpyAsync(all, c->counters.p, sizeof(all), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 24; ++k)
+            if (all[40 + k]) fprintf(stderr, "[shade-prof] phase %2d: visits %12llu  cycles/visit %10.1f  total Gcycles %8.3f\n", k,
+                                     (unsigned long long)all[40 + k], (double)all[16 + k] / (double)all[40 + k], (double)all[16 + k] * 1e-9);
+    }
+#endif
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 int mi_counters_reset(mi_ctx *c) {
     if (!c) return fail("mi_counters_reset: null ctx");
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, MI_CNT_COUNT * sizeof(uint64_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream));
     return 0;
 }
 int mi_timing_enable(mi_ctx *c, int on) {

@@ -60,6 +60,19 @@ PT_DEV Float NextFloatDown(Float v) {   // core/pbrt.h:250-261
     return u2f(ui);
 }
 
+// Wave-uniform values.  readfirstlane puts the value of the first active lane into an SGPR; the empty asm makes it
+// opaque, so that the compiler cannot "simplify" it back to the (equal, but per-lane) VGPR value inside an
+// `if (v == uniform)` block -- which would turn scalar loads (s_load, scalar cache) into per-lane vector loads.
+PT_DEV int Opaque(int s) { asm volatile("" : "+s"(s)); return s; }
+PT_DEV int UniformInt(int v) { return Opaque(__builtin_amdgcn_readfirstlane(v)); }
+// v == u, computed so that the compiler learns no equality it could use to substitute v for u
+PT_DEV bool SameAs(int v, int u) { int d = v - u; asm volatile("" : "+v"(d)); return d == 0; }
+template <typename T> PT_DEV const T *UniformPtr(const T *p) {
+    unsigned long long a = (unsigned long long)p;
+    int lo = UniformInt((int)(uint32_t)a), hi = UniformInt((int)(uint32_t)(a >> 32));
+    return (const T *)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 struct V3 {
     Float x, y, z;
     PT_DEV V3() : x(0), y(0), z(0) {}

@@ -101,20 +101,19 @@ PT_DEV void SobolBatch(const DevScene &sc, uint64_t index, int dim0, Float *out)
     uint32_t v[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = 0;
-    int d0 = __builtin_amdgcn_readfirstlane(dim0);
-    if (__all(dim0 == d0)) {
-        const uint32_t *row = c_sobolT + d0;
-        for (int i = 0; i < sc.sobol_index_bits; ++i, row += PT_SOBOLT_STRIDE) {
-            uint32_t mask = 0u - ((uint32_t)(index >> i) & 1u);
+    // Lanes of a wave may sit at different dimensions (paths with specular bounces consume fewer): loop over the distinct
+    // values so that every group still reads its matrix words through the scalar cache (a "waterfall" loop).
+    bool todo = true;
+    while (todo) {   // divergent loop: the exec mask holds the lanes still waiting, readfirstlane picks one of them
+        int d0 = UniformInt(dim0);
+        if (SameAs(dim0, d0)) {
+            const uint32_t *row = c_sobolT + d0;   // scalar address: the words come through s_load
+            for (int i = 0; i < sc.sobol_index_bits; ++i, row += PT_SOBOLT_STRIDE) {
+                uint32_t mask = 0u - ((uint32_t)(index >> i) & 1u);
 #pragma unroll
-            for (int k = 0; k < N; ++k) v[k] ^= row[k] & mask;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            uint64_t a = index;
-            for (int i = (dim0 + k) * PBRT_AMD_SOBOL_NCOL; a != 0; a >>= 1, i++)
-                if (a & 1) v[k] ^= sc.sobol32[i];
+                for (int k = 0; k < N; ++k) v[k] ^= row[k] & mask;
+            }
+            todo = false;
         }
     }
 #pragma unroll
@@ -151,6 +150,15 @@ struct TriHit { Float t, b0, b1, b2; };
 
 // Per-ray constants of the watertight test (shapes/triangle.cpp:203-216): the permutation (kz = dimension of
 // largest |d|) and the shear Sx,Sy,Sz depend on the ray only, so a ray computes them once, not per triangle.
+// The compiler sinks a load into the branch that consumes it; in a traversal step that turns "fetch the node, test,
+// maybe use the child references" into two dependent memory round trips.  Pin() makes the loaded registers live at
+// the point where all loads of a step have been issued, so they are fetched together and waited for once.
+PT_DEV void Pin(float4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+PT_DEV void Pin(uint4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+PT_DEV void Pin(float4 &a, float4 &b, float4 &c) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+}
+
 struct RayShear {
     int kz;
     Float Sx, Sy, Sz;
@@ -220,6 +228,7 @@ PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, 
 PT_DEV void LoadTri(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, uint32_t *flags) {
     const float4 *tv = sc.tri_verts + 3 * (size_t)prim;
     float4 a = tv[0], b = tv[1], c = tv[2];
+    Pin(a, b, c);
     *p0 = V3(a.x, a.y, a.z); *p1 = V3(b.x, b.y, b.z); *p2 = V3(c.x, c.y, c.z);
     *flags = __float_as_uint(a.w);
 }
@@ -252,21 +261,47 @@ struct RayBox {
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][lane] layout: a
 // lane's entries sit in one bank column, so pushes/pops of a whole wave are conflict free whatever
 // the per-lane depth), deeper entries spill to a per-thread slice of an HBM buffer (rare).
+// PT_STACK_T = 1: an entry also carries the child's entry distance, so a node whose box lies beyond the hit found in
+// the meantime is dropped at pop time without fetching it -- the test the reference makes when it visits the node
+// (bvh.cpp:672 with the shrunken ray.tMax), made earlier.
+#ifndef PT_STACK_T
+#define PT_STACK_T 0
+#endif
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 24
+#define PT_LDS_STACK (PT_STACK_T ? 12 : 24)
 #endif
 #define PT_BLOCK 256
+#if PT_STACK_T
+typedef unsigned long long StackEntry;   // child reference | entry distance bits << 32
+#else
+typedef uint32_t StackEntry;
+#endif
+typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
 struct TravStack {
-    uint32_t *lds;        // &stack[0][threadIdx.x]
-    uint32_t *spill;      // per-thread spill slice
+    LdsStackEntry *lds;   // &stack[0][threadIdx.x]; typed as LDS so that pushes / pops are ds_write / ds_read, never flat
+    StackEntry *spill;    // per-thread spill slice
     int sp;
-    PT_DEV void push(uint32_t v) {
-        if (sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = v; else spill[sp - PT_LDS_STACK] = v;
+    PT_DEV void push(uint32_t v, Float t) {
+#if PT_STACK_T
+        StackEntry e = (StackEntry)v | ((StackEntry)__float_as_uint(t) << 32);
+#else
+        StackEntry e = v;
+#endif
+        if (sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = e; else spill[sp - PT_LDS_STACK] = e;
         ++sp;
     }
-    PT_DEV uint32_t pop() {
-        --sp;
-        return (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK];
+    // next node / leaf to look at, or TRAV_DONE
+    PT_DEV uint32_t pop(Float tMax) {
+        while (sp) {
+            --sp;
+            StackEntry e = (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK];
+#if PT_STACK_T
+            if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
+#else
+            return e;
+#endif
+        }
+        return 0xFFFFFFFFu;
     }
 };
 
@@ -298,7 +333,10 @@ struct TravState {
 // one interior-node step: fetch the 128-byte node (near / far planes picked by address, per ray sign), test its
 // four boxes, go to the nearest hit child and push the others far-to-near.  Empty child slots hold an inverted
 // infinite box, so they fail the interval test without a separate check.
-template <bool COUNT>
+#ifndef PT_ANY_NOSORT
+#define PT_ANY_NOSORT 0   /* experiment: shadow rays take the hit children in slot order instead of near-to-far */
+#endif
+template <bool COUNT, bool ORDERED = true>
 PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
     const char *node = reinterpret_cast<const char *>(sc.nodes + ts.cur);
     const RayBox &rb = ts.box;
@@ -306,6 +344,7 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     float4 ny = *reinterpret_cast<const float4 *>(node + rb.offNearY), fy = *reinterpret_cast<const float4 *>(node + (80u - rb.offNearY));
     float4 nz = *reinterpret_cast<const float4 *>(node + rb.offNearZ), fz = *reinterpret_cast<const float4 *>(node + (112u - rb.offNearZ));
     uint4 ch = *reinterpret_cast<const uint4 *>(node + 96);
+    Pin(nx, fx, ny); Pin(fy, nz, fz); Pin(ch);
     if (COUNT) ++cnt->nodes;
     Float t0, t1, t2, t3;
     bool h0, h1, h2, h3;
@@ -321,14 +360,24 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     PT_BOX(0, x, t0, h0) PT_BOX(1, y, t1, h1) PT_BOX(2, z, t2, h2) PT_BOX(3, w, t3, h3)
 #undef PT_BOX
     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    if (!ORDERED) {   // any-hit: the visiting order cannot change the answer
+        uint32_t nxt = TRAV_DONE;
+        Float tn = 0;
+        if (h3) { nxt = c3; tn = t3; }
+        if (h2) { if (nxt != TRAV_DONE) st.push(nxt, tn); nxt = c2; tn = t2; }
+        if (h1) { if (nxt != TRAV_DONE) st.push(nxt, tn); nxt = c1; tn = t1; }
+        if (h0) { if (nxt != TRAV_DONE) st.push(nxt, tn); nxt = c0; tn = t0; }
+        ts.cur = nxt != TRAV_DONE ? nxt : st.pop(ts.tMax);
+        return;
+    }
 #define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
     PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
 #undef PT_CSWAP
     int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-    if (nh == 0) { ts.cur = st.sp ? st.pop() : TRAV_DONE; return; }
-    if (nh > 3) st.push(c3);
-    if (nh > 2) st.push(c2);
-    if (nh > 1) st.push(c1);
+    if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
+    if (nh > 3) st.push(c3, t3);
+    if (nh > 2) st.push(c2, t2);
+    if (nh > 1) st.push(c1, t1);
     ts.cur = c0;
 }
 
@@ -350,7 +399,7 @@ PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
         ts.tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
     }
     if (left) ts.cur = BVH4_LEAF | ((left - 1) << 27) | (first + 1);
-    else ts.cur = st.sp ? st.pop() : TRAV_DONE;
+    else ts.cur = st.pop(ts.tMax);
 }
 
 // plain per-ray loop (stage-level entry points)

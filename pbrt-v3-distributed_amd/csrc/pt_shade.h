@@ -16,7 +16,16 @@ struct Isect {
     uint32_t prim;
 };
 
-PT_DEV void TriUVs(const DevScene &sc, uint32_t prim, uint32_t meshFlags, Float uv[3][2]) {   // Triangle::GetUVs shapes/triangle.h:98-108
+// The few scene tables the out-of-line routines need, passed BY VALUE (registers).  Handing them `const DevScene &`
+// would force the whole kernel-argument struct into scratch memory and turn every field access into a memory round trip.
+struct GeomTables {
+    const uint32_t *tri_indices;
+    const uint4 *tri_info;
+    const float *N, *UV;
+    PT_DEV GeomTables(const DevScene &s) : tri_indices(s.tri_indices), tri_info(s.tri_info), N(s.N), UV(s.UV) {}
+};
+
+PT_DEV void TriUVs(const GeomTables &sc, uint32_t prim, uint32_t meshFlags, Float uv[3][2]) {   // Triangle::GetUVs shapes/triangle.h:98-108
     if (sc.UV && (meshFlags & MI_MESH_HAS_UV)) {
         const uint32_t *v = sc.tri_indices + 3 * (size_t)prim;
         for (int i = 0; i < 3; ++i) { uv[i][0] = sc.UV[2 * (size_t)v[i]]; uv[i][1] = sc.UV[2 * (size_t)v[i] + 1]; }
@@ -27,8 +36,8 @@ PT_DEV void TriUVs(const DevScene &sc, uint32_t prim, uint32_t meshFlags, Float 
 
 // Second half of Triangle::Intersect (shapes/triangle.cpp:293-421): build the interaction from the
 // barycentrics the traversal found.  rayD = direction of the ray that hit.
-PT_FN void BuildIsect(const DevScene &sc, uint32_t prim, const V3 &p0, const V3 &p1, const V3 &p2, const TriHit &th,
-                       const V3 &rayD, Isect *is) {
+PT_FN void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, const TriHit th,
+                       const V3 rayD, Isect *is) {
     uint32_t mflags = sc.tri_info[prim].x;
     Float uv[3][2];
     TriUVs(sc, prim, mflags, uv);
@@ -231,7 +240,24 @@ PT_DEV int BxdfFlags(int type) {
 }
 PT_DEV bool Matches(int bxdfFlags, int flags) { return (bxdfFlags & flags) == bxdfFlags; }   // reflection.h:215
 
-PT_FN RGB BxdfF_unscaled(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+// Material records are read through the CONSTANT address space with wave-uniform addresses, i.e. with scalar loads
+// (s_load -> SGPRs, scalar cache): k_shade runs the BSDF code once per distinct material of a wave (waterfall loop),
+// so lobe counts, types and parameters never occupy vector registers or the vector memory pipe.
+typedef const __attribute__((address_space(4))) mi_material *MatConst;
+typedef const __attribute__((address_space(4))) mi_bxdf *BxdfConst;
+typedef const __attribute__((address_space(4))) uint32_t *WordConst;
+PT_DEV const mi_bxdf *Generic(BxdfConst b) { return (const mi_bxdf *)(unsigned long long)b; }
+PT_DEV void LoadBxdfUniform(mi_bxdf &dst, const mi_bxdf *p) {   // p: the same address in every active lane
+    WordConst w = (WordConst)(unsigned long long)UniformPtr(p);
+    uint32_t tmp[sizeof(mi_bxdf) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(mi_bxdf) / 4); ++i) tmp[i] = w[i];
+    __builtin_memcpy(&dst, tmp, sizeof(mi_bxdf));
+}
+
+PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+    mi_bxdf b;
+    LoadBxdfUniform(b, bp);
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
@@ -291,11 +317,13 @@ PT_FN RGB BxdfF_unscaled(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     default: return RGB(0.f);   // specular lobes evaluate to zero
     }
 }
-PT_DEV RGB BxdfF(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
-    RGB f = BxdfF_unscaled(b, wo, wi);
-    return b.scaled ? rgb3(b.scale) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
+PT_DEV RGB BxdfF(BxdfConst b, const V3 &wo, const V3 &wi) {
+    RGB f = BxdfF_unscaled(Generic(b), wo, wi);
+    return b->scaled ? RGB(b->scale[0], b->scale[1], b->scale[2]) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
 }
-PT_FN Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+    mi_bxdf b;
+    LoadBxdfUniform(b, bp);
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
@@ -325,20 +353,22 @@ PT_FN Float BxdfPdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     }
 }
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
-PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+PT_FN RGB BxdfSample_f(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+    mi_bxdf b;
+    LoadBxdfUniform(b, bp);
     RGB f;
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
-        *pdf = BxdfPdf(b, wo, *wi);
-        f = BxdfF_unscaled(b, wo, *wi);
+        *pdf = BxdfPdf(bp, wo, *wi);
+        f = BxdfF_unscaled(bp, wo, *wi);
         break;
     case MI_BXDF_LAMBERT_T:                            // :391-398
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
-        *pdf = BxdfPdf(b, wo, *wi);
-        f = BxdfF_unscaled(b, wo, *wi);
+        *pdf = BxdfPdf(bp, wo, *wi);
+        f = BxdfF_unscaled(bp, wo, *wi);
         break;
     case MI_BXDF_SPECULAR_R:                           // :136-143
         *wi = V3(-wo.x, -wo.y, wo.z);
@@ -381,7 +411,7 @@ PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u
         *wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
-        f = BxdfF_unscaled(b, wo, *wi);
+        f = BxdfF_unscaled(bp, wo, *wi);
         break;
     }
     case MI_BXDF_MICROFACET_T: {                       // :425-434
@@ -390,8 +420,8 @@ PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u
         V3 wh = dist.Sample_wh(wo, u0, u1);
         Float eta = CosTheta(wo) > 0 ? (b.etaA / b.etaB) : (b.etaB / b.etaA);
         if (!Refract(wo, wh, eta, wi)) return RGB(0.f);
-        *pdf = BxdfPdf(b, wo, *wi);
-        f = BxdfF_unscaled(b, wo, *wi);
+        *pdf = BxdfPdf(bp, wo, *wi);
+        f = BxdfF_unscaled(bp, wo, *wi);
         break;
     }
     case MI_BXDF_FRESNEL_BLEND: {                      // :450-468
@@ -406,8 +436,8 @@ PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u
             *wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         }
-        *pdf = BxdfPdf(b, wo, *wi);
-        f = BxdfF_unscaled(b, wo, *wi);
+        *pdf = BxdfPdf(bp, wo, *wi);
+        f = BxdfF_unscaled(bp, wo, *wi);
         break;
     }
     }
@@ -416,9 +446,9 @@ PT_FN RGB BxdfSample_f(const mi_bxdf &b, const V3 &wo, V3 *wi, Float u0, Float u
 
 // ------------------------------------------------------------------ BSDF (core/reflection.h:153-202)
 struct BSDF {
-    const mi_material *m;
+    MatConst m;   // wave-uniform (see above)
     V3 ns, ng, ss, ts;
-    PT_DEV BSDF(const Isect &si, const mi_material *mat) : m(mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
+    PT_DEV BSDF(const Isect &si, const mi_material *mat) : m((MatConst)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
     PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     PT_DEV V3 LocalToWorld(const V3 &v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
@@ -434,8 +464,8 @@ struct BSDF {
         bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
         RGB f(0.f);
         for (int i = 0; i < m->n_bxdfs; ++i) {
-            const mi_bxdf &b = m->bxdfs[i];
-            int t = BxdfFlags(b.type);
+            BxdfConst b = &m->bxdfs[i];
+            int t = BxdfFlags(b->type);
             if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
         }
         return f;
@@ -447,36 +477,44 @@ struct BSDF {
         Float pdf = 0.f;
         int matchingComps = 0;
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf(m->bxdfs[i], wo, wi); }
+            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf(Generic(&m->bxdfs[i]), wo, wi); }
         return matchingComps > 0 ? pdf / matchingComps : 0.f;
     }
     PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
         int matchingComps = NumComponents(type);
         if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return RGB(0.f); }
         int comp = mni((int)__builtin_floorf(u0 * matchingComps), matchingComps - 1);
+        // the comp-th matching lobe (per lane: u0 differs) -- found with a wave-uniform loop over the lobes
         int chosen = 0, count = comp;
+        bool have = false;
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (Matches(BxdfFlags(m->bxdfs[i].type), type) && count-- == 0) { chosen = i; break; }
-        const mi_bxdf &bxdf = m->bxdfs[chosen];
+            if (!have && Matches(BxdfFlags(m->bxdfs[i].type), type) && count-- == 0) { chosen = i; have = true; }
         Float ur0 = mn(u0 * matchingComps - comp, PT_ONE_MINUS_EPS);
         V3 wi, wo = WorldToLocal(woWorld);
         if (wo.z == 0) return RGB(0.f);
         *pdf = 0;
-        int bt = BxdfFlags(bxdf.type);
-        *sampledType = bt;
-        RGB f = BxdfSample_f(bxdf, wo, &wi, ur0, u1, pdf, sampledType);
+        int bt = 0;
+        RGB f(0.f);
+        // lanes may have chosen different lobes: each lobe's sampling routine runs for the lanes that picked it,
+        // every time with a wave-uniform lobe pointer
+        for (int i = 0; i < m->n_bxdfs; ++i)
+            if (chosen == i) {
+                bt = BxdfFlags(m->bxdfs[i].type);
+                *sampledType = bt;
+                f = BxdfSample_f(Generic(&m->bxdfs[i]), wo, &wi, ur0, u1, pdf, sampledType);
+            }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
         if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
             for (int i = 0; i < m->n_bxdfs; ++i)
-                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf(m->bxdfs[i], wo, wi);
+                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf(Generic(&m->bxdfs[i]), wo, wi);
         if (matchingComps > 1) *pdf /= matchingComps;
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
             f = RGB(0.f);
             for (int i = 0; i < m->n_bxdfs; ++i) {
-                const mi_bxdf &b = m->bxdfs[i];
-                int t = BxdfFlags(b.type);
+                BxdfConst b = &m->bxdfs[i];
+                int t = BxdfFlags(b->type);
                 if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
             }
         }
@@ -502,7 +540,7 @@ PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, c
 
 struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
 
-PT_FN void SampleLi(const DevScene &sc, const DevLight &dl, const Isect &ref, Float u0, Float u1, LightSample *ls) {
+PT_FN void SampleLi(const GeomTables sc, const DevLight &dl, const Isect &ref, Float u0, Float u1, LightSample *ls) {
     const mi_light &l = dl.l;
     ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
     if (l.type == MI_LIGHT_AREA_TRI) {
@@ -569,7 +607,7 @@ PT_FN void SampleLi(const DevScene &sc, const DevLight &dl, const Isect &ref, Fl
 }
 
 // Light::Pdf_Li
-PT_FN Float PdfLi(const DevScene &sc, const DevLight &dl, const Isect &ref, const V3 &wi) {
+PT_FN Float PdfLi(const GeomTables sc, const DevLight &dl, const Isect &ref, const V3 wi) {
     const mi_light &l = dl.l;
     if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
         V3 o = OffsetRayOrigin(ref.p, ref.pError, ref.n, wi);
