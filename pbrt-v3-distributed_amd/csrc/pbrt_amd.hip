@@ -1392,7 +1392,18 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     if (tiles.empty()) return 0;
     if (upload(c, c->tiles, tiles.data(), tiles.size() * sizeof(uint32_t))) return -1;
     uint64_t npixOwned = (uint64_t)tiles.size() * 256;
-    uint32_t cap = rp->max_paths_in_flight > 0 ? (uint32_t)rp->max_paths_in_flight : (1u << 23);
+    // Paths in flight per pass.  Every launch of the wavefront pipeline ends with a tail (the longest rays) and starts with
+    // fixed costs, so the pool is made as large as the frame allows -- up to 2^27 paths (37 GB of path state) and at most
+    // 60 % of the free HBM: measured 145 -> 190 Msamples/s on the 1080p/64 spp frame going from 2^23 to a single pass.
+    uint32_t cap = rp->max_paths_in_flight > 0 ? (uint32_t)rp->max_paths_in_flight : (1u << 27);
+    if (rp->max_paths_in_flight <= 0) {
+        size_t freeB = 0, totalB = 0;
+        const size_t perPath = sizeof(PathRec) + sizeof(NeeRec) + sizeof(uint32_t) * 6 + sizeof(uint2);
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            size_t budget = freeB / 10 * 6 + (size_t)c->cap * perPath;   // what is allocated for path state now would be released
+            cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(budget / perPath, 1u << 20));
+        }
+    }
     cap = std::max(cap, 256u * 64u);
     uint64_t want = std::min<uint64_t>(cap, npixOwned * (uint64_t)(s1 - s0));
     if (ensure_state(c, (uint32_t)std::max<uint64_t>(want, 256 * 64))) return -1;
