@@ -455,9 +455,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_contrib(DevScene sc, float
         for (int k = 0; k < PT_SPATIAL_SAMPLES; ++k) {
             const float *h = &s_h[5 * k];
             intr.p = V3(LerpB(h[0], vmin.x, vmax.x), LerpB(h[1], vmin.y, vmax.y), LerpB(h[2], vmin.z, vmax.z));
-            LightSample ls;
-            ls.pdf = 0; ls.Li = RGB(0.f);
-            SampleLi(GeomTables(sc), light, intr, h[3], h[4], &ls);
+            LightSample ls = SampleLi(GeomTables(sc), &light, intr.p, intr.pError, intr.n, h[3], h[4]);
             if (ls.pdf > 0) acc += ls.Li.y() / ls.pdf;
         }
         contrib[i] = acc;
@@ -557,12 +555,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             uint4 tinfo = make_uint4(0, 0, 0, 0);
             if (found) {
                 tinfo = sc.tri_info[hr.x];
+                TriShadeRegs tsr = LoadTriShade(sc.tri_shade, hr.x);   // with the vertices: one memory round trip
                 V3 p0, p1, p2;
                 uint32_t tf;
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
+                Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d); Pin(tinfo);
                 TriHit th;
                 TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                BuildIsect(GeomTables(sc), hr.x, p0, p1, p2, th, rd, &isect);
+                isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rd, hr.x);
             }
             PROBE(3)   // triangle reload + BuildIsect
             if (bounces == 0 || specularBounce) {
@@ -615,11 +615,30 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                         PROBE(5)   // BSDF ctor + NumComponents + voxel lookup
                         Float ul = us[0];
                         ubase = 1;
-                        // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411)
-                        int size = (int)sc.n_lights + 1, first = 0, len = size;
-                        while (len > 0) {
-                            int half = len >> 1, middle = first + half;
-                            if (vcdf[middle] <= ul) { first = middle + 1; len -= half + 1; } else len = half;
+                        // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411): `first` = the
+                        // number of leading cdf entries <= u (the cdf is non-decreasing, so the reference's bisection finds exactly
+                        // that count).  Found here with up to 16 independent probes per round -- 2 memory round trips for a few
+                        // hundred lights instead of 8 dependent ones.
+                        int size = (int)sc.n_lights + 1, first = 0;
+                        {
+                            int lo = 0, hi = size;   // entries below lo are <= u; entries from hi on are > u
+                            while (lo < hi) {
+                                int step = (hi - lo + 15) >> 4;
+                                float pv[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) {
+                                    int idx = lo + (k + 1) * step - 1;
+                                    pv[k] = idx < hi ? vcdf[idx] : PT_INFINITY;
+                                }
+                                int cnt = 0;
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) cnt += (pv[k] <= ul) ? 1 : 0;   // a prefix of the probes
+                                int nlo = lo + cnt * step;
+                                int nhi = lo + (cnt + 1) * step - 1;
+                                hi = nhi < hi ? nhi : hi;
+                                lo = nlo < hi ? nlo : hi;
+                            }
+                            first = lo;
                         }
                         int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
                         Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
@@ -631,8 +650,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
                             PROBE(6)   // light pick
-                            LightSample ls;
-                            SampleLi(GeomTables(sc), light, isect, uL0, uL1, &ls);
+                            LightSample ls = SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1);
                             PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
@@ -664,7 +682,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                                     Float weight = 1;
                                     bool ok = true;
                                     if (!sampledSpecular) {
-                                        lightPdf = PdfLi(GeomTables(sc), light, isect, wi);
+                                        lightPdf = PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi);
                                         if (lightPdf == 0) ok = false;
                                         else weight = PowerHeuristic(scatteringPdf, lightPdf);
                                     }
@@ -1106,20 +1124,38 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         tv[3 * (size_t)t + 2] = make_float4(p2[0], p2[1], p2[2], 0);
     }
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
-    { DevBuf &b = next(); if (upload(c, b, d->tri_indices, 3 * (size_t)d->n_tris * 4)) return -1; sc.tri_indices = b.as<uint32_t>(); }
+    {   // per-triangle shading records (TriShade): vertex normals + uvs gathered through the index buffer
+        std::vector<TriShade> tsd(d->n_tris);
+        for (uint32_t t = 0; t < d->n_tris; ++t) {
+            const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+            const mi_mesh &m = d->meshes[d->tri_mesh[t]];
+            TriShade &r = tsd[t];
+            std::memset(&r, 0, sizeof(r));
+            if (d->N && (m.flags & MI_MESH_HAS_N))
+                for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) r.n[3 * k + a] = d->N[3 * (size_t)v[k] + a];
+            if (d->UV && (m.flags & MI_MESH_HAS_UV)) {
+                for (int k = 0; k < 3; ++k) { r.uv[2 * k] = d->UV[2 * (size_t)v[k]]; r.uv[2 * k + 1] = d->UV[2 * (size_t)v[k] + 1]; }
+            } else { r.uv[0] = 0; r.uv[1] = 0; r.uv[2] = 1; r.uv[3] = 0; r.uv[4] = 1; r.uv[5] = 1; }
+        }
+        DevBuf &b = next();
+        if (upload(c, b, tsd.data(), tsd.size() * sizeof(TriShade))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        sc.tri_shade = b.as<TriShade>();
+    }
     {
         std::vector<uint4> ti(d->n_tris);
         for (uint32_t t = 0; t < d->n_tris; ++t) {
             const mi_mesh &m = d->meshes[d->tri_mesh[t]];
-            ti[t] = make_uint4(m.flags, (uint32_t)m.material, (uint32_t)d->tri_light[t], d->tri_mesh[t]);
+            uint32_t mf = m.flags;
+            if (!d->N) mf &= ~MI_MESH_HAS_N;
+            if (!d->UV) mf &= ~MI_MESH_HAS_UV;
+            ti[t] = make_uint4(mf, (uint32_t)m.material, (uint32_t)d->tri_light[t], d->tri_mesh[t]);
         }
         DevBuf &b = next();
         if (upload(c, b, ti.data(), ti.size() * sizeof(uint4))) return -1;
         HIP_TRY(hipStreamSynchronize(c->stream));
         sc.tri_info = b.as<uint4>();
     }
-    if (d->N) { DevBuf &b = next(); if (upload(c, b, d->N, 3 * (size_t)d->n_verts * 4)) return -1; sc.N = b.as<float>(); }
-    if (d->UV) { DevBuf &b = next(); if (upload(c, b, d->UV, 2 * (size_t)d->n_verts * 4)) return -1; sc.UV = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
     {
         std::vector<DevLight> dl(d->n_lights);
@@ -1134,7 +1170,10 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
                 dl[i].p2[0] = v[2].x; dl[i].p2[1] = v[2].y; dl[i].p2[2] = v[2].z;
                 uint32_t fl;
                 std::memcpy(&fl, &v[0].w, 4);
-                dl[i].mesh_flags = d->meshes[d->tri_mesh[t]].flags | ((fl & TRI_FLAG_REJECT) ? 0x80000000u : 0u);
+                uint32_t mf = d->meshes[d->tri_mesh[t]].flags;
+                if (!d->N) mf &= ~MI_MESH_HAS_N;
+                if (!d->UV) mf &= ~MI_MESH_HAS_UV;
+                dl[i].mesh_flags = mf | ((fl & TRI_FLAG_REJECT) ? 0x80000000u : 0u);
             }
         }
         DevBuf &b = next();

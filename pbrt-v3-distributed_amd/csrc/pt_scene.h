@@ -32,13 +32,20 @@ struct DevLight {
     float p2[3]; uint32_t pad2;
 };
 
+// Per-triangle shading record: the vertex normals and uvs the interaction needs, gathered per triangle at upload time
+// (one 64-byte fetch instead of the reference's indices -> per-vertex arrays chain).  Meshes without normals / uvs
+// hold zeros / the default (0,0),(1,0),(1,1) of Triangle::GetUVs (shapes/triangle.h:98-108).
+struct __attribute__((aligned(64))) TriShade {
+    float n[9];    // n0, n1, n2
+    float uv[6];   // uv0, uv1, uv2
+    uint32_t pad;
+};
+
 struct DevScene {
     const BVH4Node *nodes;
     const float4 *tri_verts;        // 3 per triangle
-    const uint32_t *tri_indices;    // 3 per triangle (vertex ids for N / UV)
+    const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
-    const float *N;                 // may be null
-    const float *UV;                // may be null
     const mi_material *materials;
     const DevLight *lights;         // mi_light + (area lights) the triangle's vertices and mesh flags: no extra hops while sampling
     const float *light_func, *light_cdf;

@@ -19,28 +19,48 @@ struct Isect {
 // The few scene tables the out-of-line routines need, passed BY VALUE (registers).  Handing them `const DevScene &`
 // would force the whole kernel-argument struct into scratch memory and turn every field access into a memory round trip.
 struct GeomTables {
-    const uint32_t *tri_indices;
     const uint4 *tri_info;
-    const float *N, *UV;
-    PT_DEV GeomTables(const DevScene &s) : tri_indices(s.tri_indices), tri_info(s.tri_info), N(s.N), UV(s.UV) {}
+    const TriShade *tri_shade;
+    PT_DEV GeomTables(const DevScene &s) : tri_info(s.tri_info), tri_shade(s.tri_shade) {}
 };
-
-PT_DEV void TriUVs(const GeomTables &sc, uint32_t prim, uint32_t meshFlags, Float uv[3][2]) {   // Triangle::GetUVs shapes/triangle.h:98-108
-    if (sc.UV && (meshFlags & MI_MESH_HAS_UV)) {
-        const uint32_t *v = sc.tri_indices + 3 * (size_t)prim;
-        for (int i = 0; i < 3; ++i) { uv[i][0] = sc.UV[2 * (size_t)v[i]]; uv[i][1] = sc.UV[2 * (size_t)v[i] + 1]; }
-    } else {
-        uv[0][0] = 0; uv[0][1] = 0; uv[1][0] = 1; uv[1][1] = 0; uv[2][0] = 1; uv[2][1] = 1;
-    }
+// a TriShade record in registers
+struct TriShadeRegs {
+    float4 a, b, c, d;   // n0.xyz n1.x | n1.yz n2.xy | n2.z uv0.xy uv1.x | uv1.y uv2.xy pad
+    PT_DEV V3 n0() const { return V3(a.x, a.y, a.z); }
+    PT_DEV V3 n1() const { return V3(a.w, b.x, b.y); }
+    PT_DEV V3 n2() const { return V3(b.z, b.w, c.x); }
+};
+PT_DEV TriShadeRegs LoadTriShade(const TriShade *ts, uint32_t prim) {
+    const float4 *q = reinterpret_cast<const float4 *>(ts + prim);
+    TriShadeRegs r;
+    r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3];
+    return r;
 }
 
 // Second half of Triangle::Intersect (shapes/triangle.cpp:293-421): build the interaction from the
-// barycentrics the traversal found.  rayD = direction of the ray that hit.
-PT_FN void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, const TriHit th,
-                       const V3 rayD, Isect *is) {
-    uint32_t mflags = sc.tri_info[prim].x;
-    Float uv[3][2];
-    TriUVs(sc, prim, mflags, uv);
+// barycentrics the traversal found.  rayD = direction of the ray that hit; mflags / tsr = the triangle's mesh flags
+// and shading record (loaded by the caller together with the vertices: one memory round trip).
+// Arguments and result travel in registers (by value): a pointer to a caller's local would put it in scratch memory.
+// (29 argument registers, 15 result registers: more of either would go through the stack; wo and prim are the caller's)
+struct IsectCore { V3 p, pError, n, ns, dpdus; };
+PT_DEV Isect BuildIsectBody(uint32_t mflags, const TriShadeRegs &tsr, const V3 &p0, const V3 &p1, const V3 &p2, const V3 &bary);
+PT_FN IsectCore BuildIsectPre(uint32_t mflags, const TriShadeRegs tsr, const V3 p0, const V3 p1, const V3 p2, const V3 bary) {
+    Isect is = BuildIsectBody(mflags, tsr, p0, p1, p2, bary);
+    IsectCore c;
+    c.p = is.p; c.pError = is.pError; c.n = is.n; c.ns = is.ns; c.dpdus = is.dpdus;
+    return c;
+}
+PT_DEV Isect MakeIsect(const IsectCore &c, const V3 &rayD, uint32_t prim) {
+    Isect is;
+    is.p = c.p; is.pError = c.pError; is.n = c.n; is.ns = c.ns; is.dpdus = c.dpdus;
+    is.wo = Normalize(-rayD);   // Interaction ctor: wo(Normalize(wo)), core/interaction.h:60
+    is.prim = prim;
+    return is;
+}
+PT_DEV Isect BuildIsectBody(uint32_t mflags, const TriShadeRegs &tsr, const V3 &p0, const V3 &p1, const V3 &p2, const V3 &bary) {
+    Isect isv;
+    Isect *is = &isv;
+    Float uv[3][2] = {{tsr.c.y, tsr.c.z}, {tsr.c.w, tsr.d.x}, {tsr.d.y, tsr.d.z}};   // Triangle::GetUVs
     Float duv02x = uv[0][0] - uv[2][0], duv02y = uv[0][1] - uv[2][1], duv12x = uv[1][0] - uv[2][0], duv12y = uv[1][1] - uv[2][1];
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     Float determinant = duv02x * duv12y - duv02y * duv12x;
@@ -55,20 +75,18 @@ PT_FN void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3 
         V3 ng = Cross(p2 - p0, p1 - p0);   // non-zero: TRI_FLAG_REJECT triangles never get here
         CoordinateSystem(Normalize(ng), &dpdu, &dpdv);
     }
-    Float b0 = th.b0, b1 = th.b1, b2 = th.b2;
+    Float b0 = bary.x, b1 = bary.y, b2 = bary.z;
     Float xAbsSum = (absf(b0 * p0.x) + absf(b1 * p1.x) + absf(b2 * p2.x));
     Float yAbsSum = (absf(b0 * p0.y) + absf(b1 * p1.y) + absf(b2 * p2.y));
     Float zAbsSum = (absf(b0 * p0.z) + absf(b1 * p1.z) + absf(b2 * p2.z));
     is->pError = gamma_n(7) * V3(xAbsSum, yAbsSum, zAbsSum);
     is->p = b0 * p0 + b1 * p1 + b2 * p2;
-    is->wo = Normalize(-rayD);   // Interaction ctor: wo(Normalize(wo)), core/interaction.h:60
-    is->prim = prim;
+    is->wo = V3(); is->prim = 0;
     is->n = is->ns = Normalize(Cross(dp02, dp12));   // triangle.cpp:346
     is->dpdus = dpdu;
     bool flip = (mflags & MI_MESH_FLIP) != 0;
-    if (sc.N && (mflags & MI_MESH_HAS_N)) {   // :347-415
-        const uint32_t *v = sc.tri_indices + 3 * (size_t)prim;
-        V3 n0 = v3(sc.N + 3 * (size_t)v[0]), n1 = v3(sc.N + 3 * (size_t)v[1]), n2 = v3(sc.N + 3 * (size_t)v[2]);
+    if (mflags & MI_MESH_HAS_N) {   // :347-415
+        V3 n0 = tsr.n0(), n1 = tsr.n1(), n2 = tsr.n2();
         V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
         if (ns.LengthSquared() > 0) ns = Normalize(ns); else ns = is->n;
         V3 ss = Normalize(dpdu);
@@ -84,6 +102,13 @@ PT_FN void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3 
     } else if (flip) {
         is->n = is->ns = -is->n;              // :420-421
     }
+    return isv;
+}
+PT_DEV void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, const TriHit th, const V3 rayD, Isect *is) {
+    uint32_t mflags = sc.tri_info[prim].x;
+    TriShadeRegs tsr = LoadTriShade(sc.tri_shade, prim);
+    Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d);
+    *is = MakeIsect(BuildIsectPre(mflags, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rayD, prim);
 }
 
 // ------------------------------------------------------------------ BxDFs (core/reflection.{h,cpp})
@@ -353,7 +378,15 @@ PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     }
 }
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
-PT_FN RGB BxdfSample_f(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+struct BxdfSample { RGB f; V3 wi; Float pdf; int sampledType; };
+PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
+PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const V3 wo, Float u0, Float u1, int sampledTypeIn) {   // by value: registers, no scratch
+    BxdfSample r;
+    r.wi = V3(); r.pdf = 0; r.sampledType = sampledTypeIn;
+    r.f = BxdfSample_f_impl(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
+    return r;
+}
+PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdfUniform(b, bp);
     RGB f;
@@ -500,8 +533,8 @@ struct BSDF {
         for (int i = 0; i < m->n_bxdfs; ++i)
             if (chosen == i) {
                 bt = BxdfFlags(m->bxdfs[i].type);
-                *sampledType = bt;
-                f = BxdfSample_f(Generic(&m->bxdfs[i]), wo, &wi, ur0, u1, pdf, sampledType);
+                BxdfSample bs = BxdfSample_f(Generic(&m->bxdfs[i]), wo, ur0, u1, bt);
+                f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
@@ -540,21 +573,48 @@ PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, c
 
 struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
 
-PT_FN void SampleLi(const GeomTables sc, const DevLight &dl, const Isect &ref, Float u0, Float u1, LightSample *ls) {
-    const mi_light &l = dl.l;
+// A DevLight record in registers: fetched with 7 independent 16-byte loads (one memory round trip)
+struct LightRegs {
+    int type, tri, two_sided;
+    RGB L; Float area;
+    V3 pos; Float world_radius;
+    V3 p0, p1, p2; uint32_t mesh_flags;
+};
+PT_DEV LightRegs LoadLight(const DevLight *dl) {
+    const float4 *q = reinterpret_cast<const float4 *>(dl);
+    float4 a = q[0], b = q[1], c = q[2], e = q[4], f = q[5], g = q[6];
+    Pin(a, b, c); Pin(e, f, g);
+    LightRegs r;
+    r.type = (int)__float_as_uint(a.x); r.tri = (int)__float_as_uint(a.y); r.two_sided = (int)__float_as_uint(a.z);
+    r.L = RGB(b.x, b.y, b.z); r.area = b.w;
+    r.pos = V3(c.x, c.y, c.z); r.world_radius = c.w;
+    r.p0 = V3(e.x, e.y, e.z); r.mesh_flags = __float_as_uint(e.w);
+    r.p1 = V3(f.x, f.y, f.z); r.p2 = V3(g.x, g.y, g.z);
+    return r;
+}
+PT_DEV RGB AreaL(const LightRegs &l, const V3 &n, const V3 &w) { return (l.two_sided || Dot(n, w) > 0) ? l.L : RGB(0.f); }
+
+// Light::Sample_Li.  ref*: the reference point's p, pError, n (what Sample_Li and VisibilityTester's SpawnRayTo use).
+PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1) {
+    LightSample lsv;
+    LightSample *ls = &lsv;
+    Isect ref;
+    ref.p = refP; ref.pError = refPError; ref.n = refN;
+    const LightRegs l = LoadLight(dl);
+    ls->pdf = 0; ls->Li = RGB(0.f);
     ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
     if (l.type == MI_LIGHT_AREA_TRI) {
         // DiffuseAreaLight::Sample_Li lights/diffuse.cpp:68-81 -> Shape::Sample(ref,u) core/shape.cpp:56-70
         // -> Triangle::Sample(u) shapes/triangle.cpp:583-608
         Float su0 = sqrtf_(u0);
         Float b0 = 1 - su0, b1 = u1 * su0;   // UniformSampleTriangle core/sampling.cpp:154-157
-        V3 p0 = v3(dl.p0), p1 = v3(dl.p1), p2 = v3(dl.p2);
+        V3 p0 = l.p0, p1 = l.p1, p2 = l.p2;
         V3 p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
         V3 n = Normalize(Cross(p1 - p0, p2 - p0));
-        uint32_t mflags = dl.mesh_flags;
-        if (sc.N && (mflags & MI_MESH_HAS_N)) {
-            const uint32_t *v = sc.tri_indices + 3 * (size_t)l.tri;
-            V3 n0 = v3(sc.N + 3 * (size_t)v[0]), n1 = v3(sc.N + 3 * (size_t)v[1]), n2 = v3(sc.N + 3 * (size_t)v[2]);
+        uint32_t mflags = l.mesh_flags;
+        if (mflags & MI_MESH_HAS_N) {
+            TriShadeRegs tsr = LoadTriShade(sc.tri_shade, (uint32_t)l.tri);
+            V3 n0 = tsr.n0(), n1 = tsr.n1(), n2 = tsr.n2();
             V3 ns = b0 * n0 + b1 * n1 + (1 - b0 - b1) * n2;
             n = Faceforward(n, ns);
         } else if (mflags & MI_MESH_FLIP)
@@ -569,29 +629,29 @@ PT_FN void SampleLi(const GeomTables sc, const DevLight &dl, const Isect &ref, F
             pdf *= DistanceSquared(ref.p, p) / AbsDot(n, -wi);
             if (__builtin_isinf(pdf)) pdf = 0.f;
         }
-        if (pdf == 0 || (p - ref.p).LengthSquared() == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return; }
+        if (pdf == 0 || (p - ref.p).LengthSquared() == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return lsv; }
         ls->wi = Normalize(p - ref.p);
         ls->pdf = pdf;
         ls->shadow = SpawnRayTo(ref, p, pError, n);
         ls->Li = AreaL(l, n, -ls->wi);
-        return;
+        return lsv;
     }
     if (l.type == MI_LIGHT_POINT) {   // lights/point.cpp:44-53
-        V3 pLight = v3(l.pos);
+        V3 pLight = l.pos;
         ls->wi = Normalize(pLight - ref.p);
         ls->pdf = 1.f;
         ls->shadow = SpawnRayTo(ref, pLight, V3(), V3());
-        ls->Li = rgb3(l.L) / DistanceSquared(pLight, ref.p);
-        return;
+        ls->Li = l.L / DistanceSquared(pLight, ref.p);
+        return lsv;
     }
     if (l.type == MI_LIGHT_DISTANT) {   // lights/distant.cpp:49-59
-        V3 wLight = v3(l.pos);
+        V3 wLight = l.pos;
         ls->wi = wLight;
         ls->pdf = 1;
         V3 pOutside = ref.p + wLight * (2 * l.world_radius);
         ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
-        ls->Li = rgb3(l.L);
-        return;
+        ls->Li = l.L;
+        return lsv;
     }
     {   // constant InfiniteAreaLight, lights/infinite.cpp:108-132 with a 1x1 map (uv = u, mapPdf = 1)
         Float theta = u1 * PT_PI, phi = u0 * 2 * PT_PI;
@@ -602,21 +662,22 @@ PT_FN void SampleLi(const GeomTables sc, const DevLight &dl, const Isect &ref, F
         if (sinTheta == 0) ls->pdf = 0;
         V3 pOutside = ref.p + ls->wi * (2 * l.world_radius);
         ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
-        ls->Li = rgb3(l.L);
+        ls->Li = l.L;
     }
+    return lsv;
 }
 
 // Light::Pdf_Li
-PT_FN Float PdfLi(const GeomTables sc, const DevLight &dl, const Isect &ref, const V3 wi) {
-    const mi_light &l = dl.l;
+PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, const V3 wi) {
+    const LightRegs l = LoadLight(dl);
     if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
-        V3 o = OffsetRayOrigin(ref.p, ref.pError, ref.n, wi);
-        V3 p0 = v3(dl.p0), p1 = v3(dl.p1), p2 = v3(dl.p2);
+        V3 o = OffsetRayOrigin(refP, refPError, refN, wi);
+        V3 p0 = l.p0, p1 = l.p1, p2 = l.p2;
         TriHit th;
-        if ((dl.mesh_flags & 0x80000000u) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;   // bit 31: TRI_FLAG_REJECT of that triangle
+        if ((l.mesh_flags & 0x80000000u) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;   // bit 31: TRI_FLAG_REJECT of that triangle
         Isect li;
-        BuildIsect(sc, l.tri, p0, p1, p2, th, wi, &li);
-        Float pdf = DistanceSquared(ref.p, li.p) / (AbsDot(li.n, -wi) * l.area);
+        BuildIsect(sc, (uint32_t)l.tri, p0, p1, p2, th, wi, &li);
+        Float pdf = DistanceSquared(refP, li.p) / (AbsDot(li.n, -wi) * l.area);
         if (__builtin_isinf(pdf)) pdf = 0.f;
         return pdf;
     }
