@@ -107,6 +107,21 @@ PT_DEV uint32_t wave_append(uint32_t *counter, bool active) {
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+// three appends at once (k_shade's extension / shadow / MIS queues): lanes 0..2 issue the three atomics in ONE
+// instruction, so the wave pays one atomic round trip instead of three dependent ones
+PT_DEV void wave_append3(uint32_t *c0, uint32_t *c1, uint32_t *c2, bool a0, bool a1, bool a2, uint32_t *p0, uint32_t *p1, uint32_t *p2) {
+    unsigned long long m0 = __ballot(a0), m1 = __ballot(a1), m2 = __ballot(a2);
+    uint32_t lane = lane_id();
+    uint32_t n = lane == 0 ? (uint32_t)__popcll(m0) : (lane == 1 ? (uint32_t)__popcll(m1) : (uint32_t)__popcll(m2));
+    uint32_t *ctr = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+    uint32_t base = 0;
+    if (lane < 3 && n) base = atomicAdd(ctr, n);
+    uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2);
+    unsigned long long lt = (1ull << lane) - 1ull;
+    *p0 = b0 + (uint32_t)__popcll(m0 & lt);
+    *p1 = b1 + (uint32_t)__popcll(m1 & lt);
+    *p2 = b2 + (uint32_t)__popcll(m2 & lt);
+}
 // wave-aggregated histogram slot: lanes with equal key share one atomic (match-any built from ballots)
 PT_DEV uint32_t wave_key_rank(uint32_t *keycount, uint32_t key, bool active) {
     uint32_t lane = lane_id();
@@ -741,12 +756,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
             if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
         }
-        uint32_t pos = wave_append(&ps.qcount[qout], cont);
-        if (cont) ps.q_ext[qout][pos] = slot;
-        pos = wave_append(&ps.qcount[QC_SHADOW], wantShadow);
-        if (wantShadow) ps.q_shadow[pos] = slot;
-        pos = wave_append(&ps.qcount[QC_MIS], wantMis);
-        if (wantMis) ps.q_mis[pos] = slot;
+        uint32_t posE, posS, posM;
+        wave_append3(&ps.qcount[qout], &ps.qcount[QC_SHADOW], &ps.qcount[QC_MIS], cont, wantShadow, wantMis, &posE, &posS, &posM);
+        if (cont) ps.q_ext[qout][posE] = slot;
+        if (wantShadow) ps.q_shadow[posS] = slot;
+        if (wantMis) ps.q_mis[posM] = slot;
         PROBE(13)   // L store + queue appends
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
