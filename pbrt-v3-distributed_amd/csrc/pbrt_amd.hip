@@ -523,6 +523,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
+#ifndef PT_SHADE_GRID_PER_CU
+#define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
+#endif
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
@@ -931,7 +934,7 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
-    int numCUs = 256, gridBlocks = 1024;
+    int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     DevScene sc;
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
@@ -1048,6 +1051,7 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     c->numCUs = prop.multiProcessorCount;
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
+    c->gridShade = ((c->numCUs * PT_SHADE_GRID_PER_CU + 7) / 8) * 8;   // k_shade: a multiple of what is resident at PT_SHADE_WAVES per SIMD
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { delete c; return -1; }
@@ -1392,7 +1396,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
         tic(c, MI_K_SHADE);
-        hipLaunchKernelGGL(k_shade, grid, block, 0, st, sc, ps, qout);
+        hipLaunchKernelGGL(k_shade, dim3(c->gridShade), block, 0, st, sc, ps, qout);
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
