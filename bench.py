@@ -202,6 +202,11 @@ def main():
                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
                     "avg_launch_ms": t_closest_ms / max(1.0, launches_per_step), "launches_per_step": launches_per_step,
                     "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays)}
+        if traffic:
+            # measured HBM-side bytes (PMC pass of the same command, profiles/traffic_closest.json) over the live launch time:
+            # the algorithmic figure counts every node fetch, most of which the XCD L2s serve
+            roofline["hbm_traffic_GBps"] = round(traffic / (roofline["avg_launch_ms"] * 1e-3) * 1e-9, 1)
+            roofline["hbm_traffic_frac"] = round(roofline["hbm_traffic_GBps"] / HBM_PEAK_GBS, 4)
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline: the oracle port on the host cores, on a bounded centre crop of the same frame
