@@ -141,7 +141,8 @@ def test_device_triangle_intersect_matches_reference_vectors():
 
 
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
-                                                    ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial")])
+                                                    ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
+                                                    ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell")])
 def test_render_vs_reference_fixture(name, w, h, spp, strategy):
     """GPU image vs the REAL reference's render (tests/golden/*.pfm).  Stated tolerance: per-pixel L2 <= 1e-3 (1 + |ref|)
     for >= 99.5 % of the pixels and relMSE <= 1e-4; at 1 spp each pixel is one camera sample's radiance."""
@@ -201,4 +202,47 @@ def test_baseline_configs_reduced(name, tmp_path):
     d, r = ctx.li(xy, sn), ol.li(sc, xy, sn)
     ok = np.linalg.norm(d - r, axis=1) <= 1e-4 * (1 + np.linalg.norm(r, axis=1))
     assert ok.mean() >= 0.999, (name, ok.mean())
+    ctx.close()
+
+
+# ---------------------------------------------------------------- many lights: light CDF outside the LDS, 3-level CDF search
+def _many_lights_scene(strategy, nx=36, nz=35):
+    """A ceiling of nx*nz*2 emissive triangles of varying size (2520 lights > the 2047 that fit the LDS copy of the CDF)."""
+    rng = np.random.RandomState(7)
+    xs = np.sort(rng.uniform(-1, 1, nx + 1)); zs = np.sort(rng.uniform(-1, 1, nz + 1))
+    xs[0], xs[-1], zs[0], zs[-1] = -1, 1, -1, 1
+    P = [(x, 1.9, z) for z in zs for x in xs]
+    idx = []
+    for j in range(nz):
+        for i in range(nx):
+            a = j * (nx + 1) + i; b = a + 1; c = a + nx + 1; d = c + 1
+            idx += [a, b, d, a, d, c]     # facing down (-y)
+    s = 'LookAt 0 1 -3.4  0 0.9 0  0 1 0\nCamera "perspective" "float fov" [45]\nSampler "sobol" "integer pixelsamples" [8]\nPixelFilter "box"\n'
+    s += 'Integrator "path" "integer maxdepth" [3] "string lightsamplestrategy" "%s"\n' % strategy
+    s += 'Film "image" "integer xresolution" [64] "integer yresolution" [48] "string filename" "ml.pfm"\nWorldBegin\n'
+    s += 'AttributeBegin\n AreaLightSource "diffuse" "rgb L" [6 5 4]\n Material "matte" "rgb Kd" [0 0 0]\n'
+    s += ' Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\nAttributeEnd\n' % (" ".join(map(str, idx)), " ".join("%.9g %.9g %.9g" % p for p in P))
+    s += 'Material "plastic" "rgb Kd" [.6 .5 .4] "rgb Ks" [.2 .2 .2] "float roughness" [.2]\n'
+    s += 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-2 0 -2  2 0 -2  2 0 2  -2 0 2]\n'
+    s += 'Material "matte" "rgb Kd" [.3 .5 .7]\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
+    s += '"point P" [-.5 0 -.5  .5 0 -.5  .5 0 .5  -.5 0 .5  -.5 .8 -.5  .5 .8 -.5  .5 .8 .5  -.5 .8 .5]\nWorldEnd\n'
+    return s
+
+
+@pytest.mark.parametrize("strategy", ["power", "spatial"])
+def test_many_lights(strategy):
+    sc = pa.Scene(text=_many_lights_scene(strategy))
+    assert sc.info["n_lights"] == 2520
+    ctx = pa.Context(sc)
+    ctx.render()
+    img = sc.film_image(ctx.film())
+    ref_rgbw, _, _ = ol.render(sc)
+    frac, relmse = ol.image_metrics(img, sc.film_image(ref_rgbw))
+    assert frac >= 0.995 and relmse <= 1e-4, (strategy, frac, relmse)
+    ys, xs = np.mgrid[0:sc.height, 0:sc.width]
+    xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    sn = np.full(len(xy), 5, dtype=np.int32)
+    d, r = ctx.li(xy, sn), ol.li(sc, xy, sn)
+    ok = np.linalg.norm(d - r, axis=1) <= 1e-4 * (1 + np.linalg.norm(r, axis=1))
+    assert ok.mean() >= 0.999, (strategy, ok.mean())
     ctx.close()

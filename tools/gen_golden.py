@@ -32,7 +32,9 @@ def main():
 
     # strategy None = as the scene file says (cornell: uniform, materials: power); "spatial" = the reference's default
     scenes = [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
-              ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial")]
+              ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
+              # wide pixel filters (overlapping footprints, sample bounds larger than the image): variant = key of FILTERS
+              ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell")]
     for name, w, h, spp, strategy in scenes:
         text = scene_text(name, w, h, spp, strategy)
         f = os.path.join(tmp, "s.pbrt"); open(f, "w").write(text)
@@ -41,12 +43,18 @@ def main():
         print("rendered", out)
 
 
+FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]'}
+
+
 def scene_text(name, w, h, spp, strategy=None):
     """the scene edits behind each fixture (also used by the tests)"""
     import re
     text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
     text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
-    if strategy:
+    if strategy in FILTERS:
+        assert 'PixelFilter "box"' in text
+        text = text.replace('PixelFilter "box"', FILTERS[strategy])
+    elif strategy:
         text = re.sub(r'"string lightsamplestrategy" "\w+"', '"string lightsamplestrategy" "%s"' % strategy, text)
     return re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
 
