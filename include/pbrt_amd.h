@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -145,6 +145,9 @@ typedef struct mi_film {     /* Film, core/film.cpp:45-86 */
 #define MI_LIGHT_STRATEGY_TABLE 0
 #define MI_LIGHT_STRATEGY_SPATIAL 1
 
+#define MI_SAMPLER_SOBOL 0
+#define MI_SAMPLER_HALTON 1
+
 typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t max_depth;          /* path.cpp:193, default 5 */
     float rr_threshold;         /* path.cpp:208, default 1 */
@@ -154,6 +157,16 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t sobol_log2_resolution;
     int32_t light_strategy;     /* MI_LIGHT_STRATEGY_*: CreateLightSampleDistribution (lightdistrib.cpp:48-66, path.cpp:72) */
     int32_t spatial_max_voxels; /* SpatialLightDistribution maxVoxels (lightdistrib.h:92), 64; 0 -> 64 */
+    /* the GlobalSampler driving the path: SobolSampler (samplers/sobol.cpp) or HaltonSampler (samplers/halton.cpp, pbrt's default).
+     * Halton: spp is NOT rounded to a power of two; the fields below are the constructor's results (halton.cpp:71-97);
+     * the digit permutations (ComputeRadicalInversePermutations with the default RNG, lowdiscrepancy.cpp:2490-2504) are
+     * regenerated by the library. */
+    int32_t sampler;                    /* MI_SAMPLER_* */
+    int32_t halton_base_scales[2];      /* 2^e0 >= min(res.x,128), 3^e1 >= min(res.y,128) */
+    int32_t halton_base_exponents[2];
+    int32_t halton_sample_stride;       /* baseScales[0] * baseScales[1] */
+    int32_t halton_mult_inverse[2];
+    int32_t halton_sample_at_center;    /* "samplepixelcenter" */
 } mi_integrator;
 
 /* ---------------------------------------------------------------- the scene --------- */

@@ -16,6 +16,7 @@
 #include "rng.h"
 #include "sampling.h"
 #include "samplers/sobol.h"
+#include "samplers/halton.h"
 #include "shapes/triangle.h"
 #include "sobolmatrices.h"
 
@@ -86,6 +87,20 @@ int main(int argc, char **argv) {
                 putv<int32_t>(f, p[0]); putv<int32_t>(f, p[1]); putv<int32_t>(f, k++);
                 for (int d = 0; d < 24; ++d) putv<float>(f, s.Get1D());
             } while (s.StartNextSample());
+        }
+        fclose(f);
+        // HaltonSampler (pbrt's default sampler): same record layout, 6 samples per pixel (not a power of two),
+        // pixels beyond the 128 x 128 repeat of the pixel-offset computation
+        f = fopen((dir + "/halton_sampler.bin").c_str(), "wb");
+        HaltonSampler hs(6, sb);
+        const int hpx[][2] = {{0, 0}, {1, 0}, {399, 299}, {123, 45}, {256, 130}, {127, 128}};
+        for (auto &p : hpx) {
+            hs.StartPixel(Point2i(p[0], p[1]));
+            int k = 0;
+            do {
+                putv<int32_t>(f, p[0]); putv<int32_t>(f, p[1]); putv<int32_t>(f, k++);
+                for (int d = 0; d < 24; ++d) putv<float>(f, hs.Get1D());
+            } while (hs.StartNextSample());
         }
         fclose(f);
     }

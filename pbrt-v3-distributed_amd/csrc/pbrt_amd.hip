@@ -159,10 +159,13 @@ PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
 }
 PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy) {
     Float u[5];
-    SobolBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
-    // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57)
-    Float u0 = clampf((u[0] * sc.sobol_resolution + sc.sample_min[0]) - smp.px, (Float)0, PT_ONE_MINUS_EPS);
-    Float u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
+    SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
+    Float u0 = u[0], u1 = u[1];
+    if (sc.sampler_type == MI_SAMPLER_SOBOL) {
+        // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57); Halton's are in-pixel already
+        u0 = clampf((u[0] * sc.sobol_resolution + sc.sample_min[0]) - smp.px, (Float)0, PT_ONE_MINUS_EPS);
+        u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
+    }
     Float l0 = u[3], l1 = u[4];
     smp.dimension = 5;
     Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;   // static scene: the time sample (dim 2) is never read
@@ -562,7 +565,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             smp.px = smp.py = 0;   // only dimensions 0/1 (camera sample) look at the pixel
             // the (at most) 8 sample dimensions this vertex can consume: light pick, uLight, uScattering, BSDF, RR
             Float us[8];
-            SobolBatch<8>(sc, smp.index, smp.dimension, us);
+            SamplerBatch<8>(sc, smp.index, smp.dimension, us);
             PROBE(2)   // Sobol batch
             int ui = 0;      // sample dimensions consumed by this vertex (added to the path's dimension at the end)
             int ubase = 0;   // sample dimensions consumed before the BSDF sample: 0, 1 (light pick only) or 5 -- static indices keep us[] in registers
@@ -1292,6 +1295,63 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.max_depth = d->integrator.max_depth; sc.spp = d->integrator.spp;
     sc.sobol_resolution = d->integrator.sobol_resolution; sc.sobol_log2_resolution = d->integrator.sobol_log2_resolution;
     sc.rr_threshold = d->integrator.rr_threshold;
+    sc.sampler_type = d->integrator.sampler;
+    if (sc.sampler_type != MI_SAMPLER_SOBOL && sc.sampler_type != MI_SAMPLER_HALTON) return fail("mi_scene_upload: unknown sampler");
+    if (sc.sampler_type == MI_SAMPLER_HALTON) {
+        for (int i = 0; i < 2; ++i) {
+            sc.h_base_scales[i] = d->integrator.halton_base_scales[i]; sc.h_base_exps[i] = d->integrator.halton_base_exponents[i];
+            sc.h_mult_inv[i] = d->integrator.halton_mult_inverse[i];
+        }
+        sc.h_stride = d->integrator.halton_sample_stride;
+        sc.h_at_center = d->integrator.halton_sample_at_center;
+        if (sc.h_stride < 1 || sc.h_base_scales[0] < 1 || sc.h_base_scales[1] < 1 || sc.h_base_scales[0] * sc.h_base_scales[1] != sc.h_stride)
+            return fail("mi_scene_upload: inconsistent Halton parameters");
+        sc.h_magic_scale1 = sc.h_base_scales[1] > 1 ? ~0ull / (uint64_t)sc.h_base_scales[1] + 1 : 0;   // floor((2^64-1)/d)+1 == floor(2^64/d)+1 unless d | 2^64
+        if (sc.h_base_scales[1] == 1) return fail("mi_scene_upload: Halton base scale 1 in y (image of height 1) is not supported");
+        // worst-case dimensions: 5 camera + 8 per bounce; HaltonSampler can only sample PrimeTableSize = 1000 (halton.h:72-75)
+        if (5 + 8 * (int64_t)(d->integrator.max_depth + 1) > 1000) return fail("mi_scene_upload: maxdepth needs more than 1000 Halton dimensions");
+        // Primes / PrimeSums (core/lowdiscrepancy.cpp), digit permutations = ComputeRadicalInversePermutations(RNG()) (:2490-2504,
+        // Shuffle core/sampling.h:151-157, PCG32 core/rng.h:60-150)
+        const int NP = 1000;
+        std::vector<uint32_t> primes;
+        for (uint32_t cnd = 2; (int)primes.size() < NP; ++cnd) {
+            bool prime = true;
+            for (size_t k = 0; k < primes.size() && primes[k] * primes[k] <= cnd; ++k) if (cnd % primes[k] == 0) { prime = false; break; }
+            if (prime) primes.push_back(cnd);
+        }
+        std::vector<uint4> info(NP);
+        uint32_t sum = 0;
+        for (int i = 0; i < NP; ++i) {
+            uint64_t magic = ~0ull / primes[i] + 1;
+            if (primes[i] == 2) magic = 0x8000000000000001ull;   // floor(2^64/2) + 1
+            info[i] = make_uint4(primes[i], sum, (uint32_t)magic, (uint32_t)(magic >> 32));
+            sum += primes[i];
+        }
+        std::vector<uint16_t> perms(sum);
+        {
+            uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+            auto next32 = [&]() -> uint32_t {
+                uint64_t oldstate = state;
+                state = oldstate * 0x5851f42d4c957f2dULL + inc;
+                uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u), rot = (uint32_t)(oldstate >> 59u);
+                return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+            };
+            auto bounded = [&](uint32_t b) -> uint32_t {
+                uint32_t threshold = (~b + 1u) % b;
+                while (true) { uint32_t r = next32(); if (r >= threshold) return r % b; }
+            };
+            uint16_t *pp = perms.data();
+            for (int i = 0; i < NP; ++i) {
+                int n = (int)primes[i];
+                for (int j = 0; j < n; ++j) pp[j] = (uint16_t)j;
+                for (int j = 0; j < n; ++j) { int other = j + (int)bounded((uint32_t)(n - j)); std::swap(pp[j], pp[other]); }
+                pp += n;
+            }
+        }
+        { DevBuf &b = next(); if (upload(c, b, perms.data(), perms.size() * 2)) return -1; sc.h_perms = b.as<uint16_t>(); }
+        { DevBuf &b = next(); if (upload(c, b, info.data(), info.size() * sizeof(uint4))) return -1; sc.h_info = b.as<uint4>(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     {
         int sppBits = 0;
         while ((1 << sppBits) < sc.spp) ++sppBits;

@@ -66,6 +66,12 @@ struct DevScene {
     int32_t full_res[2], crop_min[2], crop_max[2], sample_min[2], sample_max[2], pixel_min[2], pixel_max[2];
     float filter_radius[2], max_sample_luminance;
     int32_t max_depth, spp, sobol_resolution, sobol_log2_resolution;
+    // HaltonSampler (samplers/halton.cpp): constructor results + tables
+    int32_t sampler_type;                 // MI_SAMPLER_*
+    int32_t h_base_scales[2], h_base_exps[2], h_stride, h_mult_inv[2], h_at_center;
+    uint64_t h_magic_scale1;              // floor(2^64 / baseScales[1]) + 1
+    const uint16_t *h_perms;              // digit permutations of all 1000 prime bases, concatenated
+    const uint4 *h_info;                  // per dimension: {prime, offset into h_perms, magic lo, magic hi}
     float rr_threshold;
 };
 
@@ -127,15 +133,90 @@ PT_DEV void SobolBatch(const DevScene &sc, uint64_t index, int dim0, Float *out)
     for (int k = 0; k < N; ++k) out[k] = mn(v[k] * 0x1p-32f, PT_ONE_MINUS_EPS);
 }
 
-struct Sampler {   // GlobalSampler/SobolSampler state per path (core/sampler.cpp:136-195, samplers/sobol.cpp:42-59)
+// ---- HaltonSampler (samplers/halton.cpp; radical inverses core/lowdiscrepancy.cpp:389-424, 427-445, 2506-2520).
+// Integer parts are exact; a / base uses a multiply-high with magic = floor(2^64 / base) + 1, exact for a < 2^64 / base
+// (indices stay below 2^46: stride <= 128 * 243, sample numbers < 2^31).
+PT_DEV uint64_t MulHi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+PT_DEV Float HaltonRadicalInverse3(uint64_t a) {   // RadicalInverseSpecialized<3>
+    const Float invBase = (Float)1 / (Float)3;
+    uint64_t reversedDigits = 0;
+    Float invBaseN = 1;
+    while (a) {
+        uint64_t next = MulHi64(a, 0x5555555555555556ull);   // a / 3
+        uint64_t digit = a - next * 3;
+        reversedDigits = reversedDigits * 3 + digit;
+        invBaseN *= invBase;
+        a = next;
+    }
+    return mn((Float)reversedDigits * invBaseN, PT_ONE_MINUS_EPS);
+}
+// ScrambledRadicalInverseSpecialized<base>(perm, a) for dimension dim >= 2 (out of line: k_shade draws 8 of them per vertex)
+__device__ __noinline__ Float HaltonScrambled(const uint16_t *perms, const uint4 *info, uint64_t a, int dim) {
+    uint4 in = info[dim];
+    const uint32_t base = in.x;
+    const uint16_t *perm = perms + in.y;
+    const uint64_t magic = (uint64_t)in.z | ((uint64_t)in.w << 32);
+    const Float invBase = (Float)1 / (Float)base;
+    uint64_t reversedDigits = 0;
+    Float invBaseN = 1;
+    while (a) {
+        uint64_t next = MulHi64(a, magic);
+        uint32_t digit = (uint32_t)(a - next * base);
+        reversedDigits = reversedDigits * base + perm[digit];
+        invBaseN *= invBase;
+        a = next;
+    }
+    return mn(invBaseN * ((Float)reversedDigits + invBase * (Float)(int)perm[0] / (1 - invBase)), PT_ONE_MINUS_EPS);
+}
+PT_DEV Float HaltonSampleDimension(const DevScene &sc, uint64_t index, int dim) {   // halton.cpp:123-132
+    if (sc.h_at_center && (dim == 0 || dim == 1)) return 0.5f;
+    if (dim == 0) {   // RadicalInverse(0, a) = ReverseBits64(a) * 2^-64, evaluated in double, rounded to Float on return
+        uint64_t a = index >> sc.h_base_exps[0];
+        uint64_t r = ((uint64_t)__brev((uint32_t)a) << 32) | (uint64_t)__brev((uint32_t)(a >> 32));
+        return (Float)((double)r * 0x1p-64);
+    }
+    if (dim == 1) return HaltonRadicalInverse3(MulHi64(index, sc.h_magic_scale1));   // index / baseScales[1]
+    if (dim > 999) dim = 999;   // the reference LOG(FATAL)s (halton.h:72-75); mi_scene_upload rejects such depths
+    return HaltonScrambled(sc.h_perms, sc.h_info, index, dim);
+}
+PT_DEV uint64_t HaltonIndexForSample(const DevScene &sc, int x, int y, uint64_t sampleNum) {   // halton.cpp:100-121
+    uint64_t offset = 0;
+    if (sc.h_stride > 1) {
+        int pm0 = x - (x / 128) * 128, pm1 = y - (y / 128) * 128;   // Mod(currentPixel, kMaxResolution) core/pbrt.h:310-313
+        if (pm0 < 0) pm0 += 128;
+        if (pm1 < 0) pm1 += 128;
+        uint64_t d0 = 0, d1 = 0;   // InverseRadicalInverse<2>, <3> core/lowdiscrepancy.h:82-91
+        { uint32_t inv = (uint32_t)pm0; for (int i = 0; i < sc.h_base_exps[0]; ++i) { d0 = d0 * 2 + (inv & 1u); inv >>= 1; } }
+        { uint32_t inv = (uint32_t)pm1; for (int i = 0; i < sc.h_base_exps[1]; ++i) { d1 = d1 * 3 + (inv % 3u); inv /= 3u; } }
+        offset = d0 * (uint64_t)(sc.h_stride / sc.h_base_scales[0]) * (uint64_t)sc.h_mult_inv[0] +
+                 d1 * (uint64_t)(sc.h_stride / sc.h_base_scales[1]) * (uint64_t)sc.h_mult_inv[1];
+        offset %= (uint64_t)sc.h_stride;
+    }
+    return offset + sampleNum * (uint64_t)sc.h_stride;
+}
+
+// N consecutive dimensions of the scene's sampler for one path
+template <int N>
+PT_DEV void SamplerBatch(const DevScene &sc, uint64_t index, int dim0, Float *out) {
+    if (sc.sampler_type == MI_SAMPLER_HALTON) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = HaltonSampleDimension(sc, index, dim0 + k);
+    } else
+        SobolBatch<N>(sc, index, dim0, out);
+}
+
+struct Sampler {   // GlobalSampler state per path (core/sampler.cpp:136-195) over SobolSampler / HaltonSampler
     uint64_t index;
     int dimension;
     int px, py;
     PT_DEV void Start(const DevScene &sc, int x, int y, uint64_t sampleNum) {
         px = x; py = y; dimension = 0;
-        index = SobolIntervalToIndex(sc, sc.sobol_log2_resolution, sampleNum, x - sc.sample_min[0], y - sc.sample_min[1]);
+        if (sc.sampler_type == MI_SAMPLER_HALTON) index = HaltonIndexForSample(sc, x, y, sampleNum);
+        else index = SobolIntervalToIndex(sc, sc.sobol_log2_resolution, sampleNum, x - sc.sample_min[0], y - sc.sample_min[1]);
     }
-    PT_DEV Float SampleDimension(const DevScene &sc, int dim) const {   // sobol.cpp:47-59
+    PT_DEV Float SampleDimension(const DevScene &sc, int dim) const {
+        if (sc.sampler_type == MI_SAMPLER_HALTON) return HaltonSampleDimension(sc, index, dim);
+        // sobol.cpp:47-59
         if (dim >= PBRT_AMD_SOBOL_NDIM) dim = PBRT_AMD_SOBOL_NDIM - 1;   // the reference LOG(FATAL)s here; host rejects such depths
         Float s = SobolSampleFloat(sc, index, dim);
         if (dim == 0 || dim == 1) {

@@ -463,12 +463,46 @@ PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &ps, const Transform &
 }
 
 SobolSampler::SobolSampler(int64_t spp, const int smin[2], const int smax[2]) {   // sobol.h:51-62
+    kind = Sobol;
     samplesPerPixel = spp <= 1 ? 1 : (int64_t)RoundUpPow2((int32_t)spp);
     if (!IsPowerOf2(spp))
         Warning("Non power-of-two sample count rounded up to %lld for SobolSampler.", (long long)samplesPerPixel);
     for (int i = 0; i < 2; ++i) { sampleMin[i] = smin[i]; sampleMax[i] = smax[i]; }
     resolution = RoundUpPow2(std::max(smax[0] - smin[0], smax[1] - smin[1]));
     log2Resolution = Log2Int((uint32_t)resolution);
+}
+
+// HaltonSampler::HaltonSampler samplers/halton.cpp:71-97 (the digit permutations are the device library's business)
+static void extendedGCD(uint64_t a, uint64_t b, int64_t *x, int64_t *y) {   // halton.cpp:55-66
+    if (b == 0) { *x = 1; *y = 0; return; }
+    int64_t d = (int64_t)(a / b), xp, yp;
+    extendedGCD(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - (d * yp);
+}
+static uint64_t multiplicativeInverse(int64_t a, int64_t n) {   // halton.cpp:49-53
+    int64_t x, y;
+    extendedGCD((uint64_t)a, (uint64_t)n, &x, &y);
+    int64_t r = x - (x / n) * n;   // Mod(x, n) core/pbrt.h:310-313
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+HaltonSampler::HaltonSampler(int64_t spp, const int smin[2], const int smax[2], bool atCenter) {
+    kind = Halton;
+    samplesPerPixel = spp;
+    sampleAtPixelCenter = atCenter;
+    const int kMaxResolution = 128;
+    for (int i = 0; i < 2; ++i) {
+        sampleMin[i] = smin[i]; sampleMax[i] = smax[i];
+        int res = smax[i] - smin[i];
+        int base = (i == 0) ? 2 : 3;
+        int scale = 1, exp = 0;
+        while (scale < std::min(res, kMaxResolution)) { scale *= base; ++exp; }
+        baseScales[i] = scale;
+        baseExponents[i] = exp;
+    }
+    sampleStride = baseScales[0] * baseScales[1];
+    multInverse[0] = (int)multiplicativeInverse(baseScales[1], baseScales[0]);
+    multInverse[1] = (int)multiplicativeInverse(baseScales[0], baseScales[1]);
 }
 
 Scene::Scene(std::shared_ptr<BVHAccel> agg, std::vector<GeometricPrimitive> prims, std::vector<LightEntry> l)
@@ -514,11 +548,18 @@ void pbrtWorldEnd() {
             camera->film->GetSampleBounds(smin, smax);
             int nsamp = renderOptions->SamplerParams.FindOneInt("pixelsamples", 16);
             if (PbrtOptions.quickRender) nsamp = 1;
-            if (renderOptions->SamplerName != "sobol")
-                Warning("Sampler \"%s\" is not implemented on the GPU path (north-star names Sobol; halton is a 'next' row); "
-                        "rendering with \"sobol\" at %d spp.", renderOptions->SamplerName.c_str(), nsamp);
+            // MakeSampler (api.cpp:815-840): "halton" (pbrt's default) and "sobol" run on the GPU path
+            std::shared_ptr<Sampler> sampler;
+            if (renderOptions->SamplerName == "halton") {
+                bool atCenter = renderOptions->SamplerParams.FindOneBool("samplepixelcenter", false);
+                sampler = std::make_shared<HaltonSampler>(nsamp, smin, smax, atCenter);
+            } else {
+                if (renderOptions->SamplerName != "sobol")
+                    Warning("Sampler \"%s\" is not implemented on the GPU path (\"sobol\" and \"halton\" are); rendering with \"sobol\" at %d spp.",
+                            renderOptions->SamplerName.c_str(), nsamp);
+                sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
+            }
             renderOptions->SamplerParams.ReportUnused();
-            auto sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
             if (renderOptions->IntegratorName == "path") {
                 integrator.reset(CreatePathIntegrator(renderOptions->IntegratorParams, sampler, camera));
                 integrator->nGpus = PbrtOptions.nGpus;

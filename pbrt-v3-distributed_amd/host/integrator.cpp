@@ -13,14 +13,14 @@
 namespace pbrt_amd {
 
 WavefrontPathIntegrator::WavefrontPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera,
-                                                 std::shared_ptr<SobolSampler> sampler, const int pmin[2],
+                                                 std::shared_ptr<Sampler> sampler, const int pmin[2],
                                                  const int pmax[2], Float rrThreshold, const std::string &strategy)
     : maxDepth(maxDepth), camera(std::move(camera)), sampler(std::move(sampler)), rrThreshold(rrThreshold),
       lightSampleStrategy(strategy) {
     for (int i = 0; i < 2; ++i) { pixelMin[i] = pmin[i]; pixelMax[i] = pmax[i]; }
 }
 
-WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<SobolSampler> sampler,
+WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<Sampler> sampler,
                                               std::shared_ptr<PerspectiveCamera> camera) {   // path.cpp:190-213
     int maxDepth = ps.FindOneInt("maxdepth", 5);
     int np;
@@ -189,6 +189,13 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.integrator.max_depth = maxDepth; d.integrator.rr_threshold = rrThreshold;
     d.integrator.spp = (int32_t)sampler->samplesPerPixel;
     d.integrator.sobol_resolution = sampler->resolution; d.integrator.sobol_log2_resolution = sampler->log2Resolution;
+    d.integrator.sampler = sampler->kind == Sampler::Halton ? MI_SAMPLER_HALTON : MI_SAMPLER_SOBOL;
+    for (int i = 0; i < 2; ++i) {
+        d.integrator.halton_base_scales[i] = sampler->baseScales[i]; d.integrator.halton_base_exponents[i] = sampler->baseExponents[i];
+        d.integrator.halton_mult_inverse[i] = sampler->multInverse[i];
+    }
+    d.integrator.halton_sample_stride = sampler->sampleStride;
+    d.integrator.halton_sample_at_center = sampler->sampleAtPixelCenter ? 1 : 0;
     return fs;
 }
 

@@ -122,12 +122,23 @@ struct PerspectiveCamera {
 };
 PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &ps, const Transform &cam2world, Film *film);
 
-// ---- Sampler: SobolSampler (samplers/sobol.h:48-69)
-struct SobolSampler {
+// ---- Samplers: the two GlobalSamplers the GPU path implements.  Only the constructor results are kept (the per-sample
+// work is the device's): SobolSampler (samplers/sobol.h:48-69) and HaltonSampler (samplers/halton.{h,cpp}, pbrt's default).
+struct Sampler {
+    enum Kind { Sobol, Halton } kind = Sobol;
+    int64_t samplesPerPixel = 1;
+    int sampleMin[2] = {0, 0}, sampleMax[2] = {0, 0};
+    // Sobol
+    int resolution = 1, log2Resolution = 0;
+    // Halton
+    int baseScales[2] = {1, 1}, baseExponents[2] = {0, 0}, sampleStride = 1, multInverse[2] = {0, 0};
+    bool sampleAtPixelCenter = false;
+};
+struct SobolSampler : Sampler {
     SobolSampler(int64_t spp, const int sampleMin[2], const int sampleMax[2]);
-    int64_t samplesPerPixel;
-    int sampleMin[2], sampleMax[2];
-    int resolution, log2Resolution;
+};
+struct HaltonSampler : Sampler {
+    HaltonSampler(int64_t spp, const int sampleMin[2], const int sampleMax[2], bool sampleAtPixelCenter);
 };
 
 // ---- Scene (core/scene.h:50-80)
@@ -162,20 +173,20 @@ struct FlatScene {
 class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)
   public:
     WavefrontPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera,
-                            std::shared_ptr<SobolSampler> sampler, const int pixelMin[2], const int pixelMax[2],
+                            std::shared_ptr<Sampler> sampler, const int pixelMin[2], const int pixelMax[2],
                             Float rrThreshold, const std::string &lightSampleStrategy);
     void Render(const Scene &scene) override;   // flatten -> mi_scene_upload -> mi_render -> Film
     // Flatten(scene): everything Render hands to the device, as POD
     std::unique_ptr<FlatScene> Flatten(const Scene &scene) const;
     int maxDepth;
     std::shared_ptr<PerspectiveCamera> camera;
-    std::shared_ptr<SobolSampler> sampler;
+    std::shared_ptr<Sampler> sampler;
     int pixelMin[2], pixelMax[2];
     Float rrThreshold;
     std::string lightSampleStrategy;
     int nGpus = 1;   // --gpus: tile-sharded over this many devices in-process
 };
-WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<SobolSampler> sampler,
+WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<Sampler> sampler,
                                               std::shared_ptr<PerspectiveCamera> camera);
 
 }  // namespace pbrt_amd

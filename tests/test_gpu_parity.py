@@ -37,6 +37,23 @@ def test_sobol_bit_exact(pair):
         assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
 
 
+def test_halton_bit_exact():
+    """HaltonSampler on the device: sample indices and the first 200 dimensions vs the oracle, and the Get1D stream of the
+    reference's own class (tests/golden/ref_vectors.npz: halton_sampler) -- bit for bit."""
+    sc = pa.Scene(text='Film "image" "integer xresolution" [400] "integer yresolution" [300] "string filename" "x.pfm"\n'
+                       'Sampler "halton" "integer pixelsamples" [6]\nWorldBegin\nWorldEnd\n')
+    ctx = pa.Context(sc)
+    rows = np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))["halton_sampler"]
+    for (px, py) in sorted(set(zip(rows["px"].tolist(), rows["py"].tolist()))):
+        sel = rows[(rows["px"] == px) & (rows["py"] == py)]
+        dev, didx = ctx.sobol(px, py, 6, 200)
+        ref, ridx = ol.sobol(sc, px, py, 6, 200)
+        assert np.array_equal(didx, ridx)
+        assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(dev[sel["s"], :24].view(np.uint32), sel["u"].view(np.uint32)), (px, py)
+    ctx.close()
+
+
 def test_camera_rays_bit_exact(pair):
     sc, ctx = pair
     xy, s = _pixels(sc, 4096)
@@ -142,7 +159,8 @@ def test_device_triangle_intersect_matches_reference_vectors():
 
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
-                                                    ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell")])
+                                                    ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+                                                    ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")])
 def test_render_vs_reference_fixture(name, w, h, spp, strategy):
     """GPU image vs the REAL reference's render (tests/golden/*.pfm).  Stated tolerance: per-pixel L2 <= 1e-3 (1 + |ref|)
     for >= 99.5 % of the pixels and relMSE <= 1e-4; at 1 spp each pixel is one camera sample's radiance."""

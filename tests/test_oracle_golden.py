@@ -49,6 +49,19 @@ def test_sobol_sampler_stream_matches_reference(vec):
         assert np.array_equal(got[sel["s"]].view(np.uint32), sel["u"].view(np.uint32)), (px, py)
 
 
+def test_halton_sampler_stream_matches_reference(vec):
+    """HaltonSampler (samplers/halton.cpp, pbrt's default sampler): Get1D stream of the class itself -- pixel offsets by the
+    Chinese-remainder construction, base-2/3 pixel dimensions, PCG32-shuffled digit permutations for dims >= 2; 6 spp."""
+    sc = pa.Scene(text='Film "image" "integer xresolution" [400] "integer yresolution" [300] "string filename" "x.pfm"\n'
+                       'Sampler "halton" "integer pixelsamples" [6]\nWorldBegin\nWorldEnd\n')
+    rows = vec["halton_sampler"]
+    assert len(rows) == 36
+    for (px, py) in sorted(set(zip(rows["px"].tolist(), rows["py"].tolist()))):
+        sel = rows[(rows["px"] == px) & (rows["py"] == py)]
+        got, _ = ol.sobol(sc, px, py, 6, 24)   # "sobol" = the scene's GlobalSampler
+        assert np.array_equal(got[sel["s"]].view(np.uint32), sel["u"].view(np.uint32)), (px, py)
+
+
 def test_sobol_elementary_intervals(built):
     """ElementaryIntervals (tests/sampling.cpp:139-188): the first 2^k samples of a pixel stratify every 2^i x 2^j grid."""
     sc = pa.Scene(text='Film "image" "integer xresolution" [64] "integer yresolution" [64] "string filename" "x.pfm"\n'
@@ -106,7 +119,8 @@ def test_distribution1d_matches_reference(vec):
 
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
-                                                    ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell")])
+                                                    ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+                                                    ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")])
 def test_oracle_render_matches_reference_image(built, name, w, h, spp, strategy):
     """Whole pipeline vs the reference's own render (lossless PFM fixture).  1 spp = per-camera-sample radiance.
     Tolerance: max |d| <= 2e-6 (1 + |ref|): the only differences are last-ulp film-sum / libm effects."""

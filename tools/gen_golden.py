@@ -22,24 +22,27 @@ def main():
     ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
     si = np.fromfile(os.path.join(tmp, "sobol_index.bin"), dtype=np.dtype([("m", "<u4"), ("frame", "<u8"), ("px", "<i4"), ("py", "<i4"), ("idx", "<u8")]))
     sp = np.fromfile(os.path.join(tmp, "sobol_sampler.bin"), dtype=np.dtype([("px", "<i4"), ("py", "<i4"), ("s", "<i4"), ("u", "<f4", 24)]))
+    hp = np.fromfile(os.path.join(tmp, "halton_sampler.bin"), dtype=np.dtype([("px", "<i4"), ("py", "<i4"), ("s", "<i4"), ("u", "<f4", 24)]))
     tri = np.fromfile(os.path.join(tmp, "triangles.bin"), dtype=np.dtype([("p", "<f4", 9), ("o", "<f4", 3), ("d", "<f4", 3), ("tmax", "<f4"), ("hit", "<i4"),
                                                                            ("t", "<f4"), ("uv", "<f4", 2), ("b1", "<f4"), ("b2", "<f4"), ("n", "<f4", 3)]))
     keep = np.zeros(len(tri), dtype=bool); keep[0] = True; keep[1::4] = True   # BadCases record + every 4th
     tri = tri[keep]
     raw = np.fromfile(os.path.join(tmp, "distribution1d.bin"), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, triangles=tri, distribution1d=raw)
+    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, halton_sampler=hp, triangles=tri, distribution1d=raw)
     print("ref_vectors.npz:", len(ss), "sobol samples,", len(si), "indices,", len(sp), "sampler rows,", len(tri), "triangle records")
 
     # strategy None = as the scene file says (cornell: uniform, materials: power); "spatial" = the reference's default
     scenes = [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
               ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
               # wide pixel filters (overlapping footprints, sample bounds larger than the image): variant = key of FILTERS
-              ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell")]
+              ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+              # HaltonSampler (pbrt's default), sample counts that are not powers of two
+              ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")]
     for name, w, h, spp, strategy in scenes:
         text = scene_text(name, w, h, spp, strategy)
         f = os.path.join(tmp, "s.pbrt"); open(f, "w").write(text)
         out = os.path.join(OUT, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else ""))
-        subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--outfile", out, f])
+        subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])   # one thread: the tile merge order (wide filters) is then fixed
         print("rendered", out)
 
 
@@ -51,7 +54,9 @@ def scene_text(name, w, h, spp, strategy=None):
     import re
     text = open(os.path.join(ROOT, "scenes", name + ".pbrt")).read()
     text = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), text)
-    if strategy in FILTERS:
+    if strategy == "halton":
+        text = re.sub(r'Sampler "sobol"', 'Sampler "halton"', text)
+    elif strategy in FILTERS:
         assert 'PixelFilter "box"' in text
         text = text.replace('PixelFilter "box"', FILTERS[strategy])
     elif strategy:
