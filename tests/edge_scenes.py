@@ -1,0 +1,60 @@
+"""Edge-case scene variants (used by tools/gen_golden.py to render reference fixtures and by the CPU / GPU tests).
+Each returns .pbrt text; names are the fixture suffixes."""
+import os, re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cornell(w=64, h=64, spp=4):
+    t = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
+    t = re.sub(r'"integer xresolution" \[\d+\] "integer yresolution" \[\d+\]', '"integer xresolution" [%d] "integer yresolution" [%d]' % (w, h), t)
+    return re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, t)
+
+
+_OPEN = '''LookAt 0 2.2 -6  0 0.8 0  0 1 0
+Camera "perspective" "float fov" [40]
+Sampler "sobol" "integer pixelsamples" [4]
+PixelFilter "box"
+Integrator "path" "integer maxdepth" [5]
+Film "image" "integer xresolution" [72] "integer yresolution" [48] "string filename" "e.pfm"
+WorldBegin
+%s
+Material "matte" "rgb Kd" [.5 .5 .5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4]
+Material "glass" "float index" [1.5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]
+  "point P" [-1.6 0.01 -.5  -.6 0.01 -.5  -.6 0.01 .5  -1.6 0.01 .5  -1.6 1 -.5  -.6 1 -.5  -.6 1 .5  -1.6 1 .5]
+Material "mirror"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [.4 0 1.5  2.4 0 .5  2.4 1.6 .5  .4 1.6 1.5]
+Material "plastic" "rgb Kd" [.7 .3 .2] "rgb Ks" [.3 .3 .3] "float roughness" [.1]
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-.3 0 -1  .7 0 -1.2  .2 1.1 -1.1]
+WorldEnd
+'''
+
+
+def scene(name):
+    if name == "infinite":      # constant InfiniteAreaLight: escaped-ray emission, light sampling + MIS, two lights -> spatial strategy
+        return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
+    if name == "infinite_only":  # a single light: CreateLightSampleDistribution substitutes uniform (lightdistrib.cpp:50)
+        return _OPEN % 'LightSource "infinite" "rgb L" [.9 .8 .7]'
+    if name == "dof":           # thin lens
+        return _cornell().replace('Camera "perspective" "float fov" [39.3]', 'Camera "perspective" "float fov" [39.3] "float lensradius" [12] "float focaldistance" [1000]')
+    if name == "crop":          # crop window + pixel bounds: partial tiles on every side, samples outside the bounds skipped
+        t = _cornell(80, 56)
+        t = t.replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float cropwindow" [.15 .8 .2 .9]')
+        return t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "path" "integer maxdepth" [5] "integer pixelbounds" [20 58 14 40]')
+    if name == "clamp":         # Film maxsampleluminance
+        return _cornell().replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float maxsampleluminance" [1.5]')
+    if name == "empty":         # no geometry at all: every camera ray escapes to the environment
+        return ('Camera "perspective" "float fov" [40]\nSampler "sobol" "integer pixelsamples" [2]\nPixelFilter "box"\nIntegrator "path"\n'
+                'Film "image" "integer xresolution" [40] "integer yresolution" [24] "string filename" "e.pfm"\nWorldBegin\n'
+                'LightSource "infinite" "rgb L" [.25 .5 1]\nWorldEnd\n')
+    if name == "onetri":        # one triangle (single-leaf BVH), one degenerate triangle next to it, a point light
+        return ('LookAt 0 0 -4  0 0 0  0 1 0\nCamera "perspective" "float fov" [40]\nSampler "sobol" "integer pixelsamples" [4]\nPixelFilter "box"\n'
+                'Integrator "path" "integer maxdepth" [2]\nFilm "image" "integer xresolution" [48] "integer yresolution" [48] "string filename" "e.pfm"\nWorldBegin\n'
+                'LightSource "point" "point from" [1 2 -3] "rgb I" [30 30 30]\nMaterial "matte" "rgb Kd" [.8 .6 .4]\n'
+                'Shape "trianglemesh" "integer indices" [0 1 2 3 3 4] "point P" [-1 -1 0  1 -1 0  0 1 .5  .5 .5 0  .6 .6 0]\nWorldEnd\n')
+    raise KeyError(name)
+
+
+NAMES = ["infinite", "infinite_only", "dof", "crop", "clamp", "empty", "onetri"]

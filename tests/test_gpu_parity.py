@@ -264,3 +264,27 @@ def test_many_lights(strategy):
     ok = np.linalg.norm(d - r, axis=1) <= 1e-4 * (1 + np.linalg.norm(r, axis=1))
     assert ok.mean() >= 0.999, (strategy, ok.mean())
     ctx.close()
+
+
+# ---------------------------------------------------------------- edge cases (tests/edge_scenes.py), against the reference's renders
+import edge_scenes
+
+
+@pytest.mark.parametrize("name", edge_scenes.NAMES)
+def test_edge_cases_vs_reference_fixture(name):
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    ctx = pa.Context(sc)
+    ctx.render()
+    img = sc.film_image(ctx.film())
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    assert img.shape == ref.shape
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
+    # split renders accumulate to the same film: samples [0,1) then [1,spp)
+    if sc.info["spp"] > 1:
+        ctx.film_clear()
+        ctx.render(spp_begin=0, spp_end=1)
+        ctx.render(spp_begin=1, spp_end=sc.info["spp"])
+        img2 = sc.film_image(ctx.film())
+        assert np.allclose(img2, img, rtol=1e-5, atol=1e-6)
+    ctx.close()

@@ -150,3 +150,19 @@ def test_oracle_vs_live_reference_binary(built, tmp_path):
     rgbw, _, _ = ol.render(sc, nthreads=4)
     img = sc.film_image(rgbw)
     assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref)))
+
+
+import edge_scenes
+
+
+@pytest.mark.parametrize("name", edge_scenes.NAMES)
+def test_oracle_edge_cases_match_reference(built, name):
+    """Edge cases of the path (tests/edge_scenes.py): constant infinite light (escaped rays, light sampling, single-light ->
+    uniform substitution), thin lens, crop window + pixel bounds, luminance clamp, empty world, single-leaf BVH with a
+    degenerate triangle -- oracle vs the reference's render."""
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    rgbw, _, _ = ol.render(sc, nthreads=4)
+    img = sc.film_image(rgbw)
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    assert img.shape == ref.shape
+    assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())

@@ -44,9 +44,21 @@ def main():
         out = os.path.join(OUT, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else ""))
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])   # one thread: the tile merge order (wide filters) is then fixed
         print("rendered", out)
+    edge_fixtures(tmp)
 
 
 FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]'}
+
+
+def edge_fixtures(tmp):
+    """tests/edge_scenes.py variants (infinite light, thin lens, crop window + pixel bounds, luminance clamp, empty world, ...)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edge_scenes
+    for name in edge_scenes.NAMES:
+        f = os.path.join(tmp, "e.pbrt"); open(f, "w").write(edge_scenes.scene(name))
+        out = os.path.join(OUT, "edge_%s.pfm" % name)
+        subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
+        print("rendered", out)
 
 
 def scene_text(name, w, h, spp, strategy=None):
