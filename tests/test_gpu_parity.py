@@ -288,3 +288,24 @@ def test_edge_cases_vs_reference_fixture(name):
         img2 = sc.film_image(ctx.film())
         assert np.allclose(img2, img, rtol=1e-5, atol=1e-6)
     ctx.close()
+
+
+# ---------------------------------------------------------------- the command-line renderer end to end (parser -> BVH -> device -> Film -> file)
+def test_cli_render_matches_reference_fixture(tmp_path):
+    import subprocess, importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tools", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
+    exe = os.path.join(ROOT, "pbrt-v3-distributed_amd", "bin", "pbrt_amd")
+    f = tmp_path / "c.pbrt"
+    f.write_text(gg.scene_text("cornell", 64, 64, 8))
+    out = tmp_path / "c.pfm"
+    r = subprocess.run([exe, "--quiet", "--outfile", str(out), str(f)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and out.exists(), r.stderr
+    img = pa.read_pfm(str(out))
+    ref = pa.read_pfm(os.path.join(G, "cornell_64x64_8spp.pfm"))
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
+    # --cropwindow and EXR output (pbrt's default output format)
+    out2 = tmp_path / "crop.exr"
+    r = subprocess.run([exe, "--quiet", "--cropwindow", "0.25", "0.75", "0.5", "1", "--outfile", str(out2), str(f)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and out2.exists() and open(out2, "rb").read(4) == bytes([0x76, 0x2F, 0x31, 0x01]), r.stderr
