@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -102,6 +102,7 @@ enum mi_light_type {
     MI_LIGHT_AREA_TRI = 0, /* DiffuseAreaLight on one Triangle (api.cpp:1357-1366, lights/diffuse.cpp) */
     MI_LIGHT_POINT = 1,    /* PointLight   lights/point.cpp:44-53  */
     MI_LIGHT_DISTANT = 2,  /* DistantLight lights/distant.cpp:49-67 */
+    MI_LIGHT_SPOT = 4,     /* SpotLight    lights/spot.cpp:54-72   */
     MI_LIGHT_INFINITE = 3  /* InfiniteAreaLight, constant L only (lights/infinite.cpp:92-132) */
 };
 typedef struct mi_light {
@@ -115,6 +116,11 @@ typedef struct mi_light {
     float world_radius;/* DISTANT/INFINITE: Scene bound radius (Preprocess) */
     float world_center[3];
     float pad2;
+    /* SPOT (lights/spot.cpp:40-72): pos = pLight, L = I * scale; frame = the upper-left 3x3 of WorldToLight (row major:
+     * Falloff() applies it to a direction), cos_total_width / cos_falloff_start as the constructor computes them */
+    float frame[9];
+    float cos_total_width, cos_falloff_start;
+    float pad3;
 } mi_light;
 
 /* ---------------------------------------------------------------- camera/film ------- */

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                         ps.rec[slot].L = L;
                     }
                 } else {
-                    const mi_light &light = sc.lights[lightNum].l;
+                    const DevLight &light = sc.lights[lightNum];
                     RGB Li(0.f);
                     if (ts.prim != TRAV_MISS) {
                         if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
@@ -589,9 +589,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             if (bounces == 0 || specularBounce) {
                 if (found) {
                     int li = (int)tinfo.z;
-                    if (li >= 0) { RGB Le = AreaL(sc.lights[li].l, isect.n, -rd); L = L + beta * Le; }
+                    if (li >= 0) { RGB Le = AreaL(sc.lights[li], isect.n, -rd); L = L + beta * Le; }
                 } else {
-                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].l.L);
+                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].L);
                 }
             }
             if (found && bounces < sc.max_depth) {
@@ -1182,7 +1182,14 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         std::vector<DevLight> dl(d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; ++i) {
             std::memset(&dl[i], 0, sizeof(DevLight));
-            dl[i].l = d->lights[i];
+            const mi_light &ml = d->lights[i];
+            dl[i].type = ml.type; dl[i].tri = ml.tri; dl[i].two_sided = ml.two_sided;
+            for (int k = 0; k < 3; ++k) { dl[i].L[k] = ml.L[k]; dl[i].pos[k] = ml.pos[k]; }
+            dl[i].area = ml.area; dl[i].world_radius = ml.world_radius;
+            if (ml.type == MI_LIGHT_SPOT) {
+                dl[i].cos_total = ml.cos_total_width; dl[i].cos_falloff = ml.cos_falloff_start;
+                for (int k = 0; k < 3; ++k) { dl[i].p0[k] = ml.frame[k]; dl[i].p1[k] = ml.frame[3 + k]; dl[i].p2[k] = ml.frame[6 + k]; }
+            }
             if (d->lights[i].type == MI_LIGHT_AREA_TRI) {
                 uint32_t t = (uint32_t)d->lights[i].tri;
                 const float4 *v = &tv[3 * (size_t)t];

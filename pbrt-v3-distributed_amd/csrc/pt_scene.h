@@ -25,11 +25,14 @@ struct __attribute__((aligned(128))) BVH4Node {
 // shapes/triangle.cpp:308-315 (decided per triangle, independent of the ray).
 #define TRI_FLAG_REJECT 1u
 
-struct DevLight {
-    mi_light l;
-    float p0[3]; uint32_t mesh_flags;
-    float p1[3]; uint32_t pad1;
-    float p2[3]; uint32_t pad2;
+struct DevLight {   // 7 x 16 bytes, fetched with independent 16-byte loads (LoadLight)
+    int32_t type, tri, two_sided; uint32_t mesh_flags;   // mesh flags of the emissive triangle (bit 31: TRI_FLAG_REJECT)
+    float L[3], area;
+    float pos[3], world_radius;
+    float cos_total, cos_falloff, pad0, pad1;            // spot
+    float p0[3], padA;                                   // area light: triangle vertices; spot: rows of WorldToLight
+    float p1[3], padB;
+    float p2[3], padC;
 };
 
 // Per-triangle shading record: the vertex normals and uvs the interaction needs, gathered per triangle at upload time

@@ -556,7 +556,7 @@ struct BSDF {
 };
 
 // ------------------------------------------------------------------ lights
-PT_DEV RGB AreaL(const mi_light &l, const V3 &n, const V3 &w) {   // DiffuseAreaLight::L lights/diffuse.h:56-58
+PT_DEV RGB AreaL(const DevLight &l, const V3 &n, const V3 &w) {   // DiffuseAreaLight::L lights/diffuse.h:56-58
     return (l.two_sided || Dot(n, w) > 0) ? rgb3(l.L) : RGB(0.f);
 }
 
@@ -578,18 +578,20 @@ struct LightRegs {
     int type, tri, two_sided;
     RGB L; Float area;
     V3 pos; Float world_radius;
+    Float cos_total, cos_falloff;
     V3 p0, p1, p2; uint32_t mesh_flags;
 };
 PT_DEV LightRegs LoadLight(const DevLight *dl) {
     const float4 *q = reinterpret_cast<const float4 *>(dl);
-    float4 a = q[0], b = q[1], c = q[2], e = q[4], f = q[5], g = q[6];
-    Pin(a, b, c); Pin(e, f, g);
+    float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+    Pin(a, b, c); Pin(e, f, g); Pin(d);
     LightRegs r;
     r.type = (int)__float_as_uint(a.x); r.tri = (int)__float_as_uint(a.y); r.two_sided = (int)__float_as_uint(a.z);
+    r.mesh_flags = __float_as_uint(a.w);
     r.L = RGB(b.x, b.y, b.z); r.area = b.w;
     r.pos = V3(c.x, c.y, c.z); r.world_radius = c.w;
-    r.p0 = V3(e.x, e.y, e.z); r.mesh_flags = __float_as_uint(e.w);
-    r.p1 = V3(f.x, f.y, f.z); r.p2 = V3(g.x, g.y, g.z);
+    r.cos_total = d.x; r.cos_falloff = d.y;
+    r.p0 = V3(e.x, e.y, e.z); r.p1 = V3(f.x, f.y, f.z); r.p2 = V3(g.x, g.y, g.z);
     return r;
 }
 PT_DEV RGB AreaL(const LightRegs &l, const V3 &n, const V3 &w) { return (l.two_sided || Dot(n, w) > 0) ? l.L : RGB(0.f); }
@@ -602,7 +604,7 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
     ref.p = refP; ref.pError = refPError; ref.n = refN;
     const LightRegs l = LoadLight(dl);
     ls->pdf = 0; ls->Li = RGB(0.f);
-    ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT;
+    ls->delta = l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT || l.type == MI_LIGHT_SPOT;
     if (l.type == MI_LIGHT_AREA_TRI) {
         // DiffuseAreaLight::Sample_Li lights/diffuse.cpp:68-81 -> Shape::Sample(ref,u) core/shape.cpp:56-70
         // -> Triangle::Sample(u) shapes/triangle.cpp:583-608
@@ -642,6 +644,24 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
         ls->pdf = 1.f;
         ls->shadow = SpawnRayTo(ref, pLight, V3(), V3());
         ls->Li = l.L / DistanceSquared(pLight, ref.p);
+        return lsv;
+    }
+    if (l.type == MI_LIGHT_SPOT) {   // lights/spot.cpp:54-72
+        V3 pLight = l.pos;
+        ls->wi = Normalize(pLight - ref.p);
+        ls->pdf = 1.f;
+        ls->shadow = SpawnRayTo(ref, pLight, V3(), V3());
+        V3 w = -ls->wi;   // Falloff(-wi): wl = Normalize(WorldToLight(w)), rows of WorldToLight in p0..p2
+        V3 wl = Normalize(V3(l.p0.x * w.x + l.p0.y * w.y + l.p0.z * w.z, l.p1.x * w.x + l.p1.y * w.y + l.p1.z * w.z,
+                             l.p2.x * w.x + l.p2.y * w.y + l.p2.z * w.z));
+        Float cosTheta = wl.z, falloff;
+        if (cosTheta < l.cos_total) falloff = 0;
+        else if (cosTheta >= l.cos_falloff) falloff = 1;
+        else {
+            Float delta = (cosTheta - l.cos_total) / (l.cos_falloff - l.cos_total);
+            falloff = (delta * delta) * (delta * delta);
+        }
+        ls->Li = l.L * falloff / DistanceSquared(pLight, ref.p);
         return lsv;
     }
     if (l.type == MI_LIGHT_DISTANT) {   // lights/distant.cpp:49-59

@@ -307,6 +307,27 @@ std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, co
         RGB Ls = L * sc;
         light->l.type = MI_LIGHT_DISTANT;
         for (int i = 0; i < 3; ++i) { light->l.L[i] = Ls.c[i]; light->l.pos[i] = w[i]; }
+    } else if (name == "spot") {   // CreateSpotLight lights/spot.cpp:104-125, constructor :40-52
+        RGB I = ps.FindOneSpectrum("I", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
+        Float coneangle = ps.FindOneFloat("coneangle", 30.), conedelta = ps.FindOneFloat("conedeltaangle", 5.);
+        Vec3 from = ps.FindOnePoint3("from", Vec3(0, 0, 0)), to = ps.FindOnePoint3("to", Vec3(0, 0, 1));
+        Vec3 dir = Normalize(to - from), du, dv;
+        CoordinateSystem(dir, &du, &dv);
+        Matrix4x4 dz;
+        dz.m[0][0] = du.x; dz.m[0][1] = du.y; dz.m[0][2] = du.z; dz.m[0][3] = 0;
+        dz.m[1][0] = dv.x; dz.m[1][1] = dv.y; dz.m[1][2] = dv.z; dz.m[1][3] = 0;
+        dz.m[2][0] = dir.x; dz.m[2][1] = dir.y; dz.m[2][2] = dir.z; dz.m[2][3] = 0;
+        dz.m[3][0] = 0; dz.m[3][1] = 0; dz.m[3][2] = 0; dz.m[3][3] = 1;
+        Transform dirToZ(dz);
+        Transform light2world = l2w * Translate(Vec3(from.x, from.y, from.z)) * Transform(dirToZ.mInv, dirToZ.m);
+        Vec3 p = light2world.Point(Vec3(0, 0, 0));
+        RGB Is = I * sc;
+        Float totalWidth = coneangle, falloffStart = coneangle - conedelta;
+        light->l.type = MI_LIGHT_SPOT;
+        for (int i = 0; i < 3; ++i) { light->l.L[i] = Is.c[i]; light->l.pos[i] = p[i]; }
+        for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) light->l.frame[3 * r + c2] = light2world.mInv.m[r][c2];   // WorldToLight = Inverse(LightToWorld)
+        light->l.cos_total_width = std::cos(Radians(totalWidth));
+        light->l.cos_falloff_start = std::cos(Radians(falloffStart));
     } else if (name == "infinite" || name == "exinfinite") {   // infinite.cpp: constant radiance only
         RGB L = ps.FindOneSpectrum("L", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
         if (ps.FindOneFilename("mapname", "") != "")
@@ -316,7 +337,7 @@ std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, co
         light->l.type = MI_LIGHT_INFINITE;
         for (int i = 0; i < 3; ++i) light->l.L[i] = Ls.c[i];
     } else {
-        Warning("Light \"%s\" is not supported by this path (spot/goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());
+        Warning("Light \"%s\" is not supported by this path (goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());
         ps.ReportUnused();
         return nullptr;
     }

@@ -52,6 +52,11 @@ inline Vec3 Cross(const Vec3 &a, const Vec3 &b) {
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return Vec3((Float)((ay * bz) - (az * by)), (Float)((az * bx) - (ax * bz)), (Float)((ax * by) - (ay * bx)));
 }
+inline void CoordinateSystem(const Vec3 &v1, Vec3 *v2, Vec3 *v3) {   // geometry.h:1020-1027
+    if (std::abs(v1.x) > std::abs(v1.y)) *v2 = Vec3(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else *v2 = Vec3(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    *v3 = Cross(v1, *v2);
+}
 inline Vec3 Min(const Vec3 &a, const Vec3 &b) { return Vec3(std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)); }
 inline Vec3 Max(const Vec3 &a, const Vec3 &b) { return Vec3(std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)); }
 

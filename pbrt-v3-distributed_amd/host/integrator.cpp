@@ -113,6 +113,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
             for (int i = 0; i < 3; ++i) l.world_center[i] = worldCenter[i];
             RGB L(l.L[0], l.L[1], l.L[2]);
             if (l.type == MI_LIGHT_POINT) power.push_back((L * (4 * kPi)).y());                       // point.cpp:56
+            else if (l.type == MI_LIGHT_SPOT) power.push_back((L * 2 * kPi * (1 - .5f * (l.cos_falloff_start + l.cos_total_width))).y());   // spot.cpp:75-77
             else power.push_back((L * kPi * worldRadius * worldRadius).y());                          // distant.cpp:64-66 / infinite
             fs->lights.push_back(l);
         } else {

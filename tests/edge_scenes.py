@@ -37,6 +37,10 @@ def scene(name):
         return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
     if name == "infinite_only":  # a single light: CreateLightSampleDistribution substitutes uniform (lightdistrib.cpp:50)
         return _OPEN % 'LightSource "infinite" "rgb L" [.9 .8 .7]'
+    if name == "spot":          # two spot lights, one under a transform (cone falloff, WorldToLight frame)
+        return _OPEN % ('LightSource "spot" "point from" [2 4 -3] "point to" [-.5 0 0] "rgb I" [120 110 90] "float coneangle" [22] "float conedeltaangle" [7]\n'
+                        'AttributeBegin\nRotate 20 0 1 0\nTranslate .3 0 0\n'
+                        'LightSource "spot" "point from" [-3 3 -2] "point to" [0 .5 0] "rgb I" [40 60 90] "rgb scale" [.5 .5 .5]\nAttributeEnd')
     if name == "dof":           # thin lens
         return _cornell().replace('Camera "perspective" "float fov" [39.3]', 'Camera "perspective" "float fov" [39.3] "float lensradius" [12] "float focaldistance" [1000]')
     if name == "crop":          # crop window + pixel bounds: partial tiles on every side, samples outside the bounds skipped
@@ -57,4 +61,4 @@ def scene(name):
     raise KeyError(name)
 
 
-NAMES = ["infinite", "infinite_only", "dof", "crop", "clamp", "empty", "onetri"]
+NAMES = ["infinite", "infinite_only", "spot", "dof", "crop", "clamp", "empty", "onetri"]
