@@ -33,6 +33,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU box shows 256 hardware
+    threads but grants a container 16 CPUs' worth of time -- more threads than that only throttle each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +228,10 @@ def main():
                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
                     "avg_launch_ms": t_closest_ms / max(1.0, launches_per_step), "launches_per_step": launches_per_step,
                     "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays)}
+        try:
+            roofline["hbm_stream_read_GBps"] = round(ctx.stream_read_gbps(4 << 30), 1)   # achievable ceiling, beside the spec peak
+        except Exception as e:   # measurement aid only
+            log("[bench] stream-read ceiling not measured: %s" % e)
         if traffic:
             # measured HBM-side bytes (PMC pass of the same command, profiles/traffic_closest.json) over the live launch time:
             # the algorithmic figure counts every node fetch, most of which the XCD L2s serve
@@ -213,7 +243,7 @@ def main():
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
             import oracle_lib as ol
-            ncores = os.cpu_count() or 1
+            ncores = host_cpus()
             ntx, nty = (sc.width + 15) // 16, (sc.height + 15) // 16
             cx, cy = ntx // 2, nty // 2
             spp_cpu = int(min(sc.info["spp"], 8))
@@ -227,8 +257,9 @@ def main():
                 side = int(side * max(1.5, min(4.0, (args.cpu_seconds / max(secs, 1e-3)) ** 0.5)))
             cpu = {"value": round(cc["camera_rays"] / secs * 1e-6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",
                    "mrays_per_s": round((cc["closest_rays"] + cc["shadow_rays"]) / secs * 1e-6, 3),
-                   "sample": "oracle/pt_oracle.cpp (CPU restatement, pinned to pbrt_ref) on tiles [%d,%d)x[%d,%d) of the same frame, %d of %d spp, %d threads, %.1f s"
-                             % (box[0], box[2], box[1], box[3], spp_cpu, sc.info["spp"], ncores, secs)}
+                   "sample": "oracle/pt_oracle.cpp (CPU restatement, pinned to pbrt_ref) on tiles [%d,%d)x[%d,%d) of the same frame, %d of %d spp, %d threads "
+                             "(= usable CPUs: affinity / cgroup quota; %d hardware threads visible), %.1f s"
+                             % (box[0], box[2], box[1], box[3], spp_cpu, sc.info["spp"], ncores, os.cpu_count() or 1, secs)}
             # parity spot check on that crop: GPU render of the same samples vs the oracle
             ctx.film_clear()
             ctx.render(spp_begin=0, spp_end=spp_cpu)

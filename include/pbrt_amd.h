@@ -276,6 +276,10 @@ enum mi_kernel_id {
 };
 int mi_timing_enable(mi_ctx *ctx, int on);
 int mi_timing_get(mi_ctx *ctx, double ms_total[MI_K_COUNT], uint64_t launches[MI_K_COUNT]);
+/* Measurement aid: achievable HBM read rate on this device -- a streaming 16-byte-per-lane read of
+ * `bytes` (>= 1 GiB recommended, beyond the 256 MiB Infinity Cache), best of 3 timed launches -- reported beside the
+ * 8 TB/s specification peak. */
+int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
 
 /* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
 

@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_intersect", "mi_triangle_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_intersect", "mi_triangle_intersect", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -99,6 +99,7 @@ def device_lib():
         L.mi_counters_reset.argtypes = [C.c_void_p]
         L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_triangle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -228,6 +229,12 @@ class Context:
         n = np.zeros(MI_K_COUNT, dtype=np.uint64)
         self._chk(device_lib().mi_timing_get(self._ctx, _ptr(ms), _ptr(n)), "mi_timing_get")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    def stream_read_gbps(self, nbytes=4 << 30):
+        """achievable HBM read rate (streaming read of nbytes), GB/s"""
+        v = C.c_double(0)
+        self._chk(device_lib().mi_stream_read_gbps(self._ctx, C.c_uint64(nbytes), C.byref(v)), "mi_stream_read_gbps")
+        return float(v.value)
 
     # ---- stage-level entry points
     def intersect(self, rays):
