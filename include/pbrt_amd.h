@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -121,7 +121,27 @@ typedef struct mi_light {
     float frame[9];
     float cos_total_width, cos_falloff_start;
     float pad3;
+    /* INFINITE with a radiance map (lights/infinite.cpp:43-132): env_map = 1 + index into mi_scene_desc::envmaps (0: constant L);
+     * frame = WorldToLight 3x3 (Le, Pdf_Li), l2w = LightToWorld 3x3 (Sample_Li) */
+    int32_t env_map;
+    float l2w[9];
+    float pad4[2];
 } mi_light;
+
+/* Radiance map of an InfiniteAreaLight as its constructor leaves it (infinite.cpp:43-84): MIPMap level 0 (texels * L, resampled to
+ * power-of-two sizes by MIPMap's constructor, mipmap.h:120-182) and the Distribution2D over the (2*width) x (2*height) image of
+ * luminance * sin(theta).  Lookups on the path use level 0 only (Lookup(st) with zero width -> triangle(0, st), mipmap.h:247-276). */
+typedef struct mi_envmap {
+    int32_t width, height;
+    const float *rgb;           /* 3 * width * height, row major, row 0 = top (theta = 0) */
+    const float *cond_func;     /* (2*width) * (2*height): pConditionalV[v]->func */
+    const float *cond_cdf;      /* (2*width + 1) * (2*height) */
+    const float *cond_func_int; /* 2*height */
+    const float *marg_func;     /* 2*height: pMarginal->func */
+    const float *marg_cdf;      /* 2*height + 1 */
+    float marg_func_int;
+    float pad;
+} mi_envmap;
 
 /* ---------------------------------------------------------------- camera/film ------- */
 
@@ -208,6 +228,9 @@ typedef struct mi_scene_desc {
     mi_camera camera;
     mi_film film;
     mi_integrator integrator;
+    uint32_t n_envmaps;
+    uint32_t pad1;
+    const mi_envmap *envmaps;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

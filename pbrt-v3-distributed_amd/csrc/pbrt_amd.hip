@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                             Li = AreaL(light, li.n, -ts.d);   // lightIsect.Le(-wi)
                         }
                     } else if (light.type == MI_LIGHT_INFINITE)
-                        Li = rgb3(light.L);                   // light.Le(ray)
+                        Li = InfiniteLe(&light, ts.d);   // light.Le(ray)
                     if (!Li.IsBlack()) {
                         float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
                         L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
@@ -529,6 +529,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
 #endif
+// ENV: the scene has an infinite light with a radiance map (escaped rays look it up); scenes without one run the leaner instance
+template <bool ENV, bool HALTON>
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
@@ -565,7 +567,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             smp.px = smp.py = 0;   // only dimensions 0/1 (camera sample) look at the pixel
             // the (at most) 8 sample dimensions this vertex can consume: light pick, uLight, uScattering, BSDF, RR
             Float us[8];
-            SamplerBatch<8>(sc, smp.index, smp.dimension, us);
+            if (HALTON) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) us[k] = HaltonSampleDimension(sc, smp.index, smp.dimension + k);
+            } else
+                SobolBatch<8>(sc, smp.index, smp.dimension, us);
             PROBE(2)   // Sobol batch
             int ui = 0;      // sample dimensions consumed by this vertex (added to the path's dimension at the end)
             int ubase = 0;   // sample dimensions consumed before the BSDF sample: 0, 1 (light pick only) or 5 -- static indices keep us[] in registers
@@ -591,7 +597,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                     int li = (int)tinfo.z;
                     if (li >= 0) { RGB Le = AreaL(sc.lights[li], isect.n, -rd); L = L + beta * Le; }
                 } else {
-                    for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * rgb3(sc.lights[sc.infinite_lights[k]].L);
+                    for (uint32_t k = 0; k < sc.n_infinite; ++k) {   // infiniteLights Le(ray)
+                        const DevLight &il = sc.lights[sc.infinite_lights[k]];
+                        L = L + beta * (ENV ? InfiniteLe(&il, rd) : rgb3(il.L));
+                    }
                 }
             }
             if (found && bounces < sc.max_depth) {
@@ -938,6 +947,7 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
+    bool hasEnvMap = false;
     DevScene sc;
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
@@ -1083,7 +1093,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(32);
+    c->sceneBufs.resize(32 + 6 * (size_t)d->n_envmaps);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1178,6 +1188,30 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         sc.tri_info = b.as<uint4>();
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
+    {   // radiance maps of infinite lights
+        std::vector<DevEnvMap> em(d->n_envmaps);
+        for (uint32_t i = 0; i < d->n_envmaps; ++i) {
+            const mi_envmap &m = d->envmaps[i];
+            if (m.width < 1 || m.height < 1 || !m.rgb || !m.cond_func || !m.cond_cdf || !m.cond_func_int || !m.marg_func || !m.marg_cdf)
+                return fail("mi_scene_upload: incomplete environment map");
+            size_t w = (size_t)m.width, h = (size_t)m.height, nu = 2 * w, nv = 2 * h;
+            std::memset(&em[i], 0, sizeof(DevEnvMap));
+            em[i].width = m.width; em[i].height = m.height; em[i].marg_func_int = m.marg_func_int;
+            if (c->sceneBufs.size() < (size_t)nb + 8) return fail("mi_scene_upload: too many environment maps");
+            { DevBuf &b = next(); if (upload(c, b, m.rgb, 3 * w * h * 4)) return -1; em[i].rgb = b.as<float>(); }
+            { DevBuf &b = next(); if (upload(c, b, m.cond_func, nu * nv * 4)) return -1; em[i].cond_func = b.as<float>(); }
+            { DevBuf &b = next(); if (upload(c, b, m.cond_cdf, (nu + 1) * nv * 4)) return -1; em[i].cond_cdf = b.as<float>(); }
+            { DevBuf &b = next(); if (upload(c, b, m.cond_func_int, nv * 4)) return -1; em[i].cond_func_int = b.as<float>(); }
+            { DevBuf &b = next(); if (upload(c, b, m.marg_func, nv * 4)) return -1; em[i].marg_func = b.as<float>(); }
+            { DevBuf &b = next(); if (upload(c, b, m.marg_cdf, (nv + 1) * 4)) return -1; em[i].marg_cdf = b.as<float>(); }
+        }
+        DevBuf &b = next();
+        if (upload(c, b, em.data(), em.size() * sizeof(DevEnvMap))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        sc.envmaps = b.as<DevEnvMap>();
+        c->hasEnvMap = d->n_envmaps > 0;
+    }
+    const DevEnvMap *envDev = sc.envmaps;
     {
         std::vector<DevLight> dl(d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; ++i) {
@@ -1186,6 +1220,14 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             dl[i].type = ml.type; dl[i].tri = ml.tri; dl[i].two_sided = ml.two_sided;
             for (int k = 0; k < 3; ++k) { dl[i].L[k] = ml.L[k]; dl[i].pos[k] = ml.pos[k]; }
             dl[i].area = ml.area; dl[i].world_radius = ml.world_radius;
+            if (ml.type == MI_LIGHT_INFINITE && ml.env_map) {
+                if ((uint32_t)ml.env_map > d->n_envmaps) return fail("mi_scene_upload: light refers to a missing environment map");
+                dl[i].env = envDev + (ml.env_map - 1);
+                for (int k = 0; k < 3; ++k) {
+                    dl[i].p0[k] = ml.frame[k]; dl[i].p1[k] = ml.frame[3 + k]; dl[i].p2[k] = ml.frame[6 + k];
+                    dl[i].l2w0[k] = ml.l2w[k]; dl[i].l2w1[k] = ml.l2w[3 + k]; dl[i].l2w2[k] = ml.l2w[6 + k];
+                }
+            }
             if (ml.type == MI_LIGHT_SPOT) {
                 dl[i].cos_total = ml.cos_total_width; dl[i].cos_falloff = ml.cos_falloff_start;
                 for (int k = 0; k < 3; ++k) { dl[i].p0[k] = ml.frame[k]; dl[i].p1[k] = ml.frame[3 + k]; dl[i].p2[k] = ml.frame[6 + k]; }
@@ -1463,7 +1505,16 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
         tic(c, MI_K_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(c->gridShade), block, 0, st, sc, ps, qout);
+        {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
+            const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
+            if (c->hasEnvMap) {
+                if (halton) hipLaunchKernelGGL((k_shade<true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+            } else {
+                if (halton) hipLaunchKernelGGL((k_shade<false, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+            }
+        }
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);

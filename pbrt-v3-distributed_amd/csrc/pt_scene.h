@@ -25,14 +25,24 @@ struct __attribute__((aligned(128))) BVH4Node {
 // shapes/triangle.cpp:308-315 (decided per triangle, independent of the ray).
 #define TRI_FLAG_REJECT 1u
 
-struct DevLight {   // 7 x 16 bytes, fetched with independent 16-byte loads (LoadLight)
+struct DevEnvMap;
+struct DevLight {   // 10 x 16 bytes; the first 7, fetched with independent 16-byte loads (LoadLight)
     int32_t type, tri, two_sided; uint32_t mesh_flags;   // mesh flags of the emissive triangle (bit 31: TRI_FLAG_REJECT)
     float L[3], area;
     float pos[3], world_radius;
-    float cos_total, cos_falloff, pad0, pad1;            // spot
+    float cos_total, cos_falloff; const struct DevEnvMap *env;   // spot cone; infinite: its radiance map (null: constant L)
     float p0[3], padA;                                   // area light: triangle vertices; spot: rows of WorldToLight
     float p1[3], padB;
     float p2[3], padC;
+    float l2w0[3], padD;                                 // infinite light with a map: rows of LightToWorld (p0..p2 hold WorldToLight)
+    float l2w1[3], padE;
+    float l2w2[3], padF;
+};
+// radiance map of an InfiniteAreaLight (mi_envmap on the device)
+struct DevEnvMap {
+    int32_t width, height;
+    const float *rgb, *cond_func, *cond_cdf, *cond_func_int, *marg_func, *marg_cdf;
+    float marg_func_int, pad;
 };
 
 // Per-triangle shading record: the vertex normals and uvs the interaction needs, gathered per triangle at upload time
@@ -50,6 +60,7 @@ struct DevScene {
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const mi_material *materials;
+    const DevEnvMap *envmaps;
     const DevLight *lights;         // mi_light + (area lights) the triangle's vertices and mesh flags: no extra hops while sampling
     const float *light_func, *light_cdf;
     const float *filter_table;

@@ -571,6 +571,77 @@ PT_DEV ShadowRay SpawnRayTo(const Isect &ref, const V3 &p2, const V3 &p2Error, c
     return r;
 }
 
+// Number of leading cdf entries <= u of a non-decreasing cdf[size] -- what FindInterval's bisection (core/pbrt.h:398-411)
+// computes -- found with up to 16 independent probes per round: 2-3 memory round trips instead of log2(size) dependent ones.
+PT_DEV int CdfCountLE(const float *cdf, int size, Float u) {
+    int lo = 0, hi = size;   // entries below lo are <= u; entries from hi on are > u
+    while (lo < hi) {
+        int step = (hi - lo + 15) >> 4;
+        float pv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int idx = lo + (k + 1) * step - 1;
+            pv[k] = idx < hi ? cdf[idx] : PT_INFINITY;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cnt += (pv[k] <= u) ? 1 : 0;   // a prefix of the probes
+        int nlo = lo + cnt * step;
+        int nhi = lo + (cnt + 1) * step - 1;
+        hi = nhi < hi ? nhi : hi;
+        lo = nlo < hi ? nlo : hi;
+    }
+    return lo;
+}
+
+// ---- InfiniteAreaLight with a radiance map (lights/infinite.cpp:92-143)
+PT_DEV int ModI(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }   // core/pbrt.h:310-313
+PT_DEV RGB EnvTexel(const DevEnvMap &e, int s, int t) {   // MIPMap::Texel, ImageWrap::Repeat (mipmap.h:206-228)
+    const float *p = e.rgb + 3 * ((size_t)ModI(t, e.height) * e.width + ModI(s, e.width));
+    return RGB(p[0], p[1], p[2]);
+}
+PT_DEV RGB EnvLookup(const DevEnvMap &e, Float s_, Float t_) {   // Lookup(st) = triangle(0, st) (mipmap.h:244-250, 263-275)
+    Float s = s_ * e.width - 0.5f, t = t_ * e.height - 0.5f;
+    int s0 = (int)__builtin_floorf(s), t0 = (int)__builtin_floorf(t);
+    Float ds = s - s0, dt = t - t0;
+    RGB a = EnvTexel(e, s0, t0), b = EnvTexel(e, s0, t0 + 1), c = EnvTexel(e, s0 + 1, t0), d = EnvTexel(e, s0 + 1, t0 + 1);
+    return ((1 - ds) * (1 - dt)) * a + ((1 - ds) * dt) * b + (ds * (1 - dt)) * c + (ds * dt) * d;
+}
+PT_DEV V3 Mul3(const V3 &r0, const V3 &r1, const V3 &r2, const V3 &v) {   // Transform::operator()(Vector3f), 3x3 part
+    return V3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
+}
+PT_DEV Float atan2f_(Float y, Float x) { return (Float)atan2((double)y, (double)x); }
+PT_DEV Float SphericalTheta(const V3 &v) { return acosf_(clampf(v.z, -1, 1)); }                                   // geometry.h:1479-1481
+PT_DEV Float SphericalPhi(const V3 &v) { Float p = atan2f_(v.y, v.x); return (p < 0) ? (p + 2 * PT_PI) : p; }      // :1483-1486
+#define PT_INV_2PI 0.15915494309189533577f
+// InfiniteAreaLight::Le (infinite.cpp:92-96)
+__device__ __noinline__ RGB InfiniteLe(const DevLight *dl, const V3 rayD) {
+    if (!dl->env) return rgb3(dl->L);
+    V3 w = Normalize(Mul3(v3(dl->p0), v3(dl->p1), v3(dl->p2), rayD));
+    return EnvLookup(*dl->env, SphericalPhi(w) * PT_INV_2PI, SphericalTheta(w) * PT_INV_PI);
+}
+// Distribution1D::SampleContinuous core/sampling.h:72-89
+PT_DEV Float SampleContinuous1D(const float *func, const float *cdf, Float funcInt, int n, Float u, Float *pdf, int *off) {
+    int first = CdfCountLE(cdf, n + 1, u);
+    int offset = first - 1 < 0 ? 0 : (first - 1 > n - 1 ? n - 1 : first - 1);
+    *off = offset;
+    Float c0 = cdf[offset], c1 = cdf[offset + 1];
+    Float du = u - c0;
+    if ((c1 - c0) > 0) du /= (c1 - c0);
+    *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / n;
+}
+
+// Distribution2D::SampleContinuous core/sampling.h:127-134 -> (u, v, pdf); out of line: only scenes with a radiance map pay for it
+__device__ __noinline__ V3 SampleEnvMap(const DevEnvMap *envp, Float u0, Float u1) {
+    const DevEnvMap &env = *envp;
+    int nu = 2 * env.width, nv = 2 * env.height, v, dummy;
+    Float pdf0, pdf1;
+    Float d1 = SampleContinuous1D(env.marg_func, env.marg_cdf, env.marg_func_int, nv, u1, &pdf1, &v);
+    Float d0 = SampleContinuous1D(env.cond_func + (size_t)v * nu, env.cond_cdf + (size_t)v * (nu + 1), env.cond_func_int[v], nu, u0, &pdf0, &dummy);
+    return V3(d0, d1, pdf0 * pdf1);
+}
+
 struct LightSample { RGB Li; V3 wi; Float pdf; ShadowRay shadow; bool delta; };
 
 // A DevLight record in registers: fetched with 7 independent 16-byte loads (one memory round trip)
@@ -579,6 +650,7 @@ struct LightRegs {
     RGB L; Float area;
     V3 pos; Float world_radius;
     Float cos_total, cos_falloff;
+    const DevEnvMap *env;
     V3 p0, p1, p2; uint32_t mesh_flags;
 };
 PT_DEV LightRegs LoadLight(const DevLight *dl) {
@@ -590,7 +662,7 @@ PT_DEV LightRegs LoadLight(const DevLight *dl) {
     r.mesh_flags = __float_as_uint(a.w);
     r.L = RGB(b.x, b.y, b.z); r.area = b.w;
     r.pos = V3(c.x, c.y, c.z); r.world_radius = c.w;
-    r.cos_total = d.x; r.cos_falloff = d.y;
+    r.cos_total = d.x; r.cos_falloff = d.y; r.env = (const DevEnvMap *)(((unsigned long long)__float_as_uint(d.w) << 32) | (unsigned long long)__float_as_uint(d.z));
     r.p0 = V3(e.x, e.y, e.z); r.p1 = V3(f.x, f.y, f.z); r.p2 = V3(g.x, g.y, g.z);
     return r;
 }
@@ -673,16 +745,24 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
         ls->Li = l.L;
         return lsv;
     }
-    {   // constant InfiniteAreaLight, lights/infinite.cpp:108-132 with a 1x1 map (uv = u, mapPdf = 1)
-        Float theta = u1 * PT_PI, phi = u0 * 2 * PT_PI;
+    {   // InfiniteAreaLight::Sample_Li lights/infinite.cpp:98-126; without a map the constructor's distribution is uniform (uv = u, mapPdf = 1)
+        Float uv0 = u0, uv1 = u1, mapPdf = 1;
+        const bool hasMap = l.env != nullptr;
+        if (hasMap) {
+            V3 smp = SampleEnvMap(l.env, u0, u1);
+            uv0 = smp.x; uv1 = smp.y; mapPdf = smp.z;
+            if (mapPdf == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return lsv; }
+        }
+        Float theta = uv1 * PT_PI, phi = uv0 * 2 * PT_PI;
         Float cosTheta = cosf_(theta), sinTheta = sinf_(theta);
         Float sinPhi = sinf_(phi), cosPhi = cosf_(phi);
-        ls->wi = V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
-        ls->pdf = 1 / (2 * PT_PI * PT_PI * sinTheta);
+        V3 wl(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+        ls->wi = hasMap ? Mul3(v3(dl->l2w0), v3(dl->l2w1), v3(dl->l2w2), wl) : wl;
+        ls->pdf = mapPdf / (2 * PT_PI * PT_PI * sinTheta);
         if (sinTheta == 0) ls->pdf = 0;
         V3 pOutside = ref.p + ls->wi * (2 * l.world_radius);
         ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
-        ls->Li = l.L;
+        ls->Li = hasMap ? EnvLookup(*l.env, uv0, uv1) : l.L;
     }
     return lsv;
 }
@@ -701,11 +781,20 @@ PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const 
         if (__builtin_isinf(pdf)) pdf = 0.f;
         return pdf;
     }
-    if (l.type == MI_LIGHT_INFINITE) {   // lights/infinite.cpp:134-143, constant map
-        Float theta = acosf_(clampf(wi.z, -1, 1));
+    if (l.type == MI_LIGHT_INFINITE) {   // lights/infinite.cpp:128-137
+        V3 wl = l.env ? Mul3(l.p0, l.p1, l.p2, wi) : wi;
+        Float theta = SphericalTheta(wl), phi = SphericalPhi(wl);
         Float sinTheta = sinf_(theta);
         if (sinTheta == 0) return 0;
-        return 1 / (2 * PT_PI * PT_PI * sinTheta);
+        Float mapPdf = 1;
+        if (l.env) {   // Distribution2D::Pdf core/sampling.h:135-141
+            const DevEnvMap &env = *l.env;
+            int nu = 2 * env.width, nv = 2 * env.height;
+            int iu = (int)(phi * PT_INV_2PI * nu), iv = (int)(theta * PT_INV_PI * nv);
+            iu = iu < 0 ? 0 : (iu > nu - 1 ? nu - 1 : iu); iv = iv < 0 ? 0 : (iv > nv - 1 ? nv - 1 : iv);
+            mapPdf = env.cond_func[(size_t)iv * nu + iu] / env.marg_func_int;
+        }
+        return mapPdf / (2 * PT_PI * PT_PI * sinTheta);
     }
     return 0;
 }

@@ -328,14 +328,17 @@ std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, co
         for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) light->l.frame[3 * r + c2] = light2world.mInv.m[r][c2];   // WorldToLight = Inverse(LightToWorld)
         light->l.cos_total_width = std::cos(Radians(totalWidth));
         light->l.cos_falloff_start = std::cos(Radians(falloffStart));
-    } else if (name == "infinite" || name == "exinfinite") {   // infinite.cpp: constant radiance only
+    } else if (name == "infinite" || name == "exinfinite") {   // CreateInfiniteLight lights/infinite.cpp:204-215
         RGB L = ps.FindOneSpectrum("L", RGB(1.0)), sc = ps.FindOneSpectrum("scale", RGB(1.0));
-        if (ps.FindOneFilename("mapname", "") != "")
-            Warning("infinite light environment maps are outside this path's scope (SURVEY.md s.8 row f1); using constant L");
+        std::string texmap = ps.FindOneFilename("mapname", "");
         ps.FindOneInt("samples", 1); ps.FindOneInt("nsamples", 1);
         RGB Ls = L * sc;
         light->l.type = MI_LIGHT_INFINITE;
         for (int i = 0; i < 3; ++i) light->l.L[i] = Ls.c[i];
+        for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) { light->l.frame[3 * r + c2] = l2w.mInv.m[r][c2]; light->l.l2w[3 * r + c2] = l2w.m.m[r][c2]; }
+        if (texmap != "") {
+            light->env = CreateEnvMap(texmap, Ls);   // texels * L (infinite.cpp:52-56); unreadable -> constant L, as the reference
+        }
     } else {
         Warning("Light \"%s\" is not supported by this path (goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());
         ps.ReportUnused();

@@ -176,17 +176,24 @@ static bool WritePFM(const std::string &fn, const Float *rgb, int w, int h) {   
     return true;
 }
 
-bool ReadImagePFM(const std::string &fn, std::vector<Float> *rgb, int *w, int *h) {
+bool ReadImagePFM(const std::string &fn, std::vector<Float> *rgb, int *w, int *h) {   // core/imageio.cpp:350-425
     FILE *fp = std::fopen(fn.c_str(), "rb");
     if (!fp) return false;
     char tag[8];
     float sc;
-    if (std::fscanf(fp, "%7s %d %d %f", tag, w, h, &sc) != 4 || std::string(tag) != "PF" || sc > 0) { std::fclose(fp); return false; }
+    if (std::fscanf(fp, "%7s %d %d %f", tag, w, h, &sc) != 4 || (std::string(tag) != "PF" && std::string(tag) != "Pf")) { std::fclose(fp); return false; }
     std::fgetc(fp);
-    rgb->resize((size_t)*w * *h * 3);
-    for (int y = *h - 1; y >= 0; --y)
-        if (std::fread(rgb->data() + (size_t)y * *w * 3, sizeof(float), (size_t)*w * 3, fp) != (size_t)*w * 3) { std::fclose(fp); return false; }
+    int nc = std::string(tag) == "PF" ? 3 : 1;
+    std::vector<float> data((size_t)*w * *h * nc);
+    for (int y = *h - 1; y >= 0; --y)   // flip in Y: P*M has the origin at the lower left
+        if (std::fread(data.data() + (size_t)y * *w * nc, sizeof(float), (size_t)*w * nc, fp) != (size_t)*w * nc) { std::fclose(fp); return false; }
     std::fclose(fp);
+    if (!(sc < 0.f))   // big-endian file on a little-endian host
+        for (float &v : data) { unsigned char b[4]; std::memcpy(b, &v, 4); std::swap(b[0], b[3]); std::swap(b[1], b[2]); std::memcpy(&v, b, 4); }
+    if (std::abs(sc) != 1.f) for (float &v : data) v *= std::abs(sc);
+    rgb->resize((size_t)*w * *h * 3);
+    for (size_t i = 0; i < (size_t)*w * *h; ++i)
+        for (int c = 0; c < 3; ++c) (*rgb)[3 * i + c] = nc == 3 ? data[3 * i + c] : data[i];
     return true;
 }
 

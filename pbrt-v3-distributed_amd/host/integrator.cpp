@@ -114,7 +114,21 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
             RGB L(l.L[0], l.L[1], l.L[2]);
             if (l.type == MI_LIGHT_POINT) power.push_back((L * (4 * kPi)).y());                       // point.cpp:56
             else if (l.type == MI_LIGHT_SPOT) power.push_back((L * 2 * kPi * (1 - .5f * (l.cos_falloff_start + l.cos_total_width))).y());   // spot.cpp:75-77
-            else power.push_back((L * kPi * worldRadius * worldRadius).y());                          // distant.cpp:64-66 / infinite
+            else if (l.type == MI_LIGHT_INFINITE) {   // infinite.cpp:86-90: Pi r^2 * Lmap->Lookup((.5,.5), .5)
+                RGB Lc = e.light->env ? e.light->env->powerLookup : L;
+                power.push_back((Lc * (kPi * worldRadius * worldRadius)).y());
+                if (e.light->env) {
+                    const EnvMap &em = *e.light->env;
+                    mi_envmap me;
+                    std::memset(&me, 0, sizeof(me));
+                    me.width = em.width; me.height = em.height; me.rgb = em.rgb.data();
+                    me.cond_func = em.condFunc.data(); me.cond_cdf = em.condCdf.data(); me.cond_func_int = em.condFuncInt.data();
+                    me.marg_func = em.margFunc.data(); me.marg_cdf = em.margCdf.data(); me.marg_func_int = em.margFuncInt;
+                    fs->envmaps.push_back(me);
+                    fs->envKeep.push_back(e.light->env);
+                    l.env_map = (int32_t)fs->envmaps.size();
+                }
+            } else power.push_back((L * kPi * worldRadius * worldRadius).y());                        // distant.cpp:64-66
             fs->lights.push_back(l);
         } else {
             const GeometricPrimitive &gp = prims[e.prim];
@@ -169,6 +183,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
     d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
+    d.n_envmaps = (uint32_t)fs->envmaps.size(); d.envmaps = fs->envmaps.empty() ? nullptr : fs->envmaps.data();
     d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
     d.integrator.spatial_max_voxels = 64;
     copyMatrix(d.camera.raster_to_camera, camera->RasterToCamera.m);

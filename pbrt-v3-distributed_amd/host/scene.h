@@ -48,7 +48,15 @@ std::shared_ptr<Material> MakeMaterial(const std::string &name, const TexturePar
 
 // ---- Lights (core/light.h:62-112)
 struct AreaLightSpec { RGB Lemit; bool twoSided; };          // CreateDiffuseAreaLight diffuse.cpp:135-146
-struct Light { mi_light l; };                                 // point / distant / infinite
+// radiance map of an InfiniteAreaLight after the reference constructor (host/envmap.cpp)
+struct EnvMap {
+    int width = 0, height = 0;
+    std::vector<Float> rgb, condFunc, condCdf, condFuncInt, margFunc, margCdf;
+    Float margFuncInt = 0;
+    RGB powerLookup;   // Lmap->Lookup((.5,.5), .5) of Power() (infinite.cpp:86-90)
+};
+std::shared_ptr<EnvMap> CreateEnvMap(const std::string &filename, const RGB &L);
+struct Light { mi_light l; std::shared_ptr<EnvMap> env; };   // point / spot / distant / infinite
 // one entry of Scene::lights in file order (api.cpp:1418-1424): a LightSource light, or
 // "every triangle of primitive `prim` is a DiffuseAreaLight" (api.cpp:1357-1366)
 struct LightEntry { std::shared_ptr<Light> light; int prim; };
@@ -168,6 +176,8 @@ struct FlatScene {
     std::vector<mi_mesh> meshes;
     std::vector<mi_material> materials;
     std::vector<mi_light> lights;
+    std::vector<mi_envmap> envmaps;
+    std::vector<std::shared_ptr<EnvMap>> envKeep;
 };
 
 class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)

@@ -41,6 +41,10 @@ def scene(name):
         return _OPEN % ('LightSource "spot" "point from" [2 4 -3] "point to" [-.5 0 0] "rgb I" [120 110 90] "float coneangle" [22] "float conedeltaangle" [7]\n'
                         'AttributeBegin\nRotate 20 0 1 0\nTranslate .3 0 0\n'
                         'LightSource "spot" "point from" [-3 3 -2] "point to" [0 .5 0] "rgb I" [40 60 90] "rgb scale" [.5 .5 .5]\nAttributeEnd')
+    if name in ("envmap", "envmap_power"):   # infinite light with a radiance map (non-power-of-two: Lanczos resampling), rotated; + a point light
+        t = _OPEN % ('AttributeBegin\nRotate -90 1 0 0\nRotate 30 0 0 1\nLightSource "infinite" "rgb L" [.8 .9 1] "string mapname" "%s"\nAttributeEnd\n'
+                     'LightSource "point" "point from" [3 4 -2] "rgb I" [5 5 5]' % os.path.join(ROOT, "scenes", "envmap_40x20.pfm"))
+        return t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "path" "integer maxdepth" [5] "string lightsamplestrategy" "power"') if name == "envmap_power" else t
     if name == "dof":           # thin lens
         return _cornell().replace('Camera "perspective" "float fov" [39.3]', 'Camera "perspective" "float fov" [39.3] "float lensradius" [12] "float focaldistance" [1000]')
     if name == "crop":          # crop window + pixel bounds: partial tiles on every side, samples outside the bounds skipped
@@ -61,4 +65,4 @@ def scene(name):
     raise KeyError(name)
 
 
-NAMES = ["infinite", "infinite_only", "spot", "dof", "crop", "clamp", "empty", "onetri"]
+NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "dof", "crop", "clamp", "empty", "onetri"]
