@@ -144,6 +144,8 @@ def main():
 
     pa = importlib.import_module("pbrt-v3-distributed_amd")
     par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
+    # every rank parses the scene and builds the (reference's) BVH itself: share the usable CPUs between the ranks of this node
+    os.environ.setdefault("PBRT_AMD_NTHREADS", str(max(1, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     t0 = time.time()
     sc = pa.Scene(scene_file)
     t_load = time.time() - t0

@@ -98,7 +98,9 @@ Matrix4x4 fromColumnMajor(const Float tr[16]) {   // api.cpp:922-925
 
 }  // namespace
 
+int g_optionNThreads = 0;
 void pbrtInit(const Options &opt) {
+    g_optionNThreads = opt.nThreads;
     PbrtOptions = opt;
     g_imageFileOverride = opt.imageFile;
     g_quickRender = opt.quickRender;

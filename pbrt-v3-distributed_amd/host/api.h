@@ -17,6 +17,7 @@ struct Options {   // core/pbrt.h:167-181 (the flags that make sense for this pa
 };
 
 void pbrtInit(const Options &opt);
+int NumHostThreads();   // host threads for scene construction (bvh.cpp)
 void pbrtCleanup();
 void pbrtIdentity();
 void pbrtTranslate(Float dx, Float dy, Float dz);

@@ -11,6 +11,9 @@
 #include <future>
 #include <mutex>
 #include <thread>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "scene.h"
 
@@ -30,6 +33,22 @@ struct BuildNode {   // BVHBuildNode, bvh.cpp:61-83
     int splitAxis = 0, firstPrimOffset = 0, nPrimitives = 0;
 };
 
+}  // namespace
+// Threads for host-side scene construction: --nthreads / PBRT_AMD_NTHREADS, else the CPUs this process may really use
+// (hardware threads, capped by the cgroup CPU quota of a container).
+int NumHostThreads() {
+    extern int g_optionNThreads;
+    if (g_optionNThreads > 0) return g_optionNThreads;
+    if (const char *e = std::getenv("PBRT_AMD_NTHREADS")) { int v = std::atoi(e); if (v > 0) return v; }
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long per = 0;
+        if (std::fscanf(f, "%63s %ld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) n = std::max(1, std::min(n, (int)((std::atol(q) + per / 2) / per)));
+        std::fclose(f);
+    }
+    return n;
+}
+namespace {
 struct Builder {
     std::vector<PrimInfo> &info;
     int maxPrimsInNode;
@@ -41,7 +60,7 @@ struct Builder {
 
     Builder(std::vector<PrimInfo> &info, int maxPrims, BVHAccel::SplitMethod m)
         : info(info), maxPrimsInNode(maxPrims), method(m) {
-        maxTasks = std::max(1u, std::thread::hardware_concurrency());
+        maxTasks = NumHostThreads();
     }
     std::deque<BuildNode> *newPool() {
         std::lock_guard<std::mutex> g(poolMutex);
