@@ -73,6 +73,8 @@ def main():
                          "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample (0 = skip)")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on a 1-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,8 +90,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     # ---- scene (generated once per node by local rank 0)
     bench_dir = os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench")
