@@ -45,6 +45,14 @@ def scene(name):
         t = _OPEN % ('AttributeBegin\nRotate -90 1 0 0\nRotate 30 0 0 1\nLightSource "infinite" "rgb L" [.8 .9 1] "string mapname" "%s"\nAttributeEnd\n'
                      'LightSource "point" "point from" [3 4 -2] "rgb I" [5 5 5]' % os.path.join(ROOT, "scenes", "envmap_40x20.pfm"))
         return t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "path" "integer maxdepth" [5] "string lightsamplestrategy" "power"') if name == "envmap_power" else t
+    if name == "instances":     # ObjectBegin / ObjectInstance (flattened to world space on the host) under rotations and non-uniform scales
+        obj = ('ObjectBegin "thing"\nMaterial "plastic" "rgb Kd" [.2 .6 .3] "rgb Ks" [.3 .3 .3] "float roughness" [.1]\n'
+               'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+               '  "point P" [-.3 0 -.3  .3 0 -.3  .3 0 .3  -.3 0 .3  -.3 .6 -.3  .3 .6 -.3  .3 .6 .3  -.3 .6 .3]\nObjectEnd\n')
+        inst = "".join('AttributeBegin\nTranslate %g 0 %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "thing"\nAttributeEnd\n' % (x, z, a, sc, sc * 1.3, sc)
+                       for x, z, a, sc in [(-1.5, 1, 20, 1), (0.2, 2, 75, .7), (1.6, .5, -40, 1.2), (-.4, -.5, 10, .5)])
+        return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
+                        'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
     if name == "dof":           # thin lens
         return _cornell().replace('Camera "perspective" "float fov" [39.3]', 'Camera "perspective" "float fov" [39.3] "float lensradius" [12] "float focaldistance" [1000]')
     if name == "crop":          # crop window + pixel bounds: partial tiles on every side, samples outside the bounds skipped
@@ -65,4 +73,4 @@ def scene(name):
     raise KeyError(name)
 
 
-NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "dof", "crop", "clamp", "empty", "onetri"]
+NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "dof", "crop", "clamp", "empty", "onetri"]
