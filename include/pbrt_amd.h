@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -103,13 +103,14 @@ enum mi_light_type {
     MI_LIGHT_POINT = 1,    /* PointLight   lights/point.cpp:44-53  */
     MI_LIGHT_DISTANT = 2,  /* DistantLight lights/distant.cpp:49-67 */
     MI_LIGHT_SPOT = 4,     /* SpotLight    lights/spot.cpp:54-72   */
+    MI_LIGHT_AREA_SPHERE = 5, /* DiffuseAreaLight on a Sphere (shapes/sphere.cpp:221-309): tri = primitive index, sphere = index into spheres[] */
     MI_LIGHT_INFINITE = 3  /* InfiniteAreaLight, constant L only (lights/infinite.cpp:92-132) */
 };
 typedef struct mi_light {
     int32_t type;
     int32_t tri;       /* AREA_TRI: triangle index in BVH primitive order */
-    int32_t two_sided; /* AREA_TRI: diffuse.h:56-58 */
-    int32_t pad;
+    int32_t two_sided; /* AREA_TRI / AREA_SPHERE: diffuse.h:56-58 */
+    int32_t sphere;    /* AREA_SPHERE: index into mi_scene_desc::spheres */
     float L[3];        /* Lemit | I | L */
     float area;        /* AREA_TRI: Triangle::Area() (triangle.cpp:575-581) */
     float pos[3];      /* POINT: pLight; DISTANT: wLight (normalised, world) */
@@ -127,6 +128,17 @@ typedef struct mi_light {
     float l2w[9];
     float pad4[2];
 } mi_light;
+
+/* Sphere (shapes/sphere.{h,cpp}), the one quadric this path carries (the reference's example scene lights itself with one).
+ * Primitive i (BVH order) is a sphere iff tri_indices[3*i] == MI_PRIM_SPHERE; tri_indices[3*i+1] is then the index here;
+ * material and area light come through tri_mesh[i] / tri_light[i] as for triangles. */
+#define MI_PRIM_SPHERE 0xFFFFFFFFu
+typedef struct mi_sphere {
+    float o2w[16], w2o[16];  /* ObjectToWorld / WorldToObject: Transform::m, row major (core/transform.h) */
+    float radius, zmin, zmax, theta_min, theta_max, phi_max;   /* as the constructor leaves them (sphere.h:50-58) */
+    uint32_t flags;          /* bit 0: reverseOrientation, bit 1: transformSwapsHandedness */
+    float area;              /* Sphere::Area() sphere.cpp:219 */
+} mi_sphere;
 
 /* Radiance map of an InfiniteAreaLight as its constructor leaves it (infinite.cpp:43-84): MIPMap level 0 (texels * L, resampled to
  * power-of-two sizes by MIPMap's constructor, mipmap.h:120-182) and the Distribution2D over the (2*width) x (2*height) image of
@@ -229,8 +241,9 @@ typedef struct mi_scene_desc {
     mi_film film;
     mi_integrator integrator;
     uint32_t n_envmaps;
-    uint32_t pad1;
+    uint32_t n_spheres;
     const mi_envmap *envmaps;
+    const mi_sphere *spheres;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_GRID_PER_CU
 #define PT_GRID_PER_CU 6   /* persistent blocks per CU (6 x 24 KiB LDS stacks fit the 160 KiB LDS) */
 #endif
-template <int MODE, bool COUNT>
+// SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
+template <int MODE, bool COUNT, bool SPHERES>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
                     ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
@@ -360,10 +361,13 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                             V3 p0, p1, p2;
                             uint32_t tf;
                             LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
-                            TriHit th;
-                            TriangleTest(p0, p1, p2, ts.o, ts.d, PT_INFINITY, &th);
                             Isect li;
-                            BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, ts.d, &li);
+                            if (SPHERES && (tf & TRI_FLAG_SPHERE)) li = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ts.o, ts.d, ts.prim);
+                            else {
+                                TriHit th;
+                                TriangleTest(p0, p1, p2, ts.o, ts.d, PT_INFINITY, &th);
+                                BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, ts.d, &li);
+                            }
                             Li = AreaL(light, li.n, -ts.d);   // lightIsect.Le(-wi)
                         }
                     } else if (light.type == MI_LIGHT_INFINITE)
@@ -473,7 +477,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_contrib(DevScene sc, float
         for (int k = 0; k < PT_SPATIAL_SAMPLES; ++k) {
             const float *h = &s_h[5 * k];
             intr.p = V3(LerpB(h[0], vmin.x, vmax.x), LerpB(h[1], vmin.y, vmax.y), LerpB(h[2], vmin.z, vmax.z));
-            LightSample ls = SampleLi(GeomTables(sc), &light, intr.p, intr.pError, intr.n, h[3], h[4]);
+            LightSample ls = SampleLiAny(GeomTables(sc), &light, intr.p, intr.pError, intr.n, h[3], h[4]);
             if (ls.pdf > 0) acc += ls.Li.y() / ls.pdf;
         }
         contrib[i] = acc;
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
 #endif
-// ENV: the scene has an infinite light with a radiance map (escaped rays look it up); scenes without one run the leaner instance
+// ENV ("rich" scenes): an infinite light with a radiance map (escaped rays look it up) or Sphere primitives; plain scenes run the leaner instance
 template <bool ENV, bool HALTON>
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
@@ -587,9 +591,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                 uint32_t tf;
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
                 Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d); Pin(tinfo);
-                TriHit th;
-                TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rd, hr.x);
+                if (ENV && (tf & TRI_FLAG_SPHERE)) isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, hr.x);
+                else {
+                    TriHit th;
+                    TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
+                    isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rd, hr.x);
+                }
             }
             PROBE(3)   // triangle reload + BuildIsect
             if (bounces == 0 || specularBounce) {
@@ -680,7 +687,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                             const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
                             PROBE(6)   // light pick
-                            LightSample ls = SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1);
+                            LightSample ls = ENV ? SampleLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
+                                                 : SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1);
                             PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
@@ -712,7 +720,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                                     Float weight = 1;
                                     bool ok = true;
                                     if (!sampledSpecular) {
-                                        lightPdf = PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi);
+                                        lightPdf = ENV ? PdfLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi) : PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi);
                                         if (lightPdf == 0) ok = false;
                                         else weight = PowerHeuristic(scatteringPdf, lightPdf);
                                     }
@@ -861,9 +869,12 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathS
                 uint32_t tf;
                 LoadTri(sc, prim, &p0, &p1, &p2, &tf);
                 TriHit th;
-                TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
                 Isect is;
-                BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
+                if (tf & TRI_FLAG_SPHERE) { is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim); th.t = t; th.b0 = th.b1 = th.b2 = 0; }
+                else {
+                    TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
+                    BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
+                }
                 h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
                 h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
             }
@@ -947,7 +958,7 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
-    bool hasEnvMap = false;
+    bool hasEnvMap = false, hasSpheres = false;
     DevScene sc;
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
@@ -1093,7 +1104,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(32 + 6 * (size_t)d->n_envmaps);
+    c->sceneBufs.resize(34 + 6 * (size_t)d->n_envmaps);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1114,9 +1125,22 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.n_nodes = (uint32_t)bb.out.size();
     sc.stack_need = 3 * (bb.maxDepth + 1) + 1;
     // triangle records
+    c->hasSpheres = false;
     std::vector<float4> tv(3 * (size_t)d->n_tris);
     for (uint32_t t = 0; t < d->n_tris; ++t) {
         const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        if (v[0] == MI_PRIM_SPHERE) {   // a Sphere primitive: the record carries its index and the flag
+            if (v[1] >= d->n_spheres || !d->spheres) return fail("mi_scene_upload: primitive refers to a missing sphere");
+            uint32_t fl = TRI_FLAG_SPHERE;
+            float flf, idf;
+            std::memcpy(&flf, &fl, 4); std::memcpy(&idf, &v[1], 4);
+            tv[3 * (size_t)t] = make_float4(idf, 0, 0, flf);
+            tv[3 * (size_t)t + 1] = make_float4(0, 0, 0, 0);
+            tv[3 * (size_t)t + 2] = make_float4(0, 0, 0, 0);
+            c->hasSpheres = true;
+            continue;
+        }
+        if (v[0] >= d->n_verts || v[1] >= d->n_verts || v[2] >= d->n_verts) return fail("mi_scene_upload: vertex index out of range");
         const float *p0 = d->P + 3 * (size_t)v[0], *p1 = d->P + 3 * (size_t)v[1], *p2 = d->P + 3 * (size_t)v[2];
         // per-triangle rejection of shapes/triangle.cpp:300-315, evaluated with the reference's arithmetic
         uint32_t mflags = d->meshes[d->tri_mesh[t]].flags;
@@ -1162,6 +1186,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             const mi_mesh &m = d->meshes[d->tri_mesh[t]];
             TriShade &r = tsd[t];
             std::memset(&r, 0, sizeof(r));
+            if (v[0] == MI_PRIM_SPHERE) continue;
             if (d->N && (m.flags & MI_MESH_HAS_N))
                 for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) r.n[3 * k + a] = d->N[3 * (size_t)v[k] + a];
             if (d->UV && (m.flags & MI_MESH_HAS_UV)) {
@@ -1188,6 +1213,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         sc.tri_info = b.as<uint4>();
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
+    if (d->n_spheres) { DevBuf &b = next(); if (upload(c, b, d->spheres, (size_t)d->n_spheres * sizeof(mi_sphere))) return -1; sc.spheres = b.as<mi_sphere>(); }
     {   // radiance maps of infinite lights
         std::vector<DevEnvMap> em(d->n_envmaps);
         for (uint32_t i = 0; i < d->n_envmaps; ++i) {
@@ -1222,11 +1248,15 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             dl[i].area = ml.area; dl[i].world_radius = ml.world_radius;
             if (ml.type == MI_LIGHT_INFINITE && ml.env_map) {
                 if ((uint32_t)ml.env_map > d->n_envmaps) return fail("mi_scene_upload: light refers to a missing environment map");
-                dl[i].env = envDev + (ml.env_map - 1);
+                dl[i].ext = envDev + (ml.env_map - 1);
                 for (int k = 0; k < 3; ++k) {
                     dl[i].p0[k] = ml.frame[k]; dl[i].p1[k] = ml.frame[3 + k]; dl[i].p2[k] = ml.frame[6 + k];
                     dl[i].l2w0[k] = ml.l2w[k]; dl[i].l2w1[k] = ml.l2w[3 + k]; dl[i].l2w2[k] = ml.l2w[6 + k];
                 }
+            }
+            if (ml.type == MI_LIGHT_AREA_SPHERE) {
+                if (ml.sphere < 0 || (uint32_t)ml.sphere >= d->n_spheres) return fail("mi_scene_upload: light refers to a missing sphere");
+                dl[i].ext = sc.spheres + ml.sphere;
             }
             if (ml.type == MI_LIGHT_SPOT) {
                 dl[i].cos_total = ml.cos_total_width; dl[i].cos_falloff = ml.cos_falloff_start;
@@ -1478,6 +1508,16 @@ static void harvest(mi_ctx *c) {
     c->evUsed = 0;
 }
 
+#define LAUNCH_TRACE(MODE)                                                                                          \
+    do {                                                                                                            \
+        if (c->hasSpheres) {                                                                                        \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true>), grid, block, 0, st, sc, ps, qin);        \
+            else hipLaunchKernelGGL((k_trace<MODE, false, true>), grid, block, 0, st, sc, ps, qin);                 \
+        } else {                                                                                                    \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false>), grid, block, 0, st, sc, ps, qin);       \
+            else hipLaunchKernelGGL((k_trace<MODE, false, false>), grid, block, 0, st, sc, ps, qin);                \
+        }                                                                                                           \
+    } while (0)
 // One pass of the wavefront pipeline over the paths generated by `pass`.
 static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm) {
     PathState &ps = c->ps;
@@ -1496,8 +1536,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         HIP_TRY(hipMemsetAsync(ps.qcount + QC_SHADOW, 0, 2 * sizeof(uint32_t), st));   // shadow + mis
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_CLOSEST);
-        if (countWork) hipLaunchKernelGGL((k_trace<0, true>), grid, block, 0, st, sc, ps, qin);
-        else hipLaunchKernelGGL((k_trace<0, false>), grid, block, 0, st, sc, ps, qin);
+        LAUNCH_TRACE(0);
         toc(c);
         tic(c, MI_K_SORT);
         hipLaunchKernelGGL(k_keycount, grid, block, c->nkeys * sizeof(uint32_t), st, sc, ps, qin, c->nkeys);
@@ -1507,7 +1546,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
-            if (c->hasEnvMap) {
+            if (c->hasEnvMap || c->hasSpheres) {
                 if (halton) hipLaunchKernelGGL((k_shade<true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             } else {
@@ -1518,13 +1557,11 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
-        if (countWork) hipLaunchKernelGGL((k_trace<2, true>), grid, block, 0, st, sc, ps, qin);
-        else hipLaunchKernelGGL((k_trace<2, false>), grid, block, 0, st, sc, ps, qin);
+        LAUNCH_TRACE(2);
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
         tic(c, MI_K_MIS_CLOSEST);
-        if (countWork) hipLaunchKernelGGL((k_trace<1, true>), grid, block, 0, st, sc, ps, qin);
-        else hipLaunchKernelGGL((k_trace<1, false>), grid, block, 0, st, sc, ps, qin);
+        LAUNCH_TRACE(1);
         toc(c);
         qin = qout;
         ++iter;

@@ -2,6 +2,7 @@
 #pragma once
 #include "pbrt_amd.h"
 #include "pt_math.h"
+#include "pt_sphere.h"
 
 // ------------------------------------------------------------------ HBM layout
 // BVH4 node: exactly one 128-byte cache line, fetched by a lane as 8 x global_load_dwordx4.
@@ -24,13 +25,15 @@ struct __attribute__((aligned(128))) BVH4Node {
 // v0.w carries flag bits (as uint): bit0 = "always rejected": the triangle is degenerate in the sense of
 // shapes/triangle.cpp:308-315 (decided per triangle, independent of the ray).
 #define TRI_FLAG_REJECT 1u
+// the primitive is a Sphere (shapes/sphere.cpp): record.v0.x holds the index into DevScene::spheres
+#define TRI_FLAG_SPHERE 2u
 
 struct DevEnvMap;
 struct DevLight {   // 10 x 16 bytes; the first 7, fetched with independent 16-byte loads (LoadLight)
     int32_t type, tri, two_sided; uint32_t mesh_flags;   // mesh flags of the emissive triangle (bit 31: TRI_FLAG_REJECT)
     float L[3], area;
     float pos[3], world_radius;
-    float cos_total, cos_falloff; const struct DevEnvMap *env;   // spot cone; infinite: its radiance map (null: constant L)
+    float cos_total, cos_falloff; const void *ext;   // spot cone; infinite: its radiance map (DevEnvMap*, null: constant L); sphere light: its mi_sphere*
     float p0[3], padA;                                   // area light: triangle vertices; spot: rows of WorldToLight
     float p1[3], padB;
     float p2[3], padC;
@@ -61,6 +64,7 @@ struct DevScene {
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const mi_material *materials;
     const DevEnvMap *envmaps;
+    const mi_sphere *spheres;
     const DevLight *lights;         // mi_light + (area lights) the triangle's vertices and mesh flags: no extra hops while sampling
     const float *light_func, *light_cdf;
     const float *filter_table;
@@ -486,7 +490,7 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
 // one leaf step = ONE triangle of the leaf (in primitive order; ties at equal t: the later one wins, as in the
 // reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261).  A lane stays at the leaf until its triangles are
 // used up, so a leaf phase of the wave costs one watertight test whatever the leaf sizes of its lanes are.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool SPHERES = false>
 PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
     uint32_t first = ts.cur & BVH4_FIRST_MASK, left = (ts.cur >> 27) & 0xfu;   // left = triangles after this one
     V3 p0, p1, p2;
@@ -494,7 +498,14 @@ PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     LoadTri(sc, first, &p0, &p1, &p2, &flags);
     if (COUNT) ++cnt->tris;
     TriHit th;
-    if (!(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th)) {
+    bool hitPrim;
+    if (SPHERES && (flags & TRI_FLAG_SPHERE)) {   // Sphere::Intersect / IntersectP (scenes with spheres only: separate kernel instance)
+        th.t = SphereIntersectT(sc.spheres + __float_as_uint(p0.x), ts.o, ts.d, ts.tMax);
+        th.b0 = th.b1 = th.b2 = 0;
+        hitPrim = th.t >= 0;
+    } else
+        hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
+    if (hitPrim) {
         ts.prim = first;
         ts.tHit = th.t;
         if (ANY) { ts.cur = TRAV_DONE; return; }
@@ -512,7 +523,7 @@ PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, T
     ts.init(sc, o, d, tMax, st);
     while (!ts.done()) {
         if (ts.atNode()) TravNodeStep<COUNT>(sc, ts, st, cnt);
-        else TravLeafStep<ANY, COUNT>(sc, ts, st, cnt);
+        else TravLeafStep<ANY, COUNT, true>(sc, ts, st, cnt);
     }
     *tHit = ts.tHit; *primHit = ts.prim;
     return ts.prim != TRAV_MISS;

@@ -111,6 +111,15 @@ PT_DEV void BuildIsect(const GeomTables sc, uint32_t prim, const V3 p0, const V3
     *is = MakeIsect(BuildIsectPre(mflags, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rayD, prim);
 }
 
+// interaction of a ray with a sphere primitive it is known to hit (the traversal accepted it)
+PT_DEV Isect SphereIsectToIsect(const mi_sphere *sp, const V3 &ro, const V3 &rd, uint32_t prim) {
+    SphereIsectOut o;
+    SphereIsect(sp, ro, rd, PT_INFINITY, &o);
+    Isect is;
+    is.p = o.p; is.pError = o.pError; is.n = o.n; is.ns = o.ns; is.dpdus = o.dpdus; is.wo = o.wo; is.prim = prim;
+    return is;
+}
+
 // ------------------------------------------------------------------ BxDFs (core/reflection.{h,cpp})
 #define BSDF_REFLECTION 1
 #define BSDF_TRANSMISSION 2
@@ -616,9 +625,9 @@ PT_DEV Float SphericalPhi(const V3 &v) { Float p = atan2f_(v.y, v.x); return (p 
 #define PT_INV_2PI 0.15915494309189533577f
 // InfiniteAreaLight::Le (infinite.cpp:92-96)
 __device__ __noinline__ RGB InfiniteLe(const DevLight *dl, const V3 rayD) {
-    if (!dl->env) return rgb3(dl->L);
+    if (!dl->ext) return rgb3(dl->L);
     V3 w = Normalize(Mul3(v3(dl->p0), v3(dl->p1), v3(dl->p2), rayD));
-    return EnvLookup(*dl->env, SphericalPhi(w) * PT_INV_2PI, SphericalTheta(w) * PT_INV_PI);
+    return EnvLookup(*(const DevEnvMap *)dl->ext, SphericalPhi(w) * PT_INV_2PI, SphericalTheta(w) * PT_INV_PI);
 }
 // Distribution1D::SampleContinuous core/sampling.h:72-89
 PT_DEV Float SampleContinuous1D(const float *func, const float *cdf, Float funcInt, int n, Float u, Float *pdf, int *off) {
@@ -650,7 +659,7 @@ struct LightRegs {
     RGB L; Float area;
     V3 pos; Float world_radius;
     Float cos_total, cos_falloff;
-    const DevEnvMap *env;
+    const void *ext;   // DevEnvMap* (infinite light) or mi_sphere* (sphere light)
     V3 p0, p1, p2; uint32_t mesh_flags;
 };
 PT_DEV LightRegs LoadLight(const DevLight *dl) {
@@ -662,7 +671,7 @@ PT_DEV LightRegs LoadLight(const DevLight *dl) {
     r.mesh_flags = __float_as_uint(a.w);
     r.L = RGB(b.x, b.y, b.z); r.area = b.w;
     r.pos = V3(c.x, c.y, c.z); r.world_radius = c.w;
-    r.cos_total = d.x; r.cos_falloff = d.y; r.env = (const DevEnvMap *)(((unsigned long long)__float_as_uint(d.w) << 32) | (unsigned long long)__float_as_uint(d.z));
+    r.cos_total = d.x; r.cos_falloff = d.y; r.ext = (const void *)(((unsigned long long)__float_as_uint(d.w) << 32) | (unsigned long long)__float_as_uint(d.z));
     r.p0 = V3(e.x, e.y, e.z); r.p1 = V3(f.x, f.y, f.z); r.p2 = V3(g.x, g.y, g.z);
     return r;
 }
@@ -747,9 +756,10 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
     }
     {   // InfiniteAreaLight::Sample_Li lights/infinite.cpp:98-126; without a map the constructor's distribution is uniform (uv = u, mapPdf = 1)
         Float uv0 = u0, uv1 = u1, mapPdf = 1;
-        const bool hasMap = l.env != nullptr;
+        const DevEnvMap *lenv = (const DevEnvMap *)l.ext;
+        const bool hasMap = lenv != nullptr;
         if (hasMap) {
-            V3 smp = SampleEnvMap(l.env, u0, u1);
+            V3 smp = SampleEnvMap(lenv, u0, u1);
             uv0 = smp.x; uv1 = smp.y; mapPdf = smp.z;
             if (mapPdf == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return lsv; }
         }
@@ -762,7 +772,7 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
         if (sinTheta == 0) ls->pdf = 0;
         V3 pOutside = ref.p + ls->wi * (2 * l.world_radius);
         ls->shadow = SpawnRayTo(ref, pOutside, V3(), V3());
-        ls->Li = hasMap ? EnvLookup(*l.env, uv0, uv1) : l.L;
+        ls->Li = hasMap ? EnvLookup(*lenv, uv0, uv1) : l.L;
     }
     return lsv;
 }
@@ -782,13 +792,13 @@ PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const 
         return pdf;
     }
     if (l.type == MI_LIGHT_INFINITE) {   // lights/infinite.cpp:128-137
-        V3 wl = l.env ? Mul3(l.p0, l.p1, l.p2, wi) : wi;
+        V3 wl = l.ext ? Mul3(l.p0, l.p1, l.p2, wi) : wi;
         Float theta = SphericalTheta(wl), phi = SphericalPhi(wl);
         Float sinTheta = sinf_(theta);
         if (sinTheta == 0) return 0;
         Float mapPdf = 1;
-        if (l.env) {   // Distribution2D::Pdf core/sampling.h:135-141
-            const DevEnvMap &env = *l.env;
+        if (l.ext) {   // Distribution2D::Pdf core/sampling.h:135-141
+            const DevEnvMap &env = *(const DevEnvMap *)l.ext;
             int nu = 2 * env.width, nv = 2 * env.height;
             int iu = (int)(phi * PT_INV_2PI * nu), iv = (int)(theta * PT_INV_PI * nv);
             iu = iu < 0 ? 0 : (iu > nu - 1 ? nu - 1 : iu); iv = iv < 0 ? 0 : (iv > nv - 1 ? nv - 1 : iv);
@@ -797,4 +807,30 @@ PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const 
         return mapPdf / (2 * PT_PI * PT_PI * sinTheta);
     }
     return 0;
+}
+
+// DiffuseAreaLight on a Sphere: Sample_Li (lights/diffuse.cpp:68-81 over Sphere::Sample(ref, u)) and Pdf_Li.  Separate
+// out-of-line routines, dispatched on the light type by the caller, so that SampleLi / PdfLi keep their register budget.
+PT_FN LightSample SampleLiSphere(const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1) {
+    LightSample lsv;
+    LightSample *ls = &lsv;
+    Isect ref;
+    ref.p = refP; ref.pError = refPError; ref.n = refN;
+    ls->delta = false; ls->pdf = 0; ls->Li = RGB(0.f);
+    SphereSample ss;
+    SphereSampleRef((const mi_sphere *)dl->ext, refP, refPError, refN, u0, u1, &ss);
+    if (ss.pdf == 0 || (ss.p - refP).LengthSquared() == 0) return lsv;
+    ls->wi = Normalize(ss.p - refP);
+    ls->pdf = ss.pdf;
+    ls->shadow = SpawnRayTo(ref, ss.p, ss.pError, ss.n);
+    ls->Li = AreaL(*dl, ss.n, -ls->wi);
+    return lsv;
+}
+PT_DEV LightSample SampleLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, Float u0, Float u1) {
+    if (dl->type == MI_LIGHT_AREA_SPHERE) return SampleLiSphere(dl, refP, refPError, refN, u0, u1);
+    return SampleLi(sc, dl, refP, refPError, refN, u0, u1);
+}
+PT_DEV Float PdfLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, const V3 &wi) {
+    if (dl->type == MI_LIGHT_AREA_SPHERE) return SpherePdf((const mi_sphere *)dl->ext, refP, refPError, refN, wi);
+    return PdfLi(sc, dl, refP, refPError, refN, wi);
 }

@@ -367,8 +367,15 @@ void pbrtShape(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("Shape");
     if (curTransform.IsAnimated())
         Warning("Animated shapes (TransformedPrimitive, primitive.cpp:76-96) are outside this path's scope; using the start transform");
-    std::shared_ptr<TriangleMesh> shape = MakeShapes(name, curTransform[0], graphicsState.reverseOrientation, params);
-    if (!shape || shape->nTriangles() == 0) return;
+    std::shared_ptr<TriangleMesh> shape;
+    std::shared_ptr<SphereShape> sphere;
+    if (name == "sphere") {
+        sphere = CreateSphereShape(curTransform[0], graphicsState.reverseOrientation, params);
+        shape = std::make_shared<TriangleMesh>();   // empty: the primitive is the sphere
+    } else {
+        shape = MakeShapes(name, curTransform[0], graphicsState.reverseOrientation, params);
+        if (!shape || shape->nTriangles() == 0) return;
+    }
     // GraphicsState::GetMaterialForShape (api.cpp:1771-1800): shape parameters may override material ones
     std::shared_ptr<Material> mtl;
     {
@@ -393,6 +400,7 @@ void pbrtShape(const std::string &name, const ParamSet &params) {
     params.ReportUnused();
     GeometricPrimitive gp;
     gp.shape = shape;
+    gp.sphere = sphere;
     gp.material = mtl;
     if (graphicsState.areaLight != "") {   // MakeAreaLight api.cpp:759-772, CreateDiffuseAreaLight diffuse.cpp:135-146
         if (graphicsState.areaLight == "area" || graphicsState.areaLight == "diffuse") {
@@ -447,6 +455,13 @@ void pbrtObjectInstance(const std::string &name) {
         for (auto &s : mesh->s) s = i2w.Vector(s);
         if (i2w.SwapsHandedness()) mesh->transformSwapsHandedness = !mesh->transformSwapsHandedness;
         gp.shape = mesh;
+        if (src.sphere) {   // the instance transform goes on top of the sphere's own
+            auto sp = std::make_shared<SphereShape>(*src.sphere);
+            sp->o2w = i2w * src.sphere->o2w;
+            sp->w2o = Transform(sp->o2w.mInv, sp->o2w.m);
+            sp->transformSwapsHandedness = sp->o2w.SwapsHandedness();
+            gp.sphere = sp;
+        }
         renderOptions->primitives.push_back(gp);
     }
 }

@@ -52,7 +52,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     bool anyN = false, anyUV = false;
     for (size_t i = 0; i < prims.size(); ++i) {
         vertexOffset[i] = (uint32_t)nv; triOffset[i] = (uint32_t)nt;
-        nv += prims[i].shape->p.size(); nt += prims[i].shape->nTriangles();
+        nv += prims[i].shape->p.size(); nt += prims[i].shape->nTriangles() + (prims[i].sphere ? 1 : 0);
         anyN |= !prims[i].shape->n.empty(); anyUV |= !prims[i].shape->uv.empty();
     }
     fs->P.resize(3 * nv);
@@ -92,6 +92,17 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     for (size_t k = 0; k < nTris; ++k) {
         const BVHAccel::PrimRef &r = bvh.primitives[k];
         const TriangleMesh &mesh = *prims[r.prim].shape;
+        if (prims[r.prim].sphere) {   // MI_PRIM_SPHERE, index into spheres[]
+            const SphereShape &sp = *prims[r.prim].sphere;
+            mi_sphere ms;
+            std::memset(&ms, 0, sizeof(ms));
+            copyMatrix(ms.o2w, sp.o2w.m); copyMatrix(ms.w2o, sp.w2o.m);
+            ms.radius = sp.radius; ms.zmin = sp.zMin; ms.zmax = sp.zMax; ms.theta_min = sp.thetaMin; ms.theta_max = sp.thetaMax; ms.phi_max = sp.phiMax;
+            ms.flags = (sp.reverseOrientation ? 1u : 0u) | (sp.transformSwapsHandedness ? 2u : 0u);
+            ms.area = sp.Area();
+            fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
+            fs->spheres.push_back(ms);
+        } else
         for (int c = 0; c < 3; ++c) fs->triIndices[3 * k + c] = vertexOffset[r.prim] + (uint32_t)mesh.indices[3 * r.tri + c];
         fs->triMesh[k] = r.prim;
         orderOf[triOffset[r.prim] + r.tri] = (uint32_t)k;
@@ -133,6 +144,20 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         } else {
             const GeometricPrimitive &gp = prims[e.prim];
             const TriangleMesh &mesh = *gp.shape;
+            if (gp.sphere) {   // DiffuseAreaLight on the sphere (api.cpp:1357-1366, one light per Shape)
+                mi_light l;
+                std::memset(&l, 0, sizeof(l));
+                l.type = MI_LIGHT_AREA_SPHERE;
+                l.tri = (int32_t)orderOf[triOffset[e.prim]];
+                l.sphere = (int32_t)fs->triIndices[3 * (size_t)l.tri + 1];
+                l.two_sided = gp.areaLight->twoSided;
+                for (int i = 0; i < 3; ++i) l.L[i] = gp.areaLight->Lemit.c[i];
+                l.area = gp.sphere->Area();
+                fs->triLight[l.tri] = (int32_t)fs->lights.size();
+                RGB pw = gp.areaLight->Lemit * (Float)(l.two_sided ? 2 : 1) * l.area * kPi;   // diffuse.cpp:64-66
+                power.push_back(pw.y());
+                fs->lights.push_back(l);
+            }
             for (int t = 0; t < mesh.nTriangles(); ++t) {
                 mi_light l;
                 std::memset(&l, 0, sizeof(l));
@@ -183,6 +208,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
     d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
+    d.n_spheres = (uint32_t)fs->spheres.size(); d.spheres = fs->spheres.empty() ? nullptr : fs->spheres.data();
     d.n_envmaps = (uint32_t)fs->envmaps.size(); d.envmaps = fs->envmaps.empty() ? nullptr : fs->envmaps.data();
     d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
     d.integrator.spatial_max_voxels = 64;

@@ -63,8 +63,19 @@ struct LightEntry { std::shared_ptr<Light> light; int prim; };
 std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, const Transform &light2world);
 
 // ---- Primitive (core/primitive.h:51-64,119-127)
-struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here
+// Sphere (shapes/sphere.h:46-77): the one quadric carried by this path; constructor results only
+struct SphereShape {
+    Transform o2w, w2o;
+    bool reverseOrientation = false, transformSwapsHandedness = false;
+    Float radius = 1, zMin = -1, zMax = 1, thetaMin = 0, thetaMax = 0, phiMax = 0;
+    Float Area() const { return phiMax * radius * (zMax - zMin); }   // sphere.cpp:219
+    Bounds3 WorldBound() const;                                        // ObjectToWorld(ObjectBound()) shape.cpp:52
+};
+std::shared_ptr<SphereShape> CreateSphereShape(const Transform &o2w, bool reverseOrientation, const ParamSet &ps);
+
+struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here, or one Sphere (then `shape` is an empty mesh)
     std::shared_ptr<TriangleMesh> shape;
+    std::shared_ptr<SphereShape> sphere;
     std::shared_ptr<Material> material;
     std::shared_ptr<AreaLightSpec> areaLight;
 };
@@ -177,6 +188,7 @@ struct FlatScene {
     std::vector<mi_material> materials;
     std::vector<mi_light> lights;
     std::vector<mi_envmap> envmaps;
+    std::vector<mi_sphere> spheres;
     std::vector<std::shared_ptr<EnvMap>> envKeep;
 };
 

@@ -206,6 +206,37 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
 
 std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &, bool, const ParamSet &);   // loopsubdiv.cpp
 
+// CreateSphereShape shapes/sphere.cpp:319-328 + the Sphere constructor (sphere.h:50-58)
+std::shared_ptr<SphereShape> CreateSphereShape(const Transform &o2w, bool ro, const ParamSet &ps) {
+    auto sp = std::make_shared<SphereShape>();
+    Float radius = ps.FindOneFloat("radius", 1.f);
+    Float zmin = ps.FindOneFloat("zmin", -radius);
+    Float zmax = ps.FindOneFloat("zmax", radius);
+    Float phimax = ps.FindOneFloat("phimax", 360.f);
+    sp->o2w = o2w;
+    sp->w2o = Transform(o2w.mInv, o2w.m);
+    sp->reverseOrientation = ro;
+    sp->transformSwapsHandedness = o2w.SwapsHandedness();
+    sp->radius = radius;
+    sp->zMin = Clamp(std::min(zmin, zmax), -radius, radius);
+    sp->zMax = Clamp(std::max(zmin, zmax), -radius, radius);
+    sp->thetaMin = std::acos(Clamp(std::min(zmin, zmax) / radius, -1, 1));
+    sp->thetaMax = std::acos(Clamp(std::max(zmin, zmax) / radius, -1, 1));
+    sp->phiMax = Radians(Clamp(phimax, 0, 360));
+    return sp;
+}
+Bounds3 SphereShape::WorldBound() const {   // Transform::operator()(Bounds3f) transform.cpp:240-249 of ObjectBound() sphere.cpp:43-46
+    Vec3 lo(-radius, -radius, zMin), hi(radius, radius, zMax);
+    Bounds3 ret;
+    bool first = true;
+    for (int k = 0; k < 8; ++k) {
+        Vec3 c((k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z);
+        Vec3 w = o2w.Point(c);
+        if (first) { ret = Bounds3(w, w); first = false; } else ret = Union(ret, w);
+    }
+    return ret;
+}
+
 std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps) {
     if (name == "trianglemesh") return CreateTriangleMeshShape(o2w, ro, ps);
     if (name == "plymesh") return CreatePLYMesh(o2w, ro, ps);

@@ -53,6 +53,15 @@ def scene(name):
                        for x, z, a, sc in [(-1.5, 1, 20, 1), (0.2, 2, 75, .7), (1.6, .5, -40, 1.2), (-.4, -.5, 10, .5)])
         return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
                         'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
+    if name == "spheres":       # Sphere primitives: glass sphere, clipped + transformed sphere, sphere area lights (one reversed, two-sided, clipped)
+        sph = ('AttributeBegin\nTranslate -1.2 .7 .3\nMaterial "glass" "float index" [1.5]\nShape "sphere" "float radius" [.7]\nAttributeEnd\n'
+               'AttributeBegin\nTranslate 1.2 .6 .8\nRotate 35 1 0 0\nScale 1 1.4 .8\n'
+               'Material "plastic" "rgb Kd" [.7 .3 .2] "rgb Ks" [.3 .3 .3] "float roughness" [.1]\n'
+               'Shape "sphere" "float radius" [.6] "float zmin" [-.3] "float zmax" [.45] "float phimax" [250]\nAttributeEnd\n'
+               'AttributeBegin\nTranslate 0 2.6 -.5\nAreaLightSource "diffuse" "rgb L" [30 28 25]\nShape "sphere" "float radius" [.25]\nAttributeEnd\n'
+               'AttributeBegin\nTranslate .2 .35 -1.2\nReverseOrientation\nAreaLightSource "diffuse" "rgb L" [3 5 8] "bool twosided" "true"\n'
+               'Shape "sphere" "float radius" [.35] "float zmax" [.2]\nAttributeEnd\n')
+        return _OPEN % sph
     if name == "dof":           # thin lens
         return _cornell().replace('Camera "perspective" "float fov" [39.3]', 'Camera "perspective" "float fov" [39.3] "float lensradius" [12] "float focaldistance" [1000]')
     if name == "crop":          # crop window + pixel bounds: partial tiles on every side, samples outside the bounds skipped
@@ -73,4 +82,4 @@ def scene(name):
     raise KeyError(name)
 
 
-NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "dof", "crop", "clamp", "empty", "onetri"]
+NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "spheres", "dof", "crop", "clamp", "empty", "onetri"]
