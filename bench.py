@@ -117,7 +117,7 @@ def main():
             os.rename(scene_file + ".tmp", scene_file)
         while not os.path.exists(scene_file):
             time.sleep(0.2)
-        workload = "killeroo-simple (sphere light as icosphere mesh, sobol): 67.8 k triangles, %dx%d, %d spp, path maxdepth 5" % (args.res[0], args.res[1], spp)
+        workload = "killeroo-simple.pbrt as the reference ships it (Sphere area light, Halton sampler; geometry pre-subdivided to PLY): 66.5 k triangles, %dx%d, %d spp, path maxdepth 5" % (args.res[0], args.res[1], spp)
     elif args.config == "c4":
         spp = args.spp if args.spp != 64 else 256
         tris = args.tris if args.tris != 10_000_000 else 600_000

@@ -309,3 +309,18 @@ def test_cli_render_matches_reference_fixture(tmp_path):
     out2 = tmp_path / "crop.exr"
     r = subprocess.run([exe, "--quiet", "--cropwindow", "0.25", "0.75", "0.5", "1", "--outfile", str(out2), str(f)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and out2.exists() and open(out2, "rb").read(4) == bytes([0x76, 0x2F, 0x31, 0x01]), r.stderr
+
+
+def test_killeroo_simple_vs_the_reference_scene():
+    """The reference's example scene as shipped (Sphere area light, Halton, Loop subdivision) -- GPU render of scenes/killeroo.pbrt vs the
+    reference's render of its own scenes/killeroo-simple.pbrt."""
+    text = open(os.path.join(ROOT, "scenes", "killeroo.pbrt")).read()
+    text = text.replace('[700] "integer yresolution" [700]', '[96] "integer yresolution" [96]').replace("killeroo_geo/", os.path.join(ROOT, "scenes", "killeroo_geo") + "/")
+    sc = pa.Scene(text=text)
+    ctx = pa.Context(sc)
+    ctx.render()
+    img = sc.film_image(ctx.film())
+    ref = pa.read_pfm(os.path.join(G, "killeroo_simple_96x96_reference.pfm"))
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
+    ctx.close()

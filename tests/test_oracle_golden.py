@@ -166,3 +166,18 @@ def test_oracle_edge_cases_match_reference(built, name):
     ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     assert img.shape == ref.shape
     assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())
+
+
+def _killeroo_96():
+    text = open(os.path.join(ol.ROOT, "scenes", "killeroo.pbrt")).read()
+    text = text.replace('[700] "integer yresolution" [700]', '[96] "integer yresolution" [96]')
+    return text.replace("killeroo_geo/", os.path.join(ol.ROOT, "scenes", "killeroo_geo") + "/")
+
+
+def test_oracle_killeroo_simple_matches_the_reference_scene(built):
+    """scenes/killeroo.pbrt (PLY geometry subdivided by this host) against the reference's UNMODIFIED killeroo-simple.pbrt rendered by the
+    reference: Sphere area light, Halton sampler, Loop subdivision, plastic + matte."""
+    sc = pa.Scene(text=_killeroo_96())
+    img = sc.film_image(ol.render(sc, nthreads=4)[0])
+    ref = pa.read_pfm(os.path.join(G, "killeroo_simple_96x96_reference.pfm"))
+    assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())

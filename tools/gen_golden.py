@@ -45,6 +45,16 @@ def main():
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])   # one thread: the tile merge order (wide filters) is then fixed
         print("rendered", out)
     edge_fixtures(tmp)
+    # the reference's own example scene, UNMODIFIED except for resolution and output name (scenes/killeroo-simple.pbrt: Sphere area
+    # light, Halton sampler, loopsubdiv geometry) -- the tests render this repository's scenes/killeroo.pbrt against it
+    text = open("/root/reference/scenes/killeroo-simple.pbrt").read()
+    text = text.replace('"integer xresolution" [700] "integer yresolution" [700]', '"integer xresolution" [96] "integer yresolution" [96]')
+    text = text.replace('"string filename" "killeroo-simple.exr"', '"string filename" "k.pfm"').replace("geometry/killeroo.pbrt", "/root/reference/scenes/geometry/killeroo.pbrt")
+    assert "[96]" in text
+    f = os.path.join(tmp, "ks.pbrt"); open(f, "w").write(text)
+    out = os.path.join(OUT, "killeroo_simple_96x96_reference.pfm")
+    subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
+    print("rendered", out)
 
 
 FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]'}
