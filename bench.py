@@ -232,7 +232,7 @@ def main():
                 traffic = json.load(open(tfile)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_trace<0,false> (BVH4 closest hit, path-extension rays)", "bound": "hbm",
+        roofline = {"kernel": "k_trace<0,false,false> (BVH4 closest hit, path-extension rays; all-triangle instance)", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
                     "avg_launch_ms": t_closest_ms / max(1.0, launches_per_step), "launches_per_step": launches_per_step,

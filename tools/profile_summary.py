@@ -4,7 +4,7 @@
   python tools/profile_summary.py stats <dir> <out.csv>        copy the --kernel-trace --stats kernel table
   python tools/profile_summary.py pmc <dir> <out.json> [--traffic profiles/traffic_closest.json]
         per-kernel sums of every counter of a --pmc run; with --traffic also writes the HBM bytes per launch of the
-        dominant kernel (k_trace<0,false>) from FETCH_SIZE: KB * 1024 * 2 (the gfx950 factor of
+        dominant kernel (k_trace<0,false,false>) from FETCH_SIZE: KB * 1024 * 2 (the gfx950 factor of
         guides/MI355X_MICROARCH.md, "HBM": FETCH_SIZE tallies 128-byte requests at 64 bytes)
 """
 import csv, glob, json, os, shutil, sys, collections
@@ -31,7 +31,7 @@ def main():
     print("wrote", out)
     if "--traffic" in sys.argv:
         tout = sys.argv[sys.argv.index("--traffic") + 1]
-        key = [k for k in res if k.startswith("void k_trace<0, false>")]
+        key = [k for k in res if k.startswith("void k_trace<0, false, false>") or k.startswith("void k_trace<0, false>")]
         if key and "FETCH_SIZE" in res[key[0]]:
             kb = res[key[0]]["FETCH_SIZE"] / res[key[0]]["launches"]
             json.dump({"kernel": key[0], "launches": res[key[0]]["launches"], "FETCH_SIZE_KB_per_launch": kb,
