@@ -329,6 +329,10 @@ int mi_intersect(mi_ctx *ctx, const mi_ray *rays, int64_t n, mi_hit *hits);
 int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits);
 /* BVHAccel::IntersectP (bvh.cpp:702-738) */
 int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded);
+/* Sphere::Intersect (shapes/sphere.cpp:48-162) of ray i against spheres[i] (explicit records, no scene): hit flag, tHit and the
+ * world-space interaction's p, pError, n -- for the FullSphere / PartialSphere reintersection vectors of the reference's tests */
+typedef struct mi_sphere_hit { int32_t hit; float t; float p[3], p_error[3], n[3]; } mi_sphere_hit;
+int mi_sphere_intersect(int device_ordinal, const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits);
 /* SobolSampler: GetIndexForSample + SampleDimension (sobol.cpp:42-59) for pixel (px,py),
  * sample numbers [0,n_samples), dimensions [0,n_dims); out[s*n_dims+d]; index_out[s] */
 int mi_sobol(mi_ctx *ctx, int px, int py, int n_samples, int n_dims, float *out, uint64_t *index_out);

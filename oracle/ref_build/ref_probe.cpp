@@ -17,6 +17,7 @@
 #include "sampling.h"
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
+#include "shapes/sphere.h"
 #include "shapes/triangle.h"
 #include "sobolmatrices.h"
 
@@ -165,6 +166,72 @@ int main(int argc, char **argv) {
         }
         fclose(f);
         fprintf(stderr, "ref_probe: %d triangle records\n", count);
+    }
+    // ---- Sphere::Intersect on the FullSphere / PartialSphere constructions of tests/shapes.cpp:376-497 (+ a transformed half):
+    // the first ray toward the bounding box, then rays spawned from the hit (expected: no re-intersection)
+    {
+        FILE *f = fopen((dir + "/spheres.bin").c_str(), "wb");
+        int32_t count = 0;
+        auto rec = [&](const Transform &o2w, const Transform &w2o, Float radius, Float zMinIn, Float zMaxIn, Float phiMaxDeg, const Sphere &sp, const Ray &r) {
+            Float tHit = 0;
+            SurfaceInteraction isect;
+            Ray ray(r);
+            bool hit = sp.Intersect(ray, &tHit, &isect, false);
+            for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) putv<float>(f, o2w.GetMatrix().m[a][b]);
+            for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) putv<float>(f, w2o.GetMatrix().m[a][b]);
+            // constructor results, recomputed with the constructor's expressions (shapes/sphere.h:50-58; the members are private)
+            putv<float>(f, radius);
+            putv<float>(f, Clamp(std::min(zMinIn, zMaxIn), -radius, radius));
+            putv<float>(f, Clamp(std::max(zMinIn, zMaxIn), -radius, radius));
+            putv<float>(f, std::acos(Clamp(std::min(zMinIn, zMaxIn) / radius, -1, 1)));
+            putv<float>(f, std::acos(Clamp(std::max(zMinIn, zMaxIn) / radius, -1, 1)));
+            putv<float>(f, Radians(Clamp(phiMaxDeg, 0, 360)));
+            putv<float>(f, sp.Area());
+            putv<int32_t>(f, (sp.reverseOrientation ? 1 : 0) | (sp.transformSwapsHandedness ? 2 : 0));
+            for (int k = 0; k < 3; ++k) putv<float>(f, r.o[k]);
+            for (int k = 0; k < 3; ++k) putv<float>(f, r.d[k]);
+            putv<float>(f, r.tMax);
+            putv<int32_t>(f, hit ? 1 : 0);
+            putv<float>(f, hit ? tHit : 0.f);
+            for (int k = 0; k < 3; ++k) putv<float>(f, hit ? isect.p[k] : 0.f);
+            for (int k = 0; k < 3; ++k) putv<float>(f, hit ? isect.pError[k] : 0.f);
+            for (int k = 0; k < 3; ++k) putv<float>(f, hit ? isect.n[k] : 0.f);
+            ++count;
+            return hit ? std::make_pair(true, isect) : std::make_pair(false, isect);
+        };
+        for (int i = 0; i < 300; ++i) {
+            RNG rng(i);
+            Float radius = pExp(rng, 4);
+            bool partial = i >= 100;
+            Float zMin = !partial || rng.UniformFloat() < 0.5 ? -radius : Lerp(rng.UniformFloat(), -radius, radius);
+            Float zMax = !partial || rng.UniformFloat() < 0.5 ? radius : Lerp(rng.UniformFloat(), -radius, radius);
+            Float phiMax = !partial || rng.UniformFloat() < 0.5 ? 360. : rng.UniformFloat() * 360.;
+            Transform o2w;
+            if (i >= 200)
+                o2w = Translate(Vector3f(pExp(rng, 2), -pExp(rng, 2), pExp(rng, 1))) * Rotate(360 * rng.UniformFloat(), Vector3f(.3f, 1, -.4f)) *
+                      Scale(1 + rng.UniformFloat(), (i & 1) ? -1.5f : 1.5f, 0.5f + rng.UniformFloat());
+            Transform w2o = Inverse(o2w);
+            Sphere sphere(&o2w, &w2o, (i % 7) == 0, radius, zMin, zMax, phiMax);
+            Point3f o;
+            for (int c = 0; c < 3; ++c) o[c] = pExp(rng, i >= 200 ? 3 : 8);
+            Bounds3f bbox = sphere.WorldBound();
+            Point3f t;
+            for (int c = 0; c < 3; ++c) t[c] = rng.UniformFloat();
+            Point3f p2 = bbox.Lerp(t);
+            Ray r(o, p2 - o);
+            if (rng.UniformFloat() < .5) r.d = Normalize(r.d);
+            auto h = rec(o2w, w2o, radius, zMin, zMax, phiMax, sphere, r);
+            if (!h.first) continue;
+            for (int j = 0; j < 8; ++j) {
+                Point2f u(rng.UniformFloat(), rng.UniformFloat());
+                Vector3f w = UniformSampleSphere(u);
+                if (j < 6) w = Faceforward(w, h.second.n);   // two of them may point back into the sphere
+                Ray rOut = h.second.SpawnRay(w);
+                rec(o2w, w2o, radius, zMin, zMax, phiMax, sphere, rOut);
+            }
+        }
+        fclose(f);
+        printf("ref_probe: %d sphere records\n", count);
     }
     // ---- Distribution1D::SampleDiscrete (sampling.h:90-100)
     {

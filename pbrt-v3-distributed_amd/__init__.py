@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_intersect", "mi_triangle_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -103,6 +103,7 @@ def device_lib():
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_triangle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mi_sphere_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_sobol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.mi_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -282,6 +283,22 @@ def triangle_intersect(tri9, rays, device=0):
     L = device_lib()
     if L.mi_triangle_intersect(device, _ptr(tri9), _ptr(rays), len(rays), _ptr(hits)) != 0:
         raise RuntimeError("mi_triangle_intersect: %s" % L.mi_last_error().decode())
+    return hits
+
+
+SPHERE_DTYPE = np.dtype([("o2w", np.float32, 16), ("w2o", np.float32, 16), ("radius", np.float32), ("zmin", np.float32), ("zmax", np.float32),
+                         ("theta_min", np.float32), ("theta_max", np.float32), ("phi_max", np.float32), ("flags", np.uint32), ("area", np.float32)])   # mi_sphere
+SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
+
+
+def sphere_intersect(spheres, rays, device=0):
+    """Device Sphere::Intersect for independent (sphere, ray) pairs (no scene)."""
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+    hits = np.zeros(len(rays), dtype=SPHERE_HIT_DTYPE)
+    L = device_lib()
+    if L.mi_sphere_intersect(device, _ptr(spheres), _ptr(rays), len(rays), _ptr(hits)) != 0:
+        raise RuntimeError("mi_sphere_intersect: %s" % L.mi_last_error().decode())
     return hits
 
 

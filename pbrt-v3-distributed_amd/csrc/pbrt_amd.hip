@@ -1684,6 +1684,39 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_spheres(const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    mi_ray r = rays[i];
+    SphereIsectOut o;
+    SphereIsect(spheres + i, V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, &o);
+    mi_sphere_hit h;
+    std::memset(&h, 0, sizeof(h));
+    if (o.hit) {
+        h.hit = 1;
+        h.t = SphereIntersectT(spheres + i, V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax);
+        h.p[0] = o.p.x; h.p[1] = o.p.y; h.p[2] = o.p.z;
+        h.p_error[0] = o.pError.x; h.p_error[1] = o.pError.y; h.p_error[2] = o.pError.z;
+        h.n[0] = o.n.x; h.n[1] = o.n.y; h.n[2] = o.n.z;
+    }
+    hits[i] = h;
+}
+int mi_sphere_intersect(int device, const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits) {
+    if (!spheres || !rays || !hits || n < 0) return fail("mi_sphere_intersect: bad argument");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("mi_sphere_intersect: no HIP device (this library has no CPU path)");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf ds, dr, dh;
+    if (ds.alloc((size_t)n * sizeof(mi_sphere)) || dr.alloc((size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_sphere_hit))) return -1;
+    HIP_TRY(hipMemcpy(ds.p, spheres, (size_t)n * sizeof(mi_sphere), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, rays, (size_t)n * sizeof(mi_ray), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_spheres, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, 0, ds.as<mi_sphere>(), dr.as<mi_ray>(), n, dh.as<mi_sphere_hit>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(mi_sphere_hit), hipMemcpyDeviceToHost));
+    return 0;
+}
 __global__ void __launch_bounds__(256) k_stream_read(const float4 *p, uint64_t n, float4 *out) {
     float4 acc = make_float4(0, 0, 0, 0);
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {

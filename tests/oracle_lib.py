@@ -35,6 +35,7 @@ def lib():
         L.oracle_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_sphere_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_render_sharded.restype = C.c_double
         L.oracle_render_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.oracle_sample_discrete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p]
@@ -137,6 +138,23 @@ def run_ref(scene_file, outfile, nthreads=None, extra=()):
     cmd += list(extra) + [scene_file]
     subprocess.check_call(cmd)
     return pa.read_pfm(outfile)
+
+
+def sphere_records(rows):
+    """ref_vectors.npz 'spheres' rows -> (mi_sphere array, ray array)"""
+    sp = np.zeros(len(rows), dtype=pa.SPHERE_DTYPE)
+    for k in ("o2w", "w2o", "radius", "zmin", "zmax", "theta_min", "theta_max", "phi_max", "area"):
+        sp[k] = rows[k]
+    sp["flags"] = rows["flags"].astype(np.uint32)
+    rays = np.zeros(len(rows), dtype=pa.RAY_DTYPE)
+    rays["o"] = rows["o"]; rays["d"] = rows["d"]; rays["tmax"] = rows["tmax"]
+    return sp, rays
+
+
+def sphere_intersect(spheres, rays):
+    hits = np.zeros(len(rays), dtype=pa.SPHERE_HIT_DTYPE)
+    lib().oracle_sphere_intersect(_p(spheres), _p(rays), len(rays), _p(hits))
+    return hits
 
 
 def image_metrics(img, ref):

@@ -157,6 +157,22 @@ def test_device_triangle_intersect_matches_reference_vectors():
     assert h["prim"][0] == -1    # Triangle.BadCases known answer
 
 
+def test_device_sphere_intersect_matches_reference_vectors():
+    """Device Sphere::Intersect on the reference's FullSphere / PartialSphere test constructions (+ transformed spheres): hit decision,
+    tHit, p and pError bit for bit.  The normal goes through acos / sin of libm (theta of the hit point), whose last-ulp differences
+    between glibc and the device's double-rounded versions are amplified near the poles: measured 16 of 429 records differ, by <= 6 ulp;
+    tolerance 1e-5 absolute, as loose as the reference's own ParialSphere.Normal test (EXPECT_FLOAT_EQ)."""
+    rows = np.load(os.path.join(G, "ref_vectors.npz"))["spheres"]
+    sp, rays = ol.sphere_records(rows)
+    h = pa.sphere_intersect(sp, rays)
+    assert np.array_equal(h["hit"], rows["hit"])
+    hit = rows["hit"] == 1
+    for k in ("t", "p", "p_error"):
+        assert np.array_equal(h[k][hit].view(np.uint32), rows[k][hit].view(np.uint32)), k
+    assert np.allclose(h["n"][hit], rows["n"][hit], rtol=0, atol=1e-5)
+    assert (h["n"][hit].view(np.uint32) == rows["n"][hit].view(np.uint32)).all(1).mean() >= 0.9
+
+
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
                                                     ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),

@@ -181,3 +181,17 @@ def test_oracle_killeroo_simple_matches_the_reference_scene(built):
     img = sc.film_image(ol.render(sc, nthreads=4)[0])
     ref = pa.read_pfm(os.path.join(G, "killeroo_simple_96x96_reference.pfm"))
     assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())
+
+
+def test_sphere_intersect_matches_reference(vec):
+    """Sphere::Intersect (EFloat quadratic, clipping, interaction through ObjectToWorld) on the FullSphere / PartialSphere constructions
+    of the reference's tests (tests/shapes.cpp:376-497) plus transformed spheres: hit decision, tHit, p, pError, n -- bit for bit; and the
+    property those tests assert: rays spawned from a hit into the normal's hemisphere of a convex sphere do not re-intersect it."""
+    rows = vec["spheres"]
+    assert len(rows) > 1000 and rows["hit"].sum() > 200
+    sp, rays = ol.sphere_records(rows)
+    h = ol.sphere_intersect(sp, rays)
+    assert np.array_equal(h["hit"], rows["hit"])
+    hit = rows["hit"] == 1
+    for k in ("t", "p", "p_error", "n"):
+        assert np.array_equal(h[k][hit].view(np.uint32), rows[k][hit].view(np.uint32)), k
