@@ -36,6 +36,7 @@ def lib():
         L.oracle_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_sphere_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_bxdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
         L.oracle_render_sharded.restype = C.c_double
         L.oracle_render_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.oracle_sample_discrete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p]
@@ -149,6 +150,16 @@ def sphere_records(rows):
     rays = np.zeros(len(rows), dtype=pa.RAY_DTYPE)
     rays["o"] = rows["o"]; rays["d"] = rows["d"]; rays["tmax"] = rows["tmax"]
     return sp, rays
+
+
+def bxdf_eval(rows):
+    """ref_vectors.npz 'bxdfs' rows -> dict of the oracle's f, pdf, Sample_f results"""
+    n = len(rows)
+    b = np.ascontiguousarray(rows["bxdf"]); wo = np.ascontiguousarray(rows["wo"]); wi = np.ascontiguousarray(rows["wi"]); u = np.ascontiguousarray(rows["u"])
+    out = {"f": np.zeros((n, 3), np.float32), "pdf": np.zeros(n, np.float32), "wi_s": np.zeros((n, 3), np.float32), "pdf_s": np.zeros(n, np.float32),
+           "f_s": np.zeros((n, 3), np.float32), "type_s": np.zeros(n, np.int32)}
+    lib().oracle_bxdf(_p(b), _p(wo), _p(wi), _p(u), n, _p(out["f"]), _p(out["pdf"]), _p(out["wi_s"]), _p(out["pdf_s"]), _p(out["f_s"]), _p(out["type_s"]))
+    return out
 
 
 def sphere_intersect(spheres, rays):

@@ -26,12 +26,14 @@ def main():
     sph = np.fromfile(os.path.join(tmp, "spheres.bin"), dtype=np.dtype([("o2w", "<f4", 16), ("w2o", "<f4", 16), ("radius", "<f4"), ("zmin", "<f4"), ("zmax", "<f4"),
                       ("theta_min", "<f4"), ("theta_max", "<f4"), ("phi_max", "<f4"), ("area", "<f4"), ("flags", "<i4"), ("o", "<f4", 3), ("d", "<f4", 3), ("tmax", "<f4"),
                       ("hit", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("p_error", "<f4", 3), ("n", "<f4", 3)]))
+    bx = np.fromfile(os.path.join(tmp, "bxdfs.bin"), dtype=np.dtype([("bxdf", "V100"), ("wo", "<f4", 3), ("wi", "<f4", 3), ("u", "<f4", 2), ("f", "<f4", 3), ("pdf", "<f4"),
+                     ("wi_s", "<f4", 3), ("pdf_s", "<f4"), ("f_s", "<f4", 3), ("type_s", "<i4")]))
     tri = np.fromfile(os.path.join(tmp, "triangles.bin"), dtype=np.dtype([("p", "<f4", 9), ("o", "<f4", 3), ("d", "<f4", 3), ("tmax", "<f4"), ("hit", "<i4"),
                                                                            ("t", "<f4"), ("uv", "<f4", 2), ("b1", "<f4"), ("b2", "<f4"), ("n", "<f4", 3)]))
     keep = np.zeros(len(tri), dtype=bool); keep[0] = True; keep[1::4] = True   # BadCases record + every 4th
     tri = tri[keep]
     raw = np.fromfile(os.path.join(tmp, "distribution1d.bin"), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, halton_sampler=hp, spheres=sph, triangles=tri, distribution1d=raw)
+    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), sobol_samples=ss, sobol_index=si, sobol_sampler=sp, halton_sampler=hp, spheres=sph, bxdfs=bx, triangles=tri, distribution1d=raw)
     print("ref_vectors.npz:", len(ss), "sobol samples,", len(si), "indices,", len(sp), "sampler rows,", len(tri), "triangle records")
 
     # strategy None = as the scene file says (cornell: uniform, materials: power); "spatial" = the reference's default
