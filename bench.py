@@ -181,6 +181,7 @@ def main():
         if world > 1:
             ctx.sync()   # the ctx stream is not torch's current stream
             par.combine_films(film_t, dst=0)
+            torch.cuda.synchronize()   # the reduction reads film_t: it must be done before the next step clears the film
 
     # ---- one counting pass (deterministic work: node / triangle fetch counts feed the roofline), then warm-up
     ctx.counters_reset()
