@@ -104,12 +104,29 @@ PT_DEV uint64_t SobolIntervalToIndex(const DevScene &sc, uint32_t m, uint64_t fr
     if (m == 0) return 0;
     const uint32_t m2 = m << 1;
     uint64_t index = uint64_t(frame) << m2;
+    // The reference loops over the set bits of `frame` and of the pixel word; column c of the two tables is the same for
+    // every lane, so the loops run over a wave-uniform column range with the columns coming through scalar loads (constant
+    // address space) and a per-lane select -- same XOR set, no per-lane dependent loads.
+    typedef const __attribute__((address_space(4))) uint64_t *ConstU64;
+    ConstU64 vdc = (ConstU64)(unsigned long long)(sc.vdc + (m - 1) * PBRT_AMD_SOBOL_NCOL);
+    ConstU64 vdcInv = (ConstU64)(unsigned long long)(sc.vdc_inv + (m - 1) * PBRT_AMD_SOBOL_NCOL);
     uint64_t delta = 0;
-    for (int c = 0; frame; frame >>= 1, ++c)
-        if (frame & 1) delta ^= sc.vdc[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    const int frameBits = sc.sobol_index_bits - (int)m2 > 0 ? sc.sobol_index_bits - (int)m2 : 0;   // log2(spp): frame < spp
+    for (int c = 0; c < frameBits; ++c)
+        if ((frame >> c) & 1) delta ^= vdc[c];
+    if (frame >> frameBits) {   // sample numbers beyond the scene's spp (stage-level calls): the reference's loop as it is
+        uint64_t fr = frame >> frameBits;
+        for (int c = frameBits; fr; fr >>= 1, ++c)
+            if (fr & 1) delta ^= sc.vdc[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    }
     uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;
-    for (int c = 0; b; b >>= 1, ++c)
-        if (b & 1) index ^= sc.vdc_inv[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    for (uint32_t c = 0; c < m2; ++c)   // px, py < 2^m and delta < 2^2m: b has at most 2m bits
+        if ((b >> c) & 1) index ^= vdcInv[c];
+    if (b >> m2) {
+        uint64_t br = b >> m2;
+        for (uint32_t c = m2; br; br >>= 1, ++c)
+            if (br & 1) index ^= sc.vdc_inv[(m - 1) * PBRT_AMD_SOBOL_NCOL + c];
+    }
     return index;
 }
 PT_DEV Float SobolSampleFloat(const DevScene &sc, uint64_t a, int dimension) {   // core/lowdiscrepancy.h:259-274 (scramble 0)
