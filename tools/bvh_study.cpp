@@ -1,0 +1,159 @@
+// Offline study tool (NOT product code): node / triangle visit statistics of alternative BVH layouts for the traversal kernel,
+// on the host, over rays supplied by tools/bvh_study.py.  Variants: the reference's BVH2 order, the device's BVH4 collapse
+// (ordered, with and without dropping popped nodes beyond the current hit), and a BVH8 collapse of the same tree.
+//   g++ -O2 -std=c++14 -shared -fPIC tools/bvh_study.cpp -Iinclude -o /tmp/libbvhstudy.so
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "pbrt_amd.h"
+
+namespace {
+struct WNode { int n; float lo[8][3], hi[8][3]; uint32_t child[8]; };   // child: leaf bit 31 | first prim, count in leafCount
+struct Wide {
+    std::vector<WNode> nodes;
+    std::vector<uint8_t> leafCount;   // per leaf ref -> stored separately keyed by (node, slot)
+    std::vector<std::vector<uint8_t>> cnt;
+};
+const uint32_t LEAF = 0x80000000u;
+
+float area(const mi_bvh2_node &n) {
+    float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+    return 2 * (dx * dy + dx * dz + dy * dz);
+}
+uint32_t buildWide(const mi_bvh2_node *n2, uint32_t i2, int width, std::vector<WNode> &out, std::vector<std::vector<uint8_t>> &cnt) {
+    uint32_t idx = (uint32_t)out.size();
+    out.emplace_back();
+    cnt.emplace_back(8, 0);
+    uint32_t kids[8];
+    int nk = 2;
+    kids[0] = i2 + 1; kids[1] = (uint32_t)n2[i2].offset;
+    while (nk < width) {
+        int best = -1; float bestA = -1;
+        for (int k = 0; k < nk; ++k) if (n2[kids[k]].n_prims == 0) { float a = area(n2[kids[k]]); if (a > bestA) { bestA = a; best = k; } }
+        if (best < 0) break;
+        uint32_t o = kids[best];
+        for (int k = nk; k > best + 1; --k) kids[k] = kids[k - 1];
+        kids[best] = o + 1; kids[best + 1] = (uint32_t)n2[o].offset;
+        ++nk;
+    }
+    out[idx].n = nk;
+    for (int k = 0; k < nk; ++k) {
+        const mi_bvh2_node &c = n2[kids[k]];
+        for (int a = 0; a < 3; ++a) { out[idx].lo[k][a] = c.bmin[a]; out[idx].hi[k][a] = c.bmax[a]; }
+        if (c.n_prims > 0) { out[idx].child[k] = LEAF | (uint32_t)c.offset; cnt[idx][k] = (uint8_t)std::min<int>(255, c.n_prims); }
+        else { uint32_t ch = buildWide(n2, kids[k], width, out, cnt); out[idx].child[k] = ch; }
+    }
+    return idx;
+}
+// Moller-Trumbore in double: the study only needs hit distances, not the watertight test
+bool triHit(const mi_scene_desc *d, uint32_t prim, const double o[3], const double dir[3], double tMax, double *t) {
+    const uint32_t *v = d->tri_indices + 3 * (size_t)prim;
+    if (v[0] == MI_PRIM_SPHERE) return false;
+    const float *p0 = d->P + 3 * (size_t)v[0], *p1 = d->P + 3 * (size_t)v[1], *p2 = d->P + 3 * (size_t)v[2];
+    double e1[3], e2[3], pv[3], tv[3], qv[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = p1[a] - p0[a]; e2[a] = p2[a] - p0[a]; }
+    pv[0] = dir[1] * e2[2] - dir[2] * e2[1]; pv[1] = dir[2] * e2[0] - dir[0] * e2[2]; pv[2] = dir[0] * e2[1] - dir[1] * e2[0];
+    double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    if (det == 0) return false;
+    double inv = 1 / det;
+    for (int a = 0; a < 3; ++a) tv[a] = o[a] - p0[a];
+    double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
+    if (u < 0 || u > 1) return false;
+    qv[0] = tv[1] * e1[2] - tv[2] * e1[1]; qv[1] = tv[2] * e1[0] - tv[0] * e1[2]; qv[2] = tv[0] * e1[1] - tv[1] * e1[0];
+    double vv = (dir[0] * qv[0] + dir[1] * qv[1] + dir[2] * qv[2]) * inv;
+    if (vv < 0 || u + vv > 1) return false;
+    double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+    if (tt <= 1e-9 || tt > tMax) return false;
+    *t = tt;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+// out[0] = nodes visited, out[1] = triangles tested, out[2] = hits, out[3] = number of wide nodes; width 2 = the reference's BVH2 traversal
+void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width, int cull_on_pop, int any_hit, double *out) {
+    double nodes = 0, tris = 0, hits = 0;
+    if (width == 2) {
+        const mi_bvh2_node *nd = d->bvh_nodes;
+        for (int64_t r = 0; r < n; ++r) {
+            double o[3] = {rays[r].o[0], rays[r].o[1], rays[r].o[2]}, dir[3] = {rays[r].d[0], rays[r].d[1], rays[r].d[2]}, tMax = rays[r].tmax;
+            double inv[3] = {1 / dir[0], 1 / dir[1], 1 / dir[2]};
+            int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
+            int stack[64], sp = 0, cur = 0;
+            bool hit = false;
+            while (true) {
+                const mi_bvh2_node &b = nd[cur];
+                ++nodes;
+                double t0 = 0, t1 = tMax;
+                bool ok = true;
+                for (int a = 0; a < 3 && ok; ++a) {
+                    double tn = ((neg[a] ? b.bmax[a] : b.bmin[a]) - o[a]) * inv[a], tf = ((neg[a] ? b.bmin[a] : b.bmax[a]) - o[a]) * inv[a];
+                    if (tn > t0) t0 = tn;
+                    if (tf < t1) t1 = tf;
+                    if (t0 > t1) ok = false;
+                }
+                if (ok) {
+                    if (b.n_prims > 0) {
+                        for (int i = 0; i < b.n_prims; ++i) { ++tris; double t; if (triHit(d, b.offset + i, o, dir, tMax, &t)) { tMax = t; hit = true; if (any_hit) goto done2; } }
+                        if (!sp) break;
+                        cur = stack[--sp];
+                    } else {
+                        if (neg[b.axis]) { stack[sp++] = cur + 1; cur = b.offset; } else { stack[sp++] = b.offset; cur = cur + 1; }
+                    }
+                } else { if (!sp) break; cur = stack[--sp]; }
+            }
+        done2:
+            hits += hit;
+        }
+        out[0] = nodes; out[1] = tris; out[2] = hits; out[3] = d->n_bvh_nodes;
+        return;
+    }
+    std::vector<WNode> wn;
+    std::vector<std::vector<uint8_t>> cnt;
+    if (d->n_bvh_nodes && d->bvh_nodes[0].n_prims == 0) buildWide(d->bvh_nodes, 0, width, wn, cnt);
+    struct Ent { uint32_t ref; uint8_t count; double t; };
+    for (int64_t r = 0; r < n && !wn.empty(); ++r) {
+        double o[3] = {rays[r].o[0], rays[r].o[1], rays[r].o[2]}, dir[3] = {rays[r].d[0], rays[r].d[1], rays[r].d[2]}, tMax = rays[r].tmax;
+        double inv[3] = {1 / dir[0], 1 / dir[1], 1 / dir[2]};
+        std::vector<Ent> st;
+        Ent cur{0, 0, 0};
+        bool hit = false;
+        while (true) {
+            if (cur.ref & LEAF) {
+                uint32_t first = cur.ref & ~LEAF;
+                for (int i = 0; i < cur.count; ++i) { ++tris; double t; if (triHit(d, first + i, o, dir, tMax, &t)) { tMax = t; hit = true; if (any_hit) goto done; } }
+            } else {
+                const WNode &w = wn[cur.ref];
+                ++nodes;
+                Ent h[8];
+                int nh = 0;
+                for (int k = 0; k < w.n; ++k) {
+                    double t0 = 0, t1 = tMax;
+                    bool ok = true;
+                    for (int a = 0; a < 3 && ok; ++a) {
+                        double tn = ((inv[a] < 0 ? w.hi[k][a] : w.lo[k][a]) - o[a]) * inv[a], tf = ((inv[a] < 0 ? w.lo[k][a] : w.hi[k][a]) - o[a]) * inv[a];
+                        if (tn > t0) t0 = tn;
+                        if (tf < t1) t1 = tf;
+                        if (t0 > t1) ok = false;
+                    }
+                    if (ok) h[nh++] = Ent{w.child[k], cnt[cur.ref][k], t0};
+                }
+                std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });   // far first: nearest ends on top
+                for (int k = 0; k < nh; ++k) st.push_back(h[k]);
+            }
+            bool got = false;
+            while (!st.empty()) {
+                cur = st.back(); st.pop_back();
+                if (!cull_on_pop || cur.t < tMax) { got = true; break; }
+            }
+            if (!got) break;
+        }
+    done:
+        hits += hit;
+    }
+    out[0] = nodes; out[1] = tris; out[2] = hits; out[3] = (double)wn.size();
+}
+}

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Offline study for the next traversal design (NOT product code): how many nodes / triangles a ray visits under different BVH
+layouts of the SAME reference tree -- BVH2 as the reference traverses it, the device's BVH4 collapse with and without dropping
+popped entries beyond the current hit, and a BVH8 collapse -- on camera rays and on incoherent diffuse-bounce rays of the
+San-Miguel-class stand-in.  Prints visits per ray and the bytes they cost with 128-byte BVH4 / 256-byte BVH8 / 80-byte
+compressed BVH8 nodes (Ylitie et al. 2017) and 48-byte triangles.
+
+  python tools/bvh_study.py [--tris 1000000]
+"""
+import argparse, ctypes as C, importlib, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--rays", type=int, default=200000)
+    args = ap.parse_args()
+    import oracle_lib as ol
+    pa = importlib.import_module("pbrt-v3-distributed_amd")
+    so = "/tmp/libbvhstudy.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", os.path.join(ROOT, "tools", "bvh_study.cpp"), "-I" + os.path.join(ROOT, "include"), "-o", so])
+    L = C.CDLL(so)
+    L.bvh_study.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f = "/tmp/bvh_study_scene.pbrt"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris), "--res", "640", "360", "--spp", "1", "--out", f], stdout=subprocess.DEVNULL)
+    sc = pa.Scene(f)
+    rng = np.random.RandomState(1)
+    xy = np.stack([rng.randint(0, sc.width, args.rays), rng.randint(0, sc.height, args.rays)], 1).astype(np.int32)
+    cam, _ = ol.camera_rays(sc, xy, np.zeros(args.rays, np.int32))
+    hits, _cnt = ol.intersect(sc, cam)
+    ok = hits["prim"] >= 0
+    p = cam["o"][ok] + cam["d"][ok] * hits["t"][ok][:, None]
+    n = hits["n"][ok]
+    n = n * np.sign(-(n * cam["d"][ok]).sum(1))[:, None]          # towards the camera side
+    # cosine-distributed bounce directions about n
+    u1, u2 = rng.rand(len(p)), rng.rand(len(p))
+    r, ph = np.sqrt(u1), 2 * np.pi * u2
+    a = np.where(np.abs(n[:, 0:1]) > 0.9, [[0, 1, 0]], [[1, 0, 0]])
+    t1 = np.cross(n, a); t1 /= np.linalg.norm(t1, axis=1)[:, None]; t2 = np.cross(n, t1)
+    d = t1 * (r * np.cos(ph))[:, None] + t2 * (r * np.sin(ph))[:, None] + n * np.sqrt(np.maximum(0, 1 - u1))[:, None]
+    sec = np.zeros(len(p), dtype=pa.RAY_DTYPE)
+    sec["o"] = (p + n * 1e-3).astype(np.float32); sec["d"] = d.astype(np.float32); sec["tmax"] = np.inf
+    print("scene: %d triangles, %d BVH2 nodes; %d camera rays, %d bounce rays" % (sc.info["n_tris"], sc.info["n_bvh_nodes"], len(cam), len(sec)))
+    print("%-8s %-28s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
+    for name, rays in (("camera", cam), ("bounce", sec)):
+        rays = np.ascontiguousarray(rays)
+        for label, width, cull, nodeB in (("BVH2 reference order", 2, 0, 32), ("BVH4 (device layout)", 4, 0, 128), ("BVH4 + cull on pop", 4, 1, 128),
+                                          ("BVH8", 8, 0, 256), ("BVH8 + cull on pop", 8, 1, 256), ("BVH8 compressed 80 B + cull", 8, 1, 80)):
+            out = np.zeros(4)
+            L.bvh_study(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), width, cull, 0, out.ctypes.data_as(C.c_void_p))
+            nr, tr = out[0] / len(rays), out[1] / len(rays)
+            print("%-8s %-28s %10.2f %10.2f %12.2f" % (name, label, nr, tr, (48 + nr * nodeB + tr * 48) / 1024))
+
+
+if __name__ == "__main__":
+    main()
