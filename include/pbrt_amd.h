@@ -312,6 +312,12 @@ enum mi_kernel_id {
 };
 int mi_timing_enable(mi_ctx *ctx, int on);
 int mi_timing_get(mi_ctx *ctx, double ms_total[MI_K_COUNT], uint64_t launches[MI_K_COUNT]);
+/* Host-only self check of the BVH2 -> BVH4 collapse mi_scene_upload performs (no device needed): builds the device tree from
+ * scene->bvh_nodes and verifies that every primitive lies in exactly one leaf range, that leaf references hold 1..16 primitives, that
+ * every child box equals the box of the reference node it stands for and contains the primitives below it, and that the stack bound
+ * covers the depth.  stats: [0] BVH4 nodes, [1] leaf references, [2] depth, [3] stack entries needed, [4] primitives covered.
+ * Returns 0 if all invariants hold (else -1 with mi_last_error()). */
+int mi_bvh4_validate(const mi_scene_desc *scene, int64_t stats[8]);
 /* Measurement aid: achievable HBM read rate on this device -- a streaming 16-byte-per-lane read of
  * `bytes` (>= 1 GiB recommended, beyond the 256 MiB Infinity Cache), best of 3 timed launches -- reported beside the
  * 8 TB/s specification peak. */

@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -99,6 +99,7 @@ def device_lib():
         L.mi_counters_reset.argtypes = [C.c_void_p]
         L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -289,6 +290,15 @@ def triangle_intersect(tri9, rays, device=0):
 SPHERE_DTYPE = np.dtype([("o2w", np.float32, 16), ("w2o", np.float32, 16), ("radius", np.float32), ("zmin", np.float32), ("zmax", np.float32),
                          ("theta_min", np.float32), ("theta_max", np.float32), ("phi_max", np.float32), ("flags", np.uint32), ("area", np.float32)])   # mi_sphere
 SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
+
+
+def bvh4_validate(scene):
+    """Host-only self check of the BVH2 -> BVH4 collapse (no GPU needed): dict of tree statistics, raises on a broken invariant."""
+    st = np.zeros(8, dtype=np.int64)
+    L = device_lib()
+    if L.mi_bvh4_validate(scene.desc, _ptr(st)) != 0:
+        raise RuntimeError("mi_bvh4_validate: %s" % L.mi_last_error().decode())
+    return {"nodes": int(st[0]), "leaf_refs": int(st[1]), "depth": int(st[2]), "stack_need": int(st[3]), "prims": int(st[4])}
 
 
 def sphere_intersect(spheres, rays, device=0):

@@ -1684,6 +1684,67 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
+    if (!d || !stats) return fail("mi_bvh4_validate: null argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    if (!d->n_bvh_nodes) return 0;
+    B4Builder bb;
+    bb.n2 = d->bvh_nodes;
+    if (d->bvh_nodes[0].n_prims > 0) {
+        bb.out.emplace_back();
+        B4Builder::clearNode(bb.out[0]);
+        uint32_t ref = bb.leafRef(d->bvh_nodes[0], (uint32_t)d->bvh_nodes[0].offset, d->bvh_nodes[0].n_prims, 0);
+        B4Builder::setChild(bb.out[0], 0, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, ref);
+    } else
+        bb.build(0, 0);
+    std::vector<uint8_t> covered(d->n_tris, 0);
+    int64_t leaves = 0, maxDepth = 0;
+    struct Item { uint32_t node; int depth; };
+    std::vector<Item> st{{0u, 0}};
+    auto primBox = [&](uint32_t t, float lo[3], float hi[3]) -> bool {   // false for spheres (their box is the reference node's)
+        const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        if (v[0] == MI_PRIM_SPHERE) return false;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
+        for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) { float x = d->P[3 * (size_t)v[k] + a]; lo[a] = std::min(lo[a], x); hi[a] = std::max(hi[a], x); }
+        return true;
+    };
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        if (it.node >= bb.out.size()) return fail("mi_bvh4_validate: child index out of range");
+        maxDepth = std::max<int64_t>(maxDepth, it.depth);
+        const BVH4Node &n = bb.out[it.node];
+        for (int k = 0; k < 4; ++k) {
+            uint32_t c = n.child[k];
+            if (c == BVH4_EMPTY) { if (!(n.lox[k] > n.hix[k])) return fail("mi_bvh4_validate: empty slot without an inverted box"); continue; }
+            if (c & BVH4_LEAF) {
+                uint32_t first = c & BVH4_FIRST_MASK, count = ((c >> 27) & 0xfu) + 1;
+                ++leaves;
+                if (count > BVH4_LEAF_MAX || first + count > d->n_tris) return fail("mi_bvh4_validate: bad leaf reference");
+                for (uint32_t t = first; t < first + count; ++t) {
+                    if (covered[t]++) return fail("mi_bvh4_validate: primitive referenced twice");
+                    float lo[3], hi[3];
+                    if (primBox(t, lo, hi))
+                        if (lo[0] < n.lox[k] || lo[1] < n.loy[k] || lo[2] < n.loz[k] || hi[0] > n.hix[k] || hi[1] > n.hiy[k] || hi[2] > n.hiz[k])
+                            return fail("mi_bvh4_validate: primitive outside its leaf box");
+                }
+            } else {
+                const BVH4Node &ch = bb.out[c];   // the child's own children must lie inside the box the parent holds for it
+                for (int j = 0; j < 4; ++j) {
+                    if (ch.child[j] == BVH4_EMPTY) continue;
+                    if (ch.lox[j] < n.lox[k] || ch.loy[j] < n.loy[k] || ch.loz[j] < n.loz[k] || ch.hix[j] > n.hix[k] || ch.hiy[j] > n.hiy[k] || ch.hiz[j] > n.hiz[k])
+                        return fail("mi_bvh4_validate: child box not contained in its parent's");
+                }
+                st.push_back({c, it.depth + 1});
+            }
+        }
+    }
+    int64_t ncov = 0;
+    for (uint8_t cflag : covered) ncov += cflag;
+    if (ncov != (int64_t)d->n_tris) return fail("mi_bvh4_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
+    if (maxDepth != bb.maxDepth) return fail("mi_bvh4_validate: depth bookkeeping differs from the tree");
+    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = maxDepth; stats[3] = 3 * (maxDepth + 1) + 1; stats[4] = ncov;
+    return 0;
+}
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_spheres(const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits) {
     int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;

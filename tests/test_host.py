@@ -124,3 +124,29 @@ def test_cli_reports_missing_gpu_loudly(built, tmp_path):
         pytest.skip("a GPU is present")
     r = subprocess.run([exe, "--quiet", "--outfile", str(out), str(f)], capture_output=True, text=True)
     assert "Error" in r.stderr and not out.exists()
+
+
+def test_bvh4_collapse_invariants(built, tmp_path):
+    """The BVH2 -> BVH4 collapse of mi_scene_upload, checked on the host (mi_bvh4_validate, no GPU): every primitive in exactly one leaf
+    reference of 1..16 primitives, child boxes = the reference nodes' boxes and nested, depth / stack bound consistent -- on the parity
+    scenes, on degenerate ones (single leaf, empty world, spheres, instances) and with reference leaves far beyond 16 primitives
+    (maxnodeprims 200 -> chained leaf nodes), under every split method."""
+    import subprocess, sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edge_scenes as es
+    for f in ("cornell.pbrt", "materials.pbrt"):
+        sc = pa.Scene(os.path.join(ROOT, "scenes", f))
+        st = pa.bvh4_validate(sc)
+        assert st["prims"] == sc.info["n_tris"] and st["nodes"] >= 1
+    for n in ("onetri", "empty", "spheres", "instances"):
+        sc = pa.Scene(text=es.scene(n))
+        assert pa.bvh4_validate(sc)["prims"] == sc.info["n_tris"]
+    out = str(tmp_path / "sm.pbrt")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", "60000", "--res", "64", "36", "--spp", "1", "--out", out], stdout=subprocess.DEVNULL)
+    text = open(out).read()
+    for acc in ('', 'Accelerator "bvh" "integer maxnodeprims" [200]\n', 'Accelerator "bvh" "string splitmethod" "middle" "integer maxnodeprims" [40]\n',
+                'Accelerator "bvh" "string splitmethod" "equal" "integer maxnodeprims" [1]\n'):
+        t = text.replace("WorldBegin", acc + "WorldBegin", 1).replace("geo/", os.path.join(str(tmp_path), "geo") + "/")
+        sc = pa.Scene(text=t) if acc else pa.Scene(out)
+        st = pa.bvh4_validate(sc)
+        assert st["prims"] == sc.info["n_tris"] and st["stack_need"] == 3 * (st["depth"] + 1) + 1, (acc, st)
