@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -57,10 +57,11 @@ typedef struct mi_mesh {
 
 /* ---------------------------------------------------------------- materials --------- */
 
-/* One BxDF of a BSDF (src/core/reflection.h).  Textures are constant in this slice, so the lobe
+/* One BxDF of a BSDF (src/core/reflection.h).  For a material whose textures are all constant the lobe
  * list Material::ComputeScatteringFunctions would build (src/materials/ *.cpp) is a function of
  * the material alone and is passed pre-evaluated (clamped, black lobes dropped, roughness
- * remapped: matte.cpp:54-61, plastic.cpp:52-69, microfacet.h:123-128). */
+ * remapped: matte.cpp:54-61, plastic.cpp:52-69, microfacet.h:123-128).  Materials with image / procedural
+ * textures or a bump map carry an mi_material_desc (below) and the same list is built per hit. */
 enum mi_bxdf_type {
     MI_BXDF_LAMBERT_R = 0,    /* LambertianReflection     reflection.cpp:178  */
     MI_BXDF_LAMBERT_T = 1,    /* LambertianTransmission   reflection.cpp:187,391-403 */
@@ -95,6 +96,84 @@ typedef struct mi_material {
     float eta; /* BSDF::eta (reflection.h:156; glass.cpp:58, uber.cpp:56-60) */
     mi_bxdf bxdfs[MI_MAX_BXDFS];
 } mi_material;
+
+
+/* ---------------------------------------------------------------- textures ---------- */
+
+/* Texture<Float> / Texture<Spectrum> (core/texture.h:139-144) as a node table: every "Texture" directive and every
+ * inline parameter value becomes one mi_texture; parameters of type texture refer to nodes by index (children always
+ * precede their parents).  The device (and the oracle) evaluate nodes per hit exactly as the reference's
+ * Texture::Evaluate(const SurfaceInteraction&) does; Ptex is not carried. */
+enum mi_tex_type {
+    MI_TEX_CONSTANT = 0,     /* textures/constant.h */
+    MI_TEX_SCALE = 1,        /* textures/scale.h:  tex1 * tex2 */
+    MI_TEX_MIX = 2,          /* textures/mix.h:    (1-amount) tex1 + amount tex2 */
+    MI_TEX_BILERP = 3,       /* textures/bilerp.h */
+    MI_TEX_IMAGEMAP = 4,     /* textures/imagemap.h + core/mipmap.h */
+    MI_TEX_UV = 5,           /* textures/uv.h */
+    MI_TEX_CHECKERBOARD = 6, /* textures/checkerboard.h (dim 2 with aa none|closedform, dim 3) */
+    MI_TEX_DOTS = 7,         /* textures/dots.h */
+    MI_TEX_FBM = 8,          /* textures/fbm.h */
+    MI_TEX_WRINKLED = 9,     /* textures/wrinkled.h */
+    MI_TEX_MARBLE = 10,      /* textures/marble.h */
+    MI_TEX_WINDY = 11        /* textures/windy.h */
+};
+enum mi_tex_mapping { /* core/texture.h:50-137, core/texture.cpp:84-163 */
+    MI_MAP_UV = 0, MI_MAP_SPHERICAL = 1, MI_MAP_CYLINDRICAL = 2, MI_MAP_PLANAR = 3, MI_MAP_IDENTITY3D = 4
+};
+typedef struct mi_texture {
+    int32_t type;     /* mi_tex_type */
+    int32_t spectrum; /* 0: Texture<Float> (value[0] etc.), 1: Texture<Spectrum> */
+    int32_t tex1, tex2, amount; /* child nodes (SCALE, MIX, CHECKERBOARD tex1/tex2, DOTS tex1 = outsideDot, tex2 = insideDot) */
+    int32_t mapping;  /* mi_tex_mapping */
+    int32_t image;    /* IMAGEMAP: index into images[] */
+    int32_t dim, aa;  /* CHECKERBOARD: "dimension" 2|3; "aamode" 0 none, 1 closedform */
+    int32_t octaves;  /* FBM / WRINKLED / MARBLE */
+    float omega, scale, variation;
+    float value[3];   /* CONSTANT */
+    float v00[3], v01[3], v10[3], v11[3]; /* BILERP */
+    float su, sv, du, dv; /* UVMapping2D; PlanarMapping2D keeps ds, dt in du, dv */
+    float vs[3], vt[3];   /* PlanarMapping2D */
+    float w2t[16];        /* the Transform the mapping was constructed with (SPHERICAL / CYLINDRICAL / IDENTITY3D), row major */
+} mi_texture;
+
+/* MIPMap<T> after its constructor (core/mipmap.h:101-199): image resampled to power-of-two size, box-filtered pyramid.
+ * Texel (s,t) of level l is texels[level_offset(l) + (t * w_l + s) * channels], w_l = max(1, width >> l); levels are
+ * stored finest first, back to back. */
+typedef struct mi_image {
+    int32_t width, height; /* level 0 */
+    int32_t levels;
+    int32_t channels;      /* 1: MIPMap<Float>, 3: MIPMap<RGBSpectrum> */
+    int32_t trilinear;     /* doTrilinear */
+    int32_t wrap;          /* ImageWrap: 0 Repeat, 1 Black, 2 Clamp (mipmap.h:55) */
+    float max_aniso;
+    float pad;
+    const float *texels;
+} mi_image;
+
+/* Material parameters as textures: what Material::ComputeScatteringFunctions evaluates per hit (materials/ *.cpp,
+ * Material::Bump core/material.cpp:46-83).  `textured` = 0 means every parameter is a constant and there is no bump map:
+ * the pre-evaluated mi_material of the same index is then exact and the per-hit evaluation is skipped.  Node indices are
+ * -1 where the material has no such parameter (or the reference's "...OrNull" lookup returned null). */
+enum mi_material_type {
+    MI_MAT_MATTE = 0, MI_MAT_PLASTIC = 1, MI_MAT_GLASS = 2, MI_MAT_MIRROR = 3, MI_MAT_METAL = 4, MI_MAT_UBER = 5,
+    MI_MAT_SUBSTRATE = 6, MI_MAT_TRANSLUCENT = 7, MI_MAT_MIX = 8
+};
+typedef struct mi_material_desc {
+    int32_t type;            /* mi_material_type */
+    int32_t textured;
+    int32_t remap_roughness;
+    int32_t bump;            /* float node */
+    int32_t Kd, Ks, Kr, Kt;  /* spectrum nodes */
+    int32_t opacity;         /* uber */
+    int32_t eta_s, k_s;      /* metal: eta, k (spectrum) */
+    int32_t amount;          /* mix: spectrum node */
+    int32_t sigma, roughness, uroughness, vroughness; /* float nodes */
+    int32_t eta_f;           /* glass / uber: "eta" | "index" (float node) */
+    int32_t reflect, transmit; /* translucent (spectrum nodes) */
+    int32_t m1, m2;          /* mix: indices into materials[] / material_descs[] */
+    int32_t pad;
+} mi_material_desc;
 
 /* ---------------------------------------------------------------- lights ------------ */
 
@@ -244,6 +323,15 @@ typedef struct mi_scene_desc {
     uint32_t n_spheres;
     const mi_envmap *envmaps;
     const mi_sphere *spheres;
+    /* textures (row f2): node table, image pyramids, per-material parameter nodes (NULL or n_materials entries), and
+     * per-mesh alpha masks: mesh_alpha[2*m] = TriangleMesh::alphaMask, [2*m+1] = shadowAlphaMask as float nodes, -1 = none
+     * (triangle.cpp:333-338,532-570); NULL when no mesh has one */
+    uint32_t n_textures;
+    uint32_t n_images;
+    const mi_texture *textures;
+    const mi_image *images;
+    const mi_material_desc *material_descs;
+    const int32_t *mesh_alpha;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

@@ -1101,6 +1101,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
     if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
+    if (d->material_descs || d->mesh_alpha)   // no silent approximation: refuse until the device evaluates textures itself
+        return fail("mi_scene_upload: the scene has image / procedural textures, bump maps or alpha masks (SURVEY.md s.8 row f2); "
+                    "this build of the device library carries the host + oracle side of that row only");
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();

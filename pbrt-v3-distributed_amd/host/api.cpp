@@ -110,6 +110,7 @@ void pbrtInit(const Options &opt) {
     if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
     currentApiState = APIState::OptionsBlock;
     renderOptions.reset(new RenderOptions);
+    ResetTextures();
     graphicsState = GraphicsState();
     curTransform = TransformSet();
     activeTransformBits = AllTransformsBits;
@@ -227,7 +228,7 @@ void pbrtTransformEnd() {
     activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
 }
 
-// MakeFloatTexture / MakeSpectrumTexture (api.cpp:613-731), constant-folded
+// pbrtTexture (api.cpp:1193-1243): the node goes into the graphics state's name map (copy-on-write there, a plain copy here)
 void pbrtTexture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &params) {
     VERIFY_WORLD("Texture");
     TextureParams tp(params, params, graphicsState.textures);
@@ -236,24 +237,10 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
     if ((isFloat && graphicsState.textures.floats.count(name)) || (isSpec && graphicsState.textures.spectra.count(name)))
         Warning("Texture \"%s\" being redefined", name.c_str());
     WARN_IF_ANIMATED_TRANSFORM("Texture");
-    if (texname == "constant") {   // textures/constant.cpp
-        if (isFloat) graphicsState.textures.floats[name] = tp.FindFloat("value", 1.f);
-        else graphicsState.textures.spectra[name] = params.FindOneSpectrum("value", RGB(1.f));
-    } else if (texname == "scale") {   // textures/scale.cpp: tex1 * tex2
-        if (isFloat) graphicsState.textures.floats[name] = tp.GetFloat("tex1", 1.f) * tp.GetFloat("tex2", 1.f);
-        else graphicsState.textures.spectra[name] = tp.GetSpectrum("tex1", RGB(1.f)) * tp.GetSpectrum("tex2", RGB(1.f));
-    } else if (texname == "mix") {     // textures/mix.h: (1 - amt) * t1 + amt * t2
-        Float amt = tp.GetFloat("amount", 0.5f);
-        if (isFloat) graphicsState.textures.floats[name] = (1 - amt) * tp.GetFloat("tex1", 0.f) + amt * tp.GetFloat("tex2", 1.f);
-        else graphicsState.textures.spectra[name] = tp.GetSpectrum("tex1", RGB(0.f)) * (1 - amt) + tp.GetSpectrum("tex2", RGB(1.f)) * amt;
-    } else {
-        Warning("Texture \"%s\" of class \"%s\" is outside this path's scope (image/procedural textures: SURVEY.md s.8 "
-                "row f2); a mid-grey constant is substituted.", name.c_str(), texname.c_str());
-        if (isFloat) graphicsState.textures.floats[name] = 1.f;
-        else graphicsState.textures.spectra[name] = RGB(0.5f);
-        return;
-    }
-    params.ReportUnused();
+    int node = isFloat ? MakeFloatTexture(texname, curTransform[0], tp) : MakeSpectrumTexture(texname, curTransform[0], tp);
+    if (node < 0) return;
+    if (isFloat) graphicsState.textures.floats[name] = node;
+    else graphicsState.textures.spectra[name] = node;
 }
 
 static std::map<std::string, std::shared_ptr<Material>> namedMaterialMap() {
@@ -375,6 +362,21 @@ void pbrtShape(const std::string &name, const ParamSet &params) {
     } else {
         shape = MakeShapes(name, curTransform[0], graphicsState.reverseOrientation, params);
         if (!shape || shape->nTriangles() == 0) return;
+        if (name == "trianglemesh" || name == "plymesh") {   // alpha masks: triangle.cpp:717-741, plymesh.cpp:259-286
+            auto alphaNode = [&](const char *pname) -> int {
+                std::string tn = params.FindTexture(pname);
+                if (tn != "") {
+                    auto it = graphicsState.textures.floats.find(tn);
+                    if (it != graphicsState.textures.floats.end()) return it->second;
+                    Error("Couldn't find float texture \"%s\" for \"%s\" parameter", tn.c_str(), pname);
+                    return -1;
+                }
+                if (params.FindOneFloat(pname, 1.f) == 0.f) return ConstantTextureNode(false, RGB(0.f));
+                return -1;
+            };
+            shape->alphaTex = alphaNode("alpha");
+            shape->shadowAlphaTex = alphaNode("shadowalpha");
+        }
     }
     // GraphicsState::GetMaterialForShape (api.cpp:1771-1800): shape parameters may override material ones
     std::shared_ptr<Material> mtl;
@@ -621,6 +623,7 @@ void pbrtWorldEnd() {
         }
         renderOptions->AcceleratorParams.ReportUnused();
         scene.reset(new Scene(accel, std::move(renderOptions->primitives), std::move(renderOptions->lights)));
+        scene->textures = CurrentTextures();
     }
     if (scene && integrator) {
         if (PbrtOptions.deferRender) {

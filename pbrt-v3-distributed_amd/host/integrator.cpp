@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <functional>
 
 #include "api.h"
 
@@ -58,12 +59,19 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     fs->P.resize(3 * nv);
     if (anyN) fs->N.assign(3 * nv, 0.f);
     if (anyUV) fs->UV.assign(2 * nv, 0.f);
-    // materials: identical BxDF lists share one slot (sort key of the shading kernels)
-    auto materialIndex = [&](const std::shared_ptr<Material> &m) -> int {
+    // materials: identical BxDF lists (constant materials) / identical parameter nodes (textured ones) share one slot,
+    // the sort key of the shading kernels; a textured mix refers to its two sub-materials by slot
+    std::function<int(const std::shared_ptr<Material> &)> materialIndex = [&](const std::shared_ptr<Material> &m) -> int {
         if (!m) return -1;
-        for (size_t k = 0; k < fs->materials.size(); ++k)
-            if (std::memcmp(&fs->materials[k], &m->bsdf, sizeof(mi_material)) == 0) return (int)k;
+        mi_material_desc md = m->desc;
+        if (md.type == MI_MAT_MIX && md.textured) { md.m1 = materialIndex(m->m1); md.m2 = materialIndex(m->m2); }
+        for (size_t k = 0; k < fs->materials.size(); ++k) {
+            if (md.textured != fs->materialDescs[k].textured) continue;
+            if (md.textured ? std::memcmp(&fs->materialDescs[k], &md, sizeof(md)) == 0
+                            : std::memcmp(&fs->materials[k], &m->bsdf, sizeof(mi_material)) == 0) return (int)k;
+        }
         fs->materials.push_back(m->bsdf);
+        fs->materialDescs.push_back(md);
         return (int)fs->materials.size() - 1;
     };
     fs->meshes.resize(prims.size());
@@ -82,6 +90,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         if (mesh.reverseOrientation ^ mesh.transformSwapsHandedness) flags |= MI_MESH_FLIP;
         fs->meshes[i].flags = flags;
         fs->meshes[i].material = materialIndex(prims[i].material);
+        fs->meshAlpha.push_back(mesh.alphaTex); fs->meshAlpha.push_back(mesh.shadowAlphaTex);
     }
     // --- triangles in BVH primitive order
     size_t nTris = bvh.primitives.size();
@@ -210,6 +219,25 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
     d.n_spheres = (uint32_t)fs->spheres.size(); d.spheres = fs->spheres.empty() ? nullptr : fs->spheres.data();
     d.n_envmaps = (uint32_t)fs->envmaps.size(); d.envmaps = fs->envmaps.empty() ? nullptr : fs->envmaps.data();
+    // textures: the parse's node table and image pyramids (kept alive by texKeep)
+    bool anyAlpha = false, anyTextured = false;
+    for (int32_t a : fs->meshAlpha) anyAlpha |= a >= 0;
+    for (const mi_material_desc &md : fs->materialDescs) anyTextured |= md.textured != 0;
+    if (scene.textures && (anyAlpha || anyTextured)) {
+        fs->texKeep = scene.textures;
+        fs->textures = scene.textures->nodes;
+        for (const auto &im : scene.textures->images) {
+            mi_image mi;
+            std::memset(&mi, 0, sizeof(mi));
+            mi.width = im->width; mi.height = im->height; mi.levels = im->levels; mi.channels = im->channels;
+            mi.trilinear = im->trilinear; mi.wrap = im->wrap; mi.max_aniso = im->maxAniso; mi.texels = im->texels.data();
+            fs->images.push_back(mi);
+        }
+        d.n_textures = (uint32_t)fs->textures.size(); d.textures = fs->textures.data();
+        d.n_images = (uint32_t)fs->images.size(); d.images = fs->images.empty() ? nullptr : fs->images.data();
+    }
+    d.material_descs = anyTextured ? fs->materialDescs.data() : nullptr;
+    d.mesh_alpha = anyAlpha ? fs->meshAlpha.data() : nullptr;
     d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
     d.integrator.spatial_max_voxels = 64;
     copyMatrix(d.camera.raster_to_camera, camera->RasterToCamera.m);

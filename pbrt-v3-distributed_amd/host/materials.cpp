@@ -1,8 +1,10 @@
 // Material factories (host).  Each Create*Material reads the same parameters with the same
-// defaults as the reference factory, then performs the reference's
+// defaults as the reference factory and records the parameter textures as nodes (mi_material_desc).
+// When every parameter is hit-independent (constants, scale / mix of constants) and there is no bump
+// map, it also performs the reference's
 // ComputeScatteringFunctions(si, arena, TransportMode::Radiance, allowMultipleLobes=true)
-// once -- legal here because every texture on this path is constant -- and records the BxDFs
-// it would Add(), in order, as mi_bxdf PODs.  File:line of each reference routine is cited.
+// once and records the BxDFs it would Add(), in order, as mi_bxdf PODs; otherwise the device builds the
+// same list per hit from the desc.  File:line of each reference routine is cited.
 #include "scene.h"
 
 namespace pbrt_amd {
@@ -57,24 +59,57 @@ static mi_bxdf specT(const RGB &t, Float etaA, Float etaB) {
     return b;
 }
 
-static std::shared_ptr<Material> newMat(const std::string &type, Float eta = 1) {
+static std::shared_ptr<Material> newMat(const std::string &type, int descType, Float eta = 1) {
     auto m = std::make_shared<Material>();
     m->type = type;
     std::memset(&m->bsdf, 0, sizeof(m->bsdf));
     m->bsdf.eta = eta;
+    std::memset(&m->desc, 0xff, sizeof(m->desc));   // every node index -1
+    m->desc.type = descType; m->desc.textured = 0; m->desc.remap_roughness = 0; m->desc.pad = 0;
     return m;
 }
-static void warnBump(const TextureParams &mp) {
-    Float dummy;
-    if (mp.geom().FindTexture("bumpmap") != "" || mp.mat().FindTexture("bumpmap") != "" || mp.GetFloatOrNull("bumpmap", &dummy))
-        Warning("bump mapping is not supported by this path (SURVEY.md s.8 row f2); ignored");
-}
+
+// The parameter textures of one material: node ids for the desc, folded values for the constant path.
+// `textured` turns on as soon as one parameter depends on the hit, or a bump map is present (Material::Bump changes
+// the shading frame even for a constant displacement when the mesh has shading normals, material.cpp:73-80).
+struct ParamNodes {
+    const TextureParams &mp;
+    std::shared_ptr<TextureStore> st = CurrentTextures();
+    bool textured = false;
+    explicit ParamNodes(const TextureParams &mp) : mp(mp) {}
+    int spec(const char *n, const RGB &def, RGB *v) {
+        int t = mp.GetSpectrumTexture(n, def);
+        if (!st->Fold(t, v)) { textured = true; *v = def; }
+        return t;
+    }
+    int flt(const char *n, Float def, Float *v) {
+        int t = mp.GetFloatTexture(n, def);
+        RGB r;
+        if (st->Fold(t, &r)) *v = r.c[0]; else { textured = true; *v = def; }
+        return t;
+    }
+    int fltOrNull(const char *n, Float *v, bool *has) {
+        int t = mp.GetFloatTextureOrNull(n);
+        *has = t >= 0;
+        RGB r;
+        if (t >= 0) { if (st->Fold(t, &r)) *v = r.c[0]; else textured = true; }
+        return t;
+    }
+    int bump() {
+        int t = mp.GetFloatTextureOrNull("bumpmap");
+        if (t >= 0) textured = true;
+        return t;
+    }
+};
 
 static std::shared_ptr<Material> CreateMatte(const TextureParams &mp) {   // matte.cpp:45-72
-    RGB Kd = mp.GetSpectrum("Kd", RGB(0.5f));
-    Float sigma = mp.GetFloat("sigma", 0.f);
-    warnBump(mp);
-    auto m = newMat("matte");
+    ParamNodes pn(mp);
+    RGB Kd; Float sigma;
+    auto m = newMat("matte", MI_MAT_MATTE);
+    m->desc.Kd = pn.spec("Kd", RGB(0.5f), &Kd);
+    m->desc.sigma = pn.flt("sigma", 0.f, &sigma);
+    m->desc.bump = pn.bump();
+    if ((m->desc.textured = pn.textured)) return m;
     RGB r = Kd.Clamp();
     Float sig = Clamp(sigma, 0, 90);
     if (!r.IsBlack()) add(m->bsdf, sig == 0 ? lambertR(r) : orenNayar(r, sig));
@@ -82,11 +117,15 @@ static std::shared_ptr<Material> CreateMatte(const TextureParams &mp) {   // mat
 }
 
 static std::shared_ptr<Material> CreatePlastic(const TextureParams &mp) {   // plastic.cpp:45-85
-    RGB Kd = mp.GetSpectrum("Kd", RGB(0.25f)), Ks = mp.GetSpectrum("Ks", RGB(0.25f));
-    Float rough = mp.GetFloat("roughness", .1f);
-    warnBump(mp);
+    ParamNodes pn(mp);
+    RGB Kd, Ks; Float rough;
+    auto m = newMat("plastic", MI_MAT_PLASTIC);
+    m->desc.Kd = pn.spec("Kd", RGB(0.25f), &Kd); m->desc.Ks = pn.spec("Ks", RGB(0.25f), &Ks);
+    m->desc.roughness = pn.flt("roughness", .1f, &rough);
+    m->desc.bump = pn.bump();
     bool remap = mp.FindBool("remaproughness", true);
-    auto m = newMat("plastic");
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
     RGB kd = Kd.Clamp();
     if (!kd.IsBlack()) add(m->bsdf, lambertR(kd));
     RGB ks = Ks.Clamp();
@@ -98,13 +137,19 @@ static std::shared_ptr<Material> CreatePlastic(const TextureParams &mp) {   // p
 }
 
 static std::shared_ptr<Material> CreateGlass(const TextureParams &mp) {   // glass.cpp:45-110
-    RGB Kr = mp.GetSpectrum("Kr", RGB(1.f)), Kt = mp.GetSpectrum("Kt", RGB(1.f));
-    Float eta;
-    if (!mp.GetFloatOrNull("eta", &eta)) eta = mp.GetFloat("index", 1.5f);
-    Float urough = mp.GetFloat("uroughness", 0.f), vrough = mp.GetFloat("vroughness", 0.f);
-    warnBump(mp);
+    ParamNodes pn(mp);
+    RGB Kr, Kt; Float eta = 1.5f, urough, vrough;
+    bool hasEta;
+    auto m = newMat("glass", MI_MAT_GLASS);
+    m->desc.Kr = pn.spec("Kr", RGB(1.f), &Kr); m->desc.Kt = pn.spec("Kt", RGB(1.f), &Kt);
+    m->desc.eta_f = pn.fltOrNull("eta", &eta, &hasEta);
+    if (!hasEta) m->desc.eta_f = pn.flt("index", 1.5f, &eta);
+    m->desc.uroughness = pn.flt("uroughness", 0.f, &urough); m->desc.vroughness = pn.flt("vroughness", 0.f, &vrough);
+    m->desc.bump = pn.bump();
     bool remap = mp.FindBool("remaproughness", true);
-    auto m = newMat("glass", eta);
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
+    m->bsdf.eta = eta;
     RGB R = Kr.Clamp(), T = Kt.Clamp();
     if (R.IsBlack() && T.IsBlack()) return m;
     bool isSpecular = urough == 0 && vrough == 0;
@@ -121,9 +166,12 @@ static std::shared_ptr<Material> CreateGlass(const TextureParams &mp) {   // gla
 }
 
 static std::shared_ptr<Material> CreateMirror(const TextureParams &mp) {   // mirror.cpp:45-65
-    RGB Kr = mp.GetSpectrum("Kr", RGB(0.9f));
-    warnBump(mp);
-    auto m = newMat("mirror");
+    ParamNodes pn(mp);
+    RGB Kr;
+    auto m = newMat("mirror", MI_MAT_MIRROR);
+    m->desc.Kr = pn.spec("Kr", RGB(0.9f), &Kr);
+    m->desc.bump = pn.bump();
+    if ((m->desc.textured = pn.textured)) return m;
     RGB R = Kr.Clamp();
     if (!R.IsBlack()) add(m->bsdf, specR(R, MI_FRESNEL_NOOP, 1, 1));
     return m;
@@ -133,12 +181,17 @@ static std::shared_ptr<Material> CreateMetal(const TextureParams &mp) {   // met
     // Default eta/k: copper SPD -> RGB via Spectrum::FromSampled (metal.cpp:81-118).  The two RGB
     // triples below are those values as produced by the reference build (oracle/ref_build probe).
     RGB copperN(0.19999069f, 0.92208463f, 1.09987593f), copperK(3.90463543f, 2.44763327f, 2.13765264f);
-    RGB eta = mp.GetSpectrum("eta", copperN), k = mp.GetSpectrum("k", copperK);
-    Float rough = mp.GetFloat("roughness", .01f), u, v;
-    bool hasU = mp.GetFloatOrNull("uroughness", &u), hasV = mp.GetFloatOrNull("vroughness", &v);
-    warnBump(mp);
+    ParamNodes pn(mp);
+    RGB eta, k; Float rough, u = 0, v = 0;
+    bool hasU, hasV;
+    auto m = newMat("metal", MI_MAT_METAL);
+    m->desc.eta_s = pn.spec("eta", copperN, &eta); m->desc.k_s = pn.spec("k", copperK, &k);
+    m->desc.roughness = pn.flt("roughness", .01f, &rough);
+    m->desc.uroughness = pn.fltOrNull("uroughness", &u, &hasU); m->desc.vroughness = pn.fltOrNull("vroughness", &v, &hasV);
+    m->desc.bump = pn.bump();
     bool remap = mp.FindBool("remaproughness", true);
-    auto m = newMat("metal");
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
     Float uRough = hasU ? u : rough, vRough = hasV ? v : rough;
     if (remap) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
     mi_bxdf b = microR(RGB(1.f), uRough, vRough, MI_FRESNEL_CONDUCTOR, 1.f, 1.f);
@@ -148,23 +201,28 @@ static std::shared_ptr<Material> CreateMetal(const TextureParams &mp) {   // met
 }
 
 static std::shared_ptr<Material> CreateUber(const TextureParams &mp) {   // uber.cpp:45-135
-    RGB Kd = mp.GetSpectrum("Kd", RGB(0.25f)), Ks = mp.GetSpectrum("Ks", RGB(0.25f));
-    RGB Kr = mp.GetSpectrum("Kr", RGB(0.f)), Kt = mp.GetSpectrum("Kt", RGB(0.f));
-    Float rough = mp.GetFloat("roughness", .1f), ur, vr;
-    bool hasU = mp.GetFloatOrNull("uroughness", &ur), hasV = mp.GetFloatOrNull("vroughness", &vr);
-    Float e;
-    if (!mp.GetFloatOrNull("eta", &e)) e = mp.GetFloat("index", 1.5f);
-    RGB opacity = mp.GetSpectrum("opacity", RGB(1.f));
-    warnBump(mp);
+    ParamNodes pn(mp);
+    RGB Kd, Ks, Kr, Kt, opacity; Float rough, ur = 0, vr = 0, e = 1.5f;
+    bool hasU, hasV, hasEta;
+    auto m = newMat("uber", MI_MAT_UBER);
+    m->desc.Kd = pn.spec("Kd", RGB(0.25f), &Kd); m->desc.Ks = pn.spec("Ks", RGB(0.25f), &Ks);
+    m->desc.Kr = pn.spec("Kr", RGB(0.f), &Kr); m->desc.Kt = pn.spec("Kt", RGB(0.f), &Kt);
+    m->desc.roughness = pn.flt("roughness", .1f, &rough);
+    m->desc.uroughness = pn.fltOrNull("uroughness", &ur, &hasU); m->desc.vroughness = pn.fltOrNull("vroughness", &vr, &hasV);
+    m->desc.eta_f = pn.fltOrNull("eta", &e, &hasEta);
+    if (!hasEta) m->desc.eta_f = pn.flt("index", 1.5f, &e);
+    m->desc.opacity = pn.spec("opacity", RGB(1.f), &opacity);
+    m->desc.bump = pn.bump();
     bool remap = mp.FindBool("remaproughness", true);
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
     RGB op = opacity.Clamp();
     RGB t = (-op + RGB(1.f)).Clamp();
-    std::shared_ptr<Material> m;
     if (!t.IsBlack()) {
-        m = newMat("uber", 1.f);
+        m->bsdf.eta = 1.f;
         add(m->bsdf, specT(t, 1.f, 1.f));
     } else
-        m = newMat("uber", e);
+        m->bsdf.eta = e;
     RGB kd = op * Kd.Clamp();
     if (!kd.IsBlack()) add(m->bsdf, lambertR(kd));
     RGB ks = op * Ks.Clamp();
@@ -182,11 +240,15 @@ static std::shared_ptr<Material> CreateUber(const TextureParams &mp) {   // uber
 }
 
 static std::shared_ptr<Material> CreateSubstrate(const TextureParams &mp) {   // substrate.cpp:45-81
-    RGB Kd = mp.GetSpectrum("Kd", RGB(.5f)), Ks = mp.GetSpectrum("Ks", RGB(.5f));
-    Float roughu = mp.GetFloat("uroughness", .1f), roughv = mp.GetFloat("vroughness", .1f);
-    warnBump(mp);
+    ParamNodes pn(mp);
+    RGB Kd, Ks; Float roughu, roughv;
+    auto m = newMat("substrate", MI_MAT_SUBSTRATE);
+    m->desc.Kd = pn.spec("Kd", RGB(.5f), &Kd); m->desc.Ks = pn.spec("Ks", RGB(.5f), &Ks);
+    m->desc.uroughness = pn.flt("uroughness", .1f, &roughu); m->desc.vroughness = pn.flt("vroughness", .1f, &roughv);
+    m->desc.bump = pn.bump();
     bool remap = mp.FindBool("remaproughness", true);
-    auto m = newMat("substrate");
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
     RGB d = Kd.Clamp(), s = Ks.Clamp();
     if (!d.IsBlack() || !s.IsBlack()) {
         if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
@@ -198,13 +260,17 @@ static std::shared_ptr<Material> CreateSubstrate(const TextureParams &mp) {   //
 }
 
 static std::shared_ptr<Material> CreateTranslucent(const TextureParams &mp) {   // translucent.cpp:45-98
-    RGB Kd = mp.GetSpectrum("Kd", RGB(0.25f)), Ks = mp.GetSpectrum("Ks", RGB(0.25f));
-    RGB reflect = mp.GetSpectrum("reflect", RGB(0.5f)), transmit = mp.GetSpectrum("transmit", RGB(0.5f));
-    Float rough = mp.GetFloat("roughness", .1f);
-    warnBump(mp);
-    bool remap = mp.FindBool("remaproughness", true);
+    ParamNodes pn(mp);
+    RGB Kd, Ks, reflect, transmit; Float rough;
     Float eta = 1.5f;
-    auto m = newMat("translucent", eta);
+    auto m = newMat("translucent", MI_MAT_TRANSLUCENT, eta);
+    m->desc.Kd = pn.spec("Kd", RGB(0.25f), &Kd); m->desc.Ks = pn.spec("Ks", RGB(0.25f), &Ks);
+    m->desc.reflect = pn.spec("reflect", RGB(0.5f), &reflect); m->desc.transmit = pn.spec("transmit", RGB(0.5f), &transmit);
+    m->desc.roughness = pn.flt("roughness", .1f, &rough);
+    m->desc.bump = pn.bump();
+    bool remap = mp.FindBool("remaproughness", true);
+    m->desc.remap_roughness = remap;
+    if ((m->desc.textured = pn.textured)) return m;
     RGB r = reflect.Clamp(), t = transmit.Clamp();
     if (r.IsBlack() && t.IsBlack()) return m;
     RGB kd = Kd.Clamp();
@@ -223,12 +289,16 @@ static std::shared_ptr<Material> CreateTranslucent(const TextureParams &mp) {   
 
 static std::shared_ptr<Material> CreateMix(const TextureParams &mp, const std::shared_ptr<Material> &m1,
                                            const std::shared_ptr<Material> &m2) {   // mixmat.cpp:46-77
-    RGB amount = mp.GetSpectrum("amount", RGB(0.5f));
+    ParamNodes pn(mp);
+    RGB amount;
+    // MixMaterial builds on m1's BSDF (its eta) and wraps every lobe in ScaledBxDF
+    auto m = newMat("mix", MI_MAT_MIX, m1 ? m1->bsdf.eta : 1.f);
+    m->desc.amount = pn.spec("amount", RGB(0.5f), &amount);
+    if (!m1 || !m2) { Error("mix material needs two non-null materials"); return m; }
+    m->m1 = m1; m->m2 = m2;
+    if ((m->desc.textured = (pn.textured || m1->desc.textured || m2->desc.textured))) return m;
     RGB s1 = amount.Clamp();
     RGB s2 = (RGB(1.f) - s1).Clamp();
-    // MixMaterial builds on m1's BSDF (its eta) and wraps every lobe in ScaledBxDF
-    auto m = newMat("mix", m1 ? m1->bsdf.eta : 1.f);
-    if (!m1 || !m2) { Error("mix material needs two non-null materials"); return m; }
     auto wrap = [&](const mi_bxdf &src, const RGB &s) {
         mi_bxdf b = src;
         if (b.scaled) {   // nested mix: ScaledBxDF(ScaledBxDF(x, a), s) == s * (a * f); fold (1-ulp order difference)

@@ -75,25 +75,33 @@ class ParamSet {
     std::vector<Item> items_;
 };
 
-// Constant-folded textures: this slice supports "constant", "scale" and "mix" of constants
-// (textures/constant.h, scale.h, mix.h); anything else warns and evaluates to its default.
+// Named textures of the graphics state (api.cpp:224-230): name -> node of the parse's TextureStore (host/texture.cpp).
 struct TextureMaps {
-    std::map<std::string, Float> floats;
-    std::map<std::string, RGB> spectra;
+    std::map<std::string, int> floats;
+    std::map<std::string, int> spectra;
 };
 
 class TextureParams {   // core/paramset.h:173-217: geometry params shadow material params
   public:
     TextureParams(const ParamSet &geom, const ParamSet &mat, const TextureMaps &tex)
         : geom_(geom), mat_(mat), tex_(tex) {}
-    RGB GetSpectrum(const std::string &n, const RGB &def) const;      // GetSpectrumTexture -> constant
-    Float GetFloat(const std::string &n, Float def) const;            // GetFloatTexture -> constant
-    bool GetFloatOrNull(const std::string &n, Float *out) const;      // GetFloatTextureOrNull
+    // texture nodes (paramset.cpp:720-836): a named texture, or a constant node made from the inline value / default;
+    // the ...OrNull form returns -1 where the reference returns nullptr
+    int GetSpectrumTexture(const std::string &n, const RGB &def) const;
+    int GetSpectrumTextureOrNull(const std::string &n) const;
+    int GetFloatTexture(const std::string &n, Float def) const;
+    int GetFloatTextureOrNull(const std::string &n) const;
     Float FindFloat(const std::string &n, Float d) const { return geom_.FindOneFloat(n, mat_.FindOneFloat(n, d)); }
+    int FindInt(const std::string &n, int d) const { return geom_.FindOneInt(n, mat_.FindOneInt(n, d)); }
     bool FindBool(const std::string &n, bool d) const { return geom_.FindOneBool(n, mat_.FindOneBool(n, d)); }
     std::string FindString(const std::string &n, const std::string &d = "") const {
         return geom_.FindOneString(n, mat_.FindOneString(n, d));
     }
+    std::string FindFilename(const std::string &n, const std::string &d = "") const {
+        return geom_.FindOneFilename(n, mat_.FindOneFilename(n, d));
+    }
+    Vec3 FindVector3f(const std::string &n, const Vec3 &d) const { return geom_.FindOneVector3(n, mat_.FindOneVector3(n, d)); }
+    RGB FindSpectrum(const std::string &n, const RGB &d) const { return geom_.FindOneSpectrum(n, mat_.FindOneSpectrum(n, d)); }
     void ReportUnused() const { geom_.ReportUnused(); mat_.ReportUnused(); }
     const ParamSet &geom() const { return geom_; }
     const ParamSet &mat() const { return mat_; }

@@ -5,6 +5,7 @@
 // triangle on Triangle/GeometricPrimitive/shared_ptr blocks) and the whole
 // Scene flattens to the POD mi_scene_desc of include/pbrt_amd.h.
 #pragma once
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@ struct TriangleMesh {
     std::vector<Float> uv;      // 2 per vertex, empty if absent
     std::vector<int> indices;   // 3 per triangle
     bool reverseOrientation = false, transformSwapsHandedness = false;
+    int alphaTex = -1, shadowAlphaTex = -1;   // TriangleMesh::alphaMask / shadowAlphaMask as float texture nodes (triangle.h:66-67)
     int nTriangles() const { return (int)indices.size() / 3; }
 };
 // CreateTriangleMesh (triangle.cpp:94-110) / CreateTriangleMeshShape (:648-744) / CreatePLYMesh
@@ -37,10 +39,35 @@ std::shared_ptr<TriangleMesh> CreateSphereMesh(const Transform &o2w, bool ro, co
 // MakeShapes (api.cpp:430-539)
 std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps);
 
-// ---- Material (core/material.h:51-61): ComputeScatteringFunctions folded to its constant BxDF list
+// ---- Textures (core/texture.h, core/mipmap.h, textures/*): POD nodes + image pyramids, owned per parse
+struct ImagePyramid {   // MIPMap<T> after its constructor
+    int width = 0, height = 0, levels = 0, channels = 0, wrap = 0;
+    bool trilinear = false;
+    Float maxAniso = 8;
+    std::vector<Float> texels;   // all levels, finest first
+};
+struct TextureStore {
+    std::vector<mi_texture> nodes;
+    std::vector<std::shared_ptr<ImagePyramid>> images;
+    std::map<std::string, int> imageCache;   // ImageTexture::textures keyed by TexInfo (imagemap.h:51-75)
+    bool Fold(int node, RGB *out) const;     // value of a hit-independent node (constant / scale / mix of such)
+};
+std::shared_ptr<TextureStore> CurrentTextures();   // of the parse in progress
+void ResetTextures();
+int ConstantTextureNode(bool spectrum, const RGB &v);
+int MakeFloatTexture(const std::string &name, const Transform &tex2world, const TextureParams &tp);      // api.cpp:613-647
+int MakeSpectrumTexture(const std::string &name, const Transform &tex2world, const TextureParams &tp);   // api.cpp:649-683
+std::shared_ptr<ImagePyramid> BuildMIPMap(int w, int h, int channels, std::vector<Float> img, bool doTrilinear, Float maxAniso, int wrap);
+bool ReadImage(const std::string &name, std::vector<Float> *rgb, int *w, int *h);   // imageio.cpp:60-79 (.pfm .png .tga)
+bool HasExtension(const std::string &name, const char *ext);
+
+// ---- Material (core/material.h:51-61).  `desc` = the parameter textures; when all of them are hit-independent
+// (desc.textured == 0) `bsdf` holds what ComputeScatteringFunctions(allowMultipleLobes=true, Radiance) builds.
 struct Material {
     std::string type;
-    mi_material bsdf;   // what ComputeScatteringFunctions(allowMultipleLobes=true, Radiance) builds
+    mi_material bsdf;
+    mi_material_desc desc;
+    std::shared_ptr<Material> m1, m2;   // MixMaterial
 };
 // MakeMaterial (api.cpp:541-611); returns nullptr for "" / "none"
 std::shared_ptr<Material> MakeMaterial(const std::string &name, const TextureParams &mp,
@@ -169,6 +196,7 @@ class Scene {
     std::vector<GeometricPrimitive> primitives;
     std::vector<LightEntry> lights;   // scene.lights order; area lights expand to one light per triangle
     Bounds3 worldBound;
+    std::shared_ptr<TextureStore> textures;   // nodes / images the materials and alpha masks refer to
 };
 
 // ---- Integrator (core/integrator.h:53-58) and the GPU path integrator
@@ -190,6 +218,11 @@ struct FlatScene {
     std::vector<mi_envmap> envmaps;
     std::vector<mi_sphere> spheres;
     std::vector<std::shared_ptr<EnvMap>> envKeep;
+    std::vector<mi_texture> textures;
+    std::vector<mi_image> images;
+    std::vector<mi_material_desc> materialDescs;
+    std::vector<int32_t> meshAlpha;
+    std::shared_ptr<TextureStore> texKeep;
 };
 
 class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)

@@ -33,6 +33,8 @@ WorldEnd
 
 
 def scene(name):
+    if name.startswith("tex_"):
+        return tex_scene(name)
     if name == "infinite":      # constant InfiniteAreaLight: escaped-ray emission, light sampling + MIS, two lights -> spatial strategy
         return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
     if name == "infinite_only":  # a single light: CreateLightSampleDistribution substitutes uniform (lightdistrib.cpp:50)
@@ -83,3 +85,126 @@ def scene(name):
 
 
 NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "spheres", "dof", "crop", "clamp", "empty", "onetri"]
+
+# ---- textured variants: image / procedural textures, mappings, bump maps, alpha masks
+TEX = os.path.join(ROOT, "scenes", "textures")
+_TEXHEAD = '''LookAt 0 2.4 -6  0 0.7 0  0 1 0
+Camera "perspective" "float fov" [38]
+Sampler "sobol" "integer pixelsamples" [4]
+PixelFilter "box"
+Integrator "path" "integer maxdepth" [4]
+Film "image" "integer xresolution" [72] "integer yresolution" [48] "string filename" "e.pfm"
+WorldBegin
+LightSource "point" "point from" [3 5 -3] "rgb I" [60 56 50]
+LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1.5 1.5 1.6]
+'''
+# ground quad (uv 0..4), a tilted panel (uv 0..1), a smooth-normal "bulge" mesh (3x3 grid with per-vertex normals and uv), a back wall
+_GROUND = 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4] "float uv" [0 0 4 0 4 4 0 4]\n'
+_PANEL = 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-2.4 0.1 .6  -.6 0.1 1.2  -.6 1.7 1.2  -2.4 1.7 .6] "float uv" [0 0 1 0 1 1 0 1]\n'
+_WALL = 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 3  4 0 3  4 3 3  -4 3 3] "float uv" [0 0 2 0 2 1 0 1]\n'
+
+
+def _bulge():
+    import math
+    P, N, UV, I = [], [], [], []
+    n = 5
+    for j in range(n):
+        for i in range(n):
+            u, v = i / (n - 1), j / (n - 1)
+            x, z = .5 + 1.8 * u, -.6 + 1.4 * v
+            hgt = .25 + .35 * math.sin(math.pi * u) * math.sin(math.pi * v)
+            dhx = .35 * math.pi * math.cos(math.pi * u) * math.sin(math.pi * v) / 1.8
+            dhz = .35 * math.pi * math.sin(math.pi * u) * math.cos(math.pi * v) / 1.4
+            l = math.sqrt(dhx * dhx + 1 + dhz * dhz)
+            P += [x, hgt, z]; N += [-dhx / l, 1 / l, -dhz / l]; UV += [u, v]
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i
+            I += [a, a + n, a + 1, a + 1, a + n, a + n + 1]
+    f = lambda xs: " ".join("%.6g" % x for x in xs)
+    return 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]\n' % (" ".join(map(str, I)), f(P), f(N), f(UV))
+
+
+def tex_scene(name):
+    T = lambda f: os.path.join(TEX, f)
+    w = _TEXHEAD
+    if name == "tex_imagemap":      # EWA (default) lookups of a non-power-of-two PNG (gamma), a TGA with clamp wrap + trilinear, an HDR PFM with scale; float imagemap as roughness
+        w += ('Texture "col" "color" "imagemap" "string filename" "%s" "float uscale" [2] "float vscale" [2]\n' % T("color_23x17.png") +
+              'Texture "noise" "color" "imagemap" "string filename" "%s" "bool trilinear" ["true"] "string wrap" "clamp" "float udelta" [-.2]\n' % T("noise_16x8.tga") +
+              'Texture "hdr" "color" "imagemap" "string filename" "%s" "float scale" [.6] "string wrap" "black" "float maxanisotropy" [4]\n' % T("hdr_12x10.pfm") +
+              'Texture "rough" "float" "imagemap" "string filename" "%s" "float scale" [.4] "bool gamma" ["false"]\n' % T("height_32.png") +
+              'Texture "pal" "color" "imagemap" "string filename" "%s"\n' % T("palette_8.png") +
+              'Material "matte" "texture Kd" "col"\n' + _GROUND +
+              'Material "plastic" "texture Kd" "noise" "rgb Ks" [.4 .4 .4] "texture roughness" "rough"\n' + _PANEL +
+              'Material "matte" "texture Kd" "hdr" "float sigma" [20]\n' + _bulge() +
+              'Material "matte" "texture Kd" "pal"\n' + _WALL)
+    elif name == "tex_procedural":  # checkerboard 2D (closed form + none) and 3D, dots, uv, bilerp, mix and scale of textures
+        w += ('Texture "ch" "color" "checkerboard" "float uscale" [6] "float vscale" [6] "rgb tex1" [.8 .1 .1] "rgb tex2" [.9 .9 .8]\n'
+              'Texture "chn" "color" "checkerboard" "string aamode" "none" "float uscale" [3] "float vscale" [5] "rgb tex1" [.1 .1 .7] "rgb tex2" [.8 .8 .2]\n'
+              'TransformBegin\nScale .5 .5 .5\nRotate 30 0 1 0\nTexture "ch3" "color" "checkerboard" "integer dimension" [3] "rgb tex1" [.2 .7 .2] "rgb tex2" [.7 .7 .7]\nTransformEnd\n'
+              'Texture "dots" "color" "dots" "float uscale" [5] "float vscale" [5] "rgb inside" [.9 .6 .1] "texture outside" "chn"\n'
+              'Texture "uvt" "color" "uv" "float uscale" [2] "float vscale" [3] "float udelta" [.25]\n'
+              'Texture "bil" "color" "bilerp" "rgb v00" [1 0 0] "rgb v01" [0 1 0] "rgb v10" [0 0 1] "rgb v11" [1 1 0]\n'
+              'Texture "amt" "float" "checkerboard" "float uscale" [2] "float vscale" [2] "float tex1" [.2] "float tex2" [.9]\n'
+              'Texture "mixd" "color" "mix" "texture tex1" "uvt" "texture tex2" "bil" "texture amount" "amt"\n'
+              'Texture "scl" "color" "scale" "texture tex1" "mixd" "rgb tex2" [.9 .8 .7]\n'
+              'Material "matte" "texture Kd" "ch"\n' + _GROUND +
+              'Material "matte" "texture Kd" "dots"\n' + _PANEL +
+              'Material "matte" "texture Kd" "ch3"\n' + _bulge() +
+              'Material "matte" "texture Kd" "scl"\n' + _WALL)
+    elif name == "tex_noise":       # Perlin noise family under a texture-space transform: fbm, wrinkled, marble, windy
+        w += ('TransformBegin\nScale .4 .4 .4\nRotate 25 1 0 0\n'
+              'Texture "fbm" "float" "fbm" "integer octaves" [5] "float roughness" [.6]\n'
+              'Texture "wr" "color" "wrinkled" "integer octaves" [6]\n'
+              'Texture "mar" "color" "marble" "float scale" [2.5] "float variation" [.3]\n'
+              'Texture "wi" "float" "windy"\nTransformEnd\n'
+              'Texture "fbmc" "color" "scale" "texture tex1" "wr" "rgb tex2" [.9 .7 .5]\n'
+              'Material "matte" "texture Kd" "mar"\n' + _GROUND +
+              'Material "matte" "texture Kd" "fbmc" "texture sigma" "fbm"\n' + _PANEL +
+              'Material "plastic" "texture Kd" "wr" "rgb Ks" [.3 .3 .3] "texture roughness" "wi"\n' + _bulge() +
+              'Material "matte" "texture Kd" "mar"\n' + _WALL)
+    elif name == "tex_mappings":    # spherical, cylindrical and planar 2D mappings of an image and a checkerboard
+        w += ('TransformBegin\nTranslate 0 1 0\nRotate 40 0 1 0\n'
+              'Texture "sph" "color" "imagemap" "string filename" "%s" "string mapping" "spherical"\n' % T("color_23x17.png") +
+              'Texture "cyl" "color" "checkerboard" "string mapping" "cylindrical" "rgb tex1" [.8 .2 .2] "rgb tex2" [.9 .9 .9]\nTransformEnd\n'
+              'Texture "pln" "color" "imagemap" "string filename" "%s" "string mapping" "planar" "vector v1" [.5 0 .2] "vector v2" [0 .6 .1] "float udelta" [.1] "float vdelta" [.3]\n' % T("noise_16x8.tga") +
+              'Material "matte" "texture Kd" "sph"\n' + _GROUND +
+              'Material "matte" "texture Kd" "pln"\n' + _PANEL +
+              'Material "matte" "texture Kd" "cyl"\n' + _bulge() +
+              'Material "matte" "texture Kd" "pln"\n' + _WALL)
+    elif name == "tex_bump":        # Material::Bump with an image height field and with fbm, on flat and on shading-normal geometry
+        w += ('Texture "h" "float" "imagemap" "string filename" "%s" "float scale" [.08] "bool gamma" ["false"] "float uscale" [2] "float vscale" [2]\n' % T("height_32.png") +
+              'TransformBegin\nScale .3 .3 .3\nTexture "f" "float" "fbm" "integer octaves" [4]\nTransformEnd\n'
+              'Texture "fs" "float" "scale" "texture tex1" "f" "float tex2" [.05]\n'
+              'Material "plastic" "rgb Kd" [.4 .5 .6] "rgb Ks" [.3 .3 .3] "float roughness" [.15] "texture bumpmap" "h"\n' + _GROUND +
+              'Material "matte" "rgb Kd" [.7 .6 .4] "texture bumpmap" "fs"\n' + _PANEL +
+              'Material "plastic" "rgb Kd" [.6 .3 .3] "rgb Ks" [.4 .4 .4] "float roughness" [.1] "texture bumpmap" "h"\n' + _bulge() +
+              'Material "mirror" "rgb Kr" [.8 .8 .8] "texture bumpmap" "fs"\n' + _WALL)
+    elif name == "tex_alpha":       # alpha masks: image mask (camera + shadow rays), shadow-only mask, constant "float alpha" 0
+        w += ('Texture "m" "float" "imagemap" "string filename" "%s" "bool gamma" ["false"] "string wrap" "clamp"\n' % T("mask_16.png") +
+              'Texture "stripes" "float" "checkerboard" "string aamode" "none" "float uscale" [8] "float vscale" [1] "float tex1" [0] "float tex2" [1]\n'
+              'Material "matte" "rgb Kd" [.6 .6 .6]\n' + _GROUND +
+              'Material "matte" "rgb Kd" [.8 .3 .2]\n' + _PANEL.replace('"float uv"', '"texture alpha" "m" "float uv"') +
+              'Material "matte" "rgb Kd" [.2 .5 .8]\n' + _bulge().replace('"float uv"', '"texture shadowalpha" "stripes" "float uv"') +
+              'Material "matte" "rgb Kd" [.5 .5 .5]\n' + _WALL.replace('"float uv"', '"float alpha" [0] "float uv"') +
+              'Material "matte" "rgb Kd" [.3 .7 .3]\n'
+              'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 3.5  4 0 3.5  4 3 3.5  -4 3 3.5]\n')
+    elif name == "tex_materials":   # textured parameters of the other materials: uber (opacity map), glass (rough map), metal, substrate, translucent, mix (textured amount)
+        w += ('Texture "col" "color" "imagemap" "string filename" "%s"\n' % T("color_23x17.png") +
+              'Texture "op" "color" "checkerboard" "float uscale" [4] "float vscale" [4] "rgb tex1" [1 1 1] "rgb tex2" [.2 .2 .2]\n'
+              'Texture "r" "float" "imagemap" "string filename" "%s" "float scale" [.3] "bool gamma" ["false"]\n' % T("height_32.png") +
+              'Texture "amt" "color" "checkerboard" "float uscale" [3] "float vscale" [3] "rgb tex1" [.1 .1 .1] "rgb tex2" [.9 .9 .9]\n'
+              'MakeNamedMaterial "a" "string type" "matte" "texture Kd" "col"\n'
+              'MakeNamedMaterial "b" "string type" "metal" "texture roughness" "r"\n'
+              'Material "substrate" "texture Kd" "col" "rgb Ks" [.2 .2 .2] "texture uroughness" "r" "float vroughness" [.05]\n' + _GROUND +
+              'Material "uber" "texture Kd" "col" "rgb Ks" [.2 .2 .2] "rgb Kr" [.1 .1 .1] "texture opacity" "op" "texture roughness" "r"\n' + _PANEL +
+              'Material "mix" "string namedmaterial1" "a" "string namedmaterial2" "b" "texture amount" "amt"\n' + _bulge() +
+              'Material "translucent" "texture Kd" "col" "rgb Ks" [.2 .2 .2] "texture roughness" "r"\n' + _WALL +
+              'Material "glass" "texture uroughness" "r" "float vroughness" [.02] "float index" [1.4]\n'
+              'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.4 0.1 -1.6  .6 0.1 -1.9  .6 1.0 -1.9  -.4 1.0 -1.6] "float uv" [0 0 1 0 1 1 0 1]\n')
+    else:
+        raise KeyError(name)
+    return w + "WorldEnd\n"
+
+
+TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]

@@ -155,11 +155,13 @@ def test_oracle_vs_live_reference_binary(built, tmp_path):
 import edge_scenes
 
 
-@pytest.mark.parametrize("name", edge_scenes.NAMES)
+@pytest.mark.parametrize("name", edge_scenes.NAMES + edge_scenes.TEX_NAMES)
 def test_oracle_edge_cases_match_reference(built, name):
     """Edge cases of the path (tests/edge_scenes.py): constant infinite light (escaped rays, light sampling, single-light ->
     uniform substitution), thin lens, crop window + pixel bounds, luminance clamp, empty world, single-leaf BVH with a
-    degenerate triangle -- oracle vs the reference's render."""
+    degenerate triangle; and the textured scenes of row f2 (PNG / TGA / PFM image maps with EWA and trilinear filtering and
+    all wrap modes, every procedural texture class, the four 2D mappings, bump maps, alpha / shadow-alpha masks, textured
+    parameters of all nine materials incl. mix) -- oracle vs the reference's render."""
     sc = pa.Scene(text=edge_scenes.scene(name))
     rgbw, _, _ = ol.render(sc, nthreads=4)
     img = sc.film_image(rgbw)

@@ -66,10 +66,11 @@ FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitch
 
 
 def edge_fixtures(tmp):
-    """tests/edge_scenes.py variants (infinite light, thin lens, crop window + pixel bounds, luminance clamp, empty world, ...)"""
+    """tests/edge_scenes.py variants (infinite light, thin lens, crop window + pixel bounds, luminance clamp, empty world, ...)
+    and its textured scenes (image / procedural textures, mappings, bump maps, alpha masks, textured material parameters)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import edge_scenes
-    for name in edge_scenes.NAMES:
+    for name in edge_scenes.NAMES + edge_scenes.TEX_NAMES:
         f = os.path.join(tmp, "e.pbrt"); open(f, "w").write(edge_scenes.scene(name))
         out = os.path.join(OUT, "edge_%s.pfm" % name)
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
