@@ -406,6 +406,17 @@ int mi_timing_get(mi_ctx *ctx, double ms_total[MI_K_COUNT], uint64_t launches[MI
  * covers the depth.  stats: [0] BVH4 nodes, [1] leaf references, [2] depth, [3] stack entries needed, [4] primitives covered.
  * Returns 0 if all invariants hold (else -1 with mi_last_error()). */
 int mi_bvh4_validate(const mi_scene_desc *scene, int64_t stats[8]);
+
+/* Stage-level check of the texture path (row f2): Texture<T>::Evaluate(const SurfaceInteraction&) (core/texture.h:139-144) of
+ * node `node` of the uploaded scene's texture table at n recorded interactions -> 3 floats each (Float textures: the value in
+ * all three).  Only what textures read of the interaction is passed (core/texture.cpp:84-153). */
+typedef struct mi_tex_query {
+    float p[3];
+    float uv[2];
+    float dpdx[3], dpdy[3];
+    float dudx, dvdx, dudy, dvdy;
+} mi_tex_query;
+int mi_texture_eval(mi_ctx *ctx, int32_t node, const mi_tex_query *queries, int64_t n, float *rgb_out);
 /* Measurement aid: achievable HBM read rate on this device -- a streaming 16-byte-per-lane read of
  * `bytes` (>= 1 GiB recommended, beyond the 256 MiB Infinity Cache), best of 3 timed launches -- reported beside the
  * 8 TB/s specification peak. */

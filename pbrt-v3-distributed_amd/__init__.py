@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -67,6 +67,7 @@ def host_lib():
         L.pbrt_amd_scene_desc.restype = C.c_void_p
         L.pbrt_amd_scene_desc.argtypes = [C.c_void_p]
         L.pbrt_amd_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pbrt_amd_scene_texture_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         for f in ("pbrt_amd_film_merge", "pbrt_amd_film_rgb"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
         L.pbrt_amd_film_clear.argtypes = [C.c_void_p]
@@ -100,6 +101,7 @@ def device_lib():
         L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -134,6 +136,9 @@ class Scene:
         info = (C.c_int64 * len(self.INFO_FIELDS))()
         L.pbrt_amd_scene_info(self._h, info)
         self.info = dict(zip(self.INFO_FIELDS, [int(v) for v in info]))
+        tinfo = (C.c_int64 * 4)()
+        L.pbrt_amd_scene_texture_info(self._h, tinfo)
+        self.info.update(n_textures=int(tinfo[0]), n_images=int(tinfo[1]), n_textured_materials=int(tinfo[2]), n_masked_meshes=int(tinfo[3]))
         self.width = self.info["crop_x1"] - self.info["crop_x0"]
         self.height = self.info["crop_y1"] - self.info["crop_y0"]
 
@@ -239,6 +244,13 @@ class Context:
         return float(v.value)
 
     # ---- stage-level entry points
+    def texture_eval(self, node, queries):
+        """Texture::Evaluate of node `node` of the scene's texture table at the recorded interactions -> (n, 3)"""
+        queries = np.ascontiguousarray(queries, dtype=TEX_QUERY_DTYPE)
+        out = np.zeros((len(queries), 3), dtype=np.float32)
+        self._chk(device_lib().mi_texture_eval(self._ctx, int(node), _ptr(queries), len(queries), _ptr(out)), "mi_texture_eval")
+        return out
+
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         hits = np.zeros(len(rays), dtype=HIT_DTYPE)
@@ -289,6 +301,8 @@ def triangle_intersect(tri9, rays, device=0):
 
 SPHERE_DTYPE = np.dtype([("o2w", np.float32, 16), ("w2o", np.float32, 16), ("radius", np.float32), ("zmin", np.float32), ("zmax", np.float32),
                          ("theta_min", np.float32), ("theta_max", np.float32), ("phi_max", np.float32), ("flags", np.uint32), ("area", np.float32)])   # mi_sphere
+TEX_QUERY_DTYPE = np.dtype([("p", np.float32, 3), ("uv", np.float32, 2), ("dpdx", np.float32, 3), ("dpdy", np.float32, 3), ("dudx", np.float32),
+                            ("dvdx", np.float32), ("dudy", np.float32), ("dvdy", np.float32)])   # mi_tex_query
 SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
 
 

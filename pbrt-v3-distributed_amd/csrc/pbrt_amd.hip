@@ -25,7 +25,10 @@
 #include <vector>
 
 #include "pt_shade.h"
+#include "pt_material.h"
 #include "sobol_tables.inc"
+
+__constant__ DevTex c_tex;   // texture tables of the scene being rendered (set by mi_render for textured scenes only)
 
 // ============================================================================ device side
 // Per-path state is array-of-structures, one 128-byte cache line per path (+ one for the two NEE rays): after the
@@ -36,12 +39,12 @@ struct __attribute__((aligned(128))) PathRec {
     float4 ray_o, ray_d;       // o.xyz,tMax | d.xyz,-
     float4 beta;               // rgb, etaScale
     float4 L;                  // rgb, -
-    uint4 smp;                 // sobol index lo, hi, dimension, bounces | specularBounce << 16
+    uint4 smp;                 // sobol index lo, hi, dimension, bounces | specularBounce << 16 | (textured scenes) noDifferentials << 17
     uint2 hit;                 // prim (0xffffffff = miss), t bits
     float2 pfilm;
     uint32_t pixel;            // sample-space pixel x | y << 16, 0xffffffff = inactive
     uint32_t pad0;
-    uint2 pad1;
+    float2 lens;               // textured scenes: the camera sample's pLens (k_shade rebuilds the ray differentials from pfilm + lens)
     float4 pad2;
 };
 struct __attribute__((aligned(128))) NeeRec {
@@ -157,7 +160,7 @@ PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
     Float inv = (Float)1 / wp;
     return V3(inv * xp, inv * yp, inv * zp);
 }
-PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy) {
+PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy, Float *lens0, Float *lens1) {
     Float u[5];
     SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
     Float u0 = u[0], u1 = u[1];
@@ -195,9 +198,11 @@ PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Fl
         wo_ = wo_ + wd * dt;
         tm -= dt;
     }
-    *o = wo_; *d = wd; *tMax = tm; *pfx = pFilmX; *pfy = pFilmY;
+    *o = wo_; *d = wd; *tMax = tm; *pfx = pFilmX; *pfy = pFilmY; *lens0 = l0; *lens1 = l1;
 }
 
+// TEX: the scene has textured materials -- keep the lens sample with the path
+template <bool TEX>
 __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, PassInfo pass, uint32_t qout) {
     uint32_t n = pass.list_xy ? pass.npix : pass.npix * pass.ns;
     uint32_t ncam = 0;
@@ -227,8 +232,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
             Sampler smp;
             smp.Start(sc, x, y, s);
             V3 o, d;
-            Float tMax, pfx, pfy;
-            GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy);
+            Float tMax, pfx, pfy, lens0, lens1;
+            GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy, &lens0, &lens1);
+            if (TEX) ps.rec[i].lens = make_float2(lens0, lens1);
             ps.rec[i].ray_o = make_float4(o.x, o.y, o.z, tMax);
             ps.rec[i].ray_d = make_float4(d.x, d.y, d.z, 0);
             ps.rec[i].beta = make_float4(1, 1, 1, 1);
@@ -271,7 +277,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #define PT_GRID_PER_CU 6   /* persistent blocks per CU (6 x 24 KiB LDS stacks fit the 160 KiB LDS) */
 #endif
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
-template <int MODE, bool COUNT, bool SPHERES>
+// ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
@@ -337,7 +344,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
                     ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
@@ -534,7 +541,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
 #endif
 // ENV ("rich" scenes): an infinite light with a radiance map (escaped rays look it up) or Sphere primitives; plain scenes run the leaner instance
-template <bool ENV, bool HALTON>
+// TEX: some material has image / procedural textures or a bump map -- every material's lobe list is then a per-lane record
+// (built per hit by pt_material.h for the textured ones, copied for the constant ones) and the BSDF code reads it per lane
+template <bool ENV, bool HALTON, bool TEX>
 __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
@@ -564,6 +573,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             Float etaScale = b4.w;
             int bounces = (int)(s4.w & 0xffffu);
             bool specularBounce = (s4.w >> 16) & 1u;
+            bool noDiff = TEX && ((s4.w >> 17) & 1u);   // a null-material surface was stepped through: the ray is a plain Ray from then on
             PROBE(1)   // queue + path record loads
             Sampler smp;
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
@@ -583,6 +593,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             bool found = hr.x != MISS_PRIM;
             // path.cpp:91-101: emitted light at the vertex / from the environment
             Isect isect;
+            IsectX ix;
             uint4 tinfo = make_uint4(0, 0, 0, 0);
             if (found) {
                 tinfo = sc.tri_info[hr.x];
@@ -591,11 +602,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                 uint32_t tf;
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
                 Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d); Pin(tinfo);
-                if (ENV && (tf & TRI_FLAG_SPHERE)) isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, hr.x);
-                else {
+                if (ENV && (tf & TRI_FLAG_SPHERE)) {
+                    isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, hr.x);
+                    if (TEX) ix = IsectX();   // spheres carry constant materials only (mi_scene_upload refuses textured ones)
+                } else {
                     TriHit th;
                     TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
                     isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rd, hr.x);
+                    if (TEX) ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
                 }
             }
             PROBE(3)   // triangle reload + BuildIsect
@@ -617,6 +631,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                     V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, rd);
                     ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                     cont = true;
+                    noDiff = TEX;
                 } else {
                     PROBE(4)   // emission
                     // Lanes of a wave share a material almost always (sorted queue); at the boundary between two materials
@@ -628,7 +643,20 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
                     if (SameAs(matIdx, matU)) {
                     matTodo = false;
                     const mi_material *matPtr = sc.materials + matU;
-                    BSDF bsdf(isect, matPtr);
+                    typedef BSDF_T<!TEX> BS;
+                    mi_material laneMat;
+                    if (TEX) {
+                        // isect.ComputeScatteringFunctions(ray, arena, true) path.cpp:107: ComputeDifferentials (camera rays only: every
+                        // later ray is a plain Ray, path.cpp:159), then the material's textures / bump map at this hit
+                        if (bounces == 0 && !noDiff) {
+                            float2 pf = ps.rec[slot].pfilm, ln = ps.rec[slot].lens;
+                            RayDiffT rdf = CameraDifferentials(&c_tex.camera, pf.x, pf.y, ln.x, ln.y, c_tex.spp, ro, rd);
+                            ComputeDifferentials(isect.p, isect.n, &ix, rdf);
+                        }
+                        ComputeScatteringFunctionsT(sc.materials, matU, &isect, &ix, &laneMat);
+                        matPtr = &laneMat;
+                    }
+                    BS bsdf(isect, matPtr);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
@@ -777,7 +805,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc,
             }
             PROBE(12)   // RR + record stores
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
-            if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16));
+            if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16) | (TEX ? (uint32_t)noDiff << 17 : 0u));
         }
         uint32_t posE, posS, posM;
         wave_append3(&ps.qcount[qout], &ps.qcount[QC_SHADOW], &ps.qcount[QC_MIS], cont, wantShadow, wantMis, &posE, &posS, &posM);
@@ -959,6 +987,8 @@ struct mi_ctx {
     bool ownStream = false;
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     bool hasEnvMap = false, hasSpheres = false;
+    bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
+    DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     DevScene sc;
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
@@ -1101,13 +1131,50 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
     if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
-    if (d->material_descs || d->mesh_alpha)   // no silent approximation: refuse until the device evaluates textures itself
-        return fail("mi_scene_upload: the scene has image / procedural textures, bump maps or alpha masks (SURVEY.md s.8 row f2); "
-                    "this build of the device library carries the host + oracle side of that row only");
+    // textures (row f2): validate the node table before anything is uploaded
+    c->hasTex = c->hasAlpha = false;
+    if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->hasTex |= d->material_descs[m].textured != 0;
+    if (d->mesh_alpha) for (uint32_t m = 0; m < 2 * d->n_meshes; ++m) c->hasAlpha |= d->mesh_alpha[m] >= 0;
+    if (c->hasTex || c->hasAlpha) {
+        if (!d->textures || !d->n_textures) return fail("mi_scene_upload: textured materials / alpha masks without a texture table");
+        std::vector<int> depth(d->n_textures, 0);
+        for (uint32_t i = 0; i < d->n_textures; ++i) {   // children precede parents
+            const mi_texture &t = d->textures[i];
+            int dch = 0;
+            const bool hasChildren = t.type == MI_TEX_SCALE || t.type == MI_TEX_MIX || t.type == MI_TEX_CHECKERBOARD || t.type == MI_TEX_DOTS;
+            const int children[3] = {t.tex1, t.tex2, t.amount};
+            for (int k = 0; k < (hasChildren ? (t.type == MI_TEX_MIX ? 3 : 2) : 0); ++k) {
+                int ch = children[k];
+                if (ch < 0 || (uint32_t)ch >= i) return fail("mi_scene_upload: texture node refers to a later / missing node");
+                dch = std::max(dch, depth[ch]);
+            }
+            depth[i] = dch + 1;
+            if (depth[i] > PT_TEX_MAX_DEPTH) return fail("mi_scene_upload: texture graph deeper than the device evaluates (PT_TEX_MAX_DEPTH)");
+            if (t.type == MI_TEX_IMAGEMAP && (t.image < 0 || (uint32_t)t.image >= d->n_images || !d->images)) return fail("mi_scene_upload: imagemap without an image");
+        }
+        for (uint32_t i = 0; i < d->n_images; ++i)
+            if (d->images[i].levels > 16 || d->images[i].levels < 1 || (d->images[i].channels != 1 && d->images[i].channels != 3)) return fail("mi_scene_upload: unsupported image pyramid");
+        if (c->hasTex) {
+            std::vector<int> mdepth(d->n_materials, 1);
+            for (uint32_t m = 0; m < d->n_materials; ++m) {   // sub-materials of a mix have smaller indices (host/integrator.cpp materialIndex)
+                const mi_material_desc &md = d->material_descs[m];
+                if (md.type == MI_MAT_MIX && md.textured) {
+                    if (md.m1 < 0 || md.m2 < 0 || (uint32_t)md.m1 >= m || (uint32_t)md.m2 >= m) return fail("mi_scene_upload: mix material refers to a later / missing material");
+                    mdepth[m] = 1 + std::max(mdepth[md.m1], mdepth[md.m2]);
+                    if (mdepth[m] > PT_MIX_MAX_DEPTH) return fail("mi_scene_upload: mix materials nested deeper than the device evaluates (PT_MIX_MAX_DEPTH)");
+                }
+            }
+            for (uint32_t t = 0; t < d->n_tris; ++t)
+                if (d->tri_indices[3 * (size_t)t] == MI_PRIM_SPHERE) {
+                    int mat = d->meshes[d->tri_mesh[t]].material;
+                    if (mat >= 0 && d->material_descs[mat].textured) return fail("mi_scene_upload: textured materials on Sphere primitives are not carried by this path (triangle meshes only)");
+                }
+        }
+    }
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(34 + 6 * (size_t)d->n_envmaps);
+    c->sceneBufs.resize(40 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1175,6 +1242,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             if (crossLen2(a, b) == 0) reject = true;
         }
         uint32_t fl = reject ? TRI_FLAG_REJECT : 0u;
+        if (c->hasAlpha && (d->mesh_alpha[2 * (size_t)d->tri_mesh[t]] >= 0 || d->mesh_alpha[2 * (size_t)d->tri_mesh[t] + 1] >= 0)) fl |= TRI_FLAG_ALPHA;
         float flf;
         std::memcpy(&flf, &fl, 4);
         tv[3 * (size_t)t] = make_float4(p0[0], p0[1], p0[2], flf);
@@ -1216,6 +1284,39 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         sc.tri_info = b.as<uint4>();
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
+    std::memset(&c->tex, 0, sizeof(c->tex));
+    if (c->hasTex || c->hasAlpha) {   // texture node table, image pyramids, material parameter nodes, alpha masks -> c_tex (set per render)
+        DevTex &tx = c->tex;
+        { DevBuf &b = next(); if (upload(c, b, d->textures, (size_t)d->n_textures * sizeof(mi_texture))) return -1; tx.nodes = b.as<mi_texture>(); }
+        tx.n_nodes = d->n_textures; tx.n_images = d->n_images;
+        std::vector<DevImage> imgs(d->n_images);
+        for (uint32_t i = 0; i < d->n_images; ++i) {
+            const mi_image &im = d->images[i];
+            DevImage &di = imgs[i];
+            std::memset(&di, 0, sizeof(di));
+            di.width = im.width; di.height = im.height; di.levels = im.levels; di.channels = im.channels;
+            di.trilinear = im.trilinear; di.wrap = im.wrap; di.max_aniso = im.max_aniso;
+            size_t off = 0;
+            for (int l = 0; l < im.levels; ++l) {
+                di.level_off[l] = (uint32_t)off;
+                off += (size_t)std::max(1, im.width >> l) * std::max(1, im.height >> l) * im.channels;
+            }
+            DevBuf &b = next();
+            if (upload(c, b, im.texels, off * sizeof(float))) return -1;
+            di.texels = b.as<float>();
+        }
+        { DevBuf &b = next(); if (upload(c, b, imgs.data(), imgs.size() * sizeof(DevImage))) return -1; tx.images = b.as<DevImage>(); }
+        if (c->hasTex) { DevBuf &b = next(); if (upload(c, b, d->material_descs, (size_t)d->n_materials * sizeof(mi_material_desc))) return -1; tx.descs = b.as<mi_material_desc>(); }
+        if (c->hasAlpha) { DevBuf &b = next(); if (upload(c, b, d->mesh_alpha, 2 * (size_t)d->n_meshes * sizeof(int32_t))) return -1; tx.mesh_alpha = b.as<int32_t>(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));   // `imgs` is a local
+        tx.camera = d->camera;
+        tx.spp = d->integrator.spp;
+        for (int i = 0; i < 128; ++i) {   // MIPMap::weightLut, mipmap.h:187-195
+            float alpha = 2;
+            float r2 = float(i) / float(128 - 1);
+            tx.ewa_lut[i] = std::exp(-alpha * r2) - std::exp(-alpha);
+        }
+    }
     if (d->n_spheres) { DevBuf &b = next(); if (upload(c, b, d->spheres, (size_t)d->n_spheres * sizeof(mi_sphere))) return -1; sc.spheres = b.as<mi_sphere>(); }
     {   // radiance maps of infinite lights
         std::vector<DevEnvMap> em(d->n_envmaps);
@@ -1513,7 +1614,10 @@ static void harvest(mi_ctx *c) {
 
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
-        if (c->hasSpheres) {                                                                                        \
+        if (c->hasAlpha) { /* alpha-masked meshes: the general instance (spheres + masks) */                        \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, true, true>), grid, block, 0, st, sc, ps, qin);           \
+        } else if (c->hasSpheres) {                                                                                        \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true>), grid, block, 0, st, sc, ps, qin);        \
             else hipLaunchKernelGGL((k_trace<MODE, false, true>), grid, block, 0, st, sc, ps, qin);                 \
         } else {                                                                                                    \
@@ -1528,8 +1632,11 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_COUNT * sizeof(uint32_t), st));
+    if (c->hasTex || c->hasAlpha)   // the texture tables of THIS context's scene (stream ordered: contexts sharing a device may interleave passes)
+        HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
     tic(c, MI_K_RAYGEN);
-    hipLaunchKernelGGL(k_raygen, grid, block, 0, st, sc, ps, pass, 0u);
+    if (c->hasTex) hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, st, sc, ps, pass, 0u);
+    else hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, st, sc, ps, pass, 0u);
     toc(c);
     uint32_t qin = 0;
     int iter = 0;
@@ -1549,12 +1656,15 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
-            if (c->hasEnvMap || c->hasSpheres) {
-                if (halton) hipLaunchKernelGGL((k_shade<true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+            if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
+                if (halton) hipLaunchKernelGGL((k_shade<true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<true, false, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+            } else if (c->hasEnvMap || c->hasSpheres) {
+                if (halton) hipLaunchKernelGGL((k_shade<true, true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<true, false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             } else {
-                if (halton) hipLaunchKernelGGL((k_shade<false, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                if (halton) hipLaunchKernelGGL((k_shade<false, true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             }
         }
         toc(c);
@@ -1781,6 +1891,33 @@ int mi_sphere_intersect(int device, const mi_sphere *spheres, const mi_ray *rays
     HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(mi_sphere_hit), hipMemcpyDeviceToHost));
     return 0;
 }
+// stage-level texture evaluation: Texture<T>::Evaluate of node `node` at n recorded interactions
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_texture(int node, const mi_tex_query *q, int64_t n, float *rgb) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    TexCtx tc;
+    tc.p = v3(q[i].p); tc.u = q[i].uv[0]; tc.v = q[i].uv[1];
+    tc.dpdx = v3(q[i].dpdx); tc.dpdy = v3(q[i].dpdy);
+    tc.dudx = q[i].dudx; tc.dvdx = q[i].dvdx; tc.dudy = q[i].dudy; tc.dvdy = q[i].dvdy;
+    RGB v = TexEval(node, tc);
+    rgb[3 * i] = v.r; rgb[3 * i + 1] = v.g; rgb[3 * i + 2] = v.b;
+}
+int mi_texture_eval(mi_ctx *c, int32_t node, const mi_tex_query *queries, int64_t n, float *rgb_out) {
+    if (!c || !queries || !rgb_out || n < 0) return fail("mi_texture_eval: bad argument");
+    if (!c->haveScene || !(c->hasTex || c->hasAlpha)) return fail("mi_texture_eval: the uploaded scene has no textures");
+    if (node < 0 || (uint32_t)node >= c->tex.n_nodes) return fail("mi_texture_eval: node out of range");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf dq, dr;
+    if (dq.alloc((size_t)n * sizeof(mi_tex_query)) || dr.alloc((size_t)n * 3 * sizeof(float))) return -1;
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dq.p, queries, (size_t)n * sizeof(mi_tex_query), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_stage_texture, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, c->stream, (int)node, dq.as<mi_tex_query>(), n, dr.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_out, dr.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
 __global__ void __launch_bounds__(256) k_stream_read(const float4 *p, uint64_t n, float4 *out) {
     float4 acc = make_float4(0, 0, 0, 0);
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -1898,7 +2035,7 @@ static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_
     pass.list_xy = dxy.as<int32_t>(); pass.list_s = ds.as<int32_t>();
     if (trace) return run_pass(c, pass, false, false);
     HIP_TRY(hipMemsetAsync(c->ps.qcount, 0, QC_COUNT * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_raygen, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
+    hipLaunchKernelGGL(k_raygen<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
     return 0;
 }
 int mi_camera_rays(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, mi_ray *rays, float *p_film) {

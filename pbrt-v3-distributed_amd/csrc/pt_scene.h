@@ -27,6 +27,7 @@ struct __attribute__((aligned(128))) BVH4Node {
 #define TRI_FLAG_REJECT 1u
 // the primitive is a Sphere (shapes/sphere.cpp): record.v0.x holds the index into DevScene::spheres
 #define TRI_FLAG_SPHERE 2u
+#define TRI_FLAG_ALPHA 4u    /* the triangle's mesh has an alpha or shadow-alpha mask (triangle.cpp:333-338,532-570) */
 
 struct DevEnvMap;
 struct DevLight {   // 10 x 16 bytes; the first 7, fetched with independent 16-byte loads (LoadLight)
@@ -507,7 +508,10 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
 // one leaf step = ONE triangle of the leaf (in primitive order; ties at equal t: the later one wins, as in the
 // reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261).  A lane stays at the leaf until its triangles are
 // used up, so a leaf phase of the wave costs one watertight test whatever the leaf sizes of its lanes are.
-template <bool ANY, bool COUNT, bool SPHERES = false>
+// alpha masks (scenes with masked meshes only): true if the mask(s) of `prim`'s mesh evaluate to 0 at the hit (pt_material.h)
+__device__ bool TriAlphaRejects(const uint4 *tri_info, const TriShade *tri_shade, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, Float b0, Float b1,
+                                Float b2, bool anyHit);
+template <bool ANY, bool COUNT, bool SPHERES = false, bool ALPHA = false>
 PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
     uint32_t first = ts.cur & BVH4_FIRST_MASK, left = (ts.cur >> 27) & 0xfu;   // left = triangles after this one
     V3 p0, p1, p2;
@@ -522,6 +526,7 @@ PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
         hitPrim = th.t >= 0;
     } else
         hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
+    if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
     if (hitPrim) {
         ts.prim = first;
         ts.tHit = th.t;

@@ -289,9 +289,16 @@ PT_DEV void LoadBxdfUniform(mi_bxdf &dst, const mi_bxdf *p) {   // p: the same a
     __builtin_memcpy(&dst, tmp, sizeof(mi_bxdf));
 }
 
-PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+// U = true: `bp` is wave-uniform (constant materials, scalar loads).  U = false: a per-lane record (the materials of
+// textured scenes, built per hit in private memory by pt_material.h) read with ordinary loads.
+template <bool U> PT_DEV void LoadBxdf(mi_bxdf &dst, const mi_bxdf *p) {
+    if (U) LoadBxdfUniform(dst, p);
+    else dst = *p;
+}
+PT_DEV const mi_bxdf *Generic(const mi_bxdf *b) { return b; }
+template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
-    LoadBxdfUniform(b, bp);
+    LoadBxdf<U>(b, bp);
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
@@ -351,13 +358,13 @@ PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     default: return RGB(0.f);   // specular lobes evaluate to zero
     }
 }
-PT_DEV RGB BxdfF(BxdfConst b, const V3 &wo, const V3 &wi) {
-    RGB f = BxdfF_unscaled(Generic(b), wo, wi);
+template <bool U = true, class BP = BxdfConst> PT_DEV RGB BxdfF(BP b, const V3 &wo, const V3 &wi) {
+    RGB f = BxdfF_unscaled<U>(Generic(b), wo, wi);
     return b->scaled ? RGB(b->scale[0], b->scale[1], b->scale[2]) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
 }
-PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
-    LoadBxdfUniform(b, bp);
+    LoadBxdf<U>(b, bp);
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
@@ -388,29 +395,29 @@ PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
 }
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
 struct BxdfSample { RGB f; V3 wi; Float pdf; int sampledType; };
-PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
-PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const V3 wo, Float u0, Float u1, int sampledTypeIn) {   // by value: registers, no scratch
+template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
+template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const V3 wo, Float u0, Float u1, int sampledTypeIn) {   // by value: registers, no scratch
     BxdfSample r;
     r.wi = V3(); r.pdf = 0; r.sampledType = sampledTypeIn;
-    r.f = BxdfSample_f_impl(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
+    r.f = BxdfSample_f_impl<U>(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
     return r;
 }
-PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
-    LoadBxdfUniform(b, bp);
+    LoadBxdf<U>(b, bp);
     RGB f;
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
-        *pdf = BxdfPdf(bp, wo, *wi);
-        f = BxdfF_unscaled(bp, wo, *wi);
+        *pdf = BxdfPdf<U>(bp, wo, *wi);
+        f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     case MI_BXDF_LAMBERT_T:                            // :391-398
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
-        *pdf = BxdfPdf(bp, wo, *wi);
-        f = BxdfF_unscaled(bp, wo, *wi);
+        *pdf = BxdfPdf<U>(bp, wo, *wi);
+        f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     case MI_BXDF_SPECULAR_R:                           // :136-143
         *wi = V3(-wo.x, -wo.y, wo.z);
@@ -453,7 +460,7 @@ PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, F
         *wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
-        f = BxdfF_unscaled(bp, wo, *wi);
+        f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     case MI_BXDF_MICROFACET_T: {                       // :425-434
@@ -462,8 +469,8 @@ PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, F
         V3 wh = dist.Sample_wh(wo, u0, u1);
         Float eta = CosTheta(wo) > 0 ? (b.etaA / b.etaB) : (b.etaB / b.etaA);
         if (!Refract(wo, wh, eta, wi)) return RGB(0.f);
-        *pdf = BxdfPdf(bp, wo, *wi);
-        f = BxdfF_unscaled(bp, wo, *wi);
+        *pdf = BxdfPdf<U>(bp, wo, *wi);
+        f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     case MI_BXDF_FRESNEL_BLEND: {                      // :450-468
@@ -478,8 +485,8 @@ PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, F
             *wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         }
-        *pdf = BxdfPdf(bp, wo, *wi);
-        f = BxdfF_unscaled(bp, wo, *wi);
+        *pdf = BxdfPdf<U>(bp, wo, *wi);
+        f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     }
@@ -487,10 +494,13 @@ PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, F
 }
 
 // ------------------------------------------------------------------ BSDF (core/reflection.h:153-202)
-struct BSDF {
-    MatConst m;   // wave-uniform (see above)
+template <bool U> struct MatPtrOf { typedef MatConst type; };
+template <> struct MatPtrOf<false> { typedef const mi_material *type; };
+template <bool U> struct BSDF_T {
+    typedef typename MatPtrOf<U>::type MatPtr;
+    MatPtr m;   // U: wave-uniform (see above); !U: this lane's own record
     V3 ns, ng, ss, ts;
-    PT_DEV BSDF(const Isect &si, const mi_material *mat) : m((MatConst)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
+    PT_DEV BSDF_T(const Isect &si, const mi_material *mat) : m((MatPtr)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
     PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     PT_DEV V3 LocalToWorld(const V3 &v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
@@ -506,9 +516,9 @@ struct BSDF {
         bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
         RGB f(0.f);
         for (int i = 0; i < m->n_bxdfs; ++i) {
-            BxdfConst b = &m->bxdfs[i];
+            auto b = &m->bxdfs[i];
             int t = BxdfFlags(b->type);
-            if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
+            if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
         }
         return f;
     }
@@ -519,7 +529,7 @@ struct BSDF {
         Float pdf = 0.f;
         int matchingComps = 0;
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf(Generic(&m->bxdfs[i]), wo, wi); }
+            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi); }
         return matchingComps > 0 ? pdf / matchingComps : 0.f;
     }
     PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
@@ -542,27 +552,28 @@ struct BSDF {
         for (int i = 0; i < m->n_bxdfs; ++i)
             if (chosen == i) {
                 bt = BxdfFlags(m->bxdfs[i].type);
-                BxdfSample bs = BxdfSample_f(Generic(&m->bxdfs[i]), wo, ur0, u1, bt);
+                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, bt);
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
         if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
             for (int i = 0; i < m->n_bxdfs; ++i)
-                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf(Generic(&m->bxdfs[i]), wo, wi);
+                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
         if (matchingComps > 1) *pdf /= matchingComps;
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
             f = RGB(0.f);
             for (int i = 0; i < m->n_bxdfs; ++i) {
-                BxdfConst b = &m->bxdfs[i];
+                auto b = &m->bxdfs[i];
                 int t = BxdfFlags(b->type);
-                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF(b, wo, wi);
+                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
             }
         }
         return f;
     }
 };
+typedef BSDF_T<true> BSDF;
 
 // ------------------------------------------------------------------ lights
 PT_DEV RGB AreaL(const DevLight &l, const V3 &n, const V3 &w) {   // DiffuseAreaLight::L lights/diffuse.h:56-58

@@ -1,0 +1,342 @@
+// Texture evaluation on the device: Texture<T>::Evaluate for every class of src/textures
+// (Ptex excepted), the texture mappings and Perlin noise of core/texture.{h,cpp}, MIPMap trilinear / EWA lookups
+// (core/mipmap.h:223-353).  One lane = one evaluation; the node graph of a material is wave-uniform in the shading
+// kernel (lanes are sorted by material), so the switches below are scalar branches there.  The texture tables hang
+// off a __constant__ block (c_tex): no kernel-argument growth for the kernels of untextured scenes.
+// A Float texture is evaluated on an RGB triple with equal channels (every operator involved is componentwise).
+#pragma once
+#include "pt_scene.h"
+
+struct DevImage {   // mi_image + per-level offsets (in floats) into `texels`
+    int32_t width, height, levels, channels, trilinear, wrap;
+    float max_aniso;
+    uint32_t pad;
+    const float *texels;
+    uint32_t level_off[16];
+};
+struct DevTex {
+    const mi_texture *nodes;
+    const DevImage *images;
+    const mi_material_desc *descs;   // per material; NULL when no material is textured
+    const int32_t *mesh_alpha;       // 2 per mesh; NULL when no mesh has a mask
+    uint32_t n_nodes, n_images;
+    mi_camera camera;                // for the ray differentials of camera rays (rebuilt at the first hit)
+    int32_t spp, pad;
+    float ewa_lut[128];              // MIPMap::weightLut (mipmap.h:187-195), computed on the host with the reference's expression
+};
+extern __constant__ DevTex c_tex;
+
+struct TexCtx {   // what textures read of a SurfaceInteraction
+    V3 p;
+    Float u, v;
+    V3 dpdx, dpdy;
+    Float dudx, dvdx, dudy, dvdy;
+};
+struct V2 { Float x, y; };
+
+PT_DEV Float logf_(Float v) { return (Float)log((double)v); }
+PT_DEV Float atan2f__(Float y, Float x) { return (Float)atan2((double)y, (double)x); }
+PT_DEV Float Log2T(Float x) { const Float invLog2 = 1.442695040888963387004650940071f; return logf_(x) * invLog2; }   // core/pbrt.h:324-327
+PT_DEV int ModT(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }                                 // core/pbrt.h:310-313
+
+// ---- Perlin noise (core/texture.cpp:47-220); Ken Perlin's reference permutation ("Improving Noise", SIGGRAPH 2002)
+__device__ const uint8_t c_noise_perm[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+PT_DEV int NoisePerm(int i) { return c_noise_perm[i & 255]; }
+PT_DEV Float NoiseGrad(int x, int y, int z, Float dx, Float dy, Float dz) {   // texture.cpp:186-192
+    int h = NoisePerm(NoisePerm(NoisePerm(x) + y) + z);
+    h &= 15;
+    Float u = h < 8 || h == 12 || h == 13 ? dx : dy;
+    Float v = h < 4 || h == 12 || h == 13 ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+PT_DEV Float NoiseWeight(Float t) { Float t3 = t * t * t; Float t4 = t3 * t; return 6 * t4 * t - 15 * t4 + 10 * t3; }
+__device__ __noinline__ Float Noise3(Float x, Float y, Float z) {   // texture.cpp:155-184
+    int ix = (int)__builtin_floorf(x), iy = (int)__builtin_floorf(y), iz = (int)__builtin_floorf(z);
+    Float dx = x - ix, dy = y - iy, dz = z - iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    Float w000 = NoiseGrad(ix, iy, iz, dx, dy, dz);
+    Float w100 = NoiseGrad(ix + 1, iy, iz, dx - 1, dy, dz);
+    Float w010 = NoiseGrad(ix, iy + 1, iz, dx, dy - 1, dz);
+    Float w110 = NoiseGrad(ix + 1, iy + 1, iz, dx - 1, dy - 1, dz);
+    Float w001 = NoiseGrad(ix, iy, iz + 1, dx, dy, dz - 1);
+    Float w101 = NoiseGrad(ix + 1, iy, iz + 1, dx - 1, dy, dz - 1);
+    Float w011 = NoiseGrad(ix, iy + 1, iz + 1, dx, dy - 1, dz - 1);
+    Float w111 = NoiseGrad(ix + 1, iy + 1, iz + 1, dx - 1, dy - 1, dz - 1);
+    Float wx = NoiseWeight(dx), wy = NoiseWeight(dy), wz = NoiseWeight(dz);
+    Float x00 = Lerp(wx, w000, w100), x10 = Lerp(wx, w010, w110), x01 = Lerp(wx, w001, w101), x11 = Lerp(wx, w011, w111);
+    Float y0 = Lerp(wy, x00, x10), y1 = Lerp(wy, x01, x11);
+    return Lerp(wz, y0, y1);
+}
+PT_DEV Float SmoothStepT(Float lo, Float hi, Float value) {   // texture.cpp:41-44
+    Float v = clampf((value - lo) / (hi - lo), 0, 1);
+    return v * v * (-2 * v + 3);
+}
+// FBm (turb == false, texture.cpp:200-217) and Turbulence (turb == true, :219-245)
+__device__ __noinline__ Float FBmT(const V3 p, const V3 dpdx, const V3 dpdy, Float omega, int maxOctaves, bool turb) {
+    Float len2 = mx(dpdx.LengthSquared(), dpdy.LengthSquared());
+    Float n = clampf(-1 - .5f * Log2T(len2), 0, (Float)maxOctaves);
+    int nInt = (int)__builtin_floorf(n);
+    Float sum = 0, lambda = 1, o = 1;
+    for (int i = 0; i < nInt; ++i) {
+        Float nz = Noise3(lambda * p.x, lambda * p.y, lambda * p.z);
+        sum += o * (turb ? absf(nz) : nz);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    Float nPartial = n - nInt;
+    Float nz = Noise3(lambda * p.x, lambda * p.y, lambda * p.z);
+    if (!turb) return sum + o * SmoothStepT(.3f, .7f, nPartial) * nz;
+    sum += o * Lerp(SmoothStepT(.3f, .7f, nPartial), (Float)0.2, absf(nz));
+    for (int i = nInt; i < maxOctaves; ++i) {
+        sum += o * 0.2f;
+        o *= omega;
+    }
+    return sum;
+}
+
+// ---- texture mappings (core/texture.cpp:84-153)
+PT_DEV V3 XfPointT(const float *m, const V3 &p) {   // core/transform.h:223-234
+    Float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    Float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    Float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    Float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1) return V3(xp, yp, zp);
+    Float inv = (Float)1 / wp;
+    return V3(inv * xp, inv * yp, inv * zp);
+}
+PT_DEV V3 XfVectorT(const float *m, const V3 &v) {   // core/transform.h:236-242
+    return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+PT_DEV V2 SphereST(const mi_texture *t, const V3 &P) {   // SphericalMapping2D::sphere :117-121
+    V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
+    Float theta = acosf_(clampf(vec.z, -1, 1));
+    Float phi = atan2f__(vec.y, vec.x);
+    phi = (phi < 0) ? (phi + 2 * PT_PI) : phi;
+    return V2{theta * PT_INV_PI, phi * 0.15915494309189533577f};
+}
+PT_DEV V2 CylinderST(const mi_texture *t, const V3 &P) {   // CylindricalMapping2D::cylinder texture.h:93-96
+    V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
+    return V2{(PT_PI + atan2f__(vec.y, vec.x)) * 0.15915494309189533577f, vec.z};
+}
+PT_DEV V2 DivV2(const V2 &a, const V2 &b, Float f) { Float inv = (Float)1 / f; return V2{(a.x - b.x) * inv, (a.y - b.y) * inv}; }
+struct Map2DOut { V2 st, dstdx, dstdy; };
+__device__ __noinline__ Map2DOut Map2D(const mi_texture *t, const TexCtx si) {
+    Map2DOut o;
+    switch (t->mapping) {
+    case MI_MAP_SPHERICAL: {   // texture.cpp:96-115
+        o.st = SphereST(t, si.p);
+        const Float delta = .1f;
+        o.dstdx = DivV2(SphereST(t, si.p + delta * si.dpdx), o.st, delta);
+        o.dstdy = DivV2(SphereST(t, si.p + delta * si.dpdy), o.st, delta);
+        if ((double)o.dstdx.y > .5) o.dstdx.y = 1 - o.dstdx.y; else if (o.dstdx.y < -.5f) o.dstdx.y = -(o.dstdx.y + 1);
+        if ((double)o.dstdy.y > .5) o.dstdy.y = 1 - o.dstdy.y; else if (o.dstdy.y < -.5f) o.dstdy.y = -(o.dstdy.y + 1);
+        break;
+    }
+    case MI_MAP_CYLINDRICAL: {   // texture.cpp:123-140
+        o.st = CylinderST(t, si.p);
+        const Float delta = .01f;
+        o.dstdx = DivV2(CylinderST(t, si.p + delta * si.dpdx), o.st, delta);
+        if ((double)o.dstdx.y > .5) o.dstdx.y = 1.f - o.dstdx.y; else if (o.dstdx.y < -.5f) o.dstdx.y = -(o.dstdx.y + 1);
+        o.dstdy = DivV2(CylinderST(t, si.p + delta * si.dpdy), o.st, delta);
+        if ((double)o.dstdy.y > .5) o.dstdy.y = 1.f - o.dstdy.y; else if (o.dstdy.y < -.5f) o.dstdy.y = -(o.dstdy.y + 1);
+        break;
+    }
+    case MI_MAP_PLANAR: {   // texture.cpp:142-148
+        V3 vs = v3(t->vs), vt = v3(t->vt);
+        o.dstdx = V2{Dot(si.dpdx, vs), Dot(si.dpdx, vt)};
+        o.dstdy = V2{Dot(si.dpdy, vs), Dot(si.dpdy, vt)};
+        o.st = V2{t->du + Dot(si.p, vs), t->dv + Dot(si.p, vt)};
+        break;
+    }
+    default:   // UVMapping2D texture.cpp:86-94
+        o.dstdx = V2{t->su * si.dudx, t->sv * si.dvdx};
+        o.dstdy = V2{t->su * si.dudy, t->sv * si.dvdy};
+        o.st = V2{t->su * si.u + t->du, t->sv * si.v + t->dv};
+        break;
+    }
+    return o;
+}
+
+// ---- MIPMap<T> (core/mipmap.h:201-353)
+PT_DEV int LevW(const DevImage *im, int l) { int w = im->width >> l; return w < 1 ? 1 : w; }
+PT_DEV int LevH(const DevImage *im, int l) { int h = im->height >> l; return h < 1 ? 1 : h; }
+PT_DEV RGB MipTexel(const DevImage *im, int level, int s, int t) {   // :201-221
+    int w = LevW(im, level), h = LevH(im, level);
+    if (im->wrap == 0) { s = ModT(s, w); t = ModT(t, h); }
+    else if (im->wrap == 2) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
+    else if (s < 0 || s >= w || t < 0 || t >= h) return RGB(0.f);
+    const float *px = im->texels + im->level_off[level] + ((size_t)t * w + s) * im->channels;
+    return im->channels == 1 ? RGB(px[0]) : RGB(px[0], px[1], px[2]);
+}
+__device__ __noinline__ RGB MipTriangle(const DevImage *im, int level, Float s_, Float t_) {   // :263-275
+    level = level < 0 ? 0 : (level > im->levels - 1 ? im->levels - 1 : level);
+    Float s = s_ * LevW(im, level) - 0.5f, t = t_ * LevH(im, level) - 0.5f;
+    int s0 = (int)__builtin_floorf(s), t0 = (int)__builtin_floorf(t);
+    Float ds = s - s0, dt = t - t0;
+    RGB a = MipTexel(im, level, s0, t0), b = MipTexel(im, level, s0, t0 + 1), c = MipTexel(im, level, s0 + 1, t0), d = MipTexel(im, level, s0 + 1, t0 + 1);
+    return ((1 - ds) * (1 - dt)) * a + ((1 - ds) * dt) * b + (ds * (1 - dt)) * c + (ds * dt) * d;
+}
+__device__ __noinline__ RGB MipEWA(const DevImage *im, int level, V2 st, V2 dst0, V2 dst1) {   // :309-353
+    if (level >= im->levels) return MipTexel(im, im->levels - 1, 0, 0);
+    int w = LevW(im, level), h = LevH(im, level);
+    st.x = st.x * w - 0.5f; st.y = st.y * h - 0.5f;
+    dst0.x *= w; dst0.y *= h;
+    dst1.x *= w; dst1.y *= h;
+    Float A = dst0.y * dst0.y + dst1.y * dst1.y + 1;
+    Float B = -2 * (dst0.x * dst0.y + dst1.x * dst1.y);
+    Float C = dst0.x * dst0.x + dst1.x * dst1.x + 1;
+    Float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    Float det = -B * B + 4 * A * C;
+    Float invDet = 1 / det;
+    Float uSqrt = sqrtf_(det * C), vSqrt = sqrtf_(A * det);
+    int s0 = (int)__builtin_ceilf(st.x - 2 * invDet * uSqrt), s1 = (int)__builtin_floorf(st.x + 2 * invDet * uSqrt);
+    int t0 = (int)__builtin_ceilf(st.y - 2 * invDet * vSqrt), t1 = (int)__builtin_floorf(st.y + 2 * invDet * vSqrt);
+    RGB sum(0.f);
+    Float sumWts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        Float tt = it - st.y;
+        for (int is = s0; is <= s1; ++is) {
+            Float ss = is - st.x;
+            Float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = mni((int)(r2 * 128), 128 - 1);
+                Float weight = c_tex.ewa_lut[index];
+                sum = sum + MipTexel(im, level, is, it) * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    return sum / sumWts;
+}
+__device__ __noinline__ RGB MipLookup(const DevImage *im, V2 st, V2 dst0, V2 dst1) {   // :277-307 (and :223-241 for the trilinear case)
+    if (im->trilinear) {
+        Float width = 2 * mx(mx(absf(dst0.x), absf(dst0.y)), mx(absf(dst1.x), absf(dst1.y)));
+        Float level = im->levels - 1 + Log2T(mx(width, (Float)1e-8));
+        if (level < 0) return MipTriangle(im, 0, st.x, st.y);
+        else if (level >= im->levels - 1) return MipTexel(im, im->levels - 1, 0, 0);
+        int iLevel = (int)__builtin_floorf(level);
+        Float delta = level - iLevel;
+        return (1 - delta) * MipTriangle(im, iLevel, st.x, st.y) + delta * MipTriangle(im, iLevel + 1, st.x, st.y);
+    }
+    if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+    Float majorLength = sqrtf_(dst0.x * dst0.x + dst0.y * dst0.y);
+    Float minorLength = sqrtf_(dst1.x * dst1.x + dst1.y * dst1.y);
+    if (minorLength * im->max_aniso < majorLength && minorLength > 0) {
+        Float scale = majorLength / (minorLength * im->max_aniso);
+        dst1.x *= scale; dst1.y *= scale;
+        minorLength *= scale;
+    }
+    if (minorLength == 0) return MipTriangle(im, 0, st.x, st.y);
+    Float lod = mx((Float)0, im->levels - (Float)1 + Log2T(minorLength));
+    int ilod = (int)__builtin_floorf(lod);
+    Float d = lod - ilod;
+    return (1 - d) * MipEWA(im, ilod, st, dst0, dst1) + d * MipEWA(im, ilod + 1, st, dst0, dst1);
+}
+
+// ---- Texture<T>::Evaluate.  D bounds the depth of the node graph that is followed (scale / mix / checkerboard / dots
+// refer to child textures); the upload rejects deeper graphs.
+#define PT_TEX_MAX_DEPTH 6
+template <int D> struct TexEvalD { static __device__ __noinline__ RGB eval(int node, const TexCtx si); };
+template <> struct TexEvalD<0> { static PT_DEV RGB eval(int, const TexCtx) { return RGB(0.f); } };
+template <int D> __device__ __noinline__ RGB TexEvalD<D>::eval(int node, const TexCtx si) {
+    if (node < 0 || (uint32_t)node >= c_tex.n_nodes) return RGB(0.f);
+    const mi_texture *t = c_tex.nodes + node;
+    typedef TexEvalD<D - 1> Sub;
+    switch (t->type) {
+    case MI_TEX_CONSTANT: return rgb3(t->value);
+    case MI_TEX_SCALE: return Sub::eval(t->tex1, si) * Sub::eval(t->tex2, si);
+    case MI_TEX_MIX: {
+        RGB t1 = Sub::eval(t->tex1, si), t2 = Sub::eval(t->tex2, si);
+        Float amt = Sub::eval(t->amount, si).r;
+        return (1 - amt) * t1 + amt * t2;
+    }
+    case MI_TEX_BILERP: {
+        Map2DOut m = Map2D(t, si);
+        Float s = m.st.x, tt = m.st.y;
+        return ((1 - s) * (1 - tt)) * rgb3(t->v00) + ((1 - s) * (tt)) * rgb3(t->v01) + ((s) * (1 - tt)) * rgb3(t->v10) + ((s) * (tt)) * rgb3(t->v11);
+    }
+    case MI_TEX_IMAGEMAP: {
+        Map2DOut m = Map2D(t, si);
+        if (t->image < 0 || (uint32_t)t->image >= c_tex.n_images) return RGB(0.f);
+        return MipLookup(c_tex.images + t->image, m.st, m.dstdx, m.dstdy);
+    }
+    case MI_TEX_UV: {
+        Map2DOut m = Map2D(t, si);
+        return RGB(m.st.x - __builtin_floorf(m.st.x), m.st.y - __builtin_floorf(m.st.y), 0);
+    }
+    case MI_TEX_CHECKERBOARD: {
+        if (t->dim == 3) {
+            V3 p = XfPointT(t->w2t, si.p);
+            if (((int)__builtin_floorf(p.x) + (int)__builtin_floorf(p.y) + (int)__builtin_floorf(p.z)) % 2 == 0) return Sub::eval(t->tex1, si);
+            return Sub::eval(t->tex2, si);
+        }
+        Map2DOut m = Map2D(t, si);
+        bool even = (((int)__builtin_floorf(m.st.x) + (int)__builtin_floorf(m.st.y)) % 2 == 0);
+        if (t->aa == 0) return even ? Sub::eval(t->tex1, si) : Sub::eval(t->tex2, si);
+        Float ds = mx(absf(m.dstdx.x), absf(m.dstdy.x));
+        Float dt = mx(absf(m.dstdx.y), absf(m.dstdy.y));
+        Float s0 = m.st.x - ds, s1 = m.st.x + ds;
+        Float t0 = m.st.y - dt, t1 = m.st.y + dt;
+        if (__builtin_floorf(s0) == __builtin_floorf(s1) && __builtin_floorf(t0) == __builtin_floorf(t1)) return even ? Sub::eval(t->tex1, si) : Sub::eval(t->tex2, si);
+        auto bumpInt = [](Float x) { return (int)__builtin_floorf(x / 2) + 2 * mx(x / 2 - (int)__builtin_floorf(x / 2) - (Float)0.5, (Float)0); };
+        Float sint = (bumpInt(s1) - bumpInt(s0)) / (2 * ds);
+        Float tint = (bumpInt(t1) - bumpInt(t0)) / (2 * dt);
+        Float area2 = sint + tint - 2 * sint * tint;
+        if (ds > 1 || dt > 1) area2 = .5f;
+        return (1 - area2) * Sub::eval(t->tex1, si) + area2 * Sub::eval(t->tex2, si);
+    }
+    case MI_TEX_DOTS: {
+        Map2DOut m = Map2D(t, si);
+        int sCell = (int)__builtin_floorf(m.st.x + .5f), tCell = (int)__builtin_floorf(m.st.y + .5f);
+        if (Noise3(sCell + .5f, tCell + .5f, .5f) > 0) {
+            Float radius = .35f;
+            Float maxShift = 0.5f - radius;
+            Float sCenter = sCell + maxShift * Noise3(sCell + 1.5f, tCell + 2.8f, .5f);
+            Float tCenter = tCell + maxShift * Noise3(sCell + 4.5f, tCell + 9.8f, .5f);
+            Float dx = m.st.x - sCenter, dy = m.st.y - tCenter;
+            if (dx * dx + dy * dy < radius * radius) return Sub::eval(t->tex2, si);
+        }
+        return Sub::eval(t->tex1, si);
+    }
+    case MI_TEX_FBM: case MI_TEX_WRINKLED: {
+        V3 P = XfPointT(t->w2t, si.p);
+        return RGB(FBmT(P, XfVectorT(t->w2t, si.dpdx), XfVectorT(t->w2t, si.dpdy), t->omega, t->octaves, t->type == MI_TEX_WRINKLED));
+    }
+    case MI_TEX_WINDY: {
+        V3 P = XfPointT(t->w2t, si.p), dpdx = XfVectorT(t->w2t, si.dpdx), dpdy = XfVectorT(t->w2t, si.dpdy);
+        Float windStrength = FBmT(.1f * P, .1f * dpdx, .1f * dpdy, .5f, 3, false);
+        Float waveHeight = FBmT(P, dpdx, dpdy, .5f, 6, false);
+        return RGB(absf(windStrength) * waveHeight);
+    }
+    case MI_TEX_MARBLE: {
+        V3 p = XfPointT(t->w2t, si.p), dpdx = XfVectorT(t->w2t, si.dpdx), dpdy = XfVectorT(t->w2t, si.dpdy);
+        p = p * t->scale;
+        Float marble = p.y + t->variation * FBmT(p, t->scale * dpdx, t->scale * dpdy, t->omega, t->octaves, false);
+        Float tt = .5f + .5f * sinf_(marble);
+        const Float c[9][3] = {{.58f, .58f, .6f}, {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.5f, .5f, .5f}, {.6f, .59f, .58f},
+                               {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.2f, .2f, .33f}, {.58f, .58f, .6f}};
+        const Float NSEG = 6;
+        int first = (int)__builtin_floorf(tt * NSEG);
+        tt = (tt * NSEG - first);
+        first = first > 5 ? 5 : (first < 0 ? 0 : first);
+        RGB c0 = rgb3(c[first]), c1 = rgb3(c[first + 1]), c2 = rgb3(c[first + 2]), c3 = rgb3(c[first + 3]);
+        RGB s0 = (1.f - tt) * c0 + tt * c1;
+        RGB s1 = (1.f - tt) * c1 + tt * c2;
+        RGB s2 = (1.f - tt) * c2 + tt * c3;
+        s0 = (1.f - tt) * s0 + tt * s1;
+        s1 = (1.f - tt) * s1 + tt * s2;
+        return 1.5f * ((1.f - tt) * s0 + tt * s1);
+    }
+    }
+    return RGB(0.f);
+}
+PT_DEV RGB TexEval(int node, const TexCtx &si) { return TexEvalD<PT_TEX_MAX_DEPTH>::eval(node, si); }

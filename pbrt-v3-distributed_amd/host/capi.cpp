@@ -57,6 +57,13 @@ int pbrt_amd_film_write(pbrt_amd_scene *s, const char *filename) {
 }
 // number of GeometricPrimitives (meshes) of the scene, and a binary-little-endian PLY dump of one of them
 // (world-space positions [+ normals]); used by tools/make_killeroo.py to ship subdivided geometry as plymesh
+// texture nodes / images / textured materials / masked meshes of the flattened scene (row f2)
+void pbrt_amd_scene_texture_info(pbrt_amd_scene *s, int64_t *out) {
+    const mi_scene_desc &d = s->flat->desc;
+    out[0] = d.n_textures; out[1] = d.n_images; out[2] = 0; out[3] = 0;
+    if (d.material_descs) for (uint32_t m = 0; m < d.n_materials; ++m) out[2] += d.material_descs[m].textured != 0;
+    if (d.mesh_alpha) for (uint32_t m = 0; m < d.n_meshes; ++m) out[3] += d.mesh_alpha[2 * m] >= 0 || d.mesh_alpha[2 * m + 1] >= 0;
+}
 int pbrt_amd_scene_num_prims(pbrt_amd_scene *s) { return (int)s->built->scene->primitives.size(); }
 int pbrt_amd_scene_write_ply(pbrt_amd_scene *s, int prim, const char *filename) {
     if (prim < 0 || prim >= (int)s->built->scene->primitives.size()) return -1;

@@ -37,6 +37,7 @@ def lib():
         L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_sphere_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_bxdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        L.oracle_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_render_sharded.restype = C.c_double
         L.oracle_render_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.oracle_sample_discrete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p]
@@ -159,6 +160,13 @@ def bxdf_eval(rows):
     out = {"f": np.zeros((n, 3), np.float32), "pdf": np.zeros(n, np.float32), "wi_s": np.zeros((n, 3), np.float32), "pdf_s": np.zeros(n, np.float32),
            "f_s": np.zeros((n, 3), np.float32), "type_s": np.zeros(n, np.int32)}
     lib().oracle_bxdf(_p(b), _p(wo), _p(wi), _p(u), n, _p(out["f"]), _p(out["pdf"]), _p(out["wi_s"]), _p(out["pdf_s"]), _p(out["f_s"]), _p(out["type_s"]))
+    return out
+
+
+def texture_eval(scene, node, queries):
+    queries = np.ascontiguousarray(queries, dtype=pa.TEX_QUERY_DTYPE)
+    out = np.zeros((len(queries), 3), dtype=np.float32)
+    lib().oracle_texture_eval(scene.desc, int(node), _p(queries), len(queries), _p(out))
     return out
 
 
