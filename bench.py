@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4"],
                     help="BASELINE.json config: c3 = San-Miguel-class 1080p 64spp (default, the metric's workload); "
                          "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30")
+    ap.add_argument("--textured", action="store_true", help="c3 only: the stand-in with image-mapped / bump-mapped materials (SURVEY.md s.8 row f2)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample (0 = skip)")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on a 1-GPU box)")
@@ -134,20 +135,22 @@ def main():
             time.sleep(0.2)
         workload = "Contemporary-Bathroom-class synthetic stand-in: glass/mirror/metal, %dx%d, %d spp, path maxdepth 30" % (args.res[0], args.res[1], spp)
     else:
-        key = "sanmiguel_synth_%dk_%dx%d_%dspp" % (args.tris // 1000, args.res[0], args.res[1], args.spp)
+        key = "sanmiguel_synth_%dk_%dx%d_%dspp%s" % (args.tris // 1000, args.res[0], args.res[1], args.spp, "_tex" if args.textured else "")
         d = os.path.join(bench_dir, key)
         scene_file = os.path.join(d, "sanmiguel_synth.pbrt")
         marker = os.path.join(d, ".done")
         if local_rank == 0 and not os.path.exists(marker):
             os.makedirs(d, exist_ok=True)
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris),
-                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", scene_file],
+                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", scene_file] + (["--textured"] if args.textured else []),
                                   stdout=sys.stderr)
             open(marker, "w").write("ok")
         while not os.path.exists(marker):
             time.sleep(0.2)
         workload = "San-Miguel-class synthetic stand-in (SURVEY.md s.8d): %d triangles, %dx%d, %d spp, path maxdepth 5, sobol, box filter" % (
             args.tris, args.res[0], args.res[1], args.spp)
+        if args.textured:
+            workload += "; TEXTURED variant (row f2): image-mapped Kd (EWA) on every material, roughness / bump maps"
 
     pa = importlib.import_module("pbrt-v3-distributed_amd")
     par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
