@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -543,8 +544,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 // ENV ("rich" scenes): an infinite light with a radiance map (escaped rays look it up) or Sphere primitives; plain scenes run the leaner instance
 // TEX: some material has image / procedural textures or a bump map -- every material's lobe list is then a per-lane record
 // (built per hit by pt_material.h for the textured ones, copied for the constant ones) and the BSDF code reads it per lane
+#ifndef PT_TEX_SHADE_WAVES
+#define PT_TEX_SHADE_WAVES PT_SHADE_WAVES   /* the textured instance: same register budget (168 VGPRs, 3 waves per SIMD) */
+#endif
 template <bool ENV, bool HALTON, bool TEX>
-__global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, PathState ps, uint32_t qout) {
+__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
 #if PT_SHADE_PROF
@@ -1149,7 +1153,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
                 dch = std::max(dch, depth[ch]);
             }
             depth[i] = dch + 1;
-            if (depth[i] > PT_TEX_MAX_DEPTH) return fail("mi_scene_upload: texture graph deeper than the device evaluates (PT_TEX_MAX_DEPTH)");
             if (t.type == MI_TEX_IMAGEMAP && (t.image < 0 || (uint32_t)t.image >= d->n_images || !d->images)) return fail("mi_scene_upload: imagemap without an image");
         }
         for (uint32_t i = 0; i < d->n_images; ++i)
@@ -1174,7 +1177,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(40 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
+    c->sceneBufs.resize(44 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1306,6 +1309,30 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             di.texels = b.as<float>();
         }
         { DevBuf &b = next(); if (upload(c, b, imgs.data(), imgs.size() * sizeof(DevImage))) return -1; tx.images = b.as<DevImage>(); }
+        {   // flatten the graph below every node into its post-order evaluation program (pt_texture.h TexEval)
+            std::vector<int32_t> progOff(d->n_textures + 1, 0);
+            std::vector<int4> prog;
+            for (uint32_t root = 0; root < d->n_textures; ++root) {
+                progOff[root] = (int32_t)prog.size();
+                std::vector<std::pair<int, int>> memo;   // node -> step (graphs are tiny)
+                const size_t base = prog.size();
+                std::function<int(int)> emit = [&](int n) -> int {
+                    for (auto &kv : memo) if (kv.first == n) return kv.second;
+                    const mi_texture &t = d->textures[n];
+                    const bool hasChildren = t.type == MI_TEX_SCALE || t.type == MI_TEX_MIX || t.type == MI_TEX_CHECKERBOARD || t.type == MI_TEX_DOTS;
+                    int c1 = hasChildren ? emit(t.tex1) : -1, c2 = hasChildren ? emit(t.tex2) : -1, c3 = t.type == MI_TEX_MIX ? emit(t.amount) : -1;
+                    prog.push_back(make_int4(n, c1, c2, c3));
+                    memo.push_back({n, (int)(prog.size() - base) - 1});
+                    return memo.back().second;
+                };
+                emit((int)root);
+                if (prog.size() - base > PT_TEX_MAX_PROG) return fail("mi_scene_upload: a texture refers to more than PT_TEX_MAX_PROG nodes");
+            }
+            progOff[d->n_textures] = (int32_t)prog.size();
+            { DevBuf &b = next(); if (upload(c, b, progOff.data(), progOff.size() * sizeof(int32_t))) return -1; tx.prog_off = b.as<int32_t>(); }
+            { DevBuf &b = next(); if (upload(c, b, prog.data(), prog.size() * sizeof(int4))) return -1; tx.prog = b.as<int4>(); }
+            HIP_TRY(hipStreamSynchronize(c->stream));   // locals
+        }
         if (c->hasTex) { DevBuf &b = next(); if (upload(c, b, d->material_descs, (size_t)d->n_materials * sizeof(mi_material_desc))) return -1; tx.descs = b.as<mi_material_desc>(); }
         if (c->hasAlpha) { DevBuf &b = next(); if (upload(c, b, d->mesh_alpha, 2 * (size_t)d->n_meshes * sizeof(int32_t))) return -1; tx.mesh_alpha = b.as<int32_t>(); }
         HIP_TRY(hipStreamSynchronize(c->stream));   // `imgs` is a local

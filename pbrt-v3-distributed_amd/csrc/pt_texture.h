@@ -19,6 +19,8 @@ struct DevTex {
     const DevImage *images;
     const mi_material_desc *descs;   // per material; NULL when no material is textured
     const int32_t *mesh_alpha;       // 2 per mesh; NULL when no mesh has a mask
+    const int32_t *prog_off;         // n_nodes + 1: the evaluation program of node i is prog[prog_off[i] .. prog_off[i+1])
+    const int4 *prog;                // post-order steps {node, step of tex1, step of tex2, step of amount} (-1: no such child)
     uint32_t n_nodes, n_images;
     mi_camera camera;                // for the ray differentials of camera rays (rebuilt at the first hit)
     int32_t spp, pad;
@@ -242,59 +244,57 @@ __device__ __noinline__ RGB MipLookup(const DevImage *im, V2 st, V2 dst0, V2 dst
     return (1 - d) * MipEWA(im, ilod, st, dst0, dst1) + d * MipEWA(im, ilod + 1, st, dst0, dst1);
 }
 
-// ---- Texture<T>::Evaluate.  D bounds the depth of the node graph that is followed (scale / mix / checkerboard / dots
-// refer to child textures); the upload rejects deeper graphs.
-#define PT_TEX_MAX_DEPTH 6
-template <int D> struct TexEvalD { static __device__ __noinline__ RGB eval(int node, const TexCtx si); };
-template <> struct TexEvalD<0> { static PT_DEV RGB eval(int, const TexCtx) { return RGB(0.f); } };
-template <int D> __device__ __noinline__ RGB TexEvalD<D>::eval(int node, const TexCtx si) {
-    if (node < 0 || (uint32_t)node >= c_tex.n_nodes) return RGB(0.f);
-    const mi_texture *t = c_tex.nodes + node;
-    typedef TexEvalD<D - 1> Sub;
+// ---- Texture<T>::Evaluate.  The node graph below a texture (scale / mix / checkerboard / dots refer to child textures)
+// is evaluated WITHOUT recursion: mi_scene_upload flattens the graph below every node into a post-order program
+// (c_tex.prog: {node, step of tex1, step of tex2, step of amount}); the loop below evaluates the steps in order into a
+// small per-lane value array.  Both children of a checkerboard / dots node are evaluated and one is selected (or the
+// two are blended), which gives the value the reference's lazy evaluation gives -- textures have no side effects.
+// (A recursive formulation kept every level's live state in registers across the calls: 280 VGPRs at depth 6, one
+// wave per SIMD in the shading kernel; the flat loop needs what one node needs.)
+#define PT_TEX_MAX_PROG 24
+__device__ __noinline__ RGB EvalNode(const mi_texture *t, const RGB t1v, const RGB t2v, const RGB amtv, const TexCtx si) {
     switch (t->type) {
-    case MI_TEX_CONSTANT: return rgb3(t->value);
-    case MI_TEX_SCALE: return Sub::eval(t->tex1, si) * Sub::eval(t->tex2, si);
-    case MI_TEX_MIX: {
-        RGB t1 = Sub::eval(t->tex1, si), t2 = Sub::eval(t->tex2, si);
-        Float amt = Sub::eval(t->amount, si).r;
-        return (1 - amt) * t1 + amt * t2;
+    case MI_TEX_CONSTANT: return rgb3(t->value);                     // constant.h:54
+    case MI_TEX_SCALE: return t1v * t2v;                             // scale.h:57-59
+    case MI_TEX_MIX: {                                               // mix.h:58-62
+        Float amt = amtv.r;
+        return (1 - amt) * t1v + amt * t2v;
     }
-    case MI_TEX_BILERP: {
+    case MI_TEX_BILERP: {                                            // bilerp.h:57-62
         Map2DOut m = Map2D(t, si);
         Float s = m.st.x, tt = m.st.y;
         return ((1 - s) * (1 - tt)) * rgb3(t->v00) + ((1 - s) * (tt)) * rgb3(t->v01) + ((s) * (1 - tt)) * rgb3(t->v10) + ((s) * (tt)) * rgb3(t->v11);
     }
-    case MI_TEX_IMAGEMAP: {
+    case MI_TEX_IMAGEMAP: {                                          // imagemap.h:87-94
         Map2DOut m = Map2D(t, si);
         if (t->image < 0 || (uint32_t)t->image >= c_tex.n_images) return RGB(0.f);
         return MipLookup(c_tex.images + t->image, m.st, m.dstdx, m.dstdy);
     }
-    case MI_TEX_UV: {
+    case MI_TEX_UV: {                                                // uv.h:54-60
         Map2DOut m = Map2D(t, si);
         return RGB(m.st.x - __builtin_floorf(m.st.x), m.st.y - __builtin_floorf(m.st.y), 0);
     }
     case MI_TEX_CHECKERBOARD: {
-        if (t->dim == 3) {
+        if (t->dim == 3) {                                           // checkerboard.h:116-126
             V3 p = XfPointT(t->w2t, si.p);
-            if (((int)__builtin_floorf(p.x) + (int)__builtin_floorf(p.y) + (int)__builtin_floorf(p.z)) % 2 == 0) return Sub::eval(t->tex1, si);
-            return Sub::eval(t->tex2, si);
+            return (((int)__builtin_floorf(p.x) + (int)__builtin_floorf(p.y) + (int)__builtin_floorf(p.z)) % 2 == 0) ? t1v : t2v;
         }
-        Map2DOut m = Map2D(t, si);
+        Map2DOut m = Map2D(t, si);                                   // checkerboard.h:63-99
         bool even = (((int)__builtin_floorf(m.st.x) + (int)__builtin_floorf(m.st.y)) % 2 == 0);
-        if (t->aa == 0) return even ? Sub::eval(t->tex1, si) : Sub::eval(t->tex2, si);
+        if (t->aa == 0) return even ? t1v : t2v;
         Float ds = mx(absf(m.dstdx.x), absf(m.dstdy.x));
         Float dt = mx(absf(m.dstdx.y), absf(m.dstdy.y));
         Float s0 = m.st.x - ds, s1 = m.st.x + ds;
         Float t0 = m.st.y - dt, t1 = m.st.y + dt;
-        if (__builtin_floorf(s0) == __builtin_floorf(s1) && __builtin_floorf(t0) == __builtin_floorf(t1)) return even ? Sub::eval(t->tex1, si) : Sub::eval(t->tex2, si);
+        if (__builtin_floorf(s0) == __builtin_floorf(s1) && __builtin_floorf(t0) == __builtin_floorf(t1)) return even ? t1v : t2v;
         auto bumpInt = [](Float x) { return (int)__builtin_floorf(x / 2) + 2 * mx(x / 2 - (int)__builtin_floorf(x / 2) - (Float)0.5, (Float)0); };
         Float sint = (bumpInt(s1) - bumpInt(s0)) / (2 * ds);
         Float tint = (bumpInt(t1) - bumpInt(t0)) / (2 * dt);
         Float area2 = sint + tint - 2 * sint * tint;
         if (ds > 1 || dt > 1) area2 = .5f;
-        return (1 - area2) * Sub::eval(t->tex1, si) + area2 * Sub::eval(t->tex2, si);
+        return (1 - area2) * t1v + area2 * t2v;
     }
-    case MI_TEX_DOTS: {
+    case MI_TEX_DOTS: {                                              // dots.h:59-80 (tex1 = outsideDot, tex2 = insideDot)
         Map2DOut m = Map2D(t, si);
         int sCell = (int)__builtin_floorf(m.st.x + .5f), tCell = (int)__builtin_floorf(m.st.y + .5f);
         if (Noise3(sCell + .5f, tCell + .5f, .5f) > 0) {
@@ -303,21 +303,21 @@ template <int D> __device__ __noinline__ RGB TexEvalD<D>::eval(int node, const T
             Float sCenter = sCell + maxShift * Noise3(sCell + 1.5f, tCell + 2.8f, .5f);
             Float tCenter = tCell + maxShift * Noise3(sCell + 4.5f, tCell + 9.8f, .5f);
             Float dx = m.st.x - sCenter, dy = m.st.y - tCenter;
-            if (dx * dx + dy * dy < radius * radius) return Sub::eval(t->tex2, si);
+            if (dx * dx + dy * dy < radius * radius) return t2v;
         }
-        return Sub::eval(t->tex1, si);
+        return t1v;
     }
-    case MI_TEX_FBM: case MI_TEX_WRINKLED: {
+    case MI_TEX_FBM: case MI_TEX_WRINKLED: {                         // fbm.h:57-61, wrinkled.h:56-60
         V3 P = XfPointT(t->w2t, si.p);
         return RGB(FBmT(P, XfVectorT(t->w2t, si.dpdx), XfVectorT(t->w2t, si.dpdy), t->omega, t->octaves, t->type == MI_TEX_WRINKLED));
     }
-    case MI_TEX_WINDY: {
+    case MI_TEX_WINDY: {                                             // windy.h:55-61
         V3 P = XfPointT(t->w2t, si.p), dpdx = XfVectorT(t->w2t, si.dpdx), dpdy = XfVectorT(t->w2t, si.dpdy);
         Float windStrength = FBmT(.1f * P, .1f * dpdx, .1f * dpdy, .5f, 3, false);
         Float waveHeight = FBmT(P, dpdx, dpdy, .5f, 6, false);
         return RGB(absf(windStrength) * waveHeight);
     }
-    case MI_TEX_MARBLE: {
+    case MI_TEX_MARBLE: {                                            // marble.h:60-90
         V3 p = XfPointT(t->w2t, si.p), dpdx = XfVectorT(t->w2t, si.dpdx), dpdy = XfVectorT(t->w2t, si.dpdy);
         p = p * t->scale;
         Float marble = p.y + t->variation * FBmT(p, t->scale * dpdx, t->scale * dpdy, t->omega, t->octaves, false);
@@ -339,4 +339,14 @@ template <int D> __device__ __noinline__ RGB TexEvalD<D>::eval(int node, const T
     }
     return RGB(0.f);
 }
-PT_DEV RGB TexEval(int node, const TexCtx &si) { return TexEvalD<PT_TEX_MAX_DEPTH>::eval(node, si); }
+__device__ __noinline__ RGB TexEval(int node, const TexCtx si) {
+    if (node < 0 || (uint32_t)node >= c_tex.n_nodes) return RGB(0.f);
+    const int off = c_tex.prog_off[node], len = c_tex.prog_off[node + 1] - off;
+    if (len == 1) return EvalNode(c_tex.nodes + node, RGB(0.f), RGB(0.f), RGB(0.f), si);   // a leaf (the common case: constants, image maps)
+    RGB val[PT_TEX_MAX_PROG];
+    for (int k = 0; k < len; ++k) {
+        const int4 st = c_tex.prog[off + k];
+        val[k] = EvalNode(c_tex.nodes + st.x, st.y >= 0 ? val[st.y] : RGB(0.f), st.z >= 0 ? val[st.z] : RGB(0.f), st.w >= 0 ? val[st.w] : RGB(0.f), si);
+    }
+    return val[len - 1];
+}
