@@ -326,6 +326,17 @@ def sphere_intersect(spheres, rays, device=0):
     return hits
 
 
+def read_image(path, max_pixels=1 << 24):
+    """the host's ReadImage (.pfm / .png / .tga) -> (H, W, 3) float32, row 0 = top"""
+    L = host_lib()
+    L.pbrt_amd_read_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    buf = np.zeros(3 * max_pixels, dtype=np.float32)
+    w, h = C.c_int(0), C.c_int(0)
+    if L.pbrt_amd_read_image(path.encode(), _ptr(buf), len(buf), C.byref(w), C.byref(h)) != 0:
+        raise RuntimeError("ReadImage failed: %s" % path)
+    return buf[:3 * w.value * h.value].reshape(h.value, w.value, 3).copy()
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         tag = f.readline().strip()

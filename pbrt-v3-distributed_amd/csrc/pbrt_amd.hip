@@ -1141,18 +1141,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->mesh_alpha) for (uint32_t m = 0; m < 2 * d->n_meshes; ++m) c->hasAlpha |= d->mesh_alpha[m] >= 0;
     if (c->hasTex || c->hasAlpha) {
         if (!d->textures || !d->n_textures) return fail("mi_scene_upload: textured materials / alpha masks without a texture table");
-        std::vector<int> depth(d->n_textures, 0);
-        for (uint32_t i = 0; i < d->n_textures; ++i) {   // children precede parents
+        for (uint32_t i = 0; i < d->n_textures; ++i) {   // children precede parents (the evaluation programs below rely on it)
             const mi_texture &t = d->textures[i];
-            int dch = 0;
             const bool hasChildren = t.type == MI_TEX_SCALE || t.type == MI_TEX_MIX || t.type == MI_TEX_CHECKERBOARD || t.type == MI_TEX_DOTS;
             const int children[3] = {t.tex1, t.tex2, t.amount};
-            for (int k = 0; k < (hasChildren ? (t.type == MI_TEX_MIX ? 3 : 2) : 0); ++k) {
-                int ch = children[k];
-                if (ch < 0 || (uint32_t)ch >= i) return fail("mi_scene_upload: texture node refers to a later / missing node");
-                dch = std::max(dch, depth[ch]);
-            }
-            depth[i] = dch + 1;
+            for (int k = 0; k < (hasChildren ? (t.type == MI_TEX_MIX ? 3 : 2) : 0); ++k)
+                if (children[k] < 0 || (uint32_t)children[k] >= i) return fail("mi_scene_upload: texture node refers to a later / missing node");
             if (t.type == MI_TEX_IMAGEMAP && (t.image < 0 || (uint32_t)t.image >= d->n_images || !d->images)) return fail("mi_scene_upload: imagemap without an image");
         }
         for (uint32_t i = 0; i < d->n_images; ++i)

@@ -87,6 +87,14 @@ int pbrt_amd_scene_write_ply(pbrt_amd_scene *s, int prim, const char *filename) 
     std::fclose(f);
     return 0;
 }
+// ReadImage (core/imageio.cpp:60-79) by extension: .pfm, .png, .tga -> RGB floats, row 0 = top
+int pbrt_amd_read_image(const char *filename, float *rgb, int capacity_floats, int *w, int *h) {
+    std::vector<Float> v;
+    if (!ReadImage(filename, &v, w, h)) return -1;
+    if ((int)v.size() > capacity_floats) return -2;
+    std::memcpy(rgb, v.data(), v.size() * sizeof(float));
+    return 0;
+}
 int pbrt_amd_read_pfm(const char *filename, float *rgb, int capacity_floats, int *w, int *h) {
     std::vector<Float> v;
     if (!ReadImagePFM(filename, &v, w, h)) return -1;

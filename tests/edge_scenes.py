@@ -202,9 +202,21 @@ def tex_scene(name):
               'Material "translucent" "texture Kd" "col" "rgb Ks" [.2 .2 .2] "texture roughness" "r"\n' + _WALL +
               'Material "glass" "texture uroughness" "r" "float vroughness" [.02] "float index" [1.4]\n'
               'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.4 0.1 -1.6  .6 0.1 -1.9  .6 1.0 -1.9  -.4 1.0 -1.6] "float uv" [0 0 1 0 1 1 0 1]\n')
+    elif name == "tex_dof":         # thin-lens camera (the lens branch of the ray differentials), Halton sampler, trilinear + EWA image maps, a bump map
+        w = w.replace('Camera "perspective" "float fov" [38]', 'Camera "perspective" "float fov" [38] "float lensradius" [.12] "float focaldistance" [6.2]')
+        w = w.replace('Sampler "sobol" "integer pixelsamples" [4]', 'Sampler "halton" "integer pixelsamples" [5]')
+        w += ('Texture "col" "color" "imagemap" "string filename" "%s" "float uscale" [3] "float vscale" [3]\n' % T("color_23x17.png") +
+              'Texture "tri" "color" "imagemap" "string filename" "%s" "bool trilinear" ["true"]\n' % T("hdr_12x10.pfm") +
+              'Texture "h" "float" "imagemap" "string filename" "%s" "float scale" [.05] "bool gamma" ["false"]\n' % T("height_32.png") +
+              'Material "matte" "texture Kd" "col"\n' + _GROUND +
+              'Material "plastic" "texture Kd" "tri" "rgb Ks" [.3 .3 .3] "float roughness" [.1] "texture bumpmap" "h"\n' + _PANEL +
+              'Material "matte" "texture Kd" "col" "texture bumpmap" "h"\n' + _bulge() +
+              'Material "matte" "texture Kd" "tri"\n' + _WALL)
     else:
         raise KeyError(name)
     return w + "WorldEnd\n"
 
 
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
+# pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
+TEX_ORACLE_ONLY = ["tex_dof"]

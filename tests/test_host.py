@@ -150,3 +150,118 @@ def test_bvh4_collapse_invariants(built, tmp_path):
         sc = pa.Scene(text=t) if acc else pa.Scene(out)
         st = pa.bvh4_validate(sc)
         assert st["prims"] == sc.info["n_tris"] and st["stack_need"] == 3 * (st["depth"] + 1) + 1, (acc, st)
+
+
+# ---------------------------------------------------------------- image readers (core/imageio.cpp:216-290)
+def _png_bytes(samples, w, h, ctype, depth, palette=None, filters=None):
+    """encode rows of integer samples (h x w*channels) as a PNG with the given per-row filter types (PNG spec s.9)"""
+    import struct, zlib
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    rows = []
+    for y in range(h):
+        r = [int(v) for v in samples[y]]
+        if depth == 16:
+            b = b"".join(struct.pack(">H", v) for v in r)
+        elif depth == 8:
+            b = bytes(r)
+        else:
+            bits = "".join(format(v, "0%db" % depth) for v in r)
+            bits += "0" * (-len(bits) % 8)
+            b = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        rows.append(b)
+    bpp = max(1, ch * depth // 8)
+    out = b""
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)] if filters else 0
+        enc = bytearray()
+        for i, x in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) >> 1
+            else:
+                pp = a + b - c
+                pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            enc.append((x - p) & 255)
+        out += bytes([ft]) + bytes(enc)
+        prev = row
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    half = len(out) // 2
+    comp = zlib.compress(out, 6)
+    return data + chunk(b"IDAT", comp[:half]) + chunk(b"tEXt", b"k\0v") + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")   # split IDAT + ancillary chunk
+
+
+@pytest.mark.parametrize("ctype,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)])
+def test_png_reader_all_layouts(built, tmp_path, ctype, depth):
+    """every colour type / bit depth of non-interlaced PNG, all five scanline filters, split IDAT: the host reader must give what
+    lodepng_decode24 gives the reference (8-bit RGB: 16-bit samples keep their high byte, sub-byte greys scale to 255, alpha dropped) / 255"""
+    rng = np.random.default_rng(ctype * 100 + depth)
+    w, h = 13, 9
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    s = rng.integers(0, 1 << depth, (h, w * ch))
+    pal = [int(v) for v in rng.integers(0, 256, 3 * (1 << depth))] if ctype == 3 else None
+    f = tmp_path / "t.png"
+    f.write_bytes(_png_bytes(s, w, h, ctype, depth, pal, filters=[0, 1, 2, 3, 4]))
+    img = pa.read_image(str(f))
+    px = s.reshape(h, w, ch)
+    to8 = (lambda v: v >> 8) if depth == 16 else ((lambda v: v) if depth == 8 else (lambda v: (v * 255) // ((1 << depth) - 1)))
+    if ctype == 3:
+        want = np.array(pal, dtype=np.int64).reshape(-1, 3)[px[..., 0]]
+    elif ctype in (0, 4):
+        want = np.repeat(to8(px[..., :1]), 3, axis=2)
+    else:
+        want = to8(px[..., :3])
+    assert img.shape == (h, w, 3)
+    assert np.array_equal(img, (want.astype(np.float32) / np.float32(255)))
+
+
+def test_tga_reader_variants(built, tmp_path):
+    """TGA: 24 / 32-bit true colour, uncompressed and RLE, 8-bit mono, colour-mapped; all four origin conventions"""
+    import struct
+    rng = np.random.default_rng(5)
+    w, h = 7, 5
+    rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)        # row 0 = top, what ReadImage must return (/255)
+
+    def hdr(typ, bits, desc, cmap=(0, 0, 0, 0)):
+        return struct.pack("<BBBHHBHHHHBB", 0, cmap[0], typ, cmap[1], cmap[2], cmap[3], 0, 0, w, h, bits, desc)
+
+    def rle(pixels, pb):   # alternate raw packets and run packets
+        out, i = b"", 0
+        n = len(pixels) // pb
+        while i < n:
+            k = min(3, n - i)
+            if (i // 3) % 2 == 0:
+                out += bytes([k - 1]) + pixels[i * pb:(i + k) * pb]
+                i += k
+            else:
+                out += bytes([0x80]) + pixels[i * pb:(i + 1) * pb]
+                i += 1
+        return out
+    for desc in (0x00, 0x10, 0x20, 0x30):
+        src = rgb[:, ::-1] if desc & 0x10 else rgb
+        src = src if desc & 0x20 else src[::-1]
+        bgr = np.ascontiguousarray(src[..., ::-1])
+        bgra = np.concatenate([bgr, np.full((h, w, 1), 200, np.uint8)], -1)
+        cases = {"t24": hdr(2, 24, desc) + bgr.tobytes(), "t32": hdr(2, 32, desc | 8) + bgra.tobytes(),
+                 "r24": hdr(10, 24, desc) + rle(bgr.tobytes(), 3), "r32": hdr(10, 32, desc | 8) + rle(bgra.tobytes(), 4)}
+        for name, data in cases.items():
+            f = tmp_path / ("%s_%02x.tga" % (name, desc))
+            f.write_bytes(data)
+            assert np.array_equal(pa.read_image(str(f)), rgb.astype(np.float32) / np.float32(255)), (name, desc)
+    mono = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    f = tmp_path / "m.tga"; f.write_bytes(hdr(3, 8, 0x20) + mono.tobytes())
+    assert np.array_equal(pa.read_image(str(f)), np.repeat(mono[..., None], 3, 2).astype(np.float32) / np.float32(255))
+    pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)            # BGR entries
+    idx = rng.integers(0, 16, (h, w)).astype(np.uint8)
+    f = tmp_path / "c.tga"; f.write_bytes(hdr(1, 8, 0x20, cmap=(1, 0, 16, 24)) + pal.tobytes() + idx.tobytes())
+    assert np.array_equal(pa.read_image(str(f)), pal[idx][..., ::-1].astype(np.float32) / np.float32(255))

@@ -155,7 +155,7 @@ def test_oracle_vs_live_reference_binary(built, tmp_path):
 import edge_scenes
 
 
-@pytest.mark.parametrize("name", edge_scenes.NAMES + edge_scenes.TEX_NAMES)
+@pytest.mark.parametrize("name", edge_scenes.NAMES + edge_scenes.TEX_NAMES + edge_scenes.TEX_ORACLE_ONLY)
 def test_oracle_edge_cases_match_reference(built, name):
     """Edge cases of the path (tests/edge_scenes.py): constant infinite light (escaped rays, light sampling, single-light ->
     uniform substitution), thin lens, crop window + pixel bounds, luminance clamp, empty world, single-leaf BVH with a
