@@ -75,8 +75,8 @@ void Distribution1D(const Float *f, int n, Float *func, Float *cdf, Float *funcI
 std::shared_ptr<EnvMap> CreateEnvMap(const std::string &filename, const RGB &L) {
     std::vector<Float> texels;
     int w = 0, h = 0;
-    if (!ReadImagePFM(filename, &texels, &w, &h)) {
-        Error("Unable to read environment map \"%s\" (PFM is the format this host reads; core/imageio.cpp:60-79)", filename.c_str());
+    if (!ReadImage(filename, &texels, &w, &h)) {   // .pfm, .png, .tga (host/imageread.cpp); the radiance map is used as read: no gamma (infinite.cpp:51)
+        Error("Unable to read environment map \"%s\"", filename.c_str());
         return nullptr;
     }
     Level l0;

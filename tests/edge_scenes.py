@@ -43,6 +43,8 @@ def scene(name):
         return _OPEN % ('LightSource "spot" "point from" [2 4 -3] "point to" [-.5 0 0] "rgb I" [120 110 90] "float coneangle" [22] "float conedeltaangle" [7]\n'
                         'AttributeBegin\nRotate 20 0 1 0\nTranslate .3 0 0\n'
                         'LightSource "spot" "point from" [-3 3 -2] "point to" [0 .5 0] "rgb I" [40 60 90] "rgb scale" [.5 .5 .5]\nAttributeEnd')
+    if name == "envmap_png":    # the radiance map read from an 8-bit PNG (host/imageread.cpp instead of the PFM reader); same device path as "envmap"
+        return scene("envmap").replace(os.path.join(ROOT, "scenes", "envmap_40x20.pfm"), os.path.join(ROOT, "scenes", "textures", "color_23x17.png"))
     if name in ("envmap", "envmap_power"):   # infinite light with a radiance map (non-power-of-two: Lanczos resampling), rotated; + a point light
         t = _OPEN % ('AttributeBegin\nRotate -90 1 0 0\nRotate 30 0 0 1\nLightSource "infinite" "rgb L" [.8 .9 1] "string mapname" "%s"\nAttributeEnd\n'
                      'LightSource "point" "point from" [3 4 -2] "rgb I" [5 5 5]' % os.path.join(ROOT, "scenes", "envmap_40x20.pfm"))
@@ -219,4 +221,4 @@ def tex_scene(name):
 
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
-TEX_ORACLE_ONLY = ["tex_dof"]
+TEX_ORACLE_ONLY = ["tex_dof", "envmap_png"]

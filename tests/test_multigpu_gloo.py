@@ -40,10 +40,19 @@ def _worker(rank, world, port, scene_text, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_tile_sharding_and_film_reduce(built, tmp_path):
+def _scene_text(which):
+    if which == "cornell":
+        text = open(os.path.join(ol.ROOT, "scenes", "cornell.pbrt")).read()
+        return text.replace('[400] "integer yresolution" [400]', '[80] "integer yresolution" [48]').replace('"integer pixelsamples" [8]', '"integer pixelsamples" [4]')
+    sys.path.insert(0, os.path.join(ol.ROOT, "tests"))
+    import edge_scenes
+    return edge_scenes.scene(which)   # a textured scene: every rank parses the scene and builds the image pyramids itself
+
+
+@pytest.mark.parametrize("which", ["cornell", "tex_imagemap"])
+def test_two_rank_tile_sharding_and_film_reduce(built, tmp_path, which):
     import torch.multiprocessing as mp
-    text = open(os.path.join(ol.ROOT, "scenes", "cornell.pbrt")).read()
-    text = text.replace('[400] "integer yresolution" [400]', '[80] "integer yresolution" [48]').replace('"integer pixelsamples" [8]', '"integer pixelsamples" [4]')
+    text = _scene_text(which)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, text, str(tmp_path)), nprocs=2, join=True)
     combined = np.load(tmp_path / "combined.npy")
