@@ -434,6 +434,14 @@ int mi_intersect(mi_ctx *ctx, const mi_ray *rays, int64_t n, mi_hit *hits);
 int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits);
 /* BVHAccel::IntersectP (bvh.cpp:702-738) */
 int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded);
+
+/* Host-only groundwork of the NEXT traversal layout (csrc/pt_bvh8.h; no kernel uses it yet): collapses the reference's BVH2 to
+ * 8-wide nodes with 8-bit quantised child boxes (one 128-byte line per node), checks every quantised box against its reference
+ * box in exact arithmetic, and runs the per-ray traversal state machine of the future kernel ON THE HOST for `rays` (closest hit,
+ * or first hit found when any_hit != 0).  hits (may be NULL): prim / t / barycentrics as mi_intersect reports them.
+ * stats: [0] BVH8 nodes, [1] leaf references, [2] depth, [3] deepest stack seen, [4] primitives covered, [5] nodes visited,
+ * [6] primitives tested, [7] rays that hit.  No GPU needed. */
+int mi_bvh8_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
 /* Sphere::Intersect (shapes/sphere.cpp:48-162) of ray i against spheres[i] (explicit records, no scene): hit flag, tHit and the
  * world-space interaction's p, pError, n -- for the FullSphere / PartialSphere reintersection vectors of the reference's tests */
 typedef struct mi_sphere_hit { int32_t hit; float t; float p[3], p_error[3], n[3]; } mi_sphere_hit;

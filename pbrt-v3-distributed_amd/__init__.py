@@ -47,7 +47,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -101,6 +101,7 @@ def device_lib():
         L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_bvh8_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -304,6 +305,20 @@ SPHERE_DTYPE = np.dtype([("o2w", np.float32, 16), ("w2o", np.float32, 16), ("rad
 TEX_QUERY_DTYPE = np.dtype([("p", np.float32, 3), ("uv", np.float32, 2), ("dpdx", np.float32, 3), ("dpdy", np.float32, 3), ("dudx", np.float32),
                             ("dvdx", np.float32), ("dudy", np.float32), ("dvdy", np.float32)])   # mi_tex_query
 SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
+
+
+def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True):
+    """Host-only: build the quantised BVH8 of the next traversal layout, check it, and run the future kernel's per-ray state machine on the
+    host for `rays` -> (hits or None, dict of statistics).  No GPU needed."""
+    st = np.zeros(8, dtype=np.int64)
+    L = device_lib()
+    n = 0 if rays is None else len(rays)
+    r = np.ascontiguousarray(rays, dtype=RAY_DTYPE) if n else None
+    hits = np.zeros(n, dtype=HIT_DTYPE) if (n and want_hits) else None
+    if L.mi_bvh8_validate(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
+        raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
+    keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]
+    return hits, dict(zip(keys, [int(v) for v in st]))
 
 
 def bvh4_validate(scene):

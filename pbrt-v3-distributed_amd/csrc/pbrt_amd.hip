@@ -27,6 +27,7 @@
 
 #include "pt_shade.h"
 #include "pt_material.h"
+#include "pt_bvh8.h"
 #include "sobol_tables.inc"
 
 __constant__ DevTex c_tex;   // texture tables of the scene being rendered (set by mi_render for textured scenes only)
@@ -1910,6 +1911,74 @@ int mi_sphere_intersect(int device, const mi_sphere *spheres, const mi_ray *rays
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(mi_sphere_hit), hipMemcpyDeviceToHost));
+    return 0;
+}
+// Host-only groundwork of the next traversal layout (pt_bvh8.h): collapse the reference's BVH2 to BVH8 with quantised child boxes
+// (every quantised box checked against its reference box in exact arithmetic), then run the per-ray state machine of the future
+// kernel on the host for the given rays.  hits may be NULL (statistics only).  No GPU involved.
+int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
+    if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8_validate: null argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    bvh8::Builder bb;
+    if (!bb.run(d)) return fail("mi_bvh8_validate: " + bb.error);
+    // structural checks: every primitive in exactly one leaf reference, children inside the quantised box their parent holds for them
+    std::vector<uint8_t> covered(d->n_tris, 0);
+    int64_t leaves = 0;
+    std::vector<uint32_t> todo;
+    if (!bb.out.empty()) todo.push_back(0);
+    while (!todo.empty()) {
+        uint32_t ni = todo.back(); todo.pop_back();
+        if (ni >= bb.out.size()) return fail("mi_bvh8_validate: child index out of range");
+        const BVH8Node &nd = bb.out[ni];
+        for (int k = 0; k < 8; ++k) {
+            uint32_t c = nd.child[k];
+            if (c == bvh8::EMPTY) continue;
+            double lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = (double)nd.p[a] + nd.qlo[a][k] * (double)nd.s[a]; hi[a] = (double)nd.p[a] + nd.qhi[a][k] * (double)nd.s[a]; }
+            if (c & bvh8::LEAF) {
+                uint32_t first = c & bvh8::FIRST_MASK, count = ((c >> 27) & 0xfu) + 1;
+                ++leaves;
+                if (first + count > d->n_tris) return fail("mi_bvh8_validate: bad leaf reference");
+                for (uint32_t t = first; t < first + count; ++t) {
+                    if (covered[t]++) return fail("mi_bvh8_validate: primitive referenced twice");
+                    const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+                    if (v[0] == MI_PRIM_SPHERE) continue;
+                    for (int kk = 0; kk < 3; ++kk)
+                        for (int a = 0; a < 3; ++a) {
+                            double x = d->P[3 * (size_t)v[kk] + a];
+                            if (x < lo[a] || x > hi[a]) return fail("mi_bvh8_validate: primitive outside its quantised leaf box");
+                        }
+                }
+            } else {
+                const BVH8Node &ch = bb.out[c];
+                for (int j = 0; j < 8; ++j) {
+                    if (ch.child[j] == bvh8::EMPTY) continue;
+                    for (int a = 0; a < 3; ++a) {
+                        double clo = (double)ch.p[a] + ch.qlo[a][j] * (double)ch.s[a];
+                        // a child's own quantised boxes may stick out of the box its parent holds for it by less than one parent cell
+                        // (both contain the reference boxes; the traversal never relies on nesting of the QUANTISED boxes)
+                        if (clo < lo[a] - (double)nd.s[a] - (double)ch.s[a]) return fail("mi_bvh8_validate: child grid far outside its parent's box");
+                    }
+                }
+                todo.push_back(c);
+            }
+        }
+    }
+    int64_t ncov = 0;
+    for (uint8_t f : covered) ncov += f;
+    if (ncov != (int64_t)d->n_tris) return fail("mi_bvh8_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
+    bvh8::Stats st;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t prim; float t, b[3];
+        bool hit = bvh8::traverse(d, bb.out, rays[i], any_hit != 0, &prim, &t, b, &st);
+        if (hits) {
+            std::memset(&hits[i], 0, sizeof(mi_hit));
+            hits[i].prim = hit ? (int32_t)prim : -1;
+            hits[i].t = hit ? t : 0; hits[i].b0 = b[0]; hits[i].b1 = b[1]; hits[i].b2 = b[2];
+        }
+    }
+    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
+    stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
     return 0;
 }
 // stage-level texture evaluation: Texture<T>::Evaluate of node `node` at n recorded interactions

@@ -1,0 +1,149 @@
+// Static instruction-count probe (NOT product code, never launched): one interior-node step of the traversal for alternative
+// node layouts of the same tree, compiled for gfx950 so that the per-step VALU / VMEM / LDS instruction counts can be read off the
+// ISA (tools/isa_probe/count.py).  Each kernel performs ONE step for a per-lane ray and stores what the next step would need, so that
+// nothing is optimised away.  Layouts:
+//   bvh4_full    128 B  the round-1 node (6 x float4 planes SoA + 4 child refs)
+//   bvh4_quant    64 B  4 children, 8-bit planes on a per-node power-of-two grid (origin 12 B, cell size 12 B, 24 B planes, 16 B refs)
+//   bvh8_quant   128 B  8 children, same quantisation (12 + 12 + 48 + 32 B refs + pad): one cache line per node
+//   bvh8_full    256 B  8 children, float planes (two cache lines)
+// Children are visited nearest first; the others are pushed with their entry distance (culled at pop time), unsorted for the
+// 8-wide layouts (sorting 8 keys costs 19 compare-exchanges), sorted for the 4-wide ones as in the product kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#define INF __builtin_huge_valf()
+struct Ray { float ox, oy, oz, ix, iy, iz, fx, fy, fz, tMax; uint32_t cur; };   // i = 1/d, f = (1/d) * (1 + 4 gamma(3))
+struct Out { uint32_t next; uint32_t pushed[7]; float pt[7]; int n; };
+
+#define BOXT(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z, e, x)                                                                          \
+    {                                                                                                                          \
+        float nx = r.ix < 0 ? hi_x : lo_x, fx_ = r.ix < 0 ? lo_x : hi_x, ny = r.iy < 0 ? hi_y : lo_y, fy_ = r.iy < 0 ? lo_y : hi_y; \
+        float nz = r.iz < 0 ? hi_z : lo_z, fz_ = r.iz < 0 ? lo_z : hi_z;                                                          \
+        e = __builtin_fmaxf(__builtin_fmaxf((nx - r.ox) * r.ix, (ny - r.oy) * r.iy), (nz - r.oz) * r.iz);                         \
+        x = __builtin_fminf(__builtin_fminf((fx_ - r.ox) * r.fx, (fy_ - r.oy) * r.fy), (fz_ - r.oz) * r.fz);                      \
+    }
+
+template <int W> __device__ __forceinline__ void finish(const float *t, const bool *h, const uint32_t *c, Out &o) {
+    int best = -1;
+    float tb = INF;
+#pragma unroll
+    for (int k = 0; k < W; ++k) if (h[k] && t[k] < tb) { tb = t[k]; best = k; }
+    o.n = 0;
+    o.next = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        if (!h[k]) continue;
+        if (k == best) o.next = c[k];
+        else { o.pushed[o.n] = c[k]; o.pt[o.n] = t[k]; ++o.n; }
+    }
+}
+
+struct N4F { float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4]; uint32_t child[4], pad[4]; };
+extern "C" __global__ void bvh4_full(const N4F *nodes, const Ray *rays, Out *out) {
+    Ray r = rays[threadIdx.x];
+    const float4 *q = reinterpret_cast<const float4 *>(nodes + r.cur);
+    float4 lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5];
+    uint4 ch = reinterpret_cast<const uint4 *>(nodes + r.cur)[6];
+    float t[4]; bool h[4]; uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+    float e, x;
+#define ONE(k, m) BOXT(lx.m, ly.m, lz.m, hx.m, hy.m, hz.m, e, x) h[k] = (e <= x) && (e < r.tMax) && (x > 0); t[k] = e;
+    ONE(0, x) ONE(1, y) ONE(2, z) ONE(3, w)
+#undef ONE
+    Out o; finish<4>(t, h, c, o); out[threadIdx.x] = o;
+}
+
+struct N4Q { float p[3], s[3]; uint8_t q[6][4]; uint32_t child[4]; };   // 64 B
+extern "C" __global__ void bvh4_quant(const N4Q *nodes, const Ray *rays, Out *out) {
+    Ray r = rays[threadIdx.x];
+    const uint4 *w = reinterpret_cast<const uint4 *>(nodes + r.cur);
+    uint4 a = w[0], b = w[1], cc = w[2], ch = w[3];
+    float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z), sx = __uint_as_float(a.w), sy = __uint_as_float(b.x), sz = __uint_as_float(b.y);
+    uint32_t qlx = b.z, qly = b.w, qlz = cc.x, qhx = cc.y, qhy = cc.z, qhz = cc.w;
+    float t[4]; bool h[4]; uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float lox = px + (float)((qlx >> (8 * k)) & 255u) * sx, loy = py + (float)((qly >> (8 * k)) & 255u) * sy, loz = pz + (float)((qlz >> (8 * k)) & 255u) * sz;
+        float hix = px + (float)((qhx >> (8 * k)) & 255u) * sx, hiy = py + (float)((qhy >> (8 * k)) & 255u) * sy, hiz = pz + (float)((qhz >> (8 * k)) & 255u) * sz;
+        float e, x;
+        BOXT(lox, loy, loz, hix, hiy, hiz, e, x)
+        h[k] = (e <= x) && (e < r.tMax) && (x > 0) && c[k] != 0xffffffffu; t[k] = e;
+    }
+    Out o; finish<4>(t, h, c, o); out[threadIdx.x] = o;
+}
+
+struct N8Q { float p[3], s[3]; uint32_t child[8]; uint8_t q[6][8]; uint32_t pad[6]; };   // 128 B
+extern "C" __global__ void bvh8_quant(const N8Q *nodes, const Ray *rays, Out *out) {
+    Ray r = rays[threadIdx.x];
+    const uint4 *w = reinterpret_cast<const uint4 *>(nodes + r.cur);
+    uint4 a = w[0], b = w[1], c0 = w[2], c1 = w[3], q0 = w[4], q1 = w[5], q2 = w[6];
+    float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z), sx = __uint_as_float(a.w), sy = __uint_as_float(b.x), sz = __uint_as_float(b.y);
+    uint32_t c[8] = {b.z, b.w, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};   // (layout detail irrelevant for the count)
+    uint32_t ql[3][2] = {{c1.z, c1.w}, {q0.x, q0.y}, {q0.z, q0.w}}, qh[3][2] = {{q1.x, q1.y}, {q1.z, q1.w}, {q2.x, q2.y}};
+    float t[8]; bool h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int wd = k >> 2, sh = 8 * (k & 3);
+        float lox = px + (float)((ql[0][wd] >> sh) & 255u) * sx, loy = py + (float)((ql[1][wd] >> sh) & 255u) * sy, loz = pz + (float)((ql[2][wd] >> sh) & 255u) * sz;
+        float hix = px + (float)((qh[0][wd] >> sh) & 255u) * sx, hiy = py + (float)((qh[1][wd] >> sh) & 255u) * sy, hiz = pz + (float)((qh[2][wd] >> sh) & 255u) * sz;
+        float e, x;
+        BOXT(lox, loy, loz, hix, hiy, hiz, e, x)
+        h[k] = (e <= x) && (e < r.tMax) && (x > 0) && c[k] != 0xffffffffu; t[k] = e;
+    }
+    Out o; finish<8>(t, h, c, o); out[threadIdx.x] = o;
+}
+
+// the same layout with the decode folded into the ray:  t = q * (s / d) + (p - o) / d  -- three operations per plane instead of five.
+// The rounding of this form is not the reference's, so conservativeness needs explicit slack: per node and axis
+// delta = 4 eps (|B| + 255 |A|) is subtracted from the near offsets and added to the far ones (two B's per axis, nothing per plane).
+extern "C" __global__ void bvh8_quant_folded(const N8Q *nodes, const Ray *rays, Out *out) {
+    Ray r = rays[threadIdx.x];
+    const uint4 *w = reinterpret_cast<const uint4 *>(nodes + r.cur);
+    uint4 a = w[0], b = w[1], c0 = w[2], c1 = w[3], q0 = w[4], q1 = w[5], q2 = w[6];
+    float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z), sx = __uint_as_float(a.w), sy = __uint_as_float(b.x), sz = __uint_as_float(b.y);
+    uint32_t c[8] = {b.z, b.w, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+    // near / far plane words picked per ray sign (uniform per ray: selects, not per-plane work)
+    uint32_t nxw[2] = {r.ix < 0 ? q1.x : c1.z, r.ix < 0 ? q1.y : c1.w}, fxw[2] = {r.ix < 0 ? c1.z : q1.x, r.ix < 0 ? c1.w : q1.y};
+    uint32_t nyw[2] = {r.iy < 0 ? q1.z : q0.x, r.iy < 0 ? q1.w : q0.y}, fyw[2] = {r.iy < 0 ? q0.x : q1.z, r.iy < 0 ? q0.y : q1.w};
+    uint32_t nzw[2] = {r.iz < 0 ? q2.x : q0.z, r.iz < 0 ? q2.y : q0.w}, fzw[2] = {r.iz < 0 ? q0.z : q2.x, r.iz < 0 ? q0.w : q2.y};
+    const float eps4 = 4 * 5.9604644775390625e-08f;
+    float Ax = sx * r.ix, Bx = (px - r.ox) * r.ix, dx = eps4 * (__builtin_fabsf(Bx) + 255 * __builtin_fabsf(Ax));
+    float Ay = sy * r.iy, By = (py - r.oy) * r.iy, dy = eps4 * (__builtin_fabsf(By) + 255 * __builtin_fabsf(Ay));
+    float Az = sz * r.iz, Bz = (pz - r.oz) * r.iz, dz = eps4 * (__builtin_fabsf(Bz) + 255 * __builtin_fabsf(Az));
+    float Bnx = Bx - dx, Bfx = Bx + dx, Bny = By - dy, Bfy = By + dy, Bnz = Bz - dz, Bfz = Bz + dz;
+    float t[8]; bool h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int wd = k >> 2, sh = 8 * (k & 3);
+        float e = __builtin_fmaxf(__builtin_fmaxf((float)((nxw[wd] >> sh) & 255u) * Ax + Bnx, (float)((nyw[wd] >> sh) & 255u) * Ay + Bny), (float)((nzw[wd] >> sh) & 255u) * Az + Bnz);
+        float x = __builtin_fminf(__builtin_fminf((float)((fxw[wd] >> sh) & 255u) * Ax + Bfx, (float)((fyw[wd] >> sh) & 255u) * Ay + Bfy), (float)((fzw[wd] >> sh) & 255u) * Az + Bfz);
+        h[k] = (e <= x) && (e < r.tMax) && (x > 0) && c[k] != 0xffffffffu; t[k] = e;
+    }
+    Out o; finish<8>(t, h, c, o); out[threadIdx.x] = o;
+}
+// the step without its bookkeeping: what `finish` costs alone (subtract from the others)
+extern "C" __global__ void finish8_only(const float *tt, const uint32_t *cc, Out *out) {
+    float t[8]; bool h[8]; uint32_t c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t[k] = tt[threadIdx.x * 8 + k]; c[k] = cc[threadIdx.x * 8 + k]; h[k] = t[k] < 1e30f; }
+    Out o; finish<8>(t, h, c, o); out[threadIdx.x] = o;
+}
+extern "C" __global__ void finish4_only(const float *tt, const uint32_t *cc, Out *out) {
+    float t[4]; bool h[4]; uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t[k] = tt[threadIdx.x * 4 + k]; c[k] = cc[threadIdx.x * 4 + k]; h[k] = t[k] < 1e30f; }
+    Out o; finish<4>(t, h, c, o); out[threadIdx.x] = o;
+}
+
+struct N8F { float lox[8], loy[8], loz[8], hix[8], hiy[8], hiz[8]; uint32_t child[8], pad[8]; };   // 256 B
+extern "C" __global__ void bvh8_full(const N8F *nodes, const Ray *rays, Out *out) {
+    Ray r = rays[threadIdx.x];
+    const N8F &n = nodes[r.cur];
+    float t[8]; bool h[8]; uint32_t c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float e, x;
+        BOXT(n.lox[k], n.loy[k], n.loz[k], n.hix[k], n.hiy[k], n.hiz[k], e, x)
+        c[k] = n.child[k];
+        h[k] = (e <= x) && (e < r.tMax) && (x > 0); t[k] = e;
+    }
+    Out o; finish<8>(t, h, c, o); out[threadIdx.x] = o;
+}
