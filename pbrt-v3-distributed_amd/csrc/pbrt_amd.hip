@@ -280,12 +280,16 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #endif
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false>
+// WIDE: experimental -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
+template <bool WIDE> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <> struct TravTypes<true> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
-    TravStack st;
-    st.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
-    st.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    typedef TravTypes<WIDE> TT;
+    __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
+    typename TT::Stack st;
+    st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
+    st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
     const uint32_t n = ps.qcount[MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW)];
     const uint32_t segLen = (((n + 7) / 8) + 63u) & ~63u;
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     uint32_t poolNext = 0, poolEnd = 0;   // wave-uniform
     bool active = false;
     uint32_t slot = 0, lightNum = 0;
-    TravState ts;
+    typename TT::State ts;
     ts.cur = TRAV_DONE;
     TraceCounters tc = {0, 0};
     uint32_t nrays = 0;
@@ -341,12 +345,15 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     bool wantNode = active && ts.atNode();
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
-                    if (wantNode) TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
+                    if (wantNode) {
+                        if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
+                        else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
+                    }
                     int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
                     ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
@@ -993,6 +1000,11 @@ struct mi_ctx {
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
+    // experimental BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
+    bool useBvh8 = false;
+    const BVH8Node *nodes8 = nullptr;
+    uint32_t nNodes8 = 0;
+    int stackNeed8 = 0, spill8 = 1;
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     DevScene sc;
     bool haveScene = false;
@@ -1172,7 +1184,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(44 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
+    c->sceneBufs.resize(45 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1192,6 +1204,20 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     { DevBuf &b = next(); if (upload(c, b, bb.out.data(), bb.out.size() * sizeof(BVH4Node))) return -1; sc.nodes = b.as<BVH4Node>(); }
     sc.n_nodes = (uint32_t)bb.out.size();
     sc.stack_need = 3 * (bb.maxDepth + 1) + 1;
+    c->useBvh8 = false;
+    {   // experimental: the quantised BVH8 next to the BVH4 (the k_trace<..., WIDE> instances read it through a copy of DevScene)
+        const char *e = std::getenv("PBRT_AMD_BVH8");
+        if (e && e[0] == '1' && d->n_bvh_nodes) {
+            bvh8::Builder b8;
+            if (!b8.run(d)) return fail("mi_scene_upload: BVH8 build: " + b8.error);
+            DevBuf &b = next();
+            if (upload(c, b, b8.out.data(), b8.out.size() * sizeof(BVH8Node))) return -1;
+            HIP_TRY(hipStreamSynchronize(c->stream));   // b8 is a local
+            c->nodes8 = b.as<BVH8Node>(); c->nNodes8 = (uint32_t)b8.out.size();
+            c->stackNeed8 = 7 * (b8.maxDepth + 1) + 1;
+            c->useBvh8 = true;
+        }
+    }
     // triangle records
     c->hasSpheres = false;
     std::vector<float4> tv(3 * (size_t)d->n_tris);
@@ -1602,7 +1628,11 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, 8);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * c->nkeys);
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
-    ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * ps.spill_per_thread * (sizeof(StackEntry) / 4));
+    c->spill8 = std::max(1, c->stackNeed8 - PT_LDS_STACK8);
+    {   // one spill area serves whichever traversal runs (BVH4: 4-byte entries, BVH8: 8-byte entries)
+        size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4), words8 = c->useBvh8 ? (size_t)c->spill8 * 2 : 0;
+        ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
+    }
 #undef ALLOC
     ps.counters = c->counters.as<unsigned long long>();
     ps.cap = cap;
@@ -1636,7 +1666,15 @@ static void harvest(mi_ctx *c) {
 
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
-        if (c->hasAlpha) { /* alpha-masked meshes: the general instance (spheres + masks) */                        \
+        if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* experimental: quantised BVH8 nodes */                \
+            DevScene sc8 = sc;                                                                                      \
+            sc8.nodes = reinterpret_cast<const BVH4Node *>(c->nodes8);                                              \
+            sc8.n_nodes = c->nNodes8;                                                                               \
+            PathState ps8 = ps;                                                                                     \
+            ps8.spill_per_thread = c->spill8;                                                                       \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
+        } else if (c->hasAlpha) { /* alpha-masked meshes: the general instance (spheres + masks) */                        \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true>), grid, block, 0, st, sc, ps, qin);  \
             else hipLaunchKernelGGL((k_trace<MODE, false, true, true>), grid, block, 0, st, sc, ps, qin);           \
         } else if (c->hasSpheres) {                                                                                        \

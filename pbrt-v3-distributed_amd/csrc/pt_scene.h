@@ -511,8 +511,8 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
 // alpha masks (scenes with masked meshes only): true if the mask(s) of `prim`'s mesh evaluate to 0 at the hit (pt_material.h)
 __device__ bool TriAlphaRejects(const uint4 *tri_info, const TriShade *tri_shade, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, Float b0, Float b1,
                                 Float b2, bool anyHit);
-template <bool ANY, bool COUNT, bool SPHERES = false, bool ALPHA = false>
-PT_DEV void TravLeafStep(const DevScene &sc, TravState &ts, TravStack &st, TraceCounters *cnt) {
+template <bool ANY, bool COUNT, bool SPHERES = false, bool ALPHA = false, class TS = TravState, class ST = TravStack>
+PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt) {
     uint32_t first = ts.cur & BVH4_FIRST_MASK, left = (ts.cur >> 27) & 0xfu;   // left = triangles after this one
     V3 p0, p1, p2;
     uint32_t flags;
@@ -549,4 +549,96 @@ PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, T
     }
     *tHit = ts.tHit; *primHit = ts.prim;
     return ts.prim != TRAV_MISS;
+}
+
+// ------------------------------------------------------------------ BVH8 traversal (csrc/pt_bvh8.h; experimental, off unless PBRT_AMD_BVH8=1)
+// Same per-lane state machine over the quantised 8-wide nodes.  Validated on the host (mi_bvh8_validate runs the same steps:
+// hits identical to the reference's BVH2 traversal); the kernels below were first compiled in round 1 and had not been run on a
+// GPU when that round's budget ended -- the default path is the BVH4 one above.
+#define PT_LDS_STACK8 12   /* 8-byte entries: the same 24 KiB of LDS per block as the BVH4 stack */
+typedef unsigned long long StackEntry8;   // child reference | entry distance bits << 32
+typedef __attribute__((address_space(3))) StackEntry8 LdsStackEntry8;
+struct TravStack8 {
+    LdsStackEntry8 *lds;
+    StackEntry8 *spill;
+    int sp;
+    PT_DEV void push(uint32_t v, Float t) {
+        StackEntry8 e = (StackEntry8)v | ((StackEntry8)__float_as_uint(t) << 32);
+        if (sp < PT_LDS_STACK8) lds[sp * PT_BLOCK] = e; else spill[sp - PT_LDS_STACK8] = e;
+        ++sp;
+    }
+    PT_DEV uint32_t pop(Float tMax) {   // a box entered beyond the hit found meanwhile is dropped unfetched
+        while (sp) {
+            --sp;
+            StackEntry8 e = (sp < PT_LDS_STACK8) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK8];
+            if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
+        }
+        return 0xFFFFFFFFu;
+    }
+};
+struct TravState8 {
+    V3 o, d, inv;          // inv as Ray8Init gives it (+-1e30 for zero direction components)
+    RayShear shear;
+    Float tMax, tHit;
+    uint32_t prim, cur;
+    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack8 &st) {
+        o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
+        inv = V3(d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
+                 d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z);
+        shear.init(d);
+        st.sp = 0;
+        cur = sc.n_nodes ? 0u : TRAV_DONE;
+    }
+    PT_DEV bool done() const { return cur == TRAV_DONE; }
+    PT_DEV bool atLeaf() const { return cur != TRAV_DONE && (cur & BVH4_LEAF); }
+    PT_DEV bool atNode() const { return !(cur & BVH4_LEAF); }
+};
+// one interior step (Bvh8Step of pt_bvh8.h, same operations in the same order, on a node held in registers): 7 x 16-byte loads of the
+// 128-byte line, folded plane distances t = q * A + B, nearest hit child next, the others pushed with their entry distances
+template <bool COUNT>
+PT_DEV void TravNodeStep8(const DevScene &sc, TravState8 &ts, TravStack8 &st, TraceCounters *cnt) {
+    const uint4 *w = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (size_t)ts.cur * 128u);
+    uint4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
+    Pin(w0); Pin(w1); Pin(w2); Pin(w3); Pin(w4); Pin(w5); Pin(w6);
+    if (COUNT) ++cnt->nodes;
+    // layout (BVH8Node): p[3] s[3] | child[8] | qlo[3][8] | qhi[3][8]
+    const Float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);
+    const Float sx = __uint_as_float(w0.w), sy = __uint_as_float(w1.x), sz = __uint_as_float(w1.y);
+    const uint32_t c0 = w1.z, c1 = w1.w, c2 = w2.x, c3 = w2.y, c4 = w2.z, c5 = w2.w, c6 = w3.x, c7 = w3.y;
+    const bool nx = ts.inv.x < 0, ny = ts.inv.y < 0, nz = ts.inv.z < 0;
+    // near / far plane words per axis (two words = 8 children each)
+    const uint32_t nxa = nx ? w5.x : w3.z, nxb = nx ? w5.y : w3.w, fxa = nx ? w3.z : w5.x, fxb = nx ? w3.w : w5.y;
+    const uint32_t nya = ny ? w5.z : w4.x, nyb = ny ? w5.w : w4.y, fya = ny ? w4.x : w5.z, fyb = ny ? w4.y : w5.w;
+    const uint32_t nza = nz ? w6.x : w4.z, nzb = nz ? w6.y : w4.w, fza = nz ? w4.z : w6.x, fzb = nz ? w4.w : w6.y;
+    const Float K = 16 * 5.9604644775390625e-08f;
+    const Float Ax = sx * ts.inv.x, Bx = (px - ts.o.x) * ts.inv.x, dx = K * (absf(Bx) + 255 * absf(Ax));
+    const Float Ay = sy * ts.inv.y, By = (py - ts.o.y) * ts.inv.y, dy = K * (absf(By) + 255 * absf(Ay));
+    const Float Az = sz * ts.inv.z, Bz = (pz - ts.o.z) * ts.inv.z, dz = K * (absf(Bz) + 255 * absf(Az));
+    const Float Bnx = Bx - dx, Bfx = Bx + dx, Bny = By - dy, Bfy = By + dy, Bnz = Bz - dz, Bfz = Bz + dz;
+    Float t[8];
+    bool h[8];
+    const uint32_t cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sh = 8 * (k & 3);
+        const uint32_t wnx = k < 4 ? nxa : nxb, wny = k < 4 ? nya : nyb, wnz = k < 4 ? nza : nzb;
+        const uint32_t wfx = k < 4 ? fxa : fxb, wfy = k < 4 ? fya : fyb, wfz = k < 4 ? fza : fzb;
+        Float e = __builtin_fmaxf(__builtin_fmaxf((Float)((wnx >> sh) & 255u) * Ax + Bnx, (Float)((wny >> sh) & 255u) * Ay + Bny), (Float)((wnz >> sh) & 255u) * Az + Bnz);
+        Float x = __builtin_fminf(__builtin_fminf((Float)((wfx >> sh) & 255u) * Ax + Bfx, (Float)((wfy >> sh) & 255u) * Ay + Bfy), (Float)((wfz >> sh) & 255u) * Az + Bfz);
+        h[k] = (e <= x) && (e < ts.tMax) && (x > 0) && cc[k] != BVH4_EMPTY;
+        t[k] = e;
+    }
+    int best = -1;
+    Float tb = PT_INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (h[k] && (best < 0 || t[k] < tb)) { tb = t[k]; best = k; }
+    if (best < 0) { ts.cur = st.pop(ts.tMax); return; }
+    uint32_t nxt = c0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (!h[k]) continue;
+        if (k == best) nxt = cc[k];
+        else st.push(cc[k], t[k]);
+    }
+    ts.cur = nxt;
 }
