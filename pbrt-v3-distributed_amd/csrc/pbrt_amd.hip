@@ -27,7 +27,6 @@
 
 #include "pt_shade.h"
 #include "pt_material.h"
-#include "pt_bvh8.h"
 #include "sobol_tables.inc"
 
 __constant__ DevTex c_tex;   // texture tables of the scene being rendered (set by mi_render for textured scenes only)
@@ -2017,6 +2016,7 @@ int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int 
     }
     stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
     stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
+    if (st.mismatch) return fail("mi_bvh8_validate: the packed node step (Bvh8StepWords) and the struct form (Bvh8Step) disagree on " + std::to_string(st.mismatch) + " node visits");
     return 0;
 }
 // stage-level texture evaluation: Texture<T>::Evaluate of node `node` at n recorded interactions

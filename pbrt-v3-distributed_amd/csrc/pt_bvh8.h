@@ -74,6 +74,36 @@ PT_HD uint32_t Bvh8Step(const BVH8Node &n, const Ray8 &r, float tMax, float tNea
     return mask;
 }
 
+// The same step on the node's 28 payload words as the kernel holds them in registers (7 x 16-byte loads): word / byte selection by
+// ray sign included.  The kernel (TravNodeStep8, pt_scene.h) and the host emulation below both call THIS function, so the packed
+// path is what the CPU tests validate.  Word layout = BVH8Node: [0..2] p, [3..5] s, [6..13] child, [14..19] qlo[x|y|z][0..7], [20..25] qhi.
+PT_HD float Bvh8BitsToFloat(uint32_t u) { return __builtin_bit_cast(float, u); }
+PT_HD uint32_t Bvh8StepWords(const uint32_t w[28], float ox, float oy, float oz, float ix, float iy, float iz, float tMax, float t[8]) {
+    const float px = Bvh8BitsToFloat(w[0]), py = Bvh8BitsToFloat(w[1]), pz = Bvh8BitsToFloat(w[2]);
+    const float sx = Bvh8BitsToFloat(w[3]), sy = Bvh8BitsToFloat(w[4]), sz = Bvh8BitsToFloat(w[5]);
+    const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
+    const uint32_t nxa = nx ? w[20] : w[14], nxb = nx ? w[21] : w[15], fxa = nx ? w[14] : w[20], fxb = nx ? w[15] : w[21];
+    const uint32_t nya = ny ? w[22] : w[16], nyb = ny ? w[23] : w[17], fya = ny ? w[16] : w[22], fyb = ny ? w[17] : w[23];
+    const uint32_t nza = nz ? w[24] : w[18], nzb = nz ? w[25] : w[19], fza = nz ? w[18] : w[24], fzb = nz ? w[19] : w[25];
+    const float K = 16 * 5.9604644775390625e-08f;
+    const float Ax = sx * ix, Bx = (px - ox) * ix, dx = K * (__builtin_fabsf(Bx) + 255 * __builtin_fabsf(Ax));
+    const float Ay = sy * iy, By = (py - oy) * iy, dy = K * (__builtin_fabsf(By) + 255 * __builtin_fabsf(Ay));
+    const float Az = sz * iz, Bz = (pz - oz) * iz, dz = K * (__builtin_fabsf(Bz) + 255 * __builtin_fabsf(Az));
+    const float Bnx = Bx - dx, Bfx = Bx + dx, Bny = By - dy, Bfy = By + dy, Bnz = Bz - dz, Bfz = Bz + dz;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sh = 8 * (k & 3);
+        const uint32_t wnx = k < 4 ? nxa : nxb, wny = k < 4 ? nya : nyb, wnz = k < 4 ? nza : nzb;
+        const uint32_t wfx = k < 4 ? fxa : fxb, wfy = k < 4 ? fya : fyb, wfz = k < 4 ? fza : fzb;
+        float e = __builtin_fmaxf(__builtin_fmaxf((float)((wnx >> sh) & 255u) * Ax + Bnx, (float)((wny >> sh) & 255u) * Ay + Bny), (float)((wnz >> sh) & 255u) * Az + Bnz);
+        float x = __builtin_fminf(__builtin_fminf((float)((wfx >> sh) & 255u) * Ax + Bfx, (float)((wfy >> sh) & 255u) * Ay + Bfy), (float)((wfz >> sh) & 255u) * Az + Bfz);
+        t[k] = e;
+        if ((e <= x) && (e < tMax) && (x > 0) && w[6 + k] != 0xFFFFFFFFu) mask |= 1u << k;
+    }
+    return mask;
+}
+
 // ---- host side (plain host functions: parsed in both compilation passes, emitted in the host pass only)
 #include <algorithm>
 #include <cmath>
@@ -278,7 +308,7 @@ inline bool triangleRejected(const mi_scene_desc *d, uint32_t t) {
     return false;
 }
 
-struct Stats { uint64_t nodes = 0, tris = 0, maxStack = 0, rays = 0, hits = 0; };
+struct Stats { uint64_t nodes = 0, tris = 0, maxStack = 0, rays = 0, hits = 0, mismatch = 0; };
 // the per-ray state machine of the future kernel: closest hit (anyHit = false) or first hit found (anyHit = true)
 inline bool traverse(const mi_scene_desc *d, const std::vector<BVH8Node> &nodes, const mi_ray &ray, bool anyHit, uint32_t *primOut, float *tOut, float bOut[3],
                      Stats *st) {
@@ -299,8 +329,12 @@ inline bool traverse(const mi_scene_desc *d, const std::vector<BVH8Node> &nodes,
     };
     while (cur != EMPTY) {
         if (!(cur & LEAF)) {
-            float tn[8];
-            uint32_t mask = Bvh8Step(nodes[cur], r8, tMax, tn);
+            float tn[8], tn2[8];
+            uint32_t words[32];
+            std::memcpy(words, &nodes[cur], 128);
+            uint32_t mask = Bvh8StepWords(words, r8.o[0], r8.o[1], r8.o[2], r8.inv[0], r8.inv[1], r8.inv[2], tMax, tn);   // what the kernel executes
+            uint32_t mask2 = Bvh8Step(nodes[cur], r8, tMax, tn2);                                                       // the readable form
+            if (mask != mask2 || std::memcmp(tn, tn2, sizeof(tn)) != 0) ++st->mismatch;
             ++st->nodes;
             const BVH8Node &n = nodes[cur];
             int best = -1;

@@ -3,6 +3,7 @@
 #include "pbrt_amd.h"
 #include "pt_math.h"
 #include "pt_sphere.h"
+#include "pt_bvh8.h"
 
 // ------------------------------------------------------------------ HBM layout
 // BVH4 node: exactly one 128-byte cache line, fetched by a lane as 8 x global_load_dwordx4.
@@ -601,39 +602,21 @@ PT_DEV void TravNodeStep8(const DevScene &sc, TravState8 &ts, TravStack8 &st, Tr
     uint4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
     Pin(w0); Pin(w1); Pin(w2); Pin(w3); Pin(w4); Pin(w5); Pin(w6);
     if (COUNT) ++cnt->nodes;
-    // layout (BVH8Node): p[3] s[3] | child[8] | qlo[3][8] | qhi[3][8]
-    const Float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);
-    const Float sx = __uint_as_float(w0.w), sy = __uint_as_float(w1.x), sz = __uint_as_float(w1.y);
-    const uint32_t c0 = w1.z, c1 = w1.w, c2 = w2.x, c3 = w2.y, c4 = w2.z, c5 = w2.w, c6 = w3.x, c7 = w3.y;
-    const bool nx = ts.inv.x < 0, ny = ts.inv.y < 0, nz = ts.inv.z < 0;
-    // near / far plane words per axis (two words = 8 children each)
-    const uint32_t nxa = nx ? w5.x : w3.z, nxb = nx ? w5.y : w3.w, fxa = nx ? w3.z : w5.x, fxb = nx ? w3.w : w5.y;
-    const uint32_t nya = ny ? w5.z : w4.x, nyb = ny ? w5.w : w4.y, fya = ny ? w4.x : w5.z, fyb = ny ? w4.y : w5.w;
-    const uint32_t nza = nz ? w6.x : w4.z, nzb = nz ? w6.y : w4.w, fza = nz ? w4.z : w6.x, fzb = nz ? w4.w : w6.y;
-    const Float K = 16 * 5.9604644775390625e-08f;
-    const Float Ax = sx * ts.inv.x, Bx = (px - ts.o.x) * ts.inv.x, dx = K * (absf(Bx) + 255 * absf(Ax));
-    const Float Ay = sy * ts.inv.y, By = (py - ts.o.y) * ts.inv.y, dy = K * (absf(By) + 255 * absf(Ay));
-    const Float Az = sz * ts.inv.z, Bz = (pz - ts.o.z) * ts.inv.z, dz = K * (absf(Bz) + 255 * absf(Az));
-    const Float Bnx = Bx - dx, Bfx = Bx + dx, Bny = By - dy, Bfy = By + dy, Bnz = Bz - dz, Bfz = Bz + dz;
+    // the step itself: Bvh8StepWords of pt_bvh8.h, the function the host emulation validates
+    const uint32_t wd[28] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w,
+                             w4.x, w4.y, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, w6.x, w6.y, w6.z, w6.w};
     Float t[8];
+    const uint32_t mask = Bvh8StepWords(wd, ts.o.x, ts.o.y, ts.o.z, ts.inv.x, ts.inv.y, ts.inv.z, ts.tMax, t);
     bool h[8];
-    const uint32_t cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+    const uint32_t cc[8] = {wd[6], wd[7], wd[8], wd[9], wd[10], wd[11], wd[12], wd[13]};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int sh = 8 * (k & 3);
-        const uint32_t wnx = k < 4 ? nxa : nxb, wny = k < 4 ? nya : nyb, wnz = k < 4 ? nza : nzb;
-        const uint32_t wfx = k < 4 ? fxa : fxb, wfy = k < 4 ? fya : fyb, wfz = k < 4 ? fza : fzb;
-        Float e = __builtin_fmaxf(__builtin_fmaxf((Float)((wnx >> sh) & 255u) * Ax + Bnx, (Float)((wny >> sh) & 255u) * Ay + Bny), (Float)((wnz >> sh) & 255u) * Az + Bnz);
-        Float x = __builtin_fminf(__builtin_fminf((Float)((wfx >> sh) & 255u) * Ax + Bfx, (Float)((wfy >> sh) & 255u) * Ay + Bfy), (Float)((wfz >> sh) & 255u) * Az + Bfz);
-        h[k] = (e <= x) && (e < ts.tMax) && (x > 0) && cc[k] != BVH4_EMPTY;
-        t[k] = e;
-    }
+    for (int k = 0; k < 8; ++k) h[k] = (mask >> k) & 1u;
     int best = -1;
     Float tb = PT_INFINITY;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (h[k] && (best < 0 || t[k] < tb)) { tb = t[k]; best = k; }
     if (best < 0) { ts.cur = st.pop(ts.tMax); return; }
-    uint32_t nxt = c0;
+    uint32_t nxt = cc[0];
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
         if (!h[k]) continue;
