@@ -5,6 +5,8 @@
 // (the XYZ round trip is not the identity in fp32).
 #include <cstdio>
 
+#include <zlib.h>
+
 #include "scene.h"
 
 namespace pbrt_amd {
@@ -258,12 +260,72 @@ static bool WriteEXR(const std::string &fn, const Float *rgb, int w, int h, int 
     return true;
 }
 
+// ---- 8-bit outputs (imageio.cpp:90-117): gamma-encoded bytes, then PNG (the reference: lodepng_encode24_file) or TGA
+// (tga_write_bgr: type 2, 24 bit, uncompressed, top-to-bottom)
+static inline Float GammaCorrect(Float value) {   // core/pbrt.h:289-292
+    if (value <= 0.0031308f) return 12.92f * value;
+    return 1.055f * std::pow(value, (Float)(1.f / 2.4f)) - 0.055f;
+}
+static std::vector<uint8_t> ToBytes(const Float *rgb, int w, int h) {
+    std::vector<uint8_t> out((size_t)3 * w * h);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = (uint8_t)Clamp(255.f * GammaCorrect(rgb[i]) + 0.5f, 0.f, 255.f);   // TO_BYTE imageio.cpp:98
+    return out;
+}
+static bool WritePNG(const std::string &name, const uint8_t *rgb8, int w, int h) {   // 8-bit RGB, filter type 0, one IDAT (zlib)
+    std::vector<uint8_t> raw((size_t)h * (3 * w + 1));
+    for (int y = 0; y < h; ++y) {
+        raw[(size_t)y * (3 * w + 1)] = 0;
+        std::memcpy(&raw[(size_t)y * (3 * w + 1) + 1], rgb8 + (size_t)y * 3 * w, (size_t)3 * w);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { Error("Error writing PNG \"%s\": deflate failed", name.c_str()); return false; }
+    FILE *f = std::fopen(name.c_str(), "wb");
+    if (!f) { Error("Error writing PNG \"%s\": cannot open", name.c_str()); return false; }
+    auto be32 = [](uint32_t v, uint8_t *p) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    auto chunk = [&](const char *type, const uint8_t *data, uint32_t len) {
+        uint8_t hd[8];
+        be32(len, hd); std::memcpy(hd + 4, type, 4);
+        std::fwrite(hd, 1, 8, f);
+        if (len) std::fwrite(data, 1, len, f);
+        uLong crc = crc32(0L, (const Bytef *)type, 4);
+        if (len) crc = crc32(crc, data, len);
+        uint8_t c[4]; be32((uint32_t)crc, c);
+        std::fwrite(c, 1, 4, f);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    std::fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13];
+    be32((uint32_t)w, ihdr); be32((uint32_t)h, ihdr + 4);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)clen);
+    chunk("IEND", nullptr, 0);
+    std::fclose(f);
+    return true;
+}
+static bool WriteTGA(const std::string &name, const uint8_t *rgb8, int w, int h) {
+    FILE *f = std::fopen(name.c_str(), "wb");
+    if (!f) { Error("Unable to write output file \"%s\"", name.c_str()); return false; }
+    uint8_t hd[18] = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, (uint8_t)(w & 255), (uint8_t)(w >> 8), (uint8_t)(h & 255), (uint8_t)(h >> 8), 24, 0x20};
+    std::fwrite(hd, 1, 18, f);
+    std::vector<uint8_t> bgr((size_t)3 * w * h);
+    for (size_t i = 0; i < (size_t)w * h; ++i) { bgr[3 * i] = rgb8[3 * i + 2]; bgr[3 * i + 1] = rgb8[3 * i + 1]; bgr[3 * i + 2] = rgb8[3 * i]; }
+    std::fwrite(bgr.data(), 1, bgr.size(), f);
+    std::fclose(f);
+    return true;
+}
+
 bool WriteImage(const std::string &name, const Float *rgb, const int cropMin[2], const int cropMax[2], const int fullRes[2]) {
     int w = cropMax[0] - cropMin[0], h = cropMax[1] - cropMin[1];
     auto ends = [&](const char *suf) { size_t n = std::strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
     if (ends(".pfm")) return WritePFM(name, rgb, w, h);
     if (ends(".exr")) return WriteEXR(name, rgb, w, h, fullRes[0], fullRes[1], cropMin[0], cropMin[1]);
-    Error("Can't determine image file type from suffix of filename \"%s\" (supported: .pfm, .exr)", name.c_str());
+    if (ends(".png") || ends(".tga")) {
+        std::vector<uint8_t> b = ToBytes(rgb, w, h);
+        return ends(".png") ? WritePNG(name, b.data(), w, h) : WriteTGA(name, b.data(), w, h);
+    }
+    Error("Can't determine image file type from suffix of filename \"%s\"", name.c_str());
     return false;
 }
 

@@ -309,3 +309,28 @@ def test_bvh8_quantised_layout_gives_the_reference_hits(built, tmp_path):
         assert np.array_equal((h2["prim"] >= 0).astype(np.uint8), occ)
         if sc.info["n_tris"] > 100000:   # the point of the layout: far fewer dependent node steps than the BVH2 (and than the BVH4's ~0.27 x BVH2)
             assert st["nodes_visited"] < 0.2 * cnt[0]
+
+
+def test_png_and_tga_output_match_the_reference_writer(built, tmp_path):
+    """WriteImage for the 8-bit formats (imageio.cpp:90-117): gamma-encoded bytes as PNG / TGA.  The files written by this host must decode
+    (through the host's own readers) to the bytes the formula gives, and -- when the reference binary is built here -- to the very bytes
+    the reference writes for the same scene."""
+    text = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
+    text = text.replace('[400] "integer yresolution" [400]', '[48] "integer yresolution" [40]').replace('"integer pixelsamples" [8]', '"integer pixelsamples" [2]')
+    sc = pa.Scene(text=text)
+    rgbw, _, _ = ol.render(sc, nthreads=2)
+    img = sc.film_image(rgbw)
+    g = np.where(img <= np.float32(0.0031308), np.float32(12.92) * img, np.float32(1.055) * np.power(img, np.float32(1 / 2.4), dtype=np.float32) - np.float32(0.055))
+    want = np.clip(np.float32(255) * g + np.float32(0.5), 0, 255).astype(np.uint8)
+    for ext in ("png", "tga"):
+        out = str(tmp_path / ("o." + ext))
+        sc.write_image(rgbw, out)
+        got = np.round(pa.read_image(out) * 255).astype(np.int32)
+        assert got.shape == want.shape
+        assert np.abs(got - want.astype(np.int32)).max() <= 1 and np.mean(got != want) < 2e-3   # powf vs numpy's float power at a rounding boundary
+        if ol.have_ref():
+            f = tmp_path / "s.pbrt"; f.write_text(text)
+            ref_out = str(tmp_path / ("r." + ext))
+            subprocess.check_call([ol.PBRT_REF, "--quiet", "--nthreads", "1", "--outfile", ref_out, str(f)])
+            ref = np.round(pa.read_image(ref_out) * 255).astype(np.int32)
+            assert np.abs(got - ref).max() <= 1 and np.mean(got != ref) < 2e-3   # the oracle's film differs from the reference's by <= 1 ulp
