@@ -3,8 +3,8 @@
 // 274-280), gamma is the caller's business (ImageTexture::convertIn).  PNG is decoded here with zlib's inflate
 // (the reference goes through lodepng_decode24_file: any colour type / bit depth -> 8-bit RGB, 16-bit samples keep
 // their high byte, alpha is dropped); TGA covers the uncompressed / RLE, true-colour / mono / colour-mapped variants
-// the reference's targa.c reads.  OpenEXR is absent from this image (and from oracle/_ref), so ".exr" textures are an
-// Error exactly like an unreadable file.
+// the reference's targa.c reads.  OpenEXR is absent from this image (and from oracle/_ref): ".exr" goes through a reader written
+// from the format specification (scan-line files, NONE / RLE / ZIPS / ZIP), unpinned against the reference (see DecodeEXR).
 #include <zlib.h>
 
 #include <cstdio>
@@ -165,6 +165,127 @@ bool DecodeTGA(const std::string &name, std::vector<Float> *out, int *w, int *h)
     return true;
 }
 
+// ---- OpenEXR 2 (single-part scan-line files; compression NONE / RLE / ZIPS / ZIP; HALF / FLOAT / UINT channels R G B or Y).
+// The reference reads EXR through the OpenEXR library (imageio.cpp:124-161, Imf::RgbaInputFile); that library is not in this image
+// (nor in oracle/_ref, which therefore cannot read EXR either), so this reader is written from the file-format specification and is
+// UNPINNED against the reference: tests/test_host.py checks it against files assembled independently in Python and against this
+// host's own writer.  PIZ / PXR24 / B44 / DWA compression and tiled or multi-part files are reported as unsupported.
+float HalfToFloat(uint16_t hbits) {
+    uint32_t sign = (uint32_t)(hbits >> 15) << 31, e = (hbits >> 10) & 31, m = hbits & 1023;
+    uint32_t out;
+    if (e == 0) {
+        if (m == 0) out = sign;
+        else {   // subnormal half -> normal float
+            int sh = 0;
+            while (!(m & 1024)) { m <<= 1; ++sh; }
+            out = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 1023) << 13);
+        }
+    } else if (e == 31) out = sign | 0x7f800000u | (m << 13);
+    else out = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &out, 4);
+    return f;
+}
+bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h) {
+    std::vector<uint8_t> f;
+    if (!ReadFile(name, &f) || f.size() < 16) { Error("Unable to read image file \"%s\"", name.c_str()); return false; }
+    auto rd32 = [&](size_t p) { uint32_t v; std::memcpy(&v, &f[p], 4); return v; };
+    if (rd32(0) != 20000630u) { Error("\"%s\" is not an OpenEXR file", name.c_str()); return false; }
+    uint32_t version = rd32(4);
+    if ((version & 0xff) != 2 || (version & 0x1a00)) { Error("EXR file \"%s\": tiled / multi-part / deep files are not supported", name.c_str()); return false; }
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, lineOrder = 0;
+    int32_t dw[4] = {0, 0, -1, -1};
+    size_t p = 8;
+    while (p < f.size() && f[p] != 0) {   // attributes: name\0 type\0 size data
+        std::string an((const char *)&f[p]); p += an.size() + 1;
+        std::string at((const char *)&f[p]); p += at.size() + 1;
+        uint32_t sz = rd32(p); p += 4;
+        if (p + sz > f.size()) { Error("EXR file \"%s\": truncated header", name.c_str()); return false; }
+        if (an == "channels") {
+            size_t q = p;
+            while (q < p + sz && f[q] != 0) {
+                Chan c;
+                c.name = (const char *)&f[q]; q += c.name.size() + 1;
+                c.type = (int)rd32(q);
+                uint32_t xs = rd32(q + 8), ys = rd32(q + 12);
+                q += 16;
+                if (xs != 1 || ys != 1) { Error("EXR file \"%s\": subsampled channels are not supported", name.c_str()); return false; }
+                chans.push_back(c);
+            }
+        } else if (an == "compression") compression = f[p];
+        else if (an == "dataWindow") std::memcpy(dw, &f[p], 16);
+        else if (an == "lineOrder") lineOrder = f[p];
+        p += sz;
+    }
+    ++p;   // end of header
+    int width = dw[2] - dw[0] + 1, height = dw[3] - dw[1] + 1;
+    if (width <= 0 || height <= 0 || chans.empty()) { Error("EXR file \"%s\": bad header", name.c_str()); return false; }
+    if (compression < 0 || compression > 3) { Error("EXR file \"%s\": compression method %d is not supported (NONE, RLE, ZIPS, ZIP are)", name.c_str(), compression); return false; }
+    int linesPerBlock = compression == 3 ? 16 : 1;
+    int nBlocks = (height + linesPerBlock - 1) / linesPerBlock;
+    size_t lineBytes = 0;
+    std::vector<size_t> chanOff(chans.size());
+    for (size_t c = 0; c < chans.size(); ++c) { chanOff[c] = lineBytes; lineBytes += (size_t)width * (chans[c].type == 1 ? 2 : 4); }
+    int ir = -1, ig = -1, ib = -1, iy = -1;
+    for (size_t c = 0; c < chans.size(); ++c) {
+        if (chans[c].name == "R") ir = (int)c; else if (chans[c].name == "G") ig = (int)c; else if (chans[c].name == "B") ib = (int)c; else if (chans[c].name == "Y") iy = (int)c;
+    }
+    if ((ir < 0 || ig < 0 || ib < 0) && iy < 0) { Error("EXR file \"%s\": no R, G, B (or Y) channels", name.c_str()); return false; }
+    out->assign((size_t)width * height * 3, 0.f);
+    if (p + (size_t)nBlocks * 8 > f.size()) { Error("EXR file \"%s\": truncated offset table", name.c_str()); return false; }
+    std::vector<uint8_t> buf, tmp;
+    for (int b = 0; b < nBlocks; ++b) {
+        uint64_t off;
+        std::memcpy(&off, &f[p + (size_t)b * 8], 8);
+        if (off + 8 > f.size()) { Error("EXR file \"%s\": bad block offset", name.c_str()); return false; }
+        int32_t y0 = (int32_t)rd32(off) - dw[1];
+        uint32_t dsz = rd32(off + 4);
+        if (off + 8 + dsz > f.size() || y0 < 0 || y0 >= height) { Error("EXR file \"%s\": bad block", name.c_str()); return false; }
+        int nl = std::min(linesPerBlock, height - y0);
+        size_t raw = lineBytes * nl;
+        const uint8_t *src = &f[off + 8];
+        buf.resize(raw);
+        if (compression == 0 || dsz == raw) std::memcpy(buf.data(), src, std::min<size_t>(raw, dsz));   // stored uncompressed when that is not larger
+        else {
+            tmp.resize(raw);
+            if (compression == 1) {   // RLE: signed run lengths
+                size_t o = 0, i = 0;
+                while (i < dsz && o < raw) {
+                    int c = (int8_t)src[i++];
+                    if (c < 0) { size_t n = (size_t)(-c); if (i + n > dsz || o + n > raw) break; std::memcpy(&tmp[o], &src[i], n); i += n; o += n; }
+                    else { size_t n = (size_t)c + 1; if (i >= dsz || o + n > raw) break; std::memset(&tmp[o], src[i++], n); o += n; }
+                }
+                if (o != raw) { Error("EXR file \"%s\": bad RLE data", name.c_str()); return false; }
+            } else {
+                uLongf got = (uLongf)raw;
+                if (uncompress(tmp.data(), &got, src, dsz) != Z_OK || got != raw) { Error("EXR file \"%s\": inflate failed", name.c_str()); return false; }
+            }
+            for (size_t i = 1; i < raw; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);   // undo the byte predictor ...
+            size_t half = (raw + 1) / 2;
+            for (size_t i = 0; i < raw; ++i) buf[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];   // ... and the even / odd byte split
+        }
+        for (int l = 0; l < nl; ++l) {
+            const uint8_t *line = &buf[lineBytes * l];
+            auto value = [&](int c, int x) -> Float {
+                const uint8_t *q = line + chanOff[c];
+                if (chans[c].type == 1) { uint16_t hb; std::memcpy(&hb, q + 2 * (size_t)x, 2); return HalfToFloat(hb); }
+                if (chans[c].type == 2) { float v; std::memcpy(&v, q + 4 * (size_t)x, 4); return v; }
+                uint32_t u; std::memcpy(&u, q + 4 * (size_t)x, 4); return (Float)u;
+            };
+            Float *dst = &(*out)[(size_t)(y0 + l) * width * 3];
+            for (int x = 0; x < width; ++x) {
+                if (ir >= 0 && ig >= 0 && ib >= 0) { dst[3 * x] = value(ir, x); dst[3 * x + 1] = value(ig, x); dst[3 * x + 2] = value(ib, x); }
+                else dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = value(iy, x);
+            }
+        }
+    }
+    (void)lineOrder;   // every block carries its own y coordinate
+    *w = width; *h = height;
+    return true;
+}
+
 bool HasExt(const std::string &n, const char *ext) {
     size_t l = std::strlen(ext);
     if (n.size() < l) return false;
@@ -186,7 +307,8 @@ bool ReadImage(const std::string &name, std::vector<Float> *rgb, int *w, int *h)
         return true;
     }
     if (HasExt(name, ".tga")) return DecodeTGA(name, rgb, w, h);
-    Error("Unable to load image stored in format \"%s\" for filename \"%s\" (this host reads .pfm, .png and .tga; OpenEXR is not in the image).",
+    if (HasExt(name, ".exr")) return DecodeEXR(name, rgb, w, h);
+    Error("Unable to load image stored in format \"%s\" for filename \"%s\" (this host reads .pfm, .png, .tga and scan-line .exr).",
           name.rfind('.') != std::string::npos ? name.c_str() + name.rfind('.') : "(none)", name.c_str());
     return false;
 }
