@@ -25,13 +25,7 @@ std::shared_ptr<TriangleMesh> CreateTriangleMesh(const Transform &o2w, bool reve
     return mesh;
 }
 
-static void warnAlpha(const ParamSet &ps) {
-    if (ps.FindTexture("alpha") != "" || ps.FindTexture("shadowalpha") != "")
-        Warning("alpha / shadowalpha textures are not supported by this path (SURVEY.md s.8 row f2); ignored");
-    if (ps.FindOneFloat("alpha", 1.f) == 0.f || ps.FindOneFloat("shadowalpha", 1.f) == 0.f)
-        Warning("constant zero alpha is not supported by this path; shape stays visible");
-}
-
+// "alpha" / "shadowalpha" (triangle.cpp:717-741, plymesh.cpp:259-286) are resolved by pbrtShape (host/api.cpp), which owns the texture name maps
 std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool ro, const ParamSet &ps) {
     int nvi, npi, nuvi = 0, nsi, nni;
     const int *vi = ps.FindInt("indices", &nvi);
@@ -63,7 +57,6 @@ std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool
         }
     int nfi;
     ps.FindInt("faceIndices", &nfi);   // only consumed by ptex textures (not on this path)
-    warnAlpha(ps);
     return CreateTriangleMesh(o2w, ro, nvi / 3, vi, npi, (const Vec3 *)P, (const Vec3 *)S, (const Vec3 *)N, uvs);
 }
 
@@ -199,7 +192,6 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
                 }
         }
     }
-    warnAlpha(ps);
     return CreateTriangleMesh(o2w, ro, (int)indices.size() / 3, indices.data(), (int)vertexCount, P.data(), nullptr,
                               hasN ? N.data() : nullptr, hasUV ? UV.data() : nullptr);
 }
