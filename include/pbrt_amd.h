@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -234,6 +234,28 @@ typedef struct mi_envmap {
     float pad;
 } mi_envmap;
 
+/* Object instancing (ObjectBegin / ObjectInstance; api.cpp:1555-1591, TransformedPrimitive core/primitive.cpp:76-111) as a two-level
+ * hierarchy.  By default the host FLATTENS instances into world-space copies (n_instances = 0: same hits within float tolerance, no
+ * extra device code); with PBRT_AMD_INSTANCING=1 it hands the reference's own structure over instead:
+ *   - primitive i of the top-level BVH order is a TransformedPrimitive iff tri_indices[3*i] == MI_PRIM_INSTANCE; tri_indices[3*i+1]
+ *     indexes instances[];
+ *   - an object's primitives (its own BVHAccel's order; vertices in the space the object was defined in) occupy
+ *     [first_prim, first_prim + n_prims) of the tri_* arrays, AFTER the n_top_prims top-level primitives; its LinearBVHNode array
+ *     occupies [first_node, first_node + n_nodes) of bvh_nodes, AFTER the n_bvh_nodes top-level nodes, with child / primitive offsets
+ *     relative to the object's own arrays.
+ * Instanced primitives cannot be area lights (api.cpp:1351-1353).  Carried by the host and the CPU oracle; mi_scene_upload refuses
+ * scenes with n_instances > 0 until the device traversal has the second level. */
+#define MI_PRIM_INSTANCE 0xFFFFFFFEu
+typedef struct mi_instance {
+    float i2w[16], w2i[16]; /* InstanceToWorld (the CTM at ObjectInstance) and its stored inverse, row major */
+    uint32_t object;        /* index into objects[] */
+    uint32_t pad[3];
+} mi_instance;
+typedef struct mi_object {
+    uint32_t first_prim, n_prims;
+    uint32_t first_node, n_nodes;
+} mi_object;
+
 /* ---------------------------------------------------------------- camera/film ------- */
 
 typedef struct mi_camera {     /* PerspectiveCamera, cameras/perspective.cpp:45-67 */
@@ -332,6 +354,13 @@ typedef struct mi_scene_desc {
     const mi_image *images;
     const mi_material_desc *material_descs;
     const int32_t *mesh_alpha;
+    /* two-level instancing (see mi_instance): 0 / NULL unless the host was asked not to flatten */
+    uint32_t n_instances;
+    uint32_t n_objects;
+    uint32_t n_top_prims;   /* primitives of the top-level BVH (= n_tris when there are no instances) */
+    uint32_t pad1;
+    const mi_instance *instances;
+    const mi_object *objects;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

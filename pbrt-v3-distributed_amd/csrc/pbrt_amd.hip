@@ -1147,6 +1147,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
     if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
+    if (d->n_instances)   // loud, not approximate: the default host mode (flattened instances) is what the device renders
+        return fail("mi_scene_upload: the scene keeps ObjectInstance as a two-level hierarchy (PBRT_AMD_INSTANCING=1); the device traversal has one level -- "
+                    "unset PBRT_AMD_INSTANCING so that the host flattens the instances");
     // textures (row f2): validate the node table before anything is uploaded
     c->hasTex = c->hasAlpha = false;
     if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->hasTex |= d->material_descs[m].textured != 0;
@@ -1859,6 +1862,7 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
 int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
     if (!d || !stats) return fail("mi_bvh4_validate: null argument");
     for (int i = 0; i < 8; ++i) stats[i] = 0;
+    if (d->n_instances) return fail("mi_bvh4_validate: two-level scenes are not handled (host flattening is the device's mode)");
     if (!d->n_bvh_nodes) return 0;
     B4Builder bb;
     bb.n2 = d->bvh_nodes;
@@ -1956,6 +1960,7 @@ int mi_sphere_intersect(int device, const mi_sphere *spheres, const mi_ray *rays
 int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
     if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8_validate: null argument");
     for (int i = 0; i < 8; ++i) stats[i] = 0;
+    if (d->n_instances) return fail("mi_bvh8_validate: two-level scenes are not handled (host flattening is the device's mode)");
     bvh8::Builder bb;
     if (!bb.run(d)) return fail("mi_bvh8_validate: " + bb.error);
     // structural checks: every primitive in exactly one leaf reference, children inside the quantised box their parent holds for them

@@ -10,6 +10,7 @@
 namespace pbrt_amd {
 
 std::string g_imageFileOverride;
+bool g_twoLevelInstancing = false;   // PBRT_AMD_INSTANCING=1: keep ObjectInstance as TransformedPrimitive + per-object BVH (host + oracle only so far)
 Float g_cropWindow[4] = {0, 1, 0, 1};
 bool g_quickRender = false;
 
@@ -53,6 +54,9 @@ struct RenderOptions {   // api.cpp:150-186
     std::vector<GeometricPrimitive> primitives;
     std::map<std::string, std::vector<GeometricPrimitive>> instances;
     std::vector<GeometricPrimitive> *currentInstance = nullptr;
+    // two-level mode (PBRT_AMD_INSTANCING=1): the objects that were instantiated, each with its own BVHAccel
+    std::vector<Scene::ObjectDef> objectDefs;
+    std::map<std::string, int> objectIndex;
 };
 
 APIState currentApiState = APIState::Uninitialized;
@@ -110,6 +114,7 @@ void pbrtInit(const Options &opt) {
     if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
     currentApiState = APIState::OptionsBlock;
     renderOptions.reset(new RenderOptions);
+    { const char *e = std::getenv("PBRT_AMD_INSTANCING"); g_twoLevelInstancing = e && e[0] == '1'; }
     ResetTextures();
     graphicsState = GraphicsState();
     curTransform = TransformSet();
@@ -446,22 +451,60 @@ void pbrtObjectInstance(const std::string &name) {
     auto it = renderOptions->instances.find(name);
     if (it == renderOptions->instances.end()) { Error("Unable to find instance named \"%s\"", name.c_str()); return; }
     if (it->second.empty()) return;
-    // Reference: TransformedPrimitive over a shared BVH (api.cpp:1555-1591).  Here static instances are
-    // flattened: a transformed copy of each mesh (documented deviation).
     const Transform &i2w = curTransform[0];
+    if (g_twoLevelInstancing) {
+        // The reference's structure (api.cpp:1555-1591): one BVHAccel per object (built at its first instantiation), one
+        // TransformedPrimitive per ObjectInstance holding the CTM; bounds = PrimitiveToWorld(primitive->WorldBound()) (transform.cpp:141-153)
+        if (curTransform.IsAnimated()) Warning("Animated instance transforms are outside this path's scope; using the start transform");
+        int oi;
+        auto known = renderOptions->objectIndex.find(name);
+        if (known == renderOptions->objectIndex.end()) {
+            Scene::ObjectDef od;
+            od.prims = it->second;
+            od.accel = CreateBVHAccelerator(od.prims, renderOptions->AcceleratorParams);
+            oi = (int)renderOptions->objectDefs.size();
+            renderOptions->objectDefs.push_back(std::move(od));
+            renderOptions->objectIndex[name] = oi;
+        } else oi = known->second;
+        const Bounds3 b = renderOptions->objectDefs[oi].accel->WorldBound();
+        auto inst = std::make_shared<InstanceRef>();
+        inst->object = oi;
+        inst->i2w = i2w;
+        Bounds3 wb(i2w.Point(Vec3(b.pMin.x, b.pMin.y, b.pMin.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMin.y, b.pMin.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMax.y, b.pMin.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMin.y, b.pMax.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMax.y, b.pMax.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMax.y, b.pMin.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMin.y, b.pMax.z)));
+        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMax.y, b.pMax.z)));
+        inst->worldBound = wb;
+        GeometricPrimitive gp;
+        gp.shape = std::make_shared<TriangleMesh>();   // empty: the primitive is the instance
+        gp.instance = inst;
+        renderOptions->primitives.push_back(gp);
+        return;
+    }
+    // Default: static instances are flattened -- a transformed copy of each mesh (documented deviation):
+    // same surfaces, hits equal within float tolerance, no second BVH level on the device.
     for (const GeometricPrimitive &src : it->second) {
         GeometricPrimitive gp = src;
         auto mesh = std::make_shared<TriangleMesh>(*src.shape);
         for (auto &p : mesh->p) p = i2w.Point(p);
         for (auto &n : mesh->n) n = i2w.Normal(n);
         for (auto &s : mesh->s) s = i2w.Vector(s);
-        if (i2w.SwapsHandedness()) mesh->transformSwapsHandedness = !mesh->transformSwapsHandedness;
+        // A mirroring instance transform: the reference computes the interaction in the object's space and carries the normals over with
+        // the inverse transpose, which does not flip them.  Here the geometric normal comes from the cross product of WORLD-space
+        // edges, which does flip: compensate through the orientation flag -- but only for meshes without shading normals; with
+        // them the flag only enters SetShadingGeometry's flip of the (correctly transformed) shading normal, n follows by Faceforward.
+        if (i2w.SwapsHandedness() && mesh->n.empty()) mesh->transformSwapsHandedness = !mesh->transformSwapsHandedness;
         gp.shape = mesh;
         if (src.sphere) {   // the instance transform goes on top of the sphere's own
             auto sp = std::make_shared<SphereShape>(*src.sphere);
             sp->o2w = i2w * src.sphere->o2w;
             sp->w2o = Transform(sp->o2w.mInv, sp->o2w.m);
-            sp->transformSwapsHandedness = sp->o2w.SwapsHandedness();
+            // transformSwapsHandedness stays the one of the sphere's OWN ObjectToWorld: its normal is built in the sphere's object space
+            // and transformed by inverse transposes (sphere.cpp:149, transform.cpp:262-297), an instance transform never flips it
             gp.sphere = sp;
         }
         renderOptions->primitives.push_back(gp);
@@ -624,6 +667,7 @@ void pbrtWorldEnd() {
         renderOptions->AcceleratorParams.ReportUnused();
         scene.reset(new Scene(accel, std::move(renderOptions->primitives), std::move(renderOptions->lights)));
         scene->textures = CurrentTextures();
+        scene->objects = std::move(renderOptions->objectDefs);
     }
     if (scene && integrator) {
         if (PbrtOptions.deferRender) {

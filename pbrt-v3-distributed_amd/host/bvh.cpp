@@ -186,7 +186,7 @@ BVHAccel::BVHAccel(const std::vector<GeometricPrimitive> &prims, int maxPrims, S
     // one entry per triangle, in scene order (api.cpp:1365: one GeometricPrimitive per Triangle)
     std::vector<PrimRef> refs;
     size_t total = 0;
-    for (auto &gp : prims) total += gp.shape->nTriangles() + (gp.sphere ? 1 : 0);
+    for (auto &gp : prims) total += gp.shape->nTriangles() + (gp.sphere ? 1 : 0) + (gp.instance ? 1 : 0);
     if (total == 0) return;
     refs.reserve(total);
     std::vector<PrimInfo> info(total);
@@ -201,6 +201,14 @@ BVHAccel::BVHAccel(const std::vector<GeometricPrimitive> &prims, int maxPrims, S
             info[k].bounds = b;
             info[k].centroid = .5f * b.pMin + .5f * b.pMax;
             refs.push_back({pi, (uint32_t)t});
+        }
+        if (prims[pi].instance) {   // a TransformedPrimitive: one primitive with the bounds the reference gives it
+            Bounds3 b = prims[pi].instance->worldBound;
+            info[k].primitiveNumber = k;
+            info[k].bounds = b;
+            info[k].centroid = .5f * b.pMin + .5f * b.pMax;
+            refs.push_back({pi, 0u});
+            ++k;
         }
         if (prims[pi].sphere) {   // one primitive for the whole sphere
             Bounds3 b = prims[pi].sphere->WorldBound();

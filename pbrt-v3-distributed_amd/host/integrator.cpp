@@ -46,14 +46,20 @@ static void copyMatrix(float dst[16], const Matrix4x4 &m) { std::memcpy(dst, m.m
 std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) const {
     std::unique_ptr<FlatScene> fs(new FlatScene);
     const BVHAccel &bvh = *scene.aggregate;
-    const auto &prims = scene.primitives;
+    // every GeometricPrimitive that owns geometry: the scene's own, then (two-level instancing only) those of each instanced object
+    std::vector<GeometricPrimitive> prims = scene.primitives;
+    std::vector<uint32_t> objectPrimBase(scene.objects.size());
+    for (size_t o = 0; o < scene.objects.size(); ++o) {
+        objectPrimBase[o] = (uint32_t)prims.size();
+        prims.insert(prims.end(), scene.objects[o].prims.begin(), scene.objects[o].prims.end());
+    }
     // --- vertices + meshes
     std::vector<uint32_t> vertexOffset(prims.size()), triOffset(prims.size());
     size_t nv = 0, nt = 0;
     bool anyN = false, anyUV = false;
     for (size_t i = 0; i < prims.size(); ++i) {
         vertexOffset[i] = (uint32_t)nv; triOffset[i] = (uint32_t)nt;
-        nv += prims[i].shape->p.size(); nt += prims[i].shape->nTriangles() + (prims[i].sphere ? 1 : 0);
+        nv += prims[i].shape->p.size(); nt += prims[i].shape->nTriangles() + (prims[i].sphere ? 1 : 0) + (prims[i].instance ? 1 : 0);
         anyN |= !prims[i].shape->n.empty(); anyUV |= !prims[i].shape->uv.empty();
     }
     fs->P.resize(3 * nv);
@@ -92,29 +98,55 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         fs->meshes[i].material = materialIndex(prims[i].material);
         fs->meshAlpha.push_back(mesh.alphaTex); fs->meshAlpha.push_back(mesh.shadowAlphaTex);
     }
-    // --- triangles in BVH primitive order
-    size_t nTris = bvh.primitives.size();
+    // --- triangles in BVH primitive order: the top-level BVH's, then (two-level instancing) each object's own BVH order
+    size_t nTop = bvh.primitives.size(), nTris = nTop;
+    for (const auto &od : scene.objects) nTris += od.accel->primitives.size();
     fs->triIndices.resize(3 * nTris);
     fs->triMesh.resize(nTris);
     fs->triLight.assign(nTris, -1);
-    std::vector<uint32_t> orderOf(nt);   // (prim, tri) -> position in bvh.primitives
-    for (size_t k = 0; k < nTris; ++k) {
-        const BVHAccel::PrimRef &r = bvh.primitives[k];
-        const TriangleMesh &mesh = *prims[r.prim].shape;
-        if (prims[r.prim].sphere) {   // MI_PRIM_SPHERE, index into spheres[]
-            const SphereShape &sp = *prims[r.prim].sphere;
-            mi_sphere ms;
-            std::memset(&ms, 0, sizeof(ms));
-            copyMatrix(ms.o2w, sp.o2w.m); copyMatrix(ms.w2o, sp.w2o.m);
-            ms.radius = sp.radius; ms.zmin = sp.zMin; ms.zmax = sp.zMax; ms.theta_min = sp.thetaMin; ms.theta_max = sp.thetaMax; ms.phi_max = sp.phiMax;
-            ms.flags = (sp.reverseOrientation ? 1u : 0u) | (sp.transformSwapsHandedness ? 2u : 0u);
-            ms.area = sp.Area();
-            fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
-            fs->spheres.push_back(ms);
-        } else
-        for (int c = 0; c < 3; ++c) fs->triIndices[3 * k + c] = vertexOffset[r.prim] + (uint32_t)mesh.indices[3 * r.tri + c];
-        fs->triMesh[k] = r.prim;
-        orderOf[triOffset[r.prim] + r.tri] = (uint32_t)k;
+    std::vector<uint32_t> orderOf(nt);   // (prim, tri) -> position in the ordered primitive arrays
+    auto emit = [&](const BVHAccel &acc, uint32_t primBase, size_t outBase) {
+        for (size_t j = 0; j < acc.primitives.size(); ++j) {
+            const size_t k = outBase + j;
+            BVHAccel::PrimRef r = acc.primitives[j];
+            r.prim += primBase;
+            const TriangleMesh &mesh = *prims[r.prim].shape;
+            if (prims[r.prim].instance) {   // MI_PRIM_INSTANCE, index into instances[]
+                const InstanceRef &in = *prims[r.prim].instance;
+                mi_instance mi;
+                std::memset(&mi, 0, sizeof(mi));
+                copyMatrix(mi.i2w, in.i2w.m); copyMatrix(mi.w2i, in.i2w.mInv);
+                mi.object = (uint32_t)in.object;
+                fs->triIndices[3 * k] = MI_PRIM_INSTANCE; fs->triIndices[3 * k + 1] = (uint32_t)fs->instances.size(); fs->triIndices[3 * k + 2] = 0;
+                fs->instances.push_back(mi);
+            } else if (prims[r.prim].sphere) {   // MI_PRIM_SPHERE, index into spheres[]
+                const SphereShape &sp = *prims[r.prim].sphere;
+                mi_sphere ms;
+                std::memset(&ms, 0, sizeof(ms));
+                copyMatrix(ms.o2w, sp.o2w.m); copyMatrix(ms.w2o, sp.w2o.m);
+                ms.radius = sp.radius; ms.zmin = sp.zMin; ms.zmax = sp.zMax; ms.theta_min = sp.thetaMin; ms.theta_max = sp.thetaMax; ms.phi_max = sp.phiMax;
+                ms.flags = (sp.reverseOrientation ? 1u : 0u) | (sp.transformSwapsHandedness ? 2u : 0u);
+                ms.area = sp.Area();
+                fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
+                fs->spheres.push_back(ms);
+            } else
+                for (int c = 0; c < 3; ++c) fs->triIndices[3 * k + c] = vertexOffset[r.prim] + (uint32_t)mesh.indices[3 * r.tri + c];
+            fs->triMesh[k] = r.prim;
+            orderOf[triOffset[r.prim] + r.tri] = (uint32_t)k;
+        }
+    };
+    emit(bvh, 0, 0);
+    fs->nodes = bvh.nodes;
+    {
+        size_t outBase = nTop;
+        for (size_t o = 0; o < scene.objects.size(); ++o) {
+            const BVHAccel &acc = *scene.objects[o].accel;
+            emit(acc, objectPrimBase[o], outBase);
+            mi_object mo = {(uint32_t)outBase, (uint32_t)acc.primitives.size(), (uint32_t)fs->nodes.size(), (uint32_t)acc.nodes.size()};
+            fs->objects.push_back(mo);
+            fs->nodes.insert(fs->nodes.end(), acc.nodes.begin(), acc.nodes.end());
+            outBase += acc.primitives.size();
+        }
     }
     // --- lights, in scene.lights order (api.cpp:1418-1424: appended in file order, one per emissive triangle)
     Vec3 worldCenter = (scene.WorldBound().pMin + scene.WorldBound().pMax) / 2;   // Bounds3::BoundingSphere geometry.h:808-811
@@ -213,7 +245,10 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.n_verts = (uint32_t)nv; d.P = fs->P.data(); d.N = anyN ? fs->N.data() : nullptr; d.UV = anyUV ? fs->UV.data() : nullptr;
     d.n_tris = (uint32_t)nTris; d.tri_indices = fs->triIndices.data(); d.tri_mesh = fs->triMesh.data(); d.tri_light = fs->triLight.data();
     d.n_meshes = (uint32_t)fs->meshes.size(); d.meshes = fs->meshes.data();
-    d.n_bvh_nodes = (uint32_t)bvh.nodes.size(); d.bvh_nodes = bvh.nodes.data();
+    d.n_bvh_nodes = (uint32_t)bvh.nodes.size(); d.bvh_nodes = fs->nodes.data();   // top-level nodes first, objects' nodes behind them
+    d.n_top_prims = (uint32_t)nTop;
+    d.n_instances = (uint32_t)fs->instances.size(); d.instances = fs->instances.empty() ? nullptr : fs->instances.data();
+    d.n_objects = (uint32_t)fs->objects.size(); d.objects = fs->objects.empty() ? nullptr : fs->objects.data();
     d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
     d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;

@@ -100,9 +100,17 @@ struct SphereShape {
 };
 std::shared_ptr<SphereShape> CreateSphereShape(const Transform &o2w, bool reverseOrientation, const ParamSet &ps);
 
-struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here, or one Sphere (then `shape` is an empty mesh)
+// TransformedPrimitive (primitive.h:92-117) over the object `object` of Scene::objects: only with PBRT_AMD_INSTANCING=1, otherwise
+// instances are flattened into world-space copies when they are instantiated
+struct InstanceRef {
+    int object = 0;
+    Transform i2w;           // PrimitiveToWorld (start transform)
+    Bounds3 worldBound;      // PrimitiveToWorld.MotionBounds(primitive->WorldBound()), primitive.h:104-106
+};
+struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here, or one Sphere / one instance (then `shape` is an empty mesh)
     std::shared_ptr<TriangleMesh> shape;
     std::shared_ptr<SphereShape> sphere;
+    std::shared_ptr<InstanceRef> instance;
     std::shared_ptr<Material> material;
     std::shared_ptr<AreaLightSpec> areaLight;
 };
@@ -196,6 +204,8 @@ class Scene {
     std::vector<GeometricPrimitive> primitives;
     std::vector<LightEntry> lights;   // scene.lights order; area lights expand to one light per triangle
     Bounds3 worldBound;
+    struct ObjectDef { std::vector<GeometricPrimitive> prims; std::shared_ptr<BVHAccel> accel; };
+    std::vector<ObjectDef> objects;   // instanced objects (two-level mode only): each with the BVHAccel the reference builds for it (api.cpp:1563-1572)
     std::shared_ptr<TextureStore> textures;   // nodes / images the materials and alpha masks refer to
 };
 
@@ -223,6 +233,9 @@ struct FlatScene {
     std::vector<mi_material_desc> materialDescs;
     std::vector<int32_t> meshAlpha;
     std::shared_ptr<TextureStore> texKeep;
+    std::vector<mi_bvh2_node> nodes;       // two-level mode: top-level nodes followed by every object's
+    std::vector<mi_instance> instances;
+    std::vector<mi_object> objects;
 };
 
 class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)

@@ -57,6 +57,18 @@ def scene(name):
                        for x, z, a, sc in [(-1.5, 1, 20, 1), (0.2, 2, 75, .7), (1.6, .5, -40, 1.2), (-.4, -.5, 10, .5)])
         return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
                         'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
+    if name == "instances2":    # instancing stress: an object with a triangle mesh (shading normals, textured material, alpha mask) and a sphere,
+        # instantiated under rotations, a non-uniform scale and a MIRRORING scale; a one-triangle object (no BVH in the reference)
+        obj = ('Texture "chk" "color" "checkerboard" "float uscale" [4] "float vscale" [4] "rgb tex1" [.8 .2 .2] "rgb tex2" [.9 .9 .8]\n'
+               'Texture "msk" "float" "checkerboard" "string aamode" "none" "float uscale" [3] "float vscale" [3] "float tex1" [1] "float tex2" [0]\n'
+               'ObjectBegin "thing"\nMaterial "plastic" "texture Kd" "chk" "rgb Ks" [.3 .3 .3] "float roughness" [.1]\n' + _bulge().replace('"float uv"', '"texture alpha" "msk" "float uv"') +
+               'AttributeBegin\nTranslate 1.4 .9 0\nMaterial "glass" "float index" [1.5]\nShape "sphere" "float radius" [.35]\nAttributeEnd\nObjectEnd\n'
+               'ObjectBegin "one"\nMaterial "matte" "rgb Kd" [.2 .3 .8]\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0  .8 0 0  .4 .9 0]\nObjectEnd\n')
+        inst = "".join('AttributeBegin\nTranslate %g %g %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "%s"\nAttributeEnd\n' % a for a in
+                       [(-2.6, 0, .5, 25, 1, 1, 1, "thing"), (.2, .1, 1.6, -60, .7, 1.3, .7, "thing"), (2.2, 0, -.2, 140, -.8, .8, .8, "thing"),
+                        (-.6, .05, -1.2, 10, 1, 1, 1, "one"), (1.1, .05, -1.0, -35, 1.5, .7, 1, "one")])
+        return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
+                        'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
     if name == "spheres":       # Sphere primitives: glass sphere, clipped + transformed sphere, sphere area lights (one reversed, two-sided, clipped)
         sph = ('AttributeBegin\nTranslate -1.2 .7 .3\nMaterial "glass" "float index" [1.5]\nShape "sphere" "float radius" [.7]\nAttributeEnd\n'
                'AttributeBegin\nTranslate 1.2 .6 .8\nRotate 35 1 0 0\nScale 1 1.4 .8\n'
@@ -222,3 +234,4 @@ def tex_scene(name):
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
 TEX_ORACLE_ONLY = ["tex_dof", "envmap_png"]
+INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)

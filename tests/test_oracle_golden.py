@@ -170,6 +170,26 @@ def test_oracle_edge_cases_match_reference(built, name):
     assert np.all(np.abs(img - ref) <= 2e-6 * (1 + np.abs(ref))), float(np.abs(img - ref).max())
 
 
+@pytest.mark.parametrize("name", edge_scenes.INSTANCE_NAMES)
+def test_oracle_object_instancing_both_ways(built, name, monkeypatch):
+    """ObjectBegin / ObjectInstance.  Two-level mode (PBRT_AMD_INSTANCING=1: the reference's own structure -- one
+    BVHAccel per object, TransformedPrimitive leaves in the top-level BVH, rays transformed into the object's space, interactions
+    transformed back): the oracle must reproduce the reference's render BIT FOR BIT, including a sphere and an alpha-masked, textured,
+    shading-normal mesh inside an object, a mirroring instance transform and a one-triangle object.  Default mode (instances flattened
+    to world-space copies, what the device renders): the same surfaces with different roundings -- image criterion of the GPU tests."""
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "1")
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    img = sc.film_image(ol.render(sc, nthreads=4)[0])
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    monkeypatch.delenv("PBRT_AMD_INSTANCING")
+    flat = pa.Scene(text=edge_scenes.scene(name))
+    assert flat.info["n_tris"] > sc.info["n_tris"]        # copies instead of references
+    img2 = flat.film_image(ol.render(flat, nthreads=4)[0])
+    frac, relmse = ol.image_metrics(img2, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
+
+
 def _killeroo_96():
     text = open(os.path.join(ol.ROOT, "scenes", "killeroo.pbrt")).read()
     text = text.replace('[700] "integer yresolution" [700]', '[96] "integer yresolution" [96]')
