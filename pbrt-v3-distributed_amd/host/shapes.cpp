@@ -229,11 +229,39 @@ Bounds3 SphereShape::WorldBound() const {   // Transform::operator()(Bounds3f) t
     return ret;
 }
 
+// CreateHeightfield (shapes/heightfield.cpp:41-88): the reference itself turns a height field into a TriangleMesh with uvs
+static std::shared_ptr<TriangleMesh> CreateHeightfield(const Transform &o2w, bool ro, const ParamSet &ps) {
+    int nx = ps.FindOneInt("nu", -1), ny = ps.FindOneInt("nv", -1), nitems = 0;
+    const Float *z = ps.FindFloat("Pz", &nitems);
+    if (nx < 2 || ny < 2 || !z || nitems != nx * ny) { Error("heightfield: \"nu\" x \"nv\" must match the number of \"Pz\" values (and be at least 2 x 2)"); return nullptr; }
+    int ntris = 2 * (nx - 1) * (ny - 1), nverts = nx * ny;
+    std::vector<int> indices(3 * (size_t)ntris);
+    std::vector<Vec3> P(nverts);
+    std::vector<Float> uvs(2 * (size_t)nverts);
+    int pos = 0;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            P[pos].x = uvs[2 * pos] = (float)x / (float)(nx - 1);
+            P[pos].y = uvs[2 * pos + 1] = (float)y / (float)(ny - 1);
+            P[pos].z = z[pos];
+            ++pos;
+        }
+    int *vp = indices.data();
+    for (int y = 0; y < ny - 1; ++y)
+        for (int x = 0; x < nx - 1; ++x) {
+            auto VERT = [nx](int xx, int yy) { return xx + yy * nx; };
+            *vp++ = VERT(x, y); *vp++ = VERT(x + 1, y); *vp++ = VERT(x + 1, y + 1);
+            *vp++ = VERT(x, y); *vp++ = VERT(x + 1, y + 1); *vp++ = VERT(x, y + 1);
+        }
+    return CreateTriangleMesh(o2w, ro, ntris, indices.data(), nverts, P.data(), nullptr, nullptr, uvs.data());
+}
+
 std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps) {
     if (name == "trianglemesh") return CreateTriangleMeshShape(o2w, ro, ps);
+    if (name == "heightfield") return CreateHeightfield(o2w, ro, ps);
     if (name == "plymesh") return CreatePLYMesh(o2w, ro, ps);
     if (name == "loopsubdiv") return CreateLoopSubdiv(o2w, ro, ps);
-    // quadrics / curves / nurbs / heightfield: not on the triangle hot path
+    // quadrics / curves / nurbs: not on the triangle hot path
     Warning("Shape \"%s\" is not supported by the GPU triangle path (convert with the reference's --toply); skipped.",
             name.c_str());
     return nullptr;

@@ -69,6 +69,14 @@ def scene(name):
                         (-.6, .05, -1.2, 10, 1, 1, 1, "one"), (1.1, .05, -1.0, -35, 1.5, .7, 1, "one")])
         return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
                         'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
+    if name == "heightfield":   # Shape "heightfield": the reference's own tessellation into a uv-mapped triangle mesh (heightfield.cpp), under a transform
+        import math
+        n = 9
+        z = " ".join("%.5g" % (.25 * math.sin(1.3 * x) * math.cos(.9 * y) + .3) for y in range(n) for x in range(n))
+        return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
+                        'Texture "chk" "color" "checkerboard" "float uscale" [6] "float vscale" [6] "rgb tex1" [.8 .3 .2] "rgb tex2" [.9 .9 .8]\n'
+                        'AttributeBegin\nTranslate -1.2 .05 -1.5\nRotate -90 1 0 0\nScale 2.4 2.2 1\nMaterial "matte" "texture Kd" "chk"\n'
+                        'Shape "heightfield" "integer nu" [%d] "integer nv" [%d] "float Pz" [%s]\nAttributeEnd\n' % (n, n, z))
     if name == "spheres":       # Sphere primitives: glass sphere, clipped + transformed sphere, sphere area lights (one reversed, two-sided, clipped)
         sph = ('AttributeBegin\nTranslate -1.2 .7 .3\nMaterial "glass" "float index" [1.5]\nShape "sphere" "float radius" [.7]\nAttributeEnd\n'
                'AttributeBegin\nTranslate 1.2 .6 .8\nRotate 35 1 0 0\nScale 1 1.4 .8\n'
@@ -233,5 +241,5 @@ def tex_scene(name):
 
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
-TEX_ORACLE_ONLY = ["tex_dof", "envmap_png"]
+TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield"]
 INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)
