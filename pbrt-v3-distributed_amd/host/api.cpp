@@ -332,6 +332,11 @@ std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, co
         for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) { light->l.frame[3 * r + c2] = l2w.mInv.m[r][c2]; light->l.l2w[3 * r + c2] = l2w.m.m[r][c2]; }
         if (texmap != "") {
             light->env = CreateEnvMap(texmap, Ls);   // texels * L (infinite.cpp:52-56); unreadable -> constant L, as the reference
+        } else if (!l2w.IsIdentity()) {
+            // A constant light is a 1x1 radiance map to the reference (infinite.cpp:58-62), and its LightToWorld decides which direction a
+            // sample (u, v) becomes (:116-118).  The map-less fast path of the device assumes the identity there, so a transformed constant
+            // light is handed over as that 1x1 map.
+            light->env = CreateEnvMap("", Ls);
         }
     } else {
         Warning("Light \"%s\" is not supported by this path (goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());

@@ -75,7 +75,10 @@ void Distribution1D(const Float *f, int n, Float *func, Float *cdf, Float *funcI
 std::shared_ptr<EnvMap> CreateEnvMap(const std::string &filename, const RGB &L) {
     std::vector<Float> texels;
     int w = 0, h = 0;
-    if (!ReadImage(filename, &texels, &w, &h)) {   // .pfm, .png, .tga (host/imageread.cpp); the radiance map is used as read: no gamma (infinite.cpp:51)
+    if (filename.empty()) {   // no map: the constructor's 1x1 image of ones (infinite.cpp:58-62) -- used for constant lights under a transform
+        texels.assign(3, 1.f);
+        w = h = 1;
+    } else if (!ReadImage(filename, &texels, &w, &h)) {   // .pfm, .png, .tga, .exr (host/imageread.cpp); the radiance map is used as read: no gamma (infinite.cpp:51)
         Error("Unable to read environment map \"%s\"", filename.c_str());
         return nullptr;
     }

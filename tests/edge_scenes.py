@@ -37,6 +37,9 @@ def scene(name):
         return tex_scene(name)
     if name == "infinite":      # constant InfiniteAreaLight: escaped-ray emission, light sampling + MIS, two lights -> spatial strategy
         return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
+    if name == "infinite_xf":   # a CONSTANT infinite light under a rotation + mirroring scale: LightToWorld decides where a sample (u,v) points (infinite.cpp:116-118)
+        return _OPEN % ('AttributeBegin\nRotate 50 1 .3 0\nScale -1 1 1\nLightSource "infinite" "rgb L" [.5 .6 .8]\nAttributeEnd\n'
+                        'LightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
     if name == "infinite_only":  # a single light: CreateLightSampleDistribution substitutes uniform (lightdistrib.cpp:50)
         return _OPEN % 'LightSource "infinite" "rgb L" [.9 .8 .7]'
     if name == "spot":          # two spot lights, one under a transform (cone falloff, WorldToLight frame)
@@ -241,5 +244,5 @@ def tex_scene(name):
 
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
-TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield"]
+TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield", "infinite_xf"]
 INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)

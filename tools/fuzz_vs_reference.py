@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the host + oracle against the real reference (oracle/_ref/pbrt_ref; this container only).
+
+Generates random small .pbrt scenes that exercise the directives, parameters and corner cases of the hot path -- camera / film / filter /
+sampler / integrator options, every light and material kind with random (also textured) parameters, triangle meshes with and without
+normals / uvs, clipped spheres, height fields, random transform stacks (non-uniform and mirroring scales, ReverseOrientation), object
+instancing, alpha masks -- renders each with the reference and with the CPU oracle (through this repository's own parser / scene
+construction), and reports every scene whose images differ by more than the film-sum rounding.  A mismatch is a bug in the host or the
+oracle (or a place where the two restate the reference differently from what it does); the offending scene text is kept for a fixture.
+
+    python tools/fuzz_vs_reference.py [--n 200] [--seed 1] [--keep DIR] [--two-level]
+"""
+import argparse, os, subprocess, sys, tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol   # noqa: E402
+
+pa = ol.pa
+TEX = os.path.join(ROOT, "scenes", "textures")
+
+
+def f(xs):
+    return " ".join("%.6g" % x for x in np.atleast_1d(xs))
+
+
+class Gen:
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+        self.ntex = 0
+
+    def u(self, a, b): return float(self.r.uniform(a, b))
+    def pick(self, xs): return xs[int(self.r.integers(0, len(xs)))]
+    def chance(self, p): return self.r.random() < p
+    def rgb(self, lo=0.05, hi=0.95): return "[%s]" % f(self.r.uniform(lo, hi, 3))
+
+    def transform(self, allow_mirror=True):
+        s = ""
+        for _ in range(int(self.r.integers(0, 4))):
+            k = self.pick(["T", "R", "S", "S"])
+            if k == "T": s += "Translate %s\n" % f(self.r.uniform(-.6, .6, 3))
+            elif k == "R": s += "Rotate %s %s\n" % (f(self.u(-180, 180)), f(self.pick([[1, 0, 0], [0, 1, 0], [0, 0, 1], list(self.r.uniform(-1, 1, 3))])))
+            else:
+                sc = self.r.uniform(.5, 1.6, 3)
+                if self.chance(.5): sc[:] = sc[0]
+                if allow_mirror and self.chance(.25): sc[int(self.r.integers(0, 3))] *= -1
+                s += "Scale %s\n" % f(sc)
+        return s
+
+    # ---- textures
+    def tex_float(self, lo, hi, signed_ok=False):
+        """a float texture with values in [lo, hi] -> (definition text, name); signed_ok: fbm / windy (which go negative) allowed (bump maps)"""
+        self.ntex += 1
+        n = "tf%d" % self.ntex
+        k = self.pick(["checker", "image", "scale", "bilerp", "wrinkled", "dots"] + (["fbm", "windy"] if signed_ok else []))
+        mapping = self.mapping2d()
+        if k == "checker":
+            d = 'Texture "%s" "float" "checkerboard" %s "float tex1" [%s] "float tex2" [%s] "string aamode" "%s"\n' % (n, mapping, f(self.u(lo, hi)), f(self.u(lo, hi)), self.pick(["closedform", "none"]))
+        elif k == "image":
+            d = 'Texture "%s" "float" "imagemap" "string filename" "%s" %s "float scale" [%s] "bool gamma" ["false"] "bool trilinear" ["%s"] "string wrap" "%s"\n' % (
+                n, os.path.join(TEX, self.pick(["height_32.png", "ramp_8.tga", "mask_16.png"])), mapping, f(hi), self.pick(["true", "false"]), self.pick(["repeat", "clamp", "black"]))
+        elif k == "bilerp":
+            d = 'Texture "%s" "float" "bilerp" %s "float v00" [%s] "float v01" [%s] "float v10" [%s] "float v11" [%s]\n' % ((n, mapping) + tuple(f(self.u(lo, hi)) for _ in range(4)))
+        elif k == "scale":
+            d1, a = self.tex_float(lo, hi, signed_ok)
+            d = d1 + 'Texture "%s" "float" "scale" "texture tex1" "%s" "float tex2" [%s]\n' % (n, a, f(self.u(.5, 1)))
+        elif k == "dots":
+            d = 'Texture "%s" "float" "dots" %s "float inside" [%s] "float outside" [%s]\n' % (n, mapping, f(self.u(lo, hi)), f(self.u(lo, hi)))
+        else:   # noise family: unbounded-ish -> scaled into range
+            self.ntex += 1
+            raw = "tf%d" % self.ntex
+            t = {"fbm": '"fbm" "integer octaves" [%d] "float roughness" [%s]' % (int(self.r.integers(1, 6)), f(self.u(.3, .7))),
+                 "wrinkled": '"wrinkled" "integer octaves" [%d]' % int(self.r.integers(1, 6)), "windy": '"windy"'}[k]
+            d = 'TransformBegin\n%sTexture "%s" "float" %s\nTransformEnd\n' % (self.transform(False), raw, t)
+            d += 'Texture "%s" "float" "scale" "texture tex1" "%s" "float tex2" [%s]\n' % (n, raw, f(hi * .3))
+        return d, n
+
+    def mapping2d(self):
+        k = self.pick(["uv", "uv", "uv", "spherical", "cylindrical", "planar"])
+        if k == "uv": return '"float uscale" [%s] "float vscale" [%s] "float udelta" [%s] "float vdelta" [%s]' % (f(self.u(.5, 6)), f(self.u(.5, 6)), f(self.u(0, 1)), f(self.u(0, 1)))
+        if k == "planar": return '"string mapping" "planar" "vector v1" [%s] "vector v2" [%s] "float udelta" [%s]' % (f(self.r.uniform(-1, 1, 3)), f(self.r.uniform(-1, 1, 3)), f(self.u(0, 1)))
+        return '"string mapping" "%s"' % k
+
+    def tex_rgb(self):
+        self.ntex += 1
+        n = "tc%d" % self.ntex
+        k = self.pick(["checker", "image", "image", "mix", "scale", "uv", "marble", "checker3", "bilerp", "dots"])
+        mapping = self.mapping2d()
+        if k == "checker":
+            d = 'Texture "%s" "color" "checkerboard" %s "rgb tex1" %s "rgb tex2" %s\n' % (n, mapping, self.rgb(), self.rgb())
+        elif k == "checker3":
+            d = 'TransformBegin\n%sTexture "%s" "color" "checkerboard" "integer dimension" [3] "rgb tex1" %s "rgb tex2" %s\nTransformEnd\n' % (self.transform(False), n, self.rgb(), self.rgb())
+        elif k == "image":
+            d = 'Texture "%s" "color" "imagemap" "string filename" "%s" %s "bool trilinear" ["%s"] "string wrap" "%s" "float maxanisotropy" [%s] "float scale" [%s]\n' % (
+                n, os.path.join(TEX, self.pick(["color_23x17.png", "noise_16x8.tga", "hdr_12x10.pfm", "palette_8.png"])), mapping, self.pick(["true", "false"]),
+                self.pick(["repeat", "clamp", "black"]), f(self.pick([1, 4, 8, 16])), f(self.u(.4, .9)))
+        elif k == "mix":
+            d1, a = self.tex_rgb(); d2, b = self.tex_rgb(); d3, c = self.tex_float(0, 1)
+            d = d1 + d2 + d3 + 'Texture "%s" "color" "mix" "texture tex1" "%s" "texture tex2" "%s" "texture amount" "%s"\n' % (n, a, b, c)
+        elif k == "scale":
+            d1, a = self.tex_rgb()
+            d = d1 + 'Texture "%s" "color" "scale" "texture tex1" "%s" "rgb tex2" %s\n' % (n, a, self.rgb(.5, 1))
+        elif k == "uv":
+            d = 'Texture "%s" "color" "uv" %s\n' % (n, mapping)
+        elif k == "bilerp":
+            d = 'Texture "%s" "color" "bilerp" %s "rgb v00" %s "rgb v01" %s "rgb v10" %s "rgb v11" %s\n' % ((n, mapping) + tuple(self.rgb() for _ in range(4)))
+        elif k == "dots":
+            d = 'Texture "%s" "color" "dots" %s "rgb inside" %s "rgb outside" %s\n' % (n, mapping, self.rgb(), self.rgb())
+        else:
+            d = 'TransformBegin\n%sTexture "%s" "color" "marble" "float scale" [%s] "float variation" [%s] "integer octaves" [%d]\nTransformEnd\n' % (
+                self.transform(False), n, f(self.u(.5, 4)), f(self.u(.05, .5)), int(self.r.integers(1, 7)))
+        return d, n
+
+    def spec(self, name, lo=0.05, hi=0.95, ptex=.35):
+        """a spectrum parameter: inline rgb or a texture -> (texture definitions, parameter text)"""
+        if self.chance(ptex):
+            d, n = self.tex_rgb()
+            return d, '"texture %s" "%s"' % (name, n)
+        return "", '"rgb %s" %s' % (name, self.rgb(lo, hi))
+
+    def flt(self, name, lo, hi, ptex=.3):
+        if self.chance(ptex):
+            d, n = self.tex_float(lo, hi)
+            return d, '"texture %s" "%s"' % (name, n)
+        return "", '"float %s" [%s]' % (name, f(self.u(lo, hi)))
+
+    def material(self, named=None):
+        k = self.pick(["matte", "matte", "plastic", "glass", "mirror", "metal", "uber", "substrate", "translucent", "mix"])
+        defs, ps = "", []
+
+        def add(t):
+            nonlocal defs
+            defs += t[0]; ps.append(t[1])
+        if k == "matte":
+            add(self.spec("Kd")); add(self.flt("sigma", 0, 60) if self.chance(.5) else ("", ""))
+        elif k == "plastic":
+            add(self.spec("Kd")); add(self.spec("Ks", .05, .5)); add(self.flt("roughness", .01, .4))
+        elif k == "glass":
+            add(self.spec("Kr", .5, 1, .15)); add(self.spec("Kt", .5, 1, .15)); ps.append('"float %s" [%s]' % (self.pick(["index", "eta"]), f(self.u(1.1, 1.8))))
+            if self.chance(.4): add(self.flt("uroughness", 0.01, .3)); add(self.flt("vroughness", 0.01, .3))
+        elif k == "mirror":
+            add(self.spec("Kr", .5, 1))
+        elif k == "metal":
+            add(self.spec("eta", .2, 2, .1)); add(self.spec("k", 1, 4, .1))
+            if self.chance(.5): add(self.flt("roughness", .005, .3))
+            else: add(self.flt("uroughness", .005, .3)); add(self.flt("vroughness", .005, .3))
+        elif k == "uber":
+            add(self.spec("Kd")); add(self.spec("Ks", .05, .5)); add(self.spec("Kr", 0, .4, .1)); add(self.spec("Kt", 0, .4, .1))
+            add(self.spec("opacity", .3, 1, .3)); add(self.flt("roughness", .01, .4))
+            if self.chance(.3): add(self.flt("uroughness", .01, .4))
+            ps.append('"float index" [%s]' % f(self.u(1.1, 1.8)))
+        elif k == "substrate":
+            add(self.spec("Kd")); add(self.spec("Ks", .05, .5)); add(self.flt("uroughness", .01, .4)); add(self.flt("vroughness", .01, .4))
+        elif k == "translucent":
+            add(self.spec("Kd")); add(self.spec("Ks", .05, .5)); add(self.spec("reflect", .2, .8, .15)); add(self.spec("transmit", .2, .8, .15)); add(self.flt("roughness", .01, .4))
+        else:
+            d1, a = self.material(named=True); d2, b = self.material(named=True)
+            defs += d1 + d2
+            add(self.spec("amount", .1, .9, .3))
+            ps.append('"string namedmaterial1" "%s" "string namedmaterial2" "%s"' % (a, b))
+        if k != "mix" and self.chance(.25):
+            d, n = self.tex_float(0, .05, signed_ok=True)
+            defs += d; ps.append('"texture bumpmap" "%s"' % n)
+        if k in ("plastic", "glass", "metal", "uber", "substrate", "translucent") and self.chance(.3): ps.append('"bool remaproughness" ["false"]')
+        ps = " ".join(p for p in ps if p)
+        if named:
+            self.ntex += 1
+            nm = "m%d" % self.ntex
+            return defs + 'MakeNamedMaterial "%s" "string type" "%s" %s\n' % (nm, k, ps), nm
+        return defs + 'Material "%s" %s\n' % (k, ps), None
+
+    # ---- shapes
+    def mesh(self, alpha_ok=True):
+        n = int(self.r.integers(2, 5))
+        P, N, UV, I = [], [], [], []
+        a, b = self.r.uniform(.2, .6, 2)
+        for j in range(n):
+            for i in range(n):
+                u, v = i / (n - 1), j / (n - 1)
+                x, z = u - .5, v - .5
+                h = a * np.sin(3 * u) * np.cos(2 * v) * b
+                P += [x, h, z]; UV += [u * self.u(.8, 1.2), v]
+                nn = np.array([-a * b * 3 * np.cos(3 * u) * np.cos(2 * v), 1, a * b * 2 * np.sin(3 * u) * np.sin(2 * v)])
+                N += list(nn / np.linalg.norm(nn))
+        for j in range(n - 1):
+            for i in range(n - 1):
+                q = j * n + i
+                I += [q, q + n, q + 1, q + 1, q + n, q + n + 1]
+        s = 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' % (" ".join(map(str, I)), f(P))
+        if self.chance(.5): s += ' "normal N" [%s]' % f(N)
+        if self.chance(.7): s += ' "float %s" [%s]' % (self.pick(["uv", "st"]), f(UV))
+        defs = ""
+        if alpha_ok and self.chance(.2):
+            d, nm = self.tex_float(0, 1)
+            if "checkerboard" in d or "imagemap" in d: defs += d; s += ' "texture %s" "%s"' % (self.pick(["alpha", "shadowalpha"]), nm)
+        return defs, s + "\n"
+
+    def sphere(self):
+        s = 'Shape "sphere" "float radius" [%s]' % f(self.u(.2, .5))
+        if self.chance(.4): s += ' "float zmin" [%s] "float zmax" [%s]' % (f(self.u(-.2, -.05)), f(self.u(.05, .2)))
+        if self.chance(.3): s += ' "float phimax" [%s]' % f(self.u(90, 330))
+        return s + "\n"
+
+    def shape(self):
+        k = self.pick(["mesh", "mesh", "sphere", "heightfield"])
+        if k == "mesh": return self.mesh()
+        if k == "sphere": return "", self.sphere()
+        n = int(self.r.integers(2, 5))
+        return "", 'Shape "heightfield" "integer nu" [%d] "integer nv" [%d] "float Pz" [%s]\n' % (n, n, f(self.r.uniform(0, .3, n * n)))
+
+    def scene(self, res):
+        g = self
+        w, h = res
+        s = "LookAt %s  0 .3 0  0 1 0\n" % f([g.u(-1, 1), g.u(1.5, 3), g.u(-5, -3.5)])
+        cam = '"float fov" [%s]' % f(g.u(25, 60))
+        if g.chance(.3): cam += ' "float lensradius" [%s] "float focaldistance" [%s]' % (f(g.u(.01, .1)), f(g.u(3, 6)))
+        if g.chance(.2): cam += ' "float frameaspectratio" [%s]' % f(g.u(.8, 1.8))
+        if g.chance(.15): cam += ' "float screenwindow" [%s]' % f([-g.u(.6, 1.2), g.u(.6, 1.2), -g.u(.6, 1.2), g.u(.6, 1.2)])
+        s += 'Camera "perspective" %s\n' % cam
+        spp = int(g.pick([1, 2, 3, 4]))
+        if g.chance(.5): s += 'Sampler "sobol" "integer pixelsamples" [%d]\n' % spp
+        else: s += 'Sampler "halton" "integer pixelsamples" [%d]%s\n' % (spp, ' "bool samplepixelcenter" ["true"]' if g.chance(.2) else "")
+        s += g.pick(['PixelFilter "box"\n'] * 4 + ['PixelFilter "gaussian" "float xwidth" [%s] "float ywidth" [%s]\n' % (f(g.u(.8, 2)), f(g.u(.8, 2))),
+                     'PixelFilter "mitchell"\n', 'PixelFilter "triangle" "float xwidth" [%s]\n' % f(g.u(.8, 2)), 'PixelFilter "sinc" "float tau" [%s]\n' % f(g.u(2, 4))])
+        integ = '"integer maxdepth" [%d]' % int(g.r.integers(1, 8))
+        if g.chance(.3): integ += ' "float rrthreshold" [%s]' % f(g.u(.2, 2))
+        integ += ' "string lightsamplestrategy" "%s"' % g.pick(["uniform", "power", "spatial", "spatial"])
+        if g.chance(.15): integ += ' "integer pixelbounds" [%d %d %d %d]' % (w // 5, w - w // 6, h // 6, h - h // 5)
+        s += 'Integrator "path" %s\n' % integ
+        film = '"integer xresolution" [%d] "integer yresolution" [%d] "string filename" "f.pfm"' % (w, h)
+        if g.chance(.2): film += ' "float cropwindow" [%s]' % f([g.u(0, .3), g.u(.6, 1), g.u(0, .3), g.u(.6, 1)])
+        if g.chance(.15): film += ' "float maxsampleluminance" [%s]' % f(g.u(.3, 2))
+        if g.chance(.15): film += ' "float scale" [%s]' % f(g.u(.5, 2))
+        s += 'Film "image" %s\n' % film
+        s += "WorldBegin\n"
+        # lights
+        nl = int(g.r.integers(1, 4))
+        for _ in range(nl):
+            k = g.pick(["point", "spot", "distant", "infinite", "area", "area", "areasphere"])
+            if k == "point": s += 'AttributeBegin\n%sLightSource "point" "point from" [%s] "rgb I" %s\nAttributeEnd\n' % (g.transform(), f([g.u(-2, 2), g.u(2, 4), g.u(-2, 2)]), g.rgb(5, 30))
+            elif k == "spot": s += 'AttributeBegin\n%sLightSource "spot" "point from" [%s] "point to" [%s] "rgb I" %s "float coneangle" [%s] "float conedeltaangle" [%s]\nAttributeEnd\n' % (
+                g.transform(), f([g.u(-2, 2), g.u(2, 4), g.u(-2, 2)]), f(g.r.uniform(-.5, .5, 3)), g.rgb(20, 80), f(g.u(15, 50)), f(g.u(2, 12)))
+            elif k == "distant": s += 'LightSource "distant" "point from" [%s] "point to" [0 0 0] "rgb L" %s\n' % (f([g.u(-2, 2), g.u(2, 4), g.u(-2, 2)]), g.rgb(.5, 2))
+            elif k == "infinite":
+                m = ' "string mapname" "%s"' % os.path.join(ROOT, "scenes", "envmap_40x20.pfm") if g.chance(.5) else ""
+                s += 'AttributeBegin\n%sLightSource "infinite" "rgb L" %s%s\nAttributeEnd\n' % (g.transform(), g.rgb(.2, .8), m)
+            elif k == "area":
+                ro = "ReverseOrientation\n" if g.chance(.3) else ""
+                s += 'AttributeBegin\n%sTranslate %s\n%sAreaLightSource "diffuse" "rgb L" %s%s\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.4 0 -.4 .4 0 -.4 .4 0 .4 -.4 0 .4]\nAttributeEnd\n' % (
+                    g.transform(), f([g.u(-1, 1), g.u(1.5, 2.5), g.u(-1, 1)]), ro, g.rgb(3, 15), ' "bool twosided" ["true"]' if g.chance(.4) else "")
+            else:
+                s += 'AttributeBegin\nTranslate %s\n%sAreaLightSource "diffuse" "rgb L" %s%s\n%sAttributeEnd\n' % (
+                    f([g.u(-1, 1), g.u(1.5, 2.5), g.u(-1, 1)]), g.transform(False), g.rgb(3, 15), ' "bool twosided" ["true"]' if g.chance(.4) else "", g.sphere())
+        # ground
+        d, _ = g.material()
+        s += d + 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4] "float uv" [0 0 4 0 4 4 0 4]\n'
+        # objects
+        for _ in range(int(g.r.integers(1, 5))):
+            d, _ = g.material()
+            ds, sh = g.shape()
+            s += "AttributeBegin\n" + d + ds + "Translate %s\n" % f([g.u(-1.6, 1.6), g.u(.2, .9), g.u(-1, 1.5)]) + g.transform() + ("ReverseOrientation\n" if g.chance(.2) else "") + sh + "AttributeEnd\n"
+        # instancing
+        if g.chance(.4):
+            d, _ = g.material()
+            ds, sh = g.mesh()
+            s += 'ObjectBegin "obj"\n' + d + ds + sh + ("AttributeBegin\nTranslate .3 .4 0\n" + g.sphere() + "AttributeEnd\n" if g.chance(.5) else "") + "ObjectEnd\n"
+            for _ in range(int(g.r.integers(1, 4))):
+                s += "AttributeBegin\nTranslate %s\n%sObjectInstance \"obj\"\nAttributeEnd\n" % (f([g.u(-1.6, 1.6), g.u(.2, .9), g.u(-1, 1.5)]), g.transform())
+        return s + "WorldEnd\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--keep", default=None, help="directory for the scenes that mismatch")
+    ap.add_argument("--two-level", action="store_true", help="oracle in two-level instancing mode (expected bit-exact)")
+    ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
+    a = ap.parse_args()
+    if not ol.have_ref():
+        raise SystemExit("oracle/_ref/pbrt_ref is not built (needs /root/reference)")
+    if a.two_level: os.environ["PBRT_AMD_INSTANCING"] = "1"
+    tmp = tempfile.mkdtemp()
+    bad = 0
+    for i in range(a.n):
+        seed = a.seed * 100000 + i
+        text = Gen(seed).scene(a.res)
+        fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)
+        out = os.path.join(tmp, "r.pfm")
+        if os.path.exists(out): os.remove(out)
+        r = subprocess.run([ol.PBRT_REF, "--quiet", "--nthreads", "1", "--outfile", out, fn], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(out):
+            print("seed %d: reference failed (%s)" % (seed, (r.stderr or "").strip()[:200])); continue
+        ref = pa.read_pfm(out)
+        try:
+            sc = pa.Scene(text=text)
+            img = sc.film_image(ol.render(sc, nthreads=4)[0])
+        except Exception as e:
+            print("seed %d: host/oracle failed: %s" % (seed, e)); bad += 1
+            if a.keep: os.makedirs(a.keep, exist_ok=True); open(os.path.join(a.keep, "fuzz_%d.pbrt" % seed), "w").write(text)
+            continue
+        if img.shape != ref.shape:
+            print("seed %d: image size %s vs %s" % (seed, img.shape, ref.shape)); bad += 1; continue
+        d = np.abs(img - ref)
+        ok_px = np.all(d <= 2e-6 * (1 + np.abs(ref)), axis=-1)
+        frac, relmse = ol.image_metrics(img, ref)
+        status = "ok" if ok_px.all() else ("close" if frac >= 0.995 and relmse <= 1e-4 else "MISMATCH")
+        if status != "ok":
+            print("seed %d: %s  exact-px %.4f  frac %.4f relmse %.2e maxdiff %.3e" % (seed, status, float(ok_px.mean()), frac, relmse, float(d.max())))
+            if status == "MISMATCH" or a.two_level:
+                bad += 1
+                if a.keep: os.makedirs(a.keep, exist_ok=True); open(os.path.join(a.keep, "fuzz_%d.pbrt" % seed), "w").write(text)
+    print("%d scenes, %d mismatching" % (a.n, bad))
+
+
+if __name__ == "__main__":
+    main()
