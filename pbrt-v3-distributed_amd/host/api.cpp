@@ -57,6 +57,10 @@ struct RenderOptions {   // api.cpp:150-186
     // two-level mode (PBRT_AMD_INSTANCING=1): the objects that were instantiated, each with its own BVHAccel
     std::vector<Scene::ObjectDef> objectDefs;
     std::map<std::string, int> objectIndex;
+    // flattened mode: the bounds the reference's TransformedPrimitives would have, and which primitives are flattened copies
+    Bounds3 instanceBound;
+    bool haveFlattenedInstances = false;
+    std::vector<uint8_t> flattenedPrim;
 };
 
 APIState currentApiState = APIState::Uninitialized;
@@ -450,6 +454,30 @@ void pbrtObjectEnd() {
     renderOptions->currentInstance = nullptr;
     pbrtAttributeEnd();
 }
+// Transform::operator()(const Bounds3f &) core/transform.cpp:141-153: the box of the eight transformed corners
+static Bounds3 TransformBounds(const Transform &t, const Bounds3 &b) {
+    Bounds3 wb(t.Point(Vec3(b.pMin.x, b.pMin.y, b.pMin.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMax.x, b.pMin.y, b.pMin.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMin.x, b.pMax.y, b.pMin.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMin.x, b.pMin.y, b.pMax.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMin.x, b.pMax.y, b.pMax.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMax.x, b.pMax.y, b.pMin.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMax.x, b.pMin.y, b.pMax.z)));
+    wb = Union(wb, t.Point(Vec3(b.pMax.x, b.pMax.y, b.pMax.z)));
+    return wb;
+}
+// the WorldBound() of a list of primitives = what their BVHAccel's root node holds: the union of the triangles' / spheres' bounds
+static Bounds3 PrimitiveListBound(const std::vector<GeometricPrimitive> &prims, size_t begin, size_t end) {
+    Bounds3 b;
+    for (size_t i = begin; i < end; ++i) {
+        const TriangleMesh &m = *prims[i].shape;
+        for (int idx : m.indices) b = Union(b, m.p[idx]);
+        if (prims[i].sphere) b = Union(b, prims[i].sphere->WorldBound());
+        if (prims[i].instance) b = Union(b, prims[i].instance->worldBound);
+    }
+    return b;
+}
+
 void pbrtObjectInstance(const std::string &name) {
     VERIFY_WORLD("ObjectInstance");
     if (renderOptions->currentInstance) { Error("ObjectInstance can't be called inside instance definition"); return; }
@@ -475,14 +503,7 @@ void pbrtObjectInstance(const std::string &name) {
         auto inst = std::make_shared<InstanceRef>();
         inst->object = oi;
         inst->i2w = i2w;
-        Bounds3 wb(i2w.Point(Vec3(b.pMin.x, b.pMin.y, b.pMin.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMin.y, b.pMin.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMax.y, b.pMin.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMin.y, b.pMax.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMin.x, b.pMax.y, b.pMax.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMax.y, b.pMin.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMin.y, b.pMax.z)));
-        wb = Union(wb, i2w.Point(Vec3(b.pMax.x, b.pMax.y, b.pMax.z)));
+        Bounds3 wb = TransformBounds(i2w, b);
         inst->worldBound = wb;
         GeometricPrimitive gp;
         gp.shape = std::make_shared<TriangleMesh>();   // empty: the primitive is the instance
@@ -491,7 +512,12 @@ void pbrtObjectInstance(const std::string &name) {
         return;
     }
     // Default: static instances are flattened -- a transformed copy of each mesh (documented deviation):
-    // same surfaces, hits equal within float tolerance, no second BVH level on the device.
+    // same surfaces, hits equal within float tolerance, no second BVH level on the device.  What the reference derives from
+    // scene.WorldBound() (the voxel grid of the spatial light distribution, the scene radius of distant / infinite lights) sees the
+    // TransformedPrimitive's bound there -- the box of the object's transformed box, looser than the geometry -- so that bound is kept too.
+    renderOptions->instanceBound = Union(renderOptions->instanceBound, TransformBounds(i2w, PrimitiveListBound(it->second, 0, it->second.size())));
+    renderOptions->haveFlattenedInstances = true;
+    const size_t firstFlattened = renderOptions->primitives.size();
     for (const GeometricPrimitive &src : it->second) {
         GeometricPrimitive gp = src;
         auto mesh = std::make_shared<TriangleMesh>(*src.shape);
@@ -514,6 +540,7 @@ void pbrtObjectInstance(const std::string &name) {
         }
         renderOptions->primitives.push_back(gp);
     }
+    for (size_t i = firstFlattened; i < renderOptions->primitives.size(); ++i) renderOptions->flattenedPrim.resize(i + 1, 0), renderOptions->flattenedPrim[i] = 1;
 }
 
 // ------------------------------------------------------------------ WorldEnd
@@ -671,6 +698,13 @@ void pbrtWorldEnd() {
         }
         renderOptions->AcceleratorParams.ReportUnused();
         scene.reset(new Scene(accel, std::move(renderOptions->primitives), std::move(renderOptions->lights)));
+        if (renderOptions->haveFlattenedInstances) {   // scene.WorldBound() as the reference's top-level BVH has it (see pbrtObjectInstance)
+            Bounds3 wb = renderOptions->instanceBound;
+            renderOptions->flattenedPrim.resize(scene->primitives.size(), 0);
+            for (size_t i = 0; i < scene->primitives.size(); ++i)
+                if (!renderOptions->flattenedPrim[i]) wb = Union(wb, PrimitiveListBound(scene->primitives, i, i + 1));
+            scene->worldBound = wb;
+        }
         scene->textures = CurrentTextures();
         scene->objects = std::move(renderOptions->objectDefs);
     }

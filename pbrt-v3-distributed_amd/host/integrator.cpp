@@ -137,6 +137,13 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     };
     emit(bvh, 0, 0);
     fs->nodes = bvh.nodes;
+    if (!fs->nodes.empty()) {
+        // scene.WorldBound() is read off the root node by the consumers of the desc (voxel grid of the spatial light distribution).  With
+        // flattened instances the reference's bound is looser than the geometry (api.cpp pbrtObjectInstance): widen the root box to it --
+        // a looser root only lets a few more rays start the traversal, the hits are the same.
+        const Bounds3 &wb = scene.WorldBound();
+        for (int a = 0; a < 3; ++a) { fs->nodes[0].bmin[a] = std::min(fs->nodes[0].bmin[a], wb.pMin[a]); fs->nodes[0].bmax[a] = std::max(fs->nodes[0].bmax[a], wb.pMax[a]); }
+    }
     {
         size_t outBase = nTop;
         for (size_t o = 0; o < scene.objects.size(); ++o) {
