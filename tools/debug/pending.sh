@@ -2,6 +2,7 @@
 # GPU checks that were still pending when round 1 ran out of GPU minutes (run this first next round):
 #   1. the scenes pinned for the oracle only (thin-lens + Halton textures, PNG radiance map, the instancing stress scene in its default
 #      flattened form) rendered on the device against their reference fixtures -- promote them to tests/test_gpu_parity.py when green;
+#   1b. the differential fuzzer in device mode (device vs oracle on random scenes: tools/fuzz_vs_reference.py --device);
 #   2. the experimental BVH8 traversal (tools/debug/bvh8.sh);
 #   3. the textured shading kernel built for 2 waves per SIMD (-DPT_TEX_SHADE_WAVES=2): parity + the textured C3 probe (tools/debug/abtex.sh texw2
 #      after building lib/variants/texw2.so with that flag).
@@ -23,4 +24,5 @@ for name in es.TEX_ORACLE_ONLY + ["instances2"]:
     except Exception as e:
         print("%-14s FAILED: %s" % (name, e))
 PY
+timeout 600 python tools/fuzz_vs_reference.py --device --n 60 --seed 7 --keep gpurun_out/fuzz_device 2>&1 | tail -15 | tee gpurun_out/pending_fuzz.txt
 bash tools/debug/bvh8.sh

@@ -271,6 +271,31 @@ class Gen:
         return s + "WorldEnd\n"
 
 
+def device_mode(a):
+    """device vs oracle on the same random scenes (the oracle is pinned to the reference by the default mode of this tool)"""
+    bad = 0
+    for i in range(a.n):
+        seed = a.seed * 100000 + i
+        text = Gen(seed).scene(a.res)
+        try:
+            sc = pa.Scene(text=text)
+            ref = sc.film_image(ol.render(sc, nthreads=8)[0])
+            ctx = pa.Context(sc)
+            ctx.render()
+            img = sc.film_image(ctx.film())
+            ctx.close()
+        except Exception as e:
+            print("seed %d: failed: %s" % (seed, str(e)[:200])); bad += 1
+            continue
+        if not np.all(np.isfinite(ref)):
+            continue   # the reference itself aborts on such scenes (negative / NaN radiance from out-of-range texture values)
+        frac, relmse = ol.image_metrics(img, ref)
+        if not (frac >= 0.99 and relmse <= 5e-4):
+            print("seed %d: MISMATCH frac %.4f relmse %.2e" % (seed, frac, relmse)); bad += 1
+            if a.keep: os.makedirs(a.keep, exist_ok=True); open(os.path.join(a.keep, "fuzz_%d.pbrt" % seed), "w").write(text)
+    print("%d scenes, %d mismatching (device vs oracle)" % (a.n, bad))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
@@ -278,7 +303,10 @@ def main():
     ap.add_argument("--keep", default=None, help="directory for the scenes that mismatch")
     ap.add_argument("--two-level", action="store_true", help="oracle in two-level instancing mode (expected bit-exact)")
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
+    ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
     a = ap.parse_args()
+    if a.device:
+        return device_mode(a)
     if not ol.have_ref():
         raise SystemExit("oracle/_ref/pbrt_ref is not built (needs /root/reference)")
     if a.two_level: os.environ["PBRT_AMD_INSTANCING"] = "1"
