@@ -188,6 +188,10 @@ class Gen:
             for i in range(n - 1):
                 q = j * n + i
                 I += [q, q + n, q + 1, q + 1, q + n, q + n + 1]
+        if self.chance(.08): I[3:6] = [I[3], I[3], I[5]]                       # a degenerate triangle (repeated vertex)
+        if self.chance(.08): UV = [.25, .75] * (len(UV) // 2)                 # degenerate parameterisation: every uv equal (triangle.cpp:300-315)
+        elif self.chance(.08): UV = [UV[2 * (i // n) * n] if k == 0 else UV[2 * i + 1] for i in range(len(UV) // 2) for k in range(2)]   # u constant along rows
+        if self.chance(.08): N[0:3] = [0, 0, 0]                               # a zero shading normal at one vertex
         s = 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' % (" ".join(map(str, I)), f(P))
         if self.chance(.5): s += ' "normal N" [%s]' % f(N)
         if self.chance(.7): s += ' "float %s" [%s]' % (self.pick(["uv", "st"]), f(UV))
