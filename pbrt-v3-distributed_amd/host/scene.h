@@ -35,6 +35,7 @@ std::shared_ptr<TriangleMesh> CreateTriangleMesh(const Transform &o2w, bool reve
 std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool ro, const ParamSet &ps);
 std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const ParamSet &ps);
 std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool ro, const ParamSet &ps);
+std::shared_ptr<TriangleMesh> CreateNURBS(const Transform &o2w, bool ro, const ParamSet &ps);   // shapes/nurbs.cpp: diced to a TriangleMesh by the reference itself
 std::shared_ptr<TriangleMesh> CreateSphereMesh(const Transform &o2w, bool ro, const ParamSet &ps);
 // MakeShapes (api.cpp:430-539)
 std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps);

@@ -259,9 +259,10 @@ static std::shared_ptr<TriangleMesh> CreateHeightfield(const Transform &o2w, boo
 std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transform &o2w, bool ro, const ParamSet &ps) {
     if (name == "trianglemesh") return CreateTriangleMeshShape(o2w, ro, ps);
     if (name == "heightfield") return CreateHeightfield(o2w, ro, ps);
+    if (name == "nurbs") return CreateNURBS(o2w, ro, ps);
     if (name == "plymesh") return CreatePLYMesh(o2w, ro, ps);
     if (name == "loopsubdiv") return CreateLoopSubdiv(o2w, ro, ps);
-    // quadrics / curves / nurbs: not on the triangle hot path
+    // quadrics / curves: not on the triangle hot path
     Warning("Shape \"%s\" is not supported by the GPU triangle path (convert with the reference's --toply); skipped.",
             name.c_str());
     return nullptr;

@@ -72,6 +72,24 @@ def scene(name):
                         (-.6, .05, -1.2, 10, 1, 1, 1, "one"), (1.1, .05, -1.0, -35, 1.5, .7, 1, "one")])
         return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
                         'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "rgb L" [1 1 1]\n' + obj + inst)
+    if name == "nurbs":         # Shape "nurbs": a rational bicubic patch (Pw, non-uniform knots, u0/u1 sub-range) and a biquadratic one (P), diced by the reference itself
+        import math
+        pw = []
+        for j in range(4):
+            for i in range(5):
+                wgt = 1 + .6 * ((i + j) % 2)
+                x, y, z = i * .5 - 1, .45 * math.sin(1.1 * i + .7 * j), j * .5 - .75
+                pw += [x * wgt, y * wgt, z * wgt, wgt]
+        p2 = [c for j in range(3) for i in range(3) for c in (i * .6, .3 * ((i * j) % 2), j * .6)]
+        fmt = lambda xs: " ".join("%.6g" % x for x in xs)
+        return _OPEN % ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 28 25]\n'
+                        'Texture "chk" "color" "checkerboard" "float uscale" [8] "float vscale" [8] "rgb tex1" [.8 .3 .2] "rgb tex2" [.9 .9 .8]\n'
+                        'AttributeBegin\nTranslate -.4 .7 -.6\nMaterial "plastic" "texture Kd" "chk" "rgb Ks" [.3 .3 .3] "float roughness" [.08]\n'
+                        'Shape "nurbs" "integer nu" [5] "integer nv" [4] "integer uorder" [4] "integer vorder" [4] "float uknots" [0 0 0 0 .4 1 1 1 1] "float vknots" [0 0 0 0 1 1 1 1] '
+                        '"float u0" [.05] "float u1" [.95] "float Pw" [%s]\nAttributeEnd\n'
+                        'AttributeBegin\nTranslate 1.1 .3 -1.4\nRotate 20 0 1 0\nMaterial "matte" "rgb Kd" [.3 .4 .8]\n'
+                        'Shape "nurbs" "integer nu" [3] "integer nv" [3] "integer uorder" [3] "integer vorder" [3] "float uknots" [0 0 0 1 1 1] "float vknots" [0 0 0 1 1 1] "point P" [%s]\nAttributeEnd\n'
+                        % (fmt(pw), fmt(p2)))
     if name == "heightfield":   # Shape "heightfield": the reference's own tessellation into a uv-mapped triangle mesh (heightfield.cpp), under a transform
         import math
         n = 9
@@ -244,5 +262,5 @@ def tex_scene(name):
 
 TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
-TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield", "infinite_xf"]
+TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield", "infinite_xf", "nurbs"]
 INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)
