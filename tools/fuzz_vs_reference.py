@@ -208,9 +208,22 @@ class Gen:
         return s + "\n"
 
     def shape(self):
-        k = self.pick(["mesh", "mesh", "sphere", "heightfield"])
+        k = self.pick(["mesh", "mesh", "sphere", "heightfield", "nurbs"])
         if k == "mesh": return self.mesh()
         if k == "sphere": return "", self.sphere()
+        if k == "nurbs":   # a rational patch of random order / size with clamped, randomly spaced knots
+            def knots(n, order):
+                inner = sorted(self.r.uniform(.1, .9, n - order))
+                return [0.] * order + [float(x) for x in inner] + [1.] * order
+            nu, nv = int(self.r.integers(3, 6)), int(self.r.integers(3, 6))
+            uo, vo = int(self.r.integers(2, min(4, nu) + 1)), int(self.r.integers(2, min(4, nv) + 1))
+            pw = []
+            for j in range(nv):
+                for i in range(nu):
+                    wgt = self.u(.6, 1.8)
+                    pw += [(i / (nu - 1) - .5) * wgt, self.u(0, .35) * wgt, (j / (nv - 1) - .5) * wgt, wgt]
+            return "", 'Shape "nurbs" "integer nu" [%d] "integer nv" [%d] "integer uorder" [%d] "integer vorder" [%d] "float uknots" [%s] "float vknots" [%s] "float Pw" [%s]\n' % (
+                nu, nv, uo, vo, f(knots(nu, uo)), f(knots(nv, vo)), f(pw))
         n = int(self.r.integers(2, 5))
         return "", 'Shape "heightfield" "integer nu" [%d] "integer nv" [%d] "float Pz" [%s]\n' % (n, n, f(self.r.uniform(0, .3, n * n)))
 
