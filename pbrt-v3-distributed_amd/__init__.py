@@ -327,7 +327,7 @@ def bvh4_validate(scene):
     L = device_lib()
     if L.mi_bvh4_validate(scene.desc, _ptr(st)) != 0:
         raise RuntimeError("mi_bvh4_validate: %s" % L.mi_last_error().decode())
-    return {"nodes": int(st[0]), "leaf_refs": int(st[1]), "depth": int(st[2]), "stack_need": int(st[3]), "prims": int(st[4])}
+    return {"nodes": int(st[0]), "leaf_refs": int(st[1]), "depth": int(st[2]), "stack_need": int(st[3]), "prims": int(st[4]), "objects": int(st[5])}
 
 
 def sphere_intersect(spheres, rays, device=0):

@@ -29,7 +29,8 @@
 #include "pt_material.h"
 #include "sobol_tables.inc"
 
-__constant__ DevTex c_tex;   // texture tables of the scene being rendered (set by mi_render for textured scenes only)
+__constant__ DevTex c_tex;
+__constant__ const DevInstance *c_instances;   // instance table of the scene being rendered (two-level scenes only)   // texture tables of the scene being rendered (set by mi_render for textured scenes only)
 
 // ============================================================================ device side
 // Per-path state is array-of-structures, one 128-byte cache line per path (+ one for the two NEE rays): after the
@@ -280,11 +281,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
 // WIDE: experimental -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
-template <bool WIDE> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <> struct TravTypes<true> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false>
+// INST: experimental -- two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
+template <bool WIDE, bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <> struct TravTypes<true, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
+template <> struct TravTypes<false, true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    typedef TravTypes<WIDE> TT;
+    typedef TravTypes<WIDE, INST> TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
@@ -352,10 +355,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
                     ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                    if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
                     uint32_t key = sc.n_materials;                                   // escaped rays
                     if (ts.prim != TRAV_MISS) {
                         int mat = (int)sc.tri_info[ts.prim].y;
@@ -554,7 +558,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_TEX_SHADE_WAVES
 #define PT_TEX_SHADE_WAVES PT_SHADE_WAVES   /* the textured instance: same register budget (168 VGPRs, 3 waves per SIMD) */
 #endif
-template <bool ENV, bool HALTON, bool TEX>
+// INST: experimental two-level scenes -- the hit primitive may have been reached through an instance (PathRec::pad0): the interaction is
+// built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
+template <bool ENV, bool HALTON, bool TEX, bool INST = false>
 __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
@@ -613,14 +619,27 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                 uint32_t tf;
                 LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
                 Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d); Pin(tinfo);
+                V3 iro = ro, ird = rd;   // the ray in the space the primitive lives in
+                const DevInstance *hitInst = nullptr;
+                if constexpr (INST) {
+                    uint32_t hi = ps.rec[slot].pad0;
+                    if (hi != TRAV_NO_INSTANCE) {
+                        hitInst = c_instances + hi;
+                        InstRay ir = InstanceRay(hitInst, ro, rd);
+                        iro = ir.o; ird = ir.d;
+                    }
+                }
                 if (ENV && (tf & TRI_FLAG_SPHERE)) {
-                    isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, hr.x);
+                    isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), iro, ird, hr.x);
                     if (TEX) ix = IsectX();   // spheres carry constant materials only (mi_scene_upload refuses textured ones)
                 } else {
                     TriHit th;
-                    TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                    isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), rd, hr.x);
+                    TriangleTest(p0, p1, p2, iro, ird, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
+                    isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), ird, hr.x);
                     if (TEX) ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
+                }
+                if constexpr (INST) {
+                    if (hitInst && !hitInst->identity) InstanceToWorld(hitInst, &isect, &ix);
                 }
             }
             PROBE(3)   // triangle reload + BuildIsect
@@ -1000,6 +1019,8 @@ struct mi_ctx {
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
     // experimental BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
+    bool hasInst = false;                    // two-level scene (PBRT_AMD_INSTANCING=1 on the host): experimental k_trace / k_shade INST instances
+    const DevInstance *instPtr = nullptr;
     bool useBvh8 = false;
     const BVH8Node *nodes8 = nullptr;
     uint32_t nNodes8 = 0;
@@ -1035,6 +1056,7 @@ static int upload(mi_ctx *c, DevBuf &b, const void *src, size_t bytes) {
 namespace {
 struct B4Builder {
     const mi_bvh2_node *n2;
+    uint32_t primBase = 0;   // added to every primitive offset: 0 for the top-level tree, mi_object::first_prim for an instanced object's
     std::vector<BVH4Node> out;
     int maxDepth = 0;
     static float area(const mi_bvh2_node &n) {
@@ -1093,10 +1115,43 @@ struct B4Builder {
         }
         for (int k = 0; k < nk; ++k) {
             const mi_bvh2_node &c = n2[kids[k]];
-            uint32_t ref = c.n_prims > 0 ? leafRef(c, (uint32_t)c.offset, c.n_prims, depth) : build(kids[k], depth + 1);
+            uint32_t ref = c.n_prims > 0 ? leafRef(c, primBase + (uint32_t)c.offset, c.n_prims, depth) : build(kids[k], depth + 1);
             setChild(out[idx], k, c.bmin, c.bmax, ref);
         }
         return idx;
+    }
+    // entries one lane's traversal stack can hold at once; two-level: + the rest of the leaf, the sentinel and the object's own tree
+    static int stackNeed(int topDepth, int objDepth, bool twoLevel) { return 3 * (topDepth + 1) + 1 + (twoLevel ? 2 + 3 * (objDepth + 1) + 1 : 0); }
+    // tree of one BVH2 (a single-leaf reference tree gets a one-child root node); returns the root's index in `out`
+    uint32_t buildTree(const mi_bvh2_node *nodes, uint32_t base) {
+        n2 = nodes; primBase = base; maxDepth = 0;
+        if (n2[0].n_prims > 0) {
+            uint32_t idx = (uint32_t)out.size();
+            out.emplace_back();
+            clearNode(out[idx]);
+            uint32_t ref = leafRef(n2[0], primBase + (uint32_t)n2[0].offset, n2[0].n_prims, 0);
+            setChild(out[idx], 0, n2[0].bmin, n2[0].bmax, ref);
+            return idx;
+        }
+        return build(0, 0);
+    }
+    // the top-level tree (root = node 0) and, for two-level scenes, one tree per instanced object behind it
+    bool buildScene(const mi_scene_desc *d, std::vector<uint32_t> *objRoot, int *topDepth, int *objDepth, std::string *err) {
+        *topDepth = *objDepth = 0;
+        objRoot->clear();
+        if (d->n_bvh_nodes) { buildTree(d->bvh_nodes, 0); *topDepth = maxDepth; }
+        if (!d->n_instances) return true;
+        objRoot->resize(d->n_objects);
+        for (uint32_t o = 0; o < d->n_objects; ++o) {
+            const mi_object &ob = d->objects[o];
+            if (!ob.n_nodes || (uint64_t)ob.first_prim + ob.n_prims > d->n_tris || ob.first_node < d->n_bvh_nodes) {
+                *err = "bad object record";
+                return false;
+            }
+            (*objRoot)[o] = buildTree(d->bvh_nodes + ob.first_node, ob.first_prim);
+            *objDepth = std::max(*objDepth, maxDepth);
+        }
+        return true;
     }
 };
 }  // namespace
@@ -1147,9 +1202,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
     if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
-    if (d->n_instances)   // loud, not approximate: the default host mode (flattened instances) is what the device renders
-        return fail("mi_scene_upload: the scene keeps ObjectInstance as a two-level hierarchy (PBRT_AMD_INSTANCING=1); the device traversal has one level -- "
-                    "unset PBRT_AMD_INSTANCING so that the host flattens the instances");
+    c->hasInst = d->n_instances > 0;   // two-level scenes: experimental device path (first compiled in round 1, see TravStateI)
+    if (c->hasInst && (!d->instances || !d->objects)) return fail("mi_scene_upload: instances without instance / object tables");
     // textures (row f2): validate the node table before anything is uploaded
     c->hasTex = c->hasAlpha = false;
     if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->hasTex |= d->material_descs[m].textured != 0;
@@ -1186,30 +1240,47 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(45 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
+    c->sceneBufs.resize(48 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
     std::memset(&sc, 0, sizeof(sc));
     // BVH4
     B4Builder bb;
-    bb.n2 = d->bvh_nodes;
-    if (d->n_bvh_nodes) {
-        if (d->bvh_nodes[0].n_prims > 0) {   // single-leaf tree: wrap it in one BVH4 node
-            bb.out.emplace_back();
-            B4Builder::clearNode(bb.out[0]);
-            uint32_t ref = bb.leafRef(d->bvh_nodes[0], (uint32_t)d->bvh_nodes[0].offset, d->bvh_nodes[0].n_prims, 0);
-            B4Builder::setChild(bb.out[0], 0, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, ref);
-        } else
-            bb.build(0, 0);
+    int topDepth = 0, objDepth = 0;
+    std::vector<uint32_t> objRoot;
+    std::vector<DevInstance> insts;
+    {
+        std::string err;
+        if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_scene_upload: " + err);
+    }
+    if (c->hasInst) {
+        insts.resize(d->n_instances);
+        for (uint32_t i = 0; i < d->n_instances; ++i) {
+            const mi_instance &mi = d->instances[i];
+            if (mi.object >= d->n_objects) return fail("mi_scene_upload: instance refers to a missing object");
+            std::memset(&insts[i], 0, sizeof(DevInstance));
+            std::memcpy(insts[i].w2i, mi.w2i, sizeof(mi.w2i)); std::memcpy(insts[i].i2w, mi.i2w, sizeof(mi.i2w));
+            insts[i].root = objRoot[mi.object];
+            bool identity = true;
+            for (int k = 0; k < 16; ++k) if (mi.i2w[k] != ((k % 5 == 0) ? 1.f : 0.f)) identity = false;
+            insts[i].identity = identity ? 1u : 0u;
+        }
     }
     { DevBuf &b = next(); if (upload(c, b, bb.out.data(), bb.out.size() * sizeof(BVH4Node))) return -1; sc.nodes = b.as<BVH4Node>(); }
     sc.n_nodes = (uint32_t)bb.out.size();
-    sc.stack_need = 3 * (bb.maxDepth + 1) + 1;
+    sc.stack_need = B4Builder::stackNeed(topDepth, objDepth, c->hasInst);
+    c->instPtr = nullptr;
+    if (c->hasInst) {
+        DevBuf &b = next();
+        if (upload(c, b, insts.data(), insts.size() * sizeof(DevInstance))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));   // insts is a local
+        c->instPtr = b.as<DevInstance>();
+    }
     c->useBvh8 = false;
     {   // experimental: the quantised BVH8 next to the BVH4 (the k_trace<..., WIDE> instances read it through a copy of DevScene)
         const char *e = std::getenv("PBRT_AMD_BVH8");
-        if (e && e[0] == '1' && d->n_bvh_nodes) {
+        if (e && e[0] == '1' && d->n_bvh_nodes && !c->hasInst) {
             bvh8::Builder b8;
             if (!b8.run(d)) return fail("mi_scene_upload: BVH8 build: " + b8.error);
             DevBuf &b = next();
@@ -1225,6 +1296,16 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     std::vector<float4> tv(3 * (size_t)d->n_tris);
     for (uint32_t t = 0; t < d->n_tris; ++t) {
         const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        if (v[0] == MI_PRIM_INSTANCE) {   // a TransformedPrimitive of a two-level scene: the record carries the instance index and the flag
+            if (v[1] >= d->n_instances) return fail("mi_scene_upload: primitive refers to a missing instance");
+            uint32_t fl = TRI_FLAG_INSTANCE;
+            float flf, idf;
+            std::memcpy(&flf, &fl, 4); std::memcpy(&idf, &v[1], 4);
+            tv[3 * (size_t)t] = make_float4(idf, 0, 0, flf);
+            tv[3 * (size_t)t + 1] = make_float4(0, 0, 0, 0);
+            tv[3 * (size_t)t + 2] = make_float4(0, 0, 0, 0);
+            continue;
+        }
         if (v[0] == MI_PRIM_SPHERE) {   // a Sphere primitive: the record carries its index and the flag
             if (v[1] >= d->n_spheres || !d->spheres) return fail("mi_scene_upload: primitive refers to a missing sphere");
             uint32_t fl = TRI_FLAG_SPHERE;
@@ -1283,7 +1364,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             const mi_mesh &m = d->meshes[d->tri_mesh[t]];
             TriShade &r = tsd[t];
             std::memset(&r, 0, sizeof(r));
-            if (v[0] == MI_PRIM_SPHERE) continue;
+            if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE) continue;
             if (d->N && (m.flags & MI_MESH_HAS_N))
                 for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) r.n[3 * k + a] = d->N[3 * (size_t)v[k] + a];
             if (d->UV && (m.flags & MI_MESH_HAS_UV)) {
@@ -1311,6 +1392,18 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
     std::memset(&c->tex, 0, sizeof(c->tex));
+    if (c->hasInst && !(c->hasTex || c->hasAlpha)) {   // the INST shading instance is the general (textured) one: give it "no textured material" descriptors
+        DevTex &tx = c->tex;
+        std::vector<mi_material_desc> descs(std::max<uint32_t>(1, d->n_materials));
+        std::memset(descs.data(), 0xff, descs.size() * sizeof(mi_material_desc));
+        for (auto &md : descs) { md.type = MI_MAT_MATTE; md.textured = 0; }
+        DevBuf &b = next();
+        if (upload(c, b, descs.data(), descs.size() * sizeof(mi_material_desc))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        tx.descs = b.as<mi_material_desc>();
+        tx.camera = d->camera;
+        tx.spp = d->integrator.spp;
+    }
     if (c->hasTex || c->hasAlpha) {   // texture node table, image pyramids, material parameter nodes, alpha masks -> c_tex (set per render)
         DevTex &tx = c->tex;
         { DevBuf &b = next(); if (upload(c, b, d->textures, (size_t)d->n_textures * sizeof(mi_texture))) return -1; tx.nodes = b.as<mi_texture>(); }
@@ -1355,6 +1448,15 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             { DevBuf &b = next(); if (upload(c, b, progOff.data(), progOff.size() * sizeof(int32_t))) return -1; tx.prog_off = b.as<int32_t>(); }
             { DevBuf &b = next(); if (upload(c, b, prog.data(), prog.size() * sizeof(int4))) return -1; tx.prog = b.as<int4>(); }
             HIP_TRY(hipStreamSynchronize(c->stream));   // locals
+        }
+        if (!c->hasTex && c->hasInst) {   // masks but no textured material, two-level scene: the general shading instance still wants descriptors
+            std::vector<mi_material_desc> descs(std::max<uint32_t>(1, d->n_materials));
+            std::memset(descs.data(), 0xff, descs.size() * sizeof(mi_material_desc));
+            for (auto &md : descs) { md.type = MI_MAT_MATTE; md.textured = 0; }
+            DevBuf &b = next();
+            if (upload(c, b, descs.data(), descs.size() * sizeof(mi_material_desc))) return -1;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            tx.descs = b.as<mi_material_desc>();
         }
         if (c->hasTex) { DevBuf &b = next(); if (upload(c, b, d->material_descs, (size_t)d->n_materials * sizeof(mi_material_desc))) return -1; tx.descs = b.as<mi_material_desc>(); }
         if (c->hasAlpha) { DevBuf &b = next(); if (upload(c, b, d->mesh_alpha, 2 * (size_t)d->n_meshes * sizeof(int32_t))) return -1; tx.mesh_alpha = b.as<int32_t>(); }
@@ -1668,7 +1770,10 @@ static void harvest(mi_ctx *c) {
 
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
-        if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* experimental: quantised BVH8 nodes */                \
+        if (c->hasInst) { /* experimental two-level scenes: the general instance (spheres, masks, instances) */      \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true, false, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, true, true, false, true>), grid, block, 0, st, sc, ps, qin);           \
+        } else if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* experimental: quantised BVH8 nodes */                \
             DevScene sc8 = sc;                                                                                      \
             sc8.nodes = reinterpret_cast<const BVH4Node *>(c->nodes8);                                              \
             sc8.n_nodes = c->nNodes8;                                                                               \
@@ -1694,10 +1799,11 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_COUNT * sizeof(uint32_t), st));
-    if (c->hasTex || c->hasAlpha)   // the texture tables of THIS context's scene (stream ordered: contexts sharing a device may interleave passes)
+    if (c->hasTex || c->hasAlpha || c->hasInst)   // the texture tables of THIS context's scene (stream ordered: contexts sharing a device may interleave passes)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
+    if (c->hasInst) HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_instances), &c->instPtr, sizeof(c->instPtr), 0, hipMemcpyHostToDevice, st));
     tic(c, MI_K_RAYGEN);
-    if (c->hasTex) hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, st, sc, ps, pass, 0u);
+    if (c->hasTex || c->hasInst) hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, st, sc, ps, pass, 0u);
     else hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, st, sc, ps, pass, 0u);
     toc(c);
     uint32_t qin = 0;
@@ -1718,7 +1824,10 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
-            if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
+            if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
+                if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+                else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
+            } else if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
                 if (halton) hipLaunchKernelGGL((k_shade<true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             } else if (c->hasEnvMap || c->hasSpheres) {
@@ -1862,24 +1971,22 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
 int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
     if (!d || !stats) return fail("mi_bvh4_validate: null argument");
     for (int i = 0; i < 8; ++i) stats[i] = 0;
-    if (d->n_instances) return fail("mi_bvh4_validate: two-level scenes are not handled (host flattening is the device's mode)");
     if (!d->n_bvh_nodes) return 0;
     B4Builder bb;
-    bb.n2 = d->bvh_nodes;
-    if (d->bvh_nodes[0].n_prims > 0) {
-        bb.out.emplace_back();
-        B4Builder::clearNode(bb.out[0]);
-        uint32_t ref = bb.leafRef(d->bvh_nodes[0], (uint32_t)d->bvh_nodes[0].offset, d->bvh_nodes[0].n_prims, 0);
-        B4Builder::setChild(bb.out[0], 0, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, ref);
-    } else
-        bb.build(0, 0);
+    int topDepth = 0, objDepth = 0;
+    std::vector<uint32_t> objRoot;
+    {
+        std::string err;
+        if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_bvh4_validate: " + err);
+    }
     std::vector<uint8_t> covered(d->n_tris, 0);
     int64_t leaves = 0, maxDepth = 0;
     struct Item { uint32_t node; int depth; };
     std::vector<Item> st{{0u, 0}};
-    auto primBox = [&](uint32_t t, float lo[3], float hi[3]) -> bool {   // false for spheres (their box is the reference node's)
+    for (uint32_t r : objRoot) st.push_back({r, 0});   // two-level scenes: the instanced objects' trees, each from depth 0
+    auto primBox = [&](uint32_t t, float lo[3], float hi[3]) -> bool {   // false for spheres and instances (their box is the reference node's)
         const uint32_t *v = d->tri_indices + 3 * (size_t)t;
-        if (v[0] == MI_PRIM_SPHERE) return false;
+        if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE) return false;
         for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
         for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) { float x = d->P[3 * (size_t)v[k] + a]; lo[a] = std::min(lo[a], x); hi[a] = std::max(hi[a], x); }
         return true;
@@ -1917,8 +2024,9 @@ int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
     int64_t ncov = 0;
     for (uint8_t cflag : covered) ncov += cflag;
     if (ncov != (int64_t)d->n_tris) return fail("mi_bvh4_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
-    if (maxDepth != bb.maxDepth) return fail("mi_bvh4_validate: depth bookkeeping differs from the tree");
-    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = maxDepth; stats[3] = 3 * (maxDepth + 1) + 1; stats[4] = ncov;
+    if (maxDepth != std::max(topDepth, objDepth)) return fail("mi_bvh4_validate: depth bookkeeping differs from the tree");
+    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = maxDepth; stats[3] = B4Builder::stackNeed(topDepth, objDepth, d->n_instances > 0); stats[4] = ncov;
+    stats[5] = (int64_t)objRoot.size();
     return 0;
 }
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_spheres(const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits) {

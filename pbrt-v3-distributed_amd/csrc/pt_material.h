@@ -370,3 +370,33 @@ PT_DEV void ComputeScatteringFunctionsT(const mi_material *materials, int mat, I
     out->n_bxdfs = 0; out->eta = 1;
     MaterialEvalD<PT_MIX_MAX_DEPTH>::eval(materials, mat, si, x, out);
 }
+
+// ------------------------------------------------------------------ two-level instancing (experimental), shading side
+// The ray a TransformedPrimitive hands to its object: Inverse(PrimitiveToWorld)(r) (transform.h:252-264), as EnterInstance computes it
+struct InstRay { V3 o, d; };
+__device__ __noinline__ InstRay InstanceRay(const DevInstance *in, const V3 ro, const V3 rd) {
+    V3 oErr;
+    InstRay r;
+    r.o = SXfPointErr(in->w2i, ro, &oErr);
+    r.d = SXfVector(in->w2i, rd);
+    Float lengthSquared = r.d.LengthSquared();
+    if (lengthSquared > 0) {
+        Float dt = Dot(Abs(r.d), oErr) / lengthSquared;
+        r.o = r.o + r.d * dt;
+    }
+    return r;
+}
+// Transform::operator()(const SurfaceInteraction &) core/transform.cpp:262-297 with PrimitiveToWorld
+__device__ __noinline__ void InstanceToWorld(const DevInstance *in, Isect *is, IsectX *ix) {
+    V3 pe;
+    is->p = SXfPointErr2(in->i2w, is->p, is->pError, &pe);
+    is->pError = pe;
+    is->n = Normalize(SXfNormal(in->w2i, is->n));
+    is->wo = Normalize(SXfVector(in->i2w, is->wo));
+    is->ns = Normalize(SXfNormal(in->w2i, is->ns));
+    is->dpdus = SXfVector(in->i2w, is->dpdus);
+    ix->dpdu = SXfVector(in->i2w, ix->dpdu); ix->dpdv = SXfVector(in->i2w, ix->dpdv);
+    ix->dpdvs = SXfVector(in->i2w, ix->dpdvs);
+    ix->dndus = SXfNormal(in->w2i, ix->dndus); ix->dndvs = SXfNormal(in->w2i, ix->dndvs);
+    is->ns = Faceforward(is->ns, is->n);
+}

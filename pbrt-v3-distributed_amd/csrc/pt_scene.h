@@ -28,7 +28,9 @@ struct __attribute__((aligned(128))) BVH4Node {
 #define TRI_FLAG_REJECT 1u
 // the primitive is a Sphere (shapes/sphere.cpp): record.v0.x holds the index into DevScene::spheres
 #define TRI_FLAG_SPHERE 2u
-#define TRI_FLAG_ALPHA 4u    /* the triangle's mesh has an alpha or shadow-alpha mask (triangle.cpp:333-338,532-570) */
+#define TRI_FLAG_ALPHA 4u
+/* the triangle's mesh has an alpha or shadow-alpha mask (triangle.cpp:333-338,532-570) */
+#define TRI_FLAG_INSTANCE 8u /* two-level scenes: the primitive is a TransformedPrimitive; record.v0.x holds the index into the instance table */
 
 struct DevEnvMap;
 struct DevLight {   // 10 x 16 bytes; the first 7, fetched with independent 16-byte loads (LoadLight)
@@ -506,19 +508,79 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     ts.cur = c0;
 }
 
+// ------------------------------------------------------------------ two-level instancing (experimental: PBRT_AMD_INSTANCING=1)
+// TransformedPrimitive::Intersect / IntersectP (core/primitive.cpp:76-111) inside the per-lane state machine: meeting an instance
+// primitive in a leaf, the lane pushes the rest of that leaf and a SENTINEL, takes its ray into the object's space
+// (Transform::operator()(Ray), transform.h:252-264: error-bounded origin, tMax shortened accordingly) and continues at the object's
+// own BVH; when the object's sub-tree is used up the sentinel comes off the stack and the world ray is restored with
+// r.tMax = ray.tMax if something was hit in there.  Compiled in round 1, not yet run on a GPU (the default host mode flattens).
+#define TRAV_SENTINEL 0xFFFFFFFEu   /* carries the leaf bit: arrives in the leaf step */
+#define TRAV_NO_INSTANCE 0xFFFFFFFFu
+struct DevInstance {
+    float w2i[16], i2w[16];   // Inverse(PrimitiveToWorld), PrimitiveToWorld (row major)
+    uint32_t root;            // BVH4 node of the object's tree
+    uint32_t identity;        // PrimitiveToWorld.IsIdentity(): the interaction is not transformed back (primitive.cpp:92)
+    uint32_t pad[2];
+};
+extern __constant__ const DevInstance *c_instances;
+struct TravStateI : TravState {
+    V3 wo, wd;            // the world-space ray while the lane is inside an instance
+    Float wtMax;
+    uint32_t inst, hitInst;
+    bool ihit;
+    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+        TravState::init(sc, o_, d_, tMax_, st);
+        inst = hitInst = TRAV_NO_INSTANCE; ihit = false; wtMax = tMax_;
+    }
+};
+PT_DEV void EnterInstance(TravStateI &ts, uint32_t idx) {
+    const DevInstance &in = c_instances[idx];
+    ts.wo = ts.o; ts.wd = ts.d; ts.wtMax = ts.tMax; ts.inst = idx; ts.ihit = false;
+    V3 oErr;
+    V3 o = SXfPointErr(in.w2i, ts.o, &oErr);
+    V3 d = SXfVector(in.w2i, ts.d);
+    Float lengthSquared = d.LengthSquared(), tm = ts.tMax;
+    if (lengthSquared > 0) {
+        Float dt = Dot(Abs(d), oErr) / lengthSquared;
+        o = o + d * dt;
+        tm -= dt;
+    }
+    ts.o = o; ts.d = d; ts.tMax = tm;
+    ts.box.init(o, V3(1 / d.x, 1 / d.y, 1 / d.z));
+    ts.shear.init(d);
+    ts.cur = in.root;
+}
+PT_DEV void LeaveInstance(TravStateI &ts) {
+    Float t = ts.ihit ? ts.tMax : ts.wtMax;   // r.tMax = ray.tMax only after a hit (primitive.cpp:88-90)
+    ts.o = ts.wo; ts.d = ts.wd; ts.tMax = t; ts.inst = TRAV_NO_INSTANCE;
+    ts.box.init(ts.o, V3(1 / ts.d.x, 1 / ts.d.y, 1 / ts.d.z));
+    ts.shear.init(ts.d);
+}
+
 // one leaf step = ONE triangle of the leaf (in primitive order; ties at equal t: the later one wins, as in the
 // reference's loop, bvh.cpp:677-681 with triangle.cpp:258-261).  A lane stays at the leaf until its triangles are
 // used up, so a leaf phase of the wave costs one watertight test whatever the leaf sizes of its lanes are.
 // alpha masks (scenes with masked meshes only): true if the mask(s) of `prim`'s mesh evaluate to 0 at the hit (pt_material.h)
 __device__ bool TriAlphaRejects(const uint4 *tri_info, const TriShade *tri_shade, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, Float b0, Float b1,
                                 Float b2, bool anyHit);
-template <bool ANY, bool COUNT, bool SPHERES = false, bool ALPHA = false, class TS = TravState, class ST = TravStack>
+template <bool ANY, bool COUNT, bool SPHERES = false, bool ALPHA = false, class TS = TravState, class ST = TravStack, bool INST = false>
 PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt) {
+    if constexpr (INST) {
+        if (ts.cur == TRAV_SENTINEL) { LeaveInstance(ts); ts.cur = st.pop(ts.tMax); return; }
+    }
     uint32_t first = ts.cur & BVH4_FIRST_MASK, left = (ts.cur >> 27) & 0xfu;   // left = triangles after this one
     V3 p0, p1, p2;
     uint32_t flags;
     LoadTri(sc, first, &p0, &p1, &p2, &flags);
     if (COUNT) ++cnt->tris;
+    if constexpr (INST) {
+        if (flags & TRI_FLAG_INSTANCE) {   // the rest of this leaf, the sentinel, then into the object
+            if (left) st.push(BVH4_LEAF | ((left - 1) << 27) | (first + 1), -PT_INFINITY);
+            st.push(TRAV_SENTINEL, -PT_INFINITY);
+            EnterInstance(ts, __float_as_uint(p0.x));
+            return;
+        }
+    }
     TriHit th;
     bool hitPrim;
     if (SPHERES && (flags & TRI_FLAG_SPHERE)) {   // Sphere::Intersect / IntersectP (scenes with spheres only: separate kernel instance)
@@ -531,6 +593,7 @@ PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt)
     if (hitPrim) {
         ts.prim = first;
         ts.tHit = th.t;
+        if constexpr (INST) { ts.hitInst = ts.inst; if (ts.inst != TRAV_NO_INSTANCE) ts.ihit = true; }
         if (ANY) { ts.cur = TRAV_DONE; return; }
         ts.tMax = th.t;   // GeometricPrimitive::Intersect shrinks ray.tMax (core/primitive.cpp:120)
     }

@@ -1,5 +1,5 @@
 """CPU: host-side logic of the drop-in (parser, pbrt API state machine, BVH build, flattening, film/image IO)."""
-import os
+import os, sys
 import subprocess
 
 import numpy as np
@@ -150,6 +150,20 @@ def test_bvh4_collapse_invariants(built, tmp_path):
         sc = pa.Scene(text=t) if acc else pa.Scene(out)
         st = pa.bvh4_validate(sc)
         assert st["prims"] == sc.info["n_tris"] and st["stack_need"] == 3 * (st["depth"] + 1) + 1, (acc, st)
+
+
+@pytest.mark.parametrize("name", ["instances", "instances2"])
+def test_bvh4_collapse_two_level(built, name, monkeypatch):
+    """Two-level scenes (PBRT_AMD_INSTANCING=1): mi_scene_upload collapses the top-level BVH2 and every instanced object's own BVH2 into
+    one BVH4 node array (object leaves carry GLOBAL primitive offsets).  Same invariants over all the trees together: every primitive --
+    top-level ones, the TransformedPrimitive records, the objects' own -- in exactly one leaf reference."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edge_scenes as es
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "1")
+    sc = pa.Scene(text=es.scene(name))
+    st = pa.bvh4_validate(sc)
+    assert st["objects"] >= 1 and st["prims"] == sc.info["n_tris"]
+    assert st["stack_need"] > 3 * (st["depth"] + 1) + 1    # room for the rest of a leaf, the sentinel and the object's tree
 
 
 # ---------------------------------------------------------------- image readers (core/imageio.cpp:216-290)
