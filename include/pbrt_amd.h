@@ -243,8 +243,8 @@ typedef struct mi_envmap {
  *     [first_prim, first_prim + n_prims) of the tri_* arrays, AFTER the n_top_prims top-level primitives; its LinearBVHNode array
  *     occupies [first_node, first_node + n_nodes) of bvh_nodes, AFTER the n_bvh_nodes top-level nodes, with child / primitive offsets
  *     relative to the object's own arrays.
- * Instanced primitives cannot be area lights (api.cpp:1351-1353).  Carried by the host and the CPU oracle; mi_scene_upload refuses
- * scenes with n_instances > 0 until the device traversal has the second level. */
+ * Instanced primitives cannot be area lights (api.cpp:1351-1353).  Carried by the host and the CPU oracle; the device traverses the
+ * second level through experimental kernel instances (k_trace / k_shade INST) that have not been validated on hardware yet. */
 #define MI_PRIM_INSTANCE 0xFFFFFFFEu
 typedef struct mi_instance {
     float i2w[16], w2i[16]; /* InstanceToWorld (the CTM at ObjectInstance) and its stored inverse, row major */
