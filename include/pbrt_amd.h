@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 8
+#define MI_ABI_VERSION 9
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -310,6 +310,25 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
 
 /* ---------------------------------------------------------------- the scene --------- */
 
+/* Participating media (VolPathIntegrator, integrators/volpath.cpp:55-190).  A medium is what MakeMedium builds
+ * (core/api.cpp:685-731): HomogeneousMedium (media/homogeneous.{h,cpp}) or GridDensityMedium (media/grid.{h,cpp}); the phase function of
+ * both is HenyeyGreenstein(g) (core/medium.cpp:189-215).  Carried by the host and the CPU oracle so far: mi_scene_upload refuses scenes
+ * whose integrator is "volpath" until the device has the medium-sampling kernels (PathIntegrator ignores media: path.cpp passes
+ * handleMedia = false, so "path" scenes with media declarations render as before). */
+enum mi_medium_type { MI_MEDIUM_HOMOGENEOUS = 0, MI_MEDIUM_GRID = 1 };
+typedef struct mi_medium {
+    int32_t type;
+    float sigma_a[3], sigma_s[3];
+    float sigma_t[3];          /* homogeneous: sigma_a + sigma_s (homogeneous.h:52); grid: the scalar (sigma_a + sigma_s)[0] in all three (grid.h:69) */
+    float g;
+    int32_t nx, ny, nz;        /* grid only */
+    float inv_max_density;     /* grid.h:77 */
+    float world_to_medium[16]; /* Inverse(medium2world * data2Medium) (api.cpp:723-726, grid.h:61), row major */
+    float pad;
+    const float *density;      /* nx*ny*nz, index (z*ny + y)*nx + x (grid.h:83); NULL for homogeneous media */
+} mi_medium;
+enum mi_integrator_type { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_VOLPATH = 1 };
+
 typedef struct mi_scene_desc {
     uint32_t abi_version; /* = MI_ABI_VERSION */
     /* vertices (world space, triangle.cpp:72-74) */
@@ -361,6 +380,15 @@ typedef struct mi_scene_desc {
     uint32_t pad1;
     const mi_instance *instances;
     const mi_object *objects;
+    /* participating media (see mi_medium): mesh_medium[2*m] = the GeometricPrimitive's MediumInterface::inside, [2*m+1] = outside as
+     * indices into media[], -1 = no medium (primitive.h:79, api.cpp:1355,1496-1516); NULL when no primitive names one.
+     * camera_medium: Camera::medium (camera.h:70; the outside medium of the graphics state at WorldEnd, api.cpp:793), -1 = vacuum */
+    uint32_t n_media;
+    int32_t camera_medium;
+    int32_t integrator_type; /* MI_INTEGRATOR_* */
+    uint32_t pad2;
+    const mi_medium *media;
+    const int32_t *mesh_medium;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

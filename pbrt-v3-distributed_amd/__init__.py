@@ -68,6 +68,7 @@ def host_lib():
         L.pbrt_amd_scene_desc.argtypes = [C.c_void_p]
         L.pbrt_amd_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pbrt_amd_scene_texture_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pbrt_amd_scene_media_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         for f in ("pbrt_amd_film_merge", "pbrt_amd_film_rgb"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
         L.pbrt_amd_film_clear.argtypes = [C.c_void_p]
@@ -140,6 +141,8 @@ class Scene:
         tinfo = (C.c_int64 * 4)()
         L.pbrt_amd_scene_texture_info(self._h, tinfo)
         self.info.update(n_textures=int(tinfo[0]), n_images=int(tinfo[1]), n_textured_materials=int(tinfo[2]), n_masked_meshes=int(tinfo[3]))
+        L.pbrt_amd_scene_media_info(self._h, tinfo)
+        self.info.update(n_media=int(tinfo[0]), n_medium_transitions=int(tinfo[1]), camera_medium=int(tinfo[2]), integrator=("path", "volpath")[int(tinfo[3])])
         self.width = self.info["crop_x1"] - self.info["crop_x0"]
         self.height = self.info["crop_y1"] - self.info["crop_y0"]
 

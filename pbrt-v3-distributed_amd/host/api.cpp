@@ -37,6 +37,7 @@ struct GraphicsState {
     ParamSet areaLightParams;
     std::string areaLight;
     bool reverseOrientation = false;
+    std::string currentInsideMedium, currentOutsideMedium;   // api.cpp:216
     GraphicsState() {
         ParamSet empty;
         TextureParams tp(empty, empty, textures);
@@ -54,6 +55,8 @@ struct RenderOptions {   // api.cpp:150-186
     std::vector<GeometricPrimitive> primitives;
     std::map<std::string, std::vector<GeometricPrimitive>> instances;
     std::vector<GeometricPrimitive> *currentInstance = nullptr;
+    std::map<std::string, int> namedMedia;                 // api.cpp:179, as indices into `media`
+    std::vector<std::shared_ptr<MediumSpec>> media;
     // two-level mode (PBRT_AMD_INSTANCING=1): the objects that were instantiated, each with its own BVHAccel
     std::vector<Scene::ObjectDef> objectDefs;
     std::map<std::string, int> objectIndex;
@@ -199,11 +202,96 @@ void pbrtCamera(const std::string &name, const ParamSet &params) {
     renderOptions->CameraToWorld = InverseSet(curTransform);
     namedCoordinateSystems["camera"] = renderOptions->CameraToWorld;
 }
-void pbrtMakeNamedMedium(const std::string &name, const ParamSet &) {
-    VERIFY_INITIALIZED("MakeNamedMedium");
-    Warning("Participating media are ignored by the path integrator (path.cpp:122-123); medium \"%s\" dropped.", name.c_str());
+// GetMediumScatteringProperties core/medium.cpp:174-185 over the measured-coefficient table (:48-172)
+static bool GetMediumScatteringProperties(const std::string &name, RGB *sigma_a, RGB *sigma_prime_s) {
+    struct MeasuredSS { const char *name; Float sps[3], sa[3]; };
+    static const MeasuredSS table[] = {
+#define P(n, s0, s1, s2, a0, a1, a2) {n, {(Float)s0, (Float)s1, (Float)s2}, {(Float)a0, (Float)a1, (Float)a2}},
+#include "medium_presets.inc"
+#undef P
+    };
+    for (const MeasuredSS &mss : table)
+        if (name == mss.name) {
+            *sigma_a = RGB(mss.sa[0], mss.sa[1], mss.sa[2]);
+            *sigma_prime_s = RGB(mss.sps[0], mss.sps[1], mss.sps[2]);
+            return true;
+        }
+    return false;
 }
-void pbrtMediumInterface(const std::string &, const std::string &) { VERIFY_INITIALIZED("MediumInterface"); }
+// MakeMedium core/api.cpp:685-731
+static std::shared_ptr<MediumSpec> MakeMedium(const std::string &name, const ParamSet &ps, const Transform &medium2world) {
+    RGB sig_a(.0011f, .0024f, .014f), sig_s(2.55f, 3.21f, 3.77f);
+    std::string preset = ps.FindOneString("preset", "");
+    bool found = GetMediumScatteringProperties(preset, &sig_a, &sig_s);
+    if (preset != "" && !found) Warning("Material preset \"%s\" not found.  Using defaults.", preset.c_str());
+    Float scale = ps.FindOneFloat("scale", 1.f);
+    Float g = ps.FindOneFloat("g", 0.0f);
+    sig_a = ps.FindOneSpectrum("sigma_a", sig_a) * scale;
+    sig_s = ps.FindOneSpectrum("sigma_s", sig_s) * scale;
+    auto spec = std::make_shared<MediumSpec>();
+    mi_medium &m = spec->m;
+    std::memset(&m, 0, sizeof(m));
+    RGB sig_t = sig_a + sig_s;
+    for (int c = 0; c < 3; ++c) { m.sigma_a[c] = sig_a.c[c]; m.sigma_s[c] = sig_s.c[c]; m.sigma_t[c] = sig_t.c[c]; }
+    m.g = g;
+    if (name == "homogeneous") {
+        m.type = MI_MEDIUM_HOMOGENEOUS;
+    } else if (name == "heterogeneous") {
+        int nitems;
+        const Float *data = ps.FindFloat("density", &nitems);
+        if (!data) { Error("No \"density\" values provided for heterogeneous medium?"); return nullptr; }
+        int nx = ps.FindOneInt("nx", 1), ny = ps.FindOneInt("ny", 1), nz = ps.FindOneInt("nz", 1);
+        Vec3 p0 = ps.FindOnePoint3("p0", Vec3(0.f, 0.f, 0.f)), p1 = ps.FindOnePoint3("p1", Vec3(1.f, 1.f, 1.f));
+        if (nitems != nx * ny * nz) {
+            Error("GridDensityMedium has %d density values; expected nx*ny*nz = %d", nitems, nx * ny * nz);
+            return nullptr;
+        }
+        Transform data2Medium = Translate(p0) * Scale(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
+        Transform worldToMedium = Inverse(medium2world * data2Medium);   // grid.h:61
+        m.type = MI_MEDIUM_GRID;
+        m.nx = nx; m.ny = ny; m.nz = nz;
+        std::memcpy(m.world_to_medium, worldToMedium.m.m, sizeof(m.world_to_medium));
+        spec->density.assign(data, data + nitems);
+        m.sigma_t[0] = m.sigma_t[1] = m.sigma_t[2] = sig_t.c[0];   // grid.h:69-73
+        if (!(sig_t.c[1] == sig_t.c[0] && sig_t.c[2] == sig_t.c[0])) Error("GridDensityMedium requires a spectrally uniform attenuation coefficient!");
+        Float maxDensity = 0;
+        for (int i = 0; i < nitems; ++i) maxDensity = std::max(maxDensity, data[i]);
+        m.inv_max_density = 1 / maxDensity;
+    } else {
+        Warning("Medium \"%s\" unknown.", name.c_str());
+        ps.ReportUnused();
+        return nullptr;
+    }
+    ps.ReportUnused();
+    return spec;
+}
+void pbrtMakeNamedMedium(const std::string &name, const ParamSet &params) {   // api.cpp:1093-1109
+    VERIFY_INITIALIZED("MakeNamedMedium");
+    std::string type = params.FindOneString("type", "");
+    if (type == "") { Error("No parameter string \"type\" found in MakeNamedMedium"); return; }
+    std::shared_ptr<MediumSpec> medium = MakeMedium(type, params, curTransform[0]);
+    if (medium) {
+        renderOptions->namedMedia[name] = (int)renderOptions->media.size();
+        renderOptions->media.push_back(medium);
+    }
+}
+void pbrtMediumInterface(const std::string &insideName, const std::string &outsideName) {   // api.cpp:1111-1121
+    VERIFY_INITIALIZED("MediumInterface");
+    graphicsState.currentInsideMedium = insideName;
+    graphicsState.currentOutsideMedium = outsideName;
+}
+// GraphicsState::CreateMediumInterface api.cpp:1496-1516
+static void CreateMediumInterface(int *inside, int *outside) {
+    *inside = *outside = -1;
+    auto lookup = [](const std::string &n, int *out) {
+        if (n == "") return;
+        auto it = renderOptions->namedMedia.find(n);
+        if (it != renderOptions->namedMedia.end()) *out = it->second;
+        else Error("Named medium \"%s\" undefined.", n.c_str());
+    };
+    lookup(graphicsState.currentInsideMedium, inside);
+    lookup(graphicsState.currentOutsideMedium, outside);
+}
 
 void pbrtWorldBegin() {
     VERIFY_OPTIONS("WorldBegin");
@@ -418,6 +506,7 @@ void pbrtShape(const std::string &name, const ParamSet &params) {
     gp.shape = shape;
     gp.sphere = sphere;
     gp.material = mtl;
+    CreateMediumInterface(&gp.mediumInside, &gp.mediumOutside);   // api.cpp:1355
     if (graphicsState.areaLight != "") {   // MakeAreaLight api.cpp:759-772, CreateDiffuseAreaLight diffuse.cpp:135-146
         if (graphicsState.areaLight == "area" || graphicsState.areaLight == "diffuse") {
             const ParamSet &ap = graphicsState.areaLightParams;
@@ -678,12 +767,14 @@ void pbrtWorldEnd() {
                 sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
             }
             renderOptions->SamplerParams.ReportUnused();
-            if (renderOptions->IntegratorName == "path") {
+            if (renderOptions->IntegratorName == "path" || renderOptions->IntegratorName == "volpath") {
+                // CreateVolPathIntegrator (volpath.cpp:192-214) reads the parameters CreatePathIntegrator does
                 integrator.reset(CreatePathIntegrator(renderOptions->IntegratorParams, sampler, camera));
+                integrator->volPath = renderOptions->IntegratorName == "volpath";
                 integrator->nGpus = PbrtOptions.nGpus;
                 renderOptions->IntegratorParams.ReportUnused();
             } else
-                Error("Integrator \"%s\" unknown to this path (only \"path\": SURVEY.md s.2 row 7).", renderOptions->IntegratorName.c_str());
+                Error("Integrator \"%s\" unknown to this path (\"path\" and \"volpath\": SURVEY.md s.2 row 7).", renderOptions->IntegratorName.c_str());
             if (renderOptions->lights.empty()) Warning("No light sources defined in scene; rendering a black image.");
         }
     }
@@ -706,6 +797,8 @@ void pbrtWorldEnd() {
             scene->worldBound = wb;
         }
         scene->textures = CurrentTextures();
+        scene->media = renderOptions->media;
+        { int in; CreateMediumInterface(&in, &scene->cameraMedium); }   // MakeCamera at WorldEnd: mediumInterface.outside (api.cpp:793-813)
         scene->objects = std::move(renderOptions->objectDefs);
     }
     if (scene && integrator) {

@@ -64,6 +64,12 @@ void pbrt_amd_scene_texture_info(pbrt_amd_scene *s, int64_t *out) {
     if (d.material_descs) for (uint32_t m = 0; m < d.n_materials; ++m) out[2] += d.material_descs[m].textured != 0;
     if (d.mesh_alpha) for (uint32_t m = 0; m < d.n_meshes; ++m) out[3] += d.mesh_alpha[2 * m] >= 0 || d.mesh_alpha[2 * m + 1] >= 0;
 }
+// participating media of the flattened scene (row f4): media, meshes whose two sides differ, camera medium, integrator type
+void pbrt_amd_scene_media_info(pbrt_amd_scene *s, int64_t *out) {
+    const mi_scene_desc &d = s->flat->desc;
+    out[0] = d.n_media; out[1] = 0; out[2] = d.camera_medium; out[3] = d.integrator_type;
+    if (d.mesh_medium) for (uint32_t m = 0; m < d.n_meshes; ++m) out[1] += d.mesh_medium[2 * m] != d.mesh_medium[2 * m + 1];
+}
 int pbrt_amd_scene_num_prims(pbrt_amd_scene *s) { return (int)s->built->scene->primitives.size(); }
 int pbrt_amd_scene_write_ply(pbrt_amd_scene *s, int prim, const char *filename) {
     if (prim < 0 || prim >= (int)s->built->scene->primitives.size()) return -1;

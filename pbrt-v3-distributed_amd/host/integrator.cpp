@@ -97,6 +97,7 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         fs->meshes[i].flags = flags;
         fs->meshes[i].material = materialIndex(prims[i].material);
         fs->meshAlpha.push_back(mesh.alphaTex); fs->meshAlpha.push_back(mesh.shadowAlphaTex);
+        fs->meshMedium.push_back(prims[i].mediumInside); fs->meshMedium.push_back(prims[i].mediumOutside);
     }
     // --- triangles in BVH primitive order: the top-level BVH's, then (two-level instancing) each object's own BVH order
     size_t nTop = bvh.primitives.size(), nTris = nTop;
@@ -278,6 +279,21 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         d.n_textures = (uint32_t)fs->textures.size(); d.textures = fs->textures.data();
         d.n_images = (uint32_t)fs->images.size(); d.images = fs->images.empty() ? nullptr : fs->images.data();
     }
+    // participating media: used by "volpath" only (PathIntegrator never looks at ray.medium), handed over whenever the scene names any
+    bool anyMedium = scene.cameraMedium >= 0;
+    for (int32_t m : fs->meshMedium) anyMedium |= m >= 0;
+    if (anyMedium) {
+        fs->mediaKeep = scene.media;
+        for (const auto &ms : scene.media) {
+            mi_medium m = ms->m;
+            m.density = ms->density.empty() ? nullptr : ms->density.data();
+            fs->media.push_back(m);
+        }
+        d.n_media = (uint32_t)fs->media.size(); d.media = fs->media.data();
+        d.mesh_medium = fs->meshMedium.data();
+    }
+    d.camera_medium = anyMedium ? scene.cameraMedium : -1;
+    d.integrator_type = volPath ? MI_INTEGRATOR_VOLPATH : MI_INTEGRATOR_PATH;
     d.material_descs = anyTextured ? fs->materialDescs.data() : nullptr;
     d.mesh_alpha = anyAlpha ? fs->meshAlpha.data() : nullptr;
     d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;

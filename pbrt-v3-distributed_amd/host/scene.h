@@ -114,6 +114,13 @@ struct GeometricPrimitive {   // primitive.h:66-90: one per Shape *mesh* here, o
     std::shared_ptr<InstanceRef> instance;
     std::shared_ptr<Material> material;
     std::shared_ptr<AreaLightSpec> areaLight;
+    int mediumInside = -1, mediumOutside = -1;   // MediumInterface (medium.h:100-110) as indices into Scene::media; -1 = none
+};
+
+// A participating medium as MakeMedium builds it (api.cpp:685-731): the POD record + the density grid it points into
+struct MediumSpec {
+    mi_medium m;
+    std::vector<float> density;
 };
 
 // ---- Aggregate: BVHAccel (accelerators/bvh.h:52-99)
@@ -208,6 +215,8 @@ class Scene {
     struct ObjectDef { std::vector<GeometricPrimitive> prims; std::shared_ptr<BVHAccel> accel; };
     std::vector<ObjectDef> objects;   // instanced objects (two-level mode only): each with the BVHAccel the reference builds for it (api.cpp:1563-1572)
     std::shared_ptr<TextureStore> textures;   // nodes / images the materials and alpha masks refer to
+    std::vector<std::shared_ptr<MediumSpec>> media;   // RenderOptions::namedMedia in definition order
+    int cameraMedium = -1;                             // Camera::medium (camera.h:70)
 };
 
 // ---- Integrator (core/integrator.h:53-58) and the GPU path integrator
@@ -237,6 +246,9 @@ struct FlatScene {
     std::vector<mi_bvh2_node> nodes;       // two-level mode: top-level nodes followed by every object's
     std::vector<mi_instance> instances;
     std::vector<mi_object> objects;
+    std::vector<mi_medium> media;
+    std::vector<int32_t> meshMedium;
+    std::vector<std::shared_ptr<MediumSpec>> mediaKeep;
 };
 
 class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegrator does (path.h:49-71)
@@ -254,6 +266,7 @@ class WavefrontPathIntegrator : public Integrator {   // stands where PathIntegr
     Float rrThreshold;
     std::string lightSampleStrategy;
     int nGpus = 1;   // --gpus: tile-sharded over this many devices in-process
+    bool volPath = false;   // created as Integrator "volpath" (integrators/volpath.cpp:192-214): same parameters, handleMedia = true
 };
 WavefrontPathIntegrator *CreatePathIntegrator(const ParamSet &ps, std::shared_ptr<Sampler> sampler,
                                               std::shared_ptr<PerspectiveCamera> camera);

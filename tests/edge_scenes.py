@@ -32,9 +32,58 @@ WorldEnd
 '''
 
 
+# ---- participating media: Integrator "volpath"
+def _grid_density(nx, ny, nz):
+    vals = []
+    for z in range(nz):
+        for y in range(ny):
+            for x in range(nx):
+                fx, fy, fz = (x + .5) / nx - .5, (y + .5) / ny - .5, (z + .5) / nz - .5
+                r = (fx * fx + fy * fy + fz * fz) ** .5
+                vals.append(max(0.0, 1.0 - 2.2 * r) * (1 + .5 * ((x * 7 + y * 3 + z * 5) % 4)))
+    return " ".join("%.4g" % v for v in vals)
+
+
+_SMOKE_BOX = ('Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+              '  "point P" [%s]\n')
+
+
+def vol_scene(name):
+    volpath = lambda t: t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "volpath" "integer maxdepth" [6]')
+    lights = ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 27 22]\n'
+              'AttributeBegin\nAreaLightSource "diffuse" "rgb L" [12 12 10]\n'
+              'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 3.5 -1  1 3.5 -1  1 3.5 1  -1 3.5 1]\nAttributeEnd\n')
+    if name == "vol_fog":        # the camera and every surface sit in one homogeneous medium (chromatic sigma_t, forward-scattering HG)
+        t = volpath(_OPEN % ('MediumInterface "" "fog"\n' + lights))
+        return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.02 .03 .05] "rgb sigma_s" [.12 .1 .07] "float g" [.4]\n'
+                                   'MediumInterface "" "fog"\nLookAt', 1)
+    if name == "vol_smoke":      # a heterogeneous (grid) medium inside a box without a BSDF; vacuum elsewhere; an infinite light as well
+        box = "-1 0.05 -1  1 0.05 -1  1 0.05 1  -1 0.05 1  -1 2.05 -1  1 2.05 -1  1 2.05 1  -1 2.05 1"
+        med = ('AttributeBegin\nTranslate 0 .05 0\n'
+               'MakeNamedMedium "smoke" "string type" "heterogeneous" "rgb sigma_a" [1 1 1] "rgb sigma_s" [5 5 5] "float g" [-.2]\n'
+               '  "integer nx" [5] "integer ny" [6] "integer nz" [4] "point p0" [-1 0 -1] "point p1" [1 2 1] "float density" [%s]\nAttributeEnd\n'
+               'AttributeBegin\nMediumInterface "smoke" ""\nMaterial ""\n%sAttributeEnd\n' % (_grid_density(5, 6, 4), _SMOKE_BOX % box))
+        return volpath(_OPEN % ('LightSource "infinite" "rgb L" [.3 .35 .45]\n' + lights + med))
+    if name == "vol_glass":      # a medium inside a glass box (an interface WITH a BSDF: refraction + the medium change), preset coefficients, fog outside
+        t = volpath(_OPEN % ('MakeNamedMedium "milk" "string type" "homogeneous" "string preset" "Skimmilk" "float scale" [2]\n'
+                             'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\n'
+                             'MediumInterface "" "haze"\n' + lights))
+        t = t.replace('Material "glass" "float index" [1.5]', 'MediumInterface "milk" "haze"\nMaterial "glass" "float index" [1.3]')
+        t = t.replace('Material "mirror"', 'MediumInterface "" "haze"\nMaterial "mirror"')
+        return t.replace('LookAt', 'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\nMediumInterface "" "haze"\nLookAt', 1)
+    if name == "vol_none":       # volpath on a scene without any medium: the integrator's own differences from "path" (unconditional light sample, Intersect-based visibility)
+        return volpath(_OPEN % lights)
+    raise KeyError(name)
+
+
+VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none"]
+
+
 def scene(name):
     if name.startswith("tex_"):
         return tex_scene(name)
+    if name.startswith("vol_"):
+        return vol_scene(name)
     if name == "infinite":      # constant InfiniteAreaLight: escaped-ray emission, light sampling + MIS, two lights -> spatial strategy
         return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
     if name == "infinite_xf":   # a CONSTANT infinite light under a rotation + mirroring scale: LightToWorld decides where a sample (u,v) points (infinite.cpp:116-118)

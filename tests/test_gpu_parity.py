@@ -387,3 +387,19 @@ def test_killeroo_simple_vs_the_reference_scene():
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     ctx.close()
+
+
+def test_volpath_scenes_are_refused_not_approximated():
+    """Row f4 is carried by the host and the CPU oracle so far: the device must say so instead of rendering "volpath" as "path"."""
+    sc = pa.Scene(text=edge_scenes.scene("vol_fog"))
+    with pytest.raises(RuntimeError, match="volpath"):
+        pa.Context(sc)
+    # the same media under Integrator "path" are ignored by the reference as well (handleMedia = false): rendered as before
+    sc2 = pa.Scene(text=edge_scenes.scene("vol_fog").replace('Integrator "volpath" "integer maxdepth" [6]', 'Integrator "path" "integer maxdepth" [5]'))
+    ctx = pa.Context(sc2)
+    ctx.render()
+    img = sc2.film_image(ctx.film())
+    ref = sc2.film_image(ol.render(sc2, nthreads=4)[0])
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
+    ctx.close()

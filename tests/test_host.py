@@ -430,3 +430,23 @@ def test_exr_reader(built, tmp_path, compression):
         sc.write_image(rgbw, out)
         back = pa.read_image(out)
         assert np.array_equal(back, sc.film_image(rgbw).astype(np.float16).astype(np.float32))
+
+
+def test_media_declarations_reach_the_scene_description(built):
+    """MakeNamedMedium / MediumInterface / Integrator "volpath" (core/api.cpp:685-731,1093-1121,1496-1516): media in
+    definition order, the MediumInterface of each GeometricPrimitive, the camera medium = the OUTSIDE medium of the graphics state at
+    WorldEnd (api.cpp:793), measured-coefficient presets, and -- for Integrator "path", which never looks at ray.medium -- the same
+    declarations carried along without changing what is rendered."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edge_scenes as es
+    fog = pa.Scene(text=es.scene("vol_fog"))
+    assert (fog.info["integrator"], fog.info["n_media"], fog.info["camera_medium"]) == ("volpath", 1, 0)
+    assert fog.info["n_medium_transitions"] >= 4          # every surface: vacuum inside, fog outside
+    smoke = pa.Scene(text=es.scene("vol_smoke"))
+    assert (smoke.info["n_media"], smoke.info["camera_medium"], smoke.info["n_medium_transitions"]) == (1, -1, 1)
+    glass = pa.Scene(text=es.scene("vol_glass"))
+    assert glass.info["n_media"] == 3 and glass.info["camera_medium"] == 2   # "haze" defined twice: the later definition is the one named afterwards
+    as_path = pa.Scene(text=es.scene("vol_fog").replace('Integrator "volpath"', 'Integrator "path"'))
+    assert (as_path.info["integrator"], as_path.info["n_media"]) == ("path", 1)
+    plain = pa.Scene(os.path.join(ROOT, "scenes", "cornell.pbrt"))
+    assert (plain.info["integrator"], plain.info["n_media"], plain.info["camera_medium"]) == ("path", 0, -1)
