@@ -29,6 +29,7 @@ def f(xs):
 class Gen:
     def __init__(self, seed):
         self.r = np.random.default_rng(seed)
+        self.seed = seed
         self.ntex = 0
 
     def u(self, a, b): return float(self.r.uniform(a, b))
@@ -227,9 +228,39 @@ class Gen:
         n = int(self.r.integers(2, 5))
         return "", 'Shape "heightfield" "integer nu" [%d] "integer nv" [%d] "float Pz" [%s]\n' % (n, n, f(self.r.uniform(0, .3, n * n)))
 
-    def scene(self, res):
+    # ---- participating media (--media): Integrator "volpath", named media, medium interfaces (own random stream: the scenes of the
+    # default mode stay what they were)
+    def media_decls(self):
+        m = self.m
+        names, out = [], ""
+        for i in range(int(m.integers(1, 4))):
+            name = "med%d" % i
+            k = ["homogeneous", "homogeneous", "heterogeneous", "preset"][int(m.integers(0, 4))]
+            g = ' "float g" [%s]' % f(float(m.uniform(-.8, .8))) if m.random() < .7 else ""
+            if k == "homogeneous":
+                out += 'MakeNamedMedium "%s" "string type" "homogeneous" "rgb sigma_a" [%s] "rgb sigma_s" [%s]%s\n' % (
+                    name, f(m.uniform(.01, .4, 3)), f(m.uniform(.05, 1.5, 3)), g)
+            elif k == "preset":
+                out += 'MakeNamedMedium "%s" "string type" "homogeneous" "string preset" "%s" "float scale" [%s]%s\n' % (
+                    name, ["Skimmilk", "Apple", "Ketchup", "Regular Milk", "Pacific Ocean Surface Water", "nonesuch"][int(m.integers(0, 6))], f(float(m.uniform(.2, 5))), g)
+            else:
+                nx, ny, nz = (int(v) for v in m.integers(1, 6, 3))
+                sa, ss = float(m.uniform(.1, 2)), float(m.uniform(.5, 8))
+                out += ('AttributeBegin\nTranslate %s\n%sMakeNamedMedium "%s" "string type" "heterogeneous" "rgb sigma_a" [%s %s %s] "rgb sigma_s" [%s %s %s]%s "integer nx" [%d] "integer ny" [%d] '
+                        '"integer nz" [%d] "point p0" [-1.2 -.2 -1.2] "point p1" [1.2 1.6 1.2] "float density" [%s]\nAttributeEnd\n') % (
+                    f(m.uniform(-.5, .5, 3)), self.transform(False) if m.random() < .4 else "", name, f(sa), f(sa), f(sa), f(ss), f(ss), f(ss), g, nx, ny, nz,
+                    f(m.uniform(0, 1, nx * ny * nz) * (m.uniform(0, 1, nx * ny * nz) < .8)))
+            names.append(name)
+        return names, out
+
+    def scene(self, res, media=False):
         g = self
         w, h = res
+        if media:
+            self.m = np.random.default_rng(self.seed + 77)
+            mnames, mdecls = self.media_decls()
+            mpick = lambda: "" if self.m.random() < .35 else mnames[int(self.m.integers(0, len(mnames)))]
+            outer = mpick()
         s = "LookAt %s  0 .3 0  0 1 0\n" % f([g.u(-1, 1), g.u(1.5, 3), g.u(-5, -3.5)])
         cam = '"float fov" [%s]' % f(g.u(25, 60))
         if g.chance(.3): cam += ' "float lensradius" [%s] "float focaldistance" [%s]' % (f(g.u(.01, .1)), f(g.u(3, 6)))
@@ -245,13 +276,28 @@ class Gen:
         if g.chance(.3): integ += ' "float rrthreshold" [%s]' % f(g.u(.2, 2))
         integ += ' "string lightsamplestrategy" "%s"' % g.pick(["uniform", "power", "spatial", "spatial"])
         if g.chance(.15): integ += ' "integer pixelbounds" [%d %d %d %d]' % (w // 5, w - w // 6, h // 6, h - h // 5)
-        s += 'Integrator "path" %s\n' % integ
+        s += 'Integrator "%s" %s\n' % ("volpath" if media else "path", integ)
         film = '"integer xresolution" [%d] "integer yresolution" [%d] "string filename" "f.pfm"' % (w, h)
         if g.chance(.2): film += ' "float cropwindow" [%s]' % f([g.u(0, .3), g.u(.6, 1), g.u(0, .3), g.u(.6, 1)])
         if g.chance(.15): film += ' "float maxsampleluminance" [%s]' % f(g.u(.3, 2))
         if g.chance(.15): film += ' "float scale" [%s]' % f(g.u(.5, 2))
         s += 'Film "image" %s\n' % film
         s += "WorldBegin\n"
+        if media:   # the camera medium is the OUTSIDE medium of the graphics state at WorldEnd; every surface created below sees `outer` outside
+            s += mdecls + 'MediumInterface "" "%s"\n' % outer
+            def wrap(block):   # an object with its own inside medium; sometimes without a BSDF (a pure medium boundary)
+                if self.m.random() < .5: return block
+                lines = 'MediumInterface "%s" "%s"\n' % (mpick(), outer)
+                if self.m.random() < .4: block = block.replace("AttributeBegin\n", "AttributeBegin\n@@", 1); none = True
+                else: none = False
+                block = block.replace("AttributeBegin\n", "AttributeBegin\n" + lines, 1)
+                if none:   # the material statement(s) of the block are dropped, Material "" takes their place
+                    head, tail = block.split("@@", 1)
+                    tail = "\n".join(l for l in tail.split("\n") if not (l.startswith("Material") or l.startswith("MakeNamedMaterial") or l.startswith("NamedMaterial")))
+                    block = head + 'Material ""\n' + tail
+                return block
+        else:
+            wrap = lambda block: block
         # lights
         nl = int(g.r.integers(1, 4))
         for _ in range(nl):
@@ -277,7 +323,7 @@ class Gen:
         for _ in range(int(g.r.integers(1, 5))):
             d, _ = g.material()
             ds, sh = g.shape()
-            s += "AttributeBegin\n" + d + ds + "Translate %s\n" % f([g.u(-1.6, 1.6), g.u(.2, .9), g.u(-1, 1.5)]) + g.transform() + ("ReverseOrientation\n" if g.chance(.2) else "") + sh + "AttributeEnd\n"
+            s += wrap("AttributeBegin\n" + d + ds + "Translate %s\n" % f([g.u(-1.6, 1.6), g.u(.2, .9), g.u(-1, 1.5)]) + g.transform() + ("ReverseOrientation\n" if g.chance(.2) else "") + sh + "AttributeEnd\n")
         # instancing
         if g.chance(.4):
             d, _ = g.material()
@@ -320,6 +366,7 @@ def main():
     ap.add_argument("--keep", default=None, help="directory for the scenes that mismatch")
     ap.add_argument("--two-level", action="store_true", help="oracle in two-level instancing mode (expected bit-exact)")
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
+    ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; the device has no volpath yet)")
     ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
     a = ap.parse_args()
     if a.device:
@@ -331,7 +378,7 @@ def main():
     bad = 0
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        text = Gen(seed).scene(a.res)
+        text = Gen(seed).scene(a.res, a.media)
         fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)
         out = os.path.join(tmp, "r.pfm")
         if os.path.exists(out): os.remove(out)
