@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 9
+#define MI_ABI_VERSION 10
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -71,7 +71,8 @@ enum mi_bxdf_type {
     MI_BXDF_FRESNEL_SPEC = 5, /* FresnelSpecular          reflection.cpp:477-511 */
     MI_BXDF_MICROFACET_R = 6, /* MicrofacetReflection     reflection.cpp:226-236,405-423 */
     MI_BXDF_MICROFACET_T = 7, /* MicrofacetTransmission   reflection.cpp:244-266,425-448 */
-    MI_BXDF_FRESNEL_BLEND = 8 /* FresnelBlend             reflection.cpp:279-298,450-475 */
+    MI_BXDF_FRESNEL_BLEND = 8, /* FresnelBlend             reflection.cpp:279-298,450-475 */
+    MI_BXDF_BSSRDF_ADAPTER = 9 /* SeparableBSSRDFAdapter   bssrdf.h:158-174: f = Sw(wi) * eta^2, etaB = the BSSRDF's eta (CPU oracle only so far) */
 };
 enum mi_fresnel_type { MI_FRESNEL_NOOP = 0, MI_FRESNEL_DIELECTRIC = 1, MI_FRESNEL_CONDUCTOR = 2 };
 
@@ -329,6 +330,30 @@ typedef struct mi_medium {
 } mi_medium;
 enum mi_integrator_type { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_VOLPATH = 1 };
 
+/* Subsurface scattering (the BSSRDF branch of path.cpp:153-174 / volpath.cpp:153-180).  SubsurfaceMaterial and
+ * KdSubsurfaceMaterial (materials/subsurface.cpp, kdsubsurface.cpp) build the BSDF GlassMaterial builds -- their entry in material_descs[]
+ * is an MI_MAT_GLASS record with textured = 1 -- and additionally a TabulatedBSSRDF (core/bssrdf.{h,cpp}) from per-hit coefficients and
+ * the BSSRDFTable their constructor computed (ComputeBeamDiffusionBSSRDF, bssrdf.cpp:145-176).  Each Material OBJECT with a BSSRDF keeps
+ * its own slot in materials[] (Sample_Sp accepts probe hits on primitives of the SAME material object only, bssrdf.cpp:302).
+ * Carried by the host and the CPU oracle; mi_scene_upload refuses scenes with such materials until the device has the probe kernels. */
+typedef struct mi_bssrdf_table {
+    int32_t n_rho, n_radius;      /* 100, 64 */
+    const float *rho_samples;     /* n_rho */
+    const float *radius_samples;  /* n_radius */
+    const float *profile;         /* n_rho * n_radius */
+    const float *rho_eff;         /* n_rho */
+    const float *profile_cdf;     /* n_rho * n_radius */
+} mi_bssrdf_table;
+enum mi_bssrdf_kind { MI_BSSRDF_NONE = 0, MI_BSSRDF_SUBSURFACE = 1, MI_BSSRDF_KDSUBSURFACE = 2 };
+typedef struct mi_bssrdf_desc {
+    int32_t kind;             /* mi_bssrdf_kind */
+    int32_t table;            /* index into bssrdf_tables[] */
+    int32_t sigma_a, sigma_s; /* SUBSURFACE: spectrum nodes (mm^-1 before `scale`) */
+    int32_t Kd, mfp;          /* KDSUBSURFACE: spectrum nodes (SubsurfaceFromDiffuse, bssrdf.cpp:178-188) */
+    float scale, eta, g;
+    int32_t pad;
+} mi_bssrdf_desc;
+
 typedef struct mi_scene_desc {
     uint32_t abi_version; /* = MI_ABI_VERSION */
     /* vertices (world space, triangle.cpp:72-74) */
@@ -389,6 +414,11 @@ typedef struct mi_scene_desc {
     uint32_t pad2;
     const mi_medium *media;
     const int32_t *mesh_medium;
+    /* subsurface materials (see mi_bssrdf_desc): material_bssrdf has n_materials entries or is NULL */
+    uint32_t n_bssrdf_tables;
+    uint32_t pad3;
+    const mi_bssrdf_table *bssrdf_tables;
+    const mi_bssrdf_desc *material_bssrdf;
 } mi_scene_desc;
 
 /* ---------------------------------------------------------------- ABI ---------------- */

@@ -1204,6 +1204,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
     if (d->integrator_type != MI_INTEGRATOR_PATH)   // loud, not approximate: the medium-sampling kernels do not exist yet (host + CPU oracle carry row f4 so far)
         return fail("mi_scene_upload: Integrator \"volpath\" (participating media) is not implemented on the device yet; \"path\" scenes render with their media ignored, as PathIntegrator does");
+    if (d->material_bssrdf)   // subsurface / kdsubsurface materials: the probe-ray kernels do not exist yet (host + CPU oracle carry them)
+        return fail("mi_scene_upload: materials with a BSSRDF (\"subsurface\", \"kdsubsurface\") are not implemented on the device yet");
     c->hasInst = d->n_instances > 0;   // two-level scenes: experimental device path (first compiled in round 1, see TravStateI)
     if (c->hasInst && (!d->instances || !d->objects)) return fail("mi_scene_upload: instances without instance / object tables");
     // textures (row f2): validate the node table before anything is uploaded

@@ -203,7 +203,7 @@ void pbrtCamera(const std::string &name, const ParamSet &params) {
     namedCoordinateSystems["camera"] = renderOptions->CameraToWorld;
 }
 // GetMediumScatteringProperties core/medium.cpp:174-185 over the measured-coefficient table (:48-172)
-static bool GetMediumScatteringProperties(const std::string &name, RGB *sigma_a, RGB *sigma_prime_s) {
+bool GetMediumScatteringProperties(const std::string &name, RGB *sigma_a, RGB *sigma_prime_s) {
     struct MeasuredSS { const char *name; Float sps[3], sa[3]; };
     static const MeasuredSS table[] = {
 #define P(n, s0, s1, s2, a0, a1, a2) {n, {(Float)s0, (Float)s1, (Float)s2}, {(Float)a0, (Float)a1, (Float)a2}},

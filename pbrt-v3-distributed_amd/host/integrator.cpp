@@ -67,11 +67,27 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     if (anyUV) fs->UV.assign(2 * nv, 0.f);
     // materials: identical BxDF lists (constant materials) / identical parameter nodes (textured ones) share one slot,
     // the sort key of the shading kernels; a textured mix refers to its two sub-materials by slot
+    std::map<const Material *, int> bssrdfSlot;
     std::function<int(const std::shared_ptr<Material> &)> materialIndex = [&](const std::shared_ptr<Material> &m) -> int {
         if (!m) return -1;
         mi_material_desc md = m->desc;
         if (md.type == MI_MAT_MIX && md.textured) { md.m1 = materialIndex(m->m1); md.m2 = materialIndex(m->m2); }
+        if (m->bssrdf.kind != MI_BSSRDF_NONE) {   // one slot per Material OBJECT: Sample_Sp compares material pointers (bssrdf.cpp:302)
+            auto it = bssrdfSlot.find(m.get());
+            if (it != bssrdfSlot.end()) return it->second;
+            mi_bssrdf_desc b = m->bssrdf;
+            size_t t = 0;
+            while (t < fs->tableKeep.size() && fs->tableKeep[t] != m->table) ++t;
+            if (t == fs->tableKeep.size()) fs->tableKeep.push_back(m->table);
+            b.table = (int32_t)t;
+            fs->materials.push_back(m->bsdf);
+            fs->materialDescs.push_back(md);
+            fs->materialBssrdf.resize(fs->materials.size());
+            fs->materialBssrdf.back() = b;
+            return bssrdfSlot[m.get()] = (int)fs->materials.size() - 1;
+        }
         for (size_t k = 0; k < fs->materials.size(); ++k) {
+            if (k < fs->materialBssrdf.size() && fs->materialBssrdf[k].kind != MI_BSSRDF_NONE) continue;
             if (md.textured != fs->materialDescs[k].textured) continue;
             if (md.textured ? std::memcmp(&fs->materialDescs[k], &md, sizeof(md)) == 0
                             : std::memcmp(&fs->materials[k], &m->bsdf, sizeof(mi_material)) == 0) return (int)k;
@@ -291,6 +307,18 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
         }
         d.n_media = (uint32_t)fs->media.size(); d.media = fs->media.data();
         d.mesh_medium = fs->meshMedium.data();
+    }
+    if (!fs->tableKeep.empty()) {   // subsurface materials
+        fs->materialBssrdf.resize(fs->materials.size());   // zero-filled tail = MI_BSSRDF_NONE
+        for (const auto &t : fs->tableKeep) {
+            mi_bssrdf_table bt;
+            bt.n_rho = t->nRho; bt.n_radius = t->nRadius;
+            bt.rho_samples = t->rhoSamples.data(); bt.radius_samples = t->radiusSamples.data(); bt.profile = t->profile.data();
+            bt.rho_eff = t->rhoEff.data(); bt.profile_cdf = t->profileCDF.data();
+            fs->bssrdfTables.push_back(bt);
+        }
+        d.n_bssrdf_tables = (uint32_t)fs->bssrdfTables.size(); d.bssrdf_tables = fs->bssrdfTables.data();
+        d.material_bssrdf = fs->materialBssrdf.data();
     }
     d.camera_medium = anyMedium ? scene.cameraMedium : -1;
     d.integrator_type = volPath ? MI_INTEGRATOR_VOLPATH : MI_INTEGRATOR_PATH;

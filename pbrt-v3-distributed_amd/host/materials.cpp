@@ -66,6 +66,7 @@ static std::shared_ptr<Material> newMat(const std::string &type, int descType, F
     m->bsdf.eta = eta;
     std::memset(&m->desc, 0xff, sizeof(m->desc));   // every node index -1
     m->desc.type = descType; m->desc.textured = 0; m->desc.remap_roughness = 0; m->desc.pad = 0;
+    std::memset(&m->bssrdf, 0, sizeof(m->bssrdf));   // MI_BSSRDF_NONE
     return m;
 }
 
@@ -162,6 +163,48 @@ static std::shared_ptr<Material> CreateGlass(const TextureParams &mp) {   // gla
         if (!R.IsBlack()) add(m->bsdf, microR(R, urough, vrough, MI_FRESNEL_DIELECTRIC, 1.f, eta));
         if (!T.IsBlack()) add(m->bsdf, microT(T, urough, vrough, 1.f, eta));
     }
+    return m;
+}
+
+// GetMediumScatteringProperties (core/medium.cpp:174-185) lives in api.cpp next to MakeMedium
+bool GetMediumScatteringProperties(const std::string &name, RGB *sigma_a, RGB *sigma_prime_s);
+
+// SubsurfaceMaterial / KdSubsurfaceMaterial (materials/subsurface.cpp:102-135, kdsubsurface.cpp:96-121): GlassMaterial's BSDF with the
+// material's constant eta, evaluated per hit (textured = 1), plus the BSSRDF description and the table of the constructor
+static std::shared_ptr<Material> CreateSubsurface(const TextureParams &mp, bool kd) {
+    ParamNodes pn(mp);
+    RGB dummy;
+    Float fdummy;
+    auto m = newMat(kd ? "kdsubsurface" : "subsurface", MI_MAT_GLASS);
+    mi_bssrdf_desc &b = m->bssrdf;
+    b.kind = kd ? MI_BSSRDF_KDSUBSURFACE : MI_BSSRDF_SUBSURFACE;
+    b.sigma_a = b.sigma_s = b.Kd = b.mfp = -1;
+    Float g, scale, eta;
+    if (!kd) {
+        RGB sig_a(.0011f, .0024f, .014f), sig_s(2.55f, 3.21f, 3.77f);
+        std::string name = mp.FindString("name", "");
+        bool found = GetMediumScatteringProperties(name, &sig_a, &sig_s);
+        g = mp.FindFloat("g", 0.0f);
+        if (name != "") {
+            if (!found) Warning("Named material \"%s\" not found.  Using defaults.", name.c_str());
+            else g = 0;   // the database holds reduced scattering coefficients
+        }
+        scale = mp.FindFloat("scale", 1.f);
+        eta = mp.FindFloat("eta", 1.33f);
+        b.sigma_a = pn.spec("sigma_a", sig_a, &dummy); b.sigma_s = pn.spec("sigma_s", sig_s, &dummy);
+        m->desc.Kr = pn.spec("Kr", RGB(1.f), &dummy); m->desc.Kt = pn.spec("Kt", RGB(1.f), &dummy);
+    } else {
+        b.Kd = pn.spec("Kd", RGB(.5f), &dummy); b.mfp = pn.spec("mfp", RGB(1.f), &dummy);
+        m->desc.Kr = pn.spec("Kr", RGB(1.f), &dummy); m->desc.Kt = pn.spec("Kt", RGB(1.f), &dummy);
+    }
+    m->desc.uroughness = pn.flt("uroughness", 0.f, &fdummy); m->desc.vroughness = pn.flt("vroughness", 0.f, &fdummy);
+    m->desc.bump = pn.bump();
+    if (kd) { eta = mp.FindFloat("eta", 1.33f); scale = mp.FindFloat("scale", 1.0f); g = mp.FindFloat("g", 0.0f); }
+    m->desc.remap_roughness = mp.FindBool("remaproughness", true);
+    m->desc.eta_f = ConstantTextureNode(false, RGB(eta));
+    m->desc.textured = 1;   // always built per hit: the BSSRDF needs the interaction anyway
+    b.scale = scale; b.eta = eta; b.g = g;
+    m->table = MakeBSSRDFTable(g, eta);
     return m;
 }
 
@@ -338,7 +381,9 @@ std::shared_ptr<Material> MakeMaterial(const std::string &name, const TexturePar
     } else if (name == "metal") material = CreateMetal(mp);
     else if (name == "substrate") material = CreateSubstrate(mp);
     else if (name == "uber") material = CreateUber(mp);
-    else if (name == "hair" || name == "disney" || name == "subsurface" || name == "kdsubsurface" || name == "fourier") {
+    else if (name == "subsurface") material = CreateSubsurface(mp, false);
+    else if (name == "kdsubsurface") material = CreateSubsurface(mp, true);
+    else if (name == "hair" || name == "disney" || name == "fourier") {
         Warning("Material \"%s\" is outside the GPU path's scope (SURVEY.md s.2 row 20). Using \"matte\".", name.c_str());
         material = CreateMatte(mp);
     } else {

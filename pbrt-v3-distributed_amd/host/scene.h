@@ -64,11 +64,19 @@ bool HasExtension(const std::string &name, const char *ext);
 
 // ---- Material (core/material.h:51-61).  `desc` = the parameter textures; when all of them are hit-independent
 // (desc.textured == 0) `bsdf` holds what ComputeScatteringFunctions(allowMultipleLobes=true, Radiance) builds.
+// BSSRDFTable (core/bssrdf.h:142-156) as ComputeBeamDiffusionBSSRDF fills it (host/bssrdf.cpp)
+struct BSSRDFTableData {
+    int nRho = 0, nRadius = 0;
+    std::vector<float> rhoSamples, radiusSamples, profile, rhoEff, profileCDF;
+};
+std::shared_ptr<BSSRDFTableData> MakeBSSRDFTable(Float g, Float eta);
 struct Material {
     std::string type;
     mi_material bsdf;
     mi_material_desc desc;
     std::shared_ptr<Material> m1, m2;   // MixMaterial
+    mi_bssrdf_desc bssrdf;              // kind = MI_BSSRDF_NONE unless "subsurface" / "kdsubsurface"
+    std::shared_ptr<BSSRDFTableData> table;
 };
 // MakeMaterial (api.cpp:541-611); returns nullptr for "" / "none"
 std::shared_ptr<Material> MakeMaterial(const std::string &name, const TextureParams &mp,
@@ -248,6 +256,9 @@ struct FlatScene {
     std::vector<mi_object> objects;
     std::vector<mi_medium> media;
     std::vector<int32_t> meshMedium;
+    std::vector<mi_bssrdf_desc> materialBssrdf;
+    std::vector<mi_bssrdf_table> bssrdfTables;
+    std::vector<std::shared_ptr<BSSRDFTableData>> tableKeep;
     std::vector<std::shared_ptr<MediumSpec>> mediaKeep;
 };
 

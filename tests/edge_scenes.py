@@ -79,11 +79,38 @@ def vol_scene(name):
 VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none"]
 
 
+# ---- subsurface scattering: the BSSRDF branch of path / volpath
+def sss_scene(name):
+    lights = ('LightSource "point" "point from" [3 4 -2] "rgb I" [30 27 22]\n'
+              'AttributeBegin\nAreaLightSource "diffuse" "rgb L" [12 12 10]\n'
+              'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 3.5 -1  1 3.5 -1  1 3.5 1  -1 3.5 1]\nAttributeEnd\n')
+    t = _OPEN % lights
+    if name == "sss_named":    # measured coefficients by name (g forced to 0), smooth boundary, Integrator "path"
+        return t.replace('Material "glass" "float index" [1.5]', 'Material "subsurface" "string name" "Skin1" "float scale" [12]')
+    if name == "sss_coeff":    # explicit coefficients, g, eta, rough boundary (microfacet lobes), a second object of the same KIND but another material object
+        t = t.replace('Material "glass" "float index" [1.5]',
+                      'Material "subsurface" "rgb sigma_a" [.05 .2 .4] "rgb sigma_s" [6 5 3] "float g" [.3] "float eta" [1.5] "float uroughness" [.2] "float vroughness" [.1] "float scale" [3]')
+        return t.replace('Material "plastic" "rgb Kd" [.7 .3 .2] "rgb Ks" [.3 .3 .3] "float roughness" [.1]',
+                         'Material "subsurface" "rgb sigma_a" [.05 .2 .4] "rgb sigma_s" [6 5 3] "float g" [.3] "float eta" [1.5] "float uroughness" [.2] "float vroughness" [.1] "float scale" [3]')
+    if name == "sss_kd":       # KdSubsurfaceMaterial: textured diffuse reflectance inverted to coefficients per hit (SubsurfaceFromDiffuse), under volpath in haze
+        t = t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "volpath" "integer maxdepth" [6]')
+        t = t.replace('Material "glass" "float index" [1.5]',
+                      'Texture "chk" "spectrum" "checkerboard" "float uscale" [3] "float vscale" [3] "rgb tex1" [.8 .3 .2] "rgb tex2" [.2 .5 .8]\n'
+                      'Material "kdsubsurface" "texture Kd" "chk" "rgb mfp" [.4 .3 .2] "float eta" [1.4] "float scale" [.5]')
+        return t.replace('LookAt', 'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\nMediumInterface "" "haze"\nLookAt', 1)
+    raise KeyError(name)
+
+
+SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd"]
+
+
 def scene(name):
     if name.startswith("tex_"):
         return tex_scene(name)
     if name.startswith("vol_"):
         return vol_scene(name)
+    if name.startswith("sss_"):
+        return sss_scene(name)
     if name == "infinite":      # constant InfiniteAreaLight: escaped-ray emission, light sampling + MIS, two lights -> spatial strategy
         return _OPEN % ('LightSource "infinite" "rgb L" [.5 .6 .8]\nLightSource "point" "point from" [3 4 -2] "rgb I" [20 18 15]')
     if name == "infinite_xf":   # a CONSTANT infinite light under a rotation + mirroring scale: LightToWorld decides where a sample (u,v) points (infinite.cpp:116-118)

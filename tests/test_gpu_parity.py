@@ -394,6 +394,8 @@ def test_volpath_scenes_are_refused_not_approximated():
     sc = pa.Scene(text=edge_scenes.scene("vol_fog"))
     with pytest.raises(RuntimeError, match="volpath"):
         pa.Context(sc)
+    with pytest.raises(RuntimeError, match="BSSRDF"):   # subsurface materials: likewise host + oracle only so far
+        pa.Context(pa.Scene(text=edge_scenes.scene("sss_named")))
     # the same media under Integrator "path" are ignored by the reference as well (handleMedia = false): rendered as before
     sc2 = pa.Scene(text=edge_scenes.scene("vol_fog").replace('Integrator "volpath" "integer maxdepth" [6]', 'Integrator "path" "integer maxdepth" [5]'))
     ctx = pa.Context(sc2)

@@ -189,6 +189,20 @@ def test_oracle_volpath_matches_reference(built, name):
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), float(np.abs(img - ref).max())
 
 
+@pytest.mark.parametrize("name", edge_scenes.SSS_NAMES)
+def test_oracle_subsurface_matches_reference(built, name):
+    """SURVEY.md s.8 row f4, the BSSRDF branch (path.cpp:153-174, volpath.cpp:153-180): SubsurfaceMaterial by measured name and by explicit
+    coefficients (smooth and rough boundary, two material objects of equal parameters = two different materials for the probe rays),
+    KdSubsurfaceMaterial with a textured reflectance inverted per hit, under "path" and under "volpath" in a medium.  Host (beam-diffusion
+    table of the material constructor, one slot per material object) + oracle (TabulatedBSSRDF: spline sampling of the radius, the three
+    projection axes, the probe-segment hit chain, the adapter lobe at the exit point; sampler dimensions in the order g++ evaluates the
+    reference's call arguments) against the reference's renders, BIT FOR BIT.  The device refuses such scenes so far."""
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    img = sc.film_image(ol.render(sc, nthreads=4)[0])
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), float(np.abs(img - ref).max())
+
+
 @pytest.mark.parametrize("name", edge_scenes.INSTANCE_NAMES)
 def test_oracle_object_instancing_both_ways(built, name, monkeypatch):
     """ObjectBegin / ObjectInstance.  Two-level mode (PBRT_AMD_INSTANCING=1: the reference's own structure -- one
