@@ -127,7 +127,27 @@ class Gen:
             return d, '"texture %s" "%s"' % (name, n)
         return "", '"float %s" [%s]' % (name, f(self.u(lo, hi)))
 
+    sss = False   # --sss: some top-level materials become subsurface / kdsubsurface (own random stream)
+
     def material(self, named=None):
+        if self.sss and not named:
+            if not hasattr(self, "q"): self.q = np.random.default_rng(self.seed + 99)
+            q = self.q
+            if q.random() < .45:
+                rough = ' "float uroughness" [%s] "float vroughness" [%s]' % (f(float(q.uniform(.01, .3))), f(float(q.uniform(.01, .3)))) if q.random() < .4 else ""
+                rough += ' "bool remaproughness" ["false"]' if q.random() < .2 else ""
+                eta = ' "float eta" [%s]' % f(float(q.uniform(1.1, 1.7))) if q.random() < .6 else ""
+                if q.random() < .5:
+                    d, kd = self.tex_rgb() if q.random() < .5 else ("", None)
+                    kdp = '"texture Kd" "%s"' % kd if kd else '"rgb Kd" [%s]' % f(q.uniform(.1, .9, 3))
+                    return d + 'Material "kdsubsurface" %s "rgb mfp" [%s] "float scale" [%s]%s%s%s\n' % (
+                        kdp, f(q.uniform(.05, 1, 3)), f(float(q.uniform(.2, 3))), ' "float g" [%s]' % f(float(q.uniform(-.5, .7))) if q.random() < .4 else "", eta, rough), None
+                if q.random() < .5:
+                    body = '"string name" "%s"' % ["Skin1", "Marble", "Ketchup", "Wholemilk", "nonesuch"][int(q.integers(0, 5))]
+                else:
+                    body = '"rgb sigma_a" [%s] "rgb sigma_s" [%s]' % (f(q.uniform(.001, .5, 3)), f(q.uniform(.5, 8, 3)))
+                    if q.random() < .5: body += ' "float g" [%s]' % f(float(q.uniform(-.5, .7)))
+                return 'Material "subsurface" %s "float scale" [%s]%s%s\n' % (body, f(float(q.uniform(.5, 20))), eta, rough), None
         k = self.pick(["matte", "matte", "plastic", "glass", "mirror", "metal", "uber", "substrate", "translucent", "mix"])
         defs, ps = "", []
 
@@ -366,6 +386,7 @@ def main():
     ap.add_argument("--keep", default=None, help="directory for the scenes that mismatch")
     ap.add_argument("--two-level", action="store_true", help="oracle in two-level instancing mode (expected bit-exact)")
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
+    ap.add_argument("--sss", action="store_true", help="subsurface / kdsubsurface materials among the top-level ones (host + oracle vs reference; the device has no BSSRDF yet)")
     ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; the device has no volpath yet)")
     ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
     a = ap.parse_args()
@@ -378,7 +399,8 @@ def main():
     bad = 0
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        text = Gen(seed).scene(a.res, a.media)
+        gen = Gen(seed); gen.sss = a.sss
+        text = gen.scene(a.res, a.media)
         fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)
         out = os.path.join(tmp, "r.pfm")
         if os.path.exists(out): os.remove(out)
