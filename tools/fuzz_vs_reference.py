@@ -127,10 +127,17 @@ class Gen:
             return d, '"texture %s" "%s"' % (name, n)
         return "", '"float %s" [%s]' % (name, f(self.u(lo, hi)))
 
+    def _emit(self, named, defs, kind, params):
+        if named:
+            self.ntex += 1
+            nm = "m%d" % self.ntex
+            return defs + 'MakeNamedMaterial "%s" "string type" "%s" %s\n' % (nm, kind, params), nm
+        return defs + 'Material "%s" %s\n' % (kind, params), None
+
     sss = False   # --sss: some top-level materials become subsurface / kdsubsurface (own random stream)
 
     def material(self, named=None):
-        if self.sss and not named:
+        if self.sss:
             if not hasattr(self, "q"): self.q = np.random.default_rng(self.seed + 99)
             q = self.q
             if q.random() < .45:
@@ -140,14 +147,14 @@ class Gen:
                 if q.random() < .5:
                     d, kd = self.tex_rgb() if q.random() < .5 else ("", None)
                     kdp = '"texture Kd" "%s"' % kd if kd else '"rgb Kd" [%s]' % f(q.uniform(.1, .9, 3))
-                    return d + 'Material "kdsubsurface" %s "rgb mfp" [%s] "float scale" [%s]%s%s%s\n' % (
-                        kdp, f(q.uniform(.05, 1, 3)), f(float(q.uniform(.2, 3))), ' "float g" [%s]' % f(float(q.uniform(-.5, .7))) if q.random() < .4 else "", eta, rough), None
+                    return self._emit(named, d, "kdsubsurface", '%s "rgb mfp" [%s] "float scale" [%s]%s%s%s' % (
+                        kdp, f(q.uniform(.05, 1, 3)), f(float(q.uniform(.2, 3))), ' "float g" [%s]' % f(float(q.uniform(-.5, .7))) if q.random() < .4 else "", eta, rough))
                 if q.random() < .5:
                     body = '"string name" "%s"' % ["Skin1", "Marble", "Ketchup", "Wholemilk", "nonesuch"][int(q.integers(0, 5))]
                 else:
                     body = '"rgb sigma_a" [%s] "rgb sigma_s" [%s]' % (f(q.uniform(.001, .5, 3)), f(q.uniform(.5, 8, 3)))
                     if q.random() < .5: body += ' "float g" [%s]' % f(float(q.uniform(-.5, .7)))
-                return 'Material "subsurface" %s "float scale" [%s]%s%s\n' % (body, f(float(q.uniform(.5, 20))), eta, rough), None
+                return self._emit(named, "", "subsurface", '%s "float scale" [%s]%s%s' % (body, f(float(q.uniform(.5, 20))), eta, rough))
         k = self.pick(["matte", "matte", "plastic", "glass", "mirror", "metal", "uber", "substrate", "translucent", "mix"])
         defs, ps = "", []
 
