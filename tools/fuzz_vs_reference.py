@@ -366,7 +366,8 @@ def device_mode(a):
     bad = 0
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        text = Gen(seed).scene(a.res)
+        gen = Gen(seed); gen.sss = a.sss
+        text = gen.scene(a.res, a.media)
         try:
             sc = pa.Scene(text=text)
             ref = sc.film_image(ol.render(sc, nthreads=8)[0])
