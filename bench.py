@@ -59,6 +59,169 @@ def host_cpus():
     return n
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_closest.json")
+
+
+def _lib_id():
+    """identifies the kernel build a PMC figure belongs to: hash of the device library"""
+    import hashlib
+    f = os.path.join(ROOT, "pbrt-v3-distributed_amd", "lib", "libpbrt_amd.so")
+    try:
+        return hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def traffic_live(wl_args, workload):
+    """HBM-side bytes per launch of the closest-hit kernel from a separate `rocprofv3 --pmc FETCH_SIZE` pass over the same
+    workload (child process, plain frames only).  FETCH_SIZE is in KiB of 64-byte requests; gfx950 tallies the 128-byte
+    requests of 16-byte-per-lane loads at 64 bytes, hence x2 (guides/MI355X_MICROARCH.md, HBM section)."""
+    import csv, glob, shutil, tempfile, collections
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        log("[bench] no rocprofv3: HBM traffic not measured live")
+        return None
+    d = tempfile.mkdtemp(prefix="pbrt_amd_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + wl_args + \
+          ["--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--traffic", "none", "--pmc-child"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    except Exception as e:
+        log("[bench] PMC pass failed to run: %s" % e)
+        return None
+    if r.returncode != 0:
+        log("[bench] PMC pass failed (rc %d): %s" % (r.returncode, r.stdout[-600:]))
+        return None
+    kb = collections.defaultdict(float)
+    disp = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == "FETCH_SIZE" and row["Kernel_Name"].startswith("void k_trace<0, false"):
+                kb[row["Kernel_Name"]] += float(row["Counter_Value"])
+                disp[row["Kernel_Name"]].add(row["Dispatch_Id"])
+    shutil.rmtree(d, ignore_errors=True)
+    if not kb:
+        log("[bench] PMC pass produced no FETCH_SIZE rows for k_trace<0, false, ...>")
+        return None
+    k = max(kb, key=lambda n: kb[n])
+    per = kb[k] / len(disp[k])
+    log("[bench] PMC pass: %s, %d launches, FETCH_SIZE %.0f KiB per launch (%.0f s)" % (k.split("(")[0], len(disp[k]), per, time.time() - t0))
+    return {"kernel": k.split("(")[0].replace("void ", ""), "launches": len(disp[k]), "FETCH_SIZE_KiB_per_launch": per, "bytes_per_launch": per * 1024 * 2,
+            "source": "live: rocprofv3 --pmc FETCH_SIZE pass of this workload inside this bench run (x2: gfx950 correction)", "workload": workload, "lib": _lib_id()}
+
+
+def traffic_from_file(workload):
+    try:
+        ent = json.load(open(TRAFFIC_FILE)).get("entries", {}).get(workload)
+    except Exception:
+        return None
+    if not ent:
+        return None   # never apply another workload's bytes
+    ent = dict(ent)
+    stale = ent.get("lib") != _lib_id()
+    ent["source"] = "file: profiles/traffic_closest.json (%s)%s" % (ent.get("profile", "committed PMC pass"), "; STALE: collected with a different kernel build" if stale else "")
+    return ent
+
+
+def traffic_save(workload, t):
+    try:
+        doc = json.load(open(TRAFFIC_FILE))
+        if "entries" not in doc:
+            doc = {"entries": {}}
+    except Exception:
+        doc = {"entries": {}}
+    e = {k: t[k] for k in ("kernel", "launches", "FETCH_SIZE_KiB_per_launch", "bytes_per_launch", "lib")}
+    e["profile"] = "rocprofv3 --pmc FETCH_SIZE, own pass of `bench.py` on this workload; KiB x 1024 x 2 (gfx950 correction)"
+    doc["entries"][workload] = e
+    json.dump(doc, open(TRAFFIC_FILE, "w"), indent=1, sort_keys=True)
+
+
+def cpu_reference(sc, scene_file, ncores, seconds, film_full, ol):
+    """pbrt_ref --nthreads <usable> --cropwindow <centre window> on the bench scene; None when the binary is not there."""
+    import re, tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+    if not os.access(ref, os.X_OK):
+        log("[bench] oracle/_ref/pbrt_ref not present: CPU baseline falls back to the oracle port")
+        return None
+    W, H, spp = sc.width, sc.height, sc.info["spp"]
+    est = 0.06 * ncores * 1e6                      # samples/s the reference manages on this class of scene (measured ~0.9 M/s on 16 threads)
+    frac = min(1.0, seconds * est / (float(W) * H * spp))
+    side = frac ** 0.5
+    x0, x1, y0, y1 = 0.5 - side / 2, 0.5 + side / 2, 0.5 - side / 2, 0.5 + side / 2
+    out = tempfile.mktemp(prefix="pbrt_ref_crop_", suffix=".pfm", dir="/tmp")
+    cmd = [ref, "--nthreads", str(ncores), "--cropwindow", "%.6f" % x0, "%.6f" % x1, "%.6f" % y0, "%.6f" % y1, "--outfile", out, scene_file]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, PBRT_REF_RENDER_TIMES="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+    except Exception as e:
+        log("[bench] pbrt_ref did not run: %s" % e)
+        return None
+    wall = time.time() - t0
+    m = re.search(r"Integrator::Render seconds ([0-9.]+)", r.stderr)
+    def stat(name):
+        mm = re.search(name + r"\s+(\d+)", r.stdout)
+        return int(mm.group(1)) if mm else 0
+    cam, reg, shd = stat("Camera rays traced"), stat("Regular ray intersection tests"), stat("Shadow ray intersection tests")
+    if r.returncode != 0 or not m or not cam:
+        log("[bench] pbrt_ref failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
+        return None
+    secs = float(m.group(1))
+    cpu = {"value": round(cam / secs * 1e-6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "reference",
+           "mrays_per_s": round((reg + shd) / secs * 1e-6, 3),
+           "sample": "oracle/_ref/pbrt_ref (pbrt-v3 built from the unmodified reference sources) --nthreads %d --cropwindow %.4f %.4f %.4f %.4f on the bench scene, "
+                     "all %d spp: %d camera samples, Integrator::Render tile loop %.1f s (whole process incl. parse + BVH build %.0f s); "
+                     "%d hardware threads visible, %d usable (affinity / cgroup quota)" % (ncores, x0, x1, y0, y1, spp, cam, secs, wall, os.cpu_count() or 1, ncores)}
+    try:   # parity of the SAME pixels: the GPU's full-spp frame against the reference's crop (stated tolerance of the parity tests)
+        pa = importlib.import_module("pbrt-v3-distributed_amd")
+        ci = pa.read_pfm(out)
+        f32 = np.float32   # Film::Film (core/film.cpp:52-58): ceil(fullResolution * cropWindow) in Float arithmetic; the window as the CLI parsed it (atof -> Float)
+        cw = [f32(float("%.6f" % v)) for v in (x0, x1, y0, y1)]
+        px0, px1 = int(np.ceil(f32(W) * cw[0])), int(np.ceil(f32(W) * cw[1]))
+        py0, py1 = int(np.ceil(f32(H) * cw[2])), int(np.ceil(f32(H) * cw[3]))
+        gi = film_full[py0:py1, px0:px1]
+        if gi.shape == ci.shape:
+            f, relmse = ol.image_metrics(gi, ci)
+            cpu["parity_crop"] = {"against": "pbrt_ref", "pixels": int(gi.shape[0] * gi.shape[1]), "spp": spp, "pixels_within_tol": round(f, 5), "relMSE": relmse}
+        else:
+            cpu["parity_crop"] = {"error": "crop shapes differ: %s vs %s" % (gi.shape, ci.shape)}
+    except Exception as e:
+        cpu["parity_crop"] = {"error": str(e)}
+    finally:
+        try:
+            os.remove(out)
+        except OSError:
+            pass
+    return cpu
+
+
+def cpu_port(sc, ctx, ncores, seconds, ol):
+    """the oracle port (oracle/pt_oracle.cpp) on centre tiles of the same frame, 8 spp; + parity of those samples against the GPU"""
+    ntx, nty = (sc.width + 15) // 16, (sc.height + 15) // 16
+    cx, cy = ntx // 2, nty // 2
+    spp_cpu = int(min(sc.info["spp"], 8))
+    side = 8   # centre box of side x side tiles, grown until the sample takes long enough
+    while True:
+        bx0, by0 = max(0, cx - side // 2), max(0, cy - side // 2)
+        box = [bx0, by0, min(ntx, bx0 + side), min(nty, by0 + side)]
+        rgbw_cpu, cc, secs = ol.render(sc, 0, spp_cpu, ncores, tiles=box)
+        if secs >= seconds * 0.5 or (box[2] - box[0] >= ntx and box[3] - box[1] >= nty):
+            break
+        side = int(side * max(1.5, min(4.0, (seconds / max(secs, 1e-3)) ** 0.5)))
+    cpu = {"value": round(cc["camera_rays"] / secs * 1e-6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",
+           "mrays_per_s": round((cc["closest_rays"] + cc["shadow_rays"]) / secs * 1e-6, 3),
+           "sample": "oracle/pt_oracle.cpp (CPU restatement, pinned to pbrt_ref) on tiles [%d,%d)x[%d,%d) of the same frame, %d of %d spp, %d threads, %.1f s"
+                     % (box[0], box[2], box[1], box[3], spp_cpu, sc.info["spp"], ncores, secs)}
+    ctx.film_clear()
+    ctx.render(spp_begin=0, spp_end=spp_cpu)
+    g = ctx.film()
+    ys, ye, xs, xe = box[1] * 16, min(sc.height, box[3] * 16), box[0] * 16, min(sc.width, box[2] * 16)
+    f, relmse = ol.image_metrics(sc.film_image(g)[ys:ye, xs:xe], sc.film_image(rgbw_cpu)[ys:ye, xs:xe])
+    cpu["parity_crop"] = {"against": "oracle port", "pixels_within_tol": round(f, 5), "relMSE": relmse}
+    return cpu
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,19 +235,34 @@ def main():
                     help="BASELINE.json config: c3 = San-Miguel-class 1080p 64spp (default, the metric's workload); "
                          "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30")
     ap.add_argument("--textured", action="store_true", help="c3 only: the stand-in with image-mapped / bump-mapped materials (SURVEY.md s.8 row f2)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target length of the CPU baseline sample: the reference binary oracle/_ref/pbrt_ref on a centre crop of the same frame (0 = skip)")
+    ap.add_argument("--cpu-port-seconds", type=float, default=6.0, help="length of the second CPU sample, the oracle port (0 = skip)")
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="HBM bytes per launch of the dominant kernel: live = an extra rocprofv3 --pmc FETCH_SIZE pass of this workload run as a child process; "
+                         "file = the committed profiles/traffic_closest.json entry of exactly this workload and kernel; none = null")
+    ap.add_argument("--save-traffic", action="store_true", help="write the live PMC result into profiles/traffic_closest.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
+        # same launch line the driver uses) and hand their exit code back; rank 0 of the child job prints the JSON line
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     dist = None
     torch = None
@@ -186,6 +364,13 @@ def main():
             par.combine_films(film_t, dst=0)
             torch.cuda.synchronize()   # the reduction reads film_t: it must be done before the next step clears the film
 
+    if args.pmc_child:   # under rocprofv3 --pmc: plain (non-counting) frames only, nothing printed
+        for _ in range(max(1, args.steps)):
+            step()
+        sync_all()
+        ctx.close()
+        return
+
     # ---- one counting pass (deterministic work: node / triangle fetch counts feed the roofline), then warm-up
     ctx.counters_reset()
     step(count=True)
@@ -222,66 +407,66 @@ def main():
     if rank == 0:
         msamples = samples[0] / elapsed * 1e-6
         mrays = samples[1] / elapsed * 1e-6
-        # ---- roofline of the dominant kernel (closest-hit traversal of path-extension rays), this rank
+        # ---- roofline of the dominant kernel (closest-hit traversal of path-extension rays), this rank.
+        # `achieved` = HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, x2: the gfx950 correction of
+        # guides/MI355X_MICROARCH.md) / the live average launch time (HIP events on the ctx stream): a true fraction of the
+        # 8 TB/s peak.  The ALGORITHMIC byte rate of SURVEY.md s.8(d) (every node / triangle fetch counted, most of them
+        # served by the XCD L2s) is reported beside it as l2_served_GBps -- it exceeds the HBM peak and bounds nothing.
         n_launch = max(1, timing["closest"][1])
         ext_rays = work["closest_rays"] - work["mis_rays"]
         alg_bytes = ext_rays * RAY_BYTES + work["nodes_closest"] * NODE_BYTES + work["tris_closest"] * TRI_BYTES   # per step
         t_closest_ms = timing["closest"][0] / args.steps                                                           # per step
-        achieved = alg_bytes / (t_closest_ms * 1e-3) * 1e-9 if t_closest_ms > 0 else 0.0
         launches_per_step = n_launch / args.steps
+        avg_launch_ms = t_closest_ms / max(1.0, launches_per_step)
+        alg_rate = alg_bytes / (t_closest_ms * 1e-3) * 1e-9 if t_closest_ms > 0 else 0.0
+        wl_args = ["--config", args.config, "--tris", str(args.tris), "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp)]
+        if args.scene:
+            wl_args += ["--scene", args.scene]
+        if args.textured:
+            wl_args += ["--textured"]
+        if args.max_paths:
+            wl_args += ["--max-paths", str(args.max_paths)]
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_closest.json")   # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"kernel": "k_trace<0,false,false> (BVH4 closest hit, path-extension rays; all-triangle instance)", "bound": "hbm",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
-                    "avg_launch_ms": t_closest_ms / max(1.0, launches_per_step), "launches_per_step": launches_per_step,
+        if world == 1 and args.traffic == "live":
+            traffic = traffic_live(wl_args, workload)
+        if world == 1 and traffic is None and args.traffic in ("live", "file"):
+            traffic = traffic_from_file(workload)
+        if traffic and args.save_traffic and traffic.get("source", "").startswith("live"):
+            traffic_save(workload, traffic)
+        roofline = {"kernel": (traffic or {}).get("kernel", "k_trace<0, ...> (BVH4 closest hit, path-extension rays)"), "bound": "hbm",
+                    "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                    "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
+                    "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step), "l2_served_GBps": round(alg_rate, 1),
                     "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays)}
+        if traffic:
+            roofline["achieved"] = round(traffic["bytes_per_launch"] / (avg_launch_ms * 1e-3) * 1e-9, 1)
+            roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
+            roofline["alg_over_hbm_bytes"] = round(roofline["alg_bytes_per_launch"] / traffic["bytes_per_launch"], 2)
         try:
             roofline["hbm_stream_read_GBps"] = round(ctx.stream_read_gbps(4 << 30), 1)   # achievable ceiling, beside the spec peak
+            if roofline["achieved"]:
+                roofline["frac_of_stream_ceiling"] = round(roofline["achieved"] / roofline["hbm_stream_read_GBps"], 4)
         except Exception as e:   # measurement aid only
             log("[bench] stream-read ceiling not measured: %s" % e)
-        if traffic:
-            # measured HBM-side bytes (PMC pass of the same command, profiles/traffic_closest.json) over the live launch time:
-            # the algorithmic figure counts every node fetch, most of which the XCD L2s serve
-            roofline["hbm_traffic_GBps"] = round(traffic / (roofline["avg_launch_ms"] * 1e-3) * 1e-9, 1)
-            roofline["hbm_traffic_frac"] = round(roofline["hbm_traffic_GBps"] / HBM_PEAK_GBS, 4)
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
-        # ---- CPU baseline: the oracle port on the host cores, on a bounded centre crop of the same frame
+        # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the
+        # unmodified sources -- on a centre crop of the same frame at full spp; time = SamplerIntegrator::Render's tile loop
+        # (stamped by the build shim, PBRT_REF_RENDER_TIMES), samples / rays from its own statistics.  The oracle port is
+        # timed as a second sample.  Reported baselines, not targets.
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
             import oracle_lib as ol
             ncores = host_cpus()
-            ntx, nty = (sc.width + 15) // 16, (sc.height + 15) // 16
-            cx, cy = ntx // 2, nty // 2
-            spp_cpu = int(min(sc.info["spp"], 8))
-            side = 8   # centre box of side x side tiles, grown until the sample takes long enough
-            while True:
-                bx0, by0 = max(0, cx - side // 2), max(0, cy - side // 2)
-                box = [bx0, by0, min(ntx, bx0 + side), min(nty, by0 + side)]
-                rgbw_cpu, cc, secs = ol.render(sc, 0, spp_cpu, ncores, tiles=box)
-                if secs >= args.cpu_seconds * 0.5 or (box[2] - box[0] >= ntx and box[3] - box[1] >= nty):
-                    break
-                side = int(side * max(1.5, min(4.0, (args.cpu_seconds / max(secs, 1e-3)) ** 0.5)))
-            cpu = {"value": round(cc["camera_rays"] / secs * 1e-6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",
-                   "mrays_per_s": round((cc["closest_rays"] + cc["shadow_rays"]) / secs * 1e-6, 3),
-                   "sample": "oracle/pt_oracle.cpp (CPU restatement, pinned to pbrt_ref) on tiles [%d,%d)x[%d,%d) of the same frame, %d of %d spp, %d threads "
-                             "(= usable CPUs: affinity / cgroup quota; %d hardware threads visible), %.1f s"
-                             % (box[0], box[2], box[1], box[3], spp_cpu, sc.info["spp"], ncores, os.cpu_count() or 1, secs)}
-            # parity spot check on that crop: GPU render of the same samples vs the oracle
-            ctx.film_clear()
-            ctx.render(spp_begin=0, spp_end=spp_cpu)
-            g = ctx.film()
-            ys, ye, xs, xe = box[1] * 16, min(sc.height, box[3] * 16), box[0] * 16, min(sc.width, box[2] * 16)
-            gi = sc.film_image(g)[ys:ye, xs:xe]
-            ci = sc.film_image(rgbw_cpu)[ys:ye, xs:xe]
-            frac, relmse = ol.image_metrics(gi, ci)
-            cpu["parity_crop"] = {"pixels_within_tol": round(frac, 5), "relMSE": relmse}
+            film_full = sc.film_image(ctx.film())   # the last timed step's frame (all spp)
+            cpu = cpu_reference(sc, scene_file, ncores, args.cpu_seconds, film_full, ol)
+            port = cpu_port(sc, ctx, ncores, args.cpu_port_seconds if cpu else max(args.cpu_port_seconds, args.cpu_seconds), ol) \
+                if (args.cpu_port_seconds > 0 or cpu is None) else None
+            if cpu is None:
+                cpu = port
+            elif port:
+                cpu["port"] = port
 
         out = {"metric": "Msamples/sec (whole node), San Miguel 1080p", "value": round(msamples, 3), "unit": "Msamples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

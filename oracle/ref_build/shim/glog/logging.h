@@ -35,18 +35,33 @@ struct NullSink {
     template <typename T> NullSink &operator<<(const T &) { return *this; }
     NullSink &operator<<(std::ostream &(*)(std::ostream &)) { return *this; }
 };
+// Timing of the reference's own hot path (bench.py's cpu_baseline): with PBRT_REF_RENDER_TIMES=1 in the
+// environment the LOG(INFO) lines of SamplerIntegrator::Render ("Starting image tile ..." / "Rendering finished",
+// core/integrator.cpp:256,335) are evaluated and stamped; the wall time between the first tile start and the end of
+// the tile loop goes to stderr as "[pbrt_ref] Integrator::Render seconds <t>".  Off (the default): LOG(INFO) costs one
+// load of a global flag and evaluates nothing, as before.  The reference's sources are not touched.
+extern bool g_render_times;
+void RenderMark(const std::string &msg);   // shim/stubs.cpp
+struct InfoSink {
+    std::ostringstream os;
+    template <typename T> InfoSink &operator<<(const T &v) { os << v; return *this; }
+    InfoSink &operator<<(std::ostream &(*f)(std::ostream &)) { os << f; return *this; }
+    ~InfoSink() { RenderMark(os.str()); }
+};
 struct Voidify {
     void operator&(const FatalSink &) {}
     void operator&(const NullSink &) {}
+    void operator&(const InfoSink &) {}
 };
 enum { INFO = 0, WARNING = 1, ERROR = 2, FATAL = 3 };
 }  // namespace shimlog
 
-// operands are never evaluated unless the severity is FATAL
-#define LOG(sev)                                   \
-    (shimlog::sev != shimlog::FATAL)               \
-        ? (void)0                                  \
-        : shimlog::Voidify() & shimlog::FatalSink(__FILE__, __LINE__, "LOG(FATAL)")
+// operands are never evaluated unless the severity is FATAL (or INFO while PBRT_REF_RENDER_TIMES=1 asks for the render timing)
+#define LOG(sev) SHIM_LOG_##sev
+#define SHIM_LOG_FATAL shimlog::Voidify() & shimlog::FatalSink(__FILE__, __LINE__, "LOG(FATAL)")
+#define SHIM_LOG_ERROR true ? (void)0 : shimlog::Voidify() & shimlog::NullSink()
+#define SHIM_LOG_WARNING true ? (void)0 : shimlog::Voidify() & shimlog::NullSink()
+#define SHIM_LOG_INFO !shimlog::g_render_times ? (void)0 : shimlog::Voidify() & shimlog::InfoSink()
 #define VLOG(n) true ? (void)0 : shimlog::Voidify() & shimlog::NullSink()
 #define CHECK(c) \
     (c) ? (void)0 : shimlog::Voidify() & shimlog::FatalSink(__FILE__, __LINE__, "Check failed: " #c)

@@ -27,6 +27,7 @@
 
 #include "pt_shade.h"
 #include "pt_material.h"
+#include "pt_trace_fast.h"
 #include "sobol_tables.inc"
 
 __constant__ DevTex c_tex;
@@ -282,12 +283,15 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
 // WIDE: experimental -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
 // INST: experimental -- two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
-template <bool WIDE, bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <> struct TravTypes<true, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
-template <> struct TravTypes<false, true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false>
+// FAST: the lean straight-line steps of pt_trace_fast.h (all-triangle scenes without masks / instances; the default there)
+template <bool WIDE, bool INST, bool FAST = false> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <> struct TravTypes<true, false, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
+template <> struct TravTypes<false, true, false> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <> struct TravTypes<false, false, true> { typedef FastRay State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    typedef TravTypes<WIDE, INST> TT;
+    static_assert(!FAST || (!SPHERES && !ALPHA && !WIDE && !INST && !PT_STACK_T), "the fast steps cover plain all-triangle scenes");
+    typedef TravTypes<WIDE, INST, FAST> TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
@@ -326,7 +330,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     float4 o4 = MODE == 0 ? ps.rec[slot].ray_o : (MODE == 1 ? ps.nee[slot].mi_o : ps.nee[slot].sh_o);
                     float4 d4 = MODE == 0 ? ps.rec[slot].ray_d : (MODE == 1 ? ps.nee[slot].mi_d : ps.nee[slot].sh_d);
                     if (MODE == 1) lightNum = __float_as_uint(d4.w);
-                    ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    if constexpr (FAST) FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    else ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
                     active = true;
                     ++nrays;
                 }
@@ -347,7 +352,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     bool wantNode = active && ts.atNode();
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
-                    if (wantNode) {
+                    if constexpr (FAST) {
+                        // the branch-free step needs the top of the stack inside the LDS part; a deep lane sends the wave through the general step
+                        if (__any(wantNode && st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD)) { if (wantNode) FastNodeStep<COUNT, true, true>(sc, ts, st, &tc); }
+                        else if (wantNode) FastNodeStep<COUNT, true, false>(sc, ts, st, &tc);
+                    } else if (wantNode) {
                         if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
                         else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
@@ -355,10 +364,15 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
+            if constexpr (FAST) {
+                const bool wantLeaf = active && ts.atLeaf();
+                if (__any(wantLeaf && st.sp > PT_LDS_STACK)) { if (wantLeaf) FastLeafStep<MODE == 2, COUNT, true>(sc, ts, st, &tc); }
+                else if (wantLeaf) FastLeafStep<MODE == 2, COUNT, false>(sc, ts, st, &tc);
+            } else if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             if (active && ts.done()) {
                 if (MODE == 0) {
-                    ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                    if constexpr (FAST) ps.rec[slot].hit = make_uint2(ts.prim, ts.prim != TRAV_MISS ? __float_as_uint(ts.tMax) : 0u);
+                    else ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                     if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
                     uint32_t key = sc.n_materials;                                   // escaped rays
                     if (ts.prim != TRAV_MISS) {
@@ -375,22 +389,25 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                 } else {
                     const DevLight &light = sc.lights[lightNum];
                     RGB Li(0.f);
+                    V3 ro, rd;   // the MIS ray (the lean state does not keep it)
+                    if constexpr (FAST) { float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d; ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z); }
+                    else { ro = ts.o; rd = ts.d; }
                     if (ts.prim != TRAV_MISS) {
                         if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
                             V3 p0, p1, p2;
                             uint32_t tf;
                             LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
                             Isect li;
-                            if (SPHERES && (tf & TRI_FLAG_SPHERE)) li = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ts.o, ts.d, ts.prim);
+                            if (SPHERES && (tf & TRI_FLAG_SPHERE)) li = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, ts.prim);
                             else {
                                 TriHit th;
-                                TriangleTest(p0, p1, p2, ts.o, ts.d, PT_INFINITY, &th);
-                                BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, ts.d, &li);
+                                TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);
+                                BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, rd, &li);
                             }
-                            Li = AreaL(light, li.n, -ts.d);   // lightIsect.Le(-wi)
+                            Li = AreaL(light, li.n, -rd);   // lightIsect.Le(-wi)
                         }
                     } else if (light.type == MI_LIGHT_INFINITE)
-                        Li = InfiniteLe(&light, ts.d);   // light.Le(ray)
+                        Li = InfiniteLe(&light, rd);   // light.Le(ray)
                     if (!Li.IsBlack()) {
                         float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
                         L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
@@ -905,7 +922,31 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
     }
 }
 
+// the triangle records permuted for the three dominant ray axes: copy kz holds (v[kx], v[ky], v[kz], w) with kx = kz + 1, ky = kx + 1 (mod 3)
+__global__ void __launch_bounds__(PT_BLOCK) k_permute_tris(const float4 *in, float4 *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * PT_BLOCK) {
+        float4 v = in[i];
+        out[i] = make_float4(v.y, v.z, v.x, v.w);           // kz = 0
+        out[n + i] = make_float4(v.z, v.x, v.y, v.w);       // kz = 1
+        out[2 * n + i] = v;                                 // kz = 2
+    }
+}
+
 // ---- stage-level kernels (parity tests): one lane per input record
+// plain per-ray loop over the lean steps (the stage-level entry points run what the render kernels run)
+template <bool ANY>
+PT_DEV bool TraverseFast(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit, TraceCounters *cnt) {
+    FastRay fr;
+    FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, fr, o, d, tMax, st);
+    while (!fr.done()) {
+        const bool safe = st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD;
+        if (fr.atNode()) { if (safe) FastNodeStep<false, true, true>(sc, fr, st, cnt); else FastNodeStep<false, true, false>(sc, fr, st, cnt); }
+        else { if (safe) FastLeafStep<ANY, false, true>(sc, fr, st, cnt); else FastLeafStep<ANY, false, false>(sc, fr, st, cnt); }
+    }
+    *tHit = fr.prim != TRAV_MISS ? fr.tMax : 0; *primHit = fr.prim;
+    return fr.prim != TRAV_MISS;
+}
+template <bool FAST>
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
     __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
     TravStack st;
@@ -918,11 +959,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathS
         Float t;
         uint32_t prim;
         if (occluded) {
-            occluded[i] = Traverse<true, false>(sc, o, d, r.tmax, st, &t, &prim, &tc) ? 1 : 0;
+            occluded[i] = (FAST ? TraverseFast<true>(sc, o, d, r.tmax, st, &t, &prim, &tc) : Traverse<true, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) ? 1 : 0;
         } else {
             mi_hit h;
             h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
-            if (Traverse<false, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
+            if (FAST ? TraverseFast<false>(sc, o, d, r.tmax, st, &t, &prim, &tc) : Traverse<false, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
                 V3 p0, p1, p2;
                 uint32_t tf;
                 LoadTri(sc, prim, &p0, &p1, &p2, &tf);
@@ -1021,6 +1062,7 @@ struct mi_ctx {
     // experimental BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
     bool hasInst = false;                    // two-level scene (PBRT_AMD_INSTANCING=1 on the host): experimental k_trace / k_shade INST instances
     const DevInstance *instPtr = nullptr;
+    bool useFast = false;                    // lean traversal steps (pt_trace_fast.h): all-triangle scenes without masks / instances
     bool useBvh8 = false;
     const BVH8Node *nodes8 = nullptr;
     uint32_t nNodes8 = 0;
@@ -1361,6 +1403,23 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         tv[3 * (size_t)t + 2] = make_float4(p2[0], p2[1], p2[2], 0);
     }
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
+    // lean traversal (pt_trace_fast.h): plain all-triangle scenes; PBRT_AMD_TRACE=general keeps the general steps (A/B, parity tests of both)
+    c->useFast = false;
+    {
+        const char *e = std::getenv("PBRT_AMD_TRACE");
+        const bool wantGeneral = e && std::strcmp(e, "general") == 0;
+        const char *e8 = std::getenv("PBRT_AMD_BVH8");
+        c->useFast = !wantGeneral && !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
+    }
+    sc.tri_perm = nullptr; sc.tri_perm_stride = 0;
+    if (c->useFast) {   // three copies of the records with the vertices permuted for kz = 0, 1, 2 (Permute(p, kx, ky, kz), triangle.cpp:205-209), made on the device
+        DevBuf &b = next();
+        if (b.alloc(3 * tv.size() * sizeof(float4))) return -1;
+        sc.tri_perm = b.as<float4>(); sc.tri_perm_stride = tv.size();
+        unsigned gridp = (unsigned)std::min<size_t>((tv.size() + PT_BLOCK - 1) / PT_BLOCK, 65536);
+        hipLaunchKernelGGL(k_permute_tris, dim3(gridp), dim3(PT_BLOCK), 0, c->stream, sc.tri_verts, b.as<float4>(), tv.size());
+        HIP_TRY(hipGetLastError());
+    }
     {   // per-triangle shading records (TriShade): vertex normals + uvs gathered through the index buffer
         std::vector<TriShade> tsd(d->n_tris);
         for (uint32_t t = 0; t < d->n_tris; ++t) {
@@ -1791,6 +1850,9 @@ static void harvest(mi_ctx *c) {
         } else if (c->hasSpheres) {                                                                                        \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true>), grid, block, 0, st, sc, ps, qin);        \
             else hipLaunchKernelGGL((k_trace<MODE, false, true>), grid, block, 0, st, sc, ps, qin);                 \
+        } else if (c->useFast) { /* the default for plain scenes: lean straight-line steps */                      \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
         } else {                                                                                                    \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false>), grid, block, 0, st, sc, ps, qin);       \
             else hipLaunchKernelGGL((k_trace<MODE, false, false>), grid, block, 0, st, sc, ps, qin);                \
@@ -2226,7 +2288,8 @@ int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
     if (n <= 0) return 0;
     DevBuf dr, dh;
     if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_hit))) return -1;
-    hipLaunchKernelGGL(k_stage_intersect, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
+    if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
+    else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
     HIP_TRY(hipMemcpyAsync(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     dr.release(); dh.release();
@@ -2251,7 +2314,8 @@ int mi_intersect_p(mi_ctx *c, const mi_ray *rays, int64_t n, uint8_t *occluded) 
     if (n <= 0) return 0;
     DevBuf dr, dh;
     if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n)) return -1;
-    hipLaunchKernelGGL(k_stage_intersect, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
+    if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
+    else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
     HIP_TRY(hipMemcpyAsync(occluded, dh.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     dr.release(); dh.release();

@@ -64,6 +64,8 @@ struct __attribute__((aligned(64))) TriShade {
 struct DevScene {
     const BVH4Node *nodes;
     const float4 *tri_verts;        // 3 per triangle
+    const float4 *tri_perm;         // the same records three times, vertices permuted for kz = 0, 1, 2 (pt_trace_fast.h); null: not built
+    size_t tri_perm_stride;         // float4s per copy (3 * n_tris)
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const mi_material *materials;

@@ -11,12 +11,32 @@ ROOT = ol.ROOT
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell.pbrt", "materials.pbrt"]
+# every traversal kernel instance the library ships runs the parity tests: "fast" = the lean steps of csrc/pt_trace_fast.h
+# (default for plain all-triangle scenes), "general" = TravNodeStep / TravLeafStep (what scenes with spheres / masks /
+# instances use; forced for plain scenes with PBRT_AMD_TRACE=general), "bvh8" = the quantised 8-wide nodes (PBRT_AMD_BVH8=1,
+# kept as a measured alternative: profiles/r02_*).  The variables are read by mi_scene_upload.
+TRACE_MODES = {"fast": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh8": {"PBRT_AMD_BVH8": "1"}}
 
 
-@pytest.fixture(scope="module", params=SCENES)
+def make_ctx(sc, mode="fast", **kw):
+    env = TRACE_MODES[mode]
+    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_BVH8")}
+    for k in saved:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        return pa.Context(sc, **kw)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module", params=[(s, m) for s in SCENES for m in TRACE_MODES], ids=lambda p: "%s-%s" % (p[0].split(".")[0], p[1]))
 def pair(request):
-    sc = pa.Scene(os.path.join(ROOT, "scenes", request.param))
-    ctx = pa.Context(sc)
+    sc = pa.Scene(os.path.join(ROOT, "scenes", request.param[0]))
+    ctx = make_ctx(sc, request.param[1])
     yield sc, ctx
     ctx.close()
 
@@ -91,6 +111,40 @@ def test_closest_hit_matches_reference_traversal(pair):
     # any-hit with finite segments
     r2["tmax"] = rng.uniform(0.5, 600.0, len(o)).astype(np.float32)
     assert np.array_equal(ctx.intersect_p(r2), ol.intersect_p(sc, r2)[0])
+    # rays with exactly-zero direction components (1/d = +-inf in Bounds3::IntersectP; Sobol' values like 0.5 produce them on
+    # axis-aligned surfaces) incl. -0 and origins that sit exactly on bounding planes (vertex coordinates of the scene)
+    n3 = 6000
+    r3 = np.zeros(n3, dtype=pa.RAY_DTYPE)
+    d3 = rng.standard_normal((n3, 3)).astype(np.float32)
+    kill = rng.integers(0, 3, n3)
+    d3[np.arange(n3), kill] = np.where(rng.random(n3) < 0.5, np.float32(0.0), np.float32(-0.0))
+    two = rng.random(n3) < 0.3   # a third of them: two zero components (axis-parallel rays)
+    d3[np.arange(n3)[two], (kill[two] + 1) % 3] = 0
+    d3 /= np.linalg.norm(d3, axis=1)[:, None]
+    o3 = o[rng.integers(0, len(o), n3)].copy()
+    r3["o"] = o3; r3["d"] = d3; r3["tmax"] = np.inf
+    dh3 = ctx.intersect(r3)
+    rh3, _ = ol.intersect(sc, r3)
+    assert np.array_equal(dh3["prim"], rh3["prim"]), int((dh3["prim"] != rh3["prim"]).sum())
+    h3 = rh3["prim"] >= 0
+    assert h3.sum() > 500
+    assert np.array_equal(dh3["t"][h3].view(np.uint32), rh3["t"][h3].view(np.uint32))
+    # the same directions from origins that lie exactly ON bounding planes (coordinates of hit points on the axis-aligned walls):
+    # there the reference's slab test evaluates 0 * inf = NaN, and a NaN on the x axis makes Bounds3::IntersectP REJECT the box
+    # (geometry.h:1412-1438: every comparison with the NaN tMin is false, the final tMin < ray.tMax too) although the ray runs
+    # inside its face -- the reference then misses triangles the device (whose box test skips a NaN axis: a superset) still
+    # finds.  Stated deviation: in this measure-zero configuration the device may report a hit where the
+    # reference reports none or a farther one; never the other way round.
+    src = rays["o"][hit] + rays["d"][hit] * rh["t"][hit][:, None]
+    r3["o"] = src[rng.integers(0, len(src), n3)]
+    dh4 = ctx.intersect(r3)
+    rh4, _ = ol.intersect(sc, r3)
+    differ = dh4["prim"] != rh4["prim"]
+    tdev = np.where(dh4["prim"] >= 0, dh4["t"], np.inf); tref = np.where(rh4["prim"] >= 0, rh4["t"], np.inf)
+    assert np.all(tdev[differ] <= tref[differ]), "device missed a hit the reference finds"
+    assert differ.mean() < 0.05, float(differ.mean())
+    same = ~differ & (rh4["prim"] >= 0)
+    assert np.array_equal(dh4["t"][same].view(np.uint32), rh4["t"][same].view(np.uint32))
 
 
 def test_li_per_sample(pair):
@@ -177,14 +231,15 @@ def test_device_sphere_intersect_matches_reference_vectors():
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
                                                     ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
                                                     ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")])
-def test_render_vs_reference_fixture(name, w, h, spp, strategy):
+@pytest.mark.parametrize("mode", list(TRACE_MODES))
+def test_render_vs_reference_fixture(name, w, h, spp, strategy, mode):
     """GPU image vs the REAL reference's render (tests/golden/*.pfm).  Stated tolerance: per-pixel L2 <= 1e-3 (1 + |ref|)
     for >= 99.5 % of the pixels and relMSE <= 1e-4; at 1 spp each pixel is one camera sample's radiance."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tools", "gen_golden.py"))
     gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
     sc = pa.Scene(text=gg.scene_text(name, w, h, spp, strategy))
-    ctx = pa.Context(sc)
+    ctx = make_ctx(sc, mode)
     ctx.render()
     img = sc.film_image(ctx.film())
     ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else "")))
@@ -209,11 +264,13 @@ def _config_scene(name, tmp):
     return pa.Scene(out)
 
 
-@pytest.mark.parametrize("name", ["killeroo", "sanmiguel", "bathroom"])
-def test_baseline_configs_reduced(name, tmp_path):
-    """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion."""
+@pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "fast"), ("sanmiguel", "general"), ("sanmiguel", "bvh8"),
+                                       ("bathroom", "fast"), ("bathroom", "general"), ("bathroom", "bvh8")])
+def test_baseline_configs_reduced(name, mode, tmp_path):
+    """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
+    (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
     sc = _config_scene(name, str(tmp_path))
-    ctx = pa.Context(sc)
+    ctx = make_ctx(sc, mode)
     ctx.render(count_work=True)
     img = sc.film_image(ctx.film())
     cnt = ctx.counters()
@@ -286,7 +343,7 @@ def test_many_lights(strategy):
 import edge_scenes
 
 
-@pytest.mark.parametrize("name", edge_scenes.NAMES)
+@pytest.mark.parametrize("name", edge_scenes.NAMES + edge_scenes.TEX_ORACLE_ONLY + ["instances2"])
 def test_edge_cases_vs_reference_fixture(name):
     sc = pa.Scene(text=edge_scenes.scene(name))
     ctx = pa.Context(sc)
@@ -303,6 +360,26 @@ def test_edge_cases_vs_reference_fixture(name):
         ctx.render(spp_begin=1, spp_end=sc.info["spp"])
         img2 = sc.film_image(ctx.film())
         assert np.allclose(img2, img, rtol=1e-5, atol=1e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", edge_scenes.INSTANCE_NAMES)
+def test_two_level_instancing_vs_reference_fixture(name, monkeypatch):
+    """Row f3 on the device: with PBRT_AMD_INSTANCING=1 the host hands over the reference's own structure (one BVH per object,
+    TransformedPrimitive leaves) and k_trace / k_shade <..., INST> traverse it -- ray into the object's space with the reference's
+    error-bounded origin (core/primitive.cpp:76-111, transform.h:252-264), interaction transformed back.  The oracle reproduces the
+    reference's render bit for bit in this mode; first GPU run (round 2): every pixel within tolerance, relMSE 1e-16...1e-17,
+    99.6-99.9 % of the pixels bit-identical."""
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "1")
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    assert sc.info.get("n_instances", 1) > 0
+    ctx = pa.Context(sc)
+    ctx.render()
+    img = sc.film_image(ctx.film())
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.999 and relmse <= 1e-8, (name, frac, relmse)
+    assert float(np.mean(np.abs(img - ref).max(-1) == 0)) >= 0.98
     ctx.close()
 
 
