@@ -138,7 +138,7 @@ def traffic_save(workload, t):
     json.dump(doc, open(TRAFFIC_FILE, "w"), indent=1, sort_keys=True)
 
 
-def cpu_reference(sc, scene_file, ncores, seconds, film_full, ol):
+def cpu_reference(sc, scene_file, ncores, seconds, ol):
     """pbrt_ref --nthreads <usable> --cropwindow <centre window> on the bench scene; None when the binary is not there."""
     import re, tempfile
     ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
@@ -173,17 +173,22 @@ def cpu_reference(sc, scene_file, ncores, seconds, film_full, ol):
            "sample": "oracle/_ref/pbrt_ref (pbrt-v3 built from the unmodified reference sources) --nthreads %d --cropwindow %.4f %.4f %.4f %.4f on the bench scene, "
                      "all %d spp: %d camera samples, Integrator::Render tile loop %.1f s (whole process incl. parse + BVH build %.0f s); "
                      "%d hardware threads visible, %d usable (affinity / cgroup quota)" % (ncores, x0, x1, y0, y1, spp, cam, secs, wall, os.cpu_count() or 1, ncores)}
-    try:   # parity of the SAME pixels: the GPU's full-spp frame against the reference's crop (stated tolerance of the parity tests)
+    # parity against the reference itself at full size: the SAME crop rendered on the GPU (the crop window moves the sampler's
+    # sample bounds -- sobol.cpp:65-70 builds the sampler over film->GetSampleBounds() -- so the window has to be part of the
+    # scene on both sides; pixels of the uncropped frame carry different Sobol' points)
+    try:
         pa = importlib.import_module("pbrt-v3-distributed_amd")
         ci = pa.read_pfm(out)
-        f32 = np.float32   # Film::Film (core/film.cpp:52-58): ceil(fullResolution * cropWindow) in Float arithmetic; the window as the CLI parsed it (atof -> Float)
-        cw = [f32(float("%.6f" % v)) for v in (x0, x1, y0, y1)]
-        px0, px1 = int(np.ceil(f32(W) * cw[0])), int(np.ceil(f32(W) * cw[1]))
-        py0, py1 = int(np.ceil(f32(H) * cw[2])), int(np.ceil(f32(H) * cw[3]))
-        gi = film_full[py0:py1, px0:px1]
+        cw = [float("%.6f" % v) for v in (x0, x1, y0, y1)]
+        sc2 = pa.Scene(scene_file, cropwindow=cw)
+        ctx2 = pa.Context(sc2, device=0)
+        ctx2.render()
+        gi = sc2.film_image(ctx2.film())
+        ctx2.close(); sc2.close()
         if gi.shape == ci.shape:
             f, relmse = ol.image_metrics(gi, ci)
-            cpu["parity_crop"] = {"against": "pbrt_ref", "pixels": int(gi.shape[0] * gi.shape[1]), "spp": spp, "pixels_within_tol": round(f, 5), "relMSE": relmse}
+            cpu["parity_crop"] = {"against": "pbrt_ref", "pixels": int(gi.shape[0] * gi.shape[1]), "spp": spp, "pixels_within_tol": round(f, 5), "relMSE": relmse,
+                                  "criterion": "per-pixel L2 <= 1e-3 (1 + |ref|) for >= 99.5 % of the pixels, relMSE <= 1e-4"}
         else:
             cpu["parity_crop"] = {"error": "crop shapes differ: %s vs %s" % (gi.shape, ci.shape)}
     except Exception as e:
@@ -395,6 +400,8 @@ def main():
         elapsed = float(tt.item())
     timing = ctx.timing()
     cnt = ctx.counters()
+    if cnt.get("trace_guard_trips", 0):
+        raise SystemExit("bench.py: %d traversal waves hit the non-termination guard -- the frame is invalid" % cnt["trace_guard_trips"])
     ctx.timing_enable(False)
 
     # whole-job unit counts (all ranks)
@@ -414,7 +421,8 @@ def main():
         # served by the XCD L2s) is reported beside it as l2_served_GBps -- it exceeds the HBM peak and bounds nothing.
         n_launch = max(1, timing["closest"][1])
         ext_rays = work["closest_rays"] - work["mis_rays"]
-        alg_bytes = ext_rays * RAY_BYTES + work["nodes_closest"] * NODE_BYTES + work["tris_closest"] * TRI_BYTES   # per step
+        tinfo = ctx.trace_info()
+        alg_bytes = ext_rays * RAY_BYTES + work["nodes_closest"] * tinfo["node_bytes"] + work["tris_closest"] * TRI_BYTES   # per step
         t_closest_ms = timing["closest"][0] / args.steps                                                           # per step
         launches_per_step = n_launch / args.steps
         avg_launch_ms = t_closest_ms / max(1.0, launches_per_step)
@@ -438,7 +446,8 @@ def main():
                     "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                     "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
                     "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step), "l2_served_GBps": round(alg_rate, 1),
-                    "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays)}
+                    "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays),
+                    "layout": "%s: %d nodes x %d B" % (tinfo["name"], tinfo["nodes"], tinfo["node_bytes"])}
         if traffic:
             roofline["achieved"] = round(traffic["bytes_per_launch"] / (avg_launch_ms * 1e-3) * 1e-9, 1)
             roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
@@ -459,8 +468,7 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             import oracle_lib as ol
             ncores = host_cpus()
-            film_full = sc.film_image(ctx.film())   # the last timed step's frame (all spp)
-            cpu = cpu_reference(sc, scene_file, ncores, args.cpu_seconds, film_full, ol)
+            cpu = cpu_reference(sc, scene_file, ncores, args.cpu_seconds, ol)
             port = cpu_port(sc, ctx, ncores, args.cpu_port_seconds if cpu else max(args.cpu_port_seconds, args.cpu_seconds), ol) \
                 if (args.cpu_port_seconds > 0 or cpu is None) else None
             if cpu is None:

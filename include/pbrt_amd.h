@@ -439,7 +439,11 @@ int mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 /* SamplerIntegrator::Render (integrator.cpp:228-339) over the 16x16 tiles owned by `rank` of
  * `world` (tile t -> rank t % world; integrator.cpp:235-240 gives the tile grid), samples
  * [spp_begin, spp_end) of every owned pixel, accumulated into the device film
- * (FilmTile::AddSample semantics, film.h:121-161).  Asynchronous on the ctx stream. */
+ * (FilmTile::AddSample semantics, film.h:121-161).  Asynchronous on the ctx stream: the call returns when the launches are
+ * queued (contexts on different GPUs render concurrently when driven from one host thread); mi_sync / mi_film_download wait.
+ * Two exceptions block inside the call: the first frame after mi_scene_upload or a change of (rank, world) allocates the
+ * path state / tile list, and scenes with null-material surfaces (medium interfaces, which do not count as bounces,
+ * path.cpp:107-111) read one queue counter back per pass to know when the last path has ended. */
 typedef struct mi_render_params {
     int32_t rank, world;
     int32_t spp_begin, spp_end; /* spp_end = -1 -> integrator.spp */
@@ -459,6 +463,18 @@ void *mi_film_device_ptr(mi_ctx *ctx); /* float4 per cropped pixel, for RCCL by 
  * NULL switches back to the library's own film. */
 int mi_film_bind(mi_ctx *ctx, void *device_float4_buffer);
 int64_t mi_film_pixel_count(mi_ctx *ctx);
+/* The exchange step of the tile-sharded render (replaces Film::MergeFilmTile, film.cpp:117-130, across GPUs):
+ * sums the films of the n contexts (one per GPU, same scene, rendered with rank = i, world = n) into ctxs[root]'s film with
+ * ONE grouped ncclReduce(sum, fp32) over xGMI -- RCCL, loaded at first use (librccl.so), one communicator per device set,
+ * cached.  Owned tiles are disjoint, so the sum equals a gather and is exact; with a filter wider than the box the
+ * overlapping border samples add in ring order (last-ulp differences between runs, as documented there).
+ * Waits for the renders of all contexts first and returns when the root film is complete.  n == 1 is a no-op; contexts that
+ * share a device (testing on a one-GPU box) are summed by a device kernel instead, since RCCL refuses duplicate devices. */
+int mi_film_gather(mi_ctx **ctxs, int n, int root);
+/* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
+ * 3 lean steps over the 80-byte compressed BVH8 (default for plain all-triangle scenes), 4 two-level (instanced) scene;
+ * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */
+int mi_trace_info(mi_ctx *ctx, int64_t out[4]);
 
 /* Work counters (names follow the reference's STAT_COUNTERs: integrator.cpp:48,
  * scene.cpp:40-42, triangle.cpp:45) */
@@ -474,6 +490,7 @@ enum mi_counter {
     MI_CNT_MIS_RAYS = 8,     /* the part of CLOSEST_RAYS traced by the MIS launches (integrator.cpp:202) */
     MI_CNT_NODES_MIS = 9,
     MI_CNT_TRIS_MIS = 10,
+    MI_CNT_TRACE_GUARD_TRIPS = 15, /* waves that hit the non-termination guard of the traversal kernels: must stay 0 */
     MI_CNT_COUNT = 16
 };
 int mi_counters(mi_ctx *ctx, uint64_t out[MI_CNT_COUNT]);
@@ -529,6 +546,8 @@ int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded
  * stats: [0] BVH8 nodes, [1] leaf references, [2] depth, [3] deepest stack seen, [4] primitives covered, [5] nodes visited,
  * [6] primitives tested, [7] rays that hit.  No GPU needed. */
 int mi_bvh8_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
+/* the same checks + host emulation for the 80-byte compressed 8-wide layout the traversal kernels use (csrc/pt_bvh8c.h) */
+int mi_bvh8c_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
 /* Sphere::Intersect (shapes/sphere.cpp:48-162) of ray i against spheres[i] (explicit records, no scene): hit flag, tHit and the
  * world-space interaction's p, pError, n -- for the FullSphere / PartialSphere reintersection vectors of the reference's tests */
 typedef struct mi_sphere_hit { int32_t hit; float t; float p[3], p_error[3], n[3]; } mi_sphere_hit;

@@ -1,0 +1,439 @@
+// Reference-side binding of the MI355X path tracer, COMPILED AGAINST THE UNMODIFIED REFERENCE (libpbrt_ref.a):
+// the `WavefrontPathIntegrator : public Integrator` of INTEGRATION.md s.2 with a real FlattenScene, i.e. the code a pbrt-v3
+// maintainer adds to hand an already built `Scene` to include/pbrt_amd.h.  Test infrastructure (it lives under oracle/): the
+// CPU suite parses scenes with the REFERENCE's parser / API / BVH build, flattens the reference's own objects to a
+// mi_scene_desc here and renders that description with the backend named by PBRT_AMD_BACKEND --
+//     oracle (default)  liboracle.so's oracle_render: runs on the CPU box; the image must equal pbrt_ref's own render
+//     device            libpbrt_amd.so through mi_ctx_create / mi_scene_upload / mi_render / mi_film_download (GPU box)
+// -- which proves the hand-over table of INTEGRATION.md s.1 instead of describing it.
+//
+// How it gets called without touching the reference: RenderOptions::MakeIntegrator (core/api.cpp:1666-1718) instantiates
+// integrators by name through `Create<X>Integrator(params, sampler, camera)`.  This file DEFINES pbrt::CreatePathIntegrator
+// and is linked in front of libpbrt_ref.a, so `Integrator "path"` resolves to the stub (integrators/path.o, whose only
+// symbol api.o needs is that factory, is simply not pulled from the archive).  A maintainer would instead add one
+// `else if (IntegratorName == "wavefrontpath")` line to api.cpp:1681-1701.
+//
+// Access to private members: the hand-over needs BVHAccel::nodes / primitives, GeometricPrimitive's members, Triangle::mesh,
+// the cameras' matrices, the BxDFs' parameters ...  INTEGRATION.md lists the `friend class WavefrontPathIntegrator;` lines a
+// maintainer adds; this translation unit gets the same access by including the reference's headers with `private` /
+// `protected` spelled `public` (the standard headers are included first, untouched; object layout does not depend on access
+// labels with this compiler).  No reference source is modified or copied.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <functional>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#define private public
+#define protected public
+#include "pbrt.h"
+#include "accelerators/bvh.h"
+#include "api.h"
+#include "camera.h"
+#include "cameras/perspective.h"
+#include "film.h"
+#include "filter.h"
+#include "integrator.h"
+#include "interaction.h"
+#include "light.h"
+#include "lights/diffuse.h"
+#include "lights/distant.h"
+#include "lights/infinite.h"
+#include "lights/point.h"
+#include "lights/spot.h"
+#include "material.h"
+#include "memory.h"
+#include "microfacet.h"
+#include "paramset.h"
+#include "primitive.h"
+#include "reflection.h"
+#include "sampler.h"
+#include "samplers/halton.h"
+#include "samplers/sobol.h"
+#include "scene.h"
+#include "shapes/sphere.h"
+#include "shapes/triangle.h"
+#include "integrators/path.h"
+#undef private
+#undef protected
+
+#include "pbrt_amd.h"
+
+namespace pbrt {
+
+// LinearBVHNode is private to accelerators/bvh.cpp (:95-104); mi_bvh2_node is the same 32-byte record
+static_assert(sizeof(mi_bvh2_node) == 32, "LinearBVHNode layout");
+
+namespace {
+struct Flat {
+    mi_scene_desc desc;
+    std::vector<float> P, N, UV;
+    std::vector<uint32_t> triIndices, triMesh;
+    std::vector<int32_t> triLight;
+    std::vector<mi_mesh> meshes;
+    std::vector<mi_material> materials;
+    std::vector<mi_light> lights;
+    std::vector<mi_sphere> spheres;
+    std::vector<float> lightFunc, lightCdf;
+    std::string error;
+};
+
+void copyM(float dst[16], const Matrix4x4 &m) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) dst[4 * r + c] = m.m[r][c]; }
+void rgb3(float d[3], const Spectrum &s) { Float c[3]; s.ToRGB(c); d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
+
+// one BxDF object of the reference -> the POD the library evaluates (include/pbrt_amd.h mi_bxdf)
+bool convertBxDF(const BxDF *b, mi_bxdf *out, std::string *err) {
+    std::memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 3; ++i) out->scale[i] = 1;
+    auto distrib = [&](const MicrofacetDistribution *d) -> bool {
+        if (auto tr = dynamic_cast<const TrowbridgeReitzDistribution *>(d)) { out->distrib = 0; out->alphax = tr->alphax; out->alphay = tr->alphay; return true; }
+        if (auto bk = dynamic_cast<const BeckmannDistribution *>(d)) { out->distrib = 1; out->alphax = bk->alphax; out->alphay = bk->alphay; return true; }
+        *err = "unknown MicrofacetDistribution";
+        return false;
+    };
+    auto fresnel = [&](const Fresnel *f) -> bool {
+        if (auto fd = dynamic_cast<const FresnelDielectric *>(f)) { out->fresnel = MI_FRESNEL_DIELECTRIC; out->etaA = fd->etaI; out->etaB = fd->etaT; return true; }
+        if (auto fc = dynamic_cast<const FresnelConductor *>(f)) {
+            out->fresnel = MI_FRESNEL_CONDUCTOR;
+            rgb3(out->eta_c, fc->etaT); rgb3(out->k_c, fc->k);
+            Float ei[3]; fc->etaI.ToRGB(ei);
+            if (ei[0] != 1 || ei[1] != 1 || ei[2] != 1) { *err = "FresnelConductor with etaI != 1"; return false; }
+            return true;
+        }
+        if (dynamic_cast<const FresnelNoOp *>(f)) { out->fresnel = MI_FRESNEL_NOOP; return true; }
+        *err = "unknown Fresnel";
+        return false;
+    };
+    if (auto s = dynamic_cast<const ScaledBxDF *>(b)) {   // mixmat.cpp:57-63
+        if (!convertBxDF(s->bxdf, out, err)) return false;
+        float sc[3];
+        rgb3(sc, s->scale);
+        if (out->scaled) for (int i = 0; i < 3; ++i) out->scale[i] = sc[i] * out->scale[i];
+        else { out->scaled = 1; for (int i = 0; i < 3; ++i) out->scale[i] = sc[i]; }
+        return true;
+    }
+    if (auto l = dynamic_cast<const LambertianReflection *>(b)) { out->type = MI_BXDF_LAMBERT_R; rgb3(out->R, l->R); return true; }
+    if (auto l = dynamic_cast<const LambertianTransmission *>(b)) { out->type = MI_BXDF_LAMBERT_T; rgb3(out->T, l->T); return true; }
+    if (auto o = dynamic_cast<const OrenNayar *>(b)) { out->type = MI_BXDF_OREN_NAYAR; rgb3(out->R, o->R); out->A = o->A; out->B = o->B; return true; }
+    if (auto s = dynamic_cast<const SpecularReflection *>(b)) { out->type = MI_BXDF_SPECULAR_R; rgb3(out->R, s->R); return fresnel(s->fresnel); }
+    if (auto s = dynamic_cast<const SpecularTransmission *>(b)) {
+        out->type = MI_BXDF_SPECULAR_T; rgb3(out->T, s->T); out->etaA = s->etaA; out->etaB = s->etaB; out->fresnel = MI_FRESNEL_DIELECTRIC;
+        return true;
+    }
+    if (auto s = dynamic_cast<const FresnelSpecular *>(b)) { out->type = MI_BXDF_FRESNEL_SPEC; rgb3(out->R, s->R); rgb3(out->T, s->T); out->etaA = s->etaA; out->etaB = s->etaB; return true; }
+    if (auto m = dynamic_cast<const MicrofacetReflection *>(b)) { out->type = MI_BXDF_MICROFACET_R; rgb3(out->R, m->R); return distrib(m->distribution) && fresnel(m->fresnel); }
+    if (auto m = dynamic_cast<const MicrofacetTransmission *>(b)) {
+        out->type = MI_BXDF_MICROFACET_T; rgb3(out->T, m->T); out->etaA = m->etaA; out->etaB = m->etaB; out->fresnel = MI_FRESNEL_DIELECTRIC;
+        return distrib(m->distribution);
+    }
+    if (auto f = dynamic_cast<const FresnelBlend *>(b)) { out->type = MI_BXDF_FRESNEL_BLEND; rgb3(out->R, f->Rd); rgb3(out->T, f->Rs); return distrib(f->distribution); }
+    *err = "BxDF class without a device counterpart: " + b->ToString();
+    return false;
+}
+
+// the lobe list Material::ComputeScatteringFunctions builds (materials/*.cpp) -- constant textures: independent of the interaction
+bool convertMaterial(const Material *m, mi_material *out, std::string *err) {
+    std::memset(out, 0, sizeof(*out));
+    out->eta = 1;
+    MemoryArena arena;
+    SurfaceInteraction si(Point3f(0, 0, 0), Vector3f(0, 0, 0), Point2f(0.5f, 0.5f), Vector3f(0, 0, 1), Vector3f(1, 0, 0), Vector3f(0, 1, 0),
+                          Normal3f(0, 0, 0), Normal3f(0, 0, 0), 0, nullptr);
+    m->ComputeScatteringFunctions(&si, arena, TransportMode::Radiance, true);
+    if (!si.bsdf) { *err = "material without a BSDF"; return false; }
+    if (si.bssrdf) { *err = "material with a BSSRDF (not handed over by this stub)"; return false; }
+    out->eta = si.bsdf->eta;
+    out->n_bxdfs = si.bsdf->nBxDFs;
+    for (int i = 0; i < si.bsdf->nBxDFs; ++i)
+        if (!convertBxDF(si.bsdf->bxdfs[i], &out->bxdfs[i], err)) return false;
+    return true;
+}
+
+uint32_t countNodes(const mi_bvh2_node *n) {   // the flattened array's length is not stored (bvh.cpp:222-229): walk it
+    uint32_t maxIdx = 0;
+    std::vector<uint32_t> todo{0};
+    while (!todo.empty()) {
+        uint32_t i = todo.back(); todo.pop_back();
+        maxIdx = std::max(maxIdx, i);
+        if (n[i].n_prims == 0) { todo.push_back(i + 1); todo.push_back((uint32_t)n[i].offset); }
+    }
+    return maxIdx + 1;
+}
+
+std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sampler &sampler, int maxDepth, Float rrThreshold, const Bounds2i &pixelBounds,
+                                   const std::string &lightStrategy) {
+    std::unique_ptr<Flat> fs(new Flat);
+    auto fail = [&](const std::string &m) { fs->error = m; return std::move(fs); };
+    const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene.aggregate.get());
+    if (!bvh) return fail("the aggregate is not a BVHAccel");
+    // --- primitives in BVHAccel::primitives order (bvh.cpp:205)
+    std::map<const TriangleMesh *, uint32_t> meshIndex;
+    std::map<const Material *, int32_t> materialIndex;
+    std::map<const AreaLight *, int32_t> lightOfAreaLight;
+    for (size_t i = 0; i < scene.lights.size(); ++i)
+        if (auto al = dynamic_cast<const AreaLight *>(scene.lights[i].get())) lightOfAreaLight[al] = (int32_t)i;
+    std::vector<uint32_t> meshVertexBase;
+    // Every GeometricPrimitive carries its own material pointer while vertices are per mesh: a mi_mesh entry = (TriangleMesh, material)
+    std::map<std::pair<const void *, const Material *>, uint32_t> meshEntry;
+    std::map<const TriangleMesh *, uint32_t> vertexBase;
+    size_t nPrims = bvh->primitives.size();
+    fs->triIndices.resize(3 * nPrims); fs->triMesh.resize(nPrims); fs->triLight.assign(nPrims, -1);
+    std::vector<int32_t> lightTri(scene.lights.size(), -1), lightSphere(scene.lights.size(), -1);
+    for (size_t k = 0; k < nPrims; ++k) {
+        const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(bvh->primitives[k].get());
+        if (!gp) return fail("a primitive is not a GeometricPrimitive (instancing: flatten or refuse, INTEGRATION.md s.1)");
+        int32_t mat = -1;
+        if (gp->material) {
+            auto it = materialIndex.find(gp->material.get());
+            if (it == materialIndex.end()) {
+                mi_material mm;
+                std::string err;
+                if (!convertMaterial(gp->material.get(), &mm, &err)) return fail(err);
+                it = materialIndex.emplace(gp->material.get(), (int32_t)fs->materials.size()).first;
+                fs->materials.push_back(mm);
+            }
+            mat = it->second;
+        }
+        int32_t light = -1;
+        if (gp->areaLight) {
+            auto it = lightOfAreaLight.find(gp->areaLight.get());
+            if (it == lightOfAreaLight.end()) return fail("area light not in scene.lights");
+            light = it->second;
+        }
+        fs->triLight[k] = light;
+        if (const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.get())) {
+            const TriangleMesh *mesh = tri->mesh.get();
+            if (mesh->alphaMask || mesh->shadowAlphaMask) return fail("alpha-masked mesh (texture tables are not handed over by this stub)");
+            if (!vertexBase.count(mesh)) {
+                vertexBase[mesh] = (uint32_t)(fs->P.size() / 3);
+                for (int v = 0; v < mesh->nVertices; ++v) {
+                    fs->P.push_back(mesh->p[v].x); fs->P.push_back(mesh->p[v].y); fs->P.push_back(mesh->p[v].z);
+                    if (mesh->n) { fs->N.push_back(mesh->n[v].x); fs->N.push_back(mesh->n[v].y); fs->N.push_back(mesh->n[v].z); }
+                    else { fs->N.push_back(0); fs->N.push_back(0); fs->N.push_back(0); }
+                    if (mesh->uv) { fs->UV.push_back(mesh->uv[v].x); fs->UV.push_back(mesh->uv[v].y); }
+                    else { fs->UV.push_back(0); fs->UV.push_back(0); }
+                }
+            }
+            auto key = std::make_pair((const void *)mesh, (const Material *)gp->material.get());
+            auto me = meshEntry.find(key);
+            if (me == meshEntry.end()) {
+                mi_mesh mm;
+                mm.flags = (mesh->n ? MI_MESH_HAS_N : 0u) | (mesh->uv ? MI_MESH_HAS_UV : 0u) | (mesh->s ? MI_MESH_HAS_S : 0u) |
+                           ((tri->reverseOrientation ^ tri->transformSwapsHandedness) ? MI_MESH_FLIP : 0u);
+                mm.material = mat;
+                me = meshEntry.emplace(key, (uint32_t)fs->meshes.size()).first;
+                fs->meshes.push_back(mm);
+            }
+            fs->triMesh[k] = me->second;
+            uint32_t vb = vertexBase[mesh];
+            for (int c = 0; c < 3; ++c) fs->triIndices[3 * k + c] = vb + (uint32_t)tri->v[c];
+            if (light >= 0) lightTri[light] = (int32_t)k;
+        } else if (const Sphere *sp = dynamic_cast<const Sphere *>(gp->shape.get())) {
+            mi_sphere ms;
+            std::memset(&ms, 0, sizeof(ms));
+            copyM(ms.o2w, sp->ObjectToWorld->GetMatrix()); copyM(ms.w2o, sp->WorldToObject->GetMatrix());
+            ms.radius = sp->radius; ms.zmin = sp->zMin; ms.zmax = sp->zMax; ms.theta_min = sp->thetaMin; ms.theta_max = sp->thetaMax; ms.phi_max = sp->phiMax;
+            ms.flags = (sp->reverseOrientation ? 1u : 0u) | (sp->transformSwapsHandedness ? 2u : 0u);
+            ms.area = sp->Area();
+            mi_mesh mm;
+            mm.flags = (sp->reverseOrientation ^ sp->transformSwapsHandedness) ? MI_MESH_FLIP : 0u;
+            mm.material = mat;
+            fs->triMesh[k] = (uint32_t)fs->meshes.size();
+            fs->meshes.push_back(mm);
+            fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
+            if (light >= 0) { lightTri[light] = (int32_t)k; lightSphere[light] = (int32_t)fs->spheres.size(); }
+            fs->spheres.push_back(ms);
+        } else
+            return fail("a shape that is neither a Triangle nor a Sphere has no device counterpart");
+    }
+    // --- lights in scene.lights order
+    Point3f worldCenter;
+    Float worldRadius;
+    scene.WorldBound().BoundingSphere(&worldCenter, &worldRadius);
+    std::vector<Float> power;
+    for (size_t i = 0; i < scene.lights.size(); ++i) {
+        const Light *L = scene.lights[i].get();
+        mi_light l;
+        std::memset(&l, 0, sizeof(l));
+        l.world_radius = worldRadius;
+        l.world_center[0] = worldCenter.x; l.world_center[1] = worldCenter.y; l.world_center[2] = worldCenter.z;
+        if (auto dl = dynamic_cast<const DiffuseAreaLight *>(L)) {
+            if (lightTri[i] < 0) return fail("area light without a primitive in the BVH");
+            l.type = lightSphere[i] >= 0 ? MI_LIGHT_AREA_SPHERE : MI_LIGHT_AREA_TRI;
+            l.tri = lightTri[i]; l.sphere = std::max(0, lightSphere[i]);
+            l.two_sided = dl->twoSided ? 1 : 0;
+            rgb3(l.L, dl->Lemit);
+            l.area = dl->area;
+        } else if (auto pl = dynamic_cast<const PointLight *>(L)) {
+            l.type = MI_LIGHT_POINT; rgb3(l.L, pl->I); l.pos[0] = pl->pLight.x; l.pos[1] = pl->pLight.y; l.pos[2] = pl->pLight.z;
+        } else if (auto dd = dynamic_cast<const DistantLight *>(L)) {
+            l.type = MI_LIGHT_DISTANT; rgb3(l.L, dd->L); l.pos[0] = dd->wLight.x; l.pos[1] = dd->wLight.y; l.pos[2] = dd->wLight.z;
+        } else
+            return fail("light class not handed over by this stub (spot / infinite lights: as the table of INTEGRATION.md s.1 describes)");
+        power.push_back(L->Power().y());
+        fs->lights.push_back(l);
+    }
+    // --- Distribution1D of CreateLightSampleDistribution (lightdistrib.cpp:48-84; sampling.h:55-70)
+    size_t nl = fs->lights.size();
+    bool spatial = lightStrategy == "spatial" && nl > 1, uniform = lightStrategy == "uniform" || nl == 1;
+    fs->lightFunc.resize(nl); fs->lightCdf.resize(nl + 1);
+    for (size_t i = 0; i < nl; ++i) fs->lightFunc[i] = uniform ? Float(1) : power[i];
+    Float funcInt = 0;
+    if (nl) {
+        int n = (int)nl;
+        fs->lightCdf[0] = 0;
+        for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] = fs->lightCdf[i - 1] + fs->lightFunc[i - 1] / n;
+        funcInt = fs->lightCdf[n];
+        if (funcInt == 0) for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] = Float(i) / Float(n);
+        else for (int i = 1; i < n + 1; ++i) fs->lightCdf[i] /= funcInt;
+    }
+    // --- desc
+    mi_scene_desc &d = fs->desc;
+    std::memset(&d, 0, sizeof(d));
+    d.abi_version = MI_ABI_VERSION;
+    d.n_verts = (uint32_t)(fs->P.size() / 3); d.P = fs->P.data(); d.N = fs->N.data(); d.UV = fs->UV.data();
+    d.n_tris = (uint32_t)nPrims; d.tri_indices = fs->triIndices.data(); d.tri_mesh = fs->triMesh.data(); d.tri_light = fs->triLight.data();
+    d.n_meshes = (uint32_t)fs->meshes.size(); d.meshes = fs->meshes.data();
+    d.bvh_nodes = reinterpret_cast<const mi_bvh2_node *>(bvh->nodes);   // BVHAccel::nodes as it is
+    d.n_bvh_nodes = bvh->nodes ? countNodes(d.bvh_nodes) : 0;
+    d.n_top_prims = d.n_tris;
+    d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
+    d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
+    d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
+    d.n_spheres = (uint32_t)fs->spheres.size(); d.spheres = fs->spheres.empty() ? nullptr : fs->spheres.data();
+    d.camera_medium = -1;
+    d.integrator_type = MI_INTEGRATOR_PATH;
+    d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
+    d.integrator.spatial_max_voxels = 64;
+    const PerspectiveCamera *pc = dynamic_cast<const PerspectiveCamera *>(&cam);
+    if (!pc) return fail("camera is not a PerspectiveCamera");
+    if (pc->CameraToWorld.actuallyAnimated) return fail("animated camera transforms are not carried by this path");
+    copyM(d.camera.raster_to_camera, pc->RasterToCamera.GetMatrix());
+    copyM(d.camera.camera_to_world, pc->CameraToWorld.startTransform->GetMatrix());
+    for (int i = 0; i < 3; ++i) { d.camera.dx_camera[i] = pc->dxCamera[i]; d.camera.dy_camera[i] = pc->dyCamera[i]; }
+    d.camera.lens_radius = pc->lensRadius; d.camera.focal_distance = pc->focalDistance;
+    d.camera.shutter_open = pc->shutterOpen; d.camera.shutter_close = pc->shutterClose;
+    const Film &film = *cam.film;
+    Bounds2i sb = film.GetSampleBounds();
+    for (int i = 0; i < 2; ++i) {
+        d.film.full_res[i] = film.fullResolution[i];
+        d.film.crop_min[i] = film.croppedPixelBounds.pMin[i]; d.film.crop_max[i] = film.croppedPixelBounds.pMax[i];
+        d.film.sample_min[i] = sb.pMin[i]; d.film.sample_max[i] = sb.pMax[i];
+        d.integrator.pixel_min[i] = pixelBounds.pMin[i]; d.integrator.pixel_max[i] = pixelBounds.pMax[i];
+    }
+    d.film.filter_radius[0] = film.filter->radius.x; d.film.filter_radius[1] = film.filter->radius.y;
+    static_assert(sizeof(film.filterTable) == sizeof(d.film.filter_table), "filter table");
+    std::memcpy(d.film.filter_table, film.filterTable, sizeof(d.film.filter_table));
+    d.film.max_sample_luminance = film.maxSampleLuminance;
+    d.film.scale = film.scale;
+    d.integrator.max_depth = maxDepth; d.integrator.rr_threshold = rrThreshold;
+    d.integrator.spp = (int32_t)sampler.samplesPerPixel;
+    if (auto ss = dynamic_cast<SobolSampler *>(&sampler)) {
+        d.integrator.sampler = MI_SAMPLER_SOBOL;
+        d.integrator.sobol_resolution = ss->resolution; d.integrator.sobol_log2_resolution = ss->log2Resolution;
+    } else if (auto hs = dynamic_cast<HaltonSampler *>(&sampler)) {
+        d.integrator.sampler = MI_SAMPLER_HALTON;
+        for (int i = 0; i < 2; ++i) {
+            d.integrator.halton_base_scales[i] = hs->baseScales[i]; d.integrator.halton_base_exponents[i] = hs->baseExponents[i];
+            d.integrator.halton_mult_inverse[i] = hs->multInverse[i];
+        }
+        d.integrator.halton_sample_stride = hs->sampleStride;
+        d.integrator.halton_sample_at_center = hs->sampleAtPixelCenter ? 1 : 0;
+    } else
+        return fail("sampler is neither sobol nor halton");
+    return fs;
+}
+}  // namespace
+
+class WavefrontPathIntegrator : public Integrator {   // core/integrator.h:53-58
+  public:
+    WavefrontPathIntegrator(int maxDepth, std::shared_ptr<const Camera> camera, std::shared_ptr<Sampler> sampler, const Bounds2i &pixelBounds,
+                            Float rrThreshold, const std::string &lightStrategy)
+        : maxDepth(maxDepth), camera(camera), sampler(sampler), pixelBounds(pixelBounds), rrThreshold(rrThreshold), lightStrategy(lightStrategy) {}
+    void Render(const Scene &scene);   // the one call site: core/api.cpp:1623
+
+  private:
+    const int maxDepth;
+    std::shared_ptr<const Camera> camera;
+    std::shared_ptr<Sampler> sampler;
+    const Bounds2i pixelBounds;
+    const Float rrThreshold;
+    const std::string lightStrategy;
+};
+
+void WavefrontPathIntegrator::Render(const Scene &scene) {
+    std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy);
+    if (!flat->error.empty()) { Error("WavefrontPathIntegrator: %s", flat->error.c_str()); return; }   // pbrt convention: report and return
+    Film *film = camera->film;
+    Bounds2i crop = film->croppedPixelBounds;
+    std::vector<float> rgbw(4 * (size_t)crop.Area());
+    const char *backend = std::getenv("PBRT_AMD_BACKEND");
+    const char *libPath = std::getenv("PBRT_AMD_BACKEND_LIB");
+    if (!libPath) { Error("WavefrontPathIntegrator: PBRT_AMD_BACKEND_LIB (liboracle.so or libpbrt_amd.so) is not set"); return; }
+    void *lib = dlopen(libPath, RTLD_NOW);
+    if (!lib) { Error("WavefrontPathIntegrator: %s", dlerror()); return; }
+    if (backend && !std::strcmp(backend, "device")) {   // the GPU path, exactly the calls of INTEGRATION.md s.2
+        auto ctx_create = (int (*)(int, void *, void **))dlsym(lib, "mi_ctx_create");
+        auto scene_upload = (int (*)(void *, const mi_scene_desc *))dlsym(lib, "mi_scene_upload");
+        auto render = (int (*)(void *, const mi_render_params *))dlsym(lib, "mi_render");
+        auto sync = (int (*)(void *))dlsym(lib, "mi_sync");
+        auto download = (int (*)(void *, float *))dlsym(lib, "mi_film_download");
+        auto last_error = (const char *(*)())dlsym(lib, "mi_last_error");
+        auto destroy = (void (*)(void *))dlsym(lib, "mi_ctx_destroy");
+        void *ctx = nullptr;
+        if (!ctx_create || ctx_create(0, nullptr, &ctx) || scene_upload(ctx, &flat->desc)) { Error("GPU path integrator: %s", last_error ? last_error() : "?"); return; }
+        mi_render_params rp = {0, 1, 0, -1, 0, 0};
+        if (render(ctx, &rp) || sync(ctx) || download(ctx, rgbw.data())) { Error("GPU path integrator: %s", last_error()); destroy(ctx); return; }
+        destroy(ctx);
+    } else {   // CPU box: the oracle renders the SAME description
+        auto oracle_render = (double (*)(const mi_scene_desc *, float *, int, int, int, uint64_t *, const int32_t *))dlsym(lib, "oracle_render");
+        if (!oracle_render) { Error("WavefrontPathIntegrator: oracle_render not found in %s", libPath); return; }
+        uint64_t counters[8] = {0};
+        oracle_render(&flat->desc, rgbw.data(), 0, -1, NumSystemCores(), counters, nullptr);
+    }
+    // FilmTilePixel{contribSum rgb, filterWeightSum} per cropped pixel (core/film.h:52-55) -> the reference's own Film
+    std::unique_ptr<FilmTile> tile = film->GetFilmTile(film->GetSampleBounds());   // one tile spanning the film
+    size_t k = 0;
+    for (Point2i p : crop) {   // row-major, the order of the device film
+        FilmTilePixel &px = tile->GetPixel(p);
+        Float rgb[3] = {rgbw[4 * k], rgbw[4 * k + 1], rgbw[4 * k + 2]};
+        px.contribSum = Spectrum::FromRGB(rgb);
+        px.filterWeightSum = rgbw[4 * k + 3];
+        ++k;
+    }
+    film->MergeFilmTile(std::move(tile));   // RGB -> XYZ, core/film.cpp:117-130
+    film->WriteImage();                     // core/film.cpp:168-210
+}
+
+// Same signature as integrators/path.cpp:190-213, which this definition stands in for (see the header comment): parameters read exactly as there.
+PathIntegrator *CreatePathIntegrator(const ParamSet &params, std::shared_ptr<Sampler> sampler, std::shared_ptr<const Camera> camera) {
+    int maxDepth = params.FindOneInt("maxdepth", 5);
+    int np;
+    const int *pb = params.FindInt("pixelbounds", &np);
+    Bounds2i pixelBounds = camera->film->GetSampleBounds();
+    if (pb) {
+        if (np != 4) Error("Expected four values for \"pixelbounds\" parameter. Got %d.", np);
+        else {
+            pixelBounds = Intersect(pixelBounds, Bounds2i{{pb[0], pb[2]}, {pb[1], pb[3]}});
+            if (pixelBounds.Area() == 0) Error("Degenerate \"pixelbounds\" specified.");
+        }
+    }
+    Float rrThreshold = params.FindOneFloat("rrthreshold", 1.);
+    std::string lightStrategy = params.FindOneString("lightsamplestrategy", "spatial");
+    // api.cpp keeps the result as an Integrator* and only ever calls the virtual Render on it
+    return reinterpret_cast<PathIntegrator *>(static_cast<Integrator *>(new WavefrontPathIntegrator(maxDepth, camera, sampler, pixelBounds, rrThreshold, lightStrategy)));
+}
+
+}  // namespace pbrt

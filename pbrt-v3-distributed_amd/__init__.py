@@ -21,7 +21,8 @@ DEVICE_LIB = os.environ.get("PBRT_AMD_DEVICE_LIB", os.path.join(LIB_DIR, "libpbr
 MI_CNT_COUNT = 16
 MI_K_COUNT = 8
 COUNTER_NAMES = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any",
-                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis"]
+                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis", "unused11", "unused12", "unused13", "unused14",
+                 "trace_guard_trips"]
 KERNEL_NAMES = ["raygen", "closest", "sort", "shade", "anyhit", "mis_closest", "film", "other"]
 
 
@@ -47,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_trace_info", "mi_film_gather", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -63,6 +64,8 @@ def host_lib():
         L = C.CDLL(HOST_LIB, mode=C.RTLD_GLOBAL)
         L.pbrt_amd_scene_load.restype = C.c_void_p
         L.pbrt_amd_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        L.pbrt_amd_scene_load_crop.restype = C.c_void_p
+        L.pbrt_amd_scene_load_crop.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_float)]
         L.pbrt_amd_scene_free.argtypes = [C.c_void_p]
         L.pbrt_amd_scene_desc.restype = C.c_void_p
         L.pbrt_amd_scene_desc.argtypes = [C.c_void_p]
@@ -103,6 +106,9 @@ def device_lib():
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_bvh8_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_bvh8c_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_trace_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi_film_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -127,11 +133,17 @@ class Scene:
                    "crop_x0", "crop_y0", "crop_x1", "crop_y1", "spp", "max_depth", "sobol_resolution",
                    "sobol_log2_resolution"]
 
-    def __init__(self, filename=None, text=None, quiet=True, outfile=None):
+    def __init__(self, filename=None, text=None, quiet=True, outfile=None, cropwindow=None):
+        """cropwindow = (x0, x1, y0, y1): the command line's --cropwindow (overrides the Film's own, as in the reference)"""
         L = host_lib()
         src = text if text is not None else filename
-        self._h = L.pbrt_amd_scene_load(src.encode(), 1 if text is not None else 0, 1 if quiet else 0,
-                                        outfile.encode() if outfile else None)
+        if cropwindow is not None:
+            cw = (C.c_float * 4)(*[float(v) for v in cropwindow])
+            self._h = L.pbrt_amd_scene_load_crop(src.encode(), 1 if text is not None else 0, 1 if quiet else 0,
+                                                 outfile.encode() if outfile else None, cw)
+        else:
+            self._h = L.pbrt_amd_scene_load(src.encode(), 1 if text is not None else 0, 1 if quiet else 0,
+                                            outfile.encode() if outfile else None)
         if not self._h:
             raise RuntimeError("scene load failed: %r" % (filename or "<text>"))
         self.desc = L.pbrt_amd_scene_desc(self._h)
@@ -224,6 +236,12 @@ class Context:
         """Render into a caller-owned device buffer of height*width float4 (e.g. a torch tensor's data_ptr())."""
         self._chk(device_lib().mi_film_bind(self._ctx, C.c_void_p(device_ptr) if device_ptr else None), "mi_film_bind")
 
+    def trace_info(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(device_lib().mi_trace_info(self._ctx, _ptr(out)), "mi_trace_info")
+        names = ["general BVH4 steps", "128-byte quantised BVH8 (round 1)", "lean BVH4 steps", "lean steps over the 80-byte compressed BVH8", "two-level BVH4 (instanced scene)"]
+        return {"mode": int(out[0]), "name": names[int(out[0])], "node_bytes": int(out[1]), "nodes": int(out[2]), "lds_stack_entries": int(out[3])}
+
     def counters(self):
         out = np.zeros(MI_CNT_COUNT, dtype=np.uint64)
         self._chk(device_lib().mi_counters(self._ctx, _ptr(out)), "mi_counters")
@@ -310,18 +328,27 @@ TEX_QUERY_DTYPE = np.dtype([("p", np.float32, 3), ("uv", np.float32, 2), ("dpdx"
 SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
 
 
-def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True):
-    """Host-only: build the quantised BVH8 of the next traversal layout, check it, and run the future kernel's per-ray state machine on the
-    host for `rays` -> (hits or None, dict of statistics).  No GPU needed."""
+def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=False):
+    """Host-only: build the quantised BVH8 (compressed=True: the 80-byte layout of csrc/pt_bvh8c.h the kernels traverse), check it, and run
+    the kernel's per-ray state machine on the host for `rays` -> (hits or None, dict of statistics).  No GPU needed."""
     st = np.zeros(8, dtype=np.int64)
     L = device_lib()
     n = 0 if rays is None else len(rays)
     r = np.ascontiguousarray(rays, dtype=RAY_DTYPE) if n else None
     hits = np.zeros(n, dtype=HIT_DTYPE) if (n and want_hits) else None
-    if L.mi_bvh8_validate(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
+    fn = L.mi_bvh8c_validate if compressed else L.mi_bvh8_validate
+    if fn(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
         raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
     keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]
     return hits, dict(zip(keys, [int(v) for v in st]))
+
+
+def film_gather(ctxs, root=0):
+    """mi_film_gather: sum the films of `ctxs` (one context per GPU, rendered with rank = i, world = len(ctxs)) into ctxs[root]'s
+    film -- one grouped ncclReduce over RCCL when the contexts sit on distinct GPUs, a device-side sum when they share one."""
+    arr = (C.c_void_p * len(ctxs))(*[c._ctx for c in ctxs])
+    if device_lib().mi_film_gather(arr, len(ctxs), root) != 0:
+        raise RuntimeError("mi_film_gather: %s" % device_lib().mi_last_error().decode())
 
 
 def bvh4_validate(scene):

@@ -15,6 +15,7 @@
 // All kernels are persistent grid-stride loops whose trip counts come from device-side queue
 // counters (no host round trips inside a pass) with an XCD-contiguous chunk mapping.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -23,10 +24,12 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "pt_shade.h"
 #include "pt_material.h"
+#include "pt_bvh8c.h"
 #include "pt_trace_fast.h"
 #include "sobol_tables.inc"
 
@@ -273,6 +276,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef TRACE_LEAF_MIN
 #define TRACE_LEAF_MIN 24      /* run the leaf phase as soon as this many lanes wait at a leaf */
 #endif
+#ifndef PT_TRACE_GUARD_ITERS
+#define PT_TRACE_GUARD_ITERS (1u << 22)
+#endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 1   /* __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow */
 #endif
@@ -288,10 +294,13 @@ template <bool WIDE, bool INST, bool FAST = false> struct TravTypes { typedef Tr
 template <> struct TravTypes<true, false, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
 template <> struct TravTypes<false, true, false> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<false, false, true> { typedef FastRay State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false>
+struct TravTypes8C { typedef Fast8Ray State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
+// C8: the lean steps over the 80-byte compressed 8-wide nodes (pt_bvh8c.h) -- the default for plain all-triangle scenes
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false, bool C8 = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    static_assert(!FAST || (!SPHERES && !ALPHA && !WIDE && !INST && !PT_STACK_T), "the fast steps cover plain all-triangle scenes");
-    typedef TravTypes<WIDE, INST, FAST> TT;
+    static_assert(!(FAST || C8) || (!SPHERES && !ALPHA && !WIDE && !INST && !PT_STACK_T), "the fast steps cover plain all-triangle scenes");
+    static_assert(!(FAST && C8), "one lean variant at a time");
+    typedef typename std::conditional<C8, TravTypes8C, TravTypes<WIDE, INST, FAST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
@@ -309,6 +318,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     ts.cur = TRAV_DONE;
     TraceCounters tc = {0, 0};
     uint32_t nrays = 0;
+    uint32_t waveIters = 0;
     while (true) {
         unsigned long long idle = __ballot(!active);
         int nIdle = __popcll(idle);
@@ -330,7 +340,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     float4 o4 = MODE == 0 ? ps.rec[slot].ray_o : (MODE == 1 ? ps.nee[slot].mi_o : ps.nee[slot].sh_o);
                     float4 d4 = MODE == 0 ? ps.rec[slot].ray_d : (MODE == 1 ? ps.nee[slot].mi_d : ps.nee[slot].sh_d);
                     if (MODE == 1) lightNum = __float_as_uint(d4.w);
-                    if constexpr (FAST) FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    if constexpr (C8) Fast8RayInit(sc, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    else if constexpr (FAST) FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
                     else ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
                     active = true;
                     ++nrays;
@@ -343,6 +354,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
         if (!__any(active)) break;
         const bool mayRefill = segsTried < 8;
         while (true) {
+            // safety net: a traversal that does not terminate (a corrupted stack / node reference) must not hang the GPU -- after
+            // PT_TRACE_GUARD_ITERS scheduling rounds (two orders of magnitude beyond any real frame) the wave drops its rays and
+            // reports it (MI_CNT_TRACE_GUARD_TRIPS: checked to be zero by the parity tests, bench.py and smoke())
+            if (++waveIters > PT_TRACE_GUARD_ITERS) {
+                if (lane == 0) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], 1ull);
+                active = false; segsTried = 8;
+                break;
+            }
             // node phase: keep stepping through interior nodes while enough lanes still want one (lanes that reached
             // a leaf or finished wait); then ONE leaf phase for everybody waiting at a leaf.  A leaf step (up to 16
             // watertight triangle tests) costs several node steps, so it should run with many lanes, not for one.
@@ -352,7 +371,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     bool wantNode = active && ts.atNode();
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
-                    if constexpr (FAST) {
+                    if constexpr (C8) { if (wantNode) Fast8NodeStep<COUNT>(sc, ts, st, &tc); }
+                    else if constexpr (FAST) {
                         // the branch-free step needs the top of the stack inside the LDS part; a deep lane sends the wave through the general step
                         if (__any(wantNode && st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD)) { if (wantNode) FastNodeStep<COUNT, true, true>(sc, ts, st, &tc); }
                         else if (wantNode) FastNodeStep<COUNT, true, false>(sc, ts, st, &tc);
@@ -364,14 +384,16 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if constexpr (FAST) {
+            if constexpr (C8) { if (active && ts.atLeaf()) Fast8LeafStep<MODE == 2, COUNT>(sc, ts, st, &tc); }
+            else if constexpr (FAST) {
                 const bool wantLeaf = active && ts.atLeaf();
                 if (__any(wantLeaf && st.sp > PT_LDS_STACK)) { if (wantLeaf) FastLeafStep<MODE == 2, COUNT, true>(sc, ts, st, &tc); }
                 else if (wantLeaf) FastLeafStep<MODE == 2, COUNT, false>(sc, ts, st, &tc);
             } else if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             if (active && ts.done()) {
+                if constexpr (C8) { if (ts.prim != TRAV_MISS) ts.prim = sc.trav2prim[ts.prim]; }   // traversal order -> the reference's primitive index
                 if (MODE == 0) {
-                    if constexpr (FAST) ps.rec[slot].hit = make_uint2(ts.prim, ts.prim != TRAV_MISS ? __float_as_uint(ts.tMax) : 0u);
+                    if constexpr (FAST || C8) ps.rec[slot].hit = make_uint2(ts.prim, ts.prim != TRAV_MISS ? __float_as_uint(ts.tMax) : 0u);
                     else ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                     if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
                     uint32_t key = sc.n_materials;                                   // escaped rays
@@ -390,7 +412,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     const DevLight &light = sc.lights[lightNum];
                     RGB Li(0.f);
                     V3 ro, rd;   // the MIS ray (the lean state does not keep it)
-                    if constexpr (FAST) { float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d; ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z); }
+                    if constexpr (FAST || C8) { float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d; ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z); }
                     else { ro = ts.o; rd = ts.d; }
                     if (ts.prim != TRAV_MISS) {
                         if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
@@ -938,13 +960,60 @@ template <bool ANY>
 PT_DEV bool TraverseFast(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit, TraceCounters *cnt) {
     FastRay fr;
     FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, fr, o, d, tMax, st);
+    uint32_t steps = 0;
     while (!fr.done()) {
+        if (++steps > (1u << 20)) { cnt->nodes = 0xffffffffu; fr.prim = TRAV_MISS; break; }   // non-termination guard (reported by the kernel)
         const bool safe = st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD;
         if (fr.atNode()) { if (safe) FastNodeStep<false, true, true>(sc, fr, st, cnt); else FastNodeStep<false, true, false>(sc, fr, st, cnt); }
         else { if (safe) FastLeafStep<ANY, false, true>(sc, fr, st, cnt); else FastLeafStep<ANY, false, false>(sc, fr, st, cnt); }
     }
     *tHit = fr.prim != TRAV_MISS ? fr.tMax : 0; *primHit = fr.prim;
     return fr.prim != TRAV_MISS;
+}
+template <bool ANY>
+PT_DEV bool TraverseC8(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack8 &st, Float *tHit, uint32_t *primHit, TraceCounters *cnt) {
+    Fast8Ray fr;
+    Fast8RayInit(sc, fr, o, d, tMax, st);
+    uint32_t steps = 0;
+    while (!fr.done()) {
+        if (++steps > (1u << 20)) { cnt->nodes = 0xffffffffu; fr.prim = TRAV_MISS; break; }   // non-termination guard (reported by the kernel)
+        if (fr.atNode()) Fast8NodeStep<false>(sc, fr, st, cnt);
+        else Fast8LeafStep<ANY, false>(sc, fr, st, cnt);
+    }
+    *tHit = fr.prim != TRAV_MISS ? fr.tMax : 0;
+    *primHit = fr.prim != TRAV_MISS ? sc.trav2prim[fr.prim] : TRAV_MISS;
+    return fr.prim != TRAV_MISS;
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect_c8(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
+    __shared__ StackEntry8 lds_stack[PT_LDS_STACK8 * PT_BLOCK];
+    TravStack8 st;
+    st.lds = (LdsStackEntry8 *)&lds_stack[threadIdx.x];
+    st.spill = reinterpret_cast<StackEntry8 *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    TraceCounters tc = {0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
+        mi_ray r = rays[i];
+        V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
+        Float t;
+        uint32_t prim;
+        if (occluded) occluded[i] = TraverseC8<true>(sc, o, d, r.tmax, st, &t, &prim, &tc) ? 1 : 0;
+        else {
+            mi_hit h;
+            h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
+            if (TraverseC8<false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
+                V3 p0, p1, p2;
+                uint32_t tf;
+                LoadTri(sc, prim, &p0, &p1, &p2, &tf);
+                TriHit th;
+                Isect is;
+                TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
+                BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
+                h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
+                h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
+            }
+            hits[i] = h;
+        }
+    }
+    if (tc.nodes == 0xffffffffu) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], 1ull);
 }
 template <bool FAST>
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
@@ -980,6 +1049,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathS
             hits[i] = h;
         }
     }
+    if (tc.nodes == 0xffffffffu) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], 1ull);
 }
 __global__ void k_stage_triangles(const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1062,6 +1132,11 @@ struct mi_ctx {
     // experimental BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
     bool hasInst = false;                    // two-level scene (PBRT_AMD_INSTANCING=1 on the host): experimental k_trace / k_shade INST instances
     const DevInstance *instPtr = nullptr;
+    bool hasNullMat = false;                 // some mesh has no material (medium interfaces): paths may outlive max_depth + 1 wavefront iterations
+    int tilesRank = -1, tilesWorld = -1;     // the tile list resident in `tiles` (re-uploaded only when the sharding changes)
+    std::vector<uint32_t> tilesHost;         // kept alive: the upload is asynchronous
+    size_t tilesCount = 0;
+    bool useC8 = false;                      // lean steps over the compressed 8-wide BVH (pt_bvh8c.h): the default for plain scenes
     bool useFast = false;                    // lean traversal steps (pt_trace_fast.h): all-triangle scenes without masks / instances
     bool useBvh8 = false;
     const BVH8Node *nodes8 = nullptr;
@@ -1210,19 +1285,23 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     if (e != hipSuccess || ndev == 0) return fail("mi_ctx_create: no HIP device available (this library has no CPU fallback)");
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail("mi_ctx_create: bad device ordinal");
     HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     mi_ctx *c = new mi_ctx;
     c->device = device_ordinal;
     if (stream) c->stream = (hipStream_t)stream;
-    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    else {
+        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (es != hipSuccess) { delete c; return fail(std::string("mi_ctx_create: hipStreamCreateWithFlags: ") + hipGetErrorString(es)); }
+        c->ownStream = true;
+    }
     c->numCUs = prop.multiProcessorCount;
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     c->gridShade = ((c->numCUs * PT_SHADE_GRID_PER_CU + 7) / 8) * 8;   // k_shade: a multiple of what is resident at PT_SHADE_WAVES per SIMD
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
-    if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { delete c; return -1; }
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream));
+    if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { mi_ctx_destroy(c); return -1; }
+    if (hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream) != hipSuccess) { mi_ctx_destroy(c); return fail("mi_ctx_create: hipMemsetAsync failed"); }
     *out = c;
     return 0;
 }
@@ -1248,6 +1327,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         return fail("mi_scene_upload: Integrator \"volpath\" (participating media) is not implemented on the device yet; \"path\" scenes render with their media ignored, as PathIntegrator does");
     if (d->material_bssrdf)   // subsurface / kdsubsurface materials: the probe-ray kernels do not exist yet (host + CPU oracle carry them)
         return fail("mi_scene_upload: materials with a BSSRDF (\"subsurface\", \"kdsubsurface\") are not implemented on the device yet");
+    c->hasNullMat = false;
+    for (uint32_t m = 0; m < d->n_meshes; ++m) c->hasNullMat |= d->meshes[m].material < 0;
+    c->tilesRank = c->tilesWorld = -1;
     c->hasInst = d->n_instances > 0;   // two-level scenes: experimental device path (first compiled in round 1, see TravStateI)
     if (c->hasInst && (!d->instances || !d->objects)) return fail("mi_scene_upload: instances without instance / object tables");
     // textures (row f2): validate the node table before anything is uploaded
@@ -1286,7 +1368,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(48 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
+    c->sceneBufs.resize(56 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1404,12 +1486,27 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     }
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
     // lean traversal (pt_trace_fast.h): plain all-triangle scenes; PBRT_AMD_TRACE=general keeps the general steps (A/B, parity tests of both)
-    c->useFast = false;
-    {
+    c->useFast = c->useC8 = false;
+    {   // PBRT_AMD_TRACE = bvh8c (default) | bvh4 (lean steps over the BVH4) | general (TravNodeStep / TravLeafStep); PBRT_AMD_BVH8=1: round 1's 128-byte BVH8
         const char *e = std::getenv("PBRT_AMD_TRACE");
-        const bool wantGeneral = e && std::strcmp(e, "general") == 0;
+        const bool wantGeneral = e && std::strcmp(e, "general") == 0, wantBvh4 = e && std::strcmp(e, "bvh4") == 0;
         const char *e8 = std::getenv("PBRT_AMD_BVH8");
-        c->useFast = !wantGeneral && !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
+        const bool plain = !wantGeneral && !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
+        c->useFast = plain && wantBvh4;
+        c->useC8 = plain && !wantBvh4;
+    }
+    sc.nodes8c = nullptr; sc.n_nodes8c = 0; sc.tri_trav = nullptr; sc.trav2prim = nullptr;
+    if (c->useC8) {
+        bvh8c::Builder b8;
+        if (!b8.run(d->bvh_nodes, d->n_bvh_nodes)) return fail("mi_scene_upload: BVH8C build: " + b8.error);
+        if (b8.triOrder.size() != d->n_tris) return fail("mi_scene_upload: BVH8C build lost primitives");
+        { DevBuf &b = next(); if (upload(c, b, b8.out.data(), b8.out.size() * sizeof(BVH8CNode))) return -1; sc.nodes8c = b.p; sc.n_nodes8c = (uint32_t)b8.out.size(); }
+        { DevBuf &b = next(); if (upload(c, b, b8.triOrder.data(), b8.triOrder.size() * sizeof(uint32_t))) return -1; sc.trav2prim = b.as<uint32_t>(); }
+        std::vector<float4> tt(tv.size());
+        for (size_t i = 0; i < b8.triOrder.size(); ++i) for (int k = 0; k < 3; ++k) tt[3 * i + k] = tv[3 * (size_t)b8.triOrder[i] + k];
+        { DevBuf &b = next(); if (upload(c, b, tt.data(), tt.size() * sizeof(float4))) return -1; sc.tri_trav = b.as<float4>(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));   // locals
+        c->stackNeed8 = 7 * (b8.maxDepth + 1) + 1;
     }
     sc.tri_perm = nullptr; sc.tri_perm_stride = 0;
     if (c->useFast) {   // three copies of the records with the vertices permuted for kz = 0, 1, 2 (Permute(p, kx, ky, kz), triangle.cpp:205-209), made on the device
@@ -1797,7 +1894,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
     c->spill8 = std::max(1, c->stackNeed8 - PT_LDS_STACK8);
     {   // one spill area serves whichever traversal runs (BVH4: 4-byte entries, BVH8: 8-byte entries)
-        size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4), words8 = c->useBvh8 ? (size_t)c->spill8 * 2 : 0;
+        size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4), words8 = (c->useBvh8 || c->useC8) ? (size_t)c->spill8 * 2 : 0;
         ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
     }
 #undef ALLOC
@@ -1850,7 +1947,12 @@ static void harvest(mi_ctx *c) {
         } else if (c->hasSpheres) {                                                                                        \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true>), grid, block, 0, st, sc, ps, qin);        \
             else hipLaunchKernelGGL((k_trace<MODE, false, true>), grid, block, 0, st, sc, ps, qin);                 \
-        } else if (c->useFast) { /* the default for plain scenes: lean straight-line steps */                      \
+        } else if (c->useC8) { /* the default for plain scenes: lean steps over the 80-byte compressed 8-wide nodes */  \
+            PathState ps8 = ps;                                                                                     \
+            ps8.spill_per_thread = c->spill8;                                                                       \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps8, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps8, qin);           \
+        } else if (c->useFast) { /* PBRT_AMD_TRACE=bvh4: lean straight-line steps over the BVH4 */                   \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
             else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
         } else {                                                                                                    \
@@ -1917,7 +2019,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         ++iter;
         if (iter > sc.max_depth) {
             // every ordinary path is done after max_depth+1 segments; only chains of null-BSDF surfaces
-            // (which do not count as bounces) can still be alive -- check, and keep going if so
+            // (which do not count as bounces) can still be alive -- check, and keep going if so.  Scenes without such
+            // surfaces (no mesh with a null material) need no check: the pass stays asynchronous on the ctx stream.
+            if (!c->hasNullMat) break;
             uint32_t left = 0;
             HIP_TRY(hipMemcpyAsync(&left, ps.qcount + qin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -1949,11 +2053,16 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     const int tileSize = 16;
     int ex = sc.sample_max[0] - sc.sample_min[0], ey = sc.sample_max[1] - sc.sample_min[1];
     int nTx = (ex + tileSize - 1) / tileSize, nTy = (ey + tileSize - 1) / tileSize;
-    std::vector<uint32_t> tiles;
-    for (int t = rank; t < nTx * nTy; t += world) tiles.push_back((uint32_t)t);
-    if (tiles.empty()) return 0;
-    if (upload(c, c->tiles, tiles.data(), tiles.size() * sizeof(uint32_t))) return -1;
-    uint64_t npixOwned = (uint64_t)tiles.size() * 256;
+    if (c->tilesRank != rank || c->tilesWorld != world) {   // the owned-tile list changes only with the sharding: no allocation on repeated frames
+        HIP_TRY(hipStreamSynchronize(c->stream));           // a pass still reading the old list / the host staging copy
+        c->tilesHost.clear();
+        for (int t = rank; t < nTx * nTy; t += world) c->tilesHost.push_back((uint32_t)t);
+        c->tilesCount = c->tilesHost.size();
+        if (c->tilesCount && upload(c, c->tiles, c->tilesHost.data(), c->tilesCount * sizeof(uint32_t))) return -1;
+        c->tilesRank = rank; c->tilesWorld = world;
+    }
+    if (c->tilesCount == 0) return 0;
+    uint64_t npixOwned = (uint64_t)c->tilesCount * 256;
     // Paths in flight per pass.  Every launch of the wavefront pipeline ends with a tail (the longest rays) and starts with
     // fixed costs, so the pool is made as large as the frame allows -- up to 2^27 paths (37 GB of path state) and at most
     // 60 % of the free HBM: measured 145 -> 190 Msamples/s on the 1080p/64 spp frame going from 2^23 to a single pass.
@@ -1998,6 +2107,7 @@ int mi_sync(mi_ctx *c) {
 
 int mi_film_clear(mi_ctx *c) {
     if (!c || !c->haveScene) return fail("mi_film_clear: no scene");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->filmPtr, 0, (size_t)c->filmPixels * sizeof(float4), c->stream));
     return 0;
 }
@@ -2015,6 +2125,113 @@ int mi_film_download(mi_ctx *c, float *rgbw) {
     return 0;
 }
 void *mi_film_device_ptr(mi_ctx *c) { return c ? (void *)c->filmPtr : nullptr; }
+
+// ---- mi_film_gather: RCCL reduction of the per-GPU films (see include/pbrt_amd.h).  RCCL is loaded with dlopen so that the
+// library has no link-time dependency on it (single-GPU users never touch it); the few entry points used are declared here
+// with the signatures of <rccl/rccl.h>.
+namespace {
+typedef struct ncclComm *ncclComm_t_;
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_t_ *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, ncclComm_t_, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::vector<int> devs;
+    std::vector<ncclComm_t_> comms;
+    bool load(std::string *err) {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { *err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce) { *err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+    bool commsFor(const std::vector<int> &d, std::string *err) {
+        if (d == devs && !comms.empty()) return true;
+        for (ncclComm_t_ cm : comms) CommDestroy(cm);
+        comms.assign(d.size(), nullptr);
+        int rc = CommInitAll(comms.data(), (int)d.size(), d.data());
+        if (rc != 0) { *err = std::string("ncclCommInitAll: ") + (GetErrorString ? GetErrorString(rc) : "error"); comms.clear(); devs.clear(); return false; }
+        devs = d;
+        return true;
+    }
+};
+Rccl g_rccl;
+__global__ void __launch_bounds__(PT_BLOCK) k_film_add(float4 *dst, const float4 *src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
+        float4 a = dst[i], b = src[i];
+        dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+}  // namespace
+
+int mi_trace_info(mi_ctx *c, int64_t out[4]) {
+    if (!c || !out || !c->haveScene) return fail("mi_trace_info: no scene");
+    int mode = c->hasInst ? 4 : (c->useC8 ? 3 : (c->useFast ? 2 : ((c->useBvh8 && !c->hasAlpha && !c->hasSpheres) ? 1 : 0)));
+    out[0] = mode;
+    out[1] = mode == 3 ? (int64_t)sizeof(BVH8CNode) : 128;
+    out[2] = mode == 3 ? c->sc.n_nodes8c : (mode == 1 ? c->nNodes8 : c->sc.n_nodes);
+    out[3] = (mode == 3 || mode == 1) ? PT_LDS_STACK8 : PT_LDS_STACK;
+    return 0;
+}
+
+int mi_film_gather(mi_ctx **ctxs, int n, int root) {
+    if (!ctxs || n < 1 || root < 0 || root >= n) return fail("mi_film_gather: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->haveScene) return fail("mi_film_gather: context without a scene");
+        if (ctxs[i]->filmPixels != ctxs[root]->filmPixels) return fail("mi_film_gather: films of different size");
+    }
+    for (int i = 0; i < n; ++i) if (mi_sync(ctxs[i])) return -1;   // the renders (each on its own ctx stream)
+    if (n == 1) return 0;
+    const size_t count = (size_t)ctxs[root]->filmPixels * 4;       // floats
+    std::vector<int> devs(n);
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; ++j) distinct &= devs[j] != devs[i]; }
+    if (distinct) {
+        std::string err;
+        if (!g_rccl.load(&err) || !g_rccl.commsFor(devs, &err)) return fail("mi_film_gather: " + err);
+        const int ncclFloat32_ = 7, ncclSum_ = 0;   // ncclDataType_t / ncclRedOp_t values of <rccl/rccl.h>
+        int rc = g_rccl.GroupStart();
+        for (int i = 0; i < n && rc == 0; ++i) {
+            HIP_TRY(hipSetDevice(ctxs[i]->device));
+            rc = g_rccl.Reduce(ctxs[i]->filmPtr, ctxs[i]->filmPtr, count, ncclFloat32_, ncclSum_, root, g_rccl.comms[i], ctxs[i]->stream);
+        }
+        int rc2 = g_rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) return fail(std::string("mi_film_gather: ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"));
+        for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
+        return 0;
+    }
+    // contexts sharing a device (one-GPU test boxes): plain device-side sums into the root film; contexts on other devices through a staged peer copy
+    mi_ctx *r = ctxs[root];
+    HIP_TRY(hipSetDevice(r->device));
+    DevBuf stage;
+    for (int i = 0; i < n; ++i) {
+        if (i == root) continue;
+        const float4 *src = ctxs[i]->filmPtr;
+        if (ctxs[i]->device != r->device) {
+            if (!stage.p && stage.alloc(count * sizeof(float))) return -1;
+            HIP_TRY(hipMemcpyPeerAsync(stage.p, r->device, ctxs[i]->filmPtr, ctxs[i]->device, count * sizeof(float), r->stream));
+            src = stage.as<float4>();
+        }
+        hipLaunchKernelGGL(k_film_add, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, src, (int64_t)r->filmPixels);
+        HIP_TRY(hipGetLastError());
+        if (ctxs[i]->device != r->device) HIP_TRY(hipStreamSynchronize(r->stream));   // the staging buffer is reused
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    stage.release();
+    return 0;
+}
 int64_t mi_film_pixel_count(mi_ctx *c) { return c ? c->filmPixels : 0; }
 
 int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
@@ -2198,6 +2415,75 @@ int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int 
     if (st.mismatch) return fail("mi_bvh8_validate: the packed node step (Bvh8StepWords) and the struct form (Bvh8Step) disagree on " + std::to_string(st.mismatch) + " node visits");
     return 0;
 }
+// the same for the 80-byte compressed layout the traversal kernels run (pt_bvh8c.h): build, structural checks in exact arithmetic, host emulation
+int mi_bvh8c_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
+    if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8c_validate: null argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    if (d->n_instances) return fail("mi_bvh8c_validate: two-level scenes are not handled");
+    bvh8c::Builder bb;
+    if (!bb.run(d->bvh_nodes, d->n_bvh_nodes)) return fail("mi_bvh8c_validate: " + bb.error);
+    std::vector<uint8_t> covered(d->n_tris, 0);
+    int64_t leaves = 0;
+    std::vector<uint32_t> todo;
+    if (!bb.out.empty()) todo.push_back(0);
+    std::vector<uint8_t> seenNode(bb.out.size(), 0);
+    while (!todo.empty()) {
+        uint32_t ni = todo.back(); todo.pop_back();
+        if (ni >= bb.out.size()) return fail("mi_bvh8c_validate: child index out of range");
+        if (seenNode[ni]++) return fail("mi_bvh8c_validate: node referenced twice");
+        const BVH8CNode &nd = bb.out[ni];
+        uint32_t words[20];
+        std::memcpy(words, &nd, 80);
+        for (int k = 0; k < 8; ++k) {
+            const bool interior = (nd.imask >> k) & 1u, leaf = (nd.meta[k] & 0x80u) != 0;
+            if (interior && leaf) return fail("mi_bvh8c_validate: child both interior and leaf");
+            if (!interior && !leaf) continue;
+            double lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                double s = std::ldexp(1.0, (int)nd.e[a] - 127);
+                lo[a] = (double)nd.p[a] + nd.qlo[a][k] * s; hi[a] = (double)nd.p[a] + nd.qhi[a][k] * s;
+            }
+            uint32_t c = Bvh8cChildRef(words, k);
+            if (leaf) {
+                uint32_t first = c & bvh8c::FIRST_MASK, count = ((c >> 27) & 0xfu) + 1;
+                ++leaves;
+                if (!(c & bvh8c::LEAF) || first + count > bb.triOrder.size() || count > BVH8C_LEAF_MAX) return fail("mi_bvh8c_validate: bad leaf reference");
+                for (uint32_t tt = first; tt < first + count; ++tt) {
+                    uint32_t t = bb.triOrder[tt];
+                    if (t >= d->n_tris) return fail("mi_bvh8c_validate: primitive index out of range");
+                    if (covered[t]++) return fail("mi_bvh8c_validate: primitive referenced twice");
+                    const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+                    if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE) continue;
+                    for (int kk = 0; kk < 3; ++kk)
+                        for (int a = 0; a < 3; ++a) {
+                            double x = d->P[3 * (size_t)v[kk] + a];
+                            if (x < lo[a] || x > hi[a]) return fail("mi_bvh8c_validate: primitive outside its quantised leaf box");
+                        }
+                }
+            } else {
+                if (c & bvh8c::LEAF) return fail("mi_bvh8c_validate: interior reference with the leaf bit");
+                todo.push_back(c);
+            }
+        }
+    }
+    int64_t ncov = 0;
+    for (uint8_t f : covered) ncov += f;
+    if (ncov != (int64_t)d->n_tris) return fail("mi_bvh8c_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
+    for (uint8_t f : seenNode) if (!f) return fail("mi_bvh8c_validate: unreachable node");
+    bvh8c::Stats st;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t prim; float t, b[3];
+        bool hit = bvh8c::traverse(d, bb.out, bb.triOrder, rays[i], any_hit != 0, &prim, &t, b, &st);
+        if (hits) {
+            std::memset(&hits[i], 0, sizeof(mi_hit));
+            hits[i].prim = hit ? (int32_t)prim : -1;
+            hits[i].t = hit ? t : 0; hits[i].b0 = b[0]; hits[i].b1 = b[1]; hits[i].b2 = b[2];
+        }
+    }
+    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
+    stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
+    return 0;
+}
 // stage-level texture evaluation: Texture<T>::Evaluate of node `node` at n recorded interactions
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_texture(int node, const mi_tex_query *q, int64_t n, float *rgb) {
     int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
@@ -2288,7 +2574,8 @@ int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
     if (n <= 0) return 0;
     DevBuf dr, dh;
     if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_hit))) return -1;
-    if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
+    if (c->useC8) { PathState ps8 = c->ps; ps8.spill_per_thread = c->spill8; hipLaunchKernelGGL(k_stage_intersect_c8, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, ps8, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr); }
+    else if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
     else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
     HIP_TRY(hipMemcpyAsync(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2314,7 +2601,8 @@ int mi_intersect_p(mi_ctx *c, const mi_ray *rays, int64_t n, uint8_t *occluded) 
     if (n <= 0) return 0;
     DevBuf dr, dh;
     if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n)) return -1;
-    if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
+    if (c->useC8) { PathState ps8 = c->ps; ps8.spill_per_thread = c->spill8; hipLaunchKernelGGL(k_stage_intersect_c8, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, ps8, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>()); }
+    else if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
     else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
     HIP_TRY(hipMemcpyAsync(occluded, dh.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

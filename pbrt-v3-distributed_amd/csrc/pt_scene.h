@@ -64,6 +64,10 @@ struct __attribute__((aligned(64))) TriShade {
 struct DevScene {
     const BVH4Node *nodes;
     const float4 *tri_verts;        // 3 per triangle
+    const void *nodes8c;            // BVH8CNode[] (pt_bvh8c.h), null: not built
+    uint32_t n_nodes8c;
+    const float4 *tri_trav;         // triangle records in the BVH8C's traversal order
+    const uint32_t *trav2prim;      // traversal order -> reference primitive index
     const float4 *tri_perm;         // the same records three times, vertices permuted for kz = 0, 1, 2 (pt_trace_fast.h); null: not built
     size_t tri_perm_stride;         // float4s per copy (3 * n_tris)
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs

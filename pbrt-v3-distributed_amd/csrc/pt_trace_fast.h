@@ -28,10 +28,11 @@
 // Zero direction components (I = +-inf; NOT rare: Sobol' values such as 0.5 give exact zeros in the local frame of an
 // axis-aligned surface) must keep their culling -- such a ray lives in a plane and would otherwise visit every node that
 // plane cuts (measured: a 35 ms tail per launch on the 10 M-triangle scene).  The reference gets -inf / +inf from
-// (p - o) * inf by the SIGN of p - o; here I is replaced by +-2^100 and c = o * 2^100 is exact (a power of two, no push),
-// so fma(p, 2^100, -c) = fl((p - o) 2^100) has exactly that sign and a magnitude >= 2^-49 -- beyond every finite
-// distance on the other axes unless |p - o| < 2^-100 t, which fp32 coordinates only reach within 1e-23 of the
-// coordinate origin.  p == o gives 0 where the reference gets NaN and rejects: the accepting side.
+// (p - o) * inf by the SIGN of p - o; here I is replaced by +-2^100 and c = o * 2^100 is exact (a power of two), so
+// fma(p, 2^100, -c) = fl((p - o) 2^100) has exactly that sign and a magnitude that dwarfs every finite distance on the
+// other axes.  Where p == o the reference evaluates 0 * inf = NaN and (y / z axes) IGNORES that bound, so equality must
+// land on the accepting side: c is moved by max(|c| 2^-22, 1e20) (FastZeroAxis) -- planes within 4 ulp of the origin
+// count as "inside the slab".
 // Every box the reference enters is entered here; extra boxes cost time, not correctness.
 #pragma once
 
@@ -54,6 +55,17 @@ PT_DEV Float FastFoldC(Float c, Float push) {   // c moved by 4 eps |c| in the d
     Float r = c + push * (4 * PT_MACHINE_EPS) * absf(c);
     return (absf(r) < PT_INFINITY) ? r : __builtin_nanf("");
 }
+// d == 0 on this axis: I -> +-2^100, c = o I exactly (power of two), then moved by delta = max(|c| 2^-22, 1e20) to the accepting side:
+// a plane within 4 ulp of the origin counts as "origin inside the slab".  The reference gets 0 * inf = NaN when the origin lies exactly
+// ON a plane and (on the y / z axes) ignores that bound, so equality must not reject here.
+PT_DEV void FastZeroAxis(Float o, Float d, Float *inN, Float *inF, Float *cN, Float *cF) {
+    const Float I = __builtin_copysignf(0x1p100f, d), c = o * I;
+    const Float delta = __builtin_fmaxf(absf(c) * 0x1p-22f, 1e20f);
+    *inN = *inF = I;
+    const bool fin = absf(c) < PT_INFINITY;
+    *cN = fin ? c + delta : __builtin_nanf("");
+    *cF = fin ? c - delta : __builtin_nanf("");
+}
 PT_DEV void FastRayInit(const DevScene &sc, const float4 *triPerm, size_t triCopyStride, FastRay &fr, const V3 &o, const V3 &d, Float tMax, TravStack &st) {
     const V3 inv(1 / d.x, 1 / d.y, 1 / d.z);
     const Float wn = 1 - 8 * PT_MACHINE_EPS, wf = 1 + 24 * PT_MACHINE_EPS;
@@ -61,10 +73,10 @@ PT_DEV void FastRayInit(const DevScene &sc, const float4 *triPerm, size_t triCop
     fr.inF = V3(inv.x * wf, inv.y * wf, inv.z * wf);
     fr.cN = V3(FastFoldC(o.x * fr.inN.x, 1), FastFoldC(o.y * fr.inN.y, 1), FastFoldC(o.z * fr.inN.z, 1));
     fr.cF = V3(FastFoldC(o.x * fr.inF.x, -1), FastFoldC(o.y * fr.inF.y, -1), FastFoldC(o.z * fr.inF.z, -1));
-    const Float big = 0x1p100f;   // zero direction components: sign-exact stand-in for +-inf (header comment)
-    if (d.x == 0) { fr.inN.x = fr.inF.x = __builtin_copysignf(big, d.x); fr.cN.x = fr.cF.x = FastFoldC(o.x * fr.inN.x, 0); }
-    if (d.y == 0) { fr.inN.y = fr.inF.y = __builtin_copysignf(big, d.y); fr.cN.y = fr.cF.y = FastFoldC(o.y * fr.inN.y, 0); }
-    if (d.z == 0) { fr.inN.z = fr.inF.z = __builtin_copysignf(big, d.z); fr.cN.z = fr.cF.z = FastFoldC(o.z * fr.inN.z, 0); }
+    // zero direction components: sign-exact stand-in for +-inf (header comment)
+    if (d.x == 0) FastZeroAxis(o.x, d.x, &fr.inN.x, &fr.inF.x, &fr.cN.x, &fr.cF.x);
+    if (d.y == 0) FastZeroAxis(o.y, d.y, &fr.inN.y, &fr.inF.y, &fr.cN.y, &fr.cF.y);
+    if (d.z == 0) FastZeroAxis(o.z, d.z, &fr.inN.z, &fr.inF.z, &fr.cN.z, &fr.cF.z);
     fr.offX = inv.x < 0 ? 48u : 0u;
     fr.offY = inv.y < 0 ? 64u : 16u;
     fr.offZ = inv.z < 0 ? 80u : 32u;
@@ -203,4 +215,132 @@ PT_DEV void FastLeafStep(const DevScene &sc, FastRay &fr, TravStack &st, TraceCo
     if (ANY && ok) nxt = TRAV_DONE;
     fr.cur = nxt;
     st.sp -= (popOk && !(ANY && ok)) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ BVH8C (80-byte compressed 8-wide nodes, pt_bvh8c.h)
+// Same lean per-lane state machine over the compressed layout: 5 x 16-byte loads per interior step, nearest hit child next, the
+// other hit children pushed with their entry distances (8-byte stack entries; an entry whose box lies beyond the hit found in the
+// meantime is dropped at pop time without being fetched).  Triangles are read from the traversal-order copy of the records
+// (sc.tri_trav; one copy: the axis permutation is done in registers -- with the memory side as the bound, 18 v_cndmask are
+// cheaper than three times the triangle working set) and the hit is reported as the REFERENCE primitive index (sc.trav2prim).
+struct Fast8Ray {
+    V3 o, inv;                    // inv: +-1e30 stands in for the infinities of zero direction components (Ray8Init, pt_bvh8.h)
+    RayShear shear;
+    Float tMax;
+    uint32_t prim, cur;           // prim: traversal-order index while the ray is in flight
+    PT_DEV bool done() const { return cur == TRAV_DONE; }
+    PT_DEV bool atLeaf() const { return cur != TRAV_DONE && (cur & BVH4_LEAF); }
+    PT_DEV bool atNode() const { return !(cur & BVH4_LEAF); }
+};
+PT_DEV void Fast8RayInit(const DevScene &sc, Fast8Ray &fr, const V3 &o, const V3 &d, Float tMax, TravStack8 &st) {
+    fr.o = o;
+    fr.inv = V3(d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
+                d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z);
+    fr.shear.init(d);
+    fr.tMax = tMax;
+    fr.prim = TRAV_MISS;
+    st.sp = 0;
+    fr.cur = sc.n_nodes8c ? 0u : TRAV_DONE;
+}
+// pop with culling; LDSONLY: the caller guarantees sp <= PT_LDS_STACK8 (no spill entries to look at)
+template <bool LDSONLY>
+PT_DEV uint32_t Fast8Pop(TravStack8 &st, Float tMax) {
+    if (!LDSONLY) return st.pop(tMax);
+    while (st.sp) {
+        --st.sp;
+        StackEntry8 e = st.lds[st.sp * PT_BLOCK];
+        if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
+    }
+    return TRAV_DONE;
+}
+template <bool COUNT>
+PT_DEV void Fast8NodeStep(const DevScene &sc, Fast8Ray &fr, TravStack8 &st, TraceCounters *cnt) {
+    const char *base = reinterpret_cast<const char *>(sc.nodes8c);
+    const uint32_t nb = fr.cur * 80u;
+    const uint4 w0 = LdU4(base, nb), w1 = LdU4(base, nb + 16u), w2 = LdU4(base, nb + 32u), w3 = LdU4(base, nb + 48u), w4 = LdU4(base, nb + 64u);
+    if (COUNT) ++cnt->nodes;
+    const uint32_t wd[20] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w};
+    Float t[8];
+    const uint32_t mask = Bvh8cStepWords(wd, fr.o.x, fr.o.y, fr.o.z, fr.inv.x, fr.inv.y, fr.inv.z, fr.tMax, t);
+    // nearest hit child (lowest slot among equals: pieces of a split leaf are visited in primitive order)
+    Float tb = PT_INFINITY;
+    uint32_t refBest = TRAV_DONE;
+    int best = -1;
+    uint32_t refs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        refs[k] = Bvh8cChildRef(wd, k);
+        const bool h = (mask >> k) & 1u;
+        if (h && (best < 0 || t[k] < tb)) { tb = t[k]; best = k; refBest = refs[k]; }
+    }
+    const int nh = __builtin_popcount(mask);
+    // LDS-only pushes / pop need the stack inside its LDS part before AND after the step: sp + (nh - 1) <= PT_LDS_STACK8 with pushes,
+    // sp <= PT_LDS_STACK8 for the pop of a step without a hit child.  A deeper lane sends the wave through the general push / pop (rare).
+    if (__any(st.sp + (nh > 0 ? nh : 1) > PT_LDS_STACK8 + 1)) {
+#pragma unroll
+        for (int k = 7; k >= 0; --k) if (((mask >> k) & 1u) && k != best) st.push(refs[k], t[k]);
+        fr.cur = best >= 0 ? refBest : st.pop(fr.tMax);
+        return;
+    }
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {   // the other hit children, slot order, with their entry distances (LDS part of the stack only)
+        if (((mask >> k) & 1u) && k != best) {
+            st.lds[st.sp * PT_BLOCK] = (StackEntry8)refs[k] | ((StackEntry8)__float_as_uint(t[k]) << 32);
+            ++st.sp;
+        }
+    }
+    fr.cur = best >= 0 ? refBest : Fast8Pop<true>(st, fr.tMax);
+}
+// one triangle of the leaf per step (as FastLeafStep), vertices permuted in registers
+template <bool ANY, bool COUNT>
+PT_DEV void Fast8LeafStep(const DevScene &sc, Fast8Ray &fr, TravStack8 &st, TraceCounters *cnt) {
+    const uint32_t first = fr.cur & BVH4_FIRST_MASK, left = (fr.cur >> 27) & 0xfu;
+    const float4 *tv = sc.tri_trav + 3 * (size_t)first;
+    const float4 a = tv[0], b = tv[1], c = tv[2];
+    if (COUNT) ++cnt->tris;
+    const uint32_t flags = __float_as_uint(a.w);
+    const RayShear &rs = fr.shear;
+    V3 p0t = rs.permute(V3(a.x, a.y, a.z) - fr.o), p1t = rs.permute(V3(b.x, b.y, b.z) - fr.o), p2t = rs.permute(V3(c.x, c.y, c.z) - fr.o);
+    const Float Sx = rs.Sx, Sy = rs.Sy, Sz = rs.Sz;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    Float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    Float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    Float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    const bool edge = e0 == 0.0f || e1 == 0.0f || e2 == 0.0f;
+    if (__any(edge)) {
+        if (edge) {
+            double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+            e0 = (float)(p2typ1tx - p2txp1ty);
+            double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+            e1 = (float)(p0typ2tx - p0txp2ty);
+            double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+            e2 = (float)(p1typ0tx - p1txp0ty);
+        }
+    }
+    bool ok = !((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0));
+    const Float det = e0 + e1 + e2;
+    ok = ok && det != 0;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    const Float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    const Float tmd = fr.tMax * det;
+    ok = ok && !(det < 0 && (tScaled >= 0 || tScaled < tmd)) && !(det > 0 && (tScaled <= 0 || tScaled > tmd));
+    const Float invDet = 1 / det;
+    const Float t = tScaled * invDet;
+    const Float maxZt = MaxComponent(Abs(V3(p0t.z, p1t.z, p2t.z)));
+    const Float deltaZ = gamma_n(3) * maxZt;
+    const Float maxXt = MaxComponent(Abs(V3(p0t.x, p1t.x, p2t.x)));
+    const Float maxYt = MaxComponent(Abs(V3(p0t.y, p1t.y, p2t.y)));
+    const Float deltaX = gamma_n(5) * (maxXt + maxZt);
+    const Float deltaY = gamma_n(5) * (maxYt + maxZt);
+    const Float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    const Float maxE = MaxComponent(Abs(V3(e0, e1, e2)));
+    const Float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absf(invDet);
+    ok = ok && (t > deltaT) && !(flags & TRI_FLAG_REJECT);
+    if (ok) { fr.prim = first; fr.tMax = t; }
+    if (ANY && ok) { fr.cur = TRAV_DONE; return; }
+    if (left) { fr.cur = BVH4_LEAF | ((left - 1) << 27) | (first + 1); return; }
+    if (__any(st.sp > PT_LDS_STACK8)) fr.cur = Fast8Pop<false>(st, fr.tMax);
+    else fr.cur = Fast8Pop<true>(st, fr.tMax);
 }

@@ -116,6 +116,7 @@ void pbrtInit(const Options &opt) {
     g_imageFileOverride = opt.imageFile;
     g_quickRender = opt.quickRender;
     g_quiet = opt.quiet;
+    g_unsupportedCount = 0;
     g_cropWindow[0] = opt.cropWindow[0][0]; g_cropWindow[1] = opt.cropWindow[0][1];
     g_cropWindow[2] = opt.cropWindow[1][0]; g_cropWindow[3] = opt.cropWindow[1][1];
     if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
@@ -800,6 +801,10 @@ void pbrtWorldEnd() {
         scene->media = renderOptions->media;
         { int in; CreateMediumInterface(&in, &scene->cameraMedium); }   // MakeCamera at WorldEnd: mediumInterface.outside (api.cpp:793-813)
         scene->objects = std::move(renderOptions->objectDefs);
+    }
+    if (g_unsupportedCount > 0) {
+        Error("%d unsupported parameter(s) above would change the image: not rendering", g_unsupportedCount);
+        scene.reset(); integrator.reset();
     }
     if (scene && integrator) {
         if (PbrtOptions.deferRender) {

@@ -13,11 +13,20 @@ extern "C" {
 
 // Parse `filename` (or, if is_text != 0, the scene text itself) up to WorldEnd and flatten the
 // result; returns NULL on failure.  quick/spp/res overrides <= 0 are ignored.
+static pbrt_amd_scene *LoadScene(const char *filename_or_text, int is_text, int quiet, const char *outfile, const float *crop);
 pbrt_amd_scene *pbrt_amd_scene_load(const char *filename_or_text, int is_text, int quiet, const char *outfile) {
+    return LoadScene(filename_or_text, is_text, quiet, outfile, nullptr);
+}
+// the same with the command line's --cropwindow x0 x1 y0 y1 (main/pbrt.cpp:94-100: it overrides the Film's own "cropwindow")
+pbrt_amd_scene *pbrt_amd_scene_load_crop(const char *filename_or_text, int is_text, int quiet, const char *outfile, const float crop[4]) {
+    return LoadScene(filename_or_text, is_text, quiet, outfile, crop);
+}
+static pbrt_amd_scene *LoadScene(const char *filename_or_text, int is_text, int quiet, const char *outfile, const float *crop) {
     Options opt;
     opt.quiet = quiet != 0;
     opt.deferRender = true;
     if (outfile) opt.imageFile = outfile;
+    if (crop) { opt.cropWindow[0][0] = crop[0]; opt.cropWindow[0][1] = crop[1]; opt.cropWindow[1][0] = crop[2]; opt.cropWindow[1][1] = crop[3]; }
     pbrtInit(opt);
     if (is_text) pbrtParseString(filename_or_text); else pbrtParseFile(filename_or_text);
     pbrtCleanup();

@@ -367,6 +367,7 @@ struct DeviceApi {
     int (*sync)(mi_ctx *) = nullptr;
     int (*film_download)(mi_ctx *, float *) = nullptr;
     int (*counters)(mi_ctx *, uint64_t *) = nullptr;
+    int (*film_gather)(mi_ctx **, int, int) = nullptr;
     bool load() {
         if (handle) return true;
         const char *names[] = {"libpbrt_amd.so", "./libpbrt_amd.so"};
@@ -387,7 +388,7 @@ struct DeviceApi {
 #define BIND(field, sym) field = (decltype(field))dlsym(handle, sym); if (!field) { Error("libpbrt_amd.so lacks %s", sym); return false; }
         BIND(last_error, "mi_last_error") BIND(ctx_create, "mi_ctx_create") BIND(ctx_destroy, "mi_ctx_destroy")
         BIND(scene_upload, "mi_scene_upload") BIND(render, "mi_render") BIND(sync, "mi_sync")
-        BIND(film_download, "mi_film_download") BIND(counters, "mi_counters")
+        BIND(film_download, "mi_film_download") BIND(counters, "mi_counters") BIND(film_gather, "mi_film_gather")
 #undef BIND
         return true;
     }
@@ -399,36 +400,41 @@ void WavefrontPathIntegrator::Render(const Scene &scene) {
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     std::unique_ptr<FlatScene> fs = Flatten(scene);
-    if (!g_dev.load()) return;
+    if (!g_dev.load()) { g_renderFailed = true; return; }
     int world = std::max(1, nGpus);
     std::vector<mi_ctx *> ctxs(world, nullptr);
     for (int r = 0; r < world; ++r) {
         if (g_dev.ctx_create(r, nullptr, &ctxs[r]) != 0 || g_dev.scene_upload(ctxs[r], &fs->desc) != 0) {
             Error("GPU %d: %s", r, g_dev.last_error());
             for (mi_ctx *c : ctxs) if (c) g_dev.ctx_destroy(c);
+            g_renderFailed = true;
             return;
         }
     }
     auto t1 = clk::now();
-    // image tiles shard across GPUs (scene replicated); each device renders only its tiles
-    for (int r = 0; r < world; ++r) {
+    // image tiles shard across GPUs (scene replicated); each device renders only its tiles.  mi_render is asynchronous: the loop
+    // queues every device's frame and the GPUs render concurrently; mi_film_gather then waits for all of them and sums the films
+    // into GPU 0's with one grouped ncclReduce over xGMI (replaces Film::MergeFilmTile across devices, film.cpp:117-130).
+    bool ok = true;
+    for (int r = 0; r < world && ok; ++r) {
         mi_render_params rp;
         std::memset(&rp, 0, sizeof(rp));
         rp.rank = r; rp.world = world; rp.spp_begin = 0; rp.spp_end = -1;
-        if (g_dev.render(ctxs[r], &rp) != 0) Error("GPU %d render: %s", r, g_dev.last_error());
+        if (g_dev.render(ctxs[r], &rp) != 0) { Error("GPU %d render: %s", r, g_dev.last_error()); ok = false; }
     }
-    for (int r = 0; r < world; ++r) g_dev.sync(ctxs[r]);
+    if (ok && g_dev.film_gather(ctxs.data(), world, 0) != 0) { Error("film gather: %s", g_dev.last_error()); ok = false; }
     auto t2 = clk::now();
     Film &film = *camera->film;
     std::vector<float> rgbw(4 * film.pixels.size());
     uint64_t total[MI_CNT_COUNT] = {0};
-    for (int r = 0; r < world; ++r) {   // disjoint tiles: merging every rank's film is the gather
-        if (g_dev.film_download(ctxs[r], rgbw.data()) != 0) Error("GPU %d film: %s", r, g_dev.last_error());
-        film.MergeFilm(rgbw.data());
+    if (ok && g_dev.film_download(ctxs[0], rgbw.data()) != 0) { Error("GPU 0 film: %s", g_dev.last_error()); ok = false; }
+    for (int r = 0; r < world; ++r) {
         uint64_t c[MI_CNT_COUNT];
-        if (g_dev.counters(ctxs[r], c) == 0) for (int i = 0; i < MI_CNT_COUNT; ++i) total[i] += c[i];
+        if (ok && g_dev.counters(ctxs[r], c) == 0) for (int i = 0; i < MI_CNT_COUNT; ++i) total[i] += c[i];
         g_dev.ctx_destroy(ctxs[r]);
     }
+    if (!ok) { Error("rendering failed: no image written"); g_renderFailed = true; return; }   // never an image with missing tiles
+    film.MergeFilm(rgbw.data());
     film.WriteImage();
     if (!g_quiet) {
         double setup = std::chrono::duration<double>(t1 - t0).count(), render = std::chrono::duration<double>(t2 - t1).count();

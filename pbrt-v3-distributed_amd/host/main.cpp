@@ -46,5 +46,5 @@ int main(int argc, char *argv[]) {
     pbrtInit(options);
     for (const std::string &f : filenames) pbrtParseFile(f);
     pbrtCleanup();
-    return 0;
+    return (g_unsupportedCount > 0 || g_renderFailed) ? 1 : 0;
 }

@@ -4,7 +4,8 @@
 
 namespace pbrt_amd {
 
-int g_errorCount = 0;
+int g_errorCount = 0, g_unsupportedCount = 0;
+bool g_renderFailed = false;
 bool g_quiet = false;
 extern std::string CurrentParserLocation();   // parser.cpp
 
@@ -21,6 +22,11 @@ void Warning(const char *fmt, ...) {
 void Error(const char *fmt, ...) {
     ++g_errorCount;
     va_list a; va_start(a, fmt); report("Error", fmt, a); va_end(a);
+}
+
+void Unsupported(const char *fmt, ...) {
+    ++g_errorCount; ++g_unsupportedCount;
+    va_list a; va_start(a, fmt); report("Error (unsupported, the scene will not be rendered)", fmt, a); va_end(a);
 }
 
 void ParamSet::Add(Item item) {

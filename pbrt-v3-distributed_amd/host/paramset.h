@@ -16,7 +16,12 @@ namespace pbrt_amd {
 
 void Warning(const char *fmt, ...);
 void Error(const char *fmt, ...);
-extern int g_errorCount;
+// Something the reference renders and this host does not restate (blackbody / sampled-spectrum parameters): reported like an
+// Error AND counted, so that a render which would come out plausible but wrong is refused -- pbrtWorldEnd skips Render,
+// pbrt_amd_scene_load returns NULL and the command-line renderer exits non-zero (the reference itself would go on).
+void Unsupported(const char *fmt, ...);
+extern int g_errorCount, g_unsupportedCount;
+extern bool g_renderFailed;   // the device refused / failed a render: the command-line renderer exits non-zero
 extern bool g_quiet;
 
 struct RGB {

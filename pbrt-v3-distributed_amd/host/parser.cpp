@@ -181,7 +181,7 @@ ParamSet parseParams(Tokenizer &tk) {
             break;
         case ParamType::Spectrum:
             if (kind == 2 || kind == 3) {
-                Error("\"%s\": blackbody / sampled-spectrum parameters are not supported by this RGB path", item.name.c_str());
+                Unsupported("\"%s\": blackbody / sampled-spectrum parameters (parser.cpp:662-690 AddBlackbodySpectrum / AddSampledSpectrum[Files]) are not restated by this host", item.name.c_str());
                 continue;
             }
             if (nums.size() % 3) { Warning("Excess RGB values given with parameter \"%s\". Ignoring last %d of them", item.name.c_str(), (int)(nums.size() % 3)); nums.resize(nums.size() - nums.size() % 3); }

@@ -11,14 +11,15 @@ ROOT = ol.ROOT
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell.pbrt", "materials.pbrt"]
-# every traversal kernel instance the library ships runs the parity tests: "fast" = the lean steps of csrc/pt_trace_fast.h
-# (default for plain all-triangle scenes), "general" = TravNodeStep / TravLeafStep (what scenes with spheres / masks /
-# instances use; forced for plain scenes with PBRT_AMD_TRACE=general), "bvh8" = the quantised 8-wide nodes (PBRT_AMD_BVH8=1,
-# kept as a measured alternative: profiles/r02_*).  The variables are read by mi_scene_upload.
-TRACE_MODES = {"fast": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh8": {"PBRT_AMD_BVH8": "1"}}
+# every traversal kernel instance the library ships runs the parity tests: "bvh8c" = the lean steps over the 80-byte compressed
+# 8-wide nodes (csrc/pt_bvh8c.h + pt_trace_fast.h; the default for plain all-triangle scenes), "bvh4" = the lean steps over the
+# BVH4 (PBRT_AMD_TRACE=bvh4), "general" = TravNodeStep / TravLeafStep (what scenes with spheres / masks / instances use; forced
+# for plain scenes with PBRT_AMD_TRACE=general), "bvh8" = round 1's 128-byte quantised BVH8 (PBRT_AMD_BVH8=1; kept as a measured
+# alternative: profiles/r02_*).  The variables are read by mi_scene_upload.
+TRACE_MODES = {"bvh8c": {}, "bvh4": {"PBRT_AMD_TRACE": "bvh4"}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh8": {"PBRT_AMD_BVH8": "1"}}
 
 
-def make_ctx(sc, mode="fast", **kw):
+def make_ctx(sc, mode="bvh8c", **kw):
     env = TRACE_MODES[mode]
     saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_BVH8")}
     for k in saved:
@@ -111,6 +112,7 @@ def test_closest_hit_matches_reference_traversal(pair):
     # any-hit with finite segments
     r2["tmax"] = rng.uniform(0.5, 600.0, len(o)).astype(np.float32)
     assert np.array_equal(ctx.intersect_p(r2), ol.intersect_p(sc, r2)[0])
+    assert ctx.counters()["trace_guard_trips"] == 0
     # rays with exactly-zero direction components (1/d = +-inf in Bounds3::IntersectP; Sobol' values like 0.5 produce them on
     # axis-aligned surfaces) incl. -0 and origins that sit exactly on bounding planes (vertex coordinates of the scene)
     n3 = 6000
@@ -172,6 +174,7 @@ def test_render_image_vs_oracle(pair):
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     cnt = ctx.counters()
     assert cnt["camera_rays"] == rcnt["camera_rays"]
+    assert cnt["trace_guard_trips"] == 0
     # ray counts follow the reference's issue conditions up to decision flips
     assert abs(cnt["closest_rays"] - rcnt["closest_rays"]) <= 2e-3 * rcnt["closest_rays"]
     assert abs(cnt["shadow_rays"] - rcnt["shadow_rays"]) <= 2e-3 * rcnt["shadow_rays"]
@@ -192,6 +195,24 @@ def test_tile_sharding_is_exact(pair):
     assert own_only.mean() > 0.98
     assert np.array_equal(acc[own_only].view(np.uint32), whole[own_only].view(np.uint32))
     assert np.allclose(acc, whole, rtol=1e-6, atol=1e-7)
+
+
+def test_film_gather_of_two_contexts_equals_the_single_render():
+    """mi_film_gather (the exchange step of the tile-sharded render): two contexts render the tiles of rank 0 / rank 1 of 2 -- both calls
+    return before the GPU has finished (mi_render is asynchronous), so the two renders overlap -- and the gather sums them into the
+    root film.  On this one-GPU box the contexts share device 0, so the sum runs as a device kernel (RCCL refuses duplicate devices);
+    with one context per GPU the same call issues one grouped ncclReduce."""
+    sc = pa.Scene(os.path.join(ROOT, "scenes", "materials.pbrt"))
+    whole = pa.Context(sc); whole.render(); ref = whole.film(); whole.close()
+    a, b = pa.Context(sc), pa.Context(sc)
+    a.render(rank=0, world=2, sync=False)
+    b.render(rank=1, world=2, sync=False)
+    pa.film_gather([a, b], root=0)
+    got = a.film()
+    own_only = ref[..., 3] == sc.info["spp"]
+    assert np.array_equal(got[own_only].view(np.uint32), ref[own_only].view(np.uint32))
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    a.close(); b.close()
 
 
 # ---------------------------------------------------------------- against the committed reference fixtures
@@ -264,8 +285,8 @@ def _config_scene(name, tmp):
     return pa.Scene(out)
 
 
-@pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "fast"), ("sanmiguel", "general"), ("sanmiguel", "bvh8"),
-                                       ("bathroom", "fast"), ("bathroom", "general"), ("bathroom", "bvh8")])
+@pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "bvh8c"), ("sanmiguel", "bvh4"), ("sanmiguel", "general"), ("sanmiguel", "bvh8"),
+                                       ("bathroom", "bvh8c"), ("bathroom", "bvh4"), ("bathroom", "general"), ("bathroom", "bvh8")])
 def test_baseline_configs_reduced(name, mode, tmp_path):
     """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
     (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
@@ -283,7 +304,7 @@ def test_baseline_configs_reduced(name, mode, tmp_path):
     # with the per-sample criterion below as the tight one.
     min_frac, max_relmse = (0.985, 5e-4) if name == "bathroom" else (0.995, 1e-4)
     assert frac >= min_frac and relmse <= max_relmse, (name, frac, relmse)
-    assert cnt["camera_rays"] == rcnt["camera_rays"]
+    assert cnt["camera_rays"] == rcnt["camera_rays"] and cnt["trace_guard_trips"] == 0
     assert abs(cnt["closest_rays"] - rcnt["closest_rays"]) <= 3e-3 * rcnt["closest_rays"]
     assert abs(cnt["shadow_rays"] - rcnt["shadow_rays"]) <= 3e-3 * rcnt["shadow_rays"]
     # per camera sample: >= 99.9 % within 1e-4 (1 + |L|)

@@ -1,0 +1,48 @@
+"""CPU: the reference-side binding of INTEGRATION.md s.2, compiled for real (SURVEY.md s.8 row b).
+
+oracle/ref_build/wavefrontpath.cpp is the `WavefrontPathIntegrator : public Integrator` + FlattenScene a pbrt-v3 maintainer would add,
+built against the UNMODIFIED reference (libpbrt_ref.a) into oracle/_ref/pbrt_ref_wavefront: the reference's own main, parser, API state
+machine, shape factories, Loop subdivision and BVH build run as they are, the stub flattens the reference's `Scene` / `BVHAccel` /
+`GeometricPrimitive` / `Material` (through the BxDFs its ComputeScatteringFunctions builds) / `Light` / camera / film / sampler objects
+to a `mi_scene_desc`, and the backend renders THAT description -- here the CPU oracle (a GPU box sets PBRT_AMD_BACKEND=device and
+points PBRT_AMD_BACKEND_LIB at libpbrt_amd.so).  The resulting image goes through the reference's own Film::MergeFilmTile / WriteImage
+and must equal what `pbrt_ref` renders for the same file up to the rounding of the film sum (a pixel that also receives an edge sample
+of a neighbour adds it in a different order: 1 ulp of the sum in < 0.1 % of the pixels)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pa = ol.pa
+ROOT = ol.ROOT
+REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
+ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
+
+CASES = [("cornell", os.path.join(ROOT, "scenes", "cornell.pbrt"), []),
+         ("materials", os.path.join(ROOT, "scenes", "materials.pbrt"), []),
+         # the reference's own example scene, unmodified: Sphere area light, Halton sampler, Loop subdivision surfaces
+         ("killeroo-simple", "/root/reference/scenes/killeroo-simple.pbrt", ["--cropwindow", "0.3", "0.7", "0.3", "0.7"])]
+
+
+@pytest.mark.parametrize("name,scene,extra", CASES, ids=[c[0] for c in CASES])
+def test_reference_scene_through_the_stub_equals_pbrt_ref(name, scene, extra, tmp_path):
+    if not (os.access(REF, os.X_OK) and os.access(STUB, os.X_OK)):
+        pytest.skip("oracle/_ref/pbrt_ref[_wavefront] not built here (needs /root/reference)")
+    if not os.path.exists(scene):
+        pytest.skip("scene file not present: %s" % scene)
+    a, b = str(tmp_path / "stub.pfm"), str(tmp_path / "ref.pfm")
+    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE)
+    cwd = os.path.dirname(scene)
+    r1 = subprocess.run([STUB, "--quiet", "--nthreads", "4"] + extra + ["--outfile", a, scene], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and os.path.exists(a), r1.stderr[-800:]
+    r2 = subprocess.run([REF, "--quiet", "--nthreads", "4"] + extra + ["--outfile", b, scene], cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and os.path.exists(b), r2.stderr[-800:]
+    ia, ib = pa.read_pfm(a), pa.read_pfm(b)
+    assert ia.shape == ib.shape and ib.mean() > 1e-3
+    d = np.abs(ia - ib).max(-1)
+    assert d.max() <= 5e-7, float(d.max())
+    assert (d == 0).mean() >= 0.998, float((d == 0).mean())
