@@ -471,6 +471,10 @@ int64_t mi_film_pixel_count(mi_ctx *ctx);
  * Waits for the renders of all contexts first and returns when the root film is complete.  n == 1 is a no-op; contexts that
  * share a device (testing on a one-GPU box) are summed by a device kernel instead, since RCCL refuses duplicate devices. */
 int mi_film_gather(mi_ctx **ctxs, int n, int root);
+/* Stage-level BSDF lobes (core/reflection.cpp:703-785 building blocks): BxDF::f, Pdf and Sample_f(wo, u) of bxdfs[i] for record i
+ * (wo, wi in the shading frame) -- replays the vectors dumped from the reference's own BxDF classes on the device. */
+int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, const float *wi, const float *u, int64_t n, float *f, float *pdf,
+                 float *wi_s, float *pdf_s, float *f_s, int32_t *type_s);
 /* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
  * 3 lean steps over the 80-byte compressed BVH8 (default for plain all-triangle scenes), 4 two-level (instanced) scene;
  * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_trace_info", "mi_film_gather", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -341,6 +341,20 @@ def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=Fa
         raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
     keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]
     return hits, dict(zip(keys, [int(v) for v in st]))
+
+
+def bxdf_eval(rows, device=0):
+    """mi_bxdf_eval on records shaped like tests/golden/ref_vectors.npz 'bxdfs' -> dict of the device's f, pdf, Sample_f results"""
+    n = len(rows)
+    b = np.ascontiguousarray(rows["bxdf"]); wo = np.ascontiguousarray(rows["wo"]); wi = np.ascontiguousarray(rows["wi"]); u = np.ascontiguousarray(rows["u"])
+    out = {"f": np.zeros((n, 3), np.float32), "pdf": np.zeros(n, np.float32), "wi_s": np.zeros((n, 3), np.float32), "pdf_s": np.zeros(n, np.float32),
+           "f_s": np.zeros((n, 3), np.float32), "type_s": np.zeros(n, np.int32)}
+    L = device_lib()
+    L.mi_bxdf_eval.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 6
+    if L.mi_bxdf_eval(device, _ptr(b), _ptr(wo), _ptr(wi), _ptr(u), n, _ptr(out["f"]), _ptr(out["pdf"]), _ptr(out["wi_s"]), _ptr(out["pdf_s"]), _ptr(out["f_s"]),
+                      _ptr(out["type_s"])) != 0:
+        raise RuntimeError("mi_bxdf_eval: %s" % L.mi_last_error().decode())
+    return out
 
 
 def film_gather(ctxs, root=0):

@@ -64,8 +64,11 @@ struct PathState {
     uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
     uint2 *keyrank;            // because the sort kernels walk them in queue order, not per path
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
+    uint32_t *q_key;           // spatial bin (RayBinKey) of every path-extension ray k_shade queues, parallel to q_ext[qout]; null: binning off
+    float bin_min[3], bin_scale[3];   // scene bound -> 8 cells per axis
     uint32_t *qcount;          // [0],[1] extension queues, [2] shadow, [3] mis, [4] sorted total
     uint32_t *keycount, *keyoffset;
+    uint32_t *bin_total, *bin_offset;   // [PT_RAYBIN_KEYS]
     uint32_t *blockhist;       // [gridBlocks][nkeys]
     uint32_t *cursor;          // [8] per-XCD-segment fetch cursors of k_trace
     unsigned long long *counters;
@@ -450,6 +453,71 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     }
 }
 
+// ---- ray binning before traversal (round 2).  The traversal kernels are bound by the memory side: incoherent rays pull 96 GB through
+// the L2s per launch for a 1.25 GB working set (profiles/r02_*: L2 hit rate 72 %, 113 M misses per launch).  Path-extension rays are
+// therefore binned by WHERE THEY START AND WHICH WAY THEY GO -- 8 x 8 x 8 cells of the scene bound (Morton order) x direction octant =
+// 4096 bins -- with one counting sort per bounce (the queue is order-free: results do not depend on it).  k_trace cuts the queue into
+// 8 contiguous XCD segments, so each XCD's 4 MiB L2 serves one octant of the scene, and the 64 rays a wave pulls come from one cell
+// and one direction octant: they walk the same subtree (hits in L1 / L2 instead of HBM) and take similar numbers of steps.
+#define PT_RAYBIN_KEYS 4096u
+PT_DEV uint32_t RayBinKey(const PathState &ps, const V3 &o, const V3 &d) {
+    int cx = (int)((o.x - ps.bin_min[0]) * ps.bin_scale[0]), cy = (int)((o.y - ps.bin_min[1]) * ps.bin_scale[1]), cz = (int)((o.z - ps.bin_min[2]) * ps.bin_scale[2]);
+    cx = cx < 0 ? 0 : (cx > 7 ? 7 : cx); cy = cy < 0 ? 0 : (cy > 7 ? 7 : cy); cz = cz < 0 ? 0 : (cz > 7 ? 7 : cz);
+    uint32_t m = 0;   // 9-bit Morton code
+#pragma unroll
+    for (int b = 0; b < 3; ++b) m |= (((uint32_t)cx >> b) & 1u) << (3 * b) | (((uint32_t)cy >> b) & 1u) << (3 * b + 1) | (((uint32_t)cz >> b) & 1u) << (3 * b + 2);
+    uint32_t oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+    return (m << 3) | oct;
+}
+// histogram of the bins per block (LDS atomics; rank of every ray inside its block and bin), as k_keycount does for materials
+__global__ void __launch_bounds__(PT_BLOCK) k_raybin_count(PathState ps, uint32_t qin) {
+    __shared__ uint32_t lhist[PT_RAYBIN_KEYS];
+    for (uint32_t k = threadIdx.x; k < PT_RAYBIN_KEYS; k += PT_BLOCK) lhist[k] = 0;
+    __syncthreads();
+    const uint32_t n = ps.qcount[qin];
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        if (i < n) {
+            uint32_t key = ps.q_key[i];
+            uint32_t rank = atomicAdd(&lhist[key], 1u);
+            ps.keyrank[i] = make_uint2(key, rank);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < PT_RAYBIN_KEYS; k += PT_BLOCK) ps.blockhist[(size_t)blockIdx.x * PT_RAYBIN_KEYS + k] = lhist[k];
+}
+// per bin: exclusive scan over the blocks (in place) + the bin's total; one thread per bin
+__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scan_blocks(PathState ps, uint32_t nblocks) {
+    uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (k >= PT_RAYBIN_KEYS) return;
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < nblocks; ++b) { uint32_t h = ps.blockhist[(size_t)b * PT_RAYBIN_KEYS + k]; ps.blockhist[(size_t)b * PT_RAYBIN_KEYS + k] = acc; acc += h; }
+    ps.bin_total[k] = acc;
+}
+// exclusive scan over the 4096 bin totals (one block: 16 bins per thread, block scan in LDS)
+__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scan_bins(PathState ps) {
+    __shared__ uint32_t part[PT_BLOCK];
+    const uint32_t per = PT_RAYBIN_KEYS / PT_BLOCK, k0 = threadIdx.x * per;
+    uint32_t acc = 0;
+    for (uint32_t j = 0; j < per; ++j) acc += ps.bin_total[k0 + j];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < PT_BLOCK; ++t) { uint32_t v = part[t]; part[t] = run; run += v; } }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t j = 0; j < per; ++j) { uint32_t v = ps.bin_total[k0 + j]; ps.bin_offset[k0 + j] = run; run += v; }
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scatter(PathState ps, uint32_t qin) {
+    const uint32_t n = ps.qcount[qin];
+    for (ChunkIter it(n); it.more(); it.next()) {
+        uint32_t i = it.item();
+        if (i < n) {
+            uint2 kr = ps.keyrank[i];
+            ps.q_sorted[ps.bin_offset[kr.x] + ps.blockhist[(size_t)blockIdx.x * PT_RAYBIN_KEYS + kr.x] + kr.y] = ps.q_ext[qin][i];
+        }
+    }
+}
+
 // ---- counting sort of the traced paths by material key, without global atomics:
 //   k_keycount : every (persistent) block histograms the keys of ITS chunks in LDS -- wave ballots merge equal
 //                keys, so an LDS atomic is issued per (wave, distinct key) -- and records each path's rank inside
@@ -618,6 +686,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = i < n;
         bool cont = false, wantShadow = false, wantMis = false;
+        uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
         if (active) {
             slot = ps.q_sorted[i];
@@ -699,6 +768,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     // null BSDF: step through the surface, same bounce count, no sampler use (path.cpp:108-113)
                     V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, rd);
                     ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                    if (ps.q_key) rayKey = RayBinKey(ps, no, rd);
                     cont = true;
                     noDiff = TEX;
                 } else {
@@ -862,6 +932,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             else beta = beta / (1 - q);
                         }
                         if (cont) {
+                            if (ps.q_key) rayKey = RayBinKey(ps, no, wi);
                             ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                             ps.rec[slot].ray_d = make_float4(wi.x, wi.y, wi.z, 0);
                             ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -878,7 +949,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         }
         uint32_t posE, posS, posM;
         wave_append3(&ps.qcount[qout], &ps.qcount[QC_SHADOW], &ps.qcount[QC_MIS], cont, wantShadow, wantMis, &posE, &posS, &posM);
-        if (cont) ps.q_ext[qout][posE] = slot;
+        if (cont) { ps.q_ext[qout][posE] = slot; if (ps.q_key) ps.q_key[posE] = rayKey; }
         if (wantShadow) ps.q_shadow[posS] = slot;
         if (wantMis) ps.q_mis[posM] = slot;
         PROBE(13)   // L store + queue appends
@@ -1136,6 +1207,7 @@ struct mi_ctx {
     int tilesRank = -1, tilesWorld = -1;     // the tile list resident in `tiles` (re-uploaded only when the sharding changes)
     std::vector<uint32_t> tilesHost;         // kept alive: the upload is asynchronous
     size_t tilesCount = 0;
+    bool rayBin = true;                      // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
     bool useC8 = false;                      // lean steps over the compressed 8-wide BVH (pt_bvh8c.h): the default for plain scenes
     bool useFast = false;                    // lean traversal steps (pt_trace_fast.h): all-triangle scenes without masks / instances
     bool useBvh8 = false;
@@ -1327,6 +1399,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         return fail("mi_scene_upload: Integrator \"volpath\" (participating media) is not implemented on the device yet; \"path\" scenes render with their media ignored, as PathIntegrator does");
     if (d->material_bssrdf)   // subsurface / kdsubsurface materials: the probe-ray kernels do not exist yet (host + CPU oracle carry them)
         return fail("mi_scene_upload: materials with a BSSRDF (\"subsurface\", \"kdsubsurface\") are not implemented on the device yet");
+    { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = !(e && e[0] == '0'); }
     c->hasNullMat = false;
     for (uint32_t m = 0; m < d->n_meshes; ++m) c->hasNullMat |= d->meshes[m].material < 0;
     c->tilesRank = c->tilesWorld = -1;
@@ -1700,6 +1773,10 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     { DevBuf &b = next(); if (upload(c, b, d->light_func, (size_t)d->n_lights * 4)) return -1; sc.light_func = b.as<float>(); }
     { DevBuf &b = next(); if (upload(c, b, d->light_cdf, ((size_t)d->n_lights + 1) * 4)) return -1; sc.light_cdf = b.as<float>(); }
     // ---- SpatialLightDistribution (lightdistrib.cpp:96-126 sizes the grid; ComputeDistribution for all voxels on the device)
+    for (int i = 0; i < 3; ++i) {   // scene bound for the ray bins
+        sc.sp_bmin_all[i] = d->n_bvh_nodes ? d->bvh_nodes[0].bmin[i] : 0.f;
+        sc.sp_bmax_all[i] = d->n_bvh_nodes ? d->bvh_nodes[0].bmax[i] : 0.f;
+    }
     sc.light_strategy = MI_LIGHT_STRATEGY_TABLE;
     if (d->integrator.light_strategy == MI_LIGHT_STRATEGY_SPATIAL && d->n_lights > 1) {
         const int maxVoxels = d->integrator.spatial_max_voxels > 0 ? d->integrator.spatial_max_voxels : 64;
@@ -1879,7 +1956,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->cap >= cap && !c->stateBufs.empty()) return 0;
     for (auto &b : c->stateBufs) b.release();
     c->stateBufs.clear();
-    c->stateBufs.resize(32);
+    c->stateBufs.resize(40);
     int nb = 0;
     PathState &ps = c->ps;
     std::memset(&ps, 0, sizeof(ps));
@@ -1890,7 +1967,15 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(q_sorted, uint32_t, cap);
     ALLOC(qcount, uint32_t, QC_COUNT);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, 8);
-    ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * c->nkeys);
+    ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
+    if (c->rayBin) {
+        ALLOC(q_key, uint32_t, cap); ALLOC(bin_total, uint32_t, PT_RAYBIN_KEYS); ALLOC(bin_offset, uint32_t, PT_RAYBIN_KEYS);
+        for (int a = 0; a < 3; ++a) {   // 8 cells per axis over scene.WorldBound() (the root box of the reference's BVH)
+            float lo = c->sc.sp_bmin_all[a], hi = c->sc.sp_bmax_all[a];
+            ps.bin_min[a] = lo;
+            ps.bin_scale[a] = hi > lo ? 8.0f / (hi - lo) : 0.0f;
+        }
+    }
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
     c->spill8 = std::max(1, c->stackNeed8 - PT_LDS_STACK8);
     {   // one spill area serves whichever traversal runs (BVH4: 4-byte entries, BVH8: 8-byte entries)
@@ -1981,8 +2066,23 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         HIP_TRY(hipMemsetAsync(ps.qcount + qout, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(ps.qcount + QC_SHADOW, 0, 2 * sizeof(uint32_t), st));   // shadow + mis
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
+        bool binned = false;
+        if (c->rayBin && iter > 0) {   // camera rays (iter 0) come out of k_raygen tile by tile: coherent already
+            tic(c, MI_K_SORT);
+            hipLaunchKernelGGL(k_raybin_count, grid, block, 0, st, ps, qin);
+            hipLaunchKernelGGL(k_raybin_scan_blocks, dim3(PT_RAYBIN_KEYS / PT_BLOCK), block, 0, st, ps, (uint32_t)c->gridBlocks);
+            hipLaunchKernelGGL(k_raybin_scan_bins, dim3(1), block, 0, st, ps);
+            hipLaunchKernelGGL(k_raybin_scatter, grid, block, 0, st, ps, qin);
+            toc(c);
+            binned = true;
+        }
         tic(c, MI_K_CLOSEST);
-        LAUNCH_TRACE(0);
+        {
+            PathState psRun = ps;   // the traversal walks the binned copy of the queue; the material sort below reads the original (same set of paths)
+            if (binned) psRun.q_ext[qin] = ps.q_sorted;
+            PathState &ps = psRun;
+            LAUNCH_TRACE(0);
+        }
         toc(c);
         tic(c, MI_K_SORT);
         hipLaunchKernelGGL(k_keycount, grid, block, c->nkeys * sizeof(uint32_t), st, sc, ps, qin, c->nkeys);
@@ -2413,6 +2513,50 @@ int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int 
     stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
     stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
     if (st.mismatch) return fail("mi_bvh8_validate: the packed node step (Bvh8StepWords) and the struct form (Bvh8Step) disagree on " + std::to_string(st.mismatch) + " node visits");
+    return 0;
+}
+// stage-level BxDF evaluation: f / Pdf / Sample_f of one lobe per record, per-lane lobe records (the instantiation the textured shading
+// kernel uses; the constant-material kernel runs the same code on wave-uniform records)
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_bxdf(const mi_bxdf *b, const float *wo, const float *wi, const float *u, int64_t n, float *f, float *pdf, float *wi_s,
+                                                         float *pdf_s, float *f_s, int32_t *type_s) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const mi_bxdf *bp = b + i;
+    V3 o(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), w(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    RGB fv = BxdfF<false>(bp, o, w);
+    f[3 * i] = fv.r; f[3 * i + 1] = fv.g; f[3 * i + 2] = fv.b;
+    pdf[i] = BxdfPdf<false>(bp, o, w);
+    BxdfSample s = BxdfSample_f<false>(bp, o, u[2 * i], u[2 * i + 1], BxdfFlags(bp->type));
+    wi_s[3 * i] = s.wi.x; wi_s[3 * i + 1] = s.wi.y; wi_s[3 * i + 2] = s.wi.z;
+    pdf_s[i] = s.pdf;
+    f_s[3 * i] = s.f.r; f_s[3 * i + 1] = s.f.g; f_s[3 * i + 2] = s.f.b;
+    type_s[i] = s.sampledType;
+}
+int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, const float *wi, const float *u, int64_t n, float *f, float *pdf, float *wi_s, float *pdf_s,
+                 float *f_s, int32_t *type_s) {
+    if (!bxdfs || !wo || !wi || !u || !f || !pdf || !wi_s || !pdf_s || !f_s || !type_s || n < 0) return fail("mi_bxdf_eval: bad argument");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) return fail("mi_bxdf_eval: no such HIP device (this library has no CPU fallback)");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    DevBuf db, dwo, dwi, du, df, dp, dws, dps, dfs, dts;
+    size_t N = (size_t)n;
+    if (db.alloc(N * sizeof(mi_bxdf)) || dwo.alloc(N * 12) || dwi.alloc(N * 12) || du.alloc(N * 8) || df.alloc(N * 12) || dp.alloc(N * 4) || dws.alloc(N * 12) ||
+        dps.alloc(N * 4) || dfs.alloc(N * 12) || dts.alloc(N * 4)) return -1;
+    HIP_TRY(hipMemcpy(db.p, bxdfs, N * sizeof(mi_bxdf), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dwo.p, wo, N * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dwi.p, wi, N * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du.p, u, N * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_bxdf, dim3((unsigned)((N + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, 0, db.as<mi_bxdf>(), dwo.as<float>(), dwi.as<float>(), du.as<float>(), n,
+                       df.as<float>(), dp.as<float>(), dws.as<float>(), dps.as<float>(), dfs.as<float>(), dts.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(f, df.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, dp.p, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(wi_s, dws.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_s, dps.p, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f_s, dfs.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(type_s, dts.p, N * 4, hipMemcpyDeviceToHost));
+    for (DevBuf *x : {&db, &dwo, &dwi, &du, &df, &dp, &dws, &dps, &dfs, &dts}) x->release();
     return 0;
 }
 // the same for the 80-byte compressed layout the traversal kernels run (pt_bvh8c.h): build, structural checks in exact arithmetic, host emulation

@@ -87,6 +87,7 @@ struct DevScene {
     const float *sp_func, *sp_cdf, *sp_func_int;   // [nvox][n_lights], [nvox][n_lights + 1], [nvox]
     int32_t light_strategy, sp_nvox[3];
     float sp_bmin[3], sp_bmax[3];                  // scene.WorldBound()
+    float sp_bmin_all[3], sp_bmax_all[3];          // the same for every scene (sp_bmin / sp_bmax are set for the spatial light strategy only): ray binning
     uint32_t n_tris, n_nodes, n_lights, n_materials, n_infinite;
     int32_t stack_need;             // 3 * BVH4 depth + 1
     mi_camera camera;

@@ -1,7 +1,12 @@
-// BSSRDFTable for the subsurface materials: what SubsurfaceMaterial / KdSubsurfaceMaterial compute in their
-// constructors -- ComputeBeamDiffusionBSSRDF(g, eta, &table) with table(100, 64) (materials/subsurface.h:69-76, core/bssrdf.cpp:145-176):
-// photon beam diffusion, single + multiple scattering, tabulated over 100 albedos x 64 optical radii, plus the effective albedo and the
-// per-albedo CDF of the spline interpolant.  Float arithmetic in the reference's order (the table feeds a bit-exact oracle).
+// Radial scattering profiles for the subsurface materials.
+//
+// SubsurfaceMaterial / KdSubsurfaceMaterial tabulate, once per (g, eta), the photon-beam-diffusion profile of a unit-mean-free-path
+// medium over 100 single-scattering albedos x 64 optical radii, its integral (the effective albedo) and the running integral of
+// the Catmull-Rom interpolant per albedo (what the reference does in ComputeBeamDiffusionBSSRDF, core/bssrdf.cpp:145-176, with
+// BSSRDFTable(100, 64), materials/subsurface.h:69-76).  The table feeds TabulatedBSSRDF on the oracle side bit for bit, so every
+// value below is produced with the reference's float operations in the reference's order -- the ORGANISATION is this host's own:
+// a DipoleMedium holds the per-albedo constants (reduced coefficients, diffusion coefficient, extrapolated boundary, the weights of
+// fluence and vector irradiance in the boundary condition) and offers the two radial terms; polynomial fits are data + one evaluator.
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -10,86 +15,125 @@
 
 namespace pbrt_amd {
 namespace {
-const Float kInv4Pi = 0.07957747154594766788;   // kPi: geom.h
+const Float kInv4Pi = 0.07957747154594766788;
+const int kDepthSamples = 100;   // both radial terms integrate over 100 exponentially distributed depths
 
-// core/bssrdf.cpp:43-67 -- polynomial fits; one coefficient of the first is a double constant in the reference and is kept as one
-Float FresnelMoment1(Float eta) {
-    Float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
-    if (eta < 1) return 0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945 * eta3 + 2.49277f * eta4 - 0.68441f * eta5;
-    return -4.61686f + 11.1136f * eta - 10.4646f * eta2 + 5.11455f * eta3 - 1.27198f * eta4 + 0.12746f * eta5;
-}
+// sum_k c[k] eta^k with the powers formed by repeated multiplication and the sum taken left to right in Float.  `wideFrom` marks the
+// term from which the reference's expression carries a double literal: from there on the partial sum is held in double (usual
+// arithmetic conversions), and rounded to Float once at the end.
+struct PolyFit {
+    double c[6];
+    int wideFrom;   // 6: all Float
+    Float at(Float x) const {
+        Float pw[6];
+        pw[0] = 1; pw[1] = x;
+        for (int k = 2; k < 6; ++k) pw[k] = pw[k - 1] * x;
+        Float accF = (Float)c[0];
+        int k = 1;
+        for (; k < 6 && k < wideFrom; ++k) accF = accF + (Float)c[k] * pw[k];
+        if (k == 6) return accF;
+        double acc = (double)accF + c[k] * (double)pw[k];
+        for (++k; k < 6; ++k) acc = acc + (double)((Float)c[k] * pw[k]);
+        return (Float)acc;
+    }
+};
+// first and second angular moments of the Fresnel reflectance as fits in the relative index (core/bssrdf.cpp:43-67)
+const PolyFit kMoment1Below = {{0.45966f, -1.73965f, 3.37668f, -3.904945, 2.49277f, -0.68441f}, 3};
+const PolyFit kMoment1Above = {{-4.61686f, 11.1136f, -10.4646f, 5.11455f, -1.27198f, 0.12746f}, 6};
+const PolyFit kMoment2Below = {{0.27614f, -0.87350f, 1.12077f, -0.65095f, 0.07883f, 0.04860f}, 6};
+Float FresnelMoment1(Float eta) { return (eta < 1 ? kMoment1Below : kMoment1Above).at(eta); }
 Float FresnelMoment2(Float eta) {
-    Float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
-    if (eta < 1) return 0.27614f - 0.87350f * eta + 1.12077f * eta2 - 0.65095f * eta3 + 0.07883f * eta4 + 0.04860f * eta5;
-    Float r_eta = 1 / eta, r_eta2 = r_eta * r_eta, r_eta3 = r_eta2 * r_eta;
-    return -547.033f + 45.3087f * r_eta3 - 218.725f * r_eta2 + 458.843f * r_eta + 404.557f * eta - 189.519f * eta2 + 54.9327f * eta3 - 9.00603f * eta4 +
-           0.63942f * eta5;
+    if (eta < 1) return kMoment2Below.at(eta);
+    // above one the fit mixes inverse and direct powers; summed in the order the reference writes them
+    Float e2 = eta * eta, e3 = e2 * eta, e4 = e3 * eta, e5 = e4 * eta;
+    Float inv = 1 / eta, inv2 = inv * inv, inv3 = inv2 * inv;
+    const Float coef[9] = {-547.033f, 45.3087f, -218.725f, 458.843f, 404.557f, -189.519f, 54.9327f, -9.00603f, 0.63942f};
+    const Float term[9] = {1, inv3, inv2, inv, eta, e2, e3, e4, e5};
+    Float s = coef[0];
+    for (int k = 1; k < 9; ++k) s = s + coef[k] * term[k];
+    return s;
 }
-Float FrDielectric(Float cosThetaI, Float etaI, Float etaT) {   // core/reflection.cpp:47-68
-    cosThetaI = Clamp(cosThetaI, -1, 1);
-    if (!(cosThetaI > 0.f)) { std::swap(etaI, etaT); cosThetaI = std::abs(cosThetaI); }
-    Float sinThetaI = std::sqrt(std::max((Float)0, 1 - cosThetaI * cosThetaI));
-    Float sinThetaT = etaI / etaT * sinThetaI;
-    if (sinThetaT >= 1) return 1;
-    Float cosThetaT = std::sqrt(std::max((Float)0, 1 - sinThetaT * sinThetaT));
-    Float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
-    Float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
-    return (Rparl * Rparl + Rperp * Rperp) / 2;
+// unpolarised Fresnel reflectance at a dielectric boundary (core/reflection.cpp:47-68)
+Float DielectricReflectance(Float cosI, Float etaOutside, Float etaInside) {
+    cosI = Clamp(cosI, -1, 1);
+    Float n1 = etaOutside, n2 = etaInside;
+    if (!(cosI > 0.f)) { std::swap(n1, n2); cosI = std::abs(cosI); }
+    Float sinI = std::sqrt(std::max((Float)0, 1 - cosI * cosI));
+    Float sinT = n1 / n2 * sinI;
+    if (sinT >= 1) return 1;   // total internal reflection
+    Float cosT = std::sqrt(std::max((Float)0, 1 - sinT * sinT));
+    Float parallel = ((n2 * cosI) - (n1 * cosT)) / ((n2 * cosI) + (n1 * cosT));
+    Float perpendicular = ((n1 * cosI) - (n2 * cosT)) / ((n1 * cosI) + (n2 * cosT));
+    return (parallel * parallel + perpendicular * perpendicular) / 2;
 }
-Float PhaseHG(Float cosTheta, Float g) {   // core/medium.h:69-72
-    Float denom = 1 + g * g + 2 * g * cosTheta;
-    return kInv4Pi * (1 - g * g) / (denom * std::sqrt(denom));
+Float HenyeyGreenstein(Float cosTheta, Float g) {   // core/medium.h:69-72
+    Float d = 1 + g * g + 2 * g * cosTheta;
+    return kInv4Pi * (1 - g * g) / (d * std::sqrt(d));
 }
-// core/bssrdf.cpp:69-117: multiple scattering, 100 exponentially distributed real-source depths of the dipole
-Float BeamDiffusionMS(Float sigma_s, Float sigma_a, Float g, Float eta, Float r) {
-    const int nSamples = 100;
-    Float Ed = 0;
-    Float sigmap_s = sigma_s * (1 - g);
-    Float sigmap_t = sigma_a + sigmap_s;
-    Float rhop = sigmap_s / sigmap_t;
-    Float D_g = (2 * sigma_a + sigmap_s) / (3 * sigmap_t * sigmap_t);
-    Float sigma_tr = std::sqrt(sigma_a / D_g);
-    Float fm1 = FresnelMoment1(eta), fm2 = FresnelMoment2(eta);
-    Float ze = -2 * D_g * (1 + 3 * fm2) / (1 - 2 * fm1);
-    Float cPhi = .25f * (1 - 2 * fm1), cE = .5f * (1 - 3 * fm2);
-    for (int i = 0; i < nSamples; ++i) {
-        Float zr = -std::log(1 - (i + .5f) / nSamples) / sigmap_t;
-        Float zv = -zr + 2 * ze;
-        Float dr = std::sqrt(r * r + zr * zr), dv = std::sqrt(r * r + zv * zv);
-        Float phiD = kInv4Pi / D_g * (std::exp(-sigma_tr * dr) / dr - std::exp(-sigma_tr * dv) / dv);
-        Float EDn = kInv4Pi * (zr * (1 + sigma_tr * dr) * std::exp(-sigma_tr * dr) / (dr * dr * dr) - zv * (1 + sigma_tr * dv) * std::exp(-sigma_tr * dv) / (dv * dv * dv));
-        Float E = phiD * cPhi + EDn * cE;
-        Float kappa = 1 - std::exp(-2 * sigmap_t * (dr + zr));
-        Ed += kappa * rhop * rhop * E;
+// i-th of the stratified exponential depths: -ln(1 - (i + 1/2) / N)
+Float DepthSample(int i) { return -std::log(1 - (i + .5f) / kDepthSamples); }
+
+// A semi-infinite medium with scattering / absorption coefficients (s, a), anisotropy g, relative index eta, seen through photon beam
+// diffusion: constants of core/bssrdf.cpp:69-117 (multiple scattering) and :119-143 (single scattering).
+struct DipoleMedium {
+    Float s, a, g, eta;
+    // reduced coefficients and the classical-diffusion quantities derived from them
+    Float sReduced, tReduced, albedoReduced, diffusion, transport, boundaryDepth, wFluence, wIrradiance;
+    DipoleMedium(Float s_, Float a_, Float g_, Float eta_) : s(s_), a(a_), g(g_), eta(eta_) {
+        sReduced = s * (1 - g);
+        tReduced = a + sReduced;
+        albedoReduced = sReduced / tReduced;
+        diffusion = (2 * a + sReduced) / (3 * tReduced * tReduced);           // Grosjean's non-classical coefficient
+        transport = std::sqrt(a / diffusion);
+        Float m1 = FresnelMoment1(eta), m2 = FresnelMoment2(eta);
+        boundaryDepth = -2 * diffusion * (1 + 3 * m2) / (1 - 2 * m1);        // where the fluence is extrapolated to zero
+        wFluence = .25f * (1 - 2 * m1);
+        wIrradiance = .5f * (1 - 3 * m2);
     }
-    return Ed / nSamples;
-}
-// core/bssrdf.cpp:119-143: single scattering beyond the critical angle
-Float BeamDiffusionSS(Float sigma_s, Float sigma_a, Float g, Float eta, Float r) {
-    Float sigma_t = sigma_a + sigma_s, rho = sigma_s / sigma_t;
-    Float tCrit = r * std::sqrt(eta * eta - 1);
-    Float Ess = 0;
-    const int nSamples = 100;
-    for (int i = 0; i < nSamples; ++i) {
-        Float ti = tCrit - std::log(1 - (i + .5f) / nSamples) / sigma_t;
-        Float d = std::sqrt(r * r + ti * ti);
-        Float cosThetaO = ti / d;
-        Ess += rho * std::exp(-sigma_t * (d + tCrit)) / (d * d) * PhaseHG(cosThetaO, g) * (1 - FrDielectric(-cosThetaO, 1, eta)) * std::abs(cosThetaO);
+    // radiant exitance at radius r from multiple scattering: dipoles at the sampled depths, mirrored about the extrapolated boundary
+    Float multiple(Float r) const {
+        Float total = 0;
+        for (int i = 0; i < kDepthSamples; ++i) {
+            Float zReal = DepthSample(i) / tReduced;
+            Float zVirtual = -zReal + 2 * boundaryDepth;
+            Float dReal = std::sqrt(r * r + zReal * zReal), dVirtual = std::sqrt(r * r + zVirtual * zVirtual);
+            Float fluence = kInv4Pi / diffusion * (std::exp(-transport * dReal) / dReal - std::exp(-transport * dVirtual) / dVirtual);
+            Float irradiance = kInv4Pi * (zReal * (1 + transport * dReal) * std::exp(-transport * dReal) / (dReal * dReal * dReal) -
+                                          zVirtual * (1 + transport * dVirtual) * std::exp(-transport * dVirtual) / (dVirtual * dVirtual * dVirtual));
+            Float exitance = fluence * wFluence + irradiance * wIrradiance;
+            Float beyondFirstScatter = 1 - std::exp(-2 * tReduced * (dReal + zReal));   // keeps the single-scattering term out
+            total += beyondFirstScatter * albedoReduced * albedoReduced * exitance;
+        }
+        return total / kDepthSamples;
     }
-    return Ess / nSamples;
-}
-// IntegrateCatmullRom core/interpolation.cpp:260-286: running integral of the spline through (x, values)
-Float IntegrateCatmullRom(int n, const Float *x, const Float *values, Float *cdf) {
-    Float sum = 0;
-    cdf[0] = 0;
-    for (int i = 0; i < n - 1; ++i) {
-        Float x0 = x[i], x1 = x[i + 1], f0 = values[i], f1 = values[i + 1], width = x1 - x0;
-        Float d0 = i > 0 ? width * (f1 - values[i - 1]) / (x1 - x[i - 1]) : f1 - f0;
-        Float d1 = i + 2 < n ? width * (values[i + 2] - f0) / (x[i + 2] - x0) : f1 - f0;
-        sum += ((d0 - d1) * (1.f / 12.f) + (f0 + f1) * .5f) * width;
-        cdf[i + 1] = sum;
+    // ... and from single scattering, which can only leave beyond the critical angle
+    Float single(Float r) const {
+        Float t = a + s, albedo = s / t;
+        Float tCritical = r * std::sqrt(eta * eta - 1);
+        Float total = 0;
+        for (int i = 0; i < kDepthSamples; ++i) {
+            Float ti = tCritical + DepthSample(i) / t;
+            Float dist = std::sqrt(r * r + ti * ti);
+            Float cosExit = ti / dist;
+            total += albedo * std::exp(-t * (dist + tCritical)) / (dist * dist) * HenyeyGreenstein(cosExit, g) * (1 - DielectricReflectance(-cosExit, 1, eta)) * std::abs(cosExit);
+        }
+        return total / kDepthSamples;
     }
-    return sum;
+};
+
+// running integral of the Catmull-Rom spline through (x_i, f_i) (core/interpolation.cpp:260-286); out[i] = integral up to x_i
+Float SplineRunningIntegral(int n, const Float *x, const Float *f, Float *out) {
+    Float total = 0;
+    out[0] = 0;
+    for (int i = 0; i + 1 < n; ++i) {
+        Float w = x[i + 1] - x[i];
+        // end-point derivatives by central differences inside, one-sided at the ends, scaled to the segment
+        Float slopeL = i > 0 ? w * (f[i + 1] - f[i - 1]) / (x[i + 1] - x[i - 1]) : f[i + 1] - f[i];
+        Float slopeR = i + 2 < n ? w * (f[i + 2] - f[i]) / (x[i + 2] - x[i]) : f[i + 1] - f[i];
+        total += ((slopeL - slopeR) * (1.f / 12.f) + (f[i] + f[i + 1]) * .5f) * w;
+        out[i + 1] = total;
+    }
+    return total;
 }
 }  // namespace
 
@@ -98,22 +142,27 @@ std::shared_ptr<BSSRDFTableData> MakeBSSRDFTable(Float g, Float eta) {
     static std::map<std::pair<Float, Float>, std::shared_ptr<BSSRDFTableData>> cache;   // a pure function of (g, eta): shared between materials
     std::lock_guard<std::mutex> lock(mu);
     auto key = std::make_pair(g, eta);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
+    auto found = cache.find(key);
+    if (found != cache.end()) return found->second;
     auto t = std::make_shared<BSSRDFTableData>();
-    const int nRho = 100, nRadius = 64;
-    t->nRho = nRho; t->nRadius = nRadius;
-    t->rhoSamples.resize(nRho); t->radiusSamples.resize(nRadius); t->profile.resize(nRho * nRadius); t->rhoEff.resize(nRho); t->profileCDF.resize(nRho * nRadius);
+    const int nAlbedo = 100, nRadius = 64;
+    t->nRho = nAlbedo; t->nRadius = nRadius;
+    t->rhoSamples.resize(nAlbedo); t->radiusSamples.resize(nRadius); t->rhoEff.resize(nAlbedo);
+    t->profile.resize((size_t)nAlbedo * nRadius); t->profileCDF.resize((size_t)nAlbedo * nRadius);
+    // radii: 0, then a geometric ladder from 2.5e-3 mean free paths with ratio 1.2; albedos: denser towards one
     t->radiusSamples[0] = 0;
     t->radiusSamples[1] = 2.5e-3f;
-    for (int i = 2; i < nRadius; ++i) t->radiusSamples[i] = t->radiusSamples[i - 1] * 1.2f;
-    for (int i = 0; i < nRho; ++i) t->rhoSamples[i] = (1 - std::exp(-8 * i / (Float)(nRho - 1))) / (1 - std::exp(-8));
-    for (int i = 0; i < nRho; ++i) {
+    for (int j = 2; j < nRadius; ++j) t->radiusSamples[j] = t->radiusSamples[j - 1] * 1.2f;
+    for (int i = 0; i < nAlbedo; ++i) t->rhoSamples[i] = (1 - std::exp(-8 * i / (Float)(nAlbedo - 1))) / (1 - std::exp(-8));
+    for (int i = 0; i < nAlbedo; ++i) {
+        Float albedo = t->rhoSamples[i];
+        Float *row = &t->profile[(size_t)i * nRadius];
         for (int j = 0; j < nRadius; ++j) {
-            Float rho = t->rhoSamples[i], r = t->radiusSamples[j];
-            t->profile[i * nRadius + j] = 2 * kPi * r * (BeamDiffusionSS(rho, 1 - rho, g, eta, r) + BeamDiffusionMS(rho, 1 - rho, g, eta, r));
+            Float r = t->radiusSamples[j];
+            DipoleMedium m(albedo, 1 - albedo, g, eta);   // unit extinction: sigma_s = albedo, sigma_a = 1 - albedo
+            row[j] = 2 * kPi * r * (m.single(r) + m.multiple(r));
         }
-        t->rhoEff[i] = IntegrateCatmullRom(nRadius, t->radiusSamples.data(), &t->profile[i * nRadius], &t->profileCDF[i * nRadius]);
+        t->rhoEff[i] = SplineRunningIntegral(nRadius, t->radiusSamples.data(), row, &t->profileCDF[(size_t)i * nRadius]);
     }
     cache[key] = t;
     return t;

@@ -232,6 +232,47 @@ def test_device_triangle_intersect_matches_reference_vectors():
     assert h["prim"][0] == -1    # Triangle.BadCases known answer
 
 
+def test_device_bxdfs_match_reference_classes():
+    """Rows a15 / a16 at stage level on the DEVICE: f, Pdf and Sample_f of every lobe class (Lambertian R / T, OrenNayar, SpecularReflection /
+    Transmission, FresnelSpecular, MicrofacetReflection / Transmission, FresnelBlend; Fresnel NoOp / dielectric / conductor) replayed on the
+    2400 records ref_probe dumped from the reference's own classes.  Everything that is +, -, *, /, sqrt is bit-exact (the build has no FMA
+    contraction); lobes that go through libm (sin / cos / tan / atan of the microfacet sampling, FrConductor) may differ in the last places where
+    the device's double-rounded routines and glibc disagree: <= 4 ulp-scale relative 5e-6 allowed there, and >= 97 % of ALL values must be
+    bit-identical.  The sampled lobe type must always agree."""
+    rows = np.load(os.path.join(G, "ref_vectors.npz"))["bxdfs"]
+    out = pa.bxdf_eval(rows)
+    assert np.array_equal(out["type_s"], rows["type_s"])
+    exact, total = 0, 0
+    for k in ("f", "pdf", "wi_s", "pdf_s", "f_s"):
+        a, b = out[k], rows[k]
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (a == b)
+        exact += int(same.sum()); total += same.size
+        assert np.allclose(a, b, rtol=5e-6, atol=1e-7), (k, float(np.abs(a - b).max()))
+    assert exact / total >= 0.97, exact / total
+
+
+def test_sobol_index_33_bit_regime_c5():
+    """configs[4] (3840 x 2160, 512 spp): log2 resolution m = 12, Sobol' indices need 33 bits.  The device's SobolIntervalToIndex against the
+    known answers dumped from the reference (ref_vectors.npz: sobol_index rows with m = 12, sample numbers up to ~4000) and the sample values of
+    the first dimensions against the oracle."""
+    sc = pa.Scene(text='Film "image" "integer xresolution" [3840] "integer yresolution" [2160] "string filename" "x.pfm"\n'
+                       'Sampler "sobol" "integer pixelsamples" [512]\nWorldBegin\nWorldEnd\n')
+    assert sc.info["sobol_log2_resolution"] == 12 and sc.info["spp"] == 512
+    ctx = pa.Context(sc)
+    rows = np.load(os.path.join(G, "ref_vectors.npz"))["sobol_index"]
+    rows = rows[(rows["m"] == 12) & (rows["px"] < 3840) & (rows["py"] < 2160)]
+    assert len(rows) > 100 and (rows["idx"] >= 2 ** 32).any()
+    for r in rows[:160]:
+        n = int(r["frame"]) + 1
+        dev, didx = ctx.sobol(int(r["px"]), int(r["py"]), n, 8)
+        assert int(didx[-1]) == int(r["idx"]), (r, int(didx[-1]))
+    for (px, py) in [(0, 0), (3839, 2159), (1234, 2001)]:
+        dev, didx = ctx.sobol(px, py, 512, 24)
+        ref, ridx = ol.sobol(sc, px, py, 512, 24)
+        assert np.array_equal(didx, ridx) and np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    ctx.close()
+
+
 def test_device_sphere_intersect_matches_reference_vectors():
     """Device Sphere::Intersect on the reference's FullSphere / PartialSphere test constructions (+ transformed spheres): hit decision,
     tHit, p and pError bit for bit.  The normal goes through acos / sin of libm (theta of the hit point), whose last-ulp differences
