@@ -255,32 +255,15 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
         # same launch line the driver uses) and hand their exit code back; rank 0 of the child job prints the JSON line
-        import socket
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        raise SystemExit(subprocess.call(cmd, env=env))
+        par0 = importlib.import_module("pbrt-v3-distributed_amd.parallel")
+        raise SystemExit(par0.launch_ranks(args.gpus, __file__, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.one_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
+    if world > 1 and args.one_device:
+        local_rank = 0
 
     # ---- scene (generated once per node by local rank 0)
     bench_dir = os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench")
@@ -349,25 +332,12 @@ def main():
         log("[bench] scene %s: %d tris, %d BVH2 nodes, %d materials, %d lights; parse+BVH %.1f s, upload+BVH4 %.1f s" %
             (workload, sc.info["n_tris"], sc.info["n_bvh_nodes"], sc.info["n_materials"], sc.info["n_lights"], t_load, t_upload))
 
-    film_t = None
-    if world > 1:
-        film_t = torch.zeros(sc.height * sc.width * 4, dtype=torch.float32, device="cuda")
-        ctx.film_bind(film_t.data_ptr())
-
-    def sync_all():
-        ctx.sync()
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    # one rank of the tile-sharded frame (pbrt-v3-distributed_amd/parallel.py): film in a torch tensor, RCCL reduce onto rank 0 per step
+    frame = par.ShardedFrame(ctx, sc, rank, world, local_rank, backend=args.backend, one_device=args.one_device)
+    sync_all = frame.sync_all
 
     def step(count=False):
-        ctx.film_clear()
-        ctx.render(rank=rank, world=world, count_work=count, max_paths=args.max_paths, sync=False)
-        if world > 1:
-            ctx.sync()   # the ctx stream is not torch's current stream
-            par.combine_films(film_t, dst=0)
-            torch.cuda.synchronize()   # the reduction reads film_t: it must be done before the next step clears the film
+        frame.step(count_work=count, max_paths=args.max_paths)
 
     if args.pmc_child:   # under rocprofv3 --pmc: plain (non-counting) frames only, nothing printed
         for _ in range(max(1, args.steps)):
@@ -393,11 +363,7 @@ def main():
     for _ in range(args.steps):
         step()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = frame.max_over_ranks(time.perf_counter() - t0)
     timing = ctx.timing()
     cnt = ctx.counters()
     if cnt.get("trace_guard_trips", 0):
@@ -405,11 +371,7 @@ def main():
     ctx.timing_enable(False)
 
     # whole-job unit counts (all ranks)
-    samples = np.array([cnt["camera_rays"], cnt["closest_rays"] + cnt["shadow_rays"]], dtype=np.float64)
-    if world > 1:
-        st = torch.tensor(samples, dtype=torch.float64, device="cuda")
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        samples = st.cpu().numpy()
+    samples = frame.sum_over_ranks([cnt["camera_rays"], cnt["closest_rays"] + cnt["shadow_rays"]])
 
     if rank == 0:
         msamples = samples[0] / elapsed * 1e-6
@@ -484,9 +446,7 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
                "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2)}}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    frame.close()
     ctx.close()
 
 

@@ -476,7 +476,7 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root);
 int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, const float *wi, const float *u, int64_t n, float *f, float *pdf,
                  float *wi_s, float *pdf_s, float *f_s, int32_t *type_s);
 /* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
- * 3 lean steps over the 80-byte compressed BVH8 (default for plain all-triangle scenes), 4 two-level (instanced) scene;
+ * 3 lean steps over the 80-byte compressed BVH8, 4 two-level (instanced) scene, 5 general steps over the 64-byte quantised BVH4;
  * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */
 int mi_trace_info(mi_ctx *ctx, int64_t out[4]);
 
@@ -550,6 +550,8 @@ int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded
  * stats: [0] BVH8 nodes, [1] leaf references, [2] depth, [3] deepest stack seen, [4] primitives covered, [5] nodes visited,
  * [6] primitives tested, [7] rays that hit.  No GPU needed. */
 int mi_bvh8_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
+/* quantisation (exact arithmetic) + host emulation of the traversal over the 64-byte quantised BVH4 (csrc/pt_bvh4q.h) */
+int mi_bvh4q_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
 /* the same checks + host emulation for the 80-byte compressed 8-wide layout the traversal kernels use (csrc/pt_bvh8c.h) */
 int mi_bvh8c_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
 /* Sphere::Intersect (shapes/sphere.cpp:48-162) of ray i against spheres[i] (explicit records, no scene): hit flag, tHit and the

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -107,6 +107,7 @@ def device_lib():
         L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_bvh8_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_bvh8c_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi_bvh4q_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_trace_info.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_film_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
@@ -239,7 +240,8 @@ class Context:
     def trace_info(self):
         out = np.zeros(4, dtype=np.int64)
         self._chk(device_lib().mi_trace_info(self._ctx, _ptr(out)), "mi_trace_info")
-        names = ["general BVH4 steps", "128-byte quantised BVH8 (round 1)", "lean BVH4 steps", "lean steps over the 80-byte compressed BVH8", "two-level BVH4 (instanced scene)"]
+        names = ["general BVH4 steps", "128-byte quantised BVH8 (round 1)", "lean BVH4 steps", "lean steps over the 80-byte compressed BVH8", "two-level BVH4 (instanced scene)",
+                 "general steps over the 64-byte quantised BVH4"]
         return {"mode": int(out[0]), "name": names[int(out[0])], "node_bytes": int(out[1]), "nodes": int(out[2]), "lds_stack_entries": int(out[3])}
 
     def counters(self):
@@ -336,7 +338,7 @@ def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=Fa
     n = 0 if rays is None else len(rays)
     r = np.ascontiguousarray(rays, dtype=RAY_DTYPE) if n else None
     hits = np.zeros(n, dtype=HIT_DTYPE) if (n and want_hits) else None
-    fn = L.mi_bvh8c_validate if compressed else L.mi_bvh8_validate
+    fn = L.mi_bvh4q_validate if compressed == "bvh4q" else (L.mi_bvh8c_validate if compressed else L.mi_bvh8_validate)
     if fn(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
         raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
     keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]

@@ -66,17 +66,43 @@ struct PathState {
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
     uint32_t *q_key;           // spatial bin (RayBinKey) of every path-extension ray k_shade queues, parallel to q_ext[qout]; null: binning off
     float bin_min[3], bin_scale[3];   // scene bound -> 8 cells per axis
-    uint32_t *qcount;          // [0],[1] extension queues, [2] shadow, [3] mis, [4] sorted total
+    // Queues are cut into QSEG segments (one per XCD-aligned block class, blockIdx & 7), each with its own fill counter in its own
+    // 128-byte line: qcount[QCI(queue, seg)].  A single counter per queue made every wave of the chip hit ONE word -- the L2 serialises
+    // same-address atomics at ~88 per microsecond, which is exactly what k_raygen cost (2.07 M wave appends = 24 ms per frame) and most
+    // of k_shade's launch time.  Segment `seg` of a queue occupies [seg * seg_cap, seg * seg_cap + count): producers append to the segment
+    // of their own block class, consumers walk (k_keycount / k_scatter / k_raybin_*) or pull from (k_trace) the segments.
+    uint32_t *qcount;          // rows: [0],[1] extension queues, [2] shadow, [3] mis; [4] the material-sorted total, [5] the binned total
+    uint32_t seg_cap;          // entries per queue segment
+    uint32_t trace_contig;     // k_trace<0> only: the queue it is handed is one contiguous array of qcount[QCI(QC_BINNED, 0)] entries (ray binning)
     uint32_t *keycount, *keyoffset;
     uint32_t *bin_total, *bin_offset;   // [PT_RAYBIN_KEYS]
     uint32_t *blockhist;       // [gridBlocks][nkeys]
-    uint32_t *cursor;          // [8] per-XCD-segment fetch cursors of k_trace
+    uint32_t *cursor;          // [QSEG * QC_STRIDE] per-segment fetch cursors of k_trace, one 128-byte line each
     unsigned long long *counters;
     uint32_t *spill;
     int spill_per_thread;
     uint32_t cap;
 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_COUNT = 8 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_ROWS = 6 };
+#define QSEG 8u
+#define QC_STRIDE 32u   /* words between counters: one 128-byte line each */
+#define QCI(q, seg) (((uint32_t)(q) * QSEG + (uint32_t)(seg)) * QC_STRIDE)
+#define QC_WORDS (QC_ROWS * QSEG * QC_STRIDE)
+// the items of one segmented queue, walked by the blocks of the segment's class (XCD x = blockIdx & 7 takes segment x, 256 items per block step)
+struct SegIter {
+    uint32_t n, c, bpx, base;
+    PT_DEV SegIter(const uint32_t *qcount, uint32_t q, uint32_t seg_cap) {
+        uint32_t x = blockIdx.x & 7;
+        n = qcount[QCI(q, x)];
+        base = x * seg_cap;
+        c = blockIdx.x >> 3;
+        bpx = gridDim.x >> 3;
+    }
+    PT_DEV bool more() const { return c * PT_BLOCK < n; }
+    PT_DEV bool valid() const { return c * PT_BLOCK + threadIdx.x < n; }
+    PT_DEV uint32_t item() const { return base + c * PT_BLOCK + threadIdx.x; }   // position in the queue array (also indexes keyrank)
+    PT_DEV void next() { c += bpx; }
+};
 
 struct PassInfo {
     const uint32_t *tiles;     // owned tile ids (tile = ty * nTilesX + tx)
@@ -251,8 +277,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
             ps.rec[i].pfilm = make_float2(pfx, pfy);
             ++ncam;
         }
-        uint32_t pos = wave_append(&ps.qcount[qout], active);
-        if (active) ps.q_ext[qout][pos] = i;
+        uint32_t pos = wave_append(&ps.qcount[QCI(qout, blockIdx.x & 7)], active);   // this block class's segment of the queue
+        if (active) ps.q_ext[qout][(blockIdx.x & 7) * ps.seg_cap + pos] = i;
     }
     wave_count(&ps.counters[MI_CNT_CAMERA_RAYS], ncam);
 }
@@ -297,20 +323,25 @@ template <bool WIDE, bool INST, bool FAST = false> struct TravTypes { typedef Tr
 template <> struct TravTypes<true, false, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
 template <> struct TravTypes<false, true, false> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<false, false, true> { typedef FastRay State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+struct TravTypesQ { typedef TravStateQ State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 struct TravTypes8C { typedef Fast8Ray State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
 // C8: the lean steps over the 80-byte compressed 8-wide nodes (pt_bvh8c.h) -- the default for plain all-triangle scenes
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false, bool C8 = false>
+// QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false, bool C8 = false, bool QN = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    static_assert(!(FAST || C8) || (!SPHERES && !ALPHA && !WIDE && !INST && !PT_STACK_T), "the fast steps cover plain all-triangle scenes");
+    static_assert(!QN || (!WIDE && !INST && !FAST && !C8), "quantised nodes: single-level BVH4, general steps");
+    static_assert(!(FAST || C8) || (!SPHERES && !ALPHA && !WIDE && !INST), "the fast steps cover plain all-triangle scenes");   // (they assume PT_STACK_T == 0: an experiment build with entry distances must not select them)
     static_assert(!(FAST && C8), "one lean variant at a time");
-    typedef typename std::conditional<C8, TravTypes8C, TravTypes<WIDE, INST, FAST>>::type TT;
+    typedef typename std::conditional<C8, TravTypes8C, typename std::conditional<QN, TravTypesQ, TravTypes<WIDE, INST, FAST>>::type>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
     st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
-    const uint32_t n = ps.qcount[MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW)];
-    const uint32_t segLen = (((n + 7) / 8) + 63u) & ~63u;
+    const uint32_t qrow = MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW);
+    const bool contig = MODE == 0 && ps.trace_contig;                                     // binned queue: one array, cut into eighths here
+    const uint32_t nContig = contig ? ps.qcount[QCI(QC_BINNED, 0)] : 0u;
+    const uint32_t segLen = contig ? ((((nContig + 7) / 8) + 63u) & ~63u) : ps.seg_cap;
     const uint32_t lane = lane_id();
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     uint32_t seg = blockIdx.x & 7, segsTried = 0;
@@ -329,10 +360,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
             while (segsTried < 8 && nIdle > 0) {
                 if (poolNext >= poolEnd) {   // take the next batch of this segment (one atomic per wave and batch)
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&ps.cursor[seg], TRACE_BATCH);
+                    if (lane == 0) base = atomicAdd(&ps.cursor[seg * QC_STRIDE], TRACE_BATCH);   // one cache line per segment cursor
                     base = __shfl(base, 0);
-                    uint32_t segBeg = seg * segLen, segEnd = segBeg + segLen < n ? segBeg + segLen : n;
-                    if (segBeg + base >= segEnd || segBeg >= n) { seg = (seg + 1) & 7; ++segsTried; poolNext = poolEnd = 0; continue; }
+                    uint32_t segBeg = seg * segLen, segEnd;
+                    if (contig) segEnd = segBeg + segLen < nContig ? segBeg + segLen : (segBeg < nContig ? nContig : segBeg);
+                    else segEnd = segBeg + ps.qcount[QCI(qrow, seg)];
+                    if (segBeg + base >= segEnd) { seg = (seg + 1) & 7; ++segsTried; poolNext = poolEnd = 0; continue; }
                     poolNext = segBeg + base;
                     poolEnd = poolNext + TRACE_BATCH < segEnd ? poolNext + TRACE_BATCH : segEnd;
                 }
@@ -380,7 +413,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                         if (__any(wantNode && st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD)) { if (wantNode) FastNodeStep<COUNT, true, true>(sc, ts, st, &tc); }
                         else if (wantNode) FastNodeStep<COUNT, true, false>(sc, ts, st, &tc);
                     } else if (wantNode) {
-                        if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
+                        if constexpr (QN) TravNodeStepQ<COUNT>(sc, ts, st, &tc);
+                        else if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
                         else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
                     int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
@@ -474,10 +508,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raybin_count(PathState ps, uint32_
     __shared__ uint32_t lhist[PT_RAYBIN_KEYS];
     for (uint32_t k = threadIdx.x; k < PT_RAYBIN_KEYS; k += PT_BLOCK) lhist[k] = 0;
     __syncthreads();
-    const uint32_t n = ps.qcount[qin];
-    for (ChunkIter it(n); it.more(); it.next()) {
-        uint32_t i = it.item();
-        if (i < n) {
+    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
+        if (it.valid()) {
+            uint32_t i = it.item();
             uint32_t key = ps.q_key[i];
             uint32_t rank = atomicAdd(&lhist[key], 1u);
             ps.keyrank[i] = make_uint2(key, rank);
@@ -506,12 +539,12 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raybin_scan_bins(PathState ps) {
     __syncthreads();
     uint32_t run = part[threadIdx.x];
     for (uint32_t j = 0; j < per; ++j) { uint32_t v = ps.bin_total[k0 + j]; ps.bin_offset[k0 + j] = run; run += v; }
+    if (threadIdx.x == PT_BLOCK - 1) ps.qcount[QCI(QC_BINNED, 0)] = run;   // the binned queue's length
 }
 __global__ void __launch_bounds__(PT_BLOCK) k_raybin_scatter(PathState ps, uint32_t qin) {
-    const uint32_t n = ps.qcount[qin];
-    for (ChunkIter it(n); it.more(); it.next()) {
-        uint32_t i = it.item();
-        if (i < n) {
+    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
+        if (it.valid()) {
+            uint32_t i = it.item();
             uint2 kr = ps.keyrank[i];
             ps.q_sorted[ps.bin_offset[kr.x] + ps.blockhist[(size_t)blockIdx.x * PT_RAYBIN_KEYS + kr.x] + kr.y] = ps.q_ext[qin][i];
         }
@@ -528,10 +561,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
     extern __shared__ uint32_t lhist[];
     for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) lhist[k] = 0;
     __syncthreads();
-    uint32_t n = ps.qcount[qin];
-    for (ChunkIter it(n); it.more(); it.next()) {
+    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
         uint32_t i = it.item();
-        bool active = i < n;
+        bool active = it.valid();
         uint32_t slot = 0, key = 0;
         if (active) {
             slot = ps.q_ext[qin][i];
@@ -561,13 +593,12 @@ __global__ void __launch_bounds__(PT_BLOCK) k_scan_keys(PathState ps, uint32_t n
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) ps.qcount[QC_SORTED] = carry;
+    if (threadIdx.x == 0) ps.qcount[QCI(QC_SORTED, 0)] = carry;
 }
 __global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin, uint32_t nkeys) {
-    uint32_t n = ps.qcount[qin];
-    for (ChunkIter it(n); it.more(); it.next()) {
+    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
         uint32_t i = it.item();
-        if (i < n) {
+        if (it.valid()) {
             uint32_t slot = ps.q_ext[qin][i];
             uint2 kr = ps.keyrank[i];
             ps.q_sorted[ps.keyoffset[kr.x] + ps.blockhist[(size_t)blockIdx.x * nkeys + kr.x] + kr.y] = slot;
@@ -679,7 +710,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     if (cdfInLds) for (uint32_t k = threadIdx.x; k < sc.n_lights + 1; k += PT_BLOCK) s_cdf[k] = sc.light_cdf[k];
     __syncthreads();
     const float *cdf = cdfInLds ? s_cdf : sc.light_cdf;
-    uint32_t n = ps.qcount[QC_SORTED];
+    uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
     uint32_t nseg = 0;
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
@@ -948,10 +979,11 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
             if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16) | (TEX ? (uint32_t)noDiff << 17 : 0u));
         }
         uint32_t posE, posS, posM;
-        wave_append3(&ps.qcount[qout], &ps.qcount[QC_SHADOW], &ps.qcount[QC_MIS], cont, wantShadow, wantMis, &posE, &posS, &posM);
-        if (cont) { ps.q_ext[qout][posE] = slot; if (ps.q_key) ps.q_key[posE] = rayKey; }
-        if (wantShadow) ps.q_shadow[posS] = slot;
-        if (wantMis) ps.q_mis[posM] = slot;
+        const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;   // this block class's segment of the three queues
+        wave_append3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, wantShadow, wantMis, &posE, &posS, &posM);
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (wantShadow) ps.q_shadow[qbase + posS] = slot;
+        if (wantMis) ps.q_mis[qbase + posM] = slot;
         PROBE(13)   // L store + queue appends
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
@@ -1207,7 +1239,8 @@ struct mi_ctx {
     int tilesRank = -1, tilesWorld = -1;     // the tile list resident in `tiles` (re-uploaded only when the sharding changes)
     std::vector<uint32_t> tilesHost;         // kept alive: the upload is asynchronous
     size_t tilesCount = 0;
-    bool rayBin = true;                      // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
+    bool rayBin = false;                     // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
+    bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     bool useC8 = false;                      // lean steps over the compressed 8-wide BVH (pt_bvh8c.h): the default for plain scenes
     bool useFast = false;                    // lean traversal steps (pt_trace_fast.h): all-triangle scenes without masks / instances
     bool useBvh8 = false;
@@ -1399,7 +1432,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         return fail("mi_scene_upload: Integrator \"volpath\" (participating media) is not implemented on the device yet; \"path\" scenes render with their media ignored, as PathIntegrator does");
     if (d->material_bssrdf)   // subsurface / kdsubsurface materials: the probe-ray kernels do not exist yet (host + CPU oracle carry them)
         return fail("mi_scene_upload: materials with a BSSRDF (\"subsurface\", \"kdsubsurface\") are not implemented on the device yet");
-    { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = !(e && e[0] == '0'); }
+    // ray binning before traversal: measured -63 % HBM traffic and -48 % L2 misses in the closest-hit kernel at UNCHANGED kernel time
+    // (profiles/r02_b_*: the traversal is not bound by HBM) plus ~3 % of the frame for the sort -> off unless PBRT_AMD_RAYBIN=1
+    { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = e && e[0] == '1'; }
     c->hasNullMat = false;
     for (uint32_t m = 0; m < d->n_meshes; ++m) c->hasNullMat |= d->meshes[m].material < 0;
     c->tilesRank = c->tilesWorld = -1;
@@ -1560,13 +1595,34 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
     // lean traversal (pt_trace_fast.h): plain all-triangle scenes; PBRT_AMD_TRACE=general keeps the general steps (A/B, parity tests of both)
     c->useFast = c->useC8 = false;
-    {   // PBRT_AMD_TRACE = bvh8c (default) | bvh4 (lean steps over the BVH4) | general (TravNodeStep / TravLeafStep); PBRT_AMD_BVH8=1: round 1's 128-byte BVH8
+    {   // Traversal layout.  Round 2 measured five on the 10 M-triangle frame (profiles/r02_*; Msamples/s of the 16 spp probe, all with the
+        // segmented queue counters):
+        //   bvh4q    general steps over the 64-byte quantised BVH4 (pt_bvh4q.h): 4 requests per step       254.5   <- default (single-level scenes)
+        //   general  TravNodeStep / TravLeafStep over the 128-byte BVH4 (round 1): 7 requests per step     214.3   (two-level scenes; PBRT_AMD_TRACE=general)
+        //   bvh4     lean straight-line steps over the 128-byte BVH4 (pt_trace_fast.h)                     209.5   (half the static instructions, MORE executed ones)
+        //   bvh8c    lean steps over the 80-byte compressed BVH8 (pt_bvh8c.h)                              ~185    (5 requests per 8-wide step, 3 x the arithmetic per ray)
+        //   PBRT_AMD_BVH8=1: round 1's 128-byte quantised BVH8                                              ~180
+        // What bounds these kernels is the per-lane vector-memory REQUEST count (profiles/r02_c_*: +3 requests per step = +31 % time; -63 % HBM
+        // traffic, half the instructions, 24 -> 16 waves per CU: no change).  All five are parity-tested (tests/test_gpu_parity.py TRACE_MODES).
         const char *e = std::getenv("PBRT_AMD_TRACE");
-        const bool wantGeneral = e && std::strcmp(e, "general") == 0, wantBvh4 = e && std::strcmp(e, "bvh4") == 0;
+        const bool wantC8 = e && std::strcmp(e, "bvh8c") == 0, wantBvh4 = e && std::strcmp(e, "bvh4") == 0;
         const char *e8 = std::getenv("PBRT_AMD_BVH8");
-        const bool plain = !wantGeneral && !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
+        const bool plain = !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
         c->useFast = plain && wantBvh4;
-        c->useC8 = plain && !wantBvh4;
+        c->useC8 = plain && wantC8;
+        // bvh4q: the same general steps with 64-byte quantised nodes -- any single-level scene (spheres and alpha masks only touch the leaf step)
+        const bool wantGeneral = e && std::strcmp(e, "general") == 0;
+        c->useQ = !wantGeneral && !wantBvh4 && !wantC8 && !(e8 && e8[0] == '1') && !c->hasInst && d->n_bvh_nodes > 0;
+    }
+    sc.nodesq = nullptr;
+    if (c->useQ) {
+        std::vector<BVH4QNode> qn;
+        std::string err;
+        if (!bvh4q::quantise(bb.out, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, &qn, &sc.qgrid, &err)) return fail("mi_scene_upload: BVH4Q: " + err);
+        DevBuf &b = next();
+        if (upload(c, b, qn.data(), qn.size() * sizeof(BVH4QNode))) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));   // local
+        sc.nodesq = b.as<BVH4QNode>();
     }
     sc.nodes8c = nullptr; sc.n_nodes8c = 0; sc.tri_trav = nullptr; sc.trav2prim = nullptr;
     if (c->useC8) {
@@ -1962,14 +2018,19 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     std::memset(&ps, 0, sizeof(ps));
     auto A = [&](size_t bytes) -> void * { DevBuf &b = c->stateBufs[nb++]; return b.alloc(bytes) ? nullptr : b.p; };
 #define ALLOC(field, type, count) do { ps.field = (type *)A(sizeof(type) * (size_t)(count)); if (!ps.field) return -1; } while (0)
-    ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, cap);
-    ALLOC(q_ext[0], uint32_t, cap); ALLOC(q_ext[1], uint32_t, cap); ALLOC(q_shadow, uint32_t, cap); ALLOC(q_mis, uint32_t, cap);
-    ALLOC(q_sorted, uint32_t, cap);
-    ALLOC(qcount, uint32_t, QC_COUNT);
-    ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, 8);
+    // queue segment capacity: a block class handles one contiguous eighth of the 256-item chunks of whatever it walks (ChunkIter) and
+    // appends at most one entry per item to each queue
+    const uint32_t chunks = (cap + PT_BLOCK - 1) / PT_BLOCK;
+    ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK;
+    const size_t qcap = (size_t)QSEG * ps.seg_cap;
+    ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, qcap);
+    ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);
+    ALLOC(q_sorted, uint32_t, qcap);
+    ALLOC(qcount, uint32_t, QC_WORDS);
+    ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
     if (c->rayBin) {
-        ALLOC(q_key, uint32_t, cap); ALLOC(bin_total, uint32_t, PT_RAYBIN_KEYS); ALLOC(bin_offset, uint32_t, PT_RAYBIN_KEYS);
+        ALLOC(q_key, uint32_t, qcap); ALLOC(bin_total, uint32_t, PT_RAYBIN_KEYS); ALLOC(bin_offset, uint32_t, PT_RAYBIN_KEYS);
         for (int a = 0; a < 3; ++a) {   // 8 cells per axis over scene.WorldBound() (the root box of the reference's BVH)
             float lo = c->sc.sp_bmin_all[a], hi = c->sc.sp_bmax_all[a];
             ps.bin_min[a] = lo;
@@ -2026,6 +2087,15 @@ static void harvest(mi_ctx *c) {
             ps8.spill_per_thread = c->spill8;                                                                       \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
             else hipLaunchKernelGGL((k_trace<MODE, false, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
+        } else if (c->useQ && c->hasAlpha) { /* quantised nodes, the general instance (spheres + masks) */                 \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, true, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
+        } else if (c->useQ && c->hasSpheres) {                                                                              \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
+        } else if (c->useQ) {                                                                                               \
+            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
+            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
         } else if (c->hasAlpha) { /* alpha-masked meshes: the general instance (spheres + masks) */                        \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true>), grid, block, 0, st, sc, ps, qin);  \
             else hipLaunchKernelGGL((k_trace<MODE, false, true, true>), grid, block, 0, st, sc, ps, qin);           \
@@ -2051,7 +2121,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     const DevScene &sc = c->sc;
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
-    HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_COUNT * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
     if (c->hasTex || c->hasAlpha || c->hasInst)   // the texture tables of THIS context's scene (stream ordered: contexts sharing a device may interleave passes)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
     if (c->hasInst) HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_instances), &c->instPtr, sizeof(c->instPtr), 0, hipMemcpyHostToDevice, st));
@@ -2063,9 +2133,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     int iter = 0;
     while (true) {
         uint32_t qout = qin ^ 1;
-        HIP_TRY(hipMemsetAsync(ps.qcount + qout, 0, sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(ps.qcount + QC_SHADOW, 0, 2 * sizeof(uint32_t), st));   // shadow + mis
-        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
         if (c->rayBin && iter > 0) {   // camera rays (iter 0) come out of k_raygen tile by tile: coherent already
             tic(c, MI_K_SORT);
@@ -2079,7 +2149,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_CLOSEST);
         {
             PathState psRun = ps;   // the traversal walks the binned copy of the queue; the material sort below reads the original (same set of paths)
-            if (binned) psRun.q_ext[qin] = ps.q_sorted;
+            if (binned) { psRun.q_ext[qin] = ps.q_sorted; psRun.trace_contig = 1; }
             PathState &ps = psRun;
             LAUNCH_TRACE(0);
         }
@@ -2107,11 +2177,11 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             }
         }
         toc(c);
-        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
         LAUNCH_TRACE(2);
         toc(c);
-        HIP_TRY(hipMemsetAsync(ps.cursor, 0, 8 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_MIS_CLOSEST);
         LAUNCH_TRACE(1);
         toc(c);
@@ -2122,9 +2192,10 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             // (which do not count as bounces) can still be alive -- check, and keep going if so.  Scenes without such
             // surfaces (no mesh with a null material) need no check: the pass stays asynchronous on the ctx stream.
             if (!c->hasNullMat) break;
-            uint32_t left = 0;
-            HIP_TRY(hipMemcpyAsync(&left, ps.qcount + qin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            uint32_t left = 0, row[QSEG * QC_STRIDE];
+            HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(qin, 0), sizeof(row), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
             if (left == 0 || iter > sc.max_depth + 4096) break;
         }
     }
@@ -2278,9 +2349,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film_add(float4 *dst, const float4
 
 int mi_trace_info(mi_ctx *c, int64_t out[4]) {
     if (!c || !out || !c->haveScene) return fail("mi_trace_info: no scene");
-    int mode = c->hasInst ? 4 : (c->useC8 ? 3 : (c->useFast ? 2 : ((c->useBvh8 && !c->hasAlpha && !c->hasSpheres) ? 1 : 0)));
+    int mode = c->hasInst ? 4 : (c->useC8 ? 3 : (c->useFast ? 2 : ((c->useBvh8 && !c->hasAlpha && !c->hasSpheres) ? 1 : (c->useQ ? 5 : 0))));
     out[0] = mode;
-    out[1] = mode == 3 ? (int64_t)sizeof(BVH8CNode) : 128;
+    out[1] = mode == 3 ? (int64_t)sizeof(BVH8CNode) : (mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128);
     out[2] = mode == 3 ? c->sc.n_nodes8c : (mode == 1 ? c->nNodes8 : c->sc.n_nodes);
     out[3] = (mode == 3 || mode == 1) ? PT_LDS_STACK8 : PT_LDS_STACK;
     return 0;
@@ -2559,6 +2630,37 @@ int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, cons
     for (DevBuf *x : {&db, &dwo, &dwi, &du, &df, &dp, &dws, &dps, &dfs, &dts}) x->release();
     return 0;
 }
+// host check of the 64-byte quantised BVH4 (pt_bvh4q.h): quantisation in exact arithmetic + the kernel's per-ray state machine on the host
+int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
+    if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh4q_validate: null argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    if (d->n_instances) return fail("mi_bvh4q_validate: two-level scenes are not handled");
+    if (!d->n_bvh_nodes) {   // no geometry: every ray misses
+        if (hits) for (int64_t i = 0; i < n; ++i) { std::memset(&hits[i], 0, sizeof(mi_hit)); hits[i].prim = -1; }
+        return 0;
+    }
+    B4Builder bb;
+    int topDepth = 0, objDepth = 0;
+    std::vector<uint32_t> objRoot;
+    { std::string err; if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_bvh4q_validate: " + err); }
+    std::vector<BVH4QNode> qn;
+    Bvh4qGrid g;
+    std::string err;
+    if (!bvh4q::quantise(bb.out, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, &qn, &g, &err)) return fail("mi_bvh4q_validate: " + err);
+    bvh4q::Stats st;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t prim; float t, b[3];
+        bool hit = bvh4q::traverse(d, qn, g, rays[i], any_hit != 0, &prim, &t, b, &st);
+        if (hits) {
+            std::memset(&hits[i], 0, sizeof(mi_hit));
+            hits[i].prim = hit ? (int32_t)prim : -1;
+            hits[i].t = hit ? t : 0; hits[i].b0 = b[0]; hits[i].b1 = b[1]; hits[i].b2 = b[2];
+        }
+    }
+    stats[0] = (int64_t)qn.size(); stats[2] = topDepth; stats[3] = (int64_t)st.maxStack; stats[4] = d->n_tris;
+    stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
+    return 0;
+}
 // the same for the 80-byte compressed layout the traversal kernels run (pt_bvh8c.h): build, structural checks in exact arithmetic, host emulation
 int mi_bvh8c_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
     if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8c_validate: null argument");
@@ -2775,7 +2877,7 @@ static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_
     pass.npix = cnt; pass.ns = 1;
     pass.list_xy = dxy.as<int32_t>(); pass.list_s = ds.as<int32_t>();
     if (trace) return run_pass(c, pass, false, false);
-    HIP_TRY(hipMemsetAsync(c->ps.qcount, 0, QC_COUNT * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->ps.qcount, 0, QC_WORDS * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_raygen<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
     return 0;
 }

@@ -4,6 +4,7 @@
 #include "pt_math.h"
 #include "pt_sphere.h"
 #include "pt_bvh8.h"
+#include "pt_bvh4q.h"
 
 // ------------------------------------------------------------------ HBM layout
 // BVH4 node: exactly one 128-byte cache line, fetched by a lane as 8 x global_load_dwordx4.
@@ -64,6 +65,8 @@ struct __attribute__((aligned(64))) TriShade {
 struct DevScene {
     const BVH4Node *nodes;
     const float4 *tri_verts;        // 3 per triangle
+    const BVH4QNode *nodesq;        // the same tree as `nodes` with 16-bit planes on one grid (pt_bvh4q.h); null: not built
+    Bvh4qGrid qgrid;
     const void *nodes8c;            // BVH8CNode[] (pt_bvh8c.h), null: not built
     uint32_t n_nodes8c;
     const float4 *tri_trav;         // triangle records in the BVH8C's traversal order
@@ -508,6 +511,46 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
     PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
 #undef PT_CSWAP
     int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
+    if (nh > 3) st.push(c3, t3);
+    if (nh > 2) st.push(c2, t2);
+    if (nh > 1) st.push(c1, t1);
+    ts.cur = c0;
+}
+
+// ------------------------------------------------------------------ quantised nodes (pt_bvh4q.h): four requests per step instead of seven
+// Same per-lane state machine and the same stack / leaf step as above; only the interior step differs: 4 x 16-byte loads of the 64-byte
+// node, planes converted from 16-bit grid indices (v_cvt_f32_u32 with a word select), folded slab distances t = q A + B with the per-RAY
+// constants of Bvh4qRayInit, hit children to the stack far to near.  The step itself is Bvh4qStepWords, the function the host emulation
+// (mi_bvh4q_validate) checks against the oracle's BVH2 traversal.
+struct TravStateQ : TravState {
+    Bvh4qRay q;
+    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+        o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
+        const float oo[3] = {o.x, o.y, o.z};
+        const float inv[3] = {d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
+                              d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z};   // Ray8Init's convention for zero direction components
+        Bvh4qRayInit(q, sc.qgrid, oo, inv);
+        shear.init(d);
+        st.sp = 0;
+        cur = sc.n_nodes ? 0u : TRAV_DONE;
+    }
+};
+template <bool COUNT>
+PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, TravStack &st, TraceCounters *cnt) {
+    const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
+    uint4 w0 = w[0], w1 = w[1], w2 = w[2], ch = w[3];
+    Pin(w0); Pin(w1); Pin(w2); Pin(ch);
+    if (COUNT) ++cnt->nodes;
+    const uint32_t wd[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, ch.x, ch.y, ch.z, ch.w};
+    Float t[4];
+    const uint32_t mask = Bvh4qStepWords(wd, ts.q, ts.tMax, t);
+    Float t0 = (mask & 1u) ? t[0] : PT_INFINITY, t1 = (mask & 2u) ? t[1] : PT_INFINITY, t2 = (mask & 4u) ? t[2] : PT_INFINITY, t3 = (mask & 8u) ? t[3] : PT_INFINITY;
+    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
+    PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+    const int nh = __builtin_popcount(mask);
     if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
     if (nh > 3) st.push(c3, t3);
     if (nh > 2) st.push(c2, t2);

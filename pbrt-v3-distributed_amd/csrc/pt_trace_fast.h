@@ -107,9 +107,12 @@ PT_DEV void FastNodeStep(const DevScene &sc, FastRay &fr, TravStack &st, TraceCo
     uint4 ch = LdU4(base, nb + 96u);
 #ifdef PT_FAST_EXTRA_LOADS   /* experiment (profiles/r02 notes): extra 16-byte loads from the SAME cache line -- do L1 look-ups bound the step? */
     {
-        uint4 x0 = LdU4(base, nb + 112u), x1 = LdU4(base, nb + 112u), x2 = LdU4(base, nb + 112u);
-        asm volatile("" : "+v"(x0.x), "+v"(x1.x), "+v"(x2.x));
-        asm volatile("" :: "v"(x0.y), "v"(x1.y), "v"(x2.y), "v"(x0.z), "v"(x1.z), "v"(x2.z), "v"(x0.w), "v"(x1.w), "v"(x2.w));
+        // three more per-lane requests to the node's own cache line, at distinct addresses (identical ones would be merged by the compiler)
+        uint32_t a0 = nb + 112u, a1 = nb + 100u, a2 = nb + 104u;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+        uint4 x0 = LdU4(base, a0);
+        uint32_t x1 = *reinterpret_cast<const uint32_t *>(base + a1), x2 = *reinterpret_cast<const uint32_t *>(base + a2);
+        asm volatile("" :: "v"(x0.x), "v"(x0.y), "v"(x0.z), "v"(x0.w), "v"(x1), "v"(x2));
     }
 #endif
     uint32_t top = 0;

@@ -10,7 +10,7 @@
 namespace pbrt_amd {
 
 std::string g_imageFileOverride;
-bool g_twoLevelInstancing = false;   // PBRT_AMD_INSTANCING=1: keep ObjectInstance as TransformedPrimitive + per-object BVH (host + oracle only so far)
+bool g_twoLevelInstancing = true;   // keep ObjectInstance as TransformedPrimitive + per-object BVH, the reference's own structure (default since round 2: the device's two-level kernels are validated); PBRT_AMD_INSTANCING=0 flattens instances into world-space copies
 Float g_cropWindow[4] = {0, 1, 0, 1};
 bool g_quickRender = false;
 
@@ -122,7 +122,7 @@ void pbrtInit(const Options &opt) {
     if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
     currentApiState = APIState::OptionsBlock;
     renderOptions.reset(new RenderOptions);
-    { const char *e = std::getenv("PBRT_AMD_INSTANCING"); g_twoLevelInstancing = e && e[0] == '1'; }
+    { const char *e = std::getenv("PBRT_AMD_INSTANCING"); g_twoLevelInstancing = !(e && e[0] == '0'); }
     ResetTextures();
     graphicsState = GraphicsState();
     curTransform = TransformSet();

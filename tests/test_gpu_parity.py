@@ -11,17 +11,19 @@ ROOT = ol.ROOT
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell.pbrt", "materials.pbrt"]
-# every traversal kernel instance the library ships runs the parity tests: "bvh8c" = the lean steps over the 80-byte compressed
-# 8-wide nodes (csrc/pt_bvh8c.h + pt_trace_fast.h; the default for plain all-triangle scenes), "bvh4" = the lean steps over the
-# BVH4 (PBRT_AMD_TRACE=bvh4), "general" = TravNodeStep / TravLeafStep (what scenes with spheres / masks / instances use; forced
-# for plain scenes with PBRT_AMD_TRACE=general), "bvh8" = round 1's 128-byte quantised BVH8 (PBRT_AMD_BVH8=1; kept as a measured
-# alternative: profiles/r02_*).  The variables are read by mi_scene_upload.
-TRACE_MODES = {"bvh8c": {}, "bvh4": {"PBRT_AMD_TRACE": "bvh4"}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh8": {"PBRT_AMD_BVH8": "1"}}
+# every traversal kernel instance the library ships runs the parity tests: "bvh4q" = the general steps over the 64-byte quantised BVH4
+# (csrc/pt_bvh4q.h; the default for single-level scenes, with or without spheres / masks), "general" = TravNodeStep / TravLeafStep over
+# the 128-byte BVH4 (round 1's kernels; what two-level scenes use; PBRT_AMD_TRACE=general), "bvh4" = the lean
+# straight-line steps over the same BVH4 (PBRT_AMD_TRACE=bvh4, csrc/pt_trace_fast.h), "bvh8c" = the lean steps over the 80-byte
+# compressed 8-wide nodes (PBRT_AMD_TRACE=bvh8c, csrc/pt_bvh8c.h; run here with ray binning on, PBRT_AMD_RAYBIN=1, so that the binning
+# kernels are covered too), "bvh8" = round 1's 128-byte quantised BVH8 (PBRT_AMD_BVH8=1).  The variables are read by mi_scene_upload.
+TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh4": {"PBRT_AMD_TRACE": "bvh4"}, "bvh8c": {"PBRT_AMD_TRACE": "bvh8c", "PBRT_AMD_RAYBIN": "1"},
+               "bvh8": {"PBRT_AMD_BVH8": "1"}}
 
 
-def make_ctx(sc, mode="bvh8c", **kw):
+def make_ctx(sc, mode="bvh4q", **kw):
     env = TRACE_MODES[mode]
-    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_BVH8")}
+    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_BVH8", "PBRT_AMD_RAYBIN")}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -215,6 +217,23 @@ def test_film_gather_of_two_contexts_equals_the_single_render():
     a.close(); b.close()
 
 
+def test_bench_two_ranks_self_launch_end_to_end(tmp_path):
+    """`python bench.py --gpus 2` starts its own two ranks (torch.distributed.run, one process per GPU) -- here both on GPU 0 with the gloo
+    backend, since this box has one GPU and RCCL refuses duplicate devices -- shards the tiles, reduces the films onto rank 0 and prints
+    ONE JSON line for the whole job.  Checked: the line, the whole-job sample count (every pixel rendered exactly once across the ranks)."""
+    import json, subprocess, sys
+    env = dict(os.environ, PBRT_AMD_BENCH_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+                        "--tris", "200000", "--res", "320", "192", "--spp", "4", "--cpu-seconds", "0", "--traffic", "none"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["unit"] == "Msamples/s"
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 - 320 * 192 * 4) <= 0.01 * 320 * 192 * 4   # all samples of the frame, once
+
+
 # ---------------------------------------------------------------- against the committed reference fixtures
 G = os.path.join(ROOT, "tests", "golden")
 
@@ -326,8 +345,9 @@ def _config_scene(name, tmp):
     return pa.Scene(out)
 
 
-@pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "bvh8c"), ("sanmiguel", "bvh4"), ("sanmiguel", "general"), ("sanmiguel", "bvh8"),
-                                       ("bathroom", "bvh8c"), ("bathroom", "bvh4"), ("bathroom", "general"), ("bathroom", "bvh8")])
+@pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "general"), ("sanmiguel", "bvh4"), ("sanmiguel", "bvh8c"), ("sanmiguel", "bvh8"),
+                                       ("bathroom", "general"), ("bathroom", "bvh4"), ("bathroom", "bvh8c"), ("bathroom", "bvh8"),
+                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q")])
 def test_baseline_configs_reduced(name, mode, tmp_path):
     """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
     (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
@@ -432,9 +452,8 @@ def test_two_level_instancing_vs_reference_fixture(name, monkeypatch):
     error-bounded origin (core/primitive.cpp:76-111, transform.h:252-264), interaction transformed back.  The oracle reproduces the
     reference's render bit for bit in this mode; first GPU run (round 2): every pixel within tolerance, relMSE 1e-16...1e-17,
     99.6-99.9 % of the pixels bit-identical."""
-    monkeypatch.setenv("PBRT_AMD_INSTANCING", "1")
+    monkeypatch.delenv("PBRT_AMD_INSTANCING", raising=False)   # two-level is the host's default (round 2); =0 flattens
     sc = pa.Scene(text=edge_scenes.scene(name))
-    assert sc.info.get("n_instances", 1) > 0
     ctx = pa.Context(sc)
     ctx.render()
     img = sc.film_image(ctx.film())
@@ -442,6 +461,15 @@ def test_two_level_instancing_vs_reference_fixture(name, monkeypatch):
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.999 and relmse <= 1e-8, (name, frac, relmse)
     assert float(np.mean(np.abs(img - ref).max(-1) == 0)) >= 0.98
+    ctx.close()
+    # the flattening option still renders the same surfaces (different roundings: the image criterion)
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "0")
+    flat = pa.Scene(text=edge_scenes.scene(name))
+    assert flat.info["n_tris"] > sc.info["n_tris"]
+    ctx = pa.Context(flat)
+    ctx.render()
+    frac, relmse = ol.image_metrics(flat.film_image(ctx.film()), ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
     ctx.close()
 
 

@@ -211,11 +211,11 @@ def test_oracle_object_instancing_both_ways(built, name, monkeypatch):
     shading-normal mesh inside an object, a mirroring instance transform and a one-triangle object.  Default mode (instances flattened
     to world-space copies, what the device renders): the same surfaces with different roundings -- image criterion of the GPU tests."""
     ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
-    monkeypatch.setenv("PBRT_AMD_INSTANCING", "1")
+    monkeypatch.delenv("PBRT_AMD_INSTANCING", raising=False)   # two-level is the default
     sc = pa.Scene(text=edge_scenes.scene(name))
     img = sc.film_image(ol.render(sc, nthreads=4)[0])
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
-    monkeypatch.delenv("PBRT_AMD_INSTANCING")
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "0")              # the flattening option
     flat = pa.Scene(text=edge_scenes.scene(name))
     assert flat.info["n_tris"] > sc.info["n_tris"]        # copies instead of references
     img2 = flat.film_image(ol.render(flat, nthreads=4)[0])
