@@ -989,6 +989,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
 }
 
+#include "pt_volpath.h"   // k_shade_vol: the shading kernel of "volpath" scenes and of scenes with BSSRDF materials
+
 // ---- film: the radiance guards of integrator.cpp:294-315 + FilmTile::AddSample (core/film.h:121-161).
 // One lane per owned pixel walks that pixel's samples of the pass in sample order.
 //   SPILL == false: only the lane's own pixel, as a plain running sum continued from the film value -- the
@@ -1248,6 +1250,9 @@ struct mi_ctx {
     uint32_t nNodes8 = 0;
     int stackNeed8 = 0, spill8 = 1;
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
+    bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
+    DevVol vol;                              // its extra tables (device pointers)
+    const DevScene *scDev = nullptr;         // DevScene in HBM: k_shade_vol's out-of-line routines take it by pointer
     DevScene sc;
     bool haveScene = false;
     std::vector<DevBuf> sceneBufs;
@@ -1428,10 +1433,13 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->abi_version != MI_ABI_VERSION) return fail("mi_scene_upload: ABI version mismatch");
     if (d->n_tris > BVH4_FIRST_MASK) return fail("mi_scene_upload: more than 2^27 triangles");
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
-    if (d->integrator_type != MI_INTEGRATOR_PATH)   // loud, not approximate: the medium-sampling kernels do not exist yet (host + CPU oracle carry row f4 so far)
-        return fail("mi_scene_upload: Integrator \"volpath\" (participating media) is not implemented on the device yet; \"path\" scenes render with their media ignored, as PathIntegrator does");
-    if (d->material_bssrdf)   // subsurface / kdsubsurface materials: the probe-ray kernels do not exist yet (host + CPU oracle carry them)
-        return fail("mi_scene_upload: materials with a BSSRDF (\"subsurface\", \"kdsubsurface\") are not implemented on the device yet");
+    // row f4: Integrator "volpath" and materials with a BSSRDF are shaded by k_shade_vol (pt_volpath.h)
+    c->volKernel = d->integrator_type == MI_INTEGRATOR_VOLPATH || d->material_bssrdf != nullptr;
+    if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
+    if (c->volKernel && d->n_instances > 0)   // loud, not approximate: the per-lane tracer of k_shade_vol walks single-level trees only
+        return fail("mi_scene_upload: \"volpath\" / subsurface scenes with two-level instancing are not implemented on the device; load the scene with PBRT_AMD_INSTANCING=0 (instances flattened)");
+    if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
+    if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
     // ray binning before traversal: measured -63 % HBM traffic and -48 % L2 misses in the closest-hit kernel at UNCHANGED kernel time
     // (profiles/r02_b_*: the traversal is not bound by HBM) plus ~3 % of the frame for the sort -> off unless PBRT_AMD_RAYBIN=1
     { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = e && e[0] == '1'; }
@@ -1476,7 +1484,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(56 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images);
+    c->sceneBufs.resize(64 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images + (size_t)d->n_media + 5 * (size_t)d->n_bssrdf_tables);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1990,6 +1998,63 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         return fail("mi_scene_upload: sample bounds exceed 65535 pixels per axis");
     // worst-case Sobol' dimensions: 5 camera + 8 per bounce (the reference LOG(FATAL)s past 1024, sobol.cpp:48-51)
     if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
+    // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
+    std::memset(&c->vol, 0, sizeof(c->vol));
+    c->scDev = nullptr;
+    if (c->volKernel) {
+        DevVol &v = c->vol;
+        v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
+        v.camera_medium = v.handle_media ? d->camera_medium : -1;
+        v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
+        if (v.handle_media && d->n_media) {
+            std::vector<mi_medium> med(d->media, d->media + d->n_media);
+            for (uint32_t i = 0; i < d->n_media; ++i) {
+                mi_medium &m = med[i];
+                if (m.type == MI_MEDIUM_GRID) {
+                    if (!m.density || m.nx <= 0 || m.ny <= 0 || m.nz <= 0) return fail("mi_scene_upload: grid medium without a density grid");
+                    DevBuf &b = next();
+                    if (upload(c, b, m.density, (size_t)m.nx * m.ny * m.nz * sizeof(float))) return -1;
+                    m.density = b.as<float>();
+                } else
+                    m.density = nullptr;
+            }
+            { DevBuf &b = next(); if (upload(c, b, med.data(), med.size() * sizeof(mi_medium))) return -1; v.media = b.as<mi_medium>(); }
+            HIP_TRY(hipStreamSynchronize(c->stream));   // local
+            if (d->mesh_medium) {
+                for (uint32_t m = 0; m < 2 * d->n_meshes; ++m) if (d->mesh_medium[m] >= (int32_t)d->n_media) return fail("mi_scene_upload: mesh_medium refers to a missing medium");
+                DevBuf &b = next();
+                if (upload(c, b, d->mesh_medium, 2 * (size_t)d->n_meshes * sizeof(int32_t))) return -1;
+                v.mesh_medium = b.as<int32_t>();
+            }
+        }
+        if (d->material_bssrdf) {
+            std::vector<DevBssrdfTable> tabs(d->n_bssrdf_tables);
+            for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {
+                const mi_bssrdf_table &t = d->bssrdf_tables[i];
+                if (t.n_rho < 2 || t.n_radius < 2) return fail("mi_scene_upload: degenerate BSSRDF table");
+                tabs[i].n_rho = t.n_rho; tabs[i].n_radius = t.n_radius;
+                { DevBuf &b = next(); if (upload(c, b, t.rho_samples, (size_t)t.n_rho * 4)) return -1; tabs[i].rho_samples = b.as<float>(); }
+                { DevBuf &b = next(); if (upload(c, b, t.radius_samples, (size_t)t.n_radius * 4)) return -1; tabs[i].radius_samples = b.as<float>(); }
+                { DevBuf &b = next(); if (upload(c, b, t.profile, (size_t)t.n_rho * t.n_radius * 4)) return -1; tabs[i].profile = b.as<float>(); }
+                { DevBuf &b = next(); if (upload(c, b, t.rho_eff, (size_t)t.n_rho * 4)) return -1; tabs[i].rho_eff = b.as<float>(); }
+                { DevBuf &b = next(); if (upload(c, b, t.profile_cdf, (size_t)t.n_rho * t.n_radius * 4)) return -1; tabs[i].profile_cdf = b.as<float>(); }
+            }
+            for (uint32_t m = 0; m < d->n_materials; ++m) {
+                const mi_bssrdf_desc &b = d->material_bssrdf[m];
+                if (b.kind == MI_BSSRDF_NONE) continue;
+                if (b.table < 0 || (uint32_t)b.table >= d->n_bssrdf_tables) return fail("mi_scene_upload: BSSRDF material refers to a missing table");
+                const int nodes[4] = {b.kind == MI_BSSRDF_SUBSURFACE ? b.sigma_a : b.Kd, b.kind == MI_BSSRDF_SUBSURFACE ? b.sigma_s : b.mfp, 0, 0};
+                for (int k = 0; k < 2; ++k) if (nodes[k] < 0 || (uint32_t)nodes[k] >= d->n_textures) return fail("mi_scene_upload: BSSRDF material refers to a missing texture node");
+            }
+            { DevBuf &b = next(); if (upload(c, b, tabs.data(), tabs.size() * sizeof(DevBssrdfTable))) return -1; v.tables = b.as<DevBssrdfTable>(); }
+            { DevBuf &b = next(); if (upload(c, b, d->material_bssrdf, (size_t)d->n_materials * sizeof(mi_bssrdf_desc))) return -1; v.bssrdf = b.as<mi_bssrdf_desc>(); }
+            HIP_TRY(hipStreamSynchronize(c->stream));   // local
+        }
+        // sampler dimensions: ratio / delta tracking in grid media draw a data-dependent number per segment; the reference aborts past its tables
+        // (sobol.cpp:48-51, halton.h:72-75) and the device clamps to the last dimension instead -- such paths are outside both samplers' range
+        { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->nkeys = d->n_materials + 2;
     if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
     // film
@@ -2128,6 +2193,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     tic(c, MI_K_RAYGEN);
     if (c->hasTex || c->hasInst) hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, st, sc, ps, pass, 0u);
     else hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, st, sc, ps, pass, 0u);
+    if (c->volKernel && c->vol.handle_media)
+        hipLaunchKernelGGL(k_vol_camera_medium, grid, block, 0, st, ps, pass.list_xy ? pass.npix : pass.npix * pass.ns, c->vol.camera_medium);
     toc(c);
     uint32_t qin = 0;
     int iter = 0;
@@ -2162,7 +2229,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
-            if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
+            if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
+                hipLaunchKernelGGL(k_shade_vol, grid, block, 0, st, c->scDev, ps, c->vol, qout);
+            } else if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
                 if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             } else if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
@@ -2177,6 +2246,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             }
         }
         toc(c);
+        if (!c->volKernel) {   // (k_shade_vol queues no shadow / MIS rays)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
         LAUNCH_TRACE(2);
@@ -2185,6 +2255,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_MIS_CLOSEST);
         LAUNCH_TRACE(1);
         toc(c);
+        }
         qin = qout;
         ++iter;
         if (iter > sc.max_depth) {

@@ -122,6 +122,7 @@ struct RGB {   // RGBSpectrum, core/spectrum.h:429-488: per-component true arith
     PT_DEV bool IsBlack() const { return r == 0 && g == 0 && b == 0; }
     PT_DEV RGB operator+(const RGB &o) const { return RGB(r + o.r, g + o.g, b + o.b); }
     PT_DEV RGB operator-(const RGB &o) const { return RGB(r - o.r, g - o.g, b - o.b); }
+    PT_DEV RGB operator-() const { return RGB(-r, -g, -b); }
     PT_DEV RGB operator*(const RGB &o) const { return RGB(r * o.r, g * o.g, b * o.b); }
     PT_DEV RGB operator/(const RGB &o) const { return RGB(r / o.r, g / o.g, b / o.b); }
     PT_DEV RGB operator*(Float s) const { return RGB(r * s, g * s, b * s); }

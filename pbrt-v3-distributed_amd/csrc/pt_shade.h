@@ -187,6 +187,16 @@ PT_DEV RGB FresnelEvaluate(const mi_bxdf &b, Float cosThetaI) {   // reflection.
 }
 
 // MicrofacetDistribution (core/microfacet.{h,cpp}): TrowbridgeReitz (all stock materials) / Beckmann D, Lambda
+// SeparableBSSRDF::Sw (core/bssrdf.h:93-96) over FresnelMoment1 (core/bssrdf.cpp:43-52; one coefficient is a double constant in the reference, kept as such)
+PT_DEV Float FresnelMoment1D(Float eta) {
+    Float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
+    if (eta < 1) return (Float)(0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945 * eta3 + 2.49277f * eta4 - 0.68441f * eta5);
+    return -4.61686f + 11.1136f * eta - 10.4646f * eta2 + 5.11455f * eta3 - 1.27198f * eta4 + 0.12746f * eta5;
+}
+PT_DEV Float BssrdfSw(Float eta, const V3 &w) {
+    Float c = 1 - 2 * FresnelMoment1D(1 / eta);
+    return (1 - FrDielectric(CosTheta(w), 1, eta)) / (c * PT_PI);
+}
 struct Distrib {
     Float ax, ay;
     int beckmann;
@@ -262,7 +272,7 @@ PT_DEV V3 Distrib::Sample_wh(const V3 &wo, Float u0, Float u1) const {   // micr
 
 PT_DEV int BxdfFlags(int type) {
     switch (type) {
-    case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: case MI_BXDF_BSSRDF_ADAPTER: return BSDF_REFLECTION | BSDF_DIFFUSE;
     case MI_BXDF_LAMBERT_T: return BSDF_TRANSMISSION | BSDF_DIFFUSE;
     case MI_BXDF_SPECULAR_R: return BSDF_REFLECTION | BSDF_SPECULAR;
     case MI_BXDF_SPECULAR_T: return BSDF_TRANSMISSION | BSDF_SPECULAR;
@@ -299,6 +309,9 @@ PT_DEV const mi_bxdf *Generic(const mi_bxdf *b) { return b; }
 template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
+    if constexpr (!U) {   // SeparableBSSRDFAdapter::f core/bssrdf.h:162-167 (TransportMode::Radiance): only per-lane lobe lists carry it (k_shade_vol)
+        if (b.type == MI_BXDF_BSSRDF_ADAPTER) { RGB f(BssrdfSw(b.etaB, wi)); return f * (b.etaB * b.etaB); }
+    }
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
@@ -365,6 +378,7 @@ template <bool U = true, class BP = BxdfConst> PT_DEV RGB BxdfF(BP b, const V3 &
 template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
+    if constexpr (!U) { if (b.type == MI_BXDF_BSSRDF_ADAPTER) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0; }   // BxDF::Pdf reflection.cpp:387-389
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
@@ -406,6 +420,14 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
     RGB f;
+    if constexpr (!U) {
+        if (b.type == MI_BXDF_BSSRDF_ADAPTER) {   // BxDF::Sample_f reflection.cpp:378-385
+            *wi = CosineSampleHemisphere(u0, u1);
+            if (wo.z < 0) wi->z *= -1;
+            *pdf = BxdfPdf<U>(bp, wo, *wi);
+            return BxdfF_unscaled<U>(bp, wo, *wi);
+        }
+    }
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
         *wi = CosineSampleHemisphere(u0, u1);

@@ -1,0 +1,527 @@
+// k_shade_vol -- the shading kernel of scenes rendered with Integrator "volpath" (VolPathIntegrator::Li, integrators/volpath.cpp:55-190)
+// and of scenes whose materials carry a BSSRDF (the subsurface branch, integrators/path.cpp:153-174 / volpath.cpp:153-180).
+//
+// Place in the wavefront pipeline: path-extension rays still go through k_trace<0> and the material sort -- that is where the time
+// goes -- and this kernel replaces k_shade.  What differs from k_shade is WHERE the secondary rays are traced: the reference draws
+// sampler dimensions inside its visibility code (ratio tracking in Medium::Tr, core/light.cpp:63-82, core/scene.cpp:56-70) and inside
+// the BSSRDF probe, BEFORE the continuation direction is sampled, and the count is data dependent.  The dimension stream of a path is
+// therefore only reproducible if those rays are resolved in sequence.  Here every lane walks the same general BVH4 steps the
+// traversal kernels use (TravNodeStep / TravLeafStep with spheres and alpha masks) for its own transmittance, MIS and probe rays,
+// on an LDS stack of its own.  This file is included by pbrt_amd.hip after PathState / ChunkIter / wave_append.
+#pragma once
+#include "pt_volume.h"
+
+struct LaneTracer {
+    const DevScene *scp;
+    LdsStackEntry *lds;
+    StackEntry *spill;
+    uint32_t nClosest, nAny, guardTrips;
+};
+// one ray, traced by this lane alone: closest hit (BVHAccel::Intersect) or any hit (IntersectP); returns (prim, tHit bits)
+template <bool ANY>
+__device__ __noinline__ uint2 TraceLane(LaneTracer *lt, const V3 o, const V3 d, Float tMax) {
+    const DevScene &sc = *lt->scp;
+    TravStack st;
+    st.lds = lt->lds; st.spill = lt->spill;
+    TravState ts;
+    ts.init(sc, o, d, tMax, st);
+    TraceCounters tc = {0, 0};
+    uint32_t steps = 0;
+    while (!ts.done()) {
+        if (++steps > (1u << 22)) { ++lt->guardTrips; ts.prim = TRAV_MISS; break; }   // non-termination guard, reported through MI_CNT_TRACE_GUARD_TRIPS
+        if (ts.atNode()) TravNodeStep<false>(sc, ts, st, &tc);
+        else TravLeafStep<ANY, false, true, true>(sc, ts, st, &tc);
+    }
+    if (ANY) ++lt->nAny; else ++lt->nClosest;
+    return make_uint2(ts.prim, __float_as_uint(ts.tHit));
+}
+
+// SurfaceInteraction of a hit + the medium interface GeometricPrimitive::Intersect leaves on it (core/primitive.cpp:122-126)
+struct VHit {
+    Isect is;
+    IsectX ix;
+    uint4 tinfo;
+    int mIn, mOut;
+};
+__device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, uint32_t prim, const V3 o, const V3 d, int rayMedium, bool wantTex, VHit *out) {
+    const DevScene &sc = *scp;
+    uint4 tinfo = sc.tri_info[prim];
+    TriShadeRegs tsr = LoadTriShade(sc.tri_shade, prim);
+    V3 p0, p1, p2;
+    uint32_t tf;
+    LoadTri(sc, prim, &p0, &p1, &p2, &tf);
+    out->ix = IsectX();
+    if (tf & TRI_FLAG_SPHERE) out->is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim);
+    else {
+        TriHit th;
+        TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0, b1, b2, t
+        out->is = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), d, prim);
+        if (wantTex) out->ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
+    }
+    out->tinfo = tinfo;
+    int in = -1, outm = -1;
+    if (vol->mesh_medium) { in = vol->mesh_medium[2 * tinfo.w]; outm = vol->mesh_medium[2 * tinfo.w + 1]; }
+    if (in != outm) { out->mIn = in; out->mOut = outm; }   // MediumInterface::IsMediumTransition
+    else out->mIn = out->mOut = rayMedium;
+}
+PT_DEV int GetMediumOf(const V3 &n, int mIn, int mOut, const V3 &w) { return Dot(w, n) > 0 ? mOut : mIn; }   // Interaction::GetMedium(w) interaction.h:80-82
+
+// the point Light::Sample_Li put into the VisibilityTester (p1): only needed when a transmittance ray has to be re-spawned
+// behind a BSDF-less interface (VisibilityTester::Tr, core/light.cpp:63-82), so it is re-derived there instead of carried along
+struct LightPoint { V3 p, pError, n; };
+__device__ __noinline__ LightPoint LightPointOf(const DevScene *scp, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1, const V3 wi) {
+    LightPoint lp;
+    lp.pError = V3(); lp.n = V3();
+    const int type = dl->type;
+    if (type == MI_LIGHT_AREA_TRI) {   // Triangle::Sample(u) shapes/triangle.cpp:583-608, as SampleLi evaluates it
+        Float su0 = sqrtf_(u0);
+        Float b0 = 1 - su0, b1 = u1 * su0;
+        V3 p0 = v3(dl->p0), p1 = v3(dl->p1), p2 = v3(dl->p2);
+        lp.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+        V3 n = Normalize(Cross(p1 - p0, p2 - p0));
+        if (dl->mesh_flags & MI_MESH_HAS_N) {
+            TriShadeRegs tsr = LoadTriShade(scp->tri_shade, (uint32_t)dl->tri);
+            V3 ns = b0 * tsr.n0() + b1 * tsr.n1() + (1 - b0 - b1) * tsr.n2();
+            n = Faceforward(n, ns);
+        } else if (dl->mesh_flags & MI_MESH_FLIP)
+            n = n * -1.f;
+        lp.n = n;
+        lp.pError = gamma_n(6) * (Abs(b0 * p0) + Abs(b1 * p1) + Abs((1 - b0 - b1) * p2));
+    } else if (type == MI_LIGHT_AREA_SPHERE) {
+        SphereSample ss;
+        SphereSampleRef((const mi_sphere *)dl->ext, refP, refPError, refN, u0, u1, &ss);
+        lp.p = ss.p; lp.pError = ss.pError; lp.n = ss.n;
+    } else if (type == MI_LIGHT_POINT || type == MI_LIGHT_SPOT)
+        lp.p = v3(dl->pos);
+    else   // distant / infinite: Interaction(ref.p + wi * (2 * worldRadius))
+        lp.p = refP + wi * (2 * dl->world_radius);
+    return lp;
+}
+
+struct VolCtx {
+    const DevScene *scp;
+    const DevVol *vol;
+    LaneTracer *lt;
+    Sampler *smp;
+};
+
+// VisibilityTester::Tr (core/light.cpp:63-82) with media, VisibilityTester::Unoccluded (:59-61) without
+__device__ __noinline__ RGB VisibilityTrD(VolCtx cx, V3 o, V3 d, Float tMax, int medium, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0,
+                                          Float u1, const V3 wi) {
+    if (!cx.vol->handle_media) {
+        uint2 h = TraceLane<true>(cx.lt, o, d, tMax);
+        return h.x == TRAV_MISS ? RGB(1.f) : RGB(0.f);
+    }
+    RGB Tr(1.f);
+    for (int guard = 0; guard < 65536; ++guard) {
+        uint2 h = TraceLane<false>(cx.lt, o, d, tMax);
+        const bool hitSurface = h.x != TRAV_MISS;
+        if (hitSurface && (int)cx.scp->tri_info[h.x].y >= 0) return RGB(0.f);
+        if (medium >= 0) Tr = Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? __uint_as_float(h.y) : tMax, cx.smp);
+        if (!hitSurface) break;
+        VHit vh;
+        HitToIsect(cx.scp, cx.vol, h.x, o, d, medium, false, &vh);
+        LightPoint lp = LightPointOf(cx.scp, dl, refP, refPError, refN, u0, u1, wi);
+        ShadowRay sr = SpawnRayTo(vh.is, lp.p, lp.pError, lp.n);   // isect.SpawnRayTo(p1)
+        o = sr.o; d = sr.d; tMax = sr.tMax;
+        medium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, d);
+    }
+    return Tr;
+}
+// Scene::IntersectTr (core/scene.cpp:56-70) with media, Scene::Intersect without.  *oOut: origin of the ray segment that found the hit
+__device__ __noinline__ uint32_t IntersectTrD(VolCtx cx, V3 o, const V3 d, int medium, RGB *Tr, V3 *oOut) {
+    *Tr = RGB(1.f);
+    if (!cx.vol->handle_media) {
+        uint2 h = TraceLane<false>(cx.lt, o, d, PT_INFINITY);
+        *oOut = o;
+        return h.x;
+    }
+    for (int guard = 0; guard < 65536; ++guard) {
+        uint2 h = TraceLane<false>(cx.lt, o, d, PT_INFINITY);
+        const bool hitSurface = h.x != TRAV_MISS;
+        if (medium >= 0) *Tr = *Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? __uint_as_float(h.y) : PT_INFINITY, cx.smp);
+        *oOut = o;
+        if (!hitSurface) return TRAV_MISS;
+        if ((int)cx.scp->tri_info[h.x].y >= 0) return h.x;
+        VHit vh;
+        HitToIsect(cx.scp, cx.vol, h.x, o, d, medium, false, &vh);
+        o = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, d);   // isect.SpawnRay(ray.d)
+        medium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, d);
+    }
+    return TRAV_MISS;
+}
+
+typedef BSDF_T<false> LaneBSDF;
+// EstimateDirect (core/integrator.cpp:108-215); bsdf == nullptr: `it` is a MediumInteraction with phase function HenyeyGreenstein(g)
+__device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g, Float uS0, Float uS1, int lightNum, Float uL0,
+                                            Float uL1) {
+    const DevScene &sc = *cx.scp;
+    const Isect &it = *itp;
+    const DevLight *light = sc.lights + lightNum;
+    const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+    RGB Ld(0.f);
+    LightSample ls = SampleLiAny(GeomTables(sc), light, it.p, it.pError, it.n, uL0, uL1);
+    Float lightPdf = ls.pdf, scatteringPdf = 0;
+    if (lightPdf > 0 && !ls.Li.IsBlack()) {
+        RGB f;
+        if (bsdf) {
+            f = bsdf->f(it.wo, ls.wi, bsdfFlags) * AbsDot(ls.wi, it.ns);
+            scatteringPdf = bsdf->Pdf(it.wo, ls.wi, bsdfFlags);
+        } else {
+            Float p = HGp(g, it.wo, ls.wi);
+            f = RGB(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack()) {
+            RGB Li = ls.Li * VisibilityTrD(cx, ls.shadow.o, ls.shadow.d, ls.shadow.tMax, GetMediumOf(it.n, mIn, mOut, ls.shadow.d), light, it.p, it.pError, it.n, uL0, uL1, ls.wi);
+            if (!Li.IsBlack()) {
+                if (ls.delta) Ld = Ld + f * Li / lightPdf;
+                else {
+                    Float weight = PowerHeuristic(lightPdf, scatteringPdf);
+                    Ld = Ld + f * Li * weight / lightPdf;
+                }
+            }
+        }
+    }
+    if (!ls.delta) {
+        RGB f;
+        V3 wi;
+        bool sampledSpecular = false;
+        if (bsdf) {
+            int sampledType;
+            f = bsdf->Sample_f(it.wo, &wi, uS0, uS1, &scatteringPdf, bsdfFlags, &sampledType);
+            f = f * AbsDot(wi, it.ns);
+            sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        } else {
+            Float p = HGSample_p(g, it.wo, &wi, uS0, uS1);
+            f = RGB(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack() && scatteringPdf > 0) {
+            Float weight = 1;
+            if (!sampledSpecular) {
+                lightPdf = PdfLiAny(GeomTables(sc), light, it.p, it.pError, it.n, wi);
+                if (lightPdf == 0) return Ld;
+                weight = PowerHeuristic(scatteringPdf, lightPdf);
+            }
+            V3 ro = OffsetRayOrigin(it.p, it.pError, it.n, wi), segO;   // it.SpawnRay(wi)
+            RGB Tr(1.f);
+            uint32_t prim = IntersectTrD(cx, ro, wi, GetMediumOf(it.n, mIn, mOut, wi), &Tr, &segO);
+            RGB Li(0.f);
+            if (prim != TRAV_MISS) {
+                if ((int)sc.tri_info[prim].z == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light
+                    VHit vh;
+                    HitToIsect(cx.scp, cx.vol, prim, segO, wi, -1, false, &vh);
+                    Li = AreaL(*light, vh.is.n, -wi);   // lightIsect.Le(-wi)
+                }
+            } else if (light->type == MI_LIGHT_INFINITE)
+                Li = InfiniteLe(light, wi);
+            if (!Li.IsBlack()) Ld = Ld + f * Li * Tr * weight / scatteringPdf;
+        }
+    }
+    return Ld;
+}
+
+// UniformSampleOneLight (core/integrator.cpp:85-106) over the light distribution looked up at it.p (path.cpp:125-127 / volpath.cpp:96,125)
+__device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g) {
+    const DevScene &sc = *cx.scp;
+    if (sc.n_lights == 0) return RGB(0.f);
+    const float *vcdf = sc.light_cdf, *vfunc = sc.light_func;
+    Float funcInt = sc.light_func_int;
+    if (sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL) {   // SpatialLightDistribution::Lookup lightdistrib.cpp:139-152; Bounds3::Offset geometry.h:786-792
+        V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
+        V3 off = itp->p - bmin;
+        if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
+        if (bmax.y > bmin.y) off.y /= bmax.y - bmin.y;
+        if (bmax.z > bmin.z) off.z /= bmax.z - bmin.z;
+        int v0 = (int)(off.x * sc.sp_nvox[0]), v1 = (int)(off.y * sc.sp_nvox[1]), v2 = (int)(off.z * sc.sp_nvox[2]);
+        v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
+        v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
+        v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
+        size_t vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
+        vcdf = sc.sp_cdf + vox * (sc.n_lights + 1);
+        vfunc = sc.sp_func + vox * sc.n_lights;
+        funcInt = sc.sp_func_int[vox];
+    }
+    Float ul = cx.smp->Get1D(sc);
+    const int size = (int)sc.n_lights + 1;
+    int first = CdfCountLE(vcdf, size, ul);   // Distribution1D::SampleDiscrete core/sampling.h:90-100
+    int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+    Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
+    if (selPdf == 0) return RGB(0.f);
+    Float uL0, uL1, uS0, uS1;
+    cx.smp->Get2D(sc, &uL0, &uL1);
+    cx.smp->Get2D(sc, &uS0, &uS1);
+    return EstimateDirectD(cx, itp, mIn, mOut, bsdf, g, uS0, uS1, lightNum, uL0, uL1) / selPdf;
+}
+
+// si->bssrdf of SubsurfaceMaterial / KdSubsurfaceMaterial::ComputeScatteringFunctions (materials/subsurface.cpp:95-99, kdsubsurface.cpp:87-93),
+// evaluated on the interaction the BSDF evaluation left behind (bump-mapped shading frame)
+__device__ __noinline__ void ComputeBSSRDFD(const DevVol *vol, int mat, const Isect *si, const IsectX *ix, DevBSSRDF *out) {
+    out->table = nullptr;
+    if (!vol->bssrdf) return;
+    // MixMaterial (mixmat.cpp:45-64) evaluates m1 on *si itself: si->bssrdf is then m1's, carrying m1 as its material -- which no primitive of
+    // the mix has, so its probe rays accept nothing and the path ends at the first transmission (the reference's behaviour, kept)
+    for (int guard = 0; guard < 64 && c_tex.descs && c_tex.descs[mat].type == MI_MAT_MIX && c_tex.descs[mat].textured; ++guard) mat = c_tex.descs[mat].m1;
+    const mi_bssrdf_desc b = vol->bssrdf[mat];
+    if (b.kind == MI_BSSRDF_NONE) return;
+    const DevBssrdfTable *tb = vol->tables + b.table;
+    RGB sig_a, sig_s;
+    TexCtx tc = TexCtxOf(*si, *ix);
+    if (b.kind == MI_BSSRDF_SUBSURFACE) {
+        sig_a = b.scale * ClampRGB(TexEval(b.sigma_a, tc));
+        sig_s = b.scale * ClampRGB(TexEval(b.sigma_s, tc));
+    } else {   // SubsurfaceFromDiffuse core/bssrdf.cpp:178-188
+        RGB mfree = b.scale * ClampRGB(TexEval(b.mfp, tc));
+        RGB kd = ClampRGB(TexEval(b.Kd, tc));
+        Float rr = InvertCatmullRom(tb->n_rho, tb->rho_samples, tb->rho_eff, kd.r);
+        Float rg = InvertCatmullRom(tb->n_rho, tb->rho_samples, tb->rho_eff, kd.g);
+        Float rb = InvertCatmullRom(tb->n_rho, tb->rho_samples, tb->rho_eff, kd.b);
+        sig_s = RGB(rr / mfree.r, rg / mfree.g, rb / mfree.b);
+        sig_a = RGB((1 - rr) / mfree.r, (1 - rg) / mfree.g, (1 - rb) / mfree.b);
+    }
+    out->table = tb;
+    out->poP = si->p; out->ns = si->ns; out->ss = Normalize(si->dpdus); out->ts = Cross(out->ns, out->ss);
+    out->eta = b.eta; out->material = mat;
+    out->sigma_t = sig_a + sig_s;
+    out->rho = RGB(out->sigma_t.r != 0 ? sig_s.r / out->sigma_t.r : 0, out->sigma_t.g != 0 ? sig_s.g / out->sigma_t.g : 0, out->sigma_t.b != 0 ? sig_s.b / out->sigma_t.b : 0);
+}
+// SeparableBSSRDF::Sample_Sp (core/bssrdf.cpp:249-326): a probe segment through the sphere of radius rMax around po; every hit on a primitive
+// of the same material object counts, one of them is chosen.  The reference collects the chain in a list; here the chain is walked twice
+// (count, then stop at the chosen one) -- the same rays, hence the same hits.
+__device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Float u1, Float u20, Float u21, VHit *pi, Float *pdf) {
+    V3 vx, vy, vz;
+    if (u1 < .5f) { vx = bs->ss; vy = bs->ts; vz = bs->ns; u1 *= 2; }
+    else if (u1 < .75f) { vx = bs->ts; vy = bs->ns; vz = bs->ss; u1 = (u1 - .5f) * 4; }
+    else { vx = bs->ns; vy = bs->ss; vz = bs->ts; u1 = (u1 - .75f) * 4; }
+    int ch = (int)(u1 * 3);
+    ch = ch < 0 ? 0 : (ch > 2 ? 2 : ch);
+    u1 = u1 * 3 - ch;
+    Float r = BssrdfSample_Sr(bs, ch, u20);
+    if (r < 0) return RGB(0.f);
+    Float phi = 2 * PT_PI * u21;
+    Float rMax = BssrdfSample_Sr(bs, ch, 0.999f);
+    if (r >= rMax) return RGB(0.f);
+    Float l = 2 * sqrtf_(rMax * rMax - r * r);
+    const V3 baseP = bs->poP + r * (vx * cosf_(phi) + vy * sinf_(phi)) - l * vz * 0.5f;
+    const V3 pTarget = baseP + l * vz;
+    int nFound = 0, selected = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds, no media
+        int mIn = -1, mOut = -1, seen = 0;
+        for (int guard = 0; guard < 65536; ++guard) {
+            V3 dir = pTarget - p;
+            if (dir.x == 0 && dir.y == 0 && dir.z == 0) break;
+            V3 origin = OffsetRayOrigin(p, pErr, n, dir);   // Interaction::SpawnRayTo(const Point3f &) interaction.h:68-72
+            uint2 h = TraceLane<false>(cx.lt, origin, dir, 1 - PT_SHADOW_EPS);
+            if (h.x == TRAV_MISS) break;
+            VHit vh;
+            HitToIsect(cx.scp, cx.vol, h.x, origin, dir, GetMediumOf(n, mIn, mOut, dir), false, &vh);
+            p = vh.is.p; pErr = vh.is.pError; n = vh.is.n; mIn = vh.mIn; mOut = vh.mOut;
+            if ((int)vh.tinfo.y == bs->material) {
+                if (pass == 1 && seen == selected) { *pi = vh; break; }
+                ++seen;
+            }
+        }
+        if (pass == 0) {
+            nFound = seen;
+            if (nFound == 0) return RGB(0.0f);
+            selected = (int)(u1 * nFound);
+            selected = selected < 0 ? 0 : (selected > nFound - 1 ? nFound - 1 : selected);
+        }
+    }
+    *pdf = BssrdfPdf_Sp(bs, pi->is.p, pi->is.n) / nFound;
+    return BssrdfSr(bs, (bs->poP - pi->is.p).Length());   // Sp(pi) = Sr(Distance(po.p, pi.p))
+}
+
+// The out-of-line routines this kernel shares with k_shade<..., TEX> (BSDF, texture and light code) are compiled ONCE, with the loosest
+// register bound of their callers: a lower occupancy target here would take the textured shading kernel from 168 to 244 VGPRs (measured).
+#ifndef PT_VOL_SHADE_WAVES
+#define PT_VOL_SHADE_WAVES PT_TEX_SHADE_WAVES
+#endif
+// one path vertex per lane (material-sorted queue, as k_shade): Medium::Sample on the segment, then either the medium interaction or the
+// surface interaction of VolPathIntegrator::Li's loop body; PathIntegrator::Li's body when vol.handle_media == 0 (scenes with a BSSRDF)
+__global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    const DevScene &sc = *scp;
+    LaneTracer lt;
+    lt.scp = scp;
+    lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    lt.nClosest = lt.nAny = lt.guardTrips = 0;
+    const uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
+    uint32_t nseg = 0;
+    for (ChunkIter it(n); it.more(); it.next()) {
+        const uint32_t i = it.item();
+        const bool active = i < n;
+        bool cont = false;
+        uint32_t slot = 0, rayKey = 0;
+        if (active) {
+            slot = ps.q_sorted[i];
+            const uint2 hr = ps.rec[slot].hit;
+            const float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
+            const uint4 s4 = ps.rec[slot].smp;
+            const V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            RGB beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
+            Float etaScale = b4.w;
+            int bounces = (int)(s4.w & 0xffffu);
+            bool specularBounce = (s4.w >> 16) & 1u;
+            bool noDiff = (s4.w >> 17) & 1u;
+            int medium = vol.handle_media ? (int)__float_as_uint(ps.rec[slot].pad2.x) : -1;
+            Sampler smp;
+            smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+            smp.dimension = (int)s4.z;
+            smp.px = smp.py = 0;   // only dimensions 0 / 1 (camera sample) look at the pixel
+            VolCtx cx;
+            cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = &smp;
+            ++nseg;
+            const bool found = hr.x != MISS_PRIM;
+            V3 no = ro, nd = rd;   // the next ray
+            int nmedium = medium;
+            bool alive = true, scattered = false, nullCrossing = false;
+            // volpath.cpp:82-83: if (ray.medium) beta *= ray.medium->Sample(ray, sampler, arena, &mi)
+            MediumSampleOut ms;
+            ms.valid = false;
+            if (medium >= 0) {
+                ms = MediumSample(scp, vol.media + medium, ro, rd, found ? __uint_as_float(hr.y) : o4.w, &smp);
+                beta = beta * ms.w;
+            }
+            if (beta.IsBlack()) alive = false;
+            if (alive && ms.valid) {   // volpath.cpp:87-105: scattering inside the medium
+                if (bounces >= sc.max_depth) alive = false;
+                else {
+                    Isect mi;   // the MediumInteraction as an Interaction: no normal, no error bounds, the same medium on both sides
+                    mi.p = ms.p; mi.pError = V3(); mi.n = V3(); mi.ns = V3(); mi.dpdus = V3(); mi.wo = -rd; mi.prim = MISS_PRIM;
+                    const Float g = vol.media[medium].g;
+                    L = L + beta * UniformSampleOneLightD(cx, &mi, medium, medium, nullptr, g);
+                    Float u0, u1;
+                    smp.Get2D(sc, &u0, &u1);
+                    V3 wi;
+                    HGSample_p(g, -rd, &wi, u0, u1);
+                    no = OffsetRayOrigin(mi.p, mi.pError, mi.n, wi);   // mi.SpawnRay(wi)
+                    nd = wi;
+                    specularBounce = false;
+                    scattered = true;
+                }
+            } else if (alive) {
+                VHit vh;
+                if (found) HitToIsect(scp, &vol, hr.x, ro, rd, medium, vol.textured != 0, &vh);
+                if (bounces == 0 || specularBounce) {   // volpath.cpp:110-116 / path.cpp:91-101
+                    if (found) {
+                        int li = (int)vh.tinfo.z;
+                        if (li >= 0) L = L + beta * AreaL(sc.lights[li], vh.is.n, -rd);
+                    } else
+                        for (uint32_t k = 0; k < sc.n_infinite; ++k) L = L + beta * InfiniteLe(&sc.lights[sc.infinite_lights[k]], rd);
+                }
+                if (!found || bounces >= sc.max_depth) alive = false;
+                else {
+                    const int matIdx = (int)vh.tinfo.y;
+                    if (matIdx < 0) {   // a surface without a BSDF (medium boundary): step through, same bounce count (volpath.cpp:117-121 / path.cpp:108-113)
+                        no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, rd);
+                        nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, rd);
+                        nullCrossing = true;
+                        noDiff = true;
+                    } else {
+                        mi_material laneMat;
+                        if (vol.textured) {   // isect.ComputeScatteringFunctions(ray, arena, true): differentials of camera rays, then the material
+                            if (bounces == 0 && !noDiff) {
+                                float2 pf = ps.rec[slot].pfilm, ln = ps.rec[slot].lens;
+                                RayDiffT rdf = CameraDifferentials(&c_tex.camera, pf.x, pf.y, ln.x, ln.y, c_tex.spp, ro, rd);
+                                ComputeDifferentials(vh.is.p, vh.is.n, &vh.ix, rdf);
+                            }
+                            ComputeScatteringFunctionsT(sc.materials, matIdx, &vh.is, &vh.ix, &laneMat);
+                        } else
+                            laneMat = sc.materials[matIdx];
+                        DevBSSRDF bssrdf;
+                        bssrdf.table = nullptr;
+                        if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf);
+                        LaneBSDF bsdf(vh.is, &laneMat);
+                        // volpath.cpp:125-128 samples a light unconditionally; path.cpp:122 only for surfaces with a non-specular lobe
+                        if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
+                        V3 wo = -rd, wi;
+                        Float pdf, u0, u1;
+                        int flags;
+                        smp.Get2D(sc, &u0, &u1);
+                        RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                        if (f.IsBlack() || pdf == 0.f) alive = false;
+                        else {
+                            beta = beta * (f * AbsDot(wi, vh.is.ns) / pdf);
+                            specularBounce = (flags & BSDF_SPECULAR) != 0;
+                            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                                Float eta = laneMat.eta;
+                                etaScale *= (Dot(wo, vh.is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                            }
+                            no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);   // isect.SpawnRay(wi)
+                            nd = wi;
+                            nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi);
+                            scattered = true;
+                            if (bssrdf.table && (flags & BSDF_TRANSMISSION)) {   // path.cpp:153-174 / volpath.cpp:153-180
+                                // S = bssrdf->Sample_S(scene, sampler.Get1D(), sampler.Get2D(), ...): the two calls are function ARGUMENTS and
+                                // g++ evaluates them right to left -- the 2-D sample takes the earlier dimensions (pinned by the oracle's fixtures)
+                                Float u20, u21, u1s, spdf = 0;
+                                smp.Get2D(sc, &u20, &u21);
+                                u1s = smp.Get1D(sc);
+                                VHit pi;
+                                RGB S = BssrdfSample_Sp(cx, &bssrdf, u1s, u20, u21, &pi, &spdf);
+                                if (S.IsBlack() || spdf == 0) alive = false;
+                                else {
+                                    beta = beta * (S / spdf);
+                                    // the entry vertex (bssrdf.cpp:235-247): a BSDF of the adapter lobe alone on pi's own shading frame, wo = shading.n
+                                    mi_material piMat;
+                                    piMat.n_bxdfs = 1; piMat.eta = 1;
+                                    __builtin_memset(&piMat.bxdfs[0], 0, sizeof(mi_bxdf));
+                                    piMat.bxdfs[0].type = MI_BXDF_BSSRDF_ADAPTER;
+                                    piMat.bxdfs[0].etaB = bssrdf.eta;
+                                    pi.is.wo = pi.is.ns;
+                                    LaneBSDF piBsdf(pi.is, &piMat);
+                                    L = L + beta * UniformSampleOneLightD(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
+                                    smp.Get2D(sc, &u0, &u1);
+                                    f = piBsdf.Sample_f(pi.is.wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                                    if (f.IsBlack() || pdf == 0) alive = false;
+                                    else {
+                                        beta = beta * (f * AbsDot(wi, pi.is.ns) / pdf);
+                                        specularBounce = (flags & BSDF_SPECULAR) != 0;
+                                        no = OffsetRayOrigin(pi.is.p, pi.is.pError, pi.is.n, wi);   // pi.SpawnRay(wi)
+                                        nd = wi;
+                                        nmedium = GetMediumOf(pi.is.n, pi.mIn, pi.mOut, wi);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (alive && scattered) {   // Russian roulette (volpath.cpp:183-189 / path.cpp:176-184); the loop's ++bounces
+                cont = true;
+                RGB rrBeta = beta * etaScale;
+                if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
+                    Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
+                    if (smp.Get1D(sc) < q) cont = false;
+                    else beta = beta / (1 - q);
+                }
+                ++bounces;
+            } else if (alive && nullCrossing)
+                cont = true;
+            ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
+            if (cont) {
+                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
+                ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
+                ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+                if (vol.handle_media) ps.rec[slot].pad2 = make_float4(__uint_as_float((uint32_t)nmedium), 0, 0, 0);
+            }
+        }
+        const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
+        uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+    }
+    wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
+    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], lt.nClosest);
+    wave_count(&ps.counters[MI_CNT_SHADOW_RAYS], lt.nAny);
+    if (lt.guardTrips) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], (unsigned long long)lt.guardTrips);
+}
+// Camera::medium onto the camera rays of a pass (Camera::GenerateRayDifferential sets ray->medium = medium, cameras/perspective.cpp:203)
+__global__ void __launch_bounds__(PT_BLOCK) k_vol_camera_medium(PathState ps, uint32_t n, int32_t medium) {
+    for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += gridDim.x * PT_BLOCK) ps.rec[i].pad2 = make_float4(__uint_as_float((uint32_t)medium), 0, 0, 0);
+}

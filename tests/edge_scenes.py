@@ -71,12 +71,22 @@ def vol_scene(name):
         t = t.replace('Material "glass" "float index" [1.5]', 'MediumInterface "milk" "haze"\nMaterial "glass" "float index" [1.3]')
         t = t.replace('Material "mirror"', 'MediumInterface "" "haze"\nMaterial "mirror"')
         return t.replace('LookAt', 'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\nMediumInterface "" "haze"\nLookAt', 1)
+    if name == "vol_alpha":      # alpha-masked meshes (no textured MATERIAL) in fog: VisibilityTester::Tr / Scene::IntersectTr go through Intersect, so
+        t = tex_scene("tex_alpha")   # alpha masks count and shadow-alpha masks do not; + a grid medium in a BSDF-less box crossed by shadow rays (ratio tracking)
+        t = t.replace('Integrator "path" "integer maxdepth" [4]', 'Integrator "volpath" "integer maxdepth" [4]')
+        box = "-1.5 0.1 -2  1.5 0.1 -2  1.5 0.1 0  -1.5 0.1 0  -1.5 2.1 -2  1.5 2.1 -2  1.5 2.1 0  -1.5 2.1 0"
+        med = ('AttributeBegin\nMakeNamedMedium "puff" "string type" "heterogeneous" "rgb sigma_a" [.5 .5 .5] "rgb sigma_s" [3 3 3] "float g" [.1]\n'
+               '  "integer nx" [4] "integer ny" [3] "integer nz" [5] "point p0" [-1.5 .1 -2] "point p1" [1.5 2.1 0] "float density" [%s]\nAttributeEnd\n'
+               'AttributeBegin\nMediumInterface "puff" "fog"\nMaterial ""\n%sAttributeEnd\n' % (_grid_density(4, 3, 5), _SMOKE_BOX % box))
+        t = t.replace('WorldBegin\n', 'WorldBegin\nMediumInterface "" "fog"\n' + med, 1)
+        return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.01 .015 .02] "rgb sigma_s" [.06 .05 .04] "float g" [.2]\n'
+                                   'MediumInterface "" "fog"\nLookAt', 1)
     if name == "vol_none":       # volpath on a scene without any medium: the integrator's own differences from "path" (unconditional light sample, Intersect-based visibility)
         return volpath(_OPEN % lights)
     raise KeyError(name)
 
 
-VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none"]
+VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none", "vol_alpha"]
 
 
 # ---- subsurface scattering: the BSSRDF branch of path / volpath

@@ -556,14 +556,34 @@ def test_killeroo_simple_vs_the_reference_scene():
     ctx.close()
 
 
-def test_volpath_scenes_are_refused_not_approximated():
-    """Row f4 is carried by the host and the CPU oracle so far: the device must say so instead of rendering "volpath" as "path"."""
-    sc = pa.Scene(text=edge_scenes.scene("vol_fog"))
-    with pytest.raises(RuntimeError, match="volpath"):
-        pa.Context(sc)
-    with pytest.raises(RuntimeError, match="BSSRDF"):   # subsurface materials: likewise host + oracle only so far
-        pa.Context(pa.Scene(text=edge_scenes.scene("sss_named")))
-    # the same media under Integrator "path" are ignored by the reference as well (handleMedia = false): rendered as before
+@pytest.mark.parametrize("name", edge_scenes.VOL_NAMES + edge_scenes.SSS_NAMES)
+def test_volpath_and_subsurface_scenes_vs_reference_fixture(name):
+    """Row f4 on the device (k_shade_vol, csrc/pt_volpath.h): VolPathIntegrator::Li (integrators/volpath.cpp:55-190) with homogeneous
+    and grid media, medium interfaces with and without a BSDF, the phase-function branch of EstimateDirect, VisibilityTester::Tr /
+    Scene::IntersectTr, and the BSSRDF branch (path.cpp:153-174) with TabulatedBSSRDF probe chains.  Image against the REFERENCE's render
+    of the same file (fixtures edge_vol_*.pfm / edge_sss_*.pfm), per-sample radiance against the oracle (which reproduces those fixtures
+    bit for bit): |dL| <= 1e-4 (1 + |L|) for >= 99.5 % of the samples."""
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    ctx = pa.Context(sc)
+    rng = np.random.default_rng(11)
+    n = 3000
+    xy = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n)], axis=1).astype(np.int32)
+    s = rng.integers(0, sc.info["spp"], n).astype(np.int32)
+    dev, ref = ctx.li(xy, s), ol.li(sc, xy, s)
+    ok = np.linalg.norm(dev - ref, axis=1) <= 1e-4 * (1 + np.linalg.norm(ref, axis=1))
+    assert ok.mean() >= 0.995, (name, ok.mean())
+    ctx.render()
+    img = sc.film_image(ctx.film())
+    fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    frac, relmse = ol.image_metrics(img, fx)
+    assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
+    assert ctx.counters()["trace_guard_trips"] == 0
+    ctx.close()
+
+
+def test_media_under_path_are_ignored_and_unsupported_combinations_refused(monkeypatch):
+    """PathIntegrator passes handleMedia = false: the same media under Integrator "path" do nothing, in the reference and here.  What
+    the device does not carry (k_shade_vol's per-lane tracer walks single-level trees) is refused loudly, never approximated."""
     sc2 = pa.Scene(text=edge_scenes.scene("vol_fog").replace('Integrator "volpath" "integer maxdepth" [6]', 'Integrator "path" "integer maxdepth" [5]'))
     ctx = pa.Context(sc2)
     ctx.render()
@@ -572,3 +592,8 @@ def test_volpath_scenes_are_refused_not_approximated():
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     ctx.close()
+    monkeypatch.delenv("PBRT_AMD_INSTANCING", raising=False)   # two-level instancing is the host's default
+    t = edge_scenes.scene("instances").replace('Integrator "path"', 'Integrator "volpath"')
+    assert 'Integrator "volpath"' in t
+    with pytest.raises(RuntimeError, match="two-level instancing"):
+        pa.Context(pa.Scene(text=t))

@@ -361,6 +361,24 @@ class Gen:
         return s + "WorldEnd\n"
 
 
+def oracle_image_forked(sc):
+    """the oracle's render in a child process: like the reference (LOG(FATAL) in sobol.cpp:48-51 / halton.h:72-75) it aborts when a path of a
+    volumetric scene runs past the sampler's dimension tables -- such scenes are invalid input, not mismatches"""
+    fn = tempfile.mktemp(suffix=".npy")
+    pid = os.fork()
+    if pid == 0:
+        try:
+            np.save(fn, sc.film_image(ol.render(sc, nthreads=8)[0]))
+            os._exit(0)
+        except BaseException:
+            os._exit(1)
+    _, status = os.waitpid(pid, 0)
+    if status != 0 or not os.path.exists(fn):
+        return None
+    img = np.load(fn); os.remove(fn)
+    return img
+
+
 def device_mode(a):
     """device vs oracle on the same random scenes (the oracle is pinned to the reference by the default mode of this tool)"""
     bad = refused = done = invalid = 0
@@ -372,7 +390,10 @@ def device_mode(a):
             continue
         try:
             sc = pa.Scene(text=text)
-            ref = sc.film_image(ol.render(sc, nthreads=8)[0])
+            ref = oracle_image_forked(sc)
+            if ref is None:
+                invalid += 1
+                continue
             ctx = pa.Context(sc)
             ctx.render()
             img = sc.film_image(ctx.film())
