@@ -29,6 +29,7 @@
 
 #include "pt_shade.h"
 #include "pt_material.h"
+#include "pt_volume.h"
 #include "pt_bvh8c.h"
 #include "pt_trace_fast.h"
 #include "sobol_tables.inc"
@@ -82,6 +83,7 @@ struct PathState {
     uint32_t *spill;
     int spill_per_thread;
     uint32_t cap;
+    uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_ROWS = 6 };
 #define QSEG 8u
@@ -160,6 +162,9 @@ PT_DEV void wave_append3(uint32_t *c0, uint32_t *c1, uint32_t *c2, bool a0, bool
     *p1 = b1 + (uint32_t)__popcll(m1 & lt);
     *p2 = b2 + (uint32_t)__popcll(m2 & lt);
 }
+#ifndef PT_WAVE_APPEND3
+#define PT_WAVE_APPEND3 wave_append3
+#endif
 // wave-aggregated histogram slot: lanes with equal key share one atomic (match-any built from ballots)
 PT_DEV uint32_t wave_key_rank(uint32_t *keycount, uint32_t key, bool active) {
     uint32_t lane = lane_id();
@@ -467,6 +472,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                         }
                     } else if (light.type == MI_LIGHT_INFINITE)
                         Li = InfiniteLe(&light, rd);   // light.Le(ray)
+                    if (ps.vol_tr && !Li.IsBlack()) {   // Scene::IntersectTr's Tr for a homogeneous medium up to the first surface (core/scene.cpp:56-70, homogeneous.cpp:41-44)
+                        float4 sg = ps.nee[slot].pad[0];
+                        if (sg.x != 0 || sg.y != 0 || sg.z != 0) {
+                            Float th = PT_INFINITY;
+                            if (ts.prim != TRAV_MISS) { if constexpr (FAST || C8) th = ts.tMax; else th = ts.tHit; }
+                            Li = Li * ExpRGB(-RGB(sg.x, sg.y, sg.z) * mn(th * rd.Length(), PT_MAX_FLOAT));
+                        }
+                    }
                     if (!Li.IsBlack()) {
                         float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
                         L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
@@ -980,7 +993,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         }
         uint32_t posE, posS, posM;
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;   // this block class's segment of the three queues
-        wave_append3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, wantShadow, wantMis, &posE, &posS, &posM);
+        PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, wantShadow, wantMis, &posE, &posS, &posM);
         if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
         if (wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (wantMis) ps.q_mis[qbase + posM] = slot;
@@ -1250,6 +1263,7 @@ struct mi_ctx {
     uint32_t nNodes8 = 0;
     int stackNeed8 = 0, spill8 = 1;
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
+    bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSDF-less interfaces / alpha masks / BSSRDF
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
     const DevScene *scDev = nullptr;         // DevScene in HBM: k_shade_vol's out-of-line routines take it by pointer
@@ -1435,9 +1449,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
     // row f4: Integrator "volpath" and materials with a BSSRDF are shaded by k_shade_vol (pt_volpath.h)
     c->volKernel = d->integrator_type == MI_INTEGRATOR_VOLPATH || d->material_bssrdf != nullptr;
+    c->volWave = false;
     if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
-    if (c->volKernel && d->n_instances > 0)   // loud, not approximate: the per-lane tracer of k_shade_vol walks single-level trees only
-        return fail("mi_scene_upload: \"volpath\" / subsurface scenes with two-level instancing are not implemented on the device; load the scene with PBRT_AMD_INSTANCING=0 (instances flattened)");
     if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
     if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
     // ray binning before traversal: measured -63 % HBM traffic and -48 % L2 misses in the closest-hit kernel at UNCHANGED kernel time
@@ -2005,6 +2018,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
         v.camera_medium = v.handle_media ? d->camera_medium : -1;
+        c->volWave = v.handle_media && !d->material_bssrdf && !c->hasNullMat && !c->hasAlpha;
+        for (uint32_t i = 0; i < d->n_media && c->volWave; ++i) c->volWave = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
+        { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') c->volWave = false; }   // A/B and parity tests of the general form
         v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
         if (v.handle_media && d->n_media) {
             std::vector<mi_medium> med(d->media, d->media + d->n_media);
@@ -2230,7 +2246,13 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
             if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
-                hipLaunchKernelGGL(k_shade_vol, grid, block, 0, st, c->scDev, ps, c->vol, qout);
+                if (c->volWave) {
+                    if (c->hasInst) hipLaunchKernelGGL((k_shade_vol<true, true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                    else hipLaunchKernelGGL((k_shade_vol<true, false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                } else {
+                    if (c->hasInst) hipLaunchKernelGGL((k_shade_vol<false, true>), grid, block, 0, st, c->scDev, ps, c->vol, qout);
+                    else hipLaunchKernelGGL((k_shade_vol<false, false>), grid, block, 0, st, c->scDev, ps, c->vol, qout);
+                }
             } else if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
                 if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
@@ -2246,14 +2268,19 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             }
         }
         toc(c);
-        if (!c->volKernel) {   // (k_shade_vol queues no shadow / MIS rays)
+        if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
         LAUNCH_TRACE(2);
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_MIS_CLOSEST);
-        LAUNCH_TRACE(1);
+        {
+            PathState psRun = ps;
+            psRun.vol_tr = c->volWave ? 1u : 0u;
+            PathState &ps = psRun;
+            LAUNCH_TRACE(1);
+        }
         toc(c);
         }
         qin = qout;

@@ -232,8 +232,15 @@ PT_DEV void TrowbridgeReitzSample11(Float cosTheta, Float U1, Float U2, Float *s
     if ((double)cosTheta > .9999) {
         Float r = (Float)sqrt((double)(U1 / (1 - U1)));
         Float phi = (Float)(6.28318530718 * (double)U2);
+#if defined(PT_OCML_TRIG) || defined(PT_F32_TRIG)
         *slope_x = (Float)((double)r * cos((double)phi));
         *slope_y = (Float)((double)r * sin((double)phi));
+#else
+        double sd, cd;
+        SinCosD((double)phi, &sd, &cd);   // phi in [0, 2 pi]
+        *slope_x = (Float)((double)r * cd);
+        *slope_y = (Float)((double)r * sd);
+#endif
         return;
     }
     Float sinTheta = sqrtf_(mx((Float)0, (Float)1 - cosTheta * cosTheta));
@@ -797,8 +804,9 @@ PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 ref
             if (mapPdf == 0) { ls->pdf = 0; ls->Li = RGB(0.f); return lsv; }
         }
         Float theta = uv1 * PT_PI, phi = uv0 * 2 * PT_PI;
-        Float cosTheta = cosf_(theta), sinTheta = sinf_(theta);
-        Float sinPhi = sinf_(phi), cosPhi = cosf_(phi);
+        Float cosTheta, sinTheta, sinPhi, cosPhi;
+        sincosf_(theta, &sinTheta, &cosTheta);
+        sincosf_(phi, &sinPhi, &cosPhi);
         V3 wl(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
         ls->wi = hasMap ? Mul3(v3(dl->l2w0), v3(dl->l2w1), v3(dl->l2w2), wl) : wl;
         ls->pdf = mapPdf / (2 * PT_PI * PT_PI * sinTheta);

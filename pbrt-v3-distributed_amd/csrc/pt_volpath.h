@@ -17,23 +17,28 @@ struct LaneTracer {
     StackEntry *spill;
     uint32_t nClosest, nAny, guardTrips;
 };
-// one ray, traced by this lane alone: closest hit (BVHAccel::Intersect) or any hit (IntersectP); returns (prim, tHit bits)
-template <bool ANY>
-__device__ __noinline__ uint2 TraceLane(LaneTracer *lt, const V3 o, const V3 d, Float tMax) {
+// one ray, traced by this lane alone: closest hit (BVHAccel::Intersect) or any hit (IntersectP).  INST: two-level scenes (TransformedPrimitive
+// leaves, see TravStateI); `inst` = the instance the hit primitive was reached through (TRAV_NO_INSTANCE: a top-level primitive)
+struct LaneHit { uint32_t prim; Float t; uint32_t inst; };
+template <bool ANY, bool INST>
+__device__ __noinline__ LaneHit TraceLane(LaneTracer *lt, const V3 o, const V3 d, Float tMax) {
     const DevScene &sc = *lt->scp;
     TravStack st;
     st.lds = lt->lds; st.spill = lt->spill;
-    TravState ts;
+    typename std::conditional<INST, TravStateI, TravState>::type ts;
     ts.init(sc, o, d, tMax, st);
     TraceCounters tc = {0, 0};
     uint32_t steps = 0;
     while (!ts.done()) {
         if (++steps > (1u << 22)) { ++lt->guardTrips; ts.prim = TRAV_MISS; break; }   // non-termination guard, reported through MI_CNT_TRACE_GUARD_TRIPS
         if (ts.atNode()) TravNodeStep<false>(sc, ts, st, &tc);
-        else TravLeafStep<ANY, false, true, true>(sc, ts, st, &tc);
+        else TravLeafStep<ANY, false, true, true, typename std::conditional<INST, TravStateI, TravState>::type, TravStack, INST>(sc, ts, st, &tc);
     }
     if (ANY) ++lt->nAny; else ++lt->nClosest;
-    return make_uint2(ts.prim, __float_as_uint(ts.tHit));
+    LaneHit h;
+    h.prim = ts.prim; h.t = ts.tHit; h.inst = TRAV_NO_INSTANCE;
+    if constexpr (INST) h.inst = ts.hitInst;
+    return h;
 }
 
 // SurfaceInteraction of a hit + the medium interface GeometricPrimitive::Intersect leaves on it (core/primitive.cpp:122-126)
@@ -43,8 +48,16 @@ struct VHit {
     uint4 tinfo;
     int mIn, mOut;
 };
-__device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, uint32_t prim, const V3 o, const V3 d, int rayMedium, bool wantTex, VHit *out) {
+// inst: the instance the primitive was reached through (two-level scenes; TRAV_NO_INSTANCE otherwise): the interaction is built in the
+// object's space from the transformed ray and carried back to world space (TransformedPrimitive::Intersect, core/primitive.cpp:76-111)
+__device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, uint32_t prim, V3 o, V3 d, uint32_t inst, int rayMedium, bool wantTex, VHit *out) {
     const DevScene &sc = *scp;
+    const DevInstance *hitInst = nullptr;
+    if (inst != TRAV_NO_INSTANCE) {
+        hitInst = c_instances + inst;
+        InstRay ir = InstanceRay(hitInst, o, d);
+        o = ir.o; d = ir.d;
+    }
     uint4 tinfo = sc.tri_info[prim];
     TriShadeRegs tsr = LoadTriShade(sc.tri_shade, prim);
     V3 p0, p1, p2;
@@ -58,6 +71,7 @@ __device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, 
         out->is = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), d, prim);
         if (wantTex) out->ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
     }
+    if (hitInst && !hitInst->identity) InstanceToWorld(hitInst, &out->is, &out->ix);
     out->tinfo = tinfo;
     int in = -1, outm = -1;
     if (vol->mesh_medium) { in = vol->mesh_medium[2 * tinfo.w]; outm = vol->mesh_medium[2 * tinfo.w + 1]; }
@@ -98,29 +112,44 @@ __device__ __noinline__ LightPoint LightPointOf(const DevScene *scp, const DevLi
     return lp;
 }
 
+// Wavefront form of the two direct-lighting rays (k_shade_vol<true>): scenes whose media are all homogeneous and that have neither BSDF-less
+// interfaces, alpha masks nor BSSRDF materials draw no sampler dimension inside their visibility code, and the first surface a shadow / MIS ray
+// meets ends it -- so the rays go through the shadow and MIS queues to k_trace<2> / k_trace<1> as in k_shade, with the closed-form
+// transmittance folded into the shadow term here and applied over the hit distance by k_trace<1> (PathState::vol_tr).
+struct NeeOut {
+    bool wantShadow, wantMis;
+    ShadowRay sh;
+    RGB shTerm;            // f Li Tr weight / lightPdf
+    V3 miO, miD;
+    RGB miTerm, miSigmaT;  // f weight / scatteringPdf; sigma_t of the medium the MIS ray travels in (0: vacuum)
+    int lightNum;
+    Float selPdf;
+};
 struct VolCtx {
     const DevScene *scp;
     const DevVol *vol;
     LaneTracer *lt;
     Sampler *smp;
+    NeeOut *nee;   // null: the lane traces its own rays
 };
 
 // VisibilityTester::Tr (core/light.cpp:63-82) with media, VisibilityTester::Unoccluded (:59-61) without
+template <bool INST>
 __device__ __noinline__ RGB VisibilityTrD(VolCtx cx, V3 o, V3 d, Float tMax, int medium, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0,
                                           Float u1, const V3 wi) {
     if (!cx.vol->handle_media) {
-        uint2 h = TraceLane<true>(cx.lt, o, d, tMax);
-        return h.x == TRAV_MISS ? RGB(1.f) : RGB(0.f);
+        LaneHit h = TraceLane<true, INST>(cx.lt, o, d, tMax);
+        return h.prim == TRAV_MISS ? RGB(1.f) : RGB(0.f);
     }
     RGB Tr(1.f);
     for (int guard = 0; guard < 65536; ++guard) {
-        uint2 h = TraceLane<false>(cx.lt, o, d, tMax);
-        const bool hitSurface = h.x != TRAV_MISS;
-        if (hitSurface && (int)cx.scp->tri_info[h.x].y >= 0) return RGB(0.f);
-        if (medium >= 0) Tr = Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? __uint_as_float(h.y) : tMax, cx.smp);
+        LaneHit h = TraceLane<false, INST>(cx.lt, o, d, tMax);
+        const bool hitSurface = h.prim != TRAV_MISS;
+        if (hitSurface && (int)cx.scp->tri_info[h.prim].y >= 0) return RGB(0.f);
+        if (medium >= 0) Tr = Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? h.t : tMax, cx.smp);
         if (!hitSurface) break;
         VHit vh;
-        HitToIsect(cx.scp, cx.vol, h.x, o, d, medium, false, &vh);
+        HitToIsect(cx.scp, cx.vol, h.prim, o, d, h.inst, medium, false, &vh);
         LightPoint lp = LightPointOf(cx.scp, dl, refP, refPError, refN, u0, u1, wi);
         ShadowRay sr = SpawnRayTo(vh.is, lp.p, lp.pError, lp.n);   // isect.SpawnRayTo(p1)
         o = sr.o; d = sr.d; tMax = sr.tMax;
@@ -129,30 +158,34 @@ __device__ __noinline__ RGB VisibilityTrD(VolCtx cx, V3 o, V3 d, Float tMax, int
     return Tr;
 }
 // Scene::IntersectTr (core/scene.cpp:56-70) with media, Scene::Intersect without.  *oOut: origin of the ray segment that found the hit
-__device__ __noinline__ uint32_t IntersectTrD(VolCtx cx, V3 o, const V3 d, int medium, RGB *Tr, V3 *oOut) {
+template <bool INST>
+__device__ __noinline__ LaneHit IntersectTrD(VolCtx cx, V3 o, const V3 d, int medium, RGB *Tr, V3 *oOut) {
     *Tr = RGB(1.f);
     if (!cx.vol->handle_media) {
-        uint2 h = TraceLane<false>(cx.lt, o, d, PT_INFINITY);
+        LaneHit h = TraceLane<false, INST>(cx.lt, o, d, PT_INFINITY);
         *oOut = o;
-        return h.x;
+        return h;
     }
     for (int guard = 0; guard < 65536; ++guard) {
-        uint2 h = TraceLane<false>(cx.lt, o, d, PT_INFINITY);
-        const bool hitSurface = h.x != TRAV_MISS;
-        if (medium >= 0) *Tr = *Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? __uint_as_float(h.y) : PT_INFINITY, cx.smp);
+        LaneHit h = TraceLane<false, INST>(cx.lt, o, d, PT_INFINITY);
+        const bool hitSurface = h.prim != TRAV_MISS;
+        if (medium >= 0) *Tr = *Tr * MediumTr(cx.scp, cx.vol->media + medium, o, d, hitSurface ? h.t : PT_INFINITY, cx.smp);
         *oOut = o;
-        if (!hitSurface) return TRAV_MISS;
-        if ((int)cx.scp->tri_info[h.x].y >= 0) return h.x;
+        if (!hitSurface) return h;
+        if ((int)cx.scp->tri_info[h.prim].y >= 0) return h;
         VHit vh;
-        HitToIsect(cx.scp, cx.vol, h.x, o, d, medium, false, &vh);
+        HitToIsect(cx.scp, cx.vol, h.prim, o, d, h.inst, medium, false, &vh);
         o = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, d);   // isect.SpawnRay(ray.d)
         medium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, d);
     }
-    return TRAV_MISS;
+    LaneHit miss;
+    miss.prim = TRAV_MISS; miss.t = 0; miss.inst = TRAV_NO_INSTANCE;
+    return miss;
 }
 
 typedef BSDF_T<false> LaneBSDF;
 // EstimateDirect (core/integrator.cpp:108-215); bsdf == nullptr: `it` is a MediumInteraction with phase function HenyeyGreenstein(g)
+template <bool INST>
 __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g, Float uS0, Float uS1, int lightNum, Float uL0,
                                             Float uL1) {
     const DevScene &sc = *cx.scp;
@@ -173,8 +206,20 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
             scatteringPdf = p;
         }
         if (!f.IsBlack()) {
-            RGB Li = ls.Li * VisibilityTrD(cx, ls.shadow.o, ls.shadow.d, ls.shadow.tMax, GetMediumOf(it.n, mIn, mOut, ls.shadow.d), light, it.p, it.pError, it.n, uL0, uL1, ls.wi);
-            if (!Li.IsBlack()) {
+            const int shMedium = GetMediumOf(it.n, mIn, mOut, ls.shadow.d);
+            RGB Li;
+            if (cx.nee) {   // unoccluded transmittance in closed form (HomogeneousMedium::Tr); occlusion is k_trace<2>'s answer
+                Li = ls.Li;
+                if (shMedium >= 0) Li = Li * ExpRGB(-rgb3(cx.vol->media[shMedium].sigma_t) * mn(ls.shadow.tMax * ls.shadow.d.Length(), PT_MAX_FLOAT));
+            } else
+                Li = ls.Li * VisibilityTrD<INST>(cx, ls.shadow.o, ls.shadow.d, ls.shadow.tMax, shMedium, light, it.p, it.pError, it.n, uL0, uL1, ls.wi);
+            if (cx.nee) {
+                if (!Li.IsBlack()) {
+                    cx.nee->wantShadow = true;
+                    cx.nee->sh = ls.shadow;
+                    cx.nee->shTerm = ls.delta ? f * Li / lightPdf : f * Li * PowerHeuristic(lightPdf, scatteringPdf) / lightPdf;
+                }
+            } else if (!Li.IsBlack()) {
                 if (ls.delta) Ld = Ld + f * Li / lightPdf;
                 else {
                     Float weight = PowerHeuristic(lightPdf, scatteringPdf);
@@ -205,13 +250,23 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
                 weight = PowerHeuristic(scatteringPdf, lightPdf);
             }
             V3 ro = OffsetRayOrigin(it.p, it.pError, it.n, wi), segO;   // it.SpawnRay(wi)
+            if (cx.nee) {
+                const int miMedium = GetMediumOf(it.n, mIn, mOut, wi);
+                cx.nee->wantMis = true;
+                cx.nee->miO = ro; cx.nee->miD = wi;
+                cx.nee->miTerm = f * weight / scatteringPdf;
+                cx.nee->miSigmaT = miMedium >= 0 ? rgb3(cx.vol->media[miMedium].sigma_t) : RGB(0.f);
+                cx.nee->lightNum = lightNum;
+                return Ld;
+            }
             RGB Tr(1.f);
-            uint32_t prim = IntersectTrD(cx, ro, wi, GetMediumOf(it.n, mIn, mOut, wi), &Tr, &segO);
+            const LaneHit lh = IntersectTrD<INST>(cx, ro, wi, GetMediumOf(it.n, mIn, mOut, wi), &Tr, &segO);
+            const uint32_t prim = lh.prim;
             RGB Li(0.f);
             if (prim != TRAV_MISS) {
                 if ((int)sc.tri_info[prim].z == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light
                     VHit vh;
-                    HitToIsect(cx.scp, cx.vol, prim, segO, wi, -1, false, &vh);
+                    HitToIsect(cx.scp, cx.vol, prim, segO, wi, lh.inst, -1, false, &vh);
                     Li = AreaL(*light, vh.is.n, -wi);   // lightIsect.Le(-wi)
                 }
             } else if (light->type == MI_LIGHT_INFINITE)
@@ -223,6 +278,7 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
 }
 
 // UniformSampleOneLight (core/integrator.cpp:85-106) over the light distribution looked up at it.p (path.cpp:125-127 / volpath.cpp:96,125)
+template <bool INST>
 __device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g) {
     const DevScene &sc = *cx.scp;
     if (sc.n_lights == 0) return RGB(0.f);
@@ -252,7 +308,8 @@ __device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, 
     Float uL0, uL1, uS0, uS1;
     cx.smp->Get2D(sc, &uL0, &uL1);
     cx.smp->Get2D(sc, &uS0, &uS1);
-    return EstimateDirectD(cx, itp, mIn, mOut, bsdf, g, uS0, uS1, lightNum, uL0, uL1) / selPdf;
+    if (cx.nee) cx.nee->selPdf = selPdf;
+    return EstimateDirectD<INST>(cx, itp, mIn, mOut, bsdf, g, uS0, uS1, lightNum, uL0, uL1) / selPdf;
 }
 
 // si->bssrdf of SubsurfaceMaterial / KdSubsurfaceMaterial::ComputeScatteringFunctions (materials/subsurface.cpp:95-99, kdsubsurface.cpp:87-93),
@@ -289,6 +346,7 @@ __device__ __noinline__ void ComputeBSSRDFD(const DevVol *vol, int mat, const Is
 // SeparableBSSRDF::Sample_Sp (core/bssrdf.cpp:249-326): a probe segment through the sphere of radius rMax around po; every hit on a primitive
 // of the same material object counts, one of them is chosen.  The reference collects the chain in a list; here the chain is walked twice
 // (count, then stop at the chosen one) -- the same rays, hence the same hits.
+template <bool INST>
 __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Float u1, Float u20, Float u21, VHit *pi, Float *pdf) {
     V3 vx, vy, vz;
     if (u1 < .5f) { vx = bs->ss; vy = bs->ts; vz = bs->ns; u1 *= 2; }
@@ -313,10 +371,10 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
             V3 dir = pTarget - p;
             if (dir.x == 0 && dir.y == 0 && dir.z == 0) break;
             V3 origin = OffsetRayOrigin(p, pErr, n, dir);   // Interaction::SpawnRayTo(const Point3f &) interaction.h:68-72
-            uint2 h = TraceLane<false>(cx.lt, origin, dir, 1 - PT_SHADOW_EPS);
-            if (h.x == TRAV_MISS) break;
+            LaneHit h = TraceLane<false, INST>(cx.lt, origin, dir, 1 - PT_SHADOW_EPS);
+            if (h.prim == TRAV_MISS) break;
             VHit vh;
-            HitToIsect(cx.scp, cx.vol, h.x, origin, dir, GetMediumOf(n, mIn, mOut, dir), false, &vh);
+            HitToIsect(cx.scp, cx.vol, h.prim, origin, dir, h.inst, GetMediumOf(n, mIn, mOut, dir), false, &vh);
             p = vh.is.p; pErr = vh.is.pError; n = vh.is.n; mIn = vh.mIn; mOut = vh.mOut;
             if ((int)vh.tinfo.y == bs->material) {
                 if (pass == 1 && seen == selected) { *pi = vh; break; }
@@ -341,12 +399,15 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
 #endif
 // one path vertex per lane (material-sorted queue, as k_shade): Medium::Sample on the segment, then either the medium interaction or the
 // surface interaction of VolPathIntegrator::Li's loop body; PathIntegrator::Li's body when vol.handle_media == 0 (scenes with a BSSRDF)
+// WAVE: the direct-lighting rays go through the shadow / MIS queues (see NeeOut) instead of being traced by the lane
+// INST: two-level scenes (the hit primitive may have been reached through an instance, PathRec::pad0)
+template <bool WAVE, bool INST>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
-    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    __shared__ StackEntry lds_stack[WAVE ? 1 : PT_LDS_STACK * PT_BLOCK];
     const DevScene &sc = *scp;
     LaneTracer lt;
     lt.scp = scp;
-    lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    lt.lds = (LdsStackEntry *)&lds_stack[WAVE ? 0 : threadIdx.x];
     lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     lt.nClosest = lt.nAny = lt.guardTrips = 0;
     const uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
@@ -356,6 +417,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
         const bool active = i < n;
         bool cont = false;
         uint32_t slot = 0, rayKey = 0;
+        NeeOut nee;
+        nee.wantShadow = nee.wantMis = false;
         if (active) {
             slot = ps.q_sorted[i];
             const uint2 hr = ps.rec[slot].hit;
@@ -373,12 +436,13 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             smp.dimension = (int)s4.z;
             smp.px = smp.py = 0;   // only dimensions 0 / 1 (camera sample) look at the pixel
             VolCtx cx;
-            cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = &smp;
+            cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = &smp; cx.nee = WAVE ? &nee : nullptr;
             ++nseg;
             const bool found = hr.x != MISS_PRIM;
             V3 no = ro, nd = rd;   // the next ray
             int nmedium = medium;
             bool alive = true, scattered = false, nullCrossing = false;
+            RGB betaNee(0.f);   // beta at the vertex's light sample
             // volpath.cpp:82-83: if (ray.medium) beta *= ray.medium->Sample(ray, sampler, arena, &mi)
             MediumSampleOut ms;
             ms.valid = false;
@@ -393,7 +457,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     Isect mi;   // the MediumInteraction as an Interaction: no normal, no error bounds, the same medium on both sides
                     mi.p = ms.p; mi.pError = V3(); mi.n = V3(); mi.ns = V3(); mi.dpdus = V3(); mi.wo = -rd; mi.prim = MISS_PRIM;
                     const Float g = vol.media[medium].g;
-                    L = L + beta * UniformSampleOneLightD(cx, &mi, medium, medium, nullptr, g);
+                    L = L + beta * UniformSampleOneLightD<INST>(cx, &mi, medium, medium, nullptr, g);
+                    betaNee = beta;
                     Float u0, u1;
                     smp.Get2D(sc, &u0, &u1);
                     V3 wi;
@@ -405,7 +470,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                 }
             } else if (alive) {
                 VHit vh;
-                if (found) HitToIsect(scp, &vol, hr.x, ro, rd, medium, vol.textured != 0, &vh);
+                if (found) HitToIsect(scp, &vol, hr.x, ro, rd, INST ? ps.rec[slot].pad0 : TRAV_NO_INSTANCE, medium, vol.textured != 0, &vh);
                 if (bounces == 0 || specularBounce) {   // volpath.cpp:110-116 / path.cpp:91-101
                     if (found) {
                         int li = (int)vh.tinfo.z;
@@ -437,7 +502,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                         if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf);
                         LaneBSDF bsdf(vh.is, &laneMat);
                         // volpath.cpp:125-128 samples a light unconditionally; path.cpp:122 only for surfaces with a non-specular lobe
-                        if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
+                        if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
+                        betaNee = beta;
                         V3 wo = -rd, wi;
                         Float pdf, u0, u1;
                         int flags;
@@ -462,7 +528,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                 smp.Get2D(sc, &u20, &u21);
                                 u1s = smp.Get1D(sc);
                                 VHit pi;
-                                RGB S = BssrdfSample_Sp(cx, &bssrdf, u1s, u20, u21, &pi, &spdf);
+                                RGB S = BssrdfSample_Sp<INST>(cx, &bssrdf, u1s, u20, u21, &pi, &spdf);
                                 if (S.IsBlack() || spdf == 0) alive = false;
                                 else {
                                     beta = beta * (S / spdf);
@@ -474,7 +540,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                     piMat.bxdfs[0].etaB = bssrdf.eta;
                                     pi.is.wo = pi.is.ns;
                                     LaneBSDF piBsdf(pi.is, &piMat);
-                                    L = L + beta * UniformSampleOneLightD(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
+                                    L = L + beta * UniformSampleOneLightD<INST>(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
                                     smp.Get2D(sc, &u0, &u1);
                                     f = piBsdf.Sample_f(pi.is.wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
                                     if (f.IsBlack() || pdf == 0) alive = false;
@@ -503,6 +569,21 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             } else if (alive && nullCrossing)
                 cont = true;
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
+            if (WAVE) {   // added by k_trace<2> iff unoccluded / by k_trace<1> times Le times the transmittance up to the hit
+                if (nee.wantShadow) {
+                    RGB c = betaNee * (nee.shTerm / nee.selPdf);
+                    ps.nee[slot].sh_o = make_float4(nee.sh.o.x, nee.sh.o.y, nee.sh.o.z, nee.sh.tMax);
+                    ps.nee[slot].sh_d = make_float4(nee.sh.d.x, nee.sh.d.y, nee.sh.d.z, 0);
+                    ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, 0);
+                }
+                if (nee.wantMis) {
+                    RGB c = betaNee * (nee.miTerm / nee.selPdf);
+                    ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, 0);
+                    ps.nee[slot].mi_d = make_float4(nee.miD.x, nee.miD.y, nee.miD.z, __uint_as_float((uint32_t)nee.lightNum));
+                    ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
+                    ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
+                }
+            }
             if (cont) {
                 if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
                 ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
@@ -513,8 +594,16 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             }
         }
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
-        uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
-        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (WAVE) {
+            uint32_t posE, posS, posM;
+            PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, nee.wantShadow, nee.wantMis, &posE, &posS, &posM);
+            if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+            if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
+            if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
+        } else {
+            uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
+            if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        }
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
     wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], lt.nClosest);

@@ -46,7 +46,9 @@ PT_DEV Float HGSample_p(Float g, const V3 &wo, V3 *wi, Float u0, Float u1) {
     Float phi = 2 * PT_PI * u1;
     V3 v1, v2;
     CoordinateSystem(wo, &v1, &v2);
-    *wi = sinTheta * cosf_(phi) * v1 + sinTheta * sinf_(phi) * v2 + cosTheta * (-wo);   // SphericalDirection geometry.h:1467-1472
+    Float sp, cp;
+    sincosf_(phi, &sp, &cp);
+    *wi = sinTheta * cp * v1 + sinTheta * sp * v2 + cosTheta * (-wo);   // SphericalDirection geometry.h:1467-1472
     return PhaseHG(-cosTheta, g);
 }
 

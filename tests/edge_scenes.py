@@ -81,12 +81,28 @@ def vol_scene(name):
         t = t.replace('WorldBegin\n', 'WorldBegin\nMediumInterface "" "fog"\n' + med, 1)
         return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.01 .015 .02] "rgb sigma_s" [.06 .05 .04] "float g" [.2]\n'
                                    'MediumInterface "" "fog"\nLookAt', 1)
+    if name == "vol_inst":       # two-level instancing under volpath: instanced objects (one carrying its own inside medium behind a BSDF-less boundary, one of glass)
+        # in fog, with rotations and a mirroring scale -- the per-lane transmittance / MIS rays of k_shade_vol enter and leave instances
+        obj = ('ObjectBegin "cloud"\nMediumInterface "dense" "fog"\nMaterial ""\n'
+               'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+               '  "point P" [-.4 0 -.4  .4 0 -.4  .4 0 .4  -.4 0 .4  -.4 .8 -.4  .4 .8 -.4  .4 .8 .4  -.4 .8 .4]\nObjectEnd\n'
+               'ObjectBegin "thing"\nMediumInterface "" "fog"\nMaterial "plastic" "rgb Kd" [.2 .6 .3] "rgb Ks" [.3 .3 .3] "float roughness" [.1]\n'
+               'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+               '  "point P" [-.3 0 -.3  .3 0 -.3  .3 0 .3  -.3 0 .3  -.3 .6 -.3  .3 .6 -.3  .3 .6 .3  -.3 .6 .3]\n'
+               'AttributeBegin\nTranslate 0 1 0\nMaterial "glass" "float index" [1.4]\nShape "sphere" "float radius" [.3]\nAttributeEnd\nObjectEnd\n')
+        inst = "".join('AttributeBegin\nTranslate %g %g %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "%s"\nAttributeEnd\n' % a for a in
+                       [(-1.5, .05, 1, 20, 1, 1, 1, "thing"), (1.6, .05, .5, -40, -1.1, 1.2, 1, "thing"), (.2, .06, 1.6, 30, 1, 1.2, 1, "cloud"), (-.6, .06, -.6, 10, .8, .8, 1.5, "cloud")])
+        t = volpath(_OPEN % ('MakeNamedMedium "dense" "string type" "homogeneous" "rgb sigma_a" [.3 .2 .1] "rgb sigma_s" [2.5 2.8 3] "float g" [-.3]\n'
+                             'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.02 .03 .05] "rgb sigma_s" [.12 .1 .07] "float g" [.4]\n'
+                             'MediumInterface "" "fog"\n' + lights + obj + inst))
+        return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.02 .03 .05] "rgb sigma_s" [.12 .1 .07] "float g" [.4]\n'
+                                   'MediumInterface "" "fog"\nLookAt', 1)
     if name == "vol_none":       # volpath on a scene without any medium: the integrator's own differences from "path" (unconditional light sample, Intersect-based visibility)
         return volpath(_OPEN % lights)
     raise KeyError(name)
 
 
-VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none", "vol_alpha"]
+VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none", "vol_alpha", "vol_inst"]
 
 
 # ---- subsurface scattering: the BSSRDF branch of path / volpath
@@ -108,10 +124,15 @@ def sss_scene(name):
                       'Texture "chk" "spectrum" "checkerboard" "float uscale" [3] "float vscale" [3] "rgb tex1" [.8 .3 .2] "rgb tex2" [.2 .5 .8]\n'
                       'Material "kdsubsurface" "texture Kd" "chk" "rgb mfp" [.4 .3 .2] "float eta" [1.4] "float scale" [.5]')
         return t.replace('LookAt', 'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\nMediumInterface "" "haze"\nLookAt', 1)
+    if name == "sss_inst":     # a subsurface object INSTANTIATED twice (two-level instancing): probe-ray chains through TransformedPrimitives, under "path"
+        obj = ('ObjectBegin "blob"\nMaterial "subsurface" "string name" "Ketchup" "float scale" [6] "float eta" [1.35]\n' + _bulge() + 'ObjectEnd\n')
+        inst = "".join('AttributeBegin\nTranslate %g %g %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "blob"\nAttributeEnd\n' % a for a in
+                       [(-2.2, 0, 1.2, 25, 1, 1, 1), (1.9, 0, .8, -50, .8, 1.2, -.9)])
+        return t.replace('WorldBegin\n', 'WorldBegin\n' + obj + inst, 1)
     raise KeyError(name)
 
 
-SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd"]
+SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst"]
 
 
 def scene(name):
