@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                 }
                 if (ENV && (tf & TRI_FLAG_SPHERE)) {
                     isect = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), iro, ird, hr.x);
-                    if (TEX) ix = IsectX();   // spheres carry constant materials only (mi_scene_upload refuses textured ones)
+                    if (TEX) ix = SphereIsectTex(sc.spheres + __float_as_uint(p0.x), iro, ird);
                 } else {
                     TriHit th;
                     TriangleTest(p0, p1, p2, iro, ird, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
@@ -1487,11 +1487,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
                     if (mdepth[m] > PT_MIX_MAX_DEPTH) return fail("mi_scene_upload: mix materials nested deeper than the device evaluates (PT_MIX_MAX_DEPTH)");
                 }
             }
-            for (uint32_t t = 0; t < d->n_tris; ++t)
-                if (d->tri_indices[3 * (size_t)t] == MI_PRIM_SPHERE) {
-                    int mat = d->meshes[d->tri_mesh[t]].material;
-                    if (mat >= 0 && d->material_descs[mat].textured) return fail("mi_scene_upload: textured materials on Sphere primitives are not carried by this path (triangle meshes only)");
-                }
         }
     }
     HIP_TRY(hipSetDevice(c->device));

@@ -67,6 +67,45 @@ __device__ __noinline__ IsectX BuildIsectTex(uint32_t mflags, const TriShadeRegs
     return x;
 }
 
+// The same for a Sphere hit (shapes/sphere.cpp:108-145): (u, v), dpdu / dpdv, dndu / dndv from the fundamental forms (Weingarten), carried to
+// world space as Transform::operator()(SurfaceInteraction) does (core/transform.cpp:262-297) -- read by textures and bump mapping only.
+__device__ __noinline__ IsectX SphereIsectTex(const mi_sphere *spp, const V3 ro, const V3 rd) {
+    const mi_sphere &sp = *spp;
+    IsectX x;
+    x.u = x.v = 0;
+    x.dpdx = x.dpdy = V3(0, 0, 0);
+    x.dudx = x.dvdx = x.dudy = x.dvdy = 0;
+    x.flipN = ((sp.flags & 1u) != 0) != ((sp.flags & 2u) != 0);
+    SphereHit h = SphereHitTest(sp, ro, rd, PT_INFINITY);
+    if (!h.hit) return x;   // (cannot happen: the traversal found this hit with the same code)
+    const V3 pHit = h.pHit;
+    Float phi = satan2f_(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * PT_PI;
+    const Float phiMax = sp.phi_max, dTheta = sp.theta_max - sp.theta_min;
+    Float theta = acosf_(clampf(pHit.z / sp.radius, -1, 1));
+    x.u = phi / phiMax;
+    x.v = (theta - sp.theta_min) / dTheta;
+    Float zRadius = sqrtf_(pHit.x * pHit.x + pHit.y * pHit.y);
+    Float invZRadius = 1 / zRadius;
+    Float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+    V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+    V3 dpdv = dTheta * V3(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * sinf_(theta));
+    V3 d2Pduu = -phiMax * phiMax * V3(pHit.x, pHit.y, 0);
+    V3 d2Pduv = dTheta * pHit.z * phiMax * V3(-sinPhi, cosPhi, 0.);
+    V3 d2Pdvv = -dTheta * dTheta * V3(pHit.x, pHit.y, pHit.z);
+    Float E = Dot(dpdu, dpdu), F = Dot(dpdu, dpdv), G = Dot(dpdv, dpdv);
+    V3 N = Normalize(Cross(dpdu, dpdv));
+    Float e = Dot(N, d2Pduu), f = Dot(N, d2Pduv), g = Dot(N, d2Pdvv);
+    Float invEGF2 = 1 / (E * G - F * F);
+    V3 dndu = (f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv;
+    V3 dndv = (g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv;
+    x.dpdu = SXfVector(sp.o2w, dpdu);
+    x.dpdv = x.dpdvs = SXfVector(sp.o2w, dpdv);
+    x.dndus = SXfNormal(sp.w2o, dndu);
+    x.dndvs = SXfNormal(sp.w2o, dndv);
+    return x;
+}
+
 // the offset rays of PerspectiveCamera::GenerateRayDifferential (cameras/perspective.cpp:117-139), through CameraToWorld
 // (core/transform.h:396-405) and ScaleDifferentials(1 / sqrt(spp)) (core/geometry.h:908-913, integrator.cpp:285-286).
 // (o, d) = the camera ray as raygen stored it.

@@ -64,7 +64,10 @@ __device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, 
     uint32_t tf;
     LoadTri(sc, prim, &p0, &p1, &p2, &tf);
     out->ix = IsectX();
-    if (tf & TRI_FLAG_SPHERE) out->is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim);
+    if (tf & TRI_FLAG_SPHERE) {
+        out->is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim);
+        if (wantTex) out->ix = SphereIsectTex(sc.spheres + __float_as_uint(p0.x), o, d);
+    }
     else {
         TriHit th;
         TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0, b1, b2, t
@@ -129,7 +132,7 @@ struct VolCtx {
     const DevScene *scp;
     const DevVol *vol;
     LaneTracer *lt;
-    Sampler *smp;
+    VSampler *smp;
     NeeOut *nee;   // null: the lane traces its own rays
 };
 
@@ -431,10 +434,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             bool specularBounce = (s4.w >> 16) & 1u;
             bool noDiff = (s4.w >> 17) & 1u;
             int medium = vol.handle_media ? (int)__float_as_uint(ps.rec[slot].pad2.x) : -1;
-            Sampler smp;
+            VSampler smp;
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
             smp.dimension = (int)s4.z;
             smp.px = smp.py = 0;   // only dimensions 0 / 1 (camera sample) look at the pixel
+            smp.Prefetch(sc);
             VolCtx cx;
             cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = &smp; cx.nee = WAVE ? &nee : nullptr;
             ++nseg;
@@ -495,12 +499,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                 ComputeDifferentials(vh.is.p, vh.is.n, &vh.ix, rdf);
                             }
                             ComputeScatteringFunctionsT(sc.materials, matIdx, &vh.is, &vh.ix, &laneMat);
-                        } else
-                            laneMat = sc.materials[matIdx];
+                        }
+                        const mi_material *matPtr = vol.textured ? &laneMat : sc.materials + matIdx;   // constant lobe lists are read in place
                         DevBSSRDF bssrdf;
                         bssrdf.table = nullptr;
                         if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf);
-                        LaneBSDF bsdf(vh.is, &laneMat);
+                        LaneBSDF bsdf(vh.is, matPtr);
                         // volpath.cpp:125-128 samples a light unconditionally; path.cpp:122 only for surfaces with a non-specular lobe
                         if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
                         betaNee = beta;
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                             beta = beta * (f * AbsDot(wi, vh.is.ns) / pdf);
                             specularBounce = (flags & BSDF_SPECULAR) != 0;
                             if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
-                                Float eta = laneMat.eta;
+                                Float eta = matPtr->eta;
                                 etaScale *= (Dot(wo, vh.is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
                             }
                             no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);   // isect.SpawnRay(wi)

@@ -26,6 +26,32 @@ struct DevVol {
     int32_t pad;
 };
 
+// The path's sampler with the next PT_VOL_PRE dimensions drawn ahead in ONE batch (SamplerBatch: wave-uniform matrix rows through the scalar
+// cache, as k_shade does) -- Sampler::SampleDimension fetches its 20-50 matrix words per dimension with per-lane vector loads.  Dimensions
+// past the batch (long delta / ratio tracking chains) fall back to it.
+#ifndef PT_VOL_PRE
+#define PT_VOL_PRE 12
+#endif
+struct VSampler : Sampler {
+    Float pre[PT_VOL_PRE];
+    int preBase, preN;
+    PT_DEV void Prefetch(const DevScene &sc) {
+        preBase = dimension;
+        const int limit = sc.sampler_type == MI_SAMPLER_HALTON ? 1000 : PBRT_AMD_SOBOL_NDIM;
+        preN = limit - dimension < PT_VOL_PRE ? (limit - dimension < 0 ? 0 : limit - dimension) : PT_VOL_PRE;
+        SamplerBatch<PT_VOL_PRE>(sc, index, dimension, pre);
+    }
+    PT_DEV Float Get1D(const DevScene &sc) {
+        const int k = dimension - preBase;
+        Float v;
+        if (k >= 0 && k < preN) v = pre[k];
+        else v = SampleDimension(sc, dimension);
+        ++dimension;
+        return v;
+    }
+    PT_DEV void Get2D(const DevScene &sc, Float *u0, Float *u1) { *u0 = Get1D(sc); *u1 = Get1D(sc); }
+};
+
 PT_DEV RGB ExpRGB(const RGB &s) { return RGB(expf_(s.r), expf_(s.g), expf_(s.b)); }   // Exp(Spectrum) core/spectrum.h:253-258
 PT_DEV Float logf1_(Float v) { return (Float)log((double)v); }
 
@@ -112,7 +138,7 @@ PT_DEV MRay GridRay(const mi_medium *m, const V3 &wo_, const V3 &wd_, Float wtMa
 // ------------------------------------------------------------------ Medium::Tr / Medium::Sample
 // HomogeneousMedium media/homogeneous.cpp:41-74; GridDensityMedium: ratio tracking grid.cpp:90-118, delta tracking grid.cpp:61-88.
 // `smp` advances by however many dimensions the tracking loop draws (none for homogeneous Tr).
-__device__ __noinline__ RGB MediumTr(const DevScene *scp, const mi_medium *m, const V3 ro, const V3 rd, Float tMax, Sampler *smp) {
+__device__ __noinline__ RGB MediumTr(const DevScene *scp, const mi_medium *m, const V3 ro, const V3 rd, Float tMax, VSampler *smp) {
     if (m->type == MI_MEDIUM_HOMOGENEOUS) return ExpRGB(-rgb3(m->sigma_t) * mn(tMax * rd.Length(), PT_MAX_FLOAT));
     MRay ray = GridRay(m, ro, rd, tMax);
     Float tMin, tEnd;
@@ -134,7 +160,7 @@ __device__ __noinline__ RGB MediumTr(const DevScene *scp, const mi_medium *m, co
     return RGB(Tr);
 }
 struct MediumSampleOut { RGB w; V3 p; bool valid; };
-__device__ __noinline__ MediumSampleOut MediumSample(const DevScene *scp, const mi_medium *m, const V3 ro, const V3 rd, Float tMax, Sampler *smp) {
+__device__ __noinline__ MediumSampleOut MediumSample(const DevScene *scp, const mi_medium *m, const V3 ro, const V3 rd, Float tMax, VSampler *smp) {
     MediumSampleOut out;
     out.valid = false; out.w = RGB(1.f);
     if (m->type == MI_MEDIUM_HOMOGENEOUS) {

@@ -288,6 +288,22 @@ def tex_scene(name):
               'Material "plastic" "texture Kd" "noise" "rgb Ks" [.4 .4 .4] "texture roughness" "rough"\n' + _PANEL +
               'Material "matte" "texture Kd" "hdr" "float sigma" [20]\n' + _bulge() +
               'Material "matte" "texture Kd" "pal"\n' + _WALL)
+    elif name == "tex_spheres":     # textured / bump-mapped materials ON SPHERES (uv = (phi / phiMax, (theta - thetaMin) / dTheta), dndu / dndv from the fundamental
+        # forms): a full sphere, a clipped one under a non-uniform scale + mirroring, one inside an instantiated object
+        w += ('Texture "col" "color" "imagemap" "string filename" "%s" "float uscale" [3] "float vscale" [2]\n' % T("color_23x17.png") +
+              'Texture "ch" "color" "checkerboard" "float uscale" [8] "float vscale" [6] "rgb tex1" [.8 .1 .1] "rgb tex2" [.9 .9 .8]\n'
+              'Texture "hgt" "float" "imagemap" "string filename" "%s" "float scale" [.08] "bool gamma" ["false"] "float uscale" [2]\n' % T("height_32.png") +
+              'Texture "wr" "float" "wrinkled" "integer octaves" [3]\nTexture "wrs" "float" "scale" "texture tex1" "wr" "float tex2" [.04]\n'
+              'Texture "rough" "float" "checkerboard" "string aamode" "none" "float uscale" [5] "float vscale" [5] "float tex1" [.02] "float tex2" [.3]\n'
+              'Material "matte" "rgb Kd" [.6 .6 .6]\n' + _GROUND +
+              'AttributeBegin\nTranslate -1.6 .8 .4\nRotate 30 0 1 0\nMaterial "plastic" "texture Kd" "col" "rgb Ks" [.3 .3 .3] "texture roughness" "rough" "texture bumpmap" "hgt"\n'
+              'Shape "sphere" "float radius" [.8]\nAttributeEnd\n'
+              'AttributeBegin\nTranslate .6 .7 -.3\nRotate -70 1 0 0\nScale -1 1.3 1\nMaterial "matte" "texture Kd" "ch" "texture bumpmap" "wrs"\n'
+              'Shape "sphere" "float radius" [.7] "float zmin" [-.5] "float zmax" [.6] "float phimax" [300]\nAttributeEnd\n'
+              'ObjectBegin "ball"\nMaterial "uber" "texture Kd" "ch" "rgb Ks" [.2 .2 .2] "texture roughness" "rough"\nShape "sphere" "float radius" [.45]\nObjectEnd\n'
+              'AttributeBegin\nTranslate 2.2 .5 .8\nRotate 40 0 0 1\nScale 1 .8 1.2\nObjectInstance "ball"\nAttributeEnd\n'
+              'AttributeBegin\nTranslate -.2 .45 1.9\nObjectInstance "ball"\nAttributeEnd\n' +
+              'Material "matte" "rgb Kd" [.5 .55 .6]\n' + _WALL)
     elif name == "tex_procedural":  # checkerboard 2D (closed form + none) and 3D, dots, uv, bilerp, mix and scale of textures
         w += ('Texture "ch" "color" "checkerboard" "float uscale" [6] "float vscale" [6] "rgb tex1" [.8 .1 .1] "rgb tex2" [.9 .9 .8]\n'
               'Texture "chn" "color" "checkerboard" "string aamode" "none" "float uscale" [3] "float vscale" [5] "rgb tex1" [.1 .1 .7] "rgb tex2" [.8 .8 .2]\n'
@@ -367,7 +383,7 @@ def tex_scene(name):
     return w + "WorldEnd\n"
 
 
-TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials"]
+TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials", "tex_spheres"]
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
 TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield", "infinite_xf", "nurbs"]
 INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)

@@ -361,22 +361,33 @@ class Gen:
         return s + "WorldEnd\n"
 
 
-def oracle_image_forked(sc):
-    """the oracle's render in a child process: like the reference (LOG(FATAL) in sobol.cpp:48-51 / halton.h:72-75) it aborts when a path of a
-    volumetric scene runs past the sampler's dimension tables -- such scenes are invalid input, not mismatches"""
+def _oracle_rgbw_forked(sc, raw):
     fn = tempfile.mktemp(suffix=".npy")
     pid = os.fork()
     if pid == 0:
         try:
-            np.save(fn, sc.film_image(ol.render(sc, nthreads=8)[0]))
+            if raw: os.environ["PT_ORACLE_RAW_L"] = "1"   # radiance before the guards of integrator.cpp:294-315 (read once per process)
+            np.save(fn, ol.render(sc, nthreads=8)[0])
             os._exit(0)
         except BaseException:
             os._exit(1)
     _, status = os.waitpid(pid, 0)
     if status != 0 or not os.path.exists(fn):
         return None
-    img = np.load(fn); os.remove(fn)
-    return img
+    a = np.load(fn); os.remove(fn)
+    return a
+
+
+def oracle_image_forked(sc):
+    """the oracle's render in child processes.  Returns None for scenes that are invalid INPUT rather than mismatches: like the reference
+    (LOG(FATAL) in sobol.cpp:48-51 / halton.h:72-75) the oracle aborts when a path of a volumetric scene runs past the sampler's dimension
+    tables, and a scene on which some sample comes out NaN / infinite / negative (out-of-range random texture values: the film sums with and
+    without the guards of integrator.cpp:294-315 differ) is one on which the reference's own CHECKs (path.cpp:126,140) abort."""
+    guarded = _oracle_rgbw_forked(sc, False)
+    if guarded is None: return None
+    raw = _oracle_rgbw_forked(sc, True)
+    if raw is None or not np.array_equal(raw, guarded, equal_nan=False): return None
+    return sc.film_image(guarded)
 
 
 def device_mode(a):
@@ -399,7 +410,7 @@ def device_mode(a):
             img = sc.film_image(ctx.film())
             ctx.close()
         except Exception as e:
-            if "not carried by this path" in str(e) or "not implemented on the device" in str(e) or "PT_MIX_MAX_DEPTH" in str(e):
+            if "not carried by this path" in str(e) or "not implemented on the device" in str(e) or "PT_MIX_MAX_DEPTH" in str(e) or "PT_TEX_MAX_PROG" in str(e):
                 refused += 1   # stated device limits (textured materials on Sphere primitives, volpath, BSSRDF): refused loudly, not a mismatch
                 continue
             print("seed %d: failed: %s" % (seed, str(e)[:200])); bad += 1
