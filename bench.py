@@ -425,6 +425,20 @@ def main():
                 roofline["frac_of_stream_ceiling"] = round(roofline["achieved"] / roofline["hbm_stream_read_GBps"], 4)
         except Exception as e:   # measurement aid only
             log("[bench] stream-read ceiling not measured: %s" % e)
+        # What the traversal IS bound by: the rate at which a CU serves incoherent 16-byte loads.  achieved = the kernel's own
+        # lane requests (node words + triangle vertices + the ray record, from the counting pass) / its launch time; ceiling = mi_gather_rate:
+        # chains of dependent random fetches of records of the node size from a buffer of the node array's size, same launch shape, no arithmetic.
+        try:
+            loads = max(1, min(4, tinfo["node_bytes"] // 16))
+            req_per_step = work["nodes_closest"] * (tinfo["node_bytes"] // 16) + work["tris_closest"] * 3 + ext_rays * 3
+            ceiling = ctx.gather_rate(max(1 << 20, tinfo["nodes"] * tinfo["node_bytes"]), loads)
+            ach = req_per_step / (t_closest_ms * 1e-3) * 1e-9 if t_closest_ms > 0 else 0.0
+            roofline["request_rate"] = {"achieved_Greq_per_s": round(ach, 1), "ceiling_Greq_per_s": round(ceiling, 1), "frac": round(ach / ceiling, 4) if ceiling > 0 else None,
+                                        "requests_per_ray": round(req_per_step / max(1, ext_rays), 1),
+                                        "ceiling_is": "mi_gather_rate: dependent random %d x 16 B record fetches per lane over a %d MB buffer, traversal launch shape, no arithmetic" % (
+                                            loads, (tinfo["nodes"] * tinfo["node_bytes"]) >> 20)}
+        except Exception as e:   # measurement aid only
+            log("[bench] request-rate ceiling not measured: %s" % e)
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the

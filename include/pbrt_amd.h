@@ -529,6 +529,11 @@ int mi_texture_eval(mi_ctx *ctx, int32_t node, const mi_tex_query *queries, int6
  * `bytes` (>= 1 GiB recommended, beyond the 256 MiB Infinity Cache), best of 3 timed launches -- reported beside the
  * 8 TB/s specification peak. */
 int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
+/* Measurement aid (bench.py's `request_rate` object): the rate at which this device serves chains of DEPENDENT random 64-byte record fetches
+ * (loads_per_record x 16-byte loads per record, per lane, traversal launch shape, no arithmetic) from a buffer of `bytes` bytes, in 1e9 lane
+ * requests per second -- the memory-side ceiling of a BVH interior step (the traversal kernels are bound by the request rate of incoherent
+ * 16-byte loads, not by HBM bandwidth: DESIGN.md s.5). */
+int mi_gather_rate(mi_ctx *ctx, uint64_t bytes, int loads_per_record, double *grequests_per_s);
 
 /* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
 

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -265,6 +265,14 @@ class Context:
         """achievable HBM read rate (streaming read of nbytes), GB/s"""
         v = C.c_double(0)
         self._chk(device_lib().mi_stream_read_gbps(self._ctx, C.c_uint64(nbytes), C.byref(v)), "mi_stream_read_gbps")
+        return float(v.value)
+
+    def gather_rate(self, nbytes, loads_per_record=4):
+        """rate of dependent random 64-byte record fetches (loads_per_record x 16 B per lane) over a buffer of nbytes, 1e9 lane requests / s"""
+        v = C.c_double(0)
+        L = device_lib()
+        L.mi_gather_rate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+        self._chk(L.mi_gather_rate(self._ctx, C.c_uint64(int(nbytes)), int(loads_per_record), C.byref(v)), "mi_gather_rate")
         return float(v.value)
 
     # ---- stage-level entry points

@@ -2882,6 +2882,63 @@ int mi_stream_read_gbps(mi_ctx *c, uint64_t bytes, double *gbps) {
     *gbps = best;
     return 0;
 }
+// ---- the request-rate ceiling the traversal kernels are measured against: every lane walks a chain of DEPENDENT fetches of
+// 64-byte records at random places of a buffer -- LOADS 16-byte loads per record, issued together, the next record's index taken from the data
+// just loaded -- with the traversal kernels' launch shape (256-thread blocks, PT_GRID_PER_CU blocks per CU) and no arithmetic beyond the index.
+// That is the memory-side work of one BVH4Q interior step (4 x 16 B of one node, next node from its child words) stripped of the box tests.
+}   // extern "C"
+template <int LOADS>
+__global__ void __launch_bounds__(PT_BLOCK) k_gather_probe(const uint4 *buf, uint32_t nrec, int iters, uint4 *out) {
+    uint32_t s = (blockIdx.x * PT_BLOCK + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t rec = (uint32_t)(((uint64_t)s * nrec) >> 32);
+        const uint4 *p = buf + (size_t)rec * 4;
+        uint4 a = p[0], b = LOADS > 1 ? p[1] : a, c = LOADS > 2 ? p[2] : a, d = LOADS > 3 ? p[3] : a;
+        Pin(a); if (LOADS > 1) Pin(b); if (LOADS > 2) Pin(c); if (LOADS > 3) Pin(d);
+        acc += a.y ^ b.z ^ c.w ^ d.x;
+        s = s * 1664525u + a.x;   // the next index depends on the record
+    }
+    if (acc == 0x12345678u) out[0] = make_uint4(acc, s, 0, 0);   // keeps the loads alive
+}
+extern "C" {
+int mi_gather_rate(mi_ctx *c, uint64_t bytes, int loads_per_record, double *grequests_per_s) {
+    if (!c || !grequests_per_s || bytes < (1u << 16) || loads_per_record < 1 || loads_per_record > 4) return fail("mi_gather_rate: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nrec = (uint32_t)std::min<uint64_t>(bytes / 64, 0xffffffffull);
+    DevBuf buf;
+    if (buf.alloc((size_t)nrec * 64)) return -1;
+    {   // random words (the chain must not fall into a short cycle): a host-side LCG fill
+        std::vector<uint32_t> h((size_t)nrec * 16);
+        uint32_t x = 2463534242u;
+        for (auto &w : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; w = x; }
+        HIP_TRY(hipMemcpyAsync(buf.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    const int iters = 2048;
+    const dim3 grid(c->gridBlocks), block(PT_BLOCK);
+    double best = 0;
+    for (int it = 0; it < 4; ++it) {   // first launch = warm-up
+        HIP_TRY(hipEventRecord(a, c->stream));
+        switch (loads_per_record) {
+        case 1: hipLaunchKernelGGL(k_gather_probe<1>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, buf.as<uint4>()); break;
+        case 2: hipLaunchKernelGGL(k_gather_probe<2>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, buf.as<uint4>()); break;
+        case 3: hipLaunchKernelGGL(k_gather_probe<3>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, buf.as<uint4>()); break;
+        default: hipLaunchKernelGGL(k_gather_probe<4>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, buf.as<uint4>()); break;
+        }
+        HIP_TRY(hipEventRecord(b, c->stream));
+        HIP_TRY(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        if (it > 0 && ms > 0) best = std::max(best, (double)c->gridBlocks * PT_BLOCK * iters * loads_per_record / (ms * 1e-3) * 1e-9);
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    buf.release();
+    *grequests_per_s = best;
+    return 0;
+}
 int mi_counters_reset(mi_ctx *c) {
     if (!c) return fail("mi_counters_reset: null ctx");
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream));
