@@ -431,12 +431,15 @@ def main():
         try:
             loads = max(1, min(4, tinfo["node_bytes"] // 16))
             req_per_step = work["nodes_closest"] * (tinfo["node_bytes"] // 16) + work["tris_closest"] * 3 + ext_rays * 3
-            ceiling = ctx.gather_rate(max(1 << 20, tinfo["nodes"] * tinfo["node_bytes"]), loads)
             ach = req_per_step / (t_closest_ms * 1e-3) * 1e-9 if t_closest_ms > 0 else 0.0
-            roofline["request_rate"] = {"achieved_Greq_per_s": round(ach, 1), "ceiling_Greq_per_s": round(ceiling, 1), "frac": round(ach / ceiling, 4) if ceiling > 0 else None,
-                                        "requests_per_ray": round(req_per_step / max(1, ext_rays), 1),
-                                        "ceiling_is": "mi_gather_rate: dependent random %d x 16 B record fetches per lane over a %d MB buffer, traversal launch shape, no arithmetic" % (
-                                            loads, (tinfo["nodes"] * tinfo["node_bytes"]) >> 20)}
+            node_mb = max(1, (tinfo["nodes"] * tinfo["node_bytes"]) >> 20)
+            ladder = {}   # the same chain of dependent record fetches over working sets that sit in the L1s, the L2s, the Infinity Cache, HBM
+            for name, nbytes in (("L1_32KB", 32 << 10), ("L2_2MB", 2 << 20), ("MALL_64MB", 64 << 20), ("HBM_%dMB_node_array" % node_mb, node_mb << 20)):
+                ladder[name] = round(ctx.gather_rate(nbytes, loads), 1)
+            roofline["request_rate"] = {"achieved_Greq_per_s": round(ach, 1), "requests_per_ray": round(req_per_step / max(1, ext_rays), 1),
+                                        "ceilings_Greq_per_s": ladder, "frac_of_L2_resident_ceiling": round(ach / ladder["L2_2MB"], 4) if ladder["L2_2MB"] > 0 else None,
+                                        "ceilings_are": "mi_gather_rate: chains of dependent random %d x 16 B record fetches per lane over a buffer of the stated size, "
+                                                        "traversal launch shape, no arithmetic; the traversal's own fetches are a MIX of these levels (upper tree levels are shared)" % loads}
         except Exception as e:   # measurement aid only
             log("[bench] request-rate ceiling not measured: %s" % e)
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}

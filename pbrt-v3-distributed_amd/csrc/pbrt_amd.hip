@@ -135,6 +135,41 @@ struct ChunkIter {
     PT_DEV void next() { c += bpx; }
 };
 
+// The same item range handed out DYNAMICALLY, per wave: block class x (= XCD x) owns one contiguous eighth (as ChunkIter), and a wave takes
+// PT_DYN_GRAIN items of its class's eighth at a time with one atomic on that eighth's cursor (its own 128-byte line).  No stealing across
+// classes: a class appends to ITS segment of the output queues, whose capacity is one eighth of the items (ensure_state).
+// Static partitions leave the machine part-empty while the slowest blocks finish (k_shade: 2.2 of 3 resident waves per SIMD on average, SQ counters).
+#ifndef PT_DYN_GRAIN
+#define PT_DYN_GRAIN 256u   /* measured on the C3 frame (profiles/r02_h_*): 64 / 128 / 256 / 512 / 1024 / 4096 -> shade 39.4 / 39.1 / 39.3 / 40.0 / 39.9 / 44.0 ms, static 40.7 */
+#endif
+#ifndef PT_WAVE_SIZE
+#define PT_WAVE_SIZE 64u
+#endif
+struct DynIter {
+    uint32_t segBeg, segEnd, cur, end;
+    uint32_t *cursor;
+    PT_DEV DynIter(uint32_t n, uint32_t *cursor_) {
+        const uint32_t seg = blockIdx.x & 7;
+        const uint32_t per = ((((n + PT_BLOCK - 1) / PT_BLOCK + 7) / 8) * PT_BLOCK);   // the eighth ChunkIter gives the class: <= seg_cap items
+        segBeg = seg * per;
+        segEnd = segBeg + per < n ? segBeg + per : (segBeg < n ? n : segBeg);
+        cursor = cursor_ + seg * QC_STRIDE;
+        cur = end = 0;
+    }
+    PT_DEV bool more() {
+        if (cur < end) return true;
+        uint32_t base = 0;
+        if (__lane_id() == 0) base = atomicAdd(cursor, PT_DYN_GRAIN);
+        base = __shfl(base, 0);
+        if (segBeg + base >= segEnd) return false;
+        cur = segBeg + base;
+        end = cur + PT_DYN_GRAIN < segEnd ? cur + PT_DYN_GRAIN : segEnd;
+        return true;
+    }
+    PT_DEV uint32_t item() const { return cur + __lane_id(); }
+    PT_DEV bool valid() const { return cur + __lane_id() < end; }
+    PT_DEV void next() { cur += PT_WAVE_SIZE; }
+};
 PT_DEV uint32_t lane_id() { return __lane_id(); }
 // wave-aggregated queue append: one atomic per wave (ballot + popcount), order-preserving inside the wave
 PT_DEV uint32_t wave_append(uint32_t *counter, bool active) {
@@ -700,6 +735,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
+#ifndef PT_SHADE_DYN
+#define PT_SHADE_DYN 1   /* k_shade / k_shade_vol take their items through DynIter (dynamic, per wave); 0: the static ChunkIter partition (A/B) */
+#endif
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
 #endif
@@ -725,10 +763,17 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     const float *cdf = cdfInLds ? s_cdf : sc.light_cdf;
     uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
     uint32_t nseg = 0;
+#if PT_SHADE_DYN
+    for (DynIter it(n, ps.cursor); it.more(); it.next()) {
+        uint32_t i = it.item();
+        PROBE(0)   // loop overhead / queue bookkeeping of the previous item
+        bool active = it.valid();
+#else
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
         PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = i < n;
+#endif
         bool cont = false, wantShadow = false, wantMis = false;
         uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
@@ -2237,6 +2282,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         hipLaunchKernelGGL(k_scan_keys, dim3(1), block, 0, st, ps, c->nkeys, (uint32_t)c->gridBlocks);
         hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
+#if PT_SHADE_DYN
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+#endif
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
@@ -2903,7 +2951,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_gather_probe(const uint4 *buf, uin
 }
 extern "C" {
 int mi_gather_rate(mi_ctx *c, uint64_t bytes, int loads_per_record, double *grequests_per_s) {
-    if (!c || !grequests_per_s || bytes < (1u << 16) || loads_per_record < 1 || loads_per_record > 4) return fail("mi_gather_rate: bad argument");
+    if (!c || !grequests_per_s || bytes < 4096 || loads_per_record < 1 || loads_per_record > 4) return fail("mi_gather_rate: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t nrec = (uint32_t)std::min<uint64_t>(bytes / 64, 0xffffffffull);
     DevBuf buf;

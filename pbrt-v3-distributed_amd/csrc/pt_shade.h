@@ -423,9 +423,18 @@ template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const 
     r.f = BxdfSample_f_impl<U>(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
     return r;
 }
+// PT_SAMPLE_SKIP_F in *sampledType: the caller (BSDF::Sample_f) discards the f of a non-specular lobe -- it re-evaluates f over all matching
+// lobes afterwards (reflection.cpp:747-763) -- so the lobe's own f (one more D, G and Fresnel evaluation for the microfacet lobes) is not computed
+#ifdef PT_NO_SKIP_F   /* A/B: always compute the lobe's own f */
+#define PT_SAMPLE_SKIP_F 0
+#else
+#define PT_SAMPLE_SKIP_F 0x100
+#endif
 template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
+    const bool needF = !(*sampledType & PT_SAMPLE_SKIP_F);
+    *sampledType &= ~PT_SAMPLE_SKIP_F;
     RGB f;
     if constexpr (!U) {
         if (b.type == MI_BXDF_BSSRDF_ADAPTER) {   // BxDF::Sample_f reflection.cpp:378-385
@@ -440,13 +449,13 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
         *pdf = BxdfPdf<U>(bp, wo, *wi);
-        f = BxdfF_unscaled<U>(bp, wo, *wi);
+        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     case MI_BXDF_LAMBERT_T:                            // :391-398
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
         *pdf = BxdfPdf<U>(bp, wo, *wi);
-        f = BxdfF_unscaled<U>(bp, wo, *wi);
+        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     case MI_BXDF_SPECULAR_R:                           // :136-143
         *wi = V3(-wo.x, -wo.y, wo.z);
@@ -489,7 +498,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         *wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
-        f = BxdfF_unscaled<U>(bp, wo, *wi);
+        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     case MI_BXDF_MICROFACET_T: {                       // :425-434
@@ -499,7 +508,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         Float eta = CosTheta(wo) > 0 ? (b.etaA / b.etaB) : (b.etaB / b.etaA);
         if (!Refract(wo, wh, eta, wi)) return RGB(0.f);
         *pdf = BxdfPdf<U>(bp, wo, *wi);
-        f = BxdfF_unscaled<U>(bp, wo, *wi);
+        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     case MI_BXDF_FRESNEL_BLEND: {                      // :450-468
@@ -515,7 +524,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
             if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         }
         *pdf = BxdfPdf<U>(bp, wo, *wi);
-        f = BxdfF_unscaled<U>(bp, wo, *wi);
+        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
     }
     }
@@ -581,7 +590,7 @@ template <bool U> struct BSDF_T {
         for (int i = 0; i < m->n_bxdfs; ++i)
             if (chosen == i) {
                 bt = BxdfFlags(m->bxdfs[i].type);
-                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, bt);
+                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }

@@ -415,9 +415,15 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
     lt.nClosest = lt.nAny = lt.guardTrips = 0;
     const uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
     uint32_t nseg = 0;
+#if PT_SHADE_DYN
+    for (DynIter it(n, ps.cursor); it.more(); it.next()) {
+        const uint32_t i = it.item();
+        const bool active = it.valid();
+#else
     for (ChunkIter it(n); it.more(); it.next()) {
         const uint32_t i = it.item();
         const bool active = i < n;
+#endif
         bool cont = false;
         uint32_t slot = 0, rayKey = 0;
         NeeOut nee;
