@@ -2289,13 +2289,17 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
             if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
+                const dim3 gw(c->gridShade);
+#define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
+                const bool umat = !c->vol.textured;   // constant lobe lists only: wave-uniform material access
                 if (c->volWave) {
-                    if (c->hasInst) hipLaunchKernelGGL((k_shade_vol<true, true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
-                    else hipLaunchKernelGGL((k_shade_vol<true, false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                    if (c->hasInst) { if (umat) LAUNCH_VOL(true, true, true, gw); else LAUNCH_VOL(true, true, false, gw); }
+                    else { if (umat) LAUNCH_VOL(true, false, true, gw); else LAUNCH_VOL(true, false, false, gw); }
                 } else {
-                    if (c->hasInst) hipLaunchKernelGGL((k_shade_vol<false, true>), grid, block, 0, st, c->scDev, ps, c->vol, qout);
-                    else hipLaunchKernelGGL((k_shade_vol<false, false>), grid, block, 0, st, c->scDev, ps, c->vol, qout);
+                    if (c->hasInst) { if (umat) LAUNCH_VOL(false, true, true, grid); else LAUNCH_VOL(false, true, false, grid); }
+                    else { if (umat) LAUNCH_VOL(false, false, true, grid); else LAUNCH_VOL(false, false, false, grid); }
                 }
+#undef LAUNCH_VOL
             } else if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
                 if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);

@@ -188,8 +188,8 @@ __device__ __noinline__ LaneHit IntersectTrD(VolCtx cx, V3 o, const V3 d, int me
 
 typedef BSDF_T<false> LaneBSDF;
 // EstimateDirect (core/integrator.cpp:108-215); bsdf == nullptr: `it` is a MediumInteraction with phase function HenyeyGreenstein(g)
-template <bool INST>
-__device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g, Float uS0, Float uS1, int lightNum, Float uL0,
+template <bool INST, class BS>
+__device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn, int mOut, const BS *bsdf, Float g, Float uS0, Float uS1, int lightNum, Float uL0,
                                             Float uL1) {
     const DevScene &sc = *cx.scp;
     const Isect &it = *itp;
@@ -281,8 +281,8 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
 }
 
 // UniformSampleOneLight (core/integrator.cpp:85-106) over the light distribution looked up at it.p (path.cpp:125-127 / volpath.cpp:96,125)
-template <bool INST>
-__device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, int mIn, int mOut, const LaneBSDF *bsdf, Float g) {
+template <bool INST, class BS>
+__device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, int mIn, int mOut, const BS *bsdf, Float g) {
     const DevScene &sc = *cx.scp;
     if (sc.n_lights == 0) return RGB(0.f);
     const float *vcdf = sc.light_cdf, *vfunc = sc.light_func;
@@ -312,7 +312,7 @@ __device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, 
     cx.smp->Get2D(sc, &uL0, &uL1);
     cx.smp->Get2D(sc, &uS0, &uS1);
     if (cx.nee) cx.nee->selPdf = selPdf;
-    return EstimateDirectD<INST>(cx, itp, mIn, mOut, bsdf, g, uS0, uS1, lightNum, uL0, uL1) / selPdf;
+    return EstimateDirectD<INST, BS>(cx, itp, mIn, mOut, bsdf, g, uS0, uS1, lightNum, uL0, uL1) / selPdf;
 }
 
 // si->bssrdf of SubsurfaceMaterial / KdSubsurfaceMaterial::ComputeScatteringFunctions (materials/subsurface.cpp:95-99, kdsubsurface.cpp:87-93),
@@ -404,7 +404,9 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
 // surface interaction of VolPathIntegrator::Li's loop body; PathIntegrator::Li's body when vol.handle_media == 0 (scenes with a BSSRDF)
 // WAVE: the direct-lighting rays go through the shadow / MIS queues (see NeeOut) instead of being traced by the lane
 // INST: two-level scenes (the hit primitive may have been reached through an instance, PathRec::pad0)
-template <bool WAVE, bool INST>
+// UMAT: no material of the scene is textured -- lanes of a wave share a material almost always (sorted queue), and the surface branch runs once per
+// distinct material of the wave with a WAVE-UNIFORM material pointer (lobe lists through scalar loads, lobe switches as scalar branches), as in k_shade
+template <bool WAVE, bool INST, bool UMAT>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
     __shared__ StackEntry lds_stack[WAVE ? 1 : PT_LDS_STACK * PT_BLOCK];
     const DevScene &sc = *scp;
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     Isect mi;   // the MediumInteraction as an Interaction: no normal, no error bounds, the same medium on both sides
                     mi.p = ms.p; mi.pError = V3(); mi.n = V3(); mi.ns = V3(); mi.dpdus = V3(); mi.wo = -rd; mi.prim = MISS_PRIM;
                     const Float g = vol.media[medium].g;
-                    L = L + beta * UniformSampleOneLightD<INST>(cx, &mi, medium, medium, nullptr, g);
+                    L = L + beta * UniformSampleOneLightD<INST, LaneBSDF>(cx, &mi, medium, medium, nullptr, g);
                     betaNee = beta;
                     Float u0, u1;
                     smp.Get2D(sc, &u0, &u1);
@@ -497,22 +499,28 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                         nullCrossing = true;
                         noDiff = true;
                     } else {
+                        typedef typename std::conditional<UMAT, BSDF_T<true>, LaneBSDF>::type SurfBSDF;
+                        bool matTodo = true;
+                        while (matTodo) {   // material waterfall (one trip for per-lane lobe lists)
+                        const int matU = UMAT ? UniformInt(matIdx) : matIdx;
+                        if (UMAT ? SameAs(matIdx, matU) : true) {
+                        matTodo = false;
                         mi_material laneMat;
-                        if (vol.textured) {   // isect.ComputeScatteringFunctions(ray, arena, true): differentials of camera rays, then the material
+                        if (!UMAT && vol.textured) {   // isect.ComputeScatteringFunctions(ray, arena, true): differentials of camera rays, then the material
                             if (bounces == 0 && !noDiff) {
                                 float2 pf = ps.rec[slot].pfilm, ln = ps.rec[slot].lens;
                                 RayDiffT rdf = CameraDifferentials(&c_tex.camera, pf.x, pf.y, ln.x, ln.y, c_tex.spp, ro, rd);
                                 ComputeDifferentials(vh.is.p, vh.is.n, &vh.ix, rdf);
                             }
-                            ComputeScatteringFunctionsT(sc.materials, matIdx, &vh.is, &vh.ix, &laneMat);
+                            if constexpr (!UMAT) ComputeScatteringFunctionsT(sc.materials, matIdx, &vh.is, &vh.ix, &laneMat);
                         }
-                        const mi_material *matPtr = vol.textured ? &laneMat : sc.materials + matIdx;   // constant lobe lists are read in place
+                        const mi_material *matPtr = (!UMAT && vol.textured) ? &laneMat : sc.materials + matU;   // constant lobe lists are read in place
                         DevBSSRDF bssrdf;
                         bssrdf.table = nullptr;
-                        if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf);
-                        LaneBSDF bsdf(vh.is, matPtr);
+                        if constexpr (!UMAT) { if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf); }
+                        SurfBSDF bsdf(vh.is, matPtr);
                         // volpath.cpp:125-128 samples a light unconditionally; path.cpp:122 only for surfaces with a non-specular lobe
-                        if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
+                        if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST, SurfBSDF>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
                         betaNee = beta;
                         V3 wo = -rd, wi;
                         Float pdf, u0, u1;
@@ -524,14 +532,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                             beta = beta * (f * AbsDot(wi, vh.is.ns) / pdf);
                             specularBounce = (flags & BSDF_SPECULAR) != 0;
                             if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
-                                Float eta = matPtr->eta;
+                                Float eta = bsdf.m->eta;
                                 etaScale *= (Dot(wo, vh.is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
                             }
                             no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);   // isect.SpawnRay(wi)
                             nd = wi;
                             nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi);
                             scattered = true;
-                            if (bssrdf.table && (flags & BSDF_TRANSMISSION)) {   // path.cpp:153-174 / volpath.cpp:153-180
+                            if (!UMAT && bssrdf.table && (flags & BSDF_TRANSMISSION)) {   // path.cpp:153-174 / volpath.cpp:153-180
                                 // S = bssrdf->Sample_S(scene, sampler.Get1D(), sampler.Get2D(), ...): the two calls are function ARGUMENTS and
                                 // g++ evaluates them right to left -- the 2-D sample takes the earlier dimensions (pinned by the oracle's fixtures)
                                 Float u20, u21, u1s, spdf = 0;
@@ -550,7 +558,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                     piMat.bxdfs[0].etaB = bssrdf.eta;
                                     pi.is.wo = pi.is.ns;
                                     LaneBSDF piBsdf(pi.is, &piMat);
-                                    L = L + beta * UniformSampleOneLightD<INST>(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
+                                    L = L + beta * UniformSampleOneLightD<INST, LaneBSDF>(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
                                     smp.Get2D(sc, &u0, &u1);
                                     f = piBsdf.Sample_f(pi.is.wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
                                     if (f.IsBlack() || pdf == 0) alive = false;
@@ -564,6 +572,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                 }
                             }
                         }
+                        }   // matIdx == matU
+                        }   // material waterfall
                     }
                 }
             }
