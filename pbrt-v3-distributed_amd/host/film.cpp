@@ -185,6 +185,7 @@ bool ReadImagePFM(const std::string &fn, std::vector<Float> *rgb, int *w, int *h
     float sc;
     if (std::fscanf(fp, "%7s %d %d %f", tag, w, h, &sc) != 4 || (std::string(tag) != "PF" && std::string(tag) != "Pf")) { std::fclose(fp); return false; }
     std::fgetc(fp);
+    if (*w <= 0 || *h <= 0 || (int64_t)*w * *h > (int64_t)1 << 28) { std::fclose(fp); return false; }   // header values come from the file
     int nc = std::string(tag) == "PF" ? 3 : 1;
     std::vector<float> data((size_t)*w * *h * nc);
     for (int y = *h - 1; y >= 0; --y)   // flip in Y: P*M has the origin at the lower left

@@ -115,13 +115,16 @@ bool DecodeTGA(const std::string &name, std::vector<Float> *out, int *w, int *h)
     bool rle = type >= 9;
     int base = rle ? type - 8 : type;
     if ((base != 1 && base != 2 && base != 3) || width <= 0 || height <= 0 || (bits != 8 && bits != 24 && bits != 32) ||
-        (base == 1 && (cmapType != 1 || (cmapBits != 24 && cmapBits != 32)))) {
+        (base == 1 && (cmapType != 1 || (cmapBits != 24 && cmapBits != 32) || bits != 8)) ||   // colour-mapped: 8-bit indices
+        (base == 2 && bits != 24 && bits != 32) ||                                             // true colour: 3 or 4 bytes per pixel
+        (base == 3 && bits != 8)) {                                                            // mono: one byte
         Error("Unable to read from TGA file \"%s\" (unsupported image type %d / %d bpp)", name.c_str(), type, bits);
         return false;
     }
     size_t pos = 18 + idLen;
     const uint8_t *cmap = &f[std::min(pos, f.size())];
     int cmapBytes = cmapType ? (cmapBits + 7) / 8 : 0;
+    if (pos + (size_t)cmapLen * cmapBytes > f.size()) { Error("Unable to read from TGA file \"%s\" (truncated colour map)", name.c_str()); return false; }
     pos += (size_t)cmapLen * cmapBytes;
     int pb = bits / 8;
     std::vector<uint8_t> px((size_t)width * height * pb);
@@ -198,30 +201,37 @@ bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h)
     int compression = -1, lineOrder = 0;
     int32_t dw[4] = {0, 0, -1, -1};
     size_t p = 8;
+    // every string of the header must end inside the file: strnlen over what is left
+    auto cstr = [&](size_t at, std::string *s) { size_t n = at < f.size() ? strnlen((const char *)&f[at], f.size() - at) : 0; if (at + n >= f.size()) return false; s->assign((const char *)&f[at], n); return true; };
     while (p < f.size() && f[p] != 0) {   // attributes: name\0 type\0 size data
-        std::string an((const char *)&f[p]); p += an.size() + 1;
-        std::string at((const char *)&f[p]); p += at.size() + 1;
+        std::string an, at;
+        if (!cstr(p, &an)) { Error("EXR file \"%s\": truncated header", name.c_str()); return false; }
+        p += an.size() + 1;
+        if (!cstr(p, &at)) { Error("EXR file \"%s\": truncated header", name.c_str()); return false; }
+        p += at.size() + 1;
+        if (p + 4 > f.size()) { Error("EXR file \"%s\": truncated header", name.c_str()); return false; }
         uint32_t sz = rd32(p); p += 4;
         if (p + sz > f.size()) { Error("EXR file \"%s\": truncated header", name.c_str()); return false; }
         if (an == "channels") {
             size_t q = p;
             while (q < p + sz && f[q] != 0) {
                 Chan c;
-                c.name = (const char *)&f[q]; q += c.name.size() + 1;
+                if (!cstr(q, &c.name) || q + c.name.size() + 1 + 16 > p + sz) { Error("EXR file \"%s\": truncated channel list", name.c_str()); return false; }
+                q += c.name.size() + 1;
                 c.type = (int)rd32(q);
                 uint32_t xs = rd32(q + 8), ys = rd32(q + 12);
                 q += 16;
                 if (xs != 1 || ys != 1) { Error("EXR file \"%s\": subsampled channels are not supported", name.c_str()); return false; }
                 chans.push_back(c);
             }
-        } else if (an == "compression") compression = f[p];
-        else if (an == "dataWindow") std::memcpy(dw, &f[p], 16);
-        else if (an == "lineOrder") lineOrder = f[p];
+        } else if (an == "compression" && sz >= 1) compression = f[p];
+        else if (an == "dataWindow" && sz >= 16) std::memcpy(dw, &f[p], 16);
+        else if (an == "lineOrder" && sz >= 1) lineOrder = f[p];
         p += sz;
     }
     ++p;   // end of header
     int width = dw[2] - dw[0] + 1, height = dw[3] - dw[1] + 1;
-    if (width <= 0 || height <= 0 || chans.empty()) { Error("EXR file \"%s\": bad header", name.c_str()); return false; }
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 28 || chans.empty()) { Error("EXR file \"%s\": bad header", name.c_str()); return false; }
     if (compression < 0 || compression > 3) { Error("EXR file \"%s\": compression method %d is not supported (NONE, RLE, ZIPS, ZIP are)", name.c_str(), compression); return false; }
     int linesPerBlock = compression == 3 ? 16 : 1;
     int nBlocks = (height + linesPerBlock - 1) / linesPerBlock;
