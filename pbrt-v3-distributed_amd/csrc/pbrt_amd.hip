@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 // TEX: some material has image / procedural textures or a bump map -- every material's lobe list is then a per-lane record
 // (built per hit by pt_material.h for the textured ones, copied for the constant ones) and the BSDF code reads it per lane
 #ifndef PT_TEX_SHADE_WAVES
-#define PT_TEX_SHADE_WAVES PT_SHADE_WAVES   /* the textured instance: same register budget (168 VGPRs, 3 waves per SIMD) */
+#define PT_TEX_SHADE_WAVES 2   /* the textured / volumetric instances: 242-256 VGPRs, 2 waves per SIMD -- measured against 3 (168 VGPRs, more scratch): textured C3 141.8 -> 145.2, volpath C3 144.2 -> 149.9 Msamples/s (profiles/r02_j_*); the plain instances keep 168 */
 #endif
 // INST: experimental two-level scenes -- the hit primitive may have been reached through an instance (PathRec::pad0): the interaction is
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)

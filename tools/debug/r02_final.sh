@@ -10,8 +10,8 @@ find gpurun_out/r02f_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {}
 rm -rf gpurun_out/r02f_prof
 timeout 400 python bench.py --volpath --cpu-seconds 12 --cpu-port-seconds 0 --traffic none > gpurun_out/r02f_bench_volpath.json 2> gpurun_out/r02f_bench_volpath.err; python -c "
 import json; d=json.load(open('gpurun_out/r02f_bench_volpath.json')); print('volpath 64spp', d['value'], d['kernel_ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['parity_crop'])"
-timeout 400 python bench.py --textured --spp 16 --steps 2 --cpu-seconds 0 --cpu-port-seconds 0 --traffic none > gpurun_out/r02f_bench_textured16.json 2> gpurun_out/r02f_bench_textured16.err; python -c "
-import json; d=json.load(open('gpurun_out/r02f_bench_textured16.json')); print('textured 16spp', d['value'], d['kernel_ms_per_step'])"
+timeout 500 python bench.py --textured --steps 2 --cpu-seconds 10 --cpu-port-seconds 0 --traffic none > gpurun_out/r02f_bench_textured.json 2> gpurun_out/r02f_bench_textured.err; python -c "
+import json; d=json.load(open('gpurun_out/r02f_bench_textured.json')); print('textured 64spp', d['value'], d['kernel_ms_per_step'])"
 timeout 400 python bench.py --config c2 --cpu-seconds 8 --cpu-port-seconds 0 --traffic none > gpurun_out/r02f_bench_c2.json 2> gpurun_out/r02f_bench_c2.err; python -c "
 import json; d=json.load(open('gpurun_out/r02f_bench_c2.json')); print('c2', d['value'], d['kernel_ms_per_step'], d['cpu_baseline']['value'])"
 timeout 500 python bench.py --config c4 --steps 2 --cpu-seconds 8 --cpu-port-seconds 0 --traffic none > gpurun_out/r02f_bench_c4.json 2> gpurun_out/r02f_bench_c4.err; python -c "
