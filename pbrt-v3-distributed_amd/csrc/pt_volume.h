@@ -39,7 +39,7 @@ struct VSampler : Sampler {
         preBase = dimension;
         const int limit = sc.sampler_type == MI_SAMPLER_HALTON ? 1000 : PBRT_AMD_SOBOL_NDIM;
         preN = limit - dimension < PT_VOL_PRE ? (limit - dimension < 0 ? 0 : limit - dimension) : PT_VOL_PRE;
-        SamplerBatch<PT_VOL_PRE>(sc, index, dimension, pre);
+        if (preN > 0) SamplerBatch<PT_VOL_PRE>(sc, index, dimension, pre);   // (past the tables -- long tracking chains -- nothing is drawn ahead: SampleDimension clamps)
     }
     PT_DEV Float Get1D(const DevScene &sc) {
         const int k = dimension - preBase;
