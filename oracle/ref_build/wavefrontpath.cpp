@@ -35,6 +35,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <tuple>
 #include <vector>
 
 #define private public
@@ -54,6 +55,8 @@
 #include "lights/infinite.h"
 #include "lights/point.h"
 #include "lights/spot.h"
+#include "mipmap.h"
+#include "sampling.h"
 #include "material.h"
 #include "memory.h"
 #include "microfacet.h"
@@ -67,6 +70,10 @@
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
 #include "integrators/path.h"
+#include "integrators/volpath.h"
+#include "medium.h"
+#include "media/homogeneous.h"
+#include "media/grid.h"
 #undef private
 #undef protected
 
@@ -88,6 +95,14 @@ struct Flat {
     std::vector<mi_light> lights;
     std::vector<mi_sphere> spheres;
     std::vector<float> lightFunc, lightCdf;
+    std::vector<mi_instance> instances;     // two-level instancing: TransformedPrimitives of the top-level BVH, the objects' own BVHAccels behind it
+    std::vector<mi_object> objects;
+    std::vector<mi_bvh2_node> nodes;        // top-level LinearBVHNodes followed by the objects' (only built when the scene has instances)
+    std::vector<mi_envmap> envmaps;         // InfiniteAreaLight: level-0 texels of Lmap + its Distribution2D, as the reference built them
+    std::vector<std::vector<float>> envKeep;
+    std::vector<mi_medium> media;           // row f4: the Medium objects reachable from the primitives' MediumInterfaces and the camera
+    std::vector<int32_t> meshMedium;        // 2 per mi_mesh entry: inside, outside (-1: none)
+    bool anyInterface = false;
     std::string error;
 };
 
@@ -173,11 +188,39 @@ uint32_t countNodes(const mi_bvh2_node *n) {   // the flattened array's length i
 }
 
 std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sampler &sampler, int maxDepth, Float rrThreshold, const Bounds2i &pixelBounds,
-                                   const std::string &lightStrategy) {
+                                   const std::string &lightStrategy, bool volpath) {
     std::unique_ptr<Flat> fs(new Flat);
     auto fail = [&](const std::string &m) { fs->error = m; return std::move(fs); };
     const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene.aggregate.get());
     if (!bvh) return fail("the aggregate is not a BVHAccel");
+    // --- media (row f4): Medium* -> index into mi_scene_desc::media.  HomogeneousMedium (media/homogeneous.h:49-58) and GridDensityMedium
+    // (media/grid.h:55-78) hand over their constructor results; the density grid stays where the reference keeps it (host pointer).
+    std::map<const Medium *, int32_t> mediumIndex;
+    std::string mediumError;
+    auto mediumOf = [&](const Medium *m) -> int32_t {
+        if (!m) return -1;
+        auto it = mediumIndex.find(m);
+        if (it != mediumIndex.end()) return it->second;
+        mi_medium mm;
+        std::memset(&mm, 0, sizeof(mm));
+        if (auto h = dynamic_cast<const HomogeneousMedium *>(m)) {
+            mm.type = MI_MEDIUM_HOMOGENEOUS;
+            rgb3(mm.sigma_a, h->sigma_a); rgb3(mm.sigma_s, h->sigma_s); rgb3(mm.sigma_t, h->sigma_t);
+            mm.g = h->g;
+        } else if (auto gm = dynamic_cast<const GridDensityMedium *>(m)) {
+            mm.type = MI_MEDIUM_GRID;
+            rgb3(mm.sigma_a, gm->sigma_a); rgb3(mm.sigma_s, gm->sigma_s);
+            mm.sigma_t[0] = mm.sigma_t[1] = mm.sigma_t[2] = gm->sigma_t;
+            mm.g = gm->g; mm.nx = gm->nx; mm.ny = gm->ny; mm.nz = gm->nz;
+            mm.inv_max_density = gm->invMaxDensity;
+            copyM(mm.world_to_medium, gm->WorldToMedium.GetMatrix());
+            mm.density = gm->density.get();
+        } else { mediumError = "a Medium that is neither homogeneous nor a density grid"; return -1; }
+        int32_t idx = (int32_t)fs->media.size();
+        fs->media.push_back(mm);
+        mediumIndex[m] = idx;
+        return idx;
+    };
     // --- primitives in BVHAccel::primitives order (bvh.cpp:205)
     std::map<const TriangleMesh *, uint32_t> meshIndex;
     std::map<const Material *, int32_t> materialIndex;
@@ -186,14 +229,68 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
         if (auto al = dynamic_cast<const AreaLight *>(scene.lights[i].get())) lightOfAreaLight[al] = (int32_t)i;
     std::vector<uint32_t> meshVertexBase;
     // Every GeometricPrimitive carries its own material pointer while vertices are per mesh: a mi_mesh entry = (TriangleMesh, material)
-    std::map<std::pair<const void *, const Material *>, uint32_t> meshEntry;
+    std::map<std::tuple<const void *, const Material *, const Medium *, const Medium *>, uint32_t> meshEntry;
     std::map<const TriangleMesh *, uint32_t> vertexBase;
-    size_t nPrims = bvh->primitives.size();
+    // Primitive order of the hand-over: the top-level BVHAccel's primitives, then -- two-level instancing, include/pbrt_amd.h mi_instance --
+    // the primitives of every instantiated object in ITS accelerator's order (pbrtObjectInstance api.cpp:1555-1591: a BVHAccel over the
+    // object's primitives, or the single primitive itself when the object has only one).
+    const size_t nTop = bvh->primitives.size();
+    std::vector<const Primitive *> order;
+    for (size_t k = 0; k < nTop; ++k) order.push_back(bvh->primitives[k].get());
+    std::map<const Primitive *, uint32_t> objectIndex;
+    std::vector<const Primitive *> objectRoots;
+    for (size_t k = 0; k < nTop; ++k)
+        if (auto tp = dynamic_cast<const TransformedPrimitive *>(order[k])) {
+            if (tp->PrimitiveToWorld.actuallyAnimated) return fail("animated instance transforms are not carried by this path");
+            const Primitive *root = tp->primitive.get();
+            if (!objectIndex.count(root)) { objectIndex[root] = (uint32_t)objectRoots.size(); objectRoots.push_back(root); }
+        }
+    if (!objectRoots.empty()) {
+        uint32_t nTopNodes = bvh->nodes ? countNodes(reinterpret_cast<const mi_bvh2_node *>(bvh->nodes)) : 0;
+        fs->nodes.assign(reinterpret_cast<const mi_bvh2_node *>(bvh->nodes), reinterpret_cast<const mi_bvh2_node *>(bvh->nodes) + nTopNodes);
+        for (const Primitive *root : objectRoots) {
+            mi_object mo;
+            mo.first_prim = (uint32_t)order.size(); mo.first_node = (uint32_t)fs->nodes.size();
+            if (auto ob = dynamic_cast<const BVHAccel *>(root)) {
+                for (const auto &pp : ob->primitives) order.push_back(pp.get());
+                mo.n_prims = (uint32_t)ob->primitives.size();
+                mo.n_nodes = ob->nodes ? countNodes(reinterpret_cast<const mi_bvh2_node *>(ob->nodes)) : 0;
+                fs->nodes.insert(fs->nodes.end(), reinterpret_cast<const mi_bvh2_node *>(ob->nodes), reinterpret_cast<const mi_bvh2_node *>(ob->nodes) + mo.n_nodes);
+            } else {   // a one-primitive object has no accelerator in the reference: one leaf node over its bound (a conservative box test, same hits)
+                order.push_back(root);
+                mo.n_prims = 1; mo.n_nodes = 1;
+                mi_bvh2_node leaf;
+                std::memset(&leaf, 0, sizeof(leaf));
+                Bounds3f b = root->WorldBound();
+                for (int a = 0; a < 3; ++a) { leaf.bmin[a] = b.pMin[a]; leaf.bmax[a] = b.pMax[a]; }
+                leaf.offset = 0; leaf.n_prims = 1;
+                fs->nodes.push_back(leaf);
+            }
+            fs->objects.push_back(mo);
+        }
+    }
+    size_t nPrims = order.size();
     fs->triIndices.resize(3 * nPrims); fs->triMesh.resize(nPrims); fs->triLight.assign(nPrims, -1);
     std::vector<int32_t> lightTri(scene.lights.size(), -1), lightSphere(scene.lights.size(), -1);
     for (size_t k = 0; k < nPrims; ++k) {
-        const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(bvh->primitives[k].get());
-        if (!gp) return fail("a primitive is not a GeometricPrimitive (instancing: flatten or refuse, INTEGRATION.md s.1)");
+        if (auto tp = dynamic_cast<const TransformedPrimitive *>(order[k])) {   // TransformedPrimitive (core/primitive.h:92-117)
+            if (k >= nTop) return fail("nested object instances");
+            mi_instance in;
+            std::memset(&in, 0, sizeof(in));
+            copyM(in.i2w, tp->PrimitiveToWorld.startTransform->GetMatrix());
+            copyM(in.w2i, tp->PrimitiveToWorld.startTransform->GetInverseMatrix());
+            in.object = objectIndex[tp->primitive.get()];
+            fs->triIndices[3 * k] = MI_PRIM_INSTANCE; fs->triIndices[3 * k + 1] = (uint32_t)fs->instances.size(); fs->triIndices[3 * k + 2] = 0;
+            fs->instances.push_back(in);
+            mi_mesh mm;
+            mm.flags = 0; mm.material = -1;
+            fs->triMesh[k] = (uint32_t)fs->meshes.size();
+            fs->meshes.push_back(mm);
+            fs->meshMedium.push_back(-1); fs->meshMedium.push_back(-1);
+            continue;
+        }
+        const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(order[k]);
+        if (!gp) return fail("a primitive that is neither a GeometricPrimitive nor a TransformedPrimitive");
         int32_t mat = -1;
         if (gp->material) {
             auto it = materialIndex.find(gp->material.get());
@@ -226,7 +323,7 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
                     else { fs->UV.push_back(0); fs->UV.push_back(0); }
                 }
             }
-            auto key = std::make_pair((const void *)mesh, (const Material *)gp->material.get());
+            auto key = std::make_tuple((const void *)mesh, (const Material *)gp->material.get(), gp->mediumInterface.inside, gp->mediumInterface.outside);
             auto me = meshEntry.find(key);
             if (me == meshEntry.end()) {
                 mi_mesh mm;
@@ -235,6 +332,8 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
                 mm.material = mat;
                 me = meshEntry.emplace(key, (uint32_t)fs->meshes.size()).first;
                 fs->meshes.push_back(mm);
+                fs->meshMedium.push_back(mediumOf(gp->mediumInterface.inside)); fs->meshMedium.push_back(mediumOf(gp->mediumInterface.outside));
+                fs->anyInterface |= gp->mediumInterface.inside != nullptr || gp->mediumInterface.outside != nullptr;
             }
             fs->triMesh[k] = me->second;
             uint32_t vb = vertexBase[mesh];
@@ -252,6 +351,8 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
             mm.material = mat;
             fs->triMesh[k] = (uint32_t)fs->meshes.size();
             fs->meshes.push_back(mm);
+            fs->meshMedium.push_back(mediumOf(gp->mediumInterface.inside)); fs->meshMedium.push_back(mediumOf(gp->mediumInterface.outside));
+            fs->anyInterface |= gp->mediumInterface.inside != nullptr || gp->mediumInterface.outside != nullptr;
             fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
             if (light >= 0) { lightTri[light] = (int32_t)k; lightSphere[light] = (int32_t)fs->spheres.size(); }
             fs->spheres.push_back(ms);
@@ -280,8 +381,44 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
             l.type = MI_LIGHT_POINT; rgb3(l.L, pl->I); l.pos[0] = pl->pLight.x; l.pos[1] = pl->pLight.y; l.pos[2] = pl->pLight.z;
         } else if (auto dd = dynamic_cast<const DistantLight *>(L)) {
             l.type = MI_LIGHT_DISTANT; rgb3(l.L, dd->L); l.pos[0] = dd->wLight.x; l.pos[1] = dd->wLight.y; l.pos[2] = dd->wLight.z;
+        } else if (auto sl = dynamic_cast<const SpotLight *>(L)) {   // lights/spot.h:48-60
+            l.type = MI_LIGHT_SPOT; rgb3(l.L, sl->I); l.pos[0] = sl->pLight.x; l.pos[1] = sl->pLight.y; l.pos[2] = sl->pLight.z;
+            const Matrix4x4 &w2l = sl->WorldToLight.GetMatrix();
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) l.frame[3 * r + c] = w2l.m[r][c];
+            l.cos_total_width = sl->cosTotalWidth; l.cos_falloff_start = sl->cosFalloffStart;
+        } else if (auto il = dynamic_cast<const InfiniteAreaLight *>(L)) {   // lights/infinite.h:51-76: always the real Lmap (1 x 1 for a constant light) + distribution
+            l.type = MI_LIGHT_INFINITE;
+            const Matrix4x4 &w2l = il->WorldToLight.GetMatrix(), &l2w = il->LightToWorld.GetMatrix();
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { l.frame[3 * r + c] = w2l.m[r][c]; l.l2w[3 * r + c] = l2w.m[r][c]; }
+            const MIPMap<RGBSpectrum> &mm = *il->Lmap;
+            const int w = mm.Width(), h = mm.Height();
+            mi_envmap me;
+            std::memset(&me, 0, sizeof(me));
+            me.width = w; me.height = h;
+            std::vector<float> rgb(3 * (size_t)w * h);
+            for (int t = 0; t < h; ++t) for (int sx = 0; sx < w; ++sx) { Float c[3]; mm.Texel(0, sx, t).ToRGB(c); for (int k = 0; k < 3; ++k) rgb[3 * ((size_t)t * w + sx) + k] = c[k]; }
+            const Distribution2D &d2 = *il->distribution;
+            const int nu = 2 * w, nv = 2 * h;
+            std::vector<float> cf((size_t)nu * nv), cc((size_t)(nu + 1) * nv), cfi(nv), mf(nv), mc(nv + 1);
+            for (int v = 0; v < nv; ++v) {
+                const Distribution1D &d1 = *d2.pConditionalV[v];
+                for (int u = 0; u < nu; ++u) cf[(size_t)v * nu + u] = d1.func[u];
+                for (int u = 0; u <= nu; ++u) cc[(size_t)v * (nu + 1) + u] = d1.cdf[u];
+                cfi[v] = d1.funcInt;
+            }
+            for (int v = 0; v < nv; ++v) mf[v] = d2.pMarginal->func[v];
+            for (int v = 0; v <= nv; ++v) mc[v] = d2.pMarginal->cdf[v];
+            me.marg_func_int = d2.pMarginal->funcInt;
+            for (auto *vec : {&rgb, &cf, &cc, &cfi, &mf, &mc}) fs->envKeep.push_back(std::move(*vec));
+            const size_t base = fs->envKeep.size() - 6;
+            me.rgb = fs->envKeep[base].data(); me.cond_func = fs->envKeep[base + 1].data(); me.cond_cdf = fs->envKeep[base + 2].data();
+            me.cond_func_int = fs->envKeep[base + 3].data(); me.marg_func = fs->envKeep[base + 4].data(); me.marg_cdf = fs->envKeep[base + 5].data();
+            fs->envmaps.push_back(me);
+            l.env_map = (int32_t)fs->envmaps.size();
+            Float c0[3]; mm.Texel(0, 0, 0).ToRGB(c0);
+            for (int k = 0; k < 3; ++k) l.L[k] = c0[k];
         } else
-            return fail("light class not handed over by this stub (spot / infinite lights: as the table of INTEGRATION.md s.1 describes)");
+            return fail("light class without a device counterpart (goniometric / projection lights)");
         power.push_back(L->Power().y());
         fs->lights.push_back(l);
     }
@@ -306,15 +443,27 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     d.n_verts = (uint32_t)(fs->P.size() / 3); d.P = fs->P.data(); d.N = fs->N.data(); d.UV = fs->UV.data();
     d.n_tris = (uint32_t)nPrims; d.tri_indices = fs->triIndices.data(); d.tri_mesh = fs->triMesh.data(); d.tri_light = fs->triLight.data();
     d.n_meshes = (uint32_t)fs->meshes.size(); d.meshes = fs->meshes.data();
-    d.bvh_nodes = reinterpret_cast<const mi_bvh2_node *>(bvh->nodes);   // BVHAccel::nodes as it is
-    d.n_bvh_nodes = bvh->nodes ? countNodes(d.bvh_nodes) : 0;
-    d.n_top_prims = d.n_tris;
+    if (fs->objects.empty()) {
+        d.bvh_nodes = reinterpret_cast<const mi_bvh2_node *>(bvh->nodes);   // BVHAccel::nodes as it is
+        d.n_bvh_nodes = bvh->nodes ? countNodes(d.bvh_nodes) : 0;
+    } else {   // top-level nodes + the objects' nodes behind them (mi_object::first_node); n_bvh_nodes = the top-level count
+        d.bvh_nodes = fs->nodes.data();
+        d.n_bvh_nodes = fs->objects[0].first_node;
+        d.n_instances = (uint32_t)fs->instances.size(); d.instances = fs->instances.data();
+        d.n_objects = (uint32_t)fs->objects.size(); d.objects = fs->objects.data();
+    }
+    d.n_top_prims = (uint32_t)nTop;
     d.n_materials = (uint32_t)fs->materials.size(); d.materials = fs->materials.data();
     d.n_lights = (uint32_t)nl; d.lights = fs->lights.data();
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
     d.n_spheres = (uint32_t)fs->spheres.size(); d.spheres = fs->spheres.empty() ? nullptr : fs->spheres.data();
-    d.camera_medium = -1;
-    d.integrator_type = MI_INTEGRATOR_PATH;
+    d.n_envmaps = (uint32_t)fs->envmaps.size(); d.envmaps = fs->envmaps.empty() ? nullptr : fs->envmaps.data();
+    // GeometricPrimitive::mediumInterface per mesh entry, Camera::medium, and which Li runs (row f4)
+    d.camera_medium = mediumOf(cam.medium);
+    if (!mediumError.empty()) return fail(mediumError);
+    d.n_media = (uint32_t)fs->media.size(); d.media = fs->media.empty() ? nullptr : fs->media.data();
+    d.mesh_medium = fs->anyInterface ? fs->meshMedium.data() : nullptr;
+    d.integrator_type = volpath ? MI_INTEGRATOR_VOLPATH : MI_INTEGRATOR_PATH;
     d.integrator.light_strategy = spatial ? MI_LIGHT_STRATEGY_SPATIAL : MI_LIGHT_STRATEGY_TABLE;
     d.integrator.spatial_max_voxels = 64;
     const PerspectiveCamera *pc = dynamic_cast<const PerspectiveCamera *>(&cam);
@@ -360,8 +509,8 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
 class WavefrontPathIntegrator : public Integrator {   // core/integrator.h:53-58
   public:
     WavefrontPathIntegrator(int maxDepth, std::shared_ptr<const Camera> camera, std::shared_ptr<Sampler> sampler, const Bounds2i &pixelBounds,
-                            Float rrThreshold, const std::string &lightStrategy)
-        : maxDepth(maxDepth), camera(camera), sampler(sampler), pixelBounds(pixelBounds), rrThreshold(rrThreshold), lightStrategy(lightStrategy) {}
+                            Float rrThreshold, const std::string &lightStrategy, bool volpath = false)
+        : maxDepth(maxDepth), camera(camera), sampler(sampler), pixelBounds(pixelBounds), rrThreshold(rrThreshold), lightStrategy(lightStrategy), volpath(volpath) {}
     void Render(const Scene &scene);   // the one call site: core/api.cpp:1623
 
   private:
@@ -371,10 +520,11 @@ class WavefrontPathIntegrator : public Integrator {   // core/integrator.h:53-58
     const Bounds2i pixelBounds;
     const Float rrThreshold;
     const std::string lightStrategy;
+    const bool volpath;   // stands in for VolPathIntegrator (media attenuate and scatter) instead of PathIntegrator
 };
 
 void WavefrontPathIntegrator::Render(const Scene &scene) {
-    std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy);
+    std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy, volpath);
     if (!flat->error.empty()) { Error("WavefrontPathIntegrator: %s", flat->error.c_str()); return; }   // pbrt convention: report and return
     Film *film = camera->film;
     Bounds2i crop = film->croppedPixelBounds;
@@ -434,6 +584,25 @@ PathIntegrator *CreatePathIntegrator(const ParamSet &params, std::shared_ptr<Sam
     std::string lightStrategy = params.FindOneString("lightsamplestrategy", "spatial");
     // api.cpp keeps the result as an Integrator* and only ever calls the virtual Render on it
     return reinterpret_cast<PathIntegrator *>(static_cast<Integrator *>(new WavefrontPathIntegrator(maxDepth, camera, sampler, pixelBounds, rrThreshold, lightStrategy)));
+}
+
+
+// Same signature as integrators/volpath.cpp:192-215: `Integrator "volpath"` resolves to the stub as well (integrators/volpath.o is not pulled from the archive)
+VolPathIntegrator *CreateVolPathIntegrator(const ParamSet &params, std::shared_ptr<Sampler> sampler, std::shared_ptr<const Camera> camera) {
+    int maxDepth = params.FindOneInt("maxdepth", 5);
+    int np;
+    const int *pb = params.FindInt("pixelbounds", &np);
+    Bounds2i pixelBounds = camera->film->GetSampleBounds();
+    if (pb) {
+        if (np != 4) Error("Expected four values for \"pixelbounds\" parameter. Got %d.", np);
+        else {
+            pixelBounds = Intersect(pixelBounds, Bounds2i{{pb[0], pb[2]}, {pb[1], pb[3]}});
+            if (pixelBounds.Area() == 0) Error("Degenerate \"pixelbounds\" specified.");
+        }
+    }
+    Float rrThreshold = params.FindOneFloat("rrthreshold", 1.);
+    std::string lightStrategy = params.FindOneString("lightsamplestrategy", "spatial");
+    return reinterpret_cast<VolPathIntegrator *>(static_cast<Integrator *>(new WavefrontPathIntegrator(maxDepth, camera, sampler, pixelBounds, rrThreshold, lightStrategy, true)));
 }
 
 }  // namespace pbrt
