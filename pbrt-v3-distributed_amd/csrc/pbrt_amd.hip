@@ -1289,6 +1289,10 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
+    // second stream for the direct-lighting traversals of bounce b, which overlap the path-extension traversal of bounce b + 1 (PBRT_AMD_OVERLAP, run_pass)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evShaded = nullptr, evNeeDone = nullptr;
+    bool overlapNee = false;
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
@@ -1323,6 +1327,7 @@ struct mi_ctx {
     std::vector<DevBuf> stateBufs;
     uint32_t cap = 0;
     uint32_t nkeys = 0;
+    uint32_t *cursor2 = nullptr, *spill2 = nullptr;   // fetch cursors / stack spill slices of the kernels on stream2
     // timing
     bool timing = false;
     struct Ev { hipEvent_t a, b; int id; };
@@ -1483,6 +1488,9 @@ void mi_ctx_destroy(mi_ctx *c) {
     for (auto &b : c->stateBufs) b.release();
     c->film.release(); c->counters.release(); c->tiles.release();
     for (auto &e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->evShaded) (void)hipEventDestroy(c->evShaded);
+    if (c->evNeeDone) (void)hipEventDestroy(c->evNeeDone);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1501,6 +1509,14 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // ray binning before traversal: measured -63 % HBM traffic and -48 % L2 misses in the closest-hit kernel at UNCHANGED kernel time
     // (profiles/r02_b_*: the traversal is not bound by HBM) plus ~3 % of the frame for the sort -> off unless PBRT_AMD_RAYBIN=1
     { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = e && e[0] == '1'; }
+    {   // PBRT_AMD_OVERLAP=1: the shadow / MIS traversals of a bounce on a second stream, overlapping the next bounce's path-extension traversal
+        const char *e = std::getenv("PBRT_AMD_OVERLAP");
+        c->overlapNee = e && e[0] == '1';
+        if (c->overlapNee && !c->stream2) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreate(&c->evShaded)); HIP_TRY(hipEventCreate(&c->evNeeDone));
+        }
+    }
     c->hasNullMat = false;
     for (uint32_t m = 0; m < d->n_meshes; ++m) c->hasNullMat |= d->meshes[m].material < 0;
     c->tilesRank = c->tilesWorld = -1;
@@ -2163,6 +2179,12 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     {   // one spill area serves whichever traversal runs (BVH4: 4-byte entries, BVH8: 8-byte entries)
         size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4), words8 = (c->useBvh8 || c->useC8) ? (size_t)c->spill8 * 2 : 0;
         ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
+        c->cursor2 = c->spill2 = nullptr;
+        if (c->overlapNee) {
+            c->cursor2 = (uint32_t *)A(sizeof(uint32_t) * QSEG * QC_STRIDE);
+            c->spill2 = (uint32_t *)A(sizeof(uint32_t) * (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
+            if (!c->cursor2 || !c->spill2) return -1;
+        }
     }
 #undef ALLOC
     ps.counters = c->counters.as<unsigned long long>();
@@ -2172,7 +2194,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
 }
 
 // ---- launch bookkeeping (per-kernel device time from HIP events on the ctx stream)
-static void tic(mi_ctx *c, int id) {
+static void tic(mi_ctx *c, int id, hipStream_t onStream = nullptr) {
     if (!c->timing) return;
     if (c->evUsed == c->evPool.size()) {
         mi_ctx::Ev e;
@@ -2180,11 +2202,11 @@ static void tic(mi_ctx *c, int id) {
         c->evPool.push_back(e);
     }
     c->evPool[c->evUsed].id = id;
-    (void)hipEventRecord(c->evPool[c->evUsed].a, c->stream);
+    (void)hipEventRecord(c->evPool[c->evUsed].a, onStream ? onStream : c->stream);
 }
-static void toc(mi_ctx *c) {
+static void toc(mi_ctx *c, hipStream_t onStream = nullptr) {
     if (!c->timing) return;
-    (void)hipEventRecord(c->evPool[c->evUsed].b, c->stream);
+    (void)hipEventRecord(c->evPool[c->evUsed].b, onStream ? onStream : c->stream);
     ++c->evUsed;
 }
 static void harvest(mi_ctx *c) {
@@ -2257,7 +2279,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     while (true) {
         uint32_t qout = qin ^ 1;
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis
+        const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave);
+        if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
         if (c->rayBin && iter > 0) {   // camera rays (iter 0) come out of k_raygen tile by tile: coherent already
@@ -2285,6 +2308,10 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
 #if PT_SHADE_DYN
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
 #endif
+        if (overlap) {   // join: the previous bounce's shadow / MIS traversals (stream2) add into PathRec::L and read the queues k_shade refills
+            if (iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));
+            HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
+        }
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
@@ -2315,7 +2342,30 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             }
         }
         toc(c);
-        if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
+        if (overlap) {
+            // The direct-lighting traversals of this bounce run on stream2 while the main stream goes on with the next bounce's path-extension
+            // traversal and material sort: they touch disjoint data (NeeRec + PathRec::L vs PathRec::hit / keys / queues), have their own fetch
+            // cursors and stack spill slices, and every persistent traversal launch ends in a tail of a few long rays that the other launch fills.
+            HIP_TRY(hipEventRecord(c->evShaded, st));
+            hipStream_t s2 = c->stream2;
+            HIP_TRY(hipStreamWaitEvent(s2, c->evShaded, 0));
+            PathState psNee = ps;
+            psNee.cursor = c->cursor2; psNee.spill = c->spill2;
+            psNee.vol_tr = c->volWave ? 1u : 0u;
+            {
+                hipStream_t st = s2;
+                PathState &ps = psNee;
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_ANYHIT, st);
+                LAUNCH_TRACE(2);
+                toc(c, st);
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_MIS_CLOSEST, st);
+                LAUNCH_TRACE(1);
+                toc(c, st);
+            }
+            HIP_TRY(hipEventRecord(c->evNeeDone, s2));
+        } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
         LAUNCH_TRACE(2);
@@ -2344,6 +2394,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             if (left == 0 || iter > sc.max_depth + 4096) break;
         }
     }
+    if (c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));   // the last bounce's direct-lighting terms
     if (toFilm) {
         tic(c, MI_K_FILM);
         hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->filmPtr);
