@@ -69,6 +69,31 @@
 #include "scene.h"
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
+#include "texture.h"
+#include "textures/bilerp.h"
+#include "textures/checkerboard.h"
+#include "textures/constant.h"
+#include "textures/dots.h"
+#include "textures/fbm.h"
+#include "textures/imagemap.h"
+#include "textures/marble.h"
+#include "textures/mix.h"
+#include "textures/scale.h"
+#include "textures/uv.h"
+#include "textures/windy.h"
+#include "textures/wrinkled.h"
+#include "materials/glass.h"
+#include "materials/kdsubsurface.h"
+#include "materials/matte.h"
+#include "materials/metal.h"
+#include "materials/mirror.h"
+#include "materials/mixmat.h"
+#include "materials/plastic.h"
+#include "materials/subsurface.h"
+#include "materials/substrate.h"
+#include "materials/translucent.h"
+#include "materials/uber.h"
+#include "bssrdf.h"
 #include "integrators/path.h"
 #include "integrators/volpath.h"
 #include "medium.h"
@@ -95,6 +120,15 @@ struct Flat {
     std::vector<mi_light> lights;
     std::vector<mi_sphere> spheres;
     std::vector<float> lightFunc, lightCdf;
+    // row f2 / f4: texture nodes, image pyramids, per-material parameter nodes, alpha masks, BSSRDF tables -- only filled when the scene needs them
+    std::vector<mi_texture> textures;
+    std::vector<mi_image> images;
+    std::vector<std::vector<float>> imageKeep;
+    std::vector<mi_material_desc> descs;
+    std::vector<int32_t> meshAlpha;
+    std::vector<mi_bssrdf_table> bssrdfTables;
+    std::vector<mi_bssrdf_desc> bssrdfDescs;
+    bool needDescs = false, anyAlpha = false, anyBssrdf = false;
     std::vector<mi_instance> instances;     // two-level instancing: TransformedPrimitives of the top-level BVH, the objects' own BVHAccels behind it
     std::vector<mi_object> objects;
     std::vector<mi_bvh2_node> nodes;        // top-level LinearBVHNodes followed by the objects' (only built when the scene has instances)
@@ -174,6 +208,192 @@ bool convertMaterial(const Material *m, mi_material *out, std::string *err) {
     for (int i = 0; i < si.bsdf->nBxDFs; ++i)
         if (!convertBxDF(si.bsdf->bxdfs[i], &out->bxdfs[i], err)) return false;
     return true;
+}
+
+// ---- Texture<Float> / Texture<Spectrum> objects -> mi_texture nodes (children before parents), MIPMaps -> mi_image pyramids
+struct TexWalker {
+    Flat *fs;
+    std::map<const void *, int> node;            // Texture object -> node index
+    std::map<const void *, int> image;           // MIPMap object -> image index
+    std::string error;
+    static mi_texture blank(int type, bool spectrum) {
+        mi_texture t;
+        std::memset(&t, 0, sizeof(t));
+        t.type = type; t.spectrum = spectrum ? 1 : 0;
+        t.tex1 = t.tex2 = t.amount = t.image = -1;
+        t.su = t.sv = 1;
+        return t;
+    }
+    static void val3(float d[3], Float v) { d[0] = d[1] = d[2] = v; }
+    static void val3(float d[3], const Spectrum &v) { rgb3(d, v); }
+    bool map2(mi_texture &t, const TextureMapping2D *m) {
+        if (auto uv = dynamic_cast<const UVMapping2D *>(m)) { t.mapping = MI_MAP_UV; t.su = uv->su; t.sv = uv->sv; t.du = uv->du; t.dv = uv->dv; }
+        else if (auto sp = dynamic_cast<const SphericalMapping2D *>(m)) { t.mapping = MI_MAP_SPHERICAL; copyM(t.w2t, sp->WorldToTexture.GetMatrix()); }
+        else if (auto cy = dynamic_cast<const CylindricalMapping2D *>(m)) { t.mapping = MI_MAP_CYLINDRICAL; copyM(t.w2t, cy->WorldToTexture.GetMatrix()); }
+        else if (auto pl = dynamic_cast<const PlanarMapping2D *>(m)) {
+            t.mapping = MI_MAP_PLANAR;
+            for (int c = 0; c < 3; ++c) { t.vs[c] = pl->vs[c]; t.vt[c] = pl->vt[c]; }
+            t.du = pl->ds; t.dv = pl->dt;
+        } else { error = "unknown TextureMapping2D"; return false; }
+        return true;
+    }
+    bool map3(mi_texture &t, const TextureMapping3D *m) {
+        auto id = dynamic_cast<const IdentityMapping3D *>(m);
+        if (!id) { error = "unknown TextureMapping3D"; return false; }
+        t.mapping = MI_MAP_IDENTITY3D; copyM(t.w2t, id->WorldToTexture.GetMatrix());
+        return true;
+    }
+    template <class TM> int mip(const MIPMap<TM> *mm, int channels) {
+        auto it = image.find(mm);
+        if (it != image.end()) return it->second;
+        mi_image im;
+        std::memset(&im, 0, sizeof(im));
+        im.width = mm->resolution[0]; im.height = mm->resolution[1]; im.levels = (int)mm->pyramid.size(); im.channels = channels;
+        im.trilinear = mm->doTrilinear ? 1 : 0; im.wrap = mm->wrapMode == ImageWrap::Repeat ? 0 : (mm->wrapMode == ImageWrap::Black ? 1 : 2);
+        im.max_aniso = mm->maxAnisotropy;
+        std::vector<float> tex;
+        for (int l = 0; l < im.levels; ++l) {
+            const auto &lv = *mm->pyramid[l];
+            for (int t = 0; t < lv.vSize(); ++t) for (int sx = 0; sx < lv.uSize(); ++sx) pushTexel(tex, lv(sx, t));
+        }
+        fs->imageKeep.push_back(std::move(tex));
+        im.texels = fs->imageKeep.back().data();
+        int idx = (int)fs->images.size();
+        fs->images.push_back(im);
+        image[mm] = idx;
+        return idx;
+    }
+    static void pushTexel(std::vector<float> &v, Float x) { v.push_back(x); }
+    static void pushTexel(std::vector<float> &v, const RGBSpectrum &x) { Float c[3]; x.ToRGB(c); v.push_back(c[0]); v.push_back(c[1]); v.push_back(c[2]); }
+    int add(const void *key, const mi_texture &t) { int i = (int)fs->textures.size(); fs->textures.push_back(t); node[key] = i; return i; }
+    template <class T> int walk(const Texture<T> *tex) {
+        if (!tex) return -1;
+        auto it = node.find(tex);
+        if (it != node.end()) return it->second;
+        const bool S = std::is_same<T, Spectrum>::value;
+        if (auto c = dynamic_cast<const ConstantTexture<T> *>(tex)) { mi_texture t = blank(MI_TEX_CONSTANT, S); val3(t.value, c->value); return add(tex, t); }
+        if (auto sc = dynamic_cast<const ScaleTexture<T, T> *>(tex)) { mi_texture t = blank(MI_TEX_SCALE, S); t.tex1 = walk(sc->tex1.get()); t.tex2 = walk(sc->tex2.get()); return add(tex, t); }
+        if (auto mx = dynamic_cast<const MixTexture<T> *>(tex)) {
+            mi_texture t = blank(MI_TEX_MIX, S);
+            t.tex1 = walk(mx->tex1.get()); t.tex2 = walk(mx->tex2.get()); t.amount = walk(mx->amount.get());
+            return add(tex, t);
+        }
+        if (auto bl = dynamic_cast<const BilerpTexture<T> *>(tex)) {
+            mi_texture t = blank(MI_TEX_BILERP, S);
+            if (!map2(t, bl->mapping.get())) return -1;
+            val3(t.v00, bl->v00); val3(t.v01, bl->v01); val3(t.v10, bl->v10); val3(t.v11, bl->v11);
+            return add(tex, t);
+        }
+        if (auto c2 = dynamic_cast<const Checkerboard2DTexture<T> *>(tex)) {
+            mi_texture t = blank(MI_TEX_CHECKERBOARD, S);
+            t.tex1 = walk(c2->tex1.get()); t.tex2 = walk(c2->tex2.get()); t.dim = 2; t.aa = c2->aaMethod == AAMethod::None ? 0 : 1;
+            if (!map2(t, c2->mapping.get())) return -1;
+            return add(tex, t);
+        }
+        if (auto c3 = dynamic_cast<const Checkerboard3DTexture<T> *>(tex)) {
+            mi_texture t = blank(MI_TEX_CHECKERBOARD, S);
+            t.tex1 = walk(c3->tex1.get()); t.tex2 = walk(c3->tex2.get()); t.dim = 3;
+            if (!map3(t, c3->mapping.get())) return -1;
+            return add(tex, t);
+        }
+        if (auto dt = dynamic_cast<const DotsTexture<T> *>(tex)) {
+            mi_texture t = blank(MI_TEX_DOTS, S);
+            if (!map2(t, dt->mapping.get())) return -1;
+            t.tex1 = walk(dt->outsideDot.get()); t.tex2 = walk(dt->insideDot.get());
+            return add(tex, t);
+        }
+        if (auto fb = dynamic_cast<const FBmTexture<T> *>(tex)) { mi_texture t = blank(MI_TEX_FBM, S); if (!map3(t, fb->mapping.get())) return -1; t.octaves = fb->octaves; t.omega = fb->omega; return add(tex, t); }
+        if (auto wr = dynamic_cast<const WrinkledTexture<T> *>(tex)) { mi_texture t = blank(MI_TEX_WRINKLED, S); if (!map3(t, wr->mapping.get())) return -1; t.octaves = wr->octaves; t.omega = wr->omega; return add(tex, t); }
+        if (auto wd = dynamic_cast<const WindyTexture<T> *>(tex)) { mi_texture t = blank(MI_TEX_WINDY, S); if (!map3(t, wd->mapping.get())) return -1; return add(tex, t); }
+        return walkTyped(tex);
+    }
+    int walkTyped(const Texture<Float> *tex) {
+        if (auto im = dynamic_cast<const ImageTexture<Float, Float> *>(tex)) {
+            mi_texture t = blank(MI_TEX_IMAGEMAP, false);
+            if (!map2(t, im->mapping.get())) return -1;
+            t.image = mip(im->mipmap, 1);
+            return add(tex, t);
+        }
+        error = "Texture<Float> class without a device counterpart";
+        return -1;
+    }
+    int walkTyped(const Texture<Spectrum> *tex) {
+        if (auto im = dynamic_cast<const ImageTexture<RGBSpectrum, Spectrum> *>(tex)) {
+            mi_texture t = blank(MI_TEX_IMAGEMAP, true);
+            if (!map2(t, im->mapping.get())) return -1;
+            t.image = mip(im->mipmap, 3);
+            return add(tex, t);
+        }
+        if (auto uv = dynamic_cast<const UVTexture *>(tex)) { mi_texture t = blank(MI_TEX_UV, true); if (!map2(t, uv->mapping.get())) return -1; return add(tex, t); }
+        if (auto mb = dynamic_cast<const MarbleTexture *>(tex)) {
+            mi_texture t = blank(MI_TEX_MARBLE, true);
+            if (!map3(t, mb->mapping.get())) return -1;
+            t.octaves = mb->octaves; t.omega = mb->omega; t.scale = mb->scale; t.variation = mb->variation;
+            return add(tex, t);
+        }
+        error = "Texture<Spectrum> class without a device counterpart";
+        return -1;
+    }
+};
+template <class T> bool isConstant(const std::shared_ptr<Texture<T>> &t) { return !t || dynamic_cast<const ConstantTexture<T> *>(t.get()) != nullptr; }
+
+// Material object -> mi_material_desc (the parameter nodes Material::ComputeScatteringFunctions evaluates per hit, materials/*.cpp).  `textured` = some
+// parameter is not a ConstantTexture or there is a bump map; a material with a BSSRDF is always built per hit.  Returns false for unknown classes.
+bool describeMaterial(const Material *m, TexWalker &tw, const std::function<int32_t(const Material *)> &slotOf, mi_material_desc *d, mi_bssrdf_desc *b, Flat *fs) {
+    std::memset(d, 0xff, sizeof(*d));
+    d->textured = 0; d->remap_roughness = 0; d->pad = 0;
+    std::memset(b, 0, sizeof(*b));
+    bool allConst = true;
+    auto S = [&](const std::shared_ptr<Texture<Spectrum>> &t) { allConst &= isConstant(t); return tw.walk(t.get()); };
+    auto F = [&](const std::shared_ptr<Texture<Float>> &t) { allConst &= isConstant(t); return tw.walk(t.get()); };
+    auto bump = [&](const std::shared_ptr<Texture<Float>> &t) { if (t) allConst = false; return tw.walk(t.get()); };
+    if (auto x = dynamic_cast<const MatteMaterial *>(m)) { d->type = MI_MAT_MATTE; d->Kd = S(x->Kd); d->sigma = F(x->sigma); d->bump = bump(x->bumpMap); }
+    else if (auto x = dynamic_cast<const PlasticMaterial *>(m)) { d->type = MI_MAT_PLASTIC; d->Kd = S(x->Kd); d->Ks = S(x->Ks); d->roughness = F(x->roughness); d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness; }
+    else if (auto x = dynamic_cast<const GlassMaterial *>(m)) {
+        d->type = MI_MAT_GLASS; d->Kr = S(x->Kr); d->Kt = S(x->Kt); d->eta_f = F(x->index); d->uroughness = F(x->uRoughness); d->vroughness = F(x->vRoughness);
+        d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness;
+    } else if (auto x = dynamic_cast<const MirrorMaterial *>(m)) { d->type = MI_MAT_MIRROR; d->Kr = S(x->Kr); d->bump = bump(x->bumpMap); }
+    else if (auto x = dynamic_cast<const MetalMaterial *>(m)) {
+        d->type = MI_MAT_METAL; d->eta_s = S(x->eta); d->k_s = S(x->k); d->roughness = F(x->roughness); d->uroughness = F(x->uRoughness); d->vroughness = F(x->vRoughness);
+        d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness;
+    } else if (auto x = dynamic_cast<const UberMaterial *>(m)) {
+        d->type = MI_MAT_UBER; d->Kd = S(x->Kd); d->Ks = S(x->Ks); d->Kr = S(x->Kr); d->Kt = S(x->Kt); d->opacity = S(x->opacity);
+        d->roughness = F(x->roughness); d->uroughness = F(x->roughnessu); d->vroughness = F(x->roughnessv); d->eta_f = F(x->eta);
+        d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness;
+    } else if (auto x = dynamic_cast<const SubstrateMaterial *>(m)) {
+        d->type = MI_MAT_SUBSTRATE; d->Kd = S(x->Kd); d->Ks = S(x->Ks); d->uroughness = F(x->nu); d->vroughness = F(x->nv); d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness;
+    } else if (auto x = dynamic_cast<const TranslucentMaterial *>(m)) {
+        d->type = MI_MAT_TRANSLUCENT; d->Kd = S(x->Kd); d->Ks = S(x->Ks); d->roughness = F(x->roughness); d->reflect = S(x->reflect); d->transmit = S(x->transmit);
+        d->bump = bump(x->bumpMap); d->remap_roughness = x->remapRoughness;
+    } else if (auto x = dynamic_cast<const MixMaterial *>(m)) {
+        d->type = MI_MAT_MIX; d->amount = S(x->scale);
+        d->m1 = slotOf(x->m1.get()); d->m2 = slotOf(x->m2.get());
+        if (d->m1 < 0 || d->m2 < 0) return false;
+        allConst = allConst && !fs->descs[d->m1].textured && !fs->descs[d->m2].textured;
+    } else if (auto x = dynamic_cast<const SubsurfaceMaterial *>(m)) {   // the BSDF half is GlassMaterial's record; + the TabulatedBSSRDF inputs
+        d->type = MI_MAT_GLASS; d->Kr = S(x->Kr); d->Kt = S(x->Kt); d->uroughness = F(x->uRoughness); d->vroughness = F(x->vRoughness); d->bump = bump(x->bumpMap);
+        d->remap_roughness = x->remapRoughness;
+        mi_texture e = TexWalker::blank(MI_TEX_CONSTANT, false); TexWalker::val3(e.value, x->eta);
+        d->eta_f = (int32_t)fs->textures.size(); fs->textures.push_back(e);
+        b->kind = MI_BSSRDF_SUBSURFACE; b->sigma_a = S(x->sigma_a); b->sigma_s = S(x->sigma_s); b->Kd = b->mfp = -1; b->scale = x->scale; b->eta = x->eta;
+        const BSSRDFTable &tb = x->table;
+        mi_bssrdf_table mt = {tb.nRhoSamples, tb.nRadiusSamples, tb.rhoSamples.get(), tb.radiusSamples.get(), tb.profile.get(), tb.rhoEff.get(), tb.profileCDF.get()};
+        b->table = (int32_t)fs->bssrdfTables.size(); fs->bssrdfTables.push_back(mt);
+        allConst = false; fs->anyBssrdf = true;
+    } else if (auto x = dynamic_cast<const KdSubsurfaceMaterial *>(m)) {
+        d->type = MI_MAT_GLASS; d->Kr = S(x->Kr); d->Kt = S(x->Kt); d->uroughness = F(x->uRoughness); d->vroughness = F(x->vRoughness); d->bump = bump(x->bumpMap);
+        d->remap_roughness = x->remapRoughness;
+        mi_texture e = TexWalker::blank(MI_TEX_CONSTANT, false); TexWalker::val3(e.value, x->eta);
+        d->eta_f = (int32_t)fs->textures.size(); fs->textures.push_back(e);
+        b->kind = MI_BSSRDF_KDSUBSURFACE; b->Kd = S(x->Kd); b->mfp = S(x->mfp); b->sigma_a = b->sigma_s = -1; b->scale = x->scale; b->eta = x->eta;
+        const BSSRDFTable &tb = x->table;
+        mi_bssrdf_table mt = {tb.nRhoSamples, tb.nRadiusSamples, tb.rhoSamples.get(), tb.radiusSamples.get(), tb.profile.get(), tb.rhoEff.get(), tb.profileCDF.get()};
+        b->table = (int32_t)fs->bssrdfTables.size(); fs->bssrdfTables.push_back(mt);
+        allConst = false; fs->anyBssrdf = true;
+    } else
+        return false;
+    d->textured = allConst ? 0 : 1;
+    return tw.error.empty();
 }
 
 uint32_t countNodes(const mi_bvh2_node *n) {   // the flattened array's length is not stored (bvh.cpp:222-229): walk it
@@ -272,6 +492,27 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     size_t nPrims = order.size();
     fs->triIndices.resize(3 * nPrims); fs->triMesh.resize(nPrims); fs->triLight.assign(nPrims, -1);
     std::vector<int32_t> lightTri(scene.lights.size(), -1), lightSphere(scene.lights.size(), -1);
+    // one slot per Material OBJECT (sub-materials of a mix before the mix): the constant lobe list where every parameter is a ConstantTexture
+    // (read back from the reference's own ComputeScatteringFunctions), the parameter nodes otherwise (evaluated per hit by the backend)
+    TexWalker tw;
+    tw.fs = fs.get();
+    std::string matError;
+    std::function<int32_t(const Material *)> slotOf = [&](const Material *m) -> int32_t {
+        auto it = materialIndex.find(m);
+        if (it != materialIndex.end()) return it->second;
+        mi_material_desc md;
+        mi_bssrdf_desc bd;
+        if (!describeMaterial(m, tw, slotOf, &md, &bd, fs.get())) { if (matError.empty()) matError = tw.error.empty() ? "material class without a device counterpart" : tw.error; return -1; }
+        mi_material mm;
+        std::memset(&mm, 0, sizeof(mm));
+        mm.eta = 1;
+        if (!md.textured) { std::string err; if (!convertMaterial(m, &mm, &err)) { matError = err; return -1; } }
+        else fs->needDescs = true;
+        int32_t idx = (int32_t)fs->materials.size();
+        fs->materials.push_back(mm); fs->descs.push_back(md); fs->bssrdfDescs.push_back(bd);
+        materialIndex[m] = idx;
+        return idx;
+    };
     for (size_t k = 0; k < nPrims; ++k) {
         if (auto tp = dynamic_cast<const TransformedPrimitive *>(order[k])) {   // TransformedPrimitive (core/primitive.h:92-117)
             if (k >= nTop) return fail("nested object instances");
@@ -287,21 +528,15 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
             fs->triMesh[k] = (uint32_t)fs->meshes.size();
             fs->meshes.push_back(mm);
             fs->meshMedium.push_back(-1); fs->meshMedium.push_back(-1);
+            fs->meshAlpha.push_back(-1); fs->meshAlpha.push_back(-1);
             continue;
         }
         const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(order[k]);
         if (!gp) return fail("a primitive that is neither a GeometricPrimitive nor a TransformedPrimitive");
         int32_t mat = -1;
         if (gp->material) {
-            auto it = materialIndex.find(gp->material.get());
-            if (it == materialIndex.end()) {
-                mi_material mm;
-                std::string err;
-                if (!convertMaterial(gp->material.get(), &mm, &err)) return fail(err);
-                it = materialIndex.emplace(gp->material.get(), (int32_t)fs->materials.size()).first;
-                fs->materials.push_back(mm);
-            }
-            mat = it->second;
+            mat = slotOf(gp->material.get());
+            if (mat < 0) return fail(matError.empty() ? "material class without a device counterpart" : matError);
         }
         int32_t light = -1;
         if (gp->areaLight) {
@@ -312,7 +547,6 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
         fs->triLight[k] = light;
         if (const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.get())) {
             const TriangleMesh *mesh = tri->mesh.get();
-            if (mesh->alphaMask || mesh->shadowAlphaMask) return fail("alpha-masked mesh (texture tables are not handed over by this stub)");
             if (!vertexBase.count(mesh)) {
                 vertexBase[mesh] = (uint32_t)(fs->P.size() / 3);
                 for (int v = 0; v < mesh->nVertices; ++v) {
@@ -334,6 +568,9 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
                 fs->meshes.push_back(mm);
                 fs->meshMedium.push_back(mediumOf(gp->mediumInterface.inside)); fs->meshMedium.push_back(mediumOf(gp->mediumInterface.outside));
                 fs->anyInterface |= gp->mediumInterface.inside != nullptr || gp->mediumInterface.outside != nullptr;
+                fs->meshAlpha.push_back(tw.walk(mesh->alphaMask.get())); fs->meshAlpha.push_back(tw.walk(mesh->shadowAlphaMask.get()));   // TriangleMesh::alphaMask / shadowAlphaMask
+                fs->anyAlpha |= mesh->alphaMask != nullptr || mesh->shadowAlphaMask != nullptr;
+                if (!tw.error.empty()) return fail(tw.error);
             }
             fs->triMesh[k] = me->second;
             uint32_t vb = vertexBase[mesh];
@@ -353,6 +590,7 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
             fs->meshes.push_back(mm);
             fs->meshMedium.push_back(mediumOf(gp->mediumInterface.inside)); fs->meshMedium.push_back(mediumOf(gp->mediumInterface.outside));
             fs->anyInterface |= gp->mediumInterface.inside != nullptr || gp->mediumInterface.outside != nullptr;
+            fs->meshAlpha.push_back(-1); fs->meshAlpha.push_back(-1);
             fs->triIndices[3 * k] = MI_PRIM_SPHERE; fs->triIndices[3 * k + 1] = (uint32_t)fs->spheres.size(); fs->triIndices[3 * k + 2] = 0;
             if (light >= 0) { lightTri[light] = (int32_t)k; lightSphere[light] = (int32_t)fs->spheres.size(); }
             fs->spheres.push_back(ms);
@@ -458,6 +696,13 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     d.light_func = fs->lightFunc.data(); d.light_cdf = fs->lightCdf.data(); d.light_func_int = funcInt;
     d.n_spheres = (uint32_t)fs->spheres.size(); d.spheres = fs->spheres.empty() ? nullptr : fs->spheres.data();
     d.n_envmaps = (uint32_t)fs->envmaps.size(); d.envmaps = fs->envmaps.empty() ? nullptr : fs->envmaps.data();
+    if (fs->needDescs || fs->anyAlpha || fs->anyBssrdf) {   // textured materials / alpha masks / BSSRDFs: the node table, pyramids and per-material parameter nodes
+        d.n_textures = (uint32_t)fs->textures.size(); d.textures = fs->textures.data();
+        d.n_images = (uint32_t)fs->images.size(); d.images = fs->images.empty() ? nullptr : fs->images.data();
+        d.material_descs = fs->descs.data();
+        d.mesh_alpha = fs->anyAlpha ? fs->meshAlpha.data() : nullptr;
+        if (fs->anyBssrdf) { d.n_bssrdf_tables = (uint32_t)fs->bssrdfTables.size(); d.bssrdf_tables = fs->bssrdfTables.data(); d.material_bssrdf = fs->bssrdfDescs.data(); }
+    }
     // GeometricPrimitive::mediumInterface per mesh entry, Camera::medium, and which Li runs (row f4)
     d.camera_medium = mediumOf(cam.medium);
     if (!mediumError.empty()) return fail(mediumError);

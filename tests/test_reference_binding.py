@@ -57,7 +57,11 @@ import edge_scenes
 EDGE_CASES = ["infinite", "infinite_only", "infinite_xf", "envmap", "envmap_power", "spot", "spheres", "dof", "crop", "clamp", "onetri",
               "vol_fog", "vol_smoke", "vol_glass", "vol_none",
               # two-level instancing: the reference's TransformedPrimitives and per-object BVHAccels handed over as mi_instance / mi_object
-              "instances", "vol_inst", "instances_one"]
+              "instances", "vol_inst", "instances_one",
+              # rows f2 / f4: the reference's Texture / MIPMap / TextureMapping objects as mi_texture nodes and mi_image pyramids, material
+              # parameters as mi_material_desc, TriangleMesh alpha masks, SubsurfaceMaterial / KdSubsurfaceMaterial with their BSSRDFTable
+              "tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials", "tex_spheres", "tex_dof",
+              "instances2", "vol_alpha", "sss_named", "sss_coeff", "sss_kd", "sss_inst"]
 
 
 def _edge_text(name):
