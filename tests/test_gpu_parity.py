@@ -617,3 +617,29 @@ def test_media_under_path_are_ignored():
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     ctx.close()
+
+
+# ---------------------------------------------------------------- the reference's own host driving the device
+REF_STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
+
+
+@pytest.mark.parametrize("name", ["infinite", "spheres", "instances2", "tex_materials", "tex_bump", "tex_alpha", "vol_smoke", "vol_inst", "sss_coeff", "sss_inst"])
+def test_reference_host_drives_the_device(name, tmp_path):
+    """The drop-in itself: pbrt-v3's unmodified main / parser / API state machine / shape and material factories / BVH build (libpbrt_ref.a) with
+    `Integrator "path"` / `"volpath"` bound to the reference-side stub of INTEGRATION.md s.2 (oracle/ref_build/wavefrontpath.cpp), which flattens
+    the reference's own Scene to a mi_scene_desc and calls mi_ctx_create / mi_scene_upload / mi_render / mi_film_download of libpbrt_amd.so; the
+    film goes back through the reference's Film::MergeFilmTile / WriteImage.  Compared with the reference's own render of the same file
+    (committed fixture): the image criterion of this suite."""
+    import subprocess
+    if not os.access(REF_STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built (it is built where /root/reference is present and travels with the snapshot)")
+    scene = str(tmp_path / "s.pbrt")
+    open(scene, "w").write(edge_scenes.scene(name))
+    out = str(tmp_path / "o.pfm")
+    env = dict(os.environ, PBRT_AMD_BACKEND="device", PBRT_AMD_BACKEND_LIB=pa.DEVICE_LIB)
+    r = subprocess.run([REF_STUB, "--quiet", "--nthreads", "4", "--outfile", out, scene], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(out), (r.stdout[-400:], r.stderr[-800:])
+    img, ref = pa.read_pfm(out), pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    assert img.shape == ref.shape
+    frac, relmse = ol.image_metrics(img, ref)
+    assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
