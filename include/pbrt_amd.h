@@ -72,7 +72,7 @@ enum mi_bxdf_type {
     MI_BXDF_MICROFACET_R = 6, /* MicrofacetReflection     reflection.cpp:226-236,405-423 */
     MI_BXDF_MICROFACET_T = 7, /* MicrofacetTransmission   reflection.cpp:244-266,425-448 */
     MI_BXDF_FRESNEL_BLEND = 8, /* FresnelBlend             reflection.cpp:279-298,450-475 */
-    MI_BXDF_BSSRDF_ADAPTER = 9 /* SeparableBSSRDFAdapter   bssrdf.h:158-174: f = Sw(wi) * eta^2, etaB = the BSSRDF's eta (CPU oracle only so far) */
+    MI_BXDF_BSSRDF_ADAPTER = 9 /* SeparableBSSRDFAdapter   bssrdf.h:158-174: f = Sw(wi) * eta^2, etaB = the BSSRDF's eta (built by k_shade_vol / the oracle at a BSSRDF exit point) */
 };
 enum mi_fresnel_type { MI_FRESNEL_NOOP = 0, MI_FRESNEL_DIELECTRIC = 1, MI_FRESNEL_CONDUCTOR = 2 };
 
@@ -244,8 +244,8 @@ typedef struct mi_envmap {
  *     [first_prim, first_prim + n_prims) of the tri_* arrays, AFTER the n_top_prims top-level primitives; its LinearBVHNode array
  *     occupies [first_node, first_node + n_nodes) of bvh_nodes, AFTER the n_bvh_nodes top-level nodes, with child / primitive offsets
  *     relative to the object's own arrays.
- * Instanced primitives cannot be area lights (api.cpp:1351-1353).  Carried by the host and the CPU oracle; the device traverses the
- * second level through experimental kernel instances (k_trace / k_shade INST) that have not been validated on hardware yet. */
+ * Instanced primitives cannot be area lights (api.cpp:1351-1353).  The default since round 2 (PBRT_AMD_INSTANCING=0 flattens): the device
+ * traverses the second level in k_trace / k_shade / k_shade_vol <..., INST> (fixtures edge_instances*.pfm, edge_vol_inst.pfm, edge_sss_inst.pfm). */
 #define MI_PRIM_INSTANCE 0xFFFFFFFEu
 typedef struct mi_instance {
     float i2w[16], w2i[16]; /* InstanceToWorld (the CTM at ObjectInstance) and its stored inverse, row major */
@@ -313,9 +313,8 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
 
 /* Participating media (VolPathIntegrator, integrators/volpath.cpp:55-190).  A medium is what MakeMedium builds
  * (core/api.cpp:685-731): HomogeneousMedium (media/homogeneous.{h,cpp}) or GridDensityMedium (media/grid.{h,cpp}); the phase function of
- * both is HenyeyGreenstein(g) (core/medium.cpp:189-215).  Carried by the host and the CPU oracle so far: mi_scene_upload refuses scenes
- * whose integrator is "volpath" until the device has the medium-sampling kernels (PathIntegrator ignores media: path.cpp passes
- * handleMedia = false, so "path" scenes with media declarations render as before). */
+ * both is HenyeyGreenstein(g) (core/medium.cpp:189-215).  The device renders them in k_shade_vol (csrc/pt_volpath.h) when the integrator is
+ * "volpath"; PathIntegrator ignores media (path.cpp passes handleMedia = false), so "path" scenes with media declarations render without them. */
 enum mi_medium_type { MI_MEDIUM_HOMOGENEOUS = 0, MI_MEDIUM_GRID = 1 };
 typedef struct mi_medium {
     int32_t type;
@@ -335,7 +334,7 @@ enum mi_integrator_type { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_VOLPATH = 1 };
  * is an MI_MAT_GLASS record with textured = 1 -- and additionally a TabulatedBSSRDF (core/bssrdf.{h,cpp}) from per-hit coefficients and
  * the BSSRDFTable their constructor computed (ComputeBeamDiffusionBSSRDF, bssrdf.cpp:145-176).  Each Material OBJECT with a BSSRDF keeps
  * its own slot in materials[] (Sample_Sp accepts probe hits on primitives of the SAME material object only, bssrdf.cpp:302).
- * Carried by the host and the CPU oracle; mi_scene_upload refuses scenes with such materials until the device has the probe kernels. */
+ * The device evaluates them in k_shade_vol (probe-segment hit chains traced by the shading lane). */
 typedef struct mi_bssrdf_table {
     int32_t n_rho, n_radius;      /* 100, 64 */
     const float *rho_samples;     /* n_rho */

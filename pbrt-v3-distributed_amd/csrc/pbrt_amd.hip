@@ -356,8 +356,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #endif
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
-// WIDE: experimental -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
-// INST: experimental -- two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
+// WIDE: A/B layout -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
+// INST: two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
 // FAST: the lean straight-line steps of pt_trace_fast.h (all-triangle scenes without masks / instances; the default there)
 template <bool WIDE, bool INST, bool FAST = false> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<true, false, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
 #ifndef PT_TEX_SHADE_WAVES
 #define PT_TEX_SHADE_WAVES 2   /* the textured / volumetric instances: 242-256 VGPRs, 2 waves per SIMD -- measured against 3 (168 VGPRs, more scratch): textured C3 141.8 -> 145.2, volpath C3 144.2 -> 149.9 Msamples/s (profiles/r02_j_*); the plain instances keep 168 */
 #endif
-// INST: experimental two-level scenes -- the hit primitive may have been reached through an instance (PathRec::pad0): the interaction is
+// INST: two-level scenes -- the hit primitive may have been reached through an instance (PathRec::pad0): the interaction is
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
 template <bool ENV, bool HALTON, bool TEX, bool INST = false>
 __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
@@ -1296,8 +1296,8 @@ struct mi_ctx {
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
-    // experimental BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
-    bool hasInst = false;                    // two-level scene (PBRT_AMD_INSTANCING=1 on the host): experimental k_trace / k_shade INST instances
+    // A/B layout: BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
+    bool hasInst = false;                    // two-level scene (the host's default): the k_trace / k_shade / k_shade_vol INST instances
     const DevInstance *instPtr = nullptr;
     bool hasNullMat = false;                 // some mesh has no material (medium interfaces): paths may outlive max_depth + 1 wavefront iterations
     int tilesRank = -1, tilesWorld = -1;     // the tile list resident in `tiles` (re-uploaded only when the sharding changes)
@@ -1520,7 +1520,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     c->hasNullMat = false;
     for (uint32_t m = 0; m < d->n_meshes; ++m) c->hasNullMat |= d->meshes[m].material < 0;
     c->tilesRank = c->tilesWorld = -1;
-    c->hasInst = d->n_instances > 0;   // two-level scenes: experimental device path (first compiled in round 1, see TravStateI)
+    c->hasInst = d->n_instances > 0;   // two-level scenes (see TravStateI)
     if (c->hasInst && (!d->instances || !d->objects)) return fail("mi_scene_upload: instances without instance / object tables");
     // textures (row f2): validate the node table before anything is uploaded
     c->hasTex = c->hasAlpha = false;
@@ -1591,7 +1591,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         c->instPtr = b.as<DevInstance>();
     }
     c->useBvh8 = false;
-    {   // experimental: the quantised BVH8 next to the BVH4 (the k_trace<..., WIDE> instances read it through a copy of DevScene)
+    {   // A/B layout: the quantised BVH8 next to the BVH4 (the k_trace<..., WIDE> instances read it through a copy of DevScene)
         const char *e = std::getenv("PBRT_AMD_BVH8");
         if (e && e[0] == '1' && d->n_bvh_nodes && !c->hasInst) {
             bvh8::Builder b8;
@@ -2219,10 +2219,10 @@ static void harvest(mi_ctx *c) {
 
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
-        if (c->hasInst) { /* experimental two-level scenes: the general instance (spheres, masks, instances) */      \
+        if (c->hasInst) { /* two-level scenes: the general instance (spheres, masks, instances) */                   \
             if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true, false, true>), grid, block, 0, st, sc, ps, qin);  \
             else hipLaunchKernelGGL((k_trace<MODE, false, true, true, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* experimental: quantised BVH8 nodes */                \
+        } else if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* A/B layout: quantised BVH8 nodes */                 \
             DevScene sc8 = sc;                                                                                      \
             sc8.nodes = reinterpret_cast<const BVH4Node *>(c->nodes8);                                              \
             sc8.n_nodes = c->nNodes8;                                                                               \
@@ -2327,7 +2327,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                     else { if (umat) LAUNCH_VOL(false, false, true, grid); else LAUNCH_VOL(false, false, false, grid); }
                 }
 #undef LAUNCH_VOL
-            } else if (c->hasInst) {   // experimental two-level scenes: the general instance + interactions carried back from the object's space
+            } else if (c->hasInst) {   // two-level scenes: the general instance + interactions carried back from the object's space
                 if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
                 else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             } else if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)

@@ -410,7 +410,7 @@ PT_DEV void ComputeScatteringFunctionsT(const mi_material *materials, int mat, I
     MaterialEvalD<PT_MIX_MAX_DEPTH>::eval(materials, mat, si, x, out);
 }
 
-// ------------------------------------------------------------------ two-level instancing (experimental), shading side
+// ------------------------------------------------------------------ two-level instancing, shading side
 // The ray a TransformedPrimitive hands to its object: Inverse(PrimitiveToWorld)(r) (transform.h:252-264), as EnterInstance computes it
 struct InstRay { V3 o, d; };
 __device__ __noinline__ InstRay InstanceRay(const DevInstance *in, const V3 ro, const V3 rd) {

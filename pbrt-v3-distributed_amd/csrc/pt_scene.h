@@ -558,7 +558,7 @@ PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, TravStack &st, Tra
     ts.cur = c0;
 }
 
-// ------------------------------------------------------------------ two-level instancing (experimental: PBRT_AMD_INSTANCING=1)
+// ------------------------------------------------------------------ two-level instancing (the host's default since round 2; PBRT_AMD_INSTANCING=0 flattens)
 // TransformedPrimitive::Intersect / IntersectP (core/primitive.cpp:76-111) inside the per-lane state machine: meeting an instance
 // primitive in a leaf, the lane pushes the rest of that leaf and a SENTINEL, takes its ray into the object's space
 // (Transform::operator()(Ray), transform.h:252-264: error-bounded origin, tMax shortened accordingly) and continues at the object's
@@ -665,7 +665,7 @@ PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, T
     return ts.prim != TRAV_MISS;
 }
 
-// ------------------------------------------------------------------ BVH8 traversal (csrc/pt_bvh8.h; experimental, off unless PBRT_AMD_BVH8=1)
+// ------------------------------------------------------------------ BVH8 traversal (csrc/pt_bvh8.h; an A/B layout, off unless PBRT_AMD_BVH8=1: measured slower than the quantised BVH4, profiles/r02_a_*)
 // Same per-lane state machine over the quantised 8-wide nodes.  Validated on the host (mi_bvh8_validate runs the same steps:
 // hits identical to the reference's BVH2 traversal); the kernels below were first compiled in round 1 and had not been run on a
 // GPU when that round's budget ended -- the default path is the BVH4 one above.

@@ -5,9 +5,11 @@
 // goes -- and this kernel replaces k_shade.  What differs from k_shade is WHERE the secondary rays are traced: the reference draws
 // sampler dimensions inside its visibility code (ratio tracking in Medium::Tr, core/light.cpp:63-82, core/scene.cpp:56-70) and inside
 // the BSSRDF probe, BEFORE the continuation direction is sampled, and the count is data dependent.  The dimension stream of a path is
-// therefore only reproducible if those rays are resolved in sequence.  Here every lane walks the same general BVH4 steps the
-// traversal kernels use (TravNodeStep / TravLeafStep with spheres and alpha masks) for its own transmittance, MIS and probe rays,
-// on an LDS stack of its own.  This file is included by pbrt_amd.hip after PathState / ChunkIter / wave_append.
+// therefore only reproducible if those rays are resolved in sequence.  In the general form (WAVE = false) every lane walks the same general
+// BVH4 steps the traversal kernels use (TravNodeStep / TravLeafStep with spheres, alpha masks and instances) for its own transmittance, MIS and
+// probe rays, on an LDS stack of its own; scenes whose media are all homogeneous and that have no BSDF-less interfaces, masks or BSSRDFs draw
+// nothing there and send those rays through the shadow / MIS queues instead (WAVE = true, see NeeOut).  Included by pbrt_amd.hip after
+// PathState / ChunkIter / DynIter / wave_append.
 #pragma once
 #include "pt_volume.h"
 
