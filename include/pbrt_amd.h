@@ -236,8 +236,8 @@ typedef struct mi_envmap {
 } mi_envmap;
 
 /* Object instancing (ObjectBegin / ObjectInstance; api.cpp:1555-1591, TransformedPrimitive core/primitive.cpp:76-111) as a two-level
- * hierarchy.  By default the host FLATTENS instances into world-space copies (n_instances = 0: same hits within float tolerance, no
- * extra device code); with PBRT_AMD_INSTANCING=1 it hands the reference's own structure over instead:
+ * hierarchy.  The host hands the reference's own structure over (the default since round 2); with PBRT_AMD_INSTANCING=0 it FLATTENS instances
+ * into world-space copies instead (n_instances = 0: same hits within float tolerance):
  *   - primitive i of the top-level BVH order is a TransformedPrimitive iff tri_indices[3*i] == MI_PRIM_INSTANCE; tri_indices[3*i+1]
  *     indexes instances[];
  *   - an object's primitives (its own BVHAccel's order; vertices in the space the object was defined in) occupy

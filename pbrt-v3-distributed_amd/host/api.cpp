@@ -57,7 +57,7 @@ struct RenderOptions {   // api.cpp:150-186
     std::vector<GeometricPrimitive> *currentInstance = nullptr;
     std::map<std::string, int> namedMedia;                 // api.cpp:179, as indices into `media`
     std::vector<std::shared_ptr<MediumSpec>> media;
-    // two-level mode (PBRT_AMD_INSTANCING=1): the objects that were instantiated, each with its own BVHAccel
+    // two-level mode (the default; PBRT_AMD_INSTANCING=0 flattens): the objects that were instantiated, each with its own BVHAccel
     std::vector<Scene::ObjectDef> objectDefs;
     std::map<std::string, int> objectIndex;
     // flattened mode: the bounds the reference's TransformedPrimitives would have, and which primitives are flattened copies

@@ -109,7 +109,7 @@ struct SphereShape {
 };
 std::shared_ptr<SphereShape> CreateSphereShape(const Transform &o2w, bool reverseOrientation, const ParamSet &ps);
 
-// TransformedPrimitive (primitive.h:92-117) over the object `object` of Scene::objects: only with PBRT_AMD_INSTANCING=1, otherwise
+// TransformedPrimitive (primitive.h:92-117) over the object `object` of Scene::objects: in the two-level mode (the default; PBRT_AMD_INSTANCING=0: flattened), otherwise
 // instances are flattened into world-space copies when they are instantiated
 struct InstanceRef {
     int object = 0;
