@@ -433,8 +433,8 @@ def main():
     ap.add_argument("--keep", default=None, help="directory for the scenes that mismatch")
     ap.add_argument("--two-level", action="store_true", help="oracle in two-level instancing mode (expected bit-exact)")
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
-    ap.add_argument("--sss", action="store_true", help="subsurface / kdsubsurface materials among the top-level ones (host + oracle vs reference; the device has no BSSRDF yet)")
-    ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; the device has no volpath yet)")
+    ap.add_argument("--sss", action="store_true", help="subsurface / kdsubsurface materials among the top-level ones (host + oracle vs reference; add --device on the GPU box for the device's BSSRDF branch)")
+    ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; add --device on the GPU box for k_shade_vol)")
     ap.add_argument("--instanced-only", action="store_true", help="device mode: only the scenes that use ObjectInstance (two-level traversal)")
     ap.add_argument("--stub", action="store_true", help="the reference-side binding instead of this repository's host: oracle/_ref/pbrt_ref_wavefront (the reference's own parser / API / BVH build + FlattenScene of oracle/ref_build/wavefrontpath.cpp, oracle backend) against pbrt_ref")
     ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
