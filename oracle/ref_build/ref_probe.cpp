@@ -352,5 +352,35 @@ int main(int argc, char **argv) {
         fprintf(f, "%s\n", si.bsdf->ToString().c_str());
         fclose(f);
     }
+    // ---- "blackbody" / "spectrum" parameters as the parser converts them (paramset.cpp:134-169 -> RGBSpectrum::FromSampled)
+    {
+        FILE *f = fopen((dir + "/spectra.bin").c_str(), "wb");
+        auto rec = [&](int kind, const std::vector<Float> &vals) {   // kind 0: blackbody (T, scale); 1: sampled (lambda, v) pairs
+            ParamSet ps;
+            std::unique_ptr<Float[]> fl(new Float[vals.size()]);
+            for (size_t i = 0; i < vals.size(); ++i) fl[i] = vals[i];
+            if (kind == 0) ps.AddBlackbodySpectrum("s", std::move(fl), (int)vals.size());
+            else ps.AddSampledSpectrum("s", std::move(fl), (int)vals.size());
+            Float rgb[3];
+            ps.FindOneSpectrum("s", Spectrum(0.f)).ToRGB(rgb);
+            putv<int32_t>(f, kind); putv<int32_t>(f, (int32_t)vals.size());
+            for (int i = 0; i < 80; ++i) putv<float>(f, i < (int)vals.size() ? vals[i] : 0.f);
+            for (int k = 0; k < 3; ++k) putv<float>(f, rgb[k]);
+        };
+        for (Float T : {800.f, 1500.f, 2700.f, 3200.f, 4100.5f, 5000.f, 6500.f, 9000.f, 20000.f})
+            for (Float sc : {1.f, 0.37f, 25.f}) rec(0, {T, sc});
+        RNG rng(11);
+        for (int k = 0; k < 240; ++k) {
+            int n = 1 + rng.UniformUInt32() % 40;
+            std::vector<Float> lam(n);
+            for (int i = 0; i < n; ++i) lam[i] = 300 + 600 * (i + rng.UniformFloat() * .9f) / n;   // strictly increasing
+            if (k % 3 == 1) for (int i = n - 1; i > 0; --i) std::swap(lam[i], lam[rng.UniformUInt32() % (i + 1)]);   // shuffled: FromSampled sorts
+            if (k % 5 == 4) for (int i = 0; i < n; ++i) lam[i] = 450 + 100 * (lam[i] - 300) / 600;   // inside the table's range only
+            std::vector<Float> v;
+            for (int i = 0; i < n; ++i) { v.push_back(lam[i]); v.push_back(2 * rng.UniformFloat()); }
+            rec(1, v);
+        }
+        fclose(f);
+    }
     return 0;
 }

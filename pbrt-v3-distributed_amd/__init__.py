@@ -72,6 +72,7 @@ def host_lib():
         L.pbrt_amd_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pbrt_amd_scene_texture_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pbrt_amd_scene_media_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pbrt_amd_scene_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         for f in ("pbrt_amd_film_merge", "pbrt_amd_film_rgb"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
         L.pbrt_amd_film_clear.argtypes = [C.c_void_p]
@@ -158,6 +159,13 @@ class Scene:
         self.info.update(n_media=int(tinfo[0]), n_medium_transitions=int(tinfo[1]), camera_medium=int(tinfo[2]), integrator=("path", "volpath")[int(tinfo[3])])
         self.width = self.info["crop_x1"] - self.info["crop_x0"]
         self.height = self.info["crop_y1"] - self.info["crop_y0"]
+
+    def light(self, i):
+        """(type, emitted rgb) of light i of the flattened scene, as handed to mi_scene_upload"""
+        t, rgb = C.c_int(), (C.c_float * 3)()
+        if host_lib().pbrt_amd_scene_light(self._h, int(i), C.byref(t), rgb) != 0:
+            raise IndexError(i)
+        return t.value, np.array(rgb[:], dtype=np.float32)
 
     def close(self):
         if self._h:

@@ -49,6 +49,15 @@ void pbrt_amd_scene_info(pbrt_amd_scene *s, int64_t *out) {
     for (int i = 0; i < 16; ++i) out[i] = v[i];
 }
 
+// light i of the flattened scene: type and the emitted quantity (Lemit | I | L) as it crosses the boundary; returns 0, -1 when out of range
+int pbrt_amd_scene_light(pbrt_amd_scene *s, int i, int *type, float rgb[3]) {
+    const mi_scene_desc &d = s->flat->desc;
+    if (i < 0 || (uint32_t)i >= d.n_lights) return -1;
+    *type = d.lights[i].type;
+    for (int k = 0; k < 3; ++k) rgb[k] = d.lights[i].L[k];
+    return 0;
+}
+
 // Film: merge a downloaded FilmTilePixel array (4 floats per cropped pixel) and produce the
 // final RGB image exactly as Film::WriteImage would; optionally write it.
 int pbrt_amd_film_merge(pbrt_amd_scene *s, const float *rgbw) { s->built->integrator->camera->film->MergeFilm(rgbw); return 0; }

@@ -2,8 +2,8 @@
 // Interface mirrors the reference's ParamSet / TextureParams (core/paramset.h:57-118,173-217):
 // same Find*/FindOne* names, (type,name) keyed lookup, "looked up" tracking and ReportUnused().
 // Spectrum == RGB (core/spectrum.h:429): "rgb"/"color" map through unchanged, "xyz" through
-// XYZToRGB (spectrum.h:56-60).  "blackbody"/"spectrum" (SPD) parameters are not supported
-// (would need the CIE matching tables; none of the named configs use them) and raise an Error.
+// XYZToRGB (spectrum.h:56-60), "blackbody" / "spectrum" (inline samples or SPD files) through the
+// CIE integration of RGBSpectrum::FromSampled (host/spectrum.cpp).
 #pragma once
 #include <map>
 #include <memory>
@@ -16,7 +16,7 @@ namespace pbrt_amd {
 
 void Warning(const char *fmt, ...);
 void Error(const char *fmt, ...);
-// Something the reference renders and this host does not restate (blackbody / sampled-spectrum parameters): reported like an
+// Something the reference renders and this host does not restate: reported like an
 // Error AND counted, so that a render which would come out plausible but wrong is refused -- pbrtWorldEnd skips Render,
 // pbrt_amd_scene_load returns NULL and the command-line renderer exits non-zero (the reference itself would go on).
 void Unsupported(const char *fmt, ...);
@@ -39,6 +39,12 @@ struct RGB {
     RGB operator-() const { return RGB(-c[0], -c[1], -c[2]); }
     Float y() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }   // spectrum.h:462-465
 };
+
+// host/spectrum.cpp: sampled spectra -> RGB as the reference's parser does it (paramset.cpp:134-205, spectrum.h:466-489)
+RGB SpectrumFromSampled(const Float *lambda, const Float *v, int n);
+RGB BlackbodyRGB(Float T, Float scale);
+RGB SpectrumFromFile(const std::string &absoluteFilename);
+bool ReadFloatFile(const char *filename, std::vector<Float> *values);
 
 enum class ParamType { Int, Bool, Float, Point2, Vector2, Point3, Vector3, Normal, Spectrum, String, Texture };
 

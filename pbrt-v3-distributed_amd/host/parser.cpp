@@ -10,6 +10,7 @@
 #include "api.h"
 
 namespace pbrt_amd {
+std::string AbsolutePathFromScene(const std::string &f);
 
 namespace {
 struct Loc { std::string filename; int line = 1; };
@@ -180,9 +181,28 @@ ParamSet parseParams(Tokenizer &tk) {
             else { Error("Only one string allowed for \"texture\" parameter \"%s\"", item.name.c_str()); continue; }
             break;
         case ParamType::Spectrum:
-            if (kind == 2 || kind == 3) {
-                Unsupported("\"%s\": blackbody / sampled-spectrum parameters (parser.cpp:662-690 AddBlackbodySpectrum / AddSampledSpectrum[Files]) are not restated by this host", item.name.c_str());
-                continue;
+            if (kind == 2) {   // temperature (K), scale pairs: parser.cpp:663-672 -> ParamSet::AddBlackbodySpectrum
+                if (nums.size() % 2) { Warning("Excess value given with blackbody parameter \"%s\". Ignoring extra one.", item.name.c_str()); nums.resize(nums.size() - 1); }
+                for (size_t j = 0; j + 1 < nums.size(); j += 2) {
+                    RGB s = BlackbodyRGB((Float)nums[j], (Float)nums[j + 1]);
+                    item.f.push_back(s.c[0]); item.f.push_back(s.c[1]); item.f.push_back(s.c[2]);
+                }
+                break;
+            }
+            if (kind == 3) {   // SPD file names (one spectrum each) or inline (wavelength nm, value) pairs (one spectrum): parser.cpp:673-689
+                if (!strs.empty()) {
+                    for (auto &fn : strs) {
+                        RGB s = SpectrumFromFile(AbsolutePathFromScene(fn));
+                        item.f.push_back(s.c[0]); item.f.push_back(s.c[1]); item.f.push_back(s.c[2]);
+                    }
+                } else {
+                    if (nums.size() % 2) { Warning("Non-even number of values given with sampled spectrum parameter \"%s\". Ignoring extra.", item.name.c_str()); nums.resize(nums.size() - 1); }
+                    std::vector<Float> wl, v;
+                    for (size_t j = 0; j + 1 < nums.size(); j += 2) { wl.push_back((Float)nums[j]); v.push_back((Float)nums[j + 1]); }
+                    RGB s = SpectrumFromSampled(wl.data(), v.data(), (int)wl.size());
+                    item.f.push_back(s.c[0]); item.f.push_back(s.c[1]); item.f.push_back(s.c[2]);
+                }
+                break;
             }
             if (nums.size() % 3) { Warning("Excess RGB values given with parameter \"%s\". Ignoring last %d of them", item.name.c_str(), (int)(nums.size() % 3)); nums.resize(nums.size() - nums.size() % 3); }
             for (size_t j = 0; j + 2 < nums.size() + 0; j += 3) {

@@ -222,6 +222,12 @@ def scene(name):
         return t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "path" "integer maxdepth" [5] "integer pixelbounds" [20 58 14 40]')
     if name == "clamp":         # Film maxsampleluminance
         return _cornell().replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float maxsampleluminance" [1.5]')
+    if name == "spectra":       # "blackbody" and "spectrum" parameters (inline samples and SPD files): parser.cpp:662-690 -> RGB through the CIE tables
+        spd = os.path.join(ROOT, "scenes", "spds")
+        t = _OPEN % ('LightSource "point" "point from" [3 4 -2] "blackbody I" [3200 18]\n'
+                     'LightSource "distant" "point from" [-2 5 -3] "point to" [0 0 0] "blackbody L" [6500 .8]')
+        t = t.replace('Material "matte" "rgb Kd" [.5 .5 .5]', 'Material "matte" "spectrum Kd" [400 .2 500 .35 600 .7 700 .75 650 .72]')   # unsorted on purpose
+        return t.replace('Material "mirror"', 'Material "metal" "spectrum eta" "%s/testmetal.eta.spd" "spectrum k" "%s/testmetal.k.spd" "float roughness" [.08]' % (spd, spd))
     if name == "empty":         # no geometry at all: every camera ray escapes to the environment
         return ('Camera "perspective" "float fov" [40]\nSampler "sobol" "integer pixelsamples" [2]\nPixelFilter "box"\nIntegrator "path"\n'
                 'Film "image" "integer xresolution" [40] "integer yresolution" [24] "string filename" "e.pfm"\nWorldBegin\n'
@@ -234,7 +240,7 @@ def scene(name):
     raise KeyError(name)
 
 
-NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "spheres", "dof", "crop", "clamp", "empty", "onetri"]
+NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "spheres", "dof", "crop", "clamp", "empty", "onetri", "spectra"]
 
 # ---- textured variants: image / procedural textures, mappings, bump maps, alpha masks
 TEX = os.path.join(ROOT, "scenes", "textures")

@@ -457,20 +457,35 @@ def test_media_declarations_reach_the_scene_description(built):
     assert (plain.info["integrator"], plain.info["n_media"], plain.info["camera_medium"]) == ("path", 0, -1)
 
 
-def test_blackbody_and_sampled_spectra_are_refused_not_defaulted(tmp_path):
-    """`blackbody` / `spectrum` parameters (parser.cpp:662-690 in the reference) are not restated by this host.  Dropping them
-    with a non-fatal message rendered a plausible but wrong image (material / light defaults); now the scene is refused:
-    pbrt_amd_scene_load returns NULL and the command-line renderer exits non-zero without writing an image."""
-    import subprocess
-    base = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
-    for old, new in [('"rgb L" [17 12 4]', '"blackbody L" [6500 1]'), ('"rgb L" [17 12 4]', '"spectrum L" [400 1 700 2]')]:
-        assert old in base
-        with pytest.raises(RuntimeError):
-            pa.Scene(text=base.replace(old, new))
-    f = tmp_path / "bb.pbrt"
-    f.write_text(base.replace('"rgb L" [17 12 4]', '"blackbody L" [6500 1]'))
-    out = tmp_path / "bb.pfm"
-    exe = os.path.join(ROOT, "pbrt-v3-distributed_amd", "bin", "pbrt_amd")
-    r = subprocess.run([exe, "--quiet", "--outfile", str(out), str(f)], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and not out.exists() and "unsupported" in r.stderr
-    pa.Scene(text=base)   # the next scene loads normally (the count is per pbrtInit)
+def test_blackbody_and_sampled_spectrum_parameters_vs_reference(built):
+    """"blackbody" / "spectrum" parameter values -> RGB (host/spectrum.cpp) against the reference's own conversion
+    (ParamSet::AddBlackbodySpectrum / AddSampledSpectrum -> RGBSpectrum::FromSampled, recorded by oracle/ref_build/ref_probe.cpp into
+    tests/golden/spectra_vectors.npz): bit-exact, including unsorted samples and samples outside / inside the CIE range only."""
+    recs = np.load(os.path.join(ROOT, "tests", "golden", "spectra_vectors.npz"))["spectra"]
+    assert len(recs) == 27 + 240
+    lights = []
+    for r in recs:
+        vals = " ".join("%.9g" % v for v in r["vals"][:r["n"]])
+        lights.append('LightSource "point" "%s I" [%s]' % ("blackbody" if r["kind"] == 0 else "spectrum", vals))
+    sc = pa.Scene(text=MIN + "WorldBegin\n" + "\n".join(lights) + '\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
+    assert sc.info["n_lights"] == len(recs)
+    for i, r in enumerate(recs):
+        _t, rgb = sc.light(i)
+        assert rgb.tobytes() == r["rgb"].tobytes(), (i, int(r["kind"]), rgb, r["rgb"])
+
+
+def test_spectrum_files(built, tmp_path):
+    """SPD files ("spectrum" with string values, paramset.cpp:171-205): comments, exponents, unsorted samples, the reader's dropped last
+    number when the file does not end in whitespace (floatfile.cpp:52-79), a missing file -> black with a warning; several files = several spectra."""
+    (tmp_path / "a.spd").write_text("# c\n400 .2\n500 3.5e-1 # t\n700 .75\n600 .7\n")
+    (tmp_path / "b.spd").write_text("400 1 500 2 600 3 700 9")           # the trailing 9 is never stored: 7 values, the odd one ignored -> 3 pairs
+    (tmp_path / "c.spd").write_text("400 1 500 2 600 3\n")
+    t = (MIN + 'WorldBegin\nLightSource "point" "spectrum I" "%s/a.spd"\nLightSource "point" "spectrum I" [400 .2 500 .35 600 .7 700 .75]\n'
+         'LightSource "point" "spectrum I" "%s/b.spd"\nLightSource "point" "spectrum I" "%s/c.spd"\nLightSource "point" "spectrum I" "%s/missing.spd"\n'
+         'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n') % ((tmp_path,) * 4)
+    (tmp_path / "s.pbrt").write_text(t.replace(str(tmp_path) + "/", ""))   # relative names resolve against the scene file's directory
+    sc = pa.Scene(str(tmp_path / "s.pbrt"))
+    L = [sc.light(i)[1] for i in range(5)]
+    assert L[0].tobytes() == L[1].tobytes() and L[0].min() > 0
+    assert L[2].tobytes() == L[3].tobytes()
+    assert not L[4].any()

@@ -48,6 +48,76 @@ uint32_t buildWide(const mi_bvh2_node *n2, uint32_t i2, int width, std::vector<W
     }
     return idx;
 }
+
+// ---- SAH-optimal collapse (dynamic programme over the reference tree, after Ylitie et al. 2017 s.3.2): which descendants of a
+// BVH2 node become the <= W children of its wide node so that  sum over wide nodes A*cNode + sum over leaves A*n*cTri  is least.
+// mergeMax > 0 also lets a whole subtree of <= mergeMax primitives (contiguous in the reference's ordering) become one leaf.
+struct Collapse {
+    const mi_bvh2_node *n2; int W; float cNode, cTri; int mergeMax;
+    std::vector<float> A; std::vector<uint32_t> np, first;
+    std::vector<float> F;          // F[n*W + k-1]: least cost of the subtree of n under at most k slots of its parent's node (k = 1..W)
+    std::vector<uint8_t> how, howR; // how[n*W + k-1]: 0 = one slot (leaf or own wide node, see asLeaf), s>0 = split: left gets s slots, right howR
+    std::vector<uint8_t> asLeaf;   // the one-slot form of n is a leaf
+    void run(const mi_bvh2_node *nodes, size_t N, int width, float cn, float ct, int mm) {
+        n2 = nodes; W = width; cNode = cn; cTri = ct; mergeMax = mm;
+        A.resize(N); np.resize(N); first.resize(N); F.assign(N * W, 0); how.assign(N * W, 0); howR.assign(N * W, 0); asLeaf.assign(N, 0);
+        for (size_t i = N; i-- > 0;) {   // children have larger indices than their parent (depth-first layout)
+            const mi_bvh2_node &b = n2[i];
+            A[i] = area(b);
+            if (b.n_prims > 0) {
+                np[i] = b.n_prims; first[i] = (uint32_t)b.offset; asLeaf[i] = 1;
+                for (int k = 1; k <= W; ++k) F[i * W + k - 1] = A[i] * b.n_prims * cTri;
+                continue;
+            }
+            size_t l = i + 1, r = (size_t)b.offset;
+            np[i] = np[l] + np[r]; first[i] = std::min(first[l], first[r]);
+            bool contiguous = first[l] + np[l] == first[r] || first[r] + np[r] == first[l];
+            // D(i, k): the subtree as a forest of <= k slots = left under s slots + right under k - s
+            float D[9]; uint8_t Ds[9];
+            for (int k = 2; k <= W; ++k) {
+                D[k] = 1e38f; Ds[k] = 1;
+                for (int s = 1; s < k; ++s) { float c = F[l * W + s - 1] + F[r * W + k - s - 1]; if (c < D[k]) { D[k] = c; Ds[k] = (uint8_t)s; } }
+            }
+            float cInt = A[i] * cNode + D[W];
+            float cLeaf = (mergeMax > 0 && (int)np[i] <= mergeMax && contiguous) ? A[i] * np[i] * cTri : 1e38f;
+            asLeaf[i] = cLeaf < cInt;
+            F[i * W] = std::min(cLeaf, cInt); how[i * W] = 0;
+            for (int k = 2; k <= W; ++k) {
+                if (D[k] < F[i * W + k - 2]) { F[i * W + k - 1] = D[k]; how[i * W + k - 1] = Ds[k]; howR[i * W + k - 1] = (uint8_t)(k - Ds[k]); }
+                else { F[i * W + k - 1] = F[i * W + k - 2]; how[i * W + k - 1] = how[i * W + k - 2]; howR[i * W + k - 1] = howR[i * W + k - 2]; }
+            }
+        }
+    }
+    // the slots node n occupies when given at most k of them, in the reference's left-to-right order
+    void slots(uint32_t n, int k, std::vector<uint32_t> &outv) const {
+        uint8_t s = how[(size_t)n * W + k - 1];
+        if (s == 0) { outv.push_back(n); return; }
+        slots(n + 1, s, outv);
+        slots((uint32_t)n2[n].offset, howR[(size_t)n * W + k - 1], outv);
+    }
+};
+uint32_t buildWideDP(const Collapse &c, uint32_t i2, std::vector<WNode> &out, std::vector<std::vector<uint8_t>> &cnt) {
+    uint32_t idx = (uint32_t)out.size();
+    out.emplace_back();
+    cnt.emplace_back(8, 0);
+    std::vector<uint32_t> kids;
+    // the node's own children: the W-slot forest of its two reference children
+    {
+        uint8_t s = 0; float best = 1e38f;
+        size_t l = i2 + 1, r = (size_t)c.n2[i2].offset;
+        for (int t = 1; t < c.W; ++t) { float v = c.F[l * c.W + t - 1] + c.F[r * c.W + c.W - t - 1]; if (v < best) { best = v; s = (uint8_t)t; } }
+        c.slots((uint32_t)l, s, kids);
+        c.slots((uint32_t)r, c.W - s, kids);
+    }
+    out[idx].n = (int)kids.size();
+    for (int k = 0; k < (int)kids.size(); ++k) {
+        const mi_bvh2_node &b = c.n2[kids[k]];
+        for (int a = 0; a < 3; ++a) { out[idx].lo[k][a] = b.bmin[a]; out[idx].hi[k][a] = b.bmax[a]; }
+        if (c.asLeaf[kids[k]]) { out[idx].child[k] = LEAF | c.first[kids[k]]; cnt[idx][k] = (uint8_t)std::min<uint32_t>(255, c.np[kids[k]]); }
+        else { uint32_t ch = buildWideDP(c, kids[k], out, cnt); out[idx].child[k] = ch; }
+    }
+    return idx;
+}
 // Moller-Trumbore in double: the study only needs hit distances, not the watertight test
 bool triHit(const mi_scene_desc *d, uint32_t prim, const double o[3], const double dir[3], double tMax, double *t) {
     const uint32_t *v = d->tri_indices + 3 * (size_t)prim;
@@ -72,7 +142,9 @@ bool triHit(const mi_scene_desc *d, uint32_t prim, const double o[3], const doub
 }
 }  // namespace
 
+int g_dp = 0, g_merge = 0; float g_cNode = 1, g_cTri = 1;
 extern "C" {
+void bvh_study_collapse(int dp, float cNode, float cTri, int mergeMax) { g_dp = dp; g_cNode = cNode; g_cTri = cTri; g_merge = mergeMax; }
 // out[0] = nodes visited, out[1] = triangles tested, out[2] = hits, out[3] = number of wide nodes; width 2 = the reference's BVH2 traversal
 void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width, int cull_on_pop, int any_hit, double *out) {
     double nodes = 0, tris = 0, hits = 0;
@@ -113,7 +185,10 @@ void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width,
     }
     std::vector<WNode> wn;
     std::vector<std::vector<uint8_t>> cnt;
-    if (d->n_bvh_nodes && d->bvh_nodes[0].n_prims == 0) buildWide(d->bvh_nodes, 0, width, wn, cnt);
+    if (d->n_bvh_nodes && d->bvh_nodes[0].n_prims == 0) {
+        if (g_dp) { Collapse c; c.run(d->bvh_nodes, d->n_bvh_nodes, width, g_cNode, g_cTri, g_merge); buildWideDP(c, 0, wn, cnt); }
+        else buildWide(d->bvh_nodes, 0, width, wn, cnt);
+    }
     struct Ent { uint32_t ref; uint8_t count; double t; };
     for (int64_t r = 0; r < n && !wn.empty(); ++r) {
         double o[3] = {rays[r].o[0], rays[r].o[1], rays[r].o[2]}, dir[3] = {rays[r].d[0], rays[r].d[1], rays[r].d[2]}, tMax = rays[r].tmax;

@@ -21,9 +21,11 @@ def main():
     import oracle_lib as ol
     pa = importlib.import_module("pbrt-v3-distributed_amd")
     so = "/tmp/libbvhstudy.so"
+    L0 = None
     subprocess.check_call(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", os.path.join(ROOT, "tools", "bvh_study.cpp"), "-I" + os.path.join(ROOT, "include"), "-o", so])
     L = C.CDLL(so)
     L.bvh_study.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.bvh_study_collapse.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
     f = "/tmp/bvh_study_scene.pbrt"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris), "--res", "640", "360", "--spp", "1", "--out", f], stdout=subprocess.DEVNULL)
     sc = pa.Scene(f)
@@ -44,15 +46,22 @@ def main():
     sec = np.zeros(len(p), dtype=pa.RAY_DTYPE)
     sec["o"] = (p + n * 1e-3).astype(np.float32); sec["d"] = d.astype(np.float32); sec["tmax"] = np.inf
     print("scene: %d triangles, %d BVH2 nodes; %d camera rays, %d bounce rays" % (sc.info["n_tris"], sc.info["n_bvh_nodes"], len(cam), len(sec)))
-    print("%-8s %-28s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
+    print("%-8s %-36s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
     for name, rays in (("camera", cam), ("bounce", sec)):
         rays = np.ascontiguousarray(rays)
-        for label, width, cull, nodeB in (("BVH2 reference order", 2, 0, 32), ("BVH4 (device layout)", 4, 0, 128), ("BVH4 + cull on pop", 4, 1, 128),
-                                          ("BVH8", 8, 0, 256), ("BVH8 + cull on pop", 8, 1, 256), ("BVH8 compressed 80 B + cull", 8, 1, 80)):
+        for label, width, cull, nodeB, dp in (("BVH2 reference order", 2, 0, 32, None), ("BVH4 (device layout)", 4, 0, 128, None), ("BVH4 + cull on pop", 4, 1, 128, None),
+                                              ("BVH4Q greedy-area collapse + cull", 4, 1, 64, None),
+                                              ("BVH4Q SAH-optimal collapse", 4, 1, 64, (1.0, 0.75, 0)), ("BVH4Q SAH-opt, leaves <= 4", 4, 1, 64, (1.0, 0.75, 4)),
+                                              ("BVH4Q SAH-opt, leaves <= 8", 4, 1, 64, (1.0, 0.75, 8)), ("BVH4Q SAH-opt, leaves <= 16", 4, 1, 64, (1.0, 0.75, 16)),
+                                              ("BVH4Q SAH-opt cTri .4, leaves <= 8", 4, 1, 64, (1.0, 0.4, 8)),
+                                              ("BVH8", 8, 0, 256, None), ("BVH8 + cull on pop", 8, 1, 256, None), ("BVH8 compressed 80 B + cull", 8, 1, 80, None),
+                                              ("BVH8c SAH-optimal collapse", 8, 1, 80, (1.0, 0.6, 0))):
             out = np.zeros(4)
+            if dp: L.bvh_study_collapse(1, C.c_float(dp[0]), C.c_float(dp[1]), dp[2])
+            else: L.bvh_study_collapse(0, C.c_float(1), C.c_float(1), 0)
             L.bvh_study(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), width, cull, 0, out.ctypes.data_as(C.c_void_p))
             nr, tr = out[0] / len(rays), out[1] / len(rays)
-            print("%-8s %-28s %10.2f %10.2f %12.2f" % (name, label, nr, tr, (48 + nr * nodeB + tr * 48) / 1024))
+            print("%-8s %-36s %10.2f %10.2f %12.2f  req/ray %7.1f  nodes %d" % (name, label, nr, tr, (48 + nr * nodeB + tr * 48) / 1024, 3 + nr * nodeB / 16 + tr * 3, out[3]))
 
 
 if __name__ == "__main__":

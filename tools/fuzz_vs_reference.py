@@ -426,6 +426,26 @@ def device_mode(a):
     print("%d valid scenes rendered on the device (%d refused as outside the device's stated scope, %d on which the reference itself aborts), %d mismatching (device vs oracle)" % (done, refused, invalid, bad))
 
 
+def with_spectra(text, seed):
+    """--spectra: some of the scene's "rgb" parameters become "blackbody" (emission) or inline "spectrum" samples (reflectances), from an
+    RNG stream of their own so that the scenes of earlier seeds stay what they were (parser.cpp:662-690; host/spectrum.cpp)"""
+    import re
+    r = np.random.default_rng(seed + 55)
+
+    def sub(m):
+        name, vals = m.group(1), [float(v) for v in m.group(2).split()]
+        if r.random() < .45:
+            return m.group(0)
+        if name in ("L", "I"):
+            return '"blackbody %s" [%s %s]' % (name, f(r.uniform(1200, 11000)), f(max(vals) * r.uniform(.7, 1.4)))
+        n = int(r.integers(1, 9))
+        lam = np.sort(r.uniform(380, 760, n)) + np.arange(n) * .5
+        if r.random() < .3: lam = r.permutation(lam)
+        v = np.clip(np.mean(vals) + r.uniform(-.3, .3, n), .02, .98)
+        return '"spectrum %s" [%s]' % (name, " ".join("%s %s" % (f(a), f(b)) for a, b in zip(lam, v)))
+    return re.sub(r'"rgb (L|I|Kd|Ks|Kr|Kt)" \[([^\]]*)\]', sub, text)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
@@ -435,6 +455,7 @@ def main():
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
     ap.add_argument("--sss", action="store_true", help="subsurface / kdsubsurface materials among the top-level ones (host + oracle vs reference; add --device on the GPU box for the device's BSSRDF branch)")
     ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; add --device on the GPU box for k_shade_vol)")
+    ap.add_argument("--spectra", action="store_true", help="some \"rgb\" parameters become \"blackbody\" / inline \"spectrum\" parameters (the host's CIE conversion, host/spectrum.cpp)")
     ap.add_argument("--instanced-only", action="store_true", help="device mode: only the scenes that use ObjectInstance (two-level traversal)")
     ap.add_argument("--stub", action="store_true", help="the reference-side binding instead of this repository's host: oracle/_ref/pbrt_ref_wavefront (the reference's own parser / API / BVH build + FlattenScene of oracle/ref_build/wavefrontpath.cpp, oracle backend) against pbrt_ref")
     ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
@@ -450,6 +471,7 @@ def main():
         seed = a.seed * 100000 + i
         gen = Gen(seed); gen.sss = a.sss
         text = gen.scene(a.res, a.media)
+        if a.spectra: text = with_spectra(text, seed)
         fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)
         out = os.path.join(tmp, "r.pfm")
         if os.path.exists(out): os.remove(out)

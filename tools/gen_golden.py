@@ -15,10 +15,16 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+SPECTRA = np.dtype([("kind", "<i4"), ("n", "<i4"), ("vals", "<f4", 80), ("rgb", "<f4", 3)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     subprocess.check_call([os.path.join(REF, "ref_probe"), tmp])
+    np.savez_compressed(os.path.join(OUT, "spectra_vectors.npz"), spectra=np.fromfile(os.path.join(tmp, "spectra.bin"), dtype=SPECTRA))
+    if "--only-spectra" in sys.argv:
+        return
     ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
     si = np.fromfile(os.path.join(tmp, "sobol_index.bin"), dtype=np.dtype([("m", "<u4"), ("frame", "<u8"), ("px", "<i4"), ("py", "<i4"), ("idx", "<u8")]))
     sp = np.fromfile(os.path.join(tmp, "sobol_sampler.bin"), dtype=np.dtype([("px", "<i4"), ("py", "<i4"), ("s", "<i4"), ("u", "<f4", 24)]))
