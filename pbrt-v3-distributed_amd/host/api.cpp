@@ -432,7 +432,10 @@ std::shared_ptr<Light> MakeLight(const std::string &name, const ParamSet &ps, co
             light->env = CreateEnvMap("", Ls);
         }
     } else {
-        Warning("Light \"%s\" is not supported by this path (goniometric/projection: SURVEY.md s.2 row 25).", name.c_str());
+        // the reference's remaining light types would light the scene; rendering without them gives a plausible but wrong image -> refuse
+        if (name == "goniometric" || name == "projection")
+            Unsupported("LightSource \"%s\" has no counterpart on this path (lights/goniometric.cpp, lights/projection.cpp: SURVEY.md s.2 row 25)", name.c_str());
+        else Warning("Light \"%s\" unknown.", name.c_str());   // api.cpp:724 in the reference
         ps.ReportUnused();
         return nullptr;
     }
@@ -747,7 +750,9 @@ void pbrtWorldEnd() {
             camera.reset(CreatePerspectiveCamera(renderOptions->CameraParams, renderOptions->CameraToWorld[0], film));
             renderOptions->CameraParams.ReportUnused();
         } else {
-            Warning("Camera \"%s\" is not supported by this path (perspective only: SURVEY.md s.2 row 26).", renderOptions->CameraName.c_str());
+            if (renderOptions->CameraName == "orthographic" || renderOptions->CameraName == "realistic" || renderOptions->CameraName == "environment")
+                Unsupported("Camera \"%s\" has no counterpart on this path (perspective only: SURVEY.md s.2 row 26)", renderOptions->CameraName.c_str());
+            else Warning("Camera \"%s\" unknown.", renderOptions->CameraName.c_str());   // api.cpp:862 in the reference
             delete film;
         }
         if (!camera) Error("Unable to create camera");

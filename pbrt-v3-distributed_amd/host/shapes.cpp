@@ -262,9 +262,15 @@ std::shared_ptr<TriangleMesh> MakeShapes(const std::string &name, const Transfor
     if (name == "nurbs") return CreateNURBS(o2w, ro, ps);
     if (name == "plymesh") return CreatePLYMesh(o2w, ro, ps);
     if (name == "loopsubdiv") return CreateLoopSubdiv(o2w, ro, ps);
-    // quadrics / curves: not on the triangle hot path
-    Warning("Shape \"%s\" is not supported by the GPU triangle path (convert with the reference's --toply); skipped.",
-            name.c_str());
+    // the other quadrics / curves: not on the triangle hot path.  Leaving them out would render a plausible but
+    // wrong image, so the scene is refused; a name the reference does not know either is skipped with its warning (api.cpp:603)
+    static const char *const known[] = {"cone", "cylinder", "disk", "paraboloid", "hyperboloid", "curve"};
+    for (const char *k : known)
+        if (name == k) {
+            Unsupported("Shape \"%s\" has no counterpart on this path (triangle meshes, spheres, loopsubdiv / nurbs / heightfield tessellations are carried)", name.c_str());
+            return nullptr;
+        }
+    Warning("Shape \"%s\" unknown.", name.c_str());
     return nullptr;
 }
 

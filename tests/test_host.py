@@ -489,3 +489,23 @@ def test_spectrum_files(built, tmp_path):
     assert L[0].tobytes() == L[1].tobytes() and L[0].min() > 0
     assert L[2].tobytes() == L[3].tobytes()
     assert not L[4].any()
+
+
+@pytest.mark.parametrize("edit", [('Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]', 'Shape "disk" "float radius" [1]'),
+                                  ('WorldBegin\n', 'WorldBegin\nLightSource "projection" "rgb I" [1 1 1] "string mapname" "x.png"\n'),
+                                  ('WorldBegin\n', 'Camera "orthographic"\nWorldBegin\n')])
+def test_scene_content_without_a_counterpart_is_refused_not_skipped(edit, tmp_path):
+    """ADVICE r1 (plausible-but-wrong images): shapes / lights / cameras of the reference that this path does not carry used to be skipped
+    with a warning, so the scene rendered without them.  Now the scene is refused: pbrt_amd_scene_load returns NULL and the command-line
+    renderer exits non-zero without an image.  Names the reference does not know either keep its behaviour (warning, skipped)."""
+    base = MIN + 'WorldBegin\nLightSource "point" "rgb I" [1 1 1]\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n'
+    assert edit[0] in base
+    with pytest.raises(RuntimeError):
+        pa.Scene(text=base.replace(edit[0], edit[1], 1))
+    f = tmp_path / "r.pbrt"
+    f.write_text(base.replace(edit[0], edit[1], 1))
+    out = tmp_path / "r.pfm"
+    r = subprocess.run([os.path.join(ROOT, "pbrt-v3-distributed_amd", "bin", "pbrt_amd"), "--quiet", "--outfile", str(out), str(f)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and not out.exists() and "unsupported" in r.stderr
+    pa.Scene(text=base)                                                              # the count is per pbrtInit
+    pa.Scene(text=base.replace('Shape "trianglemesh"', 'Shape "nosuchshape"\nShape "trianglemesh"'))   # unknown to the reference too: skipped
