@@ -427,7 +427,10 @@ typedef struct mi_ctx mi_ctx;
 const char *mi_last_error(void);
 int mi_abi_version(void);
 
-/* context: one per GPU. `stream` = a hipStream_t to run on (0 -> library creates its own). */
+/* context: one per GPU. `stream` = a hipStream_t to run on (0 -> library creates its own).
+ * Several contexts may share a device and be driven from different host threads (one thread per context).  Scenes with textures,
+ * alpha masks or instances keep their tables in per-device __constant__ symbols, so the passes of such contexts take turns on a device
+ * (each drains its stream before the next one starts); a context that is alone on its device stays fully asynchronous. */
 int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out);
 void mi_ctx_destroy(mi_ctx *ctx);
 

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1271,9 +1272,15 @@ static int fail(const std::string &m) { g_err = m; return -1; }
 #define HIP_TRY(expr)                                                                                    \
     do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 
-struct DevBuf {
+struct DevBuf {   // owns one device allocation: released with the object, so error returns of the entry points do not leak
     void *p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+    ~DevBuf() { release(); }
     int alloc(size_t n) {
         release();
         if (n == 0) n = 16;
@@ -1342,6 +1349,40 @@ static int upload(mi_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     if (bytes && src) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
+
+// ---- turns on the per-device __constant__ tables.  c_tex / c_instances exist once per DEVICE and every pass of a scene with textures,
+// alpha masks or instances rewrites them on its own stream.  Contexts that share a device would overwrite each other's tables while
+// kernels still read them, so such passes take turns: the turn's holder first drains the streams of the other table-using contexts of
+// its device, and drains its own before it hands the turn on.  A context that is alone on its device only pays an uncontended lock
+// and stays asynchronous.
+namespace {
+std::mutex g_ctxRegistryLock;
+std::vector<mi_ctx *> g_ctxRegistry;   // live contexts (mi_ctx_create / mi_ctx_destroy)
+std::mutex g_tableTurnLock[64];        // by device ordinal
+struct TableTurn {
+    mi_ctx *c;
+    bool held = false, shared = false;
+    explicit TableTurn(mi_ctx *ctx) : c(ctx) {
+        if (!(c->hasTex || c->hasAlpha || c->hasInst)) return;
+        g_tableTurnLock[c->device & 63].lock();
+        held = true;
+        std::lock_guard<std::mutex> g(g_ctxRegistryLock);
+        for (mi_ctx *o : g_ctxRegistry)
+            if (o != c && o->device == c->device && (o->hasTex || o->hasAlpha || o->hasInst)) {
+                shared = true;
+                (void)hipStreamSynchronize(o->stream);
+                if (o->stream2) (void)hipStreamSynchronize(o->stream2);
+            }
+    }
+    ~TableTurn() {
+        if (!held) return;
+        if (shared) { (void)hipStreamSynchronize(c->stream); if (c->stream2) (void)hipStreamSynchronize(c->stream2); }
+        g_tableTurnLock[c->device & 63].unlock();
+    }
+    TableTurn(const TableTurn &) = delete;
+    TableTurn &operator=(const TableTurn &) = delete;
+};
+}  // namespace
 
 // ---- BVH2 -> BVH4 collapse (host).  Every BVH4 child box is a reference node box.
 namespace {
@@ -1476,12 +1517,14 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { mi_ctx_destroy(c); return -1; }
     if (hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream) != hipSuccess) { mi_ctx_destroy(c); return fail("mi_ctx_create: hipMemsetAsync failed"); }
+    { std::lock_guard<std::mutex> g(g_ctxRegistryLock); g_ctxRegistry.push_back(c); }
     *out = c;
     return 0;
 }
 
 void mi_ctx_destroy(mi_ctx *c) {
     if (!c) return;
+    { std::lock_guard<std::mutex> g(g_ctxRegistryLock); g_ctxRegistry.erase(std::remove(g_ctxRegistry.begin(), g_ctxRegistry.end(), c), g_ctxRegistry.end()); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->sceneBufs) b.release();
@@ -2264,8 +2307,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     const DevScene &sc = c->sc;
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
+    TableTurn turn(c);
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
-    if (c->hasTex || c->hasAlpha || c->hasInst)   // the texture tables of THIS context's scene (stream ordered: contexts sharing a device may interleave passes)
+    if (c->hasTex || c->hasAlpha || c->hasInst)   // the tables of THIS context's scene (stream ordered; contexts sharing a device take turns: TableTurn)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
     if (c->hasInst) HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_instances), &c->instPtr, sizeof(c->instPtr), 0, hipMemcpyHostToDevice, st));
     tic(c, MI_K_RAYGEN);
@@ -2945,6 +2989,7 @@ int mi_texture_eval(mi_ctx *c, int32_t node, const mi_tex_query *queries, int64_
     HIP_TRY(hipSetDevice(c->device));
     DevBuf dq, dr;
     if (dq.alloc((size_t)n * sizeof(mi_tex_query)) || dr.alloc((size_t)n * 3 * sizeof(float))) return -1;
+    TableTurn turn(c);
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dq.p, queries, (size_t)n * sizeof(mi_tex_query), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_stage_texture, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, c->stream, (int)node, dq.as<mi_tex_query>(), n, dr.as<float>());

@@ -619,6 +619,36 @@ def test_media_under_path_are_ignored():
     ctx.close()
 
 
+def test_contexts_sharing_a_device_render_concurrently():
+    """the texture / alpha / instance tables live in per-DEVICE __constant__ symbols that every pass rewrites.  Two contexts on
+    one device, rendering different textured / instanced scenes from two host threads at once, take turns on them (TableTurn in run_pass):
+    each image must equal the one the same context renders alone, bit for bit."""
+    import threading
+    names = ["tex_materials", "tex_alpha", "instances2"]
+    scenes = [pa.Scene(text=edge_scenes.scene(n)) for n in names]
+    ctxs = [pa.Context(s) for s in scenes]
+    alone = []
+    for c in ctxs:
+        c.film_clear(); c.render(); alone.append(c.film().copy())
+    rounds, got, errs = 4, [[] for _ in ctxs], []
+
+    def work(i):
+        try:
+            for _ in range(rounds):
+                ctxs[i].film_clear(); ctxs[i].render(); got[i].append(ctxs[i].film().copy())
+        except Exception as e:   # noqa: BLE001
+            errs.append((i, e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for i, n in enumerate(names):
+        assert alone[i].any()
+        for g in got[i]:
+            assert g.tobytes() == alone[i].tobytes(), n
+    for c in ctxs: c.close()
+
+
 # ---------------------------------------------------------------- the reference's own host driving the device (INTEGRATION.md s.2)
 REF_STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
 
