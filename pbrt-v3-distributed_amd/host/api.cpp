@@ -780,7 +780,13 @@ void pbrtWorldEnd() {
                 integrator->nGpus = PbrtOptions.nGpus;
                 renderOptions->IntegratorParams.ReportUnused();
             } else
-                Error("Integrator \"%s\" unknown to this path (\"path\" and \"volpath\": SURVEY.md s.2 row 7).", renderOptions->IntegratorName.c_str());
+            {
+                static const char *const known[] = {"whitted", "directlighting", "bdpt", "mlt", "ambientocclusion", "sppm"};
+                bool isKnown = false;
+                for (const char *k : known) isKnown |= renderOptions->IntegratorName == k;
+                if (isKnown) Unsupported("Integrator \"%s\" has no counterpart on this path (\"path\" and \"volpath\": SURVEY.md s.2 row 7)", renderOptions->IntegratorName.c_str());
+                else Error("Integrator \"%s\" unknown.", renderOptions->IntegratorName.c_str());   // api.cpp:1710 in the reference: no render either
+            }
             if (renderOptions->lights.empty()) Warning("No light sources defined in scene; rendering a black image.");
         }
     }
