@@ -393,3 +393,22 @@ TEX_NAMES = ["tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex
 # pinned for the oracle only so far (the device tests of these run from the round in which they were first measured on a GPU)
 TEX_ORACLE_ONLY = ["tex_dof", "envmap_png", "heightfield", "infinite_xf", "nurbs"]
 INSTANCE_NAMES = ["instances", "instances2"]   # object instancing: flattened by default, two-level with PBRT_AMD_INSTANCING=1 (oracle)
+
+
+# ---- the reference's analytic "furnace" scenes (src/tests/analytic_scenes.cpp:71-203, rendered there by :268-330 and checked by
+# CheckSceneAverage :55-68: mean of all channels 1.0 +- 0.02): the camera sits at the centre of a unit sphere seen from inside
+FURNACE_NAMES = ["furnace_point", "furnace_4points", "furnace_area", "furnace_uber"]
+
+
+def furnace_scene(name, sampler="sobol", integrator="path"):
+    world = {
+        "furnace_point": 'LightSource "point" "rgb I" [3.14159265 3.14159265 3.14159265]\nMaterial "matte" "rgb Kd" [.5 .5 .5] "float sigma" [0]\n',
+        "furnace_4points": 'LightSource "point" "rgb I" [.785398163 .785398163 .785398163]\n' * 4 + 'Material "matte" "rgb Kd" [.5 .5 .5] "float sigma" [0]\n',
+        "furnace_area": 'Material "matte" "rgb Kd" [.5 .5 .5] "float sigma" [0]\nAreaLightSource "diffuse" "rgb L" [.5 .5 .5]\n',
+        "furnace_uber": ('LightSource "point" "rgb I" [9.42477796 9.42477796 9.42477796]\n'
+                         'Material "uber" "rgb Kd" [.25 .25 .25] "rgb Ks" [0 0 0] "rgb Kr" [.5 .5 .5] "rgb Kt" [0 0 0] "float roughness" [0] '
+                         '"rgb opacity" [1 1 1] "float eta" [1] "bool remaproughness" "false"\n'),
+    }[name]
+    return ('Camera "perspective" "float fov" [45]\nSampler "%s" "integer pixelsamples" [256]\nPixelFilter "box"\n'
+            'Integrator "%s" "integer maxdepth" [8]\nFilm "image" "integer xresolution" [10] "integer yresolution" [10] "string filename" "f.pfm"\n'
+            'WorldBegin\n%sReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n' % (sampler, integrator, world))

@@ -619,6 +619,23 @@ def test_media_under_path_are_ignored():
     ctx.close()
 
 
+@pytest.mark.parametrize("name", edge_scenes.FURNACE_NAMES)
+def test_furnace_scenes(name):
+    """The reference's analytic scenes (src/tests/analytic_scenes.cpp:71-203, CheckSceneAverage :55-68) on the device: mean radiance inside the closed unit
+    sphere 1.0 +- 0.02 for Sobol' / Halton x path / volpath at 256 spp, depth 8; the Sobol' / path image also against the reference's own render (fixture)."""
+    for sampler in ("sobol", "halton"):
+        for integrator in ("path", "volpath"):
+            sc = pa.Scene(text=edge_scenes.furnace_scene(name, sampler, integrator))
+            ctx = pa.Context(sc)
+            ctx.render()
+            img = sc.film_image(ctx.film())
+            ctx.close()
+            assert abs(float(img.mean()) - 1.0) <= 0.02, (name, sampler, integrator, float(img.mean()))
+            if (sampler, integrator) == ("sobol", "path"):
+                frac, relmse = ol.image_metrics(img, pa.read_pfm(os.path.join(G, "%s.pfm" % name)))
+                assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
+
+
 def test_contexts_sharing_a_device_render_concurrently():
     """the texture / alpha / instance tables live in per-DEVICE __constant__ symbols that every pass rewrites.  Two contexts on
     one device, rendering different textured / instanced scenes from two host threads at once, take turns on them (TableTurn in run_pass):

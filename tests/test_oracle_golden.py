@@ -263,3 +263,18 @@ def test_bxdfs_match_reference_classes(vec):
         a, b = out[k], rows[k]
         same = (a.view(np.uint32) == b.view(np.uint32)) | (a == b)   # -0 == +0
         assert same.all(), (k, int((~same).sum()))
+
+
+@pytest.mark.parametrize("name", edge_scenes.FURNACE_NAMES)
+def test_oracle_furnace_scenes(name, built):
+    """The reference's analytic scenes (src/tests/analytic_scenes.cpp:71-203; CheckSceneAverage :55-68): inside a closed unit sphere the radiance is 1, so the
+    mean over all pixels and channels must be 1.0 +- 0.02 -- with the samplers (Sobol' / Halton, 256 spp) and integrators (path / volpath, depth 8) this path
+    carries.  The Sobol' / path render is also compared with the reference's own image of the same file (fixture): bit-exact."""
+    for sampler in ("sobol", "halton"):
+        for integrator in ("path", "volpath"):
+            sc = pa.Scene(text=edge_scenes.furnace_scene(name, sampler, integrator))
+            img = sc.film_image(ol.render(sc, nthreads=4)[0])
+            assert abs(float(img.mean()) - 1.0) <= 0.02, (name, sampler, integrator, float(img.mean()))
+            if (sampler, integrator) == ("sobol", "path"):
+                ref = pa.read_pfm(os.path.join(G, "%s.pfm" % name))
+                assert np.array_equal(img, ref), name

@@ -81,6 +81,11 @@ def edge_fixtures(tmp):
         out = os.path.join(OUT, "edge_%s.pfm" % name)
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
         print("rendered", out)
+    for name in edge_scenes.FURNACE_NAMES:   # the reference's analytic furnace scenes (src/tests/analytic_scenes.cpp), Sobol' 256, path depth 8
+        f = os.path.join(tmp, "e.pbrt"); open(f, "w").write(edge_scenes.furnace_scene(name))
+        out = os.path.join(OUT, "%s.pfm" % name)
+        subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
+        print("rendered", out)
 
 
 def scene_text(name, w, h, spp, strategy=None):
