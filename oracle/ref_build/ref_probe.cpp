@@ -20,6 +20,9 @@
 #include "sampling.h"
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
+#include "lights/diffuse.h"
+#include "lights/point.h"
+#include "lights/spot.h"
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
 #include "sobolmatrices.h"
@@ -381,6 +384,91 @@ int main(int argc, char **argv) {
             rec(1, v);
         }
         fclose(f);
+    }
+    // ---- Light::Sample_Li / Pdf_Li (core/light.h:63-75): DiffuseAreaLight over a Triangle and over a Sphere (Shape::Sample(ref, u) / Pdf(ref, wi),
+    // shapes/triangle.cpp:583-647, core/shape.cpp:57-108, shapes/sphere.cpp:325-400), PointLight, SpotLight; the shadow ray is
+    // VisibilityTester's SpawnRayTo (interaction.h:72-78 -> OffsetRayOrigin, geometry.h:1440-1460).  Geometry as in tests/shapes.cpp
+    // Triangle.Sampling (:210-269): random triangles in [-10, 10]^3, reference points outside that box -- plus nearby ones.
+    {
+        FILE *f = fopen((dir + "/light_samples.bin").c_str(), "wb");
+        RNG rng(29);
+        auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+        MediumInterface mi;
+        int count = 0;
+        for (int k = 0; k < 160; ++k) {
+            int kind = k % 4;   // 0 triangle area light, 1 sphere area light, 2 point, 3 spot
+            Float geom[12] = {0};
+            Float Lrgb[3] = {U(.2f, 8), U(.2f, 8), U(.2f, 8)};
+            int twoSided = (k / 4) % 2;
+            std::shared_ptr<Light> light;
+            static std::vector<std::unique_ptr<Transform>> keep;
+            if (kind == 0) {
+                Float range = (k % 8 < 4) ? 10.f : 1.f;
+                for (int i = 0; i < 9; ++i) geom[i] = U(-range, range);
+                keep.emplace_back(new Transform); Transform *id = keep.back().get();
+                int idx[3] = {0, 1, 2};
+                Point3f P[3] = {Point3f(geom[0], geom[1], geom[2]), Point3f(geom[3], geom[4], geom[5]), Point3f(geom[6], geom[7], geom[8])};
+                auto tris = CreateTriangleMesh(id, id, false, 1, idx, 3, P, nullptr, nullptr, nullptr, nullptr, nullptr);
+                light = std::make_shared<DiffuseAreaLight>(Transform(), mi, Spectrum::FromRGB(Lrgb), 1, tris[0], twoSided != 0);
+            } else if (kind == 1) {
+                geom[0] = U(-5, 5); geom[1] = U(-5, 5); geom[2] = U(-5, 5); geom[3] = U(.2f, 3);
+                keep.emplace_back(new Transform(Translate(Vector3f(geom[0], geom[1], geom[2])))); Transform *o2w = keep.back().get();
+                keep.emplace_back(new Transform(Inverse(*o2w))); Transform *w2o = keep.back().get();
+                auto sph = std::make_shared<Sphere>(o2w, w2o, false, geom[3], -geom[3], geom[3], 360.f);
+                light = std::make_shared<DiffuseAreaLight>(Transform(), mi, Spectrum::FromRGB(Lrgb), 1, sph, twoSided != 0);
+            } else {
+                for (int i = 0; i < 6; ++i) geom[i] = U(-6, 6);
+                ParamSet ps;
+                std::unique_ptr<Spectrum[]> I(new Spectrum[1]); I[0] = Spectrum::FromRGB(Lrgb);
+                ps.AddRGBSpectrum("I", std::unique_ptr<Float[]>(new Float[3]{Lrgb[0], Lrgb[1], Lrgb[2]}), 3);
+                std::unique_ptr<Point3f[]> from(new Point3f[1]); from[0] = Point3f(geom[0], geom[1], geom[2]);
+                ps.AddPoint3f("from", std::move(from), 1);
+                if (kind == 2) light = CreatePointLight(Transform(), nullptr, ps);
+                else {
+                    std::unique_ptr<Point3f[]> to(new Point3f[1]); to[0] = Point3f(geom[3], geom[4], geom[5]);
+                    ps.AddPoint3f("to", std::move(to), 1);
+                    geom[6] = U(10, 60); geom[7] = U(1, 9);
+                    ps.AddFloat("coneangle", std::unique_ptr<Float[]>(new Float[1]{geom[6]}), 1);
+                    ps.AddFloat("conedeltaangle", std::unique_ptr<Float[]>(new Float[1]{geom[7]}), 1);
+                    light = CreateSpotLight(Transform(), nullptr, ps);
+                }
+            }
+            for (int j = 0; j < 24; ++j) {
+                Point3f pc(U(-10, 10), U(-10, 10), U(-10, 10));
+                if (j % 3) pc[rng.UniformUInt32() % 3] = rng.UniformFloat() > .5f ? -13.f : 13.f;
+                Normal3f n(0, 0, 0);
+                if (j % 4) { Vector3f v = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())); n = Normal3f(v.x, v.y, v.z); }
+                Interaction ref(pc, n, Vector3f(), Vector3f(0, 0, 1), 0, mi);
+                Point2f u(rng.UniformFloat(), rng.UniformFloat());
+                Vector3f wi; Float pdf = 0; VisibilityTester vis;
+                Spectrum Li = light->Sample_Li(ref, u, &wi, &pdf, &vis);
+                bool ok = pdf > 0 && !Li.IsBlack();
+                Float rgb[3] = {0, 0, 0};
+                Ray sr;
+                if (pdf > 0) { Li.ToRGB(rgb); sr = vis.P0().SpawnRayTo(vis.P1()); }
+                // Pdf_Li for the sampled direction and for a direction next to it (mostly still hitting the shape)
+                Vector3f wi2 = pdf > 0 ? Normalize(wi + Vector3f(U(-.02f, .02f), U(-.02f, .02f), U(-.02f, .02f))) : Vector3f(0, 0, 1);
+                Float pdfA = pdf > 0 ? light->Pdf_Li(ref, wi) : 0, pdfB = light->Pdf_Li(ref, wi2);
+                putv<int32_t>(f, kind); putv<int32_t>(f, twoSided);
+                for (int i = 0; i < 12; ++i) putv<float>(f, geom[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, Lrgb[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pc[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, n[i]);
+                putv<float>(f, u[0]); putv<float>(f, u[1]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, wi[i]);
+                putv<float>(f, pdf);
+                for (int i = 0; i < 3; ++i) putv<float>(f, rgb[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pdf > 0 ? sr.o[i] : 0.f);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pdf > 0 ? sr.d[i] : 0.f);
+                putv<float>(f, pdf > 0 ? sr.tMax : 0.f);
+                for (int i = 0; i < 3; ++i) putv<float>(f, wi2[i]);
+                putv<float>(f, pdfA); putv<float>(f, pdfB);
+                putv<int32_t>(f, ok ? 1 : 0);
+                ++count;
+            }
+        }
+        fclose(f);
+        printf("ref_probe: %d light-sample records\n", count);
     }
     return 0;
 }

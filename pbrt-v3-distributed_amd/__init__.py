@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -275,6 +275,16 @@ class Context:
         self._chk(device_lib().mi_stream_read_gbps(self._ctx, C.c_uint64(nbytes), C.byref(v)), "mi_stream_read_gbps")
         return float(v.value)
 
+    def light_sample(self, queries):
+        """mi_light_sample: Light::Sample_Li / Pdf_Li of the uploaded scene's lights at explicit reference points (LIGHT_QUERY_DTYPE records)"""
+        q = np.ascontiguousarray(queries, dtype=LIGHT_QUERY_DTYPE)
+        out = np.zeros(len(q), dtype=LIGHT_RESULT_DTYPE)
+        L = device_lib()
+        L.mi_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        if L.mi_light_sample(self._ctx, _ptr(q), len(q), _ptr(out)) != 0:
+            raise RuntimeError("mi_light_sample: %s" % L.mi_last_error().decode())
+        return out
+
     def gather_rate(self, nbytes, loads_per_record=4):
         """rate of dependent random 64-byte record fetches (loads_per_record x 16 B per lane) over a buffer of nbytes, 1e9 lane requests / s"""
         v = C.c_double(0)
@@ -359,6 +369,10 @@ def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=Fa
         raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
     keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]
     return hits, dict(zip(keys, [int(v) for v in st]))
+
+
+LIGHT_QUERY_DTYPE = np.dtype([("light", "<i4"), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2), ("wi", "<f4", 3)])
+LIGHT_RESULT_DTYPE = np.dtype([("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("pdf_wi", "<f4"), ("delta", "<i4")])
 
 
 def bxdf_eval(rows, device=0):

@@ -2870,6 +2870,41 @@ int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, cons
     for (DevBuf *x : {&db, &dwo, &dwi, &du, &df, &dp, &dws, &dps, &dfs, &dts}) x->release();
     return 0;
 }
+// stage-level light sampling: Sample_Li / Pdf_Li of one light of the uploaded scene per record, the routines k_shade calls
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_light(DevScene sc, const mi_light_query *q, int64_t n, mi_light_result *out) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const mi_light_query &qi = q[i];
+    const DevLight *dl = sc.lights + qi.light;
+    V3 p(qi.p[0], qi.p[1], qi.p[2]), nr(qi.n[0], qi.n[1], qi.n[2]), zero(0.f, 0.f, 0.f), w(qi.wi[0], qi.wi[1], qi.wi[2]);
+    LightSample ls = SampleLiAny(GeomTables(sc), dl, p, zero, nr, qi.u[0], qi.u[1]);
+    mi_light_result r;
+    r.wi[0] = ls.wi.x; r.wi[1] = ls.wi.y; r.wi[2] = ls.wi.z;
+    r.pdf = ls.pdf;
+    r.Li[0] = ls.Li.r; r.Li[1] = ls.Li.g; r.Li[2] = ls.Li.b;
+    r.ray_o[0] = ls.shadow.o.x; r.ray_o[1] = ls.shadow.o.y; r.ray_o[2] = ls.shadow.o.z;
+    r.ray_d[0] = ls.shadow.d.x; r.ray_d[1] = ls.shadow.d.y; r.ray_d[2] = ls.shadow.d.z;
+    r.ray_tmax = ls.shadow.tMax;
+    r.delta = ls.delta ? 1 : 0;
+    r.pdf_wi = PdfLiAny(GeomTables(sc), dl, p, zero, nr, w);
+    out[i] = r;
+}
+int mi_light_sample(mi_ctx *c, const mi_light_query *queries, int64_t n, mi_light_result *out) {
+    if (!c || !queries || !out || n < 0) return fail("mi_light_sample: bad argument");
+    if (!c->haveScene) return fail("mi_light_sample: no scene uploaded");
+    for (int64_t i = 0; i < n; ++i)
+        if (queries[i].light < 0 || (uint32_t)queries[i].light >= c->sc.n_lights) return fail("mi_light_sample: light index out of range");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf dq, dr;
+    if (dq.alloc((size_t)n * sizeof(mi_light_query)) || dr.alloc((size_t)n * sizeof(mi_light_result))) return -1;
+    HIP_TRY(hipMemcpyAsync(dq.p, queries, (size_t)n * sizeof(mi_light_query), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_stage_light, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, c->stream, c->sc, dq.as<mi_light_query>(), n, dr.as<mi_light_result>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dr.p, (size_t)n * sizeof(mi_light_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
 // host check of the 64-byte quantised BVH4 (pt_bvh4q.h): quantisation in exact arithmetic + the kernel's per-ray state machine on the host
 int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
     if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh4q_validate: null argument");

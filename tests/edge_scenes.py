@@ -412,3 +412,25 @@ def furnace_scene(name, sampler="sobol", integrator="path"):
     return ('Camera "perspective" "float fov" [45]\nSampler "%s" "integer pixelsamples" [256]\nPixelFilter "box"\n'
             'Integrator "%s" "integer maxdepth" [8]\nFilm "image" "integer xresolution" [10] "integer yresolution" [10] "string filename" "f.pfm"\n'
             'WorldBegin\n%sReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n' % (sampler, integrator, world))
+
+
+# ---- light-sampling known-answer records (tests/golden/light_vectors.npz, from oracle/ref_build/ref_probe.cpp): one light per 24 records
+def light_kat_scene(recs):
+    """the scene whose light i is the light of records [24 i, 24 i + 24): triangle / sphere DiffuseAreaLights, point and spot lights"""
+    def fl(v):
+        return " ".join("%.9g" % x for x in v)
+    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nWorldBegin\n']
+    for i in range(0, len(recs), 24):
+        r = recs[i]
+        g, L = r["geom"], fl(r["L"])
+        two = '"bool twosided" "%s"' % ("true" if r["two_sided"] else "false")
+        if r["kind"] == 0:
+            out.append('AttributeBegin\nAreaLightSource "diffuse" "rgb L" [%s] %s\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [%s]\nAttributeEnd\n' % (L, two, fl(g[:9])))
+        elif r["kind"] == 1:
+            out.append('AttributeBegin\nTranslate %s\nAreaLightSource "diffuse" "rgb L" [%s] %s\nShape "sphere" "float radius" [%s]\nAttributeEnd\n' % (fl(g[:3]), L, two, fl(g[3:4])))
+        elif r["kind"] == 2:
+            out.append('LightSource "point" "rgb I" [%s] "point from" [%s]\n' % (L, fl(g[:3])))
+        else:
+            out.append('LightSource "spot" "rgb I" [%s] "point from" [%s] "point to" [%s] "float coneangle" [%s] "float conedeltaangle" [%s]\n' % (L, fl(g[:3]), fl(g[3:6]), fl(g[6:7]), fl(g[7:8])))
+    out.append("WorldEnd\n")
+    return "".join(out)

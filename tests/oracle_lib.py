@@ -170,6 +170,32 @@ def texture_eval(scene, node, queries):
     return out
 
 
+def light_sample(scene, queries):
+    """oracle_light_sample: Light::Sample_Li / Pdf_Li at explicit reference points (records of pa.LIGHT_QUERY_DTYPE)"""
+    q = np.ascontiguousarray(queries, dtype=pa.LIGHT_QUERY_DTYPE)
+    out = np.zeros(len(q), dtype=pa.LIGHT_RESULT_DTYPE)
+    L = lib()
+    L.oracle_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.oracle_light_sample.restype = None
+    L.oracle_light_sample(scene.desc, _p(q), len(q), _p(out))
+    return out
+
+
+def next_float_array(v, direction):
+    """NextFloatUp (direction > 0) / NextFloatDown of every element (core/pbrt.h:237-263 as the oracle restates them)"""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.zeros_like(v)
+    L = lib()
+    L.oracle_next_float.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.oracle_next_float.restype = None
+    L.oracle_next_float(_p(v), len(v), int(direction), _p(out))
+    return out
+
+
+def next_float(v, direction):
+    return next_float_array(np.array([v], dtype=np.float32), direction)[0]
+
+
 def sphere_intersect(spheres, rays):
     hits = np.zeros(len(rays), dtype=pa.SPHERE_HIT_DTYPE)
     lib().oracle_sphere_intersect(_p(spheres), _p(rays), len(rays), _p(hits))

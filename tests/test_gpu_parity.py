@@ -619,6 +619,44 @@ def test_media_under_path_are_ignored():
     ctx.close()
 
 
+def _ulp_distance(a, b):
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia); ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+def test_device_light_sampling_matches_reference_classes():
+    """mi_light_sample (the SampleLi / PdfLi routines k_shade and k_shade_vol call) against the reference's own Light classes: the 3 840 records of
+    tests/golden/light_vectors.npz (DiffuseAreaLight over triangles -- tests/shapes.cpp Triangle.Sampling geometry -- and spheres, point, spot;
+    surface and medium reference points).  Stated tolerance: <= 16 ulp (or 2e-6 (1 + |ref|) for components next to zero) on wi, pdf, Li and the shadow ray's origin (the sphere's cone sampling goes
+    through the device's own sin / cos), 1e-5 (1 + |d|) on the shadow ray's direction (a difference of two offset points), Pdf_Li <= 16 ulp where
+    both hit and identical hit / miss decisions otherwise."""
+    recs = np.load(os.path.join(G, "light_vectors.npz"))["light_samples"]
+    sc = pa.Scene(text=edge_scenes.light_kat_scene(recs))
+    q = np.zeros(len(recs), dtype=pa.LIGHT_QUERY_DTYPE)
+    q["light"] = np.arange(len(recs)) // 24
+    q["p"] = recs["p"]; q["n"] = recs["n"]; q["u"] = recs["u"]; q["wi"] = recs["wi2"]
+    ctx = pa.Context(sc)
+    o = ctx.light_sample(q)
+    ctx.close()
+    def close(a, b):   # <= 16 ulp, or (components next to zero) <= 2e-6 (1 + |ref|) absolute
+        return (_ulp_distance(a, b) <= 16) | (np.abs(a - b) <= 2e-6 * (1 + np.abs(b)))
+    for k in ("wi", "pdf", "Li", "ray_o"):
+        assert close(o[k], recs[k]).all(), (k, int(_ulp_distance(o[k], recs[k]).max()))
+    assert (np.abs(o["ray_d"] - recs["ray_d"]) <= 1e-5 * (1 + np.abs(recs["ray_d"]))).all()
+    assert o["ray_tmax"].tobytes() == recs["ray_tmax"].tobytes()
+    assert ((o["pdf_wi"] > 0) == (recs["pdf_b"] > 0)).mean() >= 0.999     # a grazing direction may flip between hit and miss
+    both = (o["pdf_wi"] > 0) & (recs["pdf_b"] > 0)
+    assert close(o["pdf_wi"][both], recs["pdf_b"][both]).all()
+    assert (o["delta"] == (recs["kind"] >= 2)).all()
+    # the triangle, point and spot records involve nothing beyond +, -, *, /, sqrt: expected bit-exact (>= 99 % required, as for the BxDF vectors)
+    ex = recs["kind"] != 1
+    same = sum(int((o[k][ex] == recs[k][ex]).sum()) for k in ("wi", "pdf", "Li", "ray_o", "ray_d"))
+    total = sum(o[k][ex].size for k in ("wi", "pdf", "Li", "ray_o", "ray_d"))
+    assert same / total >= 0.99, same / total
+
+
 @pytest.mark.parametrize("name", edge_scenes.FURNACE_NAMES)
 def test_furnace_scenes(name):
     """The reference's analytic scenes (src/tests/analytic_scenes.cpp:71-203, CheckSceneAverage :55-68) on the device: mean radiance inside the closed unit

@@ -278,3 +278,55 @@ def test_oracle_furnace_scenes(name, built):
             if (sampler, integrator) == ("sobol", "path"):
                 ref = pa.read_pfm(os.path.join(G, "%s.pfm" % name))
                 assert np.array_equal(img, ref), name
+
+
+def _light_queries(recs):
+    q = np.zeros(len(recs), dtype=pa.LIGHT_QUERY_DTYPE)
+    q["light"] = np.arange(len(recs)) // 24
+    q["p"] = recs["p"]; q["n"] = recs["n"]; q["u"] = recs["u"]; q["wi"] = recs["wi2"]
+    return q
+
+
+def test_light_sampling_matches_reference_classes(built):
+    """Light::Sample_Li / Pdf_Li against the reference's own classes (oracle/ref_build/ref_probe.cpp -> tests/golden/light_vectors.npz): 160 lights
+    (DiffuseAreaLight over random triangles -- the geometry of tests/shapes.cpp Triangle.Sampling :210-269 -- and over spheres, point and spot
+    lights) x 24 reference points (surface points with a normal and medium points without): wi, pdf, Li, the VisibilityTester's shadow ray
+    (SpawnRayTo -> OffsetRayOrigin -> NextFloatUp/Down, the arithmetic tests/fp_tests.cpp NextUpDownFloat :29-47 pins) and Pdf_Li of a second
+    direction -- bit for bit."""
+    recs = np.load(os.path.join(G, "light_vectors.npz"))["light_samples"]
+    assert len(recs) == 3840
+    sc = pa.Scene(text=edge_scenes.light_kat_scene(recs))
+    assert sc.info["n_lights"] == len(recs) // 24
+    o = ol.light_sample(sc, _light_queries(recs))
+    assert (recs["pdf"] > 0).all() and (recs["pdf_b"][recs["kind"] == 1] > 0).all() and (recs["pdf_b"][recs["kind"] == 0] > 0).mean() > .5
+    for k in ("wi", "pdf", "Li", "ray_o", "ray_d", "ray_tmax"):
+        assert o[k].tobytes() == recs[k].tobytes(), k
+    assert o["pdf_wi"].tobytes() == recs["pdf_b"].tobytes()
+    assert (o["delta"] == (recs["kind"] >= 2)).all()
+    # Triangle.Sampling's own property on the same records: 1 / pdf averaged over the light's samples estimates the solid angle of the
+    # triangle, which must agree with Pdf_Li's view of it (pdf of the sampled direction == Pdf_Li of that direction)
+    q2 = _light_queries(recs); q2["wi"] = recs["wi"]
+    o2 = ol.light_sample(sc, q2)
+    area = recs["kind"] < 2
+    assert o2["pdf_wi"][area].tobytes() == recs["pdf_a"][area].tobytes()
+    tri = recs["kind"] == 0
+    assert np.allclose(o2["pdf_wi"][tri], recs["pdf"][tri], rtol=2e-3)
+
+
+def test_next_float_up_down_known_answers(built):
+    """tests/fp_tests.cpp NextUpDownFloat :29-47 on the restated NextFloatUp / NextFloatDown (through OffsetRayOrigin: a reference point with
+    pError = 0 moves by exactly one ulp away from the surface in every component the offset touches -- geometry.h:1452-1459)."""
+    recs = np.load(os.path.join(G, "light_vectors.npz"))["light_samples"]
+    r = recs[(recs["kind"] == 2) & (np.abs(recs["n"]).sum(axis=1) > 0)]
+    # pError = 0 -> offset 0 -> po = p, then each component with offset == 0 is left alone: the origin must be p itself
+    assert r["ray_o"].tobytes() == r["p"].tobytes()
+    for v, up, down in [(np.float32(1.0), np.float32(1.0000001), np.float32(0.99999994)), (np.float32(-0.0), np.float32(1e-45), np.float32(-1e-45)),
+                        (np.float32(np.inf), np.float32(np.inf), np.float32(3.4028235e38)), (np.float32(-np.inf), np.float32(-3.4028235e38), np.float32(-np.inf))]:
+        assert np.nextafter(v, np.float32(np.inf)) == up or v == np.inf
+        assert ol.next_float(v, +1) == up and ol.next_float(v, -1) == down
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2**32, 100000, dtype=np.uint64).astype(np.uint32)
+    f = bits.view(np.float32)
+    f = f[np.isfinite(f)]
+    upv, dnv = ol.next_float_array(f, +1), ol.next_float_array(f, -1)
+    assert np.array_equal(upv, np.nextafter(f, np.float32(np.inf))) and np.array_equal(dnv, np.nextafter(f, np.float32(-np.inf)))

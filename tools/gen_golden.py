@@ -15,6 +15,9 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+LIGHT_SAMPLES = np.dtype([("kind", "<i4"), ("two_sided", "<i4"), ("geom", "<f4", 12), ("L", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2),
+                          ("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"),
+                          ("wi2", "<f4", 3), ("pdf_a", "<f4"), ("pdf_b", "<f4"), ("ok", "<i4")])
 SPECTRA = np.dtype([("kind", "<i4"), ("n", "<i4"), ("vals", "<f4", 80), ("rgb", "<f4", 3)])
 
 
@@ -23,7 +26,8 @@ def main():
     tmp = tempfile.mkdtemp()
     subprocess.check_call([os.path.join(REF, "ref_probe"), tmp])
     np.savez_compressed(os.path.join(OUT, "spectra_vectors.npz"), spectra=np.fromfile(os.path.join(tmp, "spectra.bin"), dtype=SPECTRA))
-    if "--only-spectra" in sys.argv:
+    np.savez_compressed(os.path.join(OUT, "light_vectors.npz"), light_samples=np.fromfile(os.path.join(tmp, "light_samples.bin"), dtype=LIGHT_SAMPLES))
+    if "--only-spectra" in sys.argv or "--only-kat" in sys.argv:
         return
     ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
     si = np.fromfile(os.path.join(tmp, "sobol_index.bin"), dtype=np.dtype([("m", "<u4"), ("frame", "<u8"), ("px", "<i4"), ("py", "<i4"), ("idx", "<u8")]))
