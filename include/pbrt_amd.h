@@ -480,9 +480,10 @@ int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, cons
 /* Stage-level light sampling: Light::Sample_Li(ref, u) and Light::Pdf_Li(ref, wi) (core/light.h:63-75) of light `light` of the uploaded scene
  * at a reference point (p, n with pError = 0; n = 0: a point in a medium) -- DiffuseAreaLight over a Triangle / a Sphere (Shape::Sample(ref, u),
  * Shape::Pdf(ref, wi): shapes/triangle.cpp:583-647, core/shape.cpp:57-108, shapes/sphere.cpp:325-400), point, spot, distant and infinite lights.
- * ray_*: the shadow ray of the VisibilityTester (Interaction::SpawnRayTo, interaction.h:72-78).  pdf_wi = Pdf_Li(ref, query.wi). */
+ * ray_*: the shadow ray of the VisibilityTester (Interaction::SpawnRayTo, interaction.h:72-78).  pdf_wi = Pdf_Li(ref, query.wi);
+ * le_wi = Light::Le of a ray leaving along query.wi (what an escaped ray collects, path.cpp:97-98): infinite lights, 0 for the others. */
 typedef struct mi_light_query { int32_t light; float p[3], n[3], u[2], wi[3]; } mi_light_query;
-typedef struct mi_light_result { float wi[3], pdf, Li[3], ray_o[3], ray_d[3], ray_tmax, pdf_wi; int32_t delta; } mi_light_result;
+typedef struct mi_light_result { float wi[3], pdf, Li[3], ray_o[3], ray_d[3], ray_tmax, pdf_wi; int32_t delta; float le_wi[3]; } mi_light_result;
 int mi_light_sample(mi_ctx *ctx, const mi_light_query *queries, int64_t n, mi_light_result *out);
 /* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
  * 3 lean steps over the 80-byte compressed BVH8, 4 two-level (instanced) scene, 5 general steps over the 64-byte quantised BVH4;

@@ -20,7 +20,12 @@
 #include "sampling.h"
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
+#include "accelerators/bvh.h"
+#include "api.h"
 #include "lights/diffuse.h"
+#include "lights/distant.h"
+#include "lights/infinite.h"
+#include "scene.h"
 #include "lights/point.h"
 #include "lights/spot.h"
 #include "shapes/sphere.h"
@@ -57,7 +62,7 @@ static void triRecord(FILE *f, const std::shared_ptr<Shape> &tri, const Point3f 
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: ref_probe <outdir>\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_probe <outdir> [radiance map for the infinite-light records]\n"); return 1; }
     std::string dir = argv[1];
     // ---- Sobol: SobolSampleFloat(i, d) and SobolIntervalToIndex
     {
@@ -469,6 +474,78 @@ int main(int argc, char **argv) {
         }
         fclose(f);
         printf("ref_probe: %d light-sample records\n", count);
+    }
+    // ---- the lights that depend on the scene (Light::Preprocess: world bound): DistantLight and InfiniteAreaLight -- constant, and with a
+    // radiance map (argv[2]: MIPMap::Lookup + Distribution2D, lights/infinite.cpp:43-137) under a rotation.  The scene is one triangle.
+    if (argc > 2) {
+        PbrtOptions.nThreads = 1;   // the InfiniteAreaLight constructor runs a ParallelFor
+        FILE *f = fopen((dir + "/light_samples_scene.bin").c_str(), "wb");
+        RNG rng(31);
+        auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+        static Transform id;
+        int idx[3] = {0, 1, 2};
+        Point3f P[3] = {Point3f(0, 0, 0), Point3f(1, 0, 0), Point3f(0, 1, 0)};
+        auto tris = CreateTriangleMesh(&id, &id, false, 1, idx, 3, P, nullptr, nullptr, nullptr, nullptr, nullptr);
+        std::vector<std::shared_ptr<Primitive>> prims;
+        MediumInterface mi;
+        prims.push_back(std::make_shared<GeometricPrimitive>(tris[0], nullptr, nullptr, mi));
+        std::vector<std::shared_ptr<Light>> lights;
+        std::vector<std::vector<Float>> desc;   // per light: kind, params
+        for (int k = 0; k < 12; ++k) {
+            Float Lrgb[3] = {U(.2f, 4), U(.2f, 4), U(.2f, 4)};
+            ParamSet ps;
+            ps.AddRGBSpectrum("L", std::unique_ptr<Float[]>(new Float[3]{Lrgb[0], Lrgb[1], Lrgb[2]}), 3);
+            if (k < 6) {   // distant: from / to
+                Float g[6]; for (int i = 0; i < 6; ++i) g[i] = U(-4, 4);
+                std::unique_ptr<Point3f[]> from(new Point3f[1]), to(new Point3f[1]);
+                from[0] = Point3f(g[0], g[1], g[2]); to[0] = Point3f(g[3], g[4], g[5]);
+                ps.AddPoint3f("from", std::move(from), 1); ps.AddPoint3f("to", std::move(to), 1);
+                lights.push_back(CreateDistantLight(Transform(), ps));
+                desc.push_back({4, g[0], g[1], g[2], g[3], g[4], g[5], Lrgb[0], Lrgb[1], Lrgb[2]});
+            } else {       // infinite: Rotate a1 about x, then a2 about z; k >= 9: with the radiance map
+                Float a1 = U(-120, 120), a2 = U(-180, 180);
+                if (k >= 9) { std::unique_ptr<std::string[]> m(new std::string[1]); m[0] = argv[2]; ps.AddString("mapname", std::move(m), 1); }
+                lights.push_back(CreateInfiniteLight(Rotate(a1, Vector3f(1, 0, 0)) * Rotate(a2, Vector3f(0, 0, 1)), ps));
+                desc.push_back({Float(k >= 9 ? 6 : 5), a1, a2, 0, 0, 0, 0, Lrgb[0], Lrgb[1], Lrgb[2]});
+            }
+        }
+        Scene scene(std::make_shared<BVHAccel>(prims), lights);
+        int count = 0;
+        for (size_t k = 0; k < lights.size(); ++k)
+            for (int j = 0; j < 64; ++j) {
+                Point3f pc(U(-3, 3), U(-3, 3), U(-3, 3));
+                Normal3f n(0, 0, 0);
+                if (j % 4) { Vector3f v = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())); n = Normal3f(v.x, v.y, v.z); }
+                Interaction ref(pc, n, Vector3f(), Vector3f(0, 0, 1), 0, mi);
+                Point2f u(rng.UniformFloat(), rng.UniformFloat());
+                Vector3f wi; Float pdf = 0; VisibilityTester vis;
+                Spectrum Li = lights[k]->Sample_Li(ref, u, &wi, &pdf, &vis);
+                Float rgb[3] = {0, 0, 0};
+                Ray sr;
+                if (pdf > 0) { Li.ToRGB(rgb); sr = vis.P0().SpawnRayTo(vis.P1()); }
+                Vector3f wi2 = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat()));
+                Float pdfB = lights[k]->Pdf_Li(ref, wi2);
+                // Le of the escaped ray along wi2 (infinite lights; 0 otherwise): path.cpp:97-98
+                Float le[3] = {0, 0, 0};
+                RayDifferential esc(pc, wi2);
+                lights[k]->Le(esc).ToRGB(le);
+                for (Float v : desc[k]) putv<float>(f, v);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pc[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, n[i]);
+                putv<float>(f, u[0]); putv<float>(f, u[1]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, wi[i]);
+                putv<float>(f, pdf);
+                for (int i = 0; i < 3; ++i) putv<float>(f, rgb[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pdf > 0 ? sr.o[i] : 0.f);
+                for (int i = 0; i < 3; ++i) putv<float>(f, pdf > 0 ? sr.d[i] : 0.f);
+                putv<float>(f, pdf > 0 ? sr.tMax : 0.f);
+                for (int i = 0; i < 3; ++i) putv<float>(f, wi2[i]);
+                putv<float>(f, pdfB);
+                for (int i = 0; i < 3; ++i) putv<float>(f, le[i]);
+                ++count;
+            }
+        fclose(f);
+        printf("ref_probe: %d scene-light records\n", count);
     }
     return 0;
 }

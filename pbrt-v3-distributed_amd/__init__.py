@@ -372,7 +372,7 @@ def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=Fa
 
 
 LIGHT_QUERY_DTYPE = np.dtype([("light", "<i4"), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2), ("wi", "<f4", 3)])
-LIGHT_RESULT_DTYPE = np.dtype([("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("pdf_wi", "<f4"), ("delta", "<i4")])
+LIGHT_RESULT_DTYPE = np.dtype([("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("pdf_wi", "<f4"), ("delta", "<i4"), ("le_wi", "<f4", 3)])
 
 
 def bxdf_eval(rows, device=0):

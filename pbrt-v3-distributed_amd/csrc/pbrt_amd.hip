@@ -2887,6 +2887,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_light(DevScene sc, const mi_
     r.ray_tmax = ls.shadow.tMax;
     r.delta = ls.delta ? 1 : 0;
     r.pdf_wi = PdfLiAny(GeomTables(sc), dl, p, zero, nr, w);
+    RGB le = dl->type == MI_LIGHT_INFINITE ? InfiniteLe(dl, w) : RGB(0.f);
+    r.le_wi[0] = le.r; r.le_wi[1] = le.g; r.le_wi[2] = le.b;
     out[i] = r;
 }
 int mi_light_sample(mi_ctx *c, const mi_light_query *queries, int64_t n, mi_light_result *out) {

@@ -434,3 +434,23 @@ def light_kat_scene(recs):
             out.append('LightSource "spot" "rgb I" [%s] "point from" [%s] "point to" [%s] "float coneangle" [%s] "float conedeltaangle" [%s]\n' % (L, fl(g[:3]), fl(g[3:6]), fl(g[6:7]), fl(g[7:8])))
     out.append("WorldEnd\n")
     return "".join(out)
+
+
+def scene_light_kat_scene(recs):
+    """the one-triangle scene whose light i is the light of records [64 i, 64 i + 64) of light_vectors.npz 'scene_lights': distant lights, constant
+    infinite lights and infinite lights with the radiance map scenes/envmap_40x20.pfm under Rotate a1 (x) . Rotate a2 (z)"""
+    import numpy as np
+
+    def fl(v):
+        return " ".join("%.9g" % x for x in np.atleast_1d(v))
+    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nWorldBegin\n']
+    for i in range(0, len(recs), 64):
+        r = recs[i]
+        g, L, kind = r["geom"], fl(r["L"]), int(r["kind"])
+        if kind == 4:
+            out.append('LightSource "distant" "rgb L" [%s] "point from" [%s] "point to" [%s]\n' % (L, fl(g[:3]), fl(g[3:6])))
+        else:
+            m = ' "string mapname" "%s"' % os.path.join(ROOT, "scenes", "envmap_40x20.pfm") if kind == 6 else ""
+            out.append('AttributeBegin\nRotate %s 1 0 0\nRotate %s 0 0 1\nLightSource "infinite" "rgb L" [%s]%s\nAttributeEnd\n' % (fl(g[0]), fl(g[1]), L, m))
+    out.append('Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
+    return "".join(out)

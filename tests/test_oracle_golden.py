@@ -330,3 +330,21 @@ def test_next_float_up_down_known_answers(built):
     f = f[np.isfinite(f)]
     upv, dnv = ol.next_float_array(f, +1), ol.next_float_array(f, -1)
     assert np.array_equal(upv, np.nextafter(f, np.float32(np.inf))) and np.array_equal(dnv, np.nextafter(f, np.float32(-np.inf)))
+
+
+def test_scene_dependent_lights_match_reference_classes(built):
+    """DistantLight and InfiniteAreaLight (constant -- the reference's 1 x 1 map -- and with a radiance map: MIPMap::Lookup + Distribution2D,
+    lights/infinite.cpp:43-137), which need Light::Preprocess's world bound: Sample_Li (wi, pdf, Li, shadow ray to the scene's bounding
+    sphere), Pdf_Li and Le of an escaped ray, 12 lights x 64 reference points from the reference's own classes -- bit for bit."""
+    recs = np.load(os.path.join(G, "light_vectors.npz"))["scene_lights"]
+    assert len(recs) == 768
+    sc = pa.Scene(text=edge_scenes.scene_light_kat_scene(recs))
+    assert sc.info["n_lights"] == 12
+    q = np.zeros(len(recs), dtype=pa.LIGHT_QUERY_DTYPE)
+    q["light"] = np.arange(len(recs)) // 64
+    q["p"] = recs["p"]; q["n"] = recs["n"]; q["u"] = recs["u"]; q["wi"] = recs["wi2"]
+    o = ol.light_sample(sc, q)
+    assert (recs["pdf"] > 0).all() and (recs["pdf_b"][recs["kind"] >= 5] > 0).all() and (recs["le"][recs["kind"] >= 5] > 0).all()
+    for k in ("wi", "pdf", "Li", "ray_o", "ray_d", "ray_tmax"):
+        assert o[k].tobytes() == recs[k].tobytes(), k
+    assert o["pdf_wi"].tobytes() == recs["pdf_b"].tobytes() and o["le_wi"].tobytes() == recs["le"].tobytes()

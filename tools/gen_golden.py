@@ -18,15 +18,18 @@ OUT = os.path.join(ROOT, "tests", "golden")
 LIGHT_SAMPLES = np.dtype([("kind", "<i4"), ("two_sided", "<i4"), ("geom", "<f4", 12), ("L", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2),
                           ("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"),
                           ("wi2", "<f4", 3), ("pdf_a", "<f4"), ("pdf_b", "<f4"), ("ok", "<i4")])
+SCENE_LIGHTS = np.dtype([("kind", "<f4"), ("geom", "<f4", 6), ("L", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2), ("wi", "<f4", 3), ("pdf", "<f4"),
+                         ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("wi2", "<f4", 3), ("pdf_b", "<f4"), ("le", "<f4", 3)])
 SPECTRA = np.dtype([("kind", "<i4"), ("n", "<i4"), ("vals", "<f4", 80), ("rgb", "<f4", 3)])
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
-    subprocess.check_call([os.path.join(REF, "ref_probe"), tmp])
+    subprocess.check_call([os.path.join(REF, "ref_probe"), tmp, os.path.join(ROOT, "scenes", "envmap_40x20.pfm")])
     np.savez_compressed(os.path.join(OUT, "spectra_vectors.npz"), spectra=np.fromfile(os.path.join(tmp, "spectra.bin"), dtype=SPECTRA))
-    np.savez_compressed(os.path.join(OUT, "light_vectors.npz"), light_samples=np.fromfile(os.path.join(tmp, "light_samples.bin"), dtype=LIGHT_SAMPLES))
+    np.savez_compressed(os.path.join(OUT, "light_vectors.npz"), light_samples=np.fromfile(os.path.join(tmp, "light_samples.bin"), dtype=LIGHT_SAMPLES),
+                        scene_lights=np.fromfile(os.path.join(tmp, "light_samples_scene.bin"), dtype=SCENE_LIGHTS))
     if "--only-spectra" in sys.argv or "--only-kat" in sys.argv:
         return
     ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
