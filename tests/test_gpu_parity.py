@@ -700,7 +700,7 @@ def test_furnace_scenes(name):
 def test_contexts_sharing_a_device_render_concurrently():
     """the texture / alpha / instance tables live in per-DEVICE __constant__ symbols that every pass rewrites.  Two contexts on
     one device, rendering different textured / instanced scenes from two host threads at once, take turns on them (TableTurn in run_pass):
-    each image must equal the one the same context renders alone, bit for bit."""
+    each image must equal the one the same context renders alone (bit for bit wherever the film sum has a fixed order)."""
     import threading
     names = ["tex_materials", "tex_alpha", "instances2"]
     scenes = [pa.Scene(text=edge_scenes.scene(n)) for n in names]
@@ -722,8 +722,13 @@ def test_contexts_sharing_a_device_render_concurrently():
     assert not errs, errs
     for i, n in enumerate(names):
         assert alone[i].any()
+        # pixels that only received their own samples agree bit for bit between two renders; one that also got a neighbour's sample landing
+        # exactly on its edge is summed through float atomics in no fixed order (see test_tile_sharding_is_exact)
+        own_only = alone[i][..., 3] == scenes[i].info["spp"]
+        assert own_only.mean() > 0.9
         for g in got[i]:
-            assert g.tobytes() == alone[i].tobytes(), n
+            assert np.array_equal(g[own_only].view(np.uint32), alone[i][own_only].view(np.uint32)), n
+            assert np.allclose(g, alone[i], rtol=1e-6, atol=1e-7), n
     for c in ctxs: c.close()
 
 
