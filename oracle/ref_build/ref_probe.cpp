@@ -21,6 +21,9 @@
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
 #include "accelerators/bvh.h"
+#include "cameras/perspective.h"
+#include "film.h"
+#include "filters/box.h"
 #include "api.h"
 #include "lights/diffuse.h"
 #include "lights/distant.h"
@@ -474,6 +477,72 @@ int main(int argc, char **argv) {
         }
         fclose(f);
         printf("ref_probe: %d light-sample records\n", count);
+    }
+    // ---- Sampler::GetCameraSample + PerspectiveCamera::GenerateRayDifferential (core/sampler.cpp:46-52, cameras/perspective.cpp:95-144) for a few
+    // camera configurations (pinhole and thin lens, non-square films, a crop window, a frame aspect ratio): pFilm, the main ray and its weight
+    {
+        FILE *f = fopen((dir + "/camera_rays.bin").c_str(), "wb");
+        struct Cfg { Float eye[3], look[3], up[3], fov, lensr, focald, aspect; int xres, yres; Float crop[4]; int spp; };
+        const Cfg cfgs[] = {
+            {{0, 2.2f, -6}, {0, .8f, 0}, {0, 1, 0}, 40, 0, 1e6f, 0, 72, 48, {0, 1, 0, 1}, 4},
+            {{3, 1.5f, 4}, {-.5f, .2f, 0}, {0, 1, 0}, 28.5f, .12f, 5.5f, 0, 96, 96, {0, 1, 0, 1}, 8},
+            {{-2, 4, 1}, {0, 0, 0}, {0, 0, 1}, 65, .03f, 4.2f, 0, 50, 120, {.2f, .75f, .1f, .9f}, 2},
+            {{0, 0, 5}, {0, 0, 0}, {.1f, 1, 0}, 90, 0, 1e6f, 2.2f, 160, 40, {0, 1, 0, 1}, 16},
+        };
+        int count = 0, ci = 0;
+        for (const Cfg &c : cfgs) {
+            ParamSet fp;
+            fp.AddInt("xresolution", std::unique_ptr<int[]>(new int[1]{c.xres}), 1);
+            fp.AddInt("yresolution", std::unique_ptr<int[]>(new int[1]{c.yres}), 1);
+            fp.AddFloat("cropwindow", std::unique_ptr<Float[]>(new Float[4]{c.crop[0], c.crop[1], c.crop[2], c.crop[3]}), 4);
+            std::unique_ptr<std::string[]> fn(new std::string[1]); fn[0] = "x.pfm";
+            fp.AddString("filename", std::move(fn), 1);
+            ParamSet bp;
+            Film *film = CreateFilm(fp, std::unique_ptr<Filter>(CreateBoxFilter(bp)));
+            ParamSet cp;
+            cp.AddFloat("fov", std::unique_ptr<Float[]>(new Float[1]{c.fov}), 1);
+            cp.AddFloat("lensradius", std::unique_ptr<Float[]>(new Float[1]{c.lensr}), 1);
+            cp.AddFloat("focaldistance", std::unique_ptr<Float[]>(new Float[1]{c.focald}), 1);
+            if (c.aspect > 0) cp.AddFloat("frameaspectratio", std::unique_ptr<Float[]>(new Float[1]{c.aspect}), 1);
+            // pbrtCamera: CameraToWorld = Inverse(CTM), CTM = LookAt(...) (api.cpp:806-816)
+            Transform *c2w = new Transform(Inverse(LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]))));
+            AnimatedTransform anim(c2w, 0, c2w, 1);
+            PerspectiveCamera *cam = CreatePerspectiveCamera(cp, anim, film, nullptr);
+            ParamSet sp;
+            sp.AddInt("pixelsamples", std::unique_ptr<int[]>(new int[1]{c.spp}), 1);
+            std::unique_ptr<Sampler> sampler(CreateSobolSampler(sp, film->GetSampleBounds()));
+            Bounds2i sb = film->GetSampleBounds();
+            RNG rng(41 + ci);
+            for (int k = 0; k < 400; ++k) {
+                Point2i px(sb.pMin.x + (int)(rng.UniformUInt32() % (uint32_t)(sb.pMax.x - sb.pMin.x)), sb.pMin.y + (int)(rng.UniformUInt32() % (uint32_t)(sb.pMax.y - sb.pMin.y)));
+                int sn = (int)(rng.UniformUInt32() % (uint32_t)sampler->samplesPerPixel);
+                sampler->StartPixel(px);
+                sampler->SetSampleNumber(sn);
+                CameraSample cs = sampler->GetCameraSample(px);
+                RayDifferential ray;
+                Float w = cam->GenerateRayDifferential(cs, &ray);
+                putv<int32_t>(f, ci); putv<int32_t>(f, px.x); putv<int32_t>(f, px.y); putv<int32_t>(f, sn);
+                for (int i = 0; i < 3; ++i) putv<float>(f, c.eye[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, c.look[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, c.up[i]);
+                putv<float>(f, c.fov); putv<float>(f, c.lensr); putv<float>(f, c.focald); putv<float>(f, c.aspect);
+                putv<int32_t>(f, c.xres); putv<int32_t>(f, c.yres);
+                for (int i = 0; i < 4; ++i) putv<float>(f, c.crop[i]);
+                putv<int32_t>(f, c.spp);
+                putv<float>(f, cs.pFilm.x); putv<float>(f, cs.pFilm.y); putv<float>(f, cs.pLens.x); putv<float>(f, cs.pLens.y); putv<float>(f, cs.time);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.o[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.d[i]);
+                putv<float>(f, w);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.rxOrigin[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.rxDirection[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.ryOrigin[i]);
+                for (int i = 0; i < 3; ++i) putv<float>(f, ray.ryDirection[i]);
+                ++count;
+            }
+            ++ci;
+        }
+        fclose(f);
+        printf("ref_probe: %d camera-ray records\n", count);
     }
     // ---- the lights that depend on the scene (Light::Preprocess: world bound): DistantLight and InfiniteAreaLight -- constant, and with a
     // radiance map (argv[2]: MIPMap::Lookup + Distribution2D, lights/infinite.cpp:43-137) under a rotation.  The scene is one triangle.

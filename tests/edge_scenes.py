@@ -454,3 +454,18 @@ def scene_light_kat_scene(recs):
             out.append('AttributeBegin\nRotate %s 1 0 0\nRotate %s 0 0 1\nLightSource "infinite" "rgb L" [%s]%s\nAttributeEnd\n' % (fl(g[0]), fl(g[1]), L, m))
     out.append('Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
     return "".join(out)
+
+
+def camera_kat_scene(r):
+    """the scene of one camera configuration of tests/golden/camera_vectors.npz (record r): LookAt, perspective camera (pinhole / thin lens, optional
+    frame aspect ratio), film resolution + crop window, Sobol' sampler"""
+    import numpy as np
+
+    def fl(v):
+        return " ".join("%.9g" % x for x in np.atleast_1d(v))
+    asp = ' "float frameaspectratio" [%s]' % fl(r["aspect"]) if r["aspect"] > 0 else ""
+    return ('LookAt %s %s %s\nCamera "perspective" "float fov" [%s] "float lensradius" [%s] "float focaldistance" [%s]%s\n'
+            'Sampler "sobol" "integer pixelsamples" [%d]\nPixelFilter "box"\n'
+            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "float cropwindow" [%s] "string filename" "c.pfm"\n'
+            'WorldBegin\nLightSource "point" "rgb I" [1 1 1]\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n'
+            % (fl(r["eye"]), fl(r["look"]), fl(r["up"]), fl(r["fov"]), fl(r["lensr"]), fl(r["focald"]), asp, r["spp"], r["xres"], r["yres"], fl(r["crop"])))

@@ -348,3 +348,17 @@ def test_scene_dependent_lights_match_reference_classes(built):
     for k in ("wi", "pdf", "Li", "ray_o", "ray_d", "ray_tmax"):
         assert o[k].tobytes() == recs[k].tobytes(), k
     assert o["pdf_wi"].tobytes() == recs["pdf_b"].tobytes() and o["le_wi"].tobytes() == recs["le"].tobytes()
+
+
+def test_camera_rays_match_reference_classes(built):
+    """Sampler::GetCameraSample + PerspectiveCamera::GenerateRayDifferential (core/sampler.cpp:46-52, cameras/perspective.cpp:95-144) against the
+    reference's own SobolSampler + PerspectiveCamera objects (ref_probe -> tests/golden/camera_vectors.npz): pinhole and thin-lens cameras, a
+    non-square film, a crop window, a frame aspect ratio; 400 (pixel, sample) pairs each -- pFilm and the main ray bit for bit, weight 1."""
+    recs = np.load(os.path.join(G, "camera_vectors.npz"))["camera_rays"]
+    assert len(recs) == 1600 and (recs["weight"] == 1).all()
+    for c in range(4):
+        r = recs[recs["cfg"] == c]
+        sc = pa.Scene(text=edge_scenes.camera_kat_scene(r[0]))
+        rays, pf = ol.camera_rays(sc, np.stack([r["px"], r["py"]], 1).astype(np.int32), r["s"])
+        assert pf.tobytes() == r["p_film"].tobytes(), c
+        assert np.ascontiguousarray(rays["o"]).tobytes() == r["o"].tobytes() and np.ascontiguousarray(rays["d"]).tobytes() == r["d"].tobytes(), c

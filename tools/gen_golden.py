@@ -20,6 +20,10 @@ LIGHT_SAMPLES = np.dtype([("kind", "<i4"), ("two_sided", "<i4"), ("geom", "<f4",
                           ("wi2", "<f4", 3), ("pdf_a", "<f4"), ("pdf_b", "<f4"), ("ok", "<i4")])
 SCENE_LIGHTS = np.dtype([("kind", "<f4"), ("geom", "<f4", 6), ("L", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2), ("wi", "<f4", 3), ("pdf", "<f4"),
                          ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("wi2", "<f4", 3), ("pdf_b", "<f4"), ("le", "<f4", 3)])
+CAMERA_RAYS = np.dtype([("cfg", "<i4"), ("px", "<i4"), ("py", "<i4"), ("s", "<i4"), ("eye", "<f4", 3), ("look", "<f4", 3), ("up", "<f4", 3), ("fov", "<f4"), ("lensr", "<f4"),
+                        ("focald", "<f4"), ("aspect", "<f4"), ("xres", "<i4"), ("yres", "<i4"), ("crop", "<f4", 4), ("spp", "<i4"),
+                        ("p_film", "<f4", 2), ("p_lens", "<f4", 2), ("time", "<f4"), ("o", "<f4", 3), ("d", "<f4", 3), ("weight", "<f4"),
+                        ("rx_o", "<f4", 3), ("rx_d", "<f4", 3), ("ry_o", "<f4", 3), ("ry_d", "<f4", 3)])
 SPECTRA = np.dtype([("kind", "<i4"), ("n", "<i4"), ("vals", "<f4", 80), ("rgb", "<f4", 3)])
 
 
@@ -30,6 +34,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "spectra_vectors.npz"), spectra=np.fromfile(os.path.join(tmp, "spectra.bin"), dtype=SPECTRA))
     np.savez_compressed(os.path.join(OUT, "light_vectors.npz"), light_samples=np.fromfile(os.path.join(tmp, "light_samples.bin"), dtype=LIGHT_SAMPLES),
                         scene_lights=np.fromfile(os.path.join(tmp, "light_samples_scene.bin"), dtype=SCENE_LIGHTS))
+    np.savez_compressed(os.path.join(OUT, "camera_vectors.npz"), camera_rays=np.fromfile(os.path.join(tmp, "camera_rays.bin"), dtype=CAMERA_RAYS))
     if "--only-spectra" in sys.argv or "--only-kat" in sys.argv:
         return
     ss = np.fromfile(os.path.join(tmp, "sobol_samples.bin"), dtype=np.dtype([("i", "<i8"), ("d", "<i4"), ("v", "<f4")]))
