@@ -419,7 +419,7 @@ def light_kat_scene(recs):
     """the scene whose light i is the light of records [24 i, 24 i + 24): triangle / sphere DiffuseAreaLights, point and spot lights"""
     def fl(v):
         return " ".join("%.9g" % x for x in v)
-    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nWorldBegin\n']
+    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nIntegrator "path" "string lightsamplestrategy" "uniform"\nWorldBegin\n']
     for i in range(0, len(recs), 24):
         r = recs[i]
         g, L = r["geom"], fl(r["L"])
@@ -443,7 +443,7 @@ def scene_light_kat_scene(recs):
 
     def fl(v):
         return " ".join("%.9g" % x for x in np.atleast_1d(v))
-    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nWorldBegin\n']
+    out = ['Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "l.pfm"\nSampler "sobol" "integer pixelsamples" [1]\nIntegrator "path" "string lightsamplestrategy" "uniform"\nWorldBegin\n']
     for i in range(0, len(recs), 64):
         r = recs[i]
         g, L, kind = r["geom"], fl(r["L"]), int(r["kind"])
