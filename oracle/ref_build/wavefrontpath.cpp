@@ -123,6 +123,9 @@ struct Flat {
     // row f2 / f4: texture nodes, image pyramids, per-material parameter nodes, alpha masks, BSSRDF tables -- only filled when the scene needs them
     std::vector<mi_texture> textures;
     std::vector<mi_image> images;
+    // the reference's Texture objects behind the nodes (PBRT_AMD_TEX_PROBE: Texture::Evaluate of the object against the backend's evaluation of the node)
+    std::vector<std::pair<const Texture<Float> *, int>> probeFloat;
+    std::vector<std::pair<const Texture<Spectrum> *, int>> probeSpectrum;
     std::vector<std::vector<float>> imageKeep;
     std::vector<mi_material_desc> descs;
     std::vector<int32_t> meshAlpha;
@@ -266,10 +269,17 @@ struct TexWalker {
     static void pushTexel(std::vector<float> &v, Float x) { v.push_back(x); }
     static void pushTexel(std::vector<float> &v, const RGBSpectrum &x) { Float c[3]; x.ToRGB(c); v.push_back(c[0]); v.push_back(c[1]); v.push_back(c[2]); }
     int add(const void *key, const mi_texture &t) { int i = (int)fs->textures.size(); fs->textures.push_back(t); node[key] = i; return i; }
+    void remember(const Texture<Float> *t, int i) { fs->probeFloat.emplace_back(t, i); }
+    void remember(const Texture<Spectrum> *t, int i) { fs->probeSpectrum.emplace_back(t, i); }
     template <class T> int walk(const Texture<T> *tex) {
         if (!tex) return -1;
         auto it = node.find(tex);
         if (it != node.end()) return it->second;
+        int i = walkNew(tex);
+        if (i >= 0) remember(tex, i);
+        return i;
+    }
+    template <class T> int walkNew(const Texture<T> *tex) {
         const bool S = std::is_same<T, Spectrum>::value;
         if (auto c = dynamic_cast<const ConstantTexture<T> *>(tex)) { mi_texture t = blank(MI_TEX_CONSTANT, S); val3(t.value, c->value); return add(tex, t); }
         if (auto sc = dynamic_cast<const ScaleTexture<T, T> *>(tex)) { mi_texture t = blank(MI_TEX_SCALE, S); t.tex1 = walk(sc->tex1.get()); t.tex2 = walk(sc->tex2.get()); return add(tex, t); }
@@ -768,6 +778,59 @@ class WavefrontPathIntegrator : public Integrator {   // core/integrator.h:53-58
     const bool volpath;   // stands in for VolPathIntegrator (media attenuate and scatter) instead of PathIntegrator
 };
 
+// PBRT_AMD_TEX_PROBE=<report file>: every Texture object the scene's materials reach is evaluated BY THE REFERENCE'S OWN CLASS (Texture<T>::Evaluate,
+// core/texture.h:139-144) at 2048 random interactions, and the backend evaluates the node it was flattened to (oracle_texture_eval) at the same
+// interactions.  One report line per node: node, type, spectrum, evaluations, bit-identical ones, largest absolute difference.
+static void TextureProbe(const Flat &flat, void *lib, const char *reportFile) {
+    auto tex_eval = (void (*)(const mi_scene_desc *, int32_t, const mi_tex_query *, int64_t, float *))dlsym(lib, "oracle_texture_eval");
+    if (!tex_eval) { Error("PBRT_AMD_TEX_PROBE: the backend has no oracle_texture_eval"); return; }
+    const int N = 2048;
+    std::vector<mi_tex_query> q(N);
+    RNG rng(7);
+    auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+    for (auto &x : q) {
+        for (int i = 0; i < 3; ++i) x.p[i] = U(-3, 3);
+        x.uv[0] = U(-.5f, 1.5f); x.uv[1] = U(-.5f, 1.5f);
+        Float s = std::pow(10.f, U(-3.5f, -.5f));   // footprints from sub-texel to many texels
+        for (int i = 0; i < 3; ++i) { x.dpdx[i] = U(-s, s); x.dpdy[i] = U(-s, s); }
+        x.dudx = U(-s, s); x.dvdx = U(-s, s); x.dudy = U(-s, s); x.dvdy = U(-s, s);
+    }
+    auto interaction = [](const mi_tex_query &x) {
+        SurfaceInteraction si;
+        si.p = Point3f(x.p[0], x.p[1], x.p[2]); si.uv = Point2f(x.uv[0], x.uv[1]);
+        si.dpdx = Vector3f(x.dpdx[0], x.dpdx[1], x.dpdx[2]); si.dpdy = Vector3f(x.dpdy[0], x.dpdy[1], x.dpdy[2]);
+        si.dudx = x.dudx; si.dvdx = x.dvdx; si.dudy = x.dudy; si.dvdy = x.dvdy;
+        return si;
+    };
+    FILE *f = std::fopen(reportFile, "w");
+    if (!f) { Error("PBRT_AMD_TEX_PROBE: cannot write %s", reportFile); return; }
+    std::vector<float> got(3 * (size_t)N);
+    auto report = [&](int node, const std::vector<float> &ref, int comps) {
+        tex_eval(&flat.desc, node, q.data(), N, got.data());
+        int same = 0; double worst = 0;
+        for (int i = 0; i < N; ++i) {
+            bool eq = true;
+            for (int c = 0; c < comps; ++c) {
+                float a = got[3 * i + c], b = ref[(size_t)comps * i + c];
+                if (std::memcmp(&a, &b, 4) != 0 && !(a == b)) { eq = false; worst = std::max(worst, (double)std::abs(a - b)); }
+            }
+            same += eq;
+        }
+        std::fprintf(f, "%d %d %d %d %d %.9g\n", node, flat.textures[node].type, comps == 3, N, same, worst);
+    };
+    for (auto &pr : flat.probeFloat) {
+        std::vector<float> ref(N);
+        for (int i = 0; i < N; ++i) ref[i] = pr.first->Evaluate(interaction(q[i]));
+        report(pr.second, ref, 1);
+    }
+    for (auto &pr : flat.probeSpectrum) {
+        std::vector<float> ref(3 * (size_t)N);
+        for (int i = 0; i < N; ++i) { Float c[3]; pr.first->Evaluate(interaction(q[i])).ToRGB(c); ref[3 * i] = c[0]; ref[3 * i + 1] = c[1]; ref[3 * i + 2] = c[2]; }
+        report(pr.second, ref, 3);
+    }
+    std::fclose(f);
+}
+
 void WavefrontPathIntegrator::Render(const Scene &scene) {
     std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy, volpath);
     if (!flat->error.empty()) { Error("WavefrontPathIntegrator: %s", flat->error.c_str()); return; }   // pbrt convention: report and return
@@ -795,6 +858,7 @@ void WavefrontPathIntegrator::Render(const Scene &scene) {
     } else {   // CPU box: the oracle renders the SAME description
         auto oracle_render = (double (*)(const mi_scene_desc *, float *, int, int, int, uint64_t *, const int32_t *))dlsym(lib, "oracle_render");
         if (!oracle_render) { Error("WavefrontPathIntegrator: oracle_render not found in %s", libPath); return; }
+        if (const char *probe = std::getenv("PBRT_AMD_TEX_PROBE")) TextureProbe(*flat, lib, probe);
         uint64_t counters[8] = {0};
         oracle_render(&flat->desc, rgbw.data(), 0, -1, NumSystemCores(), counters, nullptr);
     }

@@ -92,3 +92,23 @@ def test_edge_scene_through_the_stub_equals_pbrt_ref(name, tmp_path):
     d = np.abs(ia - ib).max(-1)
     assert d.max() <= 5e-7, float(d.max())
     assert (d == 0).mean() >= 0.995, float((d == 0).mean())
+
+
+@pytest.mark.parametrize("name", edge_scenes.TEX_NAMES + ["tex_dof"])
+def test_texture_nodes_equal_the_reference_classes(name, tmp_path):
+    """Row f2 at stage level against the reference's OWN texture classes: with PBRT_AMD_TEX_PROBE set the stub evaluates every Texture object the
+    scene reaches with the reference's Texture<T>::Evaluate (ImageTexture + MIPMap EWA / trilinear, the procedural classes, the 2D / 3D mappings)
+    at 2048 random interactions (sub-texel to many-texel footprints) and the oracle evaluates the node that object was flattened to
+    (oracle_texture_eval) at the same interactions: every value bit for bit."""
+    if not os.access(STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+    scene = str(tmp_path / "s.pbrt")
+    open(scene, "w").write(edge_scenes.scene(name))
+    rep = str(tmp_path / "probe.txt")
+    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_TEX_PROBE=rep)
+    r = subprocess.run([STUB, "--quiet", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(rep), r.stderr[-800:]
+    rows = [l.split() for l in open(rep)]
+    assert len(rows) >= 8
+    for node, typ, spectrum, n, same, worst in rows:
+        assert n == same, (name, "node", node, "type", typ, "identical", same, "of", n, "largest difference", worst)
