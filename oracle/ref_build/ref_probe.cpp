@@ -21,6 +21,7 @@
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
 #include "accelerators/bvh.h"
+#include "bssrdf.h"
 #include "cameras/perspective.h"
 #include "film.h"
 #include "filters/box.h"
@@ -543,6 +544,23 @@ int main(int argc, char **argv) {
         }
         fclose(f);
         printf("ref_probe: %d camera-ray records\n", count);
+    }
+    // ---- ComputeBeamDiffusionBSSRDF (core/bssrdf.cpp:113-160): the table the Subsurface / KdSubsurface material constructors compute, for a few (g, eta)
+    {
+        PbrtOptions.nThreads = 1;   // its ParallelFor
+        FILE *f = fopen((dir + "/bssrdf_tables.bin").c_str(), "wb");
+        const Float ge[][2] = {{0.f, 1.33f}, {.6f, 1.5f}, {-.3f, 1.1f}};
+        for (auto &p : ge) {
+            BSSRDFTable t(100, 64);   // materials/subsurface.h:57, kdsubsurface.h:66
+            ComputeBeamDiffusionBSSRDF(p[0], p[1], &t);
+            putv<float>(f, p[0]); putv<float>(f, p[1]);
+            for (int i = 0; i < 100; ++i) putv<float>(f, t.rhoSamples[i]);
+            for (int i = 0; i < 64; ++i) putv<float>(f, t.radiusSamples[i]);
+            for (int i = 0; i < 6400; ++i) putv<float>(f, t.profile[i]);
+            for (int i = 0; i < 100; ++i) putv<float>(f, t.rhoEff[i]);
+            for (int i = 0; i < 6400; ++i) putv<float>(f, t.profileCDF[i]);
+        }
+        fclose(f);
     }
     // ---- the lights that depend on the scene (Light::Preprocess: world bound): DistantLight and InfiniteAreaLight -- constant, and with a
     // radiance map (argv[2]: MIPMap::Lookup + Distribution2D, lights/infinite.cpp:43-137) under a rotation.  The scene is one triangle.

@@ -49,6 +49,16 @@ void pbrt_amd_scene_info(pbrt_amd_scene *s, int64_t *out) {
     for (int i = 0; i < 16; ++i) out[i] = v[i];
 }
 
+// ComputeBeamDiffusionBSSRDF as the host restates it (host/bssrdf.cpp): the 100 x 64 table of a Subsurface / KdSubsurface material for (g, eta).
+// out: rho samples [100], radius samples [64], profile [6400], rhoEff [100], profileCDF [6400], in that order
+int pbrt_amd_bssrdf_table(float g, float eta, float *out) {
+    std::shared_ptr<BSSRDFTableData> t = MakeBSSRDFTable(g, eta);
+    if (!t || t->nRho != 100 || t->nRadius != 64) return -1;
+    float *p = out;
+    for (const std::vector<float> *v : {&t->rhoSamples, &t->radiusSamples, &t->profile, &t->rhoEff, &t->profileCDF}) { std::copy(v->begin(), v->end(), p); p += v->size(); }
+    return 0;
+}
+
 // light i of the flattened scene: type and the emitted quantity (Lemit | I | L) as it crosses the boundary; returns 0, -1 when out of range
 int pbrt_amd_scene_light(pbrt_amd_scene *s, int i, int *type, float rgb[3]) {
     const mi_scene_desc &d = s->flat->desc;

@@ -510,3 +510,19 @@ def test_scene_content_without_a_counterpart_is_refused_not_skipped(edit, tmp_pa
     assert r.returncode != 0 and not out.exists() and "unsupported" in r.stderr
     pa.Scene(text=base)                                                              # the count is per pbrtInit
     pa.Scene(text=base.replace('Shape "trianglemesh"', 'Shape "nosuchshape"\nShape "trianglemesh"'))   # unknown to the reference too: skipped
+
+
+def test_beam_diffusion_table_matches_reference(built):
+    """host/bssrdf.cpp (the table the Subsurface / KdSubsurface material constructors compute) against the reference's ComputeBeamDiffusionBSSRDF
+    (core/bssrdf.cpp:113-160; tests/golden/bssrdf_tables.npz from ref_probe) for three (g, eta) pairs: albedo and radius samples, the 100 x 64
+    profile, the effective albedo and the profile CDF -- 13 064 values each, bit for bit."""
+    import ctypes as C
+    L = pa.host_lib()
+    L.pbrt_amd_bssrdf_table.argtypes = [C.c_float, C.c_float, C.c_void_p]
+    T = np.load(os.path.join(ROOT, "tests", "golden", "bssrdf_tables.npz"))["tables"]
+    assert len(T) == 3
+    for t in T:
+        out = np.zeros(100 + 64 + 6400 + 100 + 6400, np.float32)
+        assert L.pbrt_amd_bssrdf_table(float(t["g"]), float(t["eta"]), out.ctypes.data) == 0
+        ref = np.concatenate([t["rho_samples"], t["radius_samples"], t["profile"], t["rho_eff"], t["profile_cdf"]])
+        assert out.tobytes() == ref.tobytes(), (float(t["g"]), float(t["eta"]))
