@@ -485,6 +485,14 @@ int mi_bxdf_eval(int device_ordinal, const mi_bxdf *bxdfs, const float *wo, cons
 typedef struct mi_light_query { int32_t light; float p[3], n[3], u[2], wi[3]; } mi_light_query;
 typedef struct mi_light_result { float wi[3], pdf, Li[3], ray_o[3], ray_d[3], ray_tmax, pdf_wi; int32_t delta; float le_wi[3]; } mi_light_result;
 int mi_light_sample(mi_ctx *ctx, const mi_light_query *queries, int64_t n, mi_light_result *out);
+/* Stage-level row f4: TabulatedBSSRDF::Sr / Sample_Sr / Pdf_Sr (core/bssrdf.cpp:199-233, 353-390) on an explicit table for coefficient triples, and
+ * SubsurfaceFromDiffuse (:178-188: reflectance kd + mean free path -> sigma_a, sigma_s); HenyeyGreenstein::p / Sample_p (core/medium.cpp:189-213). */
+typedef struct mi_bssrdf_query { float sigma_a[3], sigma_s[3]; int32_t ch; float r, u, kd[3], mfp[3]; } mi_bssrdf_query;
+typedef struct mi_bssrdf_result { float sr[3], sample_sr, pdf_sr, sigma_a[3], sigma_s[3]; } mi_bssrdf_result;
+int mi_bssrdf_eval(int device_ordinal, const mi_bssrdf_table *table, float eta, const mi_bssrdf_query *queries, int64_t n, mi_bssrdf_result *out);
+typedef struct mi_hg_query { float g, wo[3], wi[3], u[2]; } mi_hg_query;
+typedef struct mi_hg_result { float p, wi_s[3], p_s; } mi_hg_result;
+int mi_phase_hg(int device_ordinal, const mi_hg_query *queries, int64_t n, mi_hg_result *out);
 /* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
  * 3 lean steps over the 80-byte compressed BVH8, 4 two-level (instanced) scene, 5 general steps over the 64-byte quantised BVH4;
  * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */

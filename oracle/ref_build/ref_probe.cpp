@@ -21,6 +21,7 @@
 #include "samplers/sobol.h"
 #include "samplers/halton.h"
 #include "accelerators/bvh.h"
+#include "medium.h"
 #include "bssrdf.h"
 #include "cameras/perspective.h"
 #include "film.h"
@@ -559,6 +560,62 @@ int main(int argc, char **argv) {
             for (int i = 0; i < 6400; ++i) putv<float>(f, t.profile[i]);
             for (int i = 0; i < 100; ++i) putv<float>(f, t.rhoEff[i]);
             for (int i = 0; i < 6400; ++i) putv<float>(f, t.profileCDF[i]);
+        }
+        fclose(f);
+    }
+    // ---- TabulatedBSSRDF::Sr / Sample_Sr / Pdf_Sr (core/bssrdf.cpp:199-233, 353-390) and SubsurfaceFromDiffuse (:178-188) on the (g = 0, eta = 1.33)
+    // table, HenyeyGreenstein::p / Sample_p (core/medium.cpp:210-246)
+    {
+        PbrtOptions.nThreads = 1;
+        FILE *f = fopen((dir + "/bssrdf_radial.bin").c_str(), "wb");
+        BSSRDFTable t(100, 64);
+        ComputeBeamDiffusionBSSRDF(0.f, 1.33f, &t);
+        RNG rng(53);
+        auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+        SurfaceInteraction po(Point3f(0, 0, 0), Vector3f(), Point2f(), Vector3f(0, 0, 1), Vector3f(1, 0, 0), Vector3f(0, 1, 0), Normal3f(), Normal3f(), 0, nullptr);
+        for (int k = 0; k < 2000; ++k) {
+            Float sa[3], ss[3];
+            for (int c = 0; c < 3; ++c) { sa[c] = std::pow(10.f, U(-3, 1)); ss[c] = std::pow(10.f, U(-2, 1.5f)); }
+            if (k % 50 == 0) { sa[1] = 0; ss[1] = 0; }   // sigma_t == 0 in one channel
+            TabulatedBSSRDF b(po, nullptr, TransportMode::Radiance, 1.33f, Spectrum::FromRGB(sa), Spectrum::FromRGB(ss), t);
+            int ch = (int)(rng.UniformUInt32() % 3);
+            Float r = std::pow(10.f, U(-4, 1.2f)) / std::max((Float)1e-3, sa[ch] + ss[ch]);
+            Float u = rng.UniformFloat();
+            Float sr[3];
+            b.Sr(r).ToRGB(sr);
+            Float rs = b.Sample_Sr(ch, u), pdf = b.Pdf_Sr(ch, r);
+            // SubsurfaceFromDiffuse: reflectance + mean free path -> coefficients
+            Float kd[3] = {U(.01f, .95f), U(.01f, .95f), U(.01f, .95f)}, mfp[3] = {U(.05f, 3), U(.05f, 3), U(.05f, 3)};
+            Spectrum oa, os;
+            SubsurfaceFromDiffuse(t, Spectrum::FromRGB(kd), Spectrum::FromRGB(mfp), &oa, &os);
+            Float oar[3], osr[3];
+            oa.ToRGB(oar); os.ToRGB(osr);
+            for (int c = 0; c < 3; ++c) putv<float>(f, sa[c]);
+            for (int c = 0; c < 3; ++c) putv<float>(f, ss[c]);
+            putv<int32_t>(f, ch); putv<float>(f, r); putv<float>(f, u);
+            for (int c = 0; c < 3; ++c) putv<float>(f, sr[c]);
+            putv<float>(f, rs); putv<float>(f, pdf);
+            for (int c = 0; c < 3; ++c) putv<float>(f, kd[c]);
+            for (int c = 0; c < 3; ++c) putv<float>(f, mfp[c]);
+            for (int c = 0; c < 3; ++c) putv<float>(f, oar[c]);
+            for (int c = 0; c < 3; ++c) putv<float>(f, osr[c]);
+        }
+        fclose(f);
+        f = fopen((dir + "/hg.bin").c_str(), "wb");
+        for (int k = 0; k < 4000; ++k) {
+            Float g = k % 10 == 0 ? 0.f : (k % 10 == 1 ? U(-1e-4f, 1e-4f) : U(-.97f, .97f));
+            HenyeyGreenstein hg(g);
+            Vector3f wo = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())), wi = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat()));
+            Point2f u(rng.UniformFloat(), rng.UniformFloat());
+            Vector3f ws;
+            Float p = hg.p(wo, wi), ps = hg.Sample_p(wo, &ws, u);
+            putv<float>(f, g);
+            for (int c = 0; c < 3; ++c) putv<float>(f, wo[c]);
+            for (int c = 0; c < 3; ++c) putv<float>(f, wi[c]);
+            putv<float>(f, u[0]); putv<float>(f, u[1]);
+            putv<float>(f, p);
+            for (int c = 0; c < 3; ++c) putv<float>(f, ws[c]);
+            putv<float>(f, ps);
         }
         fclose(f);
     }

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -373,6 +373,42 @@ def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=Fa
 
 LIGHT_QUERY_DTYPE = np.dtype([("light", "<i4"), ("p", "<f4", 3), ("n", "<f4", 3), ("u", "<f4", 2), ("wi", "<f4", 3)])
 LIGHT_RESULT_DTYPE = np.dtype([("wi", "<f4", 3), ("pdf", "<f4"), ("Li", "<f4", 3), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3), ("ray_tmax", "<f4"), ("pdf_wi", "<f4"), ("delta", "<i4"), ("le_wi", "<f4", 3)])
+
+
+BSSRDF_QUERY_DTYPE = np.dtype([("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("ch", "<i4"), ("r", "<f4"), ("u", "<f4"), ("kd", "<f4", 3), ("mfp", "<f4", 3)])
+BSSRDF_RESULT_DTYPE = np.dtype([("sr", "<f4", 3), ("sample_sr", "<f4"), ("pdf_sr", "<f4"), ("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3)])
+HG_QUERY_DTYPE = np.dtype([("g", "<f4"), ("wo", "<f4", 3), ("wi", "<f4", 3), ("u", "<f4", 2)])
+HG_RESULT_DTYPE = np.dtype([("p", "<f4"), ("wi_s", "<f4", 3), ("p_s", "<f4")])
+
+
+class _BssrdfTable(C.Structure):
+    _fields_ = [("n_rho", C.c_int32), ("n_radius", C.c_int32), ("rho_samples", C.c_void_p), ("radius_samples", C.c_void_p), ("profile", C.c_void_p),
+                ("rho_eff", C.c_void_p), ("profile_cdf", C.c_void_p)]
+
+
+def bssrdf_eval(table_rec, eta, queries, device=0):
+    """mi_bssrdf_eval: TabulatedBSSRDF::Sr / Sample_Sr / Pdf_Sr + SubsurfaceFromDiffuse on the device for a table given as a record with the arrays
+    rho_samples [100], radius_samples [64], profile [6400], rho_eff [100], profile_cdf [6400]"""
+    keep = [np.ascontiguousarray(table_rec[k], dtype=np.float32) for k in ("rho_samples", "radius_samples", "profile", "rho_eff", "profile_cdf")]
+    t = _BssrdfTable(len(keep[0]), len(keep[1]), *[a.ctypes.data for a in keep])
+    q = np.ascontiguousarray(queries, dtype=BSSRDF_QUERY_DTYPE)
+    out = np.zeros(len(q), dtype=BSSRDF_RESULT_DTYPE)
+    L = device_lib()
+    L.mi_bssrdf_eval.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    if L.mi_bssrdf_eval(device, C.byref(t), eta, _ptr(q), len(q), _ptr(out)) != 0:
+        raise RuntimeError("mi_bssrdf_eval: %s" % L.mi_last_error().decode())
+    return out
+
+
+def phase_hg(queries, device=0):
+    """mi_phase_hg: HenyeyGreenstein::p / Sample_p on the device"""
+    q = np.ascontiguousarray(queries, dtype=HG_QUERY_DTYPE)
+    out = np.zeros(len(q), dtype=HG_RESULT_DTYPE)
+    L = device_lib()
+    L.mi_phase_hg.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    if L.mi_phase_hg(device, _ptr(q), len(q), _ptr(out)) != 0:
+        raise RuntimeError("mi_phase_hg: %s" % L.mi_last_error().decode())
+    return out
 
 
 def bxdf_eval(rows, device=0):

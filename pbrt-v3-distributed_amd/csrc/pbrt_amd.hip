@@ -2907,6 +2907,80 @@ int mi_light_sample(mi_ctx *c, const mi_light_query *queries, int64_t n, mi_ligh
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+// stage-level row f4: the radial profile of the tabulated BSSRDF and the phase function, the routines k_shade_vol calls
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_bssrdf(const DevBssrdfTable *tb, float eta, const mi_bssrdf_query *q, int64_t n, mi_bssrdf_result *out) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const mi_bssrdf_query &x = q[i];
+    DevBSSRDF bs;
+    bs.table = tb; bs.eta = eta; bs.material = 0;
+    bs.poP = V3(0.f, 0.f, 0.f); bs.ns = V3(0.f, 0.f, 1.f); bs.ss = V3(1.f, 0.f, 0.f); bs.ts = V3(0.f, 1.f, 0.f);
+    RGB sa(x.sigma_a[0], x.sigma_a[1], x.sigma_a[2]), ss(x.sigma_s[0], x.sigma_s[1], x.sigma_s[2]);
+    bs.sigma_t = sa + ss;
+    bs.rho = RGB(bs.sigma_t.r != 0 ? ss.r / bs.sigma_t.r : 0.f, bs.sigma_t.g != 0 ? ss.g / bs.sigma_t.g : 0.f, bs.sigma_t.b != 0 ? ss.b / bs.sigma_t.b : 0.f);
+    mi_bssrdf_result r;
+    RGB sr = BssrdfSr(&bs, x.r);
+    r.sr[0] = sr.r; r.sr[1] = sr.g; r.sr[2] = sr.b;
+    r.sample_sr = BssrdfSample_Sr(&bs, x.ch, x.u);
+    r.pdf_sr = BssrdfPdf_Sr(&bs, x.ch, x.r);
+    for (int c = 0; c < 3; ++c) {   // SubsurfaceFromDiffuse
+        Float rho = InvertCatmullRom(tb->n_rho, tb->rho_samples, tb->rho_eff, x.kd[c]);
+        r.sigma_s[c] = rho / x.mfp[c];
+        r.sigma_a[c] = (1 - rho) / x.mfp[c];
+    }
+    out[i] = r;
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_hg(const mi_hg_query *q, int64_t n, mi_hg_result *out) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const mi_hg_query &x = q[i];
+    V3 wo(x.wo[0], x.wo[1], x.wo[2]), wi(x.wi[0], x.wi[1], x.wi[2]), ws;
+    mi_hg_result r;
+    r.p = HGp(x.g, wo, wi);
+    r.p_s = HGSample_p(x.g, wo, &ws, x.u[0], x.u[1]);
+    r.wi_s[0] = ws.x; r.wi_s[1] = ws.y; r.wi_s[2] = ws.z;
+    out[i] = r;
+}
+static int stage_device(int device_ordinal, const char *who) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) return fail(std::string(who) + ": no such HIP device (this library has no CPU fallback)");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    return 0;
+}
+int mi_bssrdf_eval(int device_ordinal, const mi_bssrdf_table *t, float eta, const mi_bssrdf_query *queries, int64_t n, mi_bssrdf_result *out) {
+    if (!t || !queries || !out || n < 0 || t->n_rho < 4 || t->n_radius < 4) return fail("mi_bssrdf_eval: bad argument");
+    if (n == 0) return 0;
+    if (stage_device(device_ordinal, "mi_bssrdf_eval")) return -1;
+    DevBuf a[5], dt, dq, dr;
+    const float *src[5] = {t->rho_samples, t->radius_samples, t->profile, t->rho_eff, t->profile_cdf};
+    const size_t cnt[5] = {(size_t)t->n_rho, (size_t)t->n_radius, (size_t)t->n_rho * t->n_radius, (size_t)t->n_rho, (size_t)t->n_rho * t->n_radius};
+    for (int k = 0; k < 5; ++k) {
+        if (a[k].alloc(cnt[k] * 4)) return -1;
+        HIP_TRY(hipMemcpy(a[k].p, src[k], cnt[k] * 4, hipMemcpyHostToDevice));
+    }
+    DevBssrdfTable h;
+    h.n_rho = t->n_rho; h.n_radius = t->n_radius;
+    h.rho_samples = a[0].as<float>(); h.radius_samples = a[1].as<float>(); h.profile = a[2].as<float>(); h.rho_eff = a[3].as<float>(); h.profile_cdf = a[4].as<float>();
+    if (dt.alloc(sizeof(h)) || dq.alloc((size_t)n * sizeof(mi_bssrdf_query)) || dr.alloc((size_t)n * sizeof(mi_bssrdf_result))) return -1;
+    HIP_TRY(hipMemcpy(dt.p, &h, sizeof(h), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dq.p, queries, (size_t)n * sizeof(mi_bssrdf_query), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_bssrdf, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, 0, dt.as<DevBssrdfTable>(), eta, dq.as<mi_bssrdf_query>(), n, dr.as<mi_bssrdf_result>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dr.p, (size_t)n * sizeof(mi_bssrdf_result), hipMemcpyDeviceToHost));
+    return 0;
+}
+int mi_phase_hg(int device_ordinal, const mi_hg_query *queries, int64_t n, mi_hg_result *out) {
+    if (!queries || !out || n < 0) return fail("mi_phase_hg: bad argument");
+    if (n == 0) return 0;
+    if (stage_device(device_ordinal, "mi_phase_hg")) return -1;
+    DevBuf dq, dr;
+    if (dq.alloc((size_t)n * sizeof(mi_hg_query)) || dr.alloc((size_t)n * sizeof(mi_hg_result))) return -1;
+    HIP_TRY(hipMemcpy(dq.p, queries, (size_t)n * sizeof(mi_hg_query), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_hg, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, 0, dq.as<mi_hg_query>(), n, dr.as<mi_hg_result>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dr.p, (size_t)n * sizeof(mi_hg_result), hipMemcpyDeviceToHost));
+    return 0;
+}
 // host check of the 64-byte quantised BVH4 (pt_bvh4q.h): quantisation in exact arithmetic + the kernel's per-ray state machine on the host
 int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
     if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh4q_validate: null argument");

@@ -209,3 +209,50 @@ def image_metrics(img, ref):
     frac = float(np.mean(d <= 1e-3 * (1 + r)))
     relmse = float(np.mean(d ** 2) / max(1e-30, np.mean(r ** 2)))
     return frac, relmse
+
+
+class _BssrdfTable(C.Structure):
+    _fields_ = [("n_rho", C.c_int32), ("n_radius", C.c_int32), ("rho_samples", C.c_void_p), ("radius_samples", C.c_void_p), ("profile", C.c_void_p),
+                ("rho_eff", C.c_void_p), ("profile_cdf", C.c_void_p)]
+
+
+def bssrdf_table(rec):
+    """mi_bssrdf_table over the arrays of one record of tests/golden/bssrdf_tables.npz 'tables' (the arrays are kept alive on the returned object)"""
+    keep = [np.ascontiguousarray(rec[k], dtype=np.float32) for k in ("rho_samples", "radius_samples", "profile", "rho_eff", "profile_cdf")]
+    t = _BssrdfTable(100, 64, *[a.ctypes.data for a in keep])
+    t._keep = keep
+    return t
+
+
+def bssrdf_radial(table, eta, recs):
+    """TabulatedBSSRDF::Sr / Sample_Sr / Pdf_Sr of the oracle for the coefficient records -> (Sr rgb, Sample_Sr, Pdf_Sr)"""
+    n = len(recs)
+    sa, ss = np.ascontiguousarray(recs["sigma_a"], np.float32), np.ascontiguousarray(recs["sigma_s"], np.float32)
+    ch, r, u = np.ascontiguousarray(recs["ch"], np.int32), np.ascontiguousarray(recs["r"], np.float32), np.ascontiguousarray(recs["u"], np.float32)
+    sr, smp, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    L = lib()
+    L.oracle_bssrdf_radial.argtypes = [C.c_void_p, C.c_float] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 3
+    L.oracle_bssrdf_radial.restype = None
+    L.oracle_bssrdf_radial(C.byref(table), eta, _p(sa), _p(ss), _p(ch), _p(r), _p(u), n, _p(sr), _p(smp), _p(pdf))
+    return sr, smp, pdf
+
+
+def subsurface_from_diffuse(table, kd, mfp):
+    kd, mfp = np.ascontiguousarray(kd, np.float32), np.ascontiguousarray(mfp, np.float32)
+    sa, ss = np.zeros_like(kd), np.zeros_like(kd)
+    L = lib()
+    L.oracle_subsurface_from_diffuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.oracle_subsurface_from_diffuse.restype = None
+    L.oracle_subsurface_from_diffuse(C.byref(table), _p(kd), _p(mfp), len(kd), _p(sa), _p(ss))
+    return sa, ss
+
+
+def hg(recs):
+    n = len(recs)
+    g, wo, wi, u = [np.ascontiguousarray(recs[k], np.float32) for k in ("g", "wo", "wi", "u")]
+    p, ws, ps = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    L = lib()
+    L.oracle_hg.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
+    L.oracle_hg.restype = None
+    L.oracle_hg(_p(g), _p(wo), _p(wi), _p(u), n, _p(p), _p(ws), _p(ps))
+    return p, ws, ps

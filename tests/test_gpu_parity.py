@@ -700,6 +700,33 @@ def test_device_scene_dependent_lights_match_reference_classes():
     assert same / sum(o[k][d].size for k in ("wi", "pdf", "Li", "ray_o", "ray_d")) >= 0.99
 
 
+def test_device_bssrdf_profile_and_phase_function_match_reference_classes():
+    """Row f4 at stage level on the device against the reference's own classes (tests/golden/bssrdf_tables.npz): mi_bssrdf_eval -- TabulatedBSSRDF::Sr,
+    Sample_Sr, Pdf_Sr and SubsurfaceFromDiffuse, the out-of-line routines k_shade_vol calls -- on 2 000 coefficient triples, mi_phase_hg --
+    HenyeyGreenstein::p / Sample_p -- on 4 000 records.  Everything but the sampled direction is +, -, *, /, sqrt: bit-exact expected (>= 99 % required,
+    1e-5 relative stated); the sampled direction goes through the device's sin / cos: 2e-6 absolute."""
+    d = np.load(os.path.join(G, "bssrdf_tables.npz"))
+    r = d["radial"]
+    q = np.zeros(len(r), pa.BSSRDF_QUERY_DTYPE)
+    for k in ("sigma_a", "sigma_s", "ch", "r", "u", "kd", "mfp"):
+        q[k] = r[k]
+    o = pa.bssrdf_eval(d["tables"][0], float(d["tables"][0]["eta"]), q)
+    same = total = 0
+    for a, b in ((o["sr"], r["sr"]), (o["sample_sr"], r["sample_sr"]), (o["pdf_sr"], r["pdf_sr"]), (o["sigma_a"], r["out_sigma_a"]), (o["sigma_s"], r["out_sigma_s"])):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-9), float(np.abs(a - b).max())
+        same += int((a == b).sum()); total += a.size
+    h = d["hg"]
+    qh = np.zeros(len(h), pa.HG_QUERY_DTYPE)
+    for k in ("g", "wo", "wi", "u"):
+        qh[k] = h[k]
+    oh = pa.phase_hg(qh)
+    for a, b in ((oh["p"], h["p"]), (oh["p_s"], h["p_s"])):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-9)
+        same += int((a == b).sum()); total += a.size
+    assert np.abs(oh["wi_s"] - h["wi_s"]).max() <= 2e-6
+    assert same / total >= 0.99, same / total
+
+
 @pytest.mark.parametrize("name", edge_scenes.FURNACE_NAMES)
 def test_furnace_scenes(name):
     """The reference's analytic scenes (src/tests/analytic_scenes.cpp:71-203, CheckSceneAverage :55-68) on the device: mean radiance inside the closed unit

@@ -362,3 +362,22 @@ def test_camera_rays_match_reference_classes(built):
         rays, pf = ol.camera_rays(sc, np.stack([r["px"], r["py"]], 1).astype(np.int32), r["s"])
         assert pf.tobytes() == r["p_film"].tobytes(), c
         assert np.ascontiguousarray(rays["o"]).tobytes() == r["o"].tobytes() and np.ascontiguousarray(rays["d"]).tobytes() == r["d"].tobytes(), c
+
+
+def test_bssrdf_radial_profile_and_phase_function_match_reference_classes(built):
+    """Row f4 at stage level against the reference's own classes (ref_probe -> tests/golden/bssrdf_tables.npz): TabulatedBSSRDF::Sr, Sample_Sr, Pdf_Sr
+    (core/bssrdf.cpp:199-233, 353-390: CatmullRomWeights, SampleCatmullRom2D) for 2 000 random coefficient triples on the (g = 0, eta = 1.33) table incl.
+    a channel with sigma_t = 0; SubsurfaceFromDiffuse (InvertCatmullRom, :178-188); HenyeyGreenstein::p / Sample_p (core/medium.cpp:189-213) for 4 000
+    (g, wo, wi, u) incl. |g| < 1e-3 -- every value bit for bit."""
+    d = np.load(os.path.join(G, "bssrdf_tables.npz"))
+    t = ol.bssrdf_table(d["tables"][0])
+    assert float(d["tables"][0]["g"]) == 0.0
+    r = d["radial"]
+    sr, smp, pdf = ol.bssrdf_radial(t, float(d["tables"][0]["eta"]), r)
+    assert (r["sr"] > 0).mean() > .5 and (r["sample_sr"] > 0).mean() > .9 and (r["pdf_sr"] > 0).mean() > .5
+    assert sr.tobytes() == r["sr"].tobytes() and smp.tobytes() == r["sample_sr"].tobytes() and pdf.tobytes() == r["pdf_sr"].tobytes()
+    sa, ss = ol.subsurface_from_diffuse(t, r["kd"], r["mfp"])
+    assert sa.tobytes() == r["out_sigma_a"].tobytes() and ss.tobytes() == r["out_sigma_s"].tobytes()
+    h = d["hg"]
+    p, ws, ps = ol.hg(h)
+    assert p.tobytes() == h["p"].tobytes() and ws.tobytes() == h["wi_s"].tobytes() and ps.tobytes() == h["p_s"].tobytes()

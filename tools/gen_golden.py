@@ -26,6 +26,9 @@ CAMERA_RAYS = np.dtype([("cfg", "<i4"), ("px", "<i4"), ("py", "<i4"), ("s", "<i4
                         ("rx_o", "<f4", 3), ("rx_d", "<f4", 3), ("ry_o", "<f4", 3), ("ry_d", "<f4", 3)])
 BSSRDF_TABLES = np.dtype([("g", "<f4"), ("eta", "<f4"), ("rho_samples", "<f4", 100), ("radius_samples", "<f4", 64), ("profile", "<f4", 6400), ("rho_eff", "<f4", 100),
                           ("profile_cdf", "<f4", 6400)])
+BSSRDF_RADIAL = np.dtype([("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("ch", "<i4"), ("r", "<f4"), ("u", "<f4"), ("sr", "<f4", 3), ("sample_sr", "<f4"), ("pdf_sr", "<f4"),
+                          ("kd", "<f4", 3), ("mfp", "<f4", 3), ("out_sigma_a", "<f4", 3), ("out_sigma_s", "<f4", 3)])
+HG = np.dtype([("g", "<f4"), ("wo", "<f4", 3), ("wi", "<f4", 3), ("u", "<f4", 2), ("p", "<f4"), ("wi_s", "<f4", 3), ("p_s", "<f4")])
 SPECTRA = np.dtype([("kind", "<i4"), ("n", "<i4"), ("vals", "<f4", 80), ("rgb", "<f4", 3)])
 
 
@@ -36,7 +39,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "spectra_vectors.npz"), spectra=np.fromfile(os.path.join(tmp, "spectra.bin"), dtype=SPECTRA))
     np.savez_compressed(os.path.join(OUT, "light_vectors.npz"), light_samples=np.fromfile(os.path.join(tmp, "light_samples.bin"), dtype=LIGHT_SAMPLES),
                         scene_lights=np.fromfile(os.path.join(tmp, "light_samples_scene.bin"), dtype=SCENE_LIGHTS))
-    np.savez_compressed(os.path.join(OUT, "bssrdf_tables.npz"), tables=np.fromfile(os.path.join(tmp, "bssrdf_tables.bin"), dtype=BSSRDF_TABLES))
+    np.savez_compressed(os.path.join(OUT, "bssrdf_tables.npz"), tables=np.fromfile(os.path.join(tmp, "bssrdf_tables.bin"), dtype=BSSRDF_TABLES),
+                        radial=np.fromfile(os.path.join(tmp, "bssrdf_radial.bin"), dtype=BSSRDF_RADIAL), hg=np.fromfile(os.path.join(tmp, "hg.bin"), dtype=HG))
     np.savez_compressed(os.path.join(OUT, "camera_vectors.npz"), camera_rays=np.fromfile(os.path.join(tmp, "camera_rays.bin"), dtype=CAMERA_RAYS))
     if "--only-spectra" in sys.argv or "--only-kat" in sys.argv:
         return
