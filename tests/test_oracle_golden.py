@@ -120,6 +120,7 @@ def test_distribution1d_matches_reference(vec):
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
                                                     ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+                                                    ("cornell", 64, 48, 4, "triangle"), ("cornell", 64, 48, 4, "sinc"),
                                                     ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")])
 def test_oracle_render_matches_reference_image(built, name, w, h, spp, strategy):
     """Whole pipeline vs the reference's own render (lossless PFM fixture).  1 spp = per-camera-sample radiance.
@@ -133,9 +134,10 @@ def test_oracle_render_matches_reference_image(built, name, w, h, spp, strategy)
     ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else "")))
     assert img.shape == ref.shape
     # wide filters: a pixel sums contributions of several tiles, in a different order than the reference's tile merge
-    tol = 1e-5 if strategy in ("gaussian", "mitchell") else 2e-6
+    wide = strategy in ("gaussian", "mitchell", "triangle", "sinc")
+    tol = 1e-5 if wide else 2e-6
     assert np.all(np.abs(img - ref) <= tol * (1 + np.abs(ref))), float(np.abs(img - ref).max())
-    if strategy not in ("gaussian", "mitchell"): assert cnt["camera_rays"] == w * h * spp   # wide filters: sample bounds exceed the image
+    if not wide: assert cnt["camera_rays"] == w * h * spp   # wide filters: sample bounds exceed the image
 
 
 def test_oracle_vs_live_reference_binary(built, tmp_path):

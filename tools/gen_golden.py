@@ -65,7 +65,7 @@ def main():
     scenes = [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
               ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
               # wide pixel filters (overlapping footprints, sample bounds larger than the image): variant = key of FILTERS
-              ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+              ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"), ("cornell", 64, 48, 4, "triangle"), ("cornell", 64, 48, 4, "sinc"),
               # HaltonSampler (pbrt's default), sample counts that are not powers of two
               ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")]
     for name, w, h, spp, strategy in scenes:
@@ -87,7 +87,8 @@ def main():
     print("rendered", out)
 
 
-FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]'}
+FILTERS = {"gaussian": 'PixelFilter "gaussian"', "mitchell": 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]',
+           "triangle": 'PixelFilter "triangle" "float xwidth" [1.5] "float ywidth" [2.25]', "sinc": 'PixelFilter "sinc" "float xwidth" [3] "float ywidth" [3] "float tau" [2.5]'}
 
 
 def edge_fixtures(tmp):
