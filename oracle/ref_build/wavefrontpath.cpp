@@ -831,6 +831,61 @@ static void TextureProbe(const Flat &flat, void *lib, const char *reportFile) {
     std::fclose(f);
 }
 
+// PBRT_AMD_HIT_PROBE=<report file>: 20 000 random rays through the scene's bounds (half from outside aimed into them, half from inside; finite and
+// infinite tMax) go through the REFERENCE's own Scene::Intersect / IntersectP (BVHAccel + TransformedPrimitive + Triangle / Sphere, alpha masks
+// included) and through the backend's traversal of the flattened description (oracle_intersect / oracle_intersect_p): hit or miss, the hit
+// distance and the geometric normal must be the same bit for bit.  One report line: rays, reference hits, agreeing hit flags, agreeing t, agreeing n,
+// agreeing occlusion flags.
+static void HitProbe(const Scene &scene, const Flat &flat, void *lib, const char *reportFile) {
+    auto isect_fn = (void (*)(const mi_scene_desc *, const mi_ray *, int64_t, mi_hit *, uint64_t *))dlsym(lib, "oracle_intersect");
+    auto occl_fn = (void (*)(const mi_scene_desc *, const mi_ray *, int64_t, uint8_t *, uint64_t *))dlsym(lib, "oracle_intersect_p");
+    if (!isect_fn || !occl_fn) { Error("PBRT_AMD_HIT_PROBE: the backend has no oracle_intersect / oracle_intersect_p"); return; }
+    const int N = 20000;
+    Bounds3f wb = scene.WorldBound();
+    Point3f c; Float rad;
+    wb.BoundingSphere(&c, &rad);
+    if (!(rad > 0)) rad = 1;
+    RNG rng(13);
+    auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+    std::vector<mi_ray> rays(N);
+    for (int i = 0; i < N; ++i) {
+        Point3f target(U(wb.pMin.x, wb.pMax.x), U(wb.pMin.y, wb.pMax.y), U(wb.pMin.z, wb.pMax.z));
+        Point3f o;
+        Vector3f d;
+        if (i % 2) { o = c + (2.5f * rad) * UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())); d = target - o; if (i % 4 == 1) d = Normalize(d); }
+        else { o = target; d = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())); }
+        mi_ray &r = rays[i];
+        for (int k = 0; k < 3; ++k) { r.o[k] = o[k]; r.d[k] = d[k]; }
+        r.tmax = (i % 5 == 0) ? U(.1f, 3.f) : Infinity;
+        r.time = 0;
+    }
+    std::vector<mi_hit> got(N);
+    std::vector<uint8_t> occ(N);
+    isect_fn(&flat.desc, rays.data(), N, got.data(), nullptr);
+    occl_fn(&flat.desc, rays.data(), N, occ.data(), nullptr);
+    int hits = 0, sameFlag = 0, sameT = 0, sameN = 0, sameOcc = 0;
+    for (int i = 0; i < N; ++i) {
+        const mi_ray &r = rays[i];
+        Ray ray(Point3f(r.o[0], r.o[1], r.o[2]), Vector3f(r.d[0], r.d[1], r.d[2]), r.tmax, 0.f);
+        SurfaceInteraction si;
+        bool hit = scene.Intersect(ray, &si);
+        Ray shadow(Point3f(r.o[0], r.o[1], r.o[2]), Vector3f(r.d[0], r.d[1], r.d[2]), r.tmax, 0.f);
+        bool blocked = scene.IntersectP(shadow);
+        hits += hit;
+        sameFlag += hit == (got[i].prim >= 0);
+        sameOcc += blocked == (occ[i] != 0);
+        if (hit && got[i].prim >= 0) {
+            float t = ray.tMax, n[3] = {si.n.x, si.n.y, si.n.z};
+            sameT += std::memcmp(&t, &got[i].t, 4) == 0;
+            sameN += std::memcmp(n, got[i].n, 12) == 0;
+        }
+    }
+    FILE *f = std::fopen(reportFile, "w");
+    if (!f) { Error("PBRT_AMD_HIT_PROBE: cannot write %s", reportFile); return; }
+    std::fprintf(f, "%d %d %d %d %d %d\n", N, hits, sameFlag, sameT, sameN, sameOcc);
+    std::fclose(f);
+}
+
 void WavefrontPathIntegrator::Render(const Scene &scene) {
     std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy, volpath);
     if (!flat->error.empty()) { Error("WavefrontPathIntegrator: %s", flat->error.c_str()); return; }   // pbrt convention: report and return
@@ -859,6 +914,7 @@ void WavefrontPathIntegrator::Render(const Scene &scene) {
         auto oracle_render = (double (*)(const mi_scene_desc *, float *, int, int, int, uint64_t *, const int32_t *))dlsym(lib, "oracle_render");
         if (!oracle_render) { Error("WavefrontPathIntegrator: oracle_render not found in %s", libPath); return; }
         if (const char *probe = std::getenv("PBRT_AMD_TEX_PROBE")) TextureProbe(*flat, lib, probe);
+        if (const char *probe = std::getenv("PBRT_AMD_HIT_PROBE")) HitProbe(scene, *flat, lib, probe);
         uint64_t counters[8] = {0};
         oracle_render(&flat->desc, rgbw.data(), 0, -1, NumSystemCores(), counters, nullptr);
     }

@@ -10,6 +10,7 @@ and must equal what `pbrt_ref` renders for the same file up to the rounding of t
 of a neighbour adds it in a different order: 1 ulp of the sum in < 0.1 % of the pixels)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -112,3 +113,36 @@ def test_texture_nodes_equal_the_reference_classes(name, tmp_path):
     assert len(rows) >= 8
     for node, typ, spectrum, n, same, worst in rows:
         assert n == same, (name, "node", node, "type", typ, "identical", same, "of", n, "largest difference", worst)
+
+
+HIT_PROBE_SCENES = (edge_scenes.NAMES + edge_scenes.TEX_NAMES + edge_scenes.VOL_NAMES + edge_scenes.SSS_NAMES + ["instances2", "heightfield", "nurbs"]
+                    + ["file:cornell", "file:materials", "file:killeroo", "gen:sanmiguel:200000", "gen:bathroom:60000"])
+
+
+@pytest.mark.parametrize("name", HIT_PROBE_SCENES)
+def test_traversal_equals_the_reference_scene_intersect(name, tmp_path):
+    """Rows a7-a12 against the reference's OWN Scene::Intersect / IntersectP on multi-primitive trees (SURVEY.md s.8c lists these as unpinned by any reference
+    test): with PBRT_AMD_HIT_PROBE set the reference-side binding shoots 20 000 random rays (from outside and inside the bounds, finite and infinite
+    tMax, normalised and unnormalised directions) through BVHAccel / TransformedPrimitive / Triangle / Sphere with alpha masks, and the oracle traverses
+    the flattened description with the same rays: hit or miss, the hit distance, the geometric normal and the occlusion flag all bit for bit -- on every
+    edge scene (two-level instancing, spheres, masks, tessellated height fields / NURBS) and on the 66 k-triangle killeroo, a 200 k-triangle
+    San-Miguel-class and a 60 k-triangle bathroom-class scene."""
+    if not os.access(STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+    if name.startswith("file:"):
+        scene = os.path.join(ROOT, "scenes", name[5:] + ".pbrt")
+    elif name.startswith("gen:"):
+        _, kind, tris = name.split(":")
+        scene = str(tmp_path / "g.pbrt")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), kind, "--tris", tris, "--res", "64", "36", "--spp", "1", "--out", scene],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        scene = str(tmp_path / "s.pbrt")
+        open(scene, "w").write(edge_scenes.scene(name))
+    rep = str(tmp_path / "hits.txt")
+    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_HIT_PROBE=rep)
+    r = subprocess.run([STUB, "--quiet", "--quick", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=900)
+    assert os.path.exists(rep), r.stderr[-800:]
+    n, hits, same_flag, same_t, same_n, same_occ = [int(v) for v in open(rep).read().split()]
+    assert n == 20000 and (hits > 1000 or name == "empty")
+    assert same_flag == n and same_occ == n and same_t == hits and same_n == hits, (name, n, hits, same_flag, same_t, same_n, same_occ)
