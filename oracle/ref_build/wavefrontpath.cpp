@@ -886,6 +886,72 @@ static void HitProbe(const Scene &scene, const Flat &flat, void *lib, const char
     std::fclose(f);
 }
 
+// PBRT_AMD_BSDF_PROBE=<report file>: at the first hit of 20 000 random rays the REFERENCE builds the BSDF with its own Material class
+// (SurfaceInteraction::ComputeScatteringFunctions: texture evaluation, bump mapping, lobe list, shading frame) and evaluates BSDF::f, Pdf and
+// Sample_f for a random direction / sample; the backend does the same on the flattened description (oracle_bsdf_at_hit).  One report line: rays,
+// hits with a BSDF, agreeing states, agreeing component counts, agreeing f, agreeing Pdf, agreeing Sample_f results (direction, pdf, value, type).
+static void BsdfProbe(const Scene &scene, const Flat &flat, void *lib, const char *reportFile) {
+    auto fn = (void (*)(const mi_scene_desc *, const mi_ray *, const float *, const float *, int64_t, float *))dlsym(lib, "oracle_bsdf_at_hit");
+    if (!fn) { Error("PBRT_AMD_BSDF_PROBE: the backend has no oracle_bsdf_at_hit"); return; }
+    const int N = 20000;
+    Bounds3f wb = scene.WorldBound();
+    Point3f c; Float rad;
+    wb.BoundingSphere(&c, &rad);
+    if (!(rad > 0)) rad = 1;
+    RNG rng(17);
+    auto U = [&](Float lo, Float hi) { return lo + (hi - lo) * rng.UniformFloat(); };
+    std::vector<mi_ray> rays(N);
+    std::vector<float> wi(3 * (size_t)N), u(2 * (size_t)N), got(14 * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        Point3f target(U(wb.pMin.x, wb.pMax.x), U(wb.pMin.y, wb.pMax.y), U(wb.pMin.z, wb.pMax.z));
+        Point3f o = (i % 2) ? c + (2.5f * rad) * UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat())) : target;
+        Vector3f d = (i % 2) ? Normalize(target - o) : UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat()));
+        Vector3f w = UniformSampleSphere(Point2f(rng.UniformFloat(), rng.UniformFloat()));
+        for (int k = 0; k < 3; ++k) { rays[i].o[k] = o[k]; rays[i].d[k] = d[k]; wi[3 * i + k] = w[k]; }
+        rays[i].tmax = Infinity; rays[i].time = 0;
+        u[2 * i] = rng.UniformFloat(); u[2 * i + 1] = rng.UniformFloat();
+    }
+    fn(&flat.desc, rays.data(), wi.data(), u.data(), N, got.data());
+    MemoryArena arena;
+    int withBsdf = 0, sameState = 0, sameCount = 0, sameF = 0, samePdf = 0, sameSample = 0;
+    for (int i = 0; i < N; ++i) {
+        const mi_ray &r = rays[i];
+        RayDifferential ray(Point3f(r.o[0], r.o[1], r.o[2]), Vector3f(r.d[0], r.d[1], r.d[2]));
+        SurfaceInteraction si;
+        const float *g = &got[14 * (size_t)i];
+        int state = 0;
+        if (scene.Intersect(ray, &si)) {
+            si.ComputeScatteringFunctions(ray, arena, true, TransportMode::Radiance);
+            state = si.bsdf ? 1 : 2;
+        }
+        sameState += state == (int)g[0];
+        if (state == 1 && (int)g[0] == 1) {
+            ++withBsdf;
+            Vector3f w(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+            sameCount += si.bsdf->NumComponents() == (int)g[1];
+            Float f[3];
+            si.bsdf->f(si.wo, w).ToRGB(f);
+            float ff[3] = {f[0], f[1], f[2]};
+            sameF += std::memcmp(ff, g + 2, 12) == 0;
+            float pdf = si.bsdf->Pdf(si.wo, w);
+            samePdf += std::memcmp(&pdf, g + 5, 4) == 0;
+            Vector3f ws; Float ps = 0; BxDFType st = BxDFType(0);
+            Spectrum fsv = si.bsdf->Sample_f(si.wo, &ws, Point2f(u[2 * i], u[2 * i + 1]), &ps, BSDF_ALL, &st);
+            float rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ps > 0) { Float c3[3]; fsv.ToRGB(c3); rec[0] = ws.x; rec[1] = ws.y; rec[2] = ws.z; rec[3] = ps; rec[4] = c3[0]; rec[5] = c3[1]; rec[6] = c3[2]; rec[7] = (float)(int)st; }
+            sameSample += std::memcmp(rec, g + 6, 32) == 0;
+            if (std::getenv("PBRT_AMD_BSDF_PROBE_VERBOSE") && (std::memcmp(rec, g + 6, 32) != 0 || std::memcmp(ff, g + 2, 12) != 0 || std::memcmp(&pdf, g + 5, 4) != 0))
+                std::fprintf(stderr, "ray %d comps %d: f ref %.9g %.9g %.9g got %.9g %.9g %.9g | pdf %.9g / %.9g | sample ref wi %.9g %.9g %.9g pdf %.9g f %.9g %.9g %.9g type %g got wi %.9g %.9g %.9g pdf %.9g f %.9g %.9g %.9g type %g\n",
+                             i, (int)g[1], ff[0], ff[1], ff[2], g[2], g[3], g[4], pdf, g[5], rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13]);
+        }
+        arena.Reset();
+    }
+    FILE *f = std::fopen(reportFile, "w");
+    if (!f) { Error("PBRT_AMD_BSDF_PROBE: cannot write %s", reportFile); return; }
+    std::fprintf(f, "%d %d %d %d %d %d %d\n", N, withBsdf, sameState, sameCount, sameF, samePdf, sameSample);
+    std::fclose(f);
+}
+
 void WavefrontPathIntegrator::Render(const Scene &scene) {
     std::unique_ptr<Flat> flat = FlattenScene(scene, *camera, *sampler, maxDepth, rrThreshold, pixelBounds, lightStrategy, volpath);
     if (!flat->error.empty()) { Error("WavefrontPathIntegrator: %s", flat->error.c_str()); return; }   // pbrt convention: report and return
@@ -915,6 +981,7 @@ void WavefrontPathIntegrator::Render(const Scene &scene) {
         if (!oracle_render) { Error("WavefrontPathIntegrator: oracle_render not found in %s", libPath); return; }
         if (const char *probe = std::getenv("PBRT_AMD_TEX_PROBE")) TextureProbe(*flat, lib, probe);
         if (const char *probe = std::getenv("PBRT_AMD_HIT_PROBE")) HitProbe(scene, *flat, lib, probe);
+        if (const char *probe = std::getenv("PBRT_AMD_BSDF_PROBE")) BsdfProbe(scene, *flat, lib, probe);
         uint64_t counters[8] = {0};
         oracle_render(&flat->desc, rgbw.data(), 0, -1, NumSystemCores(), counters, nullptr);
     }

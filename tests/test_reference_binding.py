@@ -146,3 +146,26 @@ def test_traversal_equals_the_reference_scene_intersect(name, tmp_path):
     n, hits, same_flag, same_t, same_n, same_occ = [int(v) for v in open(rep).read().split()]
     assert n == 20000 and (hits > 1000 or name == "empty")
     assert same_flag == n and same_occ == n and same_t == hits and same_n == hits, (name, n, hits, same_flag, same_t, same_n, same_occ)
+
+
+@pytest.mark.parametrize("name", edge_scenes.NAMES + edge_scenes.TEX_NAMES + edge_scenes.VOL_NAMES + edge_scenes.SSS_NAMES + ["instances2", "file:materials", "file:killeroo", "file:cornell"])
+def test_bsdfs_at_hits_equal_the_reference_material_classes(name, tmp_path):
+    """Rows a13-a16 against the reference's OWN Material / BSDF classes: with PBRT_AMD_BSDF_PROBE set the reference-side binding builds the BSDF at the first hit
+    of 20 000 random rays with SurfaceInteraction::ComputeScatteringFunctions (texture evaluation, bump mapping, the material's lobe list, the shading
+    frame; every material incl. mix, uber with opacity, subsurface boundaries) and evaluates BSDF::f, Pdf and Sample_f for a random direction / sample;
+    the oracle does the same on the flattened description (oracle_bsdf_at_hit): hit state (miss / BSDF / null BSDF), number of components, f, Pdf and the
+    sampled direction, pdf, value and lobe type -- all bit for bit."""
+    if not os.access(STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+    if name.startswith("file:"):
+        scene = os.path.join(ROOT, "scenes", name[5:] + ".pbrt")
+    else:
+        scene = str(tmp_path / "s.pbrt")
+        open(scene, "w").write(edge_scenes.scene(name))
+    rep = str(tmp_path / "bsdf.txt")
+    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_BSDF_PROBE=rep)
+    r = subprocess.run([STUB, "--quiet", "--quick", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=900)
+    assert os.path.exists(rep), r.stderr[-800:]
+    n, with_bsdf, same_state, same_count, same_f, same_pdf, same_sample = [int(v) for v in open(rep).read().split()]
+    assert n == 20000 and same_state == n and (with_bsdf > 1000 or name == "empty")
+    assert same_count == with_bsdf and same_f == with_bsdf and same_pdf == with_bsdf and same_sample == with_bsdf, (name, with_bsdf, same_count, same_f, same_pdf, same_sample)
