@@ -784,6 +784,10 @@ class WavefrontPathIntegrator : public Integrator {   // core/integrator.h:53-58
 static void TextureProbe(const Flat &flat, void *lib, const char *reportFile) {
     auto tex_eval = (void (*)(const mi_scene_desc *, int32_t, const mi_tex_query *, int64_t, float *))dlsym(lib, "oracle_texture_eval");
     if (!tex_eval) { Error("PBRT_AMD_TEX_PROBE: the backend has no oracle_texture_eval"); return; }
+    if (flat.desc.n_textures == 0) {   // no textured material or mask: the description carries no node table (constant parameters were folded into mi_material)
+        if (FILE *e = std::fopen(reportFile, "w")) std::fclose(e);
+        return;
+    }
     const int N = 2048;
     std::vector<mi_tex_query> q(N);
     RNG rng(7);
