@@ -552,6 +552,14 @@ int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
  * requests per second -- the memory-side ceiling of a BVH interior step (the traversal kernels are bound by the request rate of incoherent
  * 16-byte loads, not by HBM bandwidth: DESIGN.md s.5). */
 int mi_gather_rate(mi_ctx *ctx, uint64_t bytes, int loads_per_record, double *grequests_per_s);
+/* Measurement aid for the NEXT traversal layout (no rendering kernel uses the pattern yet): the same chain of dependent random 64-byte record
+ * fetches as mi_gather_rate(..., 4, ...), issued quad-cooperatively -- the four lanes of a quad fetch the four 16-byte words of ONE record in
+ * one instruction (16 cache lines per wave instruction instead of 64).  mode 0: the plain per-lane pattern with its results written out;
+ * mode 1: the quad address pattern alone (every lane consumes what it loaded); mode 2: the complete exchange -- loads land in LDS through
+ * the LDS-DMA path (global_load_lds_dwordx4), every lane reads its own record back with 4 x ds_read_b128.  Rate in 1e9 lane requests (16 B)
+ * per second.  lanes_equal / lanes_total (may be NULL): how many lanes end with exactly the chain state of the plain pattern -- all of them
+ * for modes 0 and 2 (mode 1 walks other chains by construction). */
+int mi_gather_rate_coop(mi_ctx *ctx, uint64_t bytes, int mode, double *grequests_per_s, int64_t *lanes_equal, int64_t *lanes_total);
 
 /* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
 

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_gather_rate_coop", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -292,6 +292,15 @@ class Context:
         L.mi_gather_rate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
         self._chk(L.mi_gather_rate(self._ctx, C.c_uint64(int(nbytes)), int(loads_per_record), C.byref(v)), "mi_gather_rate")
         return float(v.value)
+
+    def gather_rate_coop(self, nbytes, mode):
+        """mi_gather_rate_coop: the 4 x 16 B record chain issued quad-cooperatively (mode 0 plain, 1 quad pattern, 2 quad + LDS exchange);
+        returns (1e9 lane requests / s, lanes equal to the plain chain, lanes)"""
+        v, eq, tot = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        L = device_lib()
+        L.mi_gather_rate_coop.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._chk(L.mi_gather_rate_coop(self._ctx, C.c_uint64(int(nbytes)), int(mode), C.byref(v), C.byref(eq), C.byref(tot)), "mi_gather_rate_coop")
+        return float(v.value), int(eq.value), int(tot.value)
 
     # ---- stage-level entry points
     def texture_eval(self, node, queries):

@@ -375,6 +375,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     static_assert(!(FAST && C8), "one lean variant at a time");
     typedef typename std::conditional<C8, TravTypes8C, typename std::conditional<QN, TravTypesQ, TravTypes<WIDE, INST, FAST>>::type>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
+#if PT_COOP_NODE_FETCH
+    __shared__ uint4 coop_stage[QN ? PT_BLOCK * 4 : 1];   // experiment build: 4 KiB per wave (pt_scene.h, CoopFetchNodesQ)
+    uint4 *const coopStage = coop_stage + (QN ? 256u * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u);
+#endif
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
     st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
@@ -453,7 +457,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                         // the branch-free step needs the top of the stack inside the LDS part; a deep lane sends the wave through the general step
                         if (__any(wantNode && st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD)) { if (wantNode) FastNodeStep<COUNT, true, true>(sc, ts, st, &tc); }
                         else if (wantNode) FastNodeStep<COUNT, true, false>(sc, ts, st, &tc);
-                    } else if (wantNode) {
+                    }
+#if PT_COOP_NODE_FETCH
+                    else if constexpr (QN) {
+                        CoopFetchNodesQ(sc.nodesq, wantNode ? ts.cur : 0u, __ballot(wantNode), coopStage, lane);   // every lane of the wave
+                        if (wantNode) TravNodeStepQCoop<COUNT>(ts, st, &tc, coopStage, lane);
+                    }
+#endif
+                    else if (wantNode) {
                         if constexpr (QN) TravNodeStepQ<COUNT>(sc, ts, st, &tc);
                         else if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
                         else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
@@ -3195,6 +3206,125 @@ int mi_gather_rate(mi_ctx *c, uint64_t bytes, int loads_per_record, double *greq
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     buf.release();
+    *grequests_per_s = best;
+    return 0;
+}
+// ---- the same chain of dependent random 64-byte record fetches, issued QUAD-COOPERATIVELY (measurement aid for the next traversal layout;
+// no rendering kernel uses this yet).  k_gather_probe reaches ~1.4 lane requests per clock and CU even on an L1-resident buffer, a quarter of
+// the 64 B/clk the L1 delivers to coalesced loads: every lane of a 16-byte-per-lane load touches its own cache line.  Here the four lanes of a
+// quad fetch the four 16-byte words of ONE record in one instruction (16 lines per wave instruction instead of 64); four such instructions cover
+// the records of all 64 lanes.
+//   MODE 1  "quad":      the address pattern only -- every lane consumes what it loaded (its word of four other lanes' records);
+//   MODE 2  "quad_lds":  the complete exchange -- the loads land in LDS through the LDS-DMA path (global_load_lds_dwordx4: wave-uniform
+//                        base + lane x 16, so a quad's words of one record are contiguous there), and every lane reads ITS record back with
+//                        4 x ds_read_b128 (word order rotated per group of four lanes: conflict-free).  Same per-lane results as
+//                        k_gather_probe<4>, which the host side checks.
+}   // extern "C"
+#ifndef PT_HOST_EMU   /* 64-lane exchange + LDS-DMA: nothing a one-lane x86 build of these sources (tools/hostemu) could mean */
+typedef __attribute__((address_space(3))) void *LdsPtr;
+typedef const __attribute__((address_space(1))) void *GlobalPtr;
+template <int MODE>
+__global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_coop(const uint4 *buf, uint32_t nrec, int iters, uint32_t *out_s, uint32_t *out_acc) {
+    __shared__ uint4 stage[PT_BLOCK / 64][4][64];   // per wave: 4 instructions x 64 lanes x 16 B = 4 KiB
+    const uint32_t tid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t s = tid * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t rec = (uint32_t)(((uint64_t)s * nrec) >> 32);
+        uint4 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // instruction k serves the records of lanes 16 k .. 16 k + 15: lane L fetches word L & 3 of lane (L >> 2) + 16 k's record
+            const uint32_t owner = (lane >> 2) + 16u * k;
+            const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)rec);
+            const uint4 *src = buf + (size_t)r * 4 + (lane & 3u);
+            if (MODE == 1) w[k] = *src;
+            else __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)&stage[__builtin_amdgcn_readfirstlane(wave)][k][0], 16, 0, 0);
+        }
+        uint4 a, b, c, d;
+        if (MODE == 1) {
+            Pin(w[0]); Pin(w[1]); Pin(w[2]); Pin(w[3]);
+            a = w[0]; b = w[1]; c = w[2]; d = w[3];
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes of this wave have landed (nothing else orders a ds_read behind them)
+            const uint4 *mine = &stage[wave][lane >> 4][(lane & 15u) * 4];   // this lane's record: instruction lane / 16, slot lane % 16, 4 words
+            const uint32_t rot = (lane >> 2) & 3u;                          // word order rotated per group of four lanes: 16 lanes hit 16 distinct 4-bank groups
+            uint4 t0 = mine[(0 + rot) & 3], t1 = mine[(1 + rot) & 3], t2 = mine[(2 + rot) & 3], t3 = mine[(3 + rot) & 3];
+            Pin(t0); Pin(t1); Pin(t2); Pin(t3);
+            a = rot == 0 ? t0 : rot == 1 ? t3 : rot == 2 ? t2 : t1;   // word j sits in t[(j - rot) & 3]
+            b = rot == 0 ? t1 : rot == 1 ? t0 : rot == 2 ? t3 : t2;
+            c = rot == 0 ? t2 : rot == 1 ? t1 : rot == 2 ? t0 : t3;
+            d = rot == 0 ? t3 : rot == 1 ? t2 : rot == 2 ? t1 : t0;
+        }
+        acc += a.y ^ b.z ^ c.w ^ d.x;
+        s = s * 1664525u + a.x;
+    }
+    out_s[tid] = s; out_acc[tid] = acc;
+}
+#endif
+// k_gather_probe<4> with its per-lane results written out (the reference the quad_lds exchange is checked against)
+__global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_ref(const uint4 *buf, uint32_t nrec, int iters, uint32_t *out_s, uint32_t *out_acc) {
+    const uint32_t tid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    uint32_t s = tid * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t rec = (uint32_t)(((uint64_t)s * nrec) >> 32);
+        const uint4 *p = buf + (size_t)rec * 4;
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        Pin(a); Pin(b); Pin(c); Pin(d);
+        acc += a.y ^ b.z ^ c.w ^ d.x;
+        s = s * 1664525u + a.x;
+    }
+    out_s[tid] = s; out_acc[tid] = acc;
+}
+extern "C" {
+int mi_gather_rate_coop(mi_ctx *c, uint64_t bytes, int mode, double *grequests_per_s, int64_t *lanes_equal, int64_t *lanes_total) {
+    if (!c || !grequests_per_s || bytes < 4096 || mode < 0 || mode > 2) return fail("mi_gather_rate_coop: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nrec = (uint32_t)std::min<uint64_t>(bytes / 64, 0xffffffffull);
+    const size_t nthreads = (size_t)c->gridBlocks * PT_BLOCK;
+    DevBuf buf, outS, outA, refS, refA;
+    if (buf.alloc((size_t)nrec * 64) || outS.alloc(nthreads * 4) || outA.alloc(nthreads * 4) || refS.alloc(nthreads * 4) || refA.alloc(nthreads * 4)) return -1;
+    {
+        std::vector<uint32_t> h((size_t)nrec * 16);
+        uint32_t x = 2463534242u;
+        for (auto &w : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; w = x; }
+        HIP_TRY(hipMemcpyAsync(buf.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    const int iters = 2048;
+    const dim3 grid(c->gridBlocks), block(PT_BLOCK);
+    double best = 0;
+    for (int it = 0; it < 4; ++it) {   // first launch = warm-up
+        HIP_TRY(hipEventRecord(a, c->stream));
+        if (mode == 0) hipLaunchKernelGGL(k_gather_probe_ref, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
+#ifndef PT_HOST_EMU
+        else if (mode == 1) hipLaunchKernelGGL(k_gather_probe_coop<1>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
+        else hipLaunchKernelGGL(k_gather_probe_coop<2>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
+#else
+        else return fail("mi_gather_rate_coop: modes 1 and 2 need 64-lane waves");
+#endif
+        HIP_TRY(hipEventRecord(b, c->stream));
+        HIP_TRY(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        if (it > 0 && ms > 0) best = std::max(best, (double)nthreads * iters * 4 / (ms * 1e-3) * 1e-9);
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (lanes_equal && lanes_total) {   // the exchange of mode 2 must reproduce the plain probe lane for lane (mode 1 walks other chains by construction)
+        hipLaunchKernelGGL(k_gather_probe_ref, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, refS.as<uint32_t>(), refA.as<uint32_t>());
+        std::vector<uint32_t> hs(nthreads), ha(nthreads), rs(nthreads), ra(nthreads);
+        HIP_TRY(hipMemcpyAsync(hs.data(), outS.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(ha.data(), outA.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(rs.data(), refS.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(ra.data(), refA.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        int64_t eq = 0;
+        for (size_t i = 0; i < nthreads; ++i) eq += hs[i] == rs[i] && ha[i] == ra[i];
+        *lanes_equal = eq; *lanes_total = (int64_t)nthreads;
+    }
     *grequests_per_s = best;
     return 0;
 }

@@ -536,11 +536,17 @@ struct TravStateQ : TravState {
         cur = sc.n_nodes ? 0u : TRAV_DONE;
     }
 };
+template <bool COUNT> PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, TravStack &st, TraceCounters *cnt);
 template <bool COUNT>
 PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, TravStack &st, TraceCounters *cnt) {
     const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
     uint4 w0 = w[0], w1 = w[1], w2 = w[2], ch = w[3];
     Pin(w0); Pin(w1); Pin(w2); Pin(ch);
+    TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
+}
+// the step on the node's four 16-byte words, however they were fetched
+template <bool COUNT>
+PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, TravStack &st, TraceCounters *cnt) {
     if (COUNT) ++cnt->nodes;
     const uint32_t wd[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, ch.x, ch.y, ch.z, ch.w};
     Float t[4];
@@ -557,6 +563,47 @@ PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, TravStack &st, Tra
     if (nh > 1) st.push(c1, t1);
     ts.cur = c0;
 }
+
+#ifndef PT_COOP_NODE_FETCH
+#define PT_COOP_NODE_FETCH 0   /* experiment build (-DPT_COOP_NODE_FETCH=1, lib/variants only): quad-cooperative node fetch through LDS, below */
+#endif
+#if PT_COOP_NODE_FETCH
+// ------------------------------------------------------------------ EXPERIMENT (not in the product library; written at the end of round 2, not yet run on a GPU)
+// Quad-cooperative fetch of the quantised nodes.  The plain step issues 4 x 16-byte loads per lane, every lane on its own cache line: 64
+// lines per wave instruction, and the CU serves ~1.4 such lane requests per clock whatever the cache level (mi_gather_rate) -- a quarter of
+// what the L1 delivers to coalesced loads.  Here the four lanes of a quad fetch the four words of ONE node in one instruction (16 lines per
+// wave instruction); instruction k serves the nodes of lanes 16 k .. 16 k + 15 and is skipped when none of them takes a step.  The words go
+// straight to LDS (LDS-DMA: wave-uniform base + lane x 16, so a node's words are contiguous there) and every stepping lane reads its node
+// back with 4 x ds_read_b128, word order rotated per group of four lanes (conflict-free).  mi_gather_rate_coop measures the bare pattern.
+// All 64 lanes call CoopFetchNodesQ (wave-uniform control flow); `stage` = this wave's uint4[4][64] (4 KiB of LDS).
+typedef __attribute__((address_space(3))) void *PtLdsPtr;
+typedef const __attribute__((address_space(1))) void *PtGlobalPtr;
+PT_DEV void CoopFetchNodesQ(const BVH4QNode *nodes, uint32_t myNode /* any valid node (0) for lanes that take no step */, unsigned long long want,
+                            uint4 *stage /* wave-uniform */, uint32_t lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t owner = (lane >> 2) + 16u * k;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)myNode);
+        if ((want >> (16 * k)) & 0xffffull) {   // wave-uniform
+            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + r) + (lane & 3u);
+            __builtin_amdgcn_global_load_lds((PtGlobalPtr)src, (PtLdsPtr)(stage + 64 * k), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing else orders the ds_reads below behind the LDS-DMA writes
+}
+template <bool COUNT>
+PT_DEV void TravNodeStepQCoop(TravStateQ &ts, TravStack &st, TraceCounters *cnt, const uint4 *stage, uint32_t lane) {
+    const uint4 *mine = stage + 64 * (lane >> 4) + 4 * (lane & 15u);
+    const uint32_t rot = (lane >> 2) & 3u;
+    uint4 t0 = mine[rot], t1 = mine[(1 + rot) & 3], t2 = mine[(2 + rot) & 3], t3 = mine[(3 + rot) & 3];   // word j sits in t[(j - rot) & 3]
+    Pin(t0); Pin(t1); Pin(t2); Pin(t3);
+    const uint4 w0 = rot == 0 ? t0 : rot == 1 ? t3 : rot == 2 ? t2 : t1;
+    const uint4 w1 = rot == 0 ? t1 : rot == 1 ? t0 : rot == 2 ? t3 : t2;
+    const uint4 w2 = rot == 0 ? t2 : rot == 1 ? t1 : rot == 2 ? t0 : t3;
+    const uint4 ch = rot == 0 ? t3 : rot == 1 ? t2 : rot == 2 ? t1 : t0;
+    TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
+}
+#endif
 
 // ------------------------------------------------------------------ two-level instancing (the host's default since round 2; PBRT_AMD_INSTANCING=0 flattens)
 // TransformedPrimitive::Intersect / IntersectP (core/primitive.cpp:76-111) inside the per-lane state machine: meeting an instance
