@@ -27,12 +27,13 @@ ctx.close()
 PY
 timeout 900 python bench.py > gpurun_out/r03a_bench.json 2> gpurun_out/r03a_bench.err; tail -c 1500 gpurun_out/r03a_bench.json
 # 4. (only if the experiment build exists: `make -C pbrt-v3-distributed_amd variant NAME=coop FLAGS="-DPT_COOP_NODE_FETCH=1 -DPT_GRID_PER_CU=4"`
-#    and, for the occupancy-matched baseline, `... NAME=grid4 FLAGS="-DPT_GRID_PER_CU=4"`)
+#    and, for the occupancy-matched baseline, `... NAME=grid4 FLAGS="-DPT_GRID_PER_CU=4"`; a third one with shorter LDS stacks so that five
+#    blocks fit a CU: `... NAME=coop16 FLAGS="-DPT_COOP_NODE_FETCH=1 -DPT_LDS_STACK=16 -DPT_GRID_PER_CU=5"`)
 #    the quad-cooperative node fetch inside k_trace<..., QN>: hit-level and image-level parity first, then the 16-spp C3 probe of both builds
 V=$R/pbrt-v3-distributed_amd/lib/variants
 if [ -f $V/coop.so ]; then
   PBRT_AMD_DEVICE_LIB=$V/coop.so timeout 600 python -m pytest tests -m gpu -x -q -k "closest_hit or render_vs_reference or baseline_configs or li_per_sample or edge_cases" 2>&1 | tail -5 | tee gpurun_out/r03a_coop_parity.txt
-  for v in grid4 coop; do
+  for v in grid4 coop coop16; do
     [ -f $V/$v.so ] || continue
     PBRT_AMD_DEVICE_LIB=$V/$v.so timeout 300 python bench.py --spp 16 --steps 2 --warmup 1 --cpu-seconds 0 --cpu-port-seconds 0 --traffic none 2> gpurun_out/r03a_ab_$v.err | python -c "
 import json, sys; d = json.loads(sys.stdin.read()); print('$v', d['value'], d['kernel_ms_per_step'], d['roofline'].get('request_rate', {}).get('achieved_Greq_per_s'))" | tee -a gpurun_out/r03a_ab_coop.txt
