@@ -220,6 +220,8 @@ def scene(name):
         t = _cornell(80, 56)
         t = t.replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float cropwindow" [.15 .8 .2 .9]')
         return t.replace('Integrator "path" "integer maxdepth" [5]', 'Integrator "path" "integer maxdepth" [5] "integer pixelbounds" [20 58 14 40]')
+    if name == "c5_crop":       # configs[4]'s regime end to end: 3840 x 2160 film (m = 12), 512 spp => 33-bit Sobol' indices; a 24 x 20 pixel crop far from the origin
+        return _cornell(3840, 2160, 512).replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float cropwindow" [.55 .55625 .45 .45926]')
     if name == "clamp":         # Film maxsampleluminance
         return _cornell().replace('"string filename" "cornell.pfm"', '"string filename" "cornell.pfm" "float maxsampleluminance" [1.5]')
     if name == "spectra":       # "blackbody" and "spectrum" parameters (inline samples and SPD files): parser.cpp:662-690 -> RGB through the CIE tables
@@ -243,6 +245,7 @@ def scene(name):
 NAMES = ["infinite", "infinite_only", "envmap", "envmap_power", "spot", "instances", "spheres", "dof", "crop", "clamp", "empty", "onetri", "spectra"]
 
 # ---- textured variants: image / procedural textures, mappings, bump maps, alpha masks
+C5_NAMES = ["c5_crop"]
 TEX = os.path.join(ROOT, "scenes", "textures")
 _TEXHEAD = '''LookAt 0 2.4 -6  0 0.7 0  0 1 0
 Camera "perspective" "float fov" [38]

@@ -806,3 +806,26 @@ def test_camera_rays_match_reference_classes():
                 assert np.array_equal(a.view(np.uint32), r[k].view(np.uint32)), (c, k)
             else:   # the lens sample goes through the device's own sin / cos (ConcentricSampleDisk): bit-exact expected, 1e-6 stated
                 assert (a == r[k]).mean() >= 0.9 and np.allclose(a, r[k], rtol=1e-6, atol=1e-6), (c, k)
+
+
+
+def test_c5_regime_crop_tile_sharded():
+    """configs[4]'s regime through the whole pipeline: a 24 x 21 pixel crop of a 3840 x 2160 film at 512 spp (log2 resolution 12: the Sobol' index of a
+    sample needs 33 bits; test_sobol_index_33_bit_regime_c5 covers the index alone) against the reference's own render of the same crop, and the
+    8-rank tile-sharded form of it (rank r of 8 rendered separately, films summed) against the single render."""
+    sc = pa.Scene(text=edge_scenes.scene("c5_crop"))
+    assert sc.info["spp"] == 512
+    ctx = pa.Context(sc)
+    ctx.render()
+    whole = ctx.film()
+    frac, relmse = ol.image_metrics(sc.film_image(whole), pa.read_pfm(os.path.join(G, "edge_c5_crop.pfm")))
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
+    acc = np.zeros_like(whole)
+    for r in range(8):
+        ctx.film_clear(); ctx.render(rank=r, world=8)
+        acc += ctx.film()
+    ctx.close()
+    own_only = whole[..., 3] == sc.info["spp"]   # at 512 spp about a fifth of the pixels also get a neighbour's sample landing exactly on their edge
+    assert own_only.mean() > 0.6
+    assert np.array_equal(acc[own_only].view(np.uint32), whole[own_only].view(np.uint32))
+    assert np.allclose(acc, whole, rtol=1e-6, atol=1e-7)
