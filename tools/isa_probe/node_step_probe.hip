@@ -147,3 +147,54 @@ extern "C" __global__ void bvh8_full(const N8F *nodes, const Ray *rays, Out *out
     }
     Out o; finish<8>(t, h, c, o); out[threadIdx.x] = o;
 }
+
+// ---- round-3 candidates on the product's node (pt_bvh4q.h: 16-bit planes on one grid, folded test t = q A + B with per-ray A / Bn / Bf)
+struct RayQ { float Ax, Ay, Az, Bnx, Bny, Bnz, Bfx, Bfy, Bfz, tMax; int negx, negy, negz; uint32_t cur; };
+// (a) today's shape: one ray per lane, 4 x 16-byte loads, four children tested per lane, hit children sorted and pushed by the lane
+struct N4QF { uint16_t lo[3][4], hi[3][4]; uint32_t child[4]; };   // 64 B, plane-major
+extern "C" __global__ void bvh4q_lane(const N4QF *nodes, const RayQ *rays, Out *out) {
+    RayQ r = rays[threadIdx.x];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(nodes + r.cur);
+    uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2], ch = wp[3];
+    const uint32_t w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    const uint32_t nx0 = r.negx ? w[6] : w[0], nx1 = r.negx ? w[7] : w[1], fx0 = r.negx ? w[0] : w[6], fx1 = r.negx ? w[1] : w[7];
+    const uint32_t ny0 = r.negy ? w[8] : w[2], ny1 = r.negy ? w[9] : w[3], fy0 = r.negy ? w[2] : w[8], fy1 = r.negy ? w[3] : w[9];
+    const uint32_t nz0 = r.negz ? w[10] : w[4], nz1 = r.negz ? w[11] : w[5], fz0 = r.negz ? w[4] : w[10], fz1 = r.negz ? w[5] : w[11];
+    float t[4]; bool h[4]; uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 16 * (k & 1);
+        const uint32_t wnx = k < 2 ? nx0 : nx1, wny = k < 2 ? ny0 : ny1, wnz = k < 2 ? nz0 : nz1, wfx = k < 2 ? fx0 : fx1, wfy = k < 2 ? fy0 : fy1, wfz = k < 2 ? fz0 : fz1;
+        float e = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)((wnx >> sh) & 65535u), r.Ax, r.Bnx), __builtin_fmaf((float)((wny >> sh) & 65535u), r.Ay, r.Bny)), __builtin_fmaf((float)((wnz >> sh) & 65535u), r.Az, r.Bnz));
+        float x = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)((wfx >> sh) & 65535u), r.Ax, r.Bfx), __builtin_fmaf((float)((wfy >> sh) & 65535u), r.Ay, r.Bfy)), __builtin_fmaf((float)((wfz >> sh) & 65535u), r.Az, r.Bfz));
+        h[k] = (e <= x) && (e < r.tMax) && (x > 0) && c[k] != 0xffffffffu; t[k] = e;
+    }
+    Out o; finish<4>(t, h, c, o); out[threadIdx.x] = o;
+}
+// (b) one ray per QUAD: child-major node (child j = six 16-bit planes + its reference = ONE 16-byte word), lane j of the quad loads and tests
+// child j -- one coalesced load instruction per step (a quad reads one 64-byte line) -- the hits are ranked across the quad with quad-permute
+// DPP moves, the nearest becomes the quad's next node, the others are stored far-to-near by their own lanes (the quad shares one stack).
+struct N4QC { struct { uint16_t lo[3], hi[3]; uint32_t child; } c[4]; };   // 64 B, child-major
+struct OutQ { uint32_t next, n; };
+template <int CTRL> __device__ __forceinline__ float quadf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> __device__ __forceinline__ uint32_t quadu(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+extern "C" __global__ void bvh4q_quad(const N4QC *nodes, const RayQ *rays, OutQ *out, uint32_t *stack /* per quad: 24 entries */, float *stack_t) {
+    const uint32_t lane = threadIdx.x, j = lane & 3u, quad = lane >> 2;
+    RayQ r = rays[quad];   // the quad's ray, replicated in its four lanes
+    const uint4 w = reinterpret_cast<const uint4 *>(nodes + r.cur)[j];
+    const uint32_t lox = w.x & 65535u, loy = w.x >> 16, loz = w.y & 65535u, hix = w.y >> 16, hiy = w.z & 65535u, hiz = w.z >> 16, child = w.w;
+    const float e = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)(r.negx ? hix : lox), r.Ax, r.Bnx), __builtin_fmaf((float)(r.negy ? hiy : loy), r.Ay, r.Bny)), __builtin_fmaf((float)(r.negz ? hiz : loz), r.Az, r.Bnz));
+    const float x = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)(r.negx ? lox : hix), r.Ax, r.Bfx), __builtin_fmaf((float)(r.negy ? loy : hiy), r.Ay, r.Bfy)), __builtin_fmaf((float)(r.negz ? loz : hiz), r.Az, r.Bfz));
+    const bool hit = (e <= x) && (e < r.tMax) && (x > 0) && child != 0xffffffffu;
+    const float key = hit ? e : INF;
+    // rank among the quad's four keys (ties: the lower child slot first, as the per-lane sort network resolves them)
+    const float k1 = quadf<0x39>(key), k2 = quadf<0x4e>(key), k3 = quadf<0x93>(key);   // quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2]: lanes j+1, j+2, j+3 (mod 4)
+    const uint32_t j1 = (j + 1) & 3u, j2 = (j + 2) & 3u, j3 = (j + 3) & 3u;
+    const uint32_t rank = (uint32_t)(k1 < key || (k1 == key && j1 < j)) + (uint32_t)(k2 < key || (k2 == key && j2 < j)) + (uint32_t)(k3 < key || (k3 == key && j3 < j));
+    const uint32_t hits4 = (uint32_t)hit + (uint32_t)(k1 < INF) + (uint32_t)(k2 < INF) + (uint32_t)(k3 < INF);
+    // nearest hit child -> every lane of the quad (the lane of rank 0 contributes it, the others 0; OR over the quad)
+    uint32_t nxt = (hit && rank == 0) ? child : 0u;
+    nxt |= quadu<0x39>(nxt); nxt |= quadu<0x4e>(nxt);
+    if (hit && rank > 0) { const uint32_t slot = quad * 24u + (hits4 - 1u - rank); stack[slot] = child; stack_t[slot] = e; }   // far to near: rank hits4-1 at the bottom
+    if (j == 0) { OutQ o; o.next = hits4 ? nxt : 0xffffffffu; o.n = hits4 ? hits4 - 1u : 0u; out[quad] = o; }
+}
