@@ -3217,7 +3217,7 @@ int mi_gather_rate(mi_ctx *c, uint64_t bytes, int loads_per_record, double *greq
 //   MODE 1  "quad":      the address pattern only -- every lane consumes what it loaded (its word of four other lanes' records);
 //   MODE 2  "quad_lds":  the complete exchange -- the loads land in LDS through the LDS-DMA path (global_load_lds_dwordx4: wave-uniform
 //                        base + lane x 16, so a quad's words of one record are contiguous there), and every lane reads ITS record back with
-//                        4 x ds_read_b128 (word order rotated per group of four lanes: conflict-free).  Same per-lane results as
+//                        4 x ds_read_b128 (the producers rotate the word order per group of four owner lanes: conflict-free reads, no selects).  Same per-lane results as
 //                        k_gather_probe<4>, which the host side checks.
 }   // extern "C"
 #ifndef PT_HOST_EMU   /* 64-lane exchange + LDS-DMA: nothing a one-lane x86 build of these sources (tools/hostemu) could mean */
@@ -3237,7 +3237,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_coop(const uint4 *buf
         for (int k = 0; k < 4; ++k) {   // instruction k serves the records of lanes 16 k .. 16 k + 15: lane L fetches word L & 3 of lane (L >> 2) + 16 k's record
             const uint32_t owner = (lane >> 2) + 16u * k;
             const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)rec);
-            const uint4 *src = buf + (size_t)r * 4 + (lane & 3u);
+            // MODE 2: the producers rotate -- position j of the owner's LDS slot receives word (j + rot) & 3, rot = (owner >> 2) & 3 = (lane >> 4) & 3 -- so that
+            // the owner's four reads (positions (i - rot) & 3: 16 lanes on 16 distinct 16-byte bank groups) return words 0..3 in order, no selects
+            const uint4 *src = buf + (size_t)r * 4 + (MODE == 1 ? (lane & 3u) : ((lane & 3u) + (lane >> 4)) & 3u);
             if (MODE == 1) w[k] = *src;
             else __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)&stage[__builtin_amdgcn_readfirstlane(wave)][k][0], 16, 0, 0);
         }
@@ -3247,14 +3249,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_coop(const uint4 *buf
             a = w[0]; b = w[1]; c = w[2]; d = w[3];
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes of this wave have landed (nothing else orders a ds_read behind them)
-            const uint4 *mine = &stage[wave][lane >> 4][(lane & 15u) * 4];   // this lane's record: instruction lane / 16, slot lane % 16, 4 words
-            const uint32_t rot = (lane >> 2) & 3u;                          // word order rotated per group of four lanes: 16 lanes hit 16 distinct 4-bank groups
-            uint4 t0 = mine[(0 + rot) & 3], t1 = mine[(1 + rot) & 3], t2 = mine[(2 + rot) & 3], t3 = mine[(3 + rot) & 3];
-            Pin(t0); Pin(t1); Pin(t2); Pin(t3);
-            a = rot == 0 ? t0 : rot == 1 ? t3 : rot == 2 ? t2 : t1;   // word j sits in t[(j - rot) & 3]
-            b = rot == 0 ? t1 : rot == 1 ? t0 : rot == 2 ? t3 : t2;
-            c = rot == 0 ? t2 : rot == 1 ? t1 : rot == 2 ? t0 : t3;
-            d = rot == 0 ? t3 : rot == 1 ? t2 : rot == 2 ? t1 : t0;
+            const uint4 *mine = &stage[wave][lane >> 4][(lane & 15u) * 4];   // this lane's record: instruction lane / 16, slot lane % 16, 4 positions
+            const uint32_t rot = (lane >> 2) & 3u;
+            a = mine[(0 - rot) & 3u]; b = mine[(1 - rot) & 3u]; c = mine[(2 - rot) & 3u]; d = mine[(3 - rot) & 3u];
+            Pin(a); Pin(b); Pin(c); Pin(d);
         }
         acc += a.y ^ b.z ^ c.w ^ d.x;
         s = s * 1664525u + a.x;

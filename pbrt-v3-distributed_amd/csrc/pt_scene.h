@@ -574,7 +574,7 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
 // what the L1 delivers to coalesced loads.  Here the four lanes of a quad fetch the four words of ONE node in one instruction (16 lines per
 // wave instruction); instruction k serves the nodes of lanes 16 k .. 16 k + 15 and is skipped when none of them takes a step.  The words go
 // straight to LDS (LDS-DMA: wave-uniform base + lane x 16, so a node's words are contiguous there) and every stepping lane reads its node
-// back with 4 x ds_read_b128, word order rotated per group of four lanes (conflict-free).  mi_gather_rate_coop measures the bare pattern.
+// back with 4 x ds_read_b128; the producers rotate the word order per group of four owner lanes (conflict-free reads, words arrive in order).  mi_gather_rate_coop measures the bare pattern.
 // All 64 lanes call CoopFetchNodesQ (wave-uniform control flow); `stage` = this wave's uint4[4][64] (4 KiB of LDS).
 typedef __attribute__((address_space(3))) void *PtLdsPtr;
 typedef const __attribute__((address_space(1))) void *PtGlobalPtr;
@@ -585,7 +585,7 @@ PT_DEV void CoopFetchNodesQ(const BVH4QNode *nodes, uint32_t myNode /* any valid
         const uint32_t owner = (lane >> 2) + 16u * k;
         const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)myNode);
         if ((want >> (16 * k)) & 0xffffull) {   // wave-uniform
-            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + r) + (lane & 3u);
+            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + r) + (((lane & 3u) + (lane >> 4)) & 3u);   // producers rotate: position j <- word (j + rot_owner) & 3
             __builtin_amdgcn_global_load_lds((PtGlobalPtr)src, (PtLdsPtr)(stage + 64 * k), 16, 0, 0);
         }
     }
@@ -594,13 +594,9 @@ PT_DEV void CoopFetchNodesQ(const BVH4QNode *nodes, uint32_t myNode /* any valid
 template <bool COUNT>
 PT_DEV void TravNodeStepQCoop(TravStateQ &ts, TravStack &st, TraceCounters *cnt, const uint4 *stage, uint32_t lane) {
     const uint4 *mine = stage + 64 * (lane >> 4) + 4 * (lane & 15u);
-    const uint32_t rot = (lane >> 2) & 3u;
-    uint4 t0 = mine[rot], t1 = mine[(1 + rot) & 3], t2 = mine[(2 + rot) & 3], t3 = mine[(3 + rot) & 3];   // word j sits in t[(j - rot) & 3]
-    Pin(t0); Pin(t1); Pin(t2); Pin(t3);
-    const uint4 w0 = rot == 0 ? t0 : rot == 1 ? t3 : rot == 2 ? t2 : t1;
-    const uint4 w1 = rot == 0 ? t1 : rot == 1 ? t0 : rot == 2 ? t3 : t2;
-    const uint4 w2 = rot == 0 ? t2 : rot == 1 ? t1 : rot == 2 ? t0 : t3;
-    const uint4 ch = rot == 0 ? t3 : rot == 1 ? t2 : rot == 2 ? t1 : t0;
+    const uint32_t rot = (lane >> 2) & 3u;   // word i sits at position (i - rot) & 3: 16 lanes of a pass on 16 distinct 16-byte bank groups, words in order
+    uint4 w0 = mine[(0 - rot) & 3u], w1 = mine[(1 - rot) & 3u], w2 = mine[(2 - rot) & 3u], ch = mine[(3 - rot) & 3u];
+    Pin(w0); Pin(w1); Pin(w2); Pin(ch);
     TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
 }
 #endif
