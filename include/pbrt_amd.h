@@ -493,8 +493,14 @@ int mi_bssrdf_eval(int device_ordinal, const mi_bssrdf_table *table, float eta, 
 typedef struct mi_hg_query { float g, wo[3], wi[3], u[2]; } mi_hg_query;
 typedef struct mi_hg_result { float p, wi_s[3], p_s; } mi_hg_result;
 int mi_phase_hg(int device_ordinal, const mi_hg_query *queries, int64_t n, mi_hg_result *out);
-/* which traversal kernels the uploaded scene runs: out[0] = 0 general BVH4 steps, 1 round-1 128-byte BVH8, 2 lean BVH4 steps,
- * 3 lean steps over the 80-byte compressed BVH8, 4 two-level (instanced) scene, 5 general steps over the 64-byte quantised BVH4;
+/* Stage-level libm: the float routines the path calls (std::sin / cos / acos / atan / atan2 / exp / log on Float: core/sampling.cpp:93-150,
+ * core/geometry.h:1463-1486, core/microfacet.cpp:146-163, media/homogeneous.cpp:56, ...) as the device evaluates them (csrc/pt_libm.h: the
+ * operation sequences of the glibc the reference links against).  out[i] = fn(a[i]) (atan2f: fn(a[i], b[i]); sincosf: out = sin, out2 = cos). */
+enum { MI_LIBM_SINF = 0, MI_LIBM_COSF = 1, MI_LIBM_SINCOSF = 2, MI_LIBM_EXPF = 3, MI_LIBM_LOGF = 4, MI_LIBM_ACOSF = 5, MI_LIBM_ATANF = 6, MI_LIBM_ATAN2F = 7 };
+int mi_libm_eval(int device_ordinal, int fn, const float *a, const float *b, int64_t n, float *out, float *out2);
+/* which traversal kernels the uploaded scene runs: out[0] = 0 general steps over the full-precision 128-byte BVH4 (PBRT_AMD_TRACE=general),
+ * 4 two-level (instanced) scene over the same nodes, 5 general steps over the 64-byte quantised BVH4 (the default for single-level scenes;
+ * values 1-3 named layouts measured slower in round 2 and removed from the library);
  * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */
 int mi_trace_info(mi_ctx *ctx, int64_t out[4]);
 
@@ -552,14 +558,6 @@ int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
  * requests per second -- the memory-side ceiling of a BVH interior step (the traversal kernels are bound by the request rate of incoherent
  * 16-byte loads, not by HBM bandwidth: DESIGN.md s.5). */
 int mi_gather_rate(mi_ctx *ctx, uint64_t bytes, int loads_per_record, double *grequests_per_s);
-/* Measurement aid for the NEXT traversal layout (no rendering kernel uses the pattern yet): the same chain of dependent random 64-byte record
- * fetches as mi_gather_rate(..., 4, ...), issued quad-cooperatively -- the four lanes of a quad fetch the four 16-byte words of ONE record in
- * one instruction (16 cache lines per wave instruction instead of 64).  mode 0: the plain per-lane pattern with its results written out;
- * mode 1: the quad address pattern alone (every lane consumes what it loaded); mode 2: the complete exchange -- loads land in LDS through
- * the LDS-DMA path (global_load_lds_dwordx4), every lane reads its own record back with 4 x ds_read_b128.  Rate in 1e9 lane requests (16 B)
- * per second.  lanes_equal / lanes_total (may be NULL): how many lanes end with exactly the chain state of the plain pattern -- all of them
- * for modes 0 and 2 (mode 1 walks other chains by construction). */
-int mi_gather_rate_coop(mi_ctx *ctx, uint64_t bytes, int mode, double *grequests_per_s, int64_t *lanes_equal, int64_t *lanes_total);
 
 /* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
 
@@ -574,17 +572,12 @@ int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *r
 /* BVHAccel::IntersectP (bvh.cpp:702-738) */
 int mi_intersect_p(mi_ctx *ctx, const mi_ray *rays, int64_t n, uint8_t *occluded);
 
-/* Host-only groundwork of the NEXT traversal layout (csrc/pt_bvh8.h; no kernel uses it yet): collapses the reference's BVH2 to
- * 8-wide nodes with 8-bit quantised child boxes (one 128-byte line per node), checks every quantised box against its reference
- * box in exact arithmetic, and runs the per-ray traversal state machine of the future kernel ON THE HOST for `rays` (closest hit,
- * or first hit found when any_hit != 0).  hits (may be NULL): prim / t / barycentrics as mi_intersect reports them.
- * stats: [0] BVH8 nodes, [1] leaf references, [2] depth, [3] deepest stack seen, [4] primitives covered, [5] nodes visited,
- * [6] primitives tested, [7] rays that hit.  No GPU needed. */
-int mi_bvh8_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
-/* quantisation (exact arithmetic) + host emulation of the traversal over the 64-byte quantised BVH4 (csrc/pt_bvh4q.h) */
+/* Host-only check of the 64-byte quantised BVH4 the default traversal kernels walk (csrc/pt_bvh4q.h): collapses the reference's BVH2, quantises
+ * the child boxes, checks every quantised box against its reference box in exact arithmetic, and runs the kernel's per-ray state machine ON THE
+ * HOST for `rays` (closest hit, or first hit found when any_hit != 0).  hits (may be NULL): prim / t / barycentrics as mi_intersect reports them.
+ * stats: [0] nodes, [1] leaf references, [2] depth, [3] deepest stack seen, [4] primitives covered, [5] nodes visited, [6] primitives tested,
+ * [7] rays that hit.  No GPU needed. */
 int mi_bvh4q_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
-/* the same checks + host emulation for the 80-byte compressed 8-wide layout the traversal kernels use (csrc/pt_bvh8c.h) */
-int mi_bvh8c_validate(const mi_scene_desc *scene, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]);
 /* Sphere::Intersect (shapes/sphere.cpp:48-162) of ray i against spheres[i] (explicit records, no scene): hit flag, tHit and the
  * world-space interaction's p, pError, n -- for the FullSphere / PartialSphere reintersection vectors of the reference's tests */
 typedef struct mi_sphere_hit { int32_t hit; float t; float p[3], p_error[3], n[3]; } mi_sphere_hit;

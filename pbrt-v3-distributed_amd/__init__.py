@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_gather_rate_coop", "mi_bvh4_validate", "mi_bvh8_validate", "mi_bvh8c_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_li",
 ]
 
@@ -106,8 +106,6 @@ def device_lib():
         L.mi_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mi_timing_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi_bvh4_validate.argtypes = [C.c_void_p, C.c_void_p]
-        L.mi_bvh8_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
-        L.mi_bvh8c_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_bvh4q_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_trace_info.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_film_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -248,8 +246,7 @@ class Context:
     def trace_info(self):
         out = np.zeros(4, dtype=np.int64)
         self._chk(device_lib().mi_trace_info(self._ctx, _ptr(out)), "mi_trace_info")
-        names = ["general BVH4 steps", "128-byte quantised BVH8 (round 1)", "lean BVH4 steps", "lean steps over the 80-byte compressed BVH8", "two-level BVH4 (instanced scene)",
-                 "general steps over the 64-byte quantised BVH4"]
+        names = {0: "general steps over the 128-byte BVH4", 4: "two-level BVH4 (instanced scene)", 5: "general steps over the 64-byte quantised BVH4"}
         return {"mode": int(out[0]), "name": names[int(out[0])], "node_bytes": int(out[1]), "nodes": int(out[2]), "lds_stack_entries": int(out[3])}
 
     def counters(self):
@@ -292,15 +289,6 @@ class Context:
         L.mi_gather_rate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
         self._chk(L.mi_gather_rate(self._ctx, C.c_uint64(int(nbytes)), int(loads_per_record), C.byref(v)), "mi_gather_rate")
         return float(v.value)
-
-    def gather_rate_coop(self, nbytes, mode):
-        """mi_gather_rate_coop: the 4 x 16 B record chain issued quad-cooperatively (mode 0 plain, 1 quad pattern, 2 quad + LDS exchange);
-        returns (1e9 lane requests / s, lanes equal to the plain chain, lanes)"""
-        v, eq, tot = C.c_double(0), C.c_int64(0), C.c_int64(0)
-        L = device_lib()
-        L.mi_gather_rate_coop.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        self._chk(L.mi_gather_rate_coop(self._ctx, C.c_uint64(int(nbytes)), int(mode), C.byref(v), C.byref(eq), C.byref(tot)), "mi_gather_rate_coop")
-        return float(v.value), int(eq.value), int(tot.value)
 
     # ---- stage-level entry points
     def texture_eval(self, node, queries):
@@ -365,17 +353,16 @@ TEX_QUERY_DTYPE = np.dtype([("p", np.float32, 3), ("uv", np.float32, 2), ("dpdx"
 SPHERE_HIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("p", np.float32, 3), ("p_error", np.float32, 3), ("n", np.float32, 3)])   # mi_sphere_hit
 
 
-def bvh8_validate(scene, rays=None, any_hit=False, want_hits=True, compressed=False):
-    """Host-only: build the quantised BVH8 (compressed=True: the 80-byte layout of csrc/pt_bvh8c.h the kernels traverse), check it, and run
+def bvh4q_validate(scene, rays=None, any_hit=False, want_hits=True):
+    """Host-only: build the 64-byte quantised BVH4 of csrc/pt_bvh4q.h (what the default traversal kernels walk), check it, and run
     the kernel's per-ray state machine on the host for `rays` -> (hits or None, dict of statistics).  No GPU needed."""
     st = np.zeros(8, dtype=np.int64)
     L = device_lib()
     n = 0 if rays is None else len(rays)
     r = np.ascontiguousarray(rays, dtype=RAY_DTYPE) if n else None
     hits = np.zeros(n, dtype=HIT_DTYPE) if (n and want_hits) else None
-    fn = L.mi_bvh4q_validate if compressed == "bvh4q" else (L.mi_bvh8c_validate if compressed else L.mi_bvh8_validate)
-    if fn(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
-        raise RuntimeError("mi_bvh8_validate: %s" % L.mi_last_error().decode())
+    if L.mi_bvh4q_validate(scene.desc, _ptr(r) if n else None, n, 1 if any_hit else 0, _ptr(hits) if hits is not None else None, _ptr(st)) != 0:
+        raise RuntimeError("mi_bvh4q_validate: %s" % L.mi_last_error().decode())
     keys = ["nodes", "leaf_refs", "depth", "max_stack", "prims", "nodes_visited", "prims_tested", "rays_hit"]
     return hits, dict(zip(keys, [int(v) for v in st]))
 
@@ -418,6 +405,22 @@ def phase_hg(queries, device=0):
     if L.mi_phase_hg(device, _ptr(q), len(q), _ptr(out)) != 0:
         raise RuntimeError("mi_phase_hg: %s" % L.mi_last_error().decode())
     return out
+
+
+LIBM_FUNCS = {"sinf": 0, "cosf": 1, "sincosf": 2, "expf": 3, "logf": 4, "acosf": 5, "atanf": 6, "atan2f": 7}
+
+
+def libm_eval(fn, a, b=None, device=0):
+    """mi_libm_eval: routine `fn` of csrc/pt_libm.h on the device over float32 arrays -> out (sincosf: (sin, cos))"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.zeros(len(a), dtype=np.float32)
+    out2 = np.zeros(len(a), dtype=np.float32) if fn == "sincosf" else None
+    L = device_lib()
+    L.mi_libm_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    if L.mi_libm_eval(device, LIBM_FUNCS[fn], _ptr(a), None if b is None else _ptr(b), len(a), _ptr(out), None if out2 is None else _ptr(out2)) != 0:
+        raise RuntimeError("mi_libm_eval: %s" % L.mi_last_error().decode())
+    return (out, out2) if out2 is not None else out
 
 
 def bxdf_eval(rows, device=0):

@@ -31,8 +31,7 @@
 #include "pt_shade.h"
 #include "pt_material.h"
 #include "pt_volume.h"
-#include "pt_bvh8c.h"
-#include "pt_trace_fast.h"
+#include "pt_bvh4q.h"
 #include "sobol_tables.inc"
 
 __constant__ DevTex c_tex;
@@ -357,28 +356,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #endif
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
-// WIDE: A/B layout -- sc.nodes holds the quantised BVH8 of pt_bvh8.h instead of the BVH4 (PBRT_AMD_BVH8=1; see TravNodeStep8)
 // INST: two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
-// FAST: the lean straight-line steps of pt_trace_fast.h (all-triangle scenes without masks / instances; the default there)
-template <bool WIDE, bool INST, bool FAST = false> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <> struct TravTypes<true, false, false> { typedef TravState8 State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
-template <> struct TravTypes<false, true, false> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <> struct TravTypes<false, false, true> { typedef FastRay State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <> struct TravTypes<true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 struct TravTypesQ { typedef TravStateQ State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-struct TravTypes8C { typedef Fast8Ray State; typedef TravStack8 Stack; typedef StackEntry8 Entry; typedef LdsStackEntry8 LdsEntry; enum { LDS = PT_LDS_STACK8 }; };
-// C8: the lean steps over the 80-byte compressed 8-wide nodes (pt_bvh8c.h) -- the default for plain all-triangle scenes
 // QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool WIDE = false, bool INST = false, bool FAST = false, bool C8 = false, bool QN = false>
+// (the default for single-level scenes; the full-precision 128-byte nodes serve two-level scenes and PBRT_AMD_TRACE=general)
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
-    static_assert(!QN || (!WIDE && !INST && !FAST && !C8), "quantised nodes: single-level BVH4, general steps");
-    static_assert(!(FAST || C8) || (!SPHERES && !ALPHA && !WIDE && !INST), "the fast steps cover plain all-triangle scenes");   // (they assume PT_STACK_T == 0: an experiment build with entry distances must not select them)
-    static_assert(!(FAST && C8), "one lean variant at a time");
-    typedef typename std::conditional<C8, TravTypes8C, typename std::conditional<QN, TravTypesQ, TravTypes<WIDE, INST, FAST>>::type>::type TT;
+    static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
+    typedef typename std::conditional<QN, TravTypesQ, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
-#if PT_COOP_NODE_FETCH
-    __shared__ uint4 coop_stage[QN ? PT_BLOCK * 4 : 1];   // experiment build: 4 KiB per wave (pt_scene.h, CoopFetchNodesQ)
-    uint4 *const coopStage = coop_stage + (QN ? 256u * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u);
-#endif
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
     st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
@@ -421,9 +409,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     float4 o4 = MODE == 0 ? ps.rec[slot].ray_o : (MODE == 1 ? ps.nee[slot].mi_o : ps.nee[slot].sh_o);
                     float4 d4 = MODE == 0 ? ps.rec[slot].ray_d : (MODE == 1 ? ps.nee[slot].mi_d : ps.nee[slot].sh_d);
                     if (MODE == 1) lightNum = __float_as_uint(d4.w);
-                    if constexpr (C8) Fast8RayInit(sc, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
-                    else if constexpr (FAST) FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, ts, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
-                    else ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
+                    ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), MODE == 1 ? PT_INFINITY : o4.w, st);
                     active = true;
                     ++nrays;
                 }
@@ -452,38 +438,18 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     bool wantNode = active && ts.atNode();
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
-                    if constexpr (C8) { if (wantNode) Fast8NodeStep<COUNT>(sc, ts, st, &tc); }
-                    else if constexpr (FAST) {
-                        // the branch-free step needs the top of the stack inside the LDS part; a deep lane sends the wave through the general step
-                        if (__any(wantNode && st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD)) { if (wantNode) FastNodeStep<COUNT, true, true>(sc, ts, st, &tc); }
-                        else if (wantNode) FastNodeStep<COUNT, true, false>(sc, ts, st, &tc);
-                    }
-#if PT_COOP_NODE_FETCH
-                    else if constexpr (QN) {
-                        CoopFetchNodesQ(sc.nodesq, wantNode ? ts.cur : 0u, __ballot(wantNode), coopStage, lane);   // every lane of the wave
-                        if (wantNode) TravNodeStepQCoop<COUNT>(ts, st, &tc, coopStage, lane);
-                    }
-#endif
-                    else if (wantNode) {
+                    if (wantNode) {
                         if constexpr (QN) TravNodeStepQ<COUNT>(sc, ts, st, &tc);
-                        else if constexpr (WIDE) TravNodeStep8<COUNT>(sc, ts, st, &tc);
                         else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
                     int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if constexpr (C8) { if (active && ts.atLeaf()) Fast8LeafStep<MODE == 2, COUNT>(sc, ts, st, &tc); }
-            else if constexpr (FAST) {
-                const bool wantLeaf = active && ts.atLeaf();
-                if (__any(wantLeaf && st.sp > PT_LDS_STACK)) { if (wantLeaf) FastLeafStep<MODE == 2, COUNT, true>(sc, ts, st, &tc); }
-                else if (wantLeaf) FastLeafStep<MODE == 2, COUNT, false>(sc, ts, st, &tc);
-            } else if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
+            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             if (active && ts.done()) {
-                if constexpr (C8) { if (ts.prim != TRAV_MISS) ts.prim = sc.trav2prim[ts.prim]; }   // traversal order -> the reference's primitive index
                 if (MODE == 0) {
-                    if constexpr (FAST || C8) ps.rec[slot].hit = make_uint2(ts.prim, ts.prim != TRAV_MISS ? __float_as_uint(ts.tMax) : 0u);
-                    else ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                    ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                     if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
                     uint32_t key = sc.n_materials;                                   // escaped rays
                     if (ts.prim != TRAV_MISS) {
@@ -500,9 +466,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                 } else {
                     const DevLight &light = sc.lights[lightNum];
                     RGB Li(0.f);
-                    V3 ro, rd;   // the MIS ray (the lean state does not keep it)
-                    if constexpr (FAST || C8) { float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d; ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z); }
-                    else { ro = ts.o; rd = ts.d; }
+                    const V3 ro = ts.o, rd = ts.d;   // the MIS ray
                     if (ts.prim != TRAV_MISS) {
                         if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
                             V3 p0, p1, p2;
@@ -523,7 +487,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                         float4 sg = ps.nee[slot].pad[0];
                         if (sg.x != 0 || sg.y != 0 || sg.z != 0) {
                             Float th = PT_INFINITY;
-                            if (ts.prim != TRAV_MISS) { if constexpr (FAST || C8) th = ts.tMax; else th = ts.tHit; }
+                            if (ts.prim != TRAV_MISS) th = ts.tHit;
                             Li = Li * ExpRGB(-RGB(sg.x, sg.y, sg.z) * mn(th * rd.Length(), PT_MAX_FLOAT));
                         }
                     }
@@ -1119,112 +1083,51 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
     }
 }
 
-// the triangle records permuted for the three dominant ray axes: copy kz holds (v[kx], v[ky], v[kz], w) with kx = kz + 1, ky = kx + 1 (mod 3)
-__global__ void __launch_bounds__(PT_BLOCK) k_permute_tris(const float4 *in, float4 *out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * PT_BLOCK) {
-        float4 v = in[i];
-        out[i] = make_float4(v.y, v.z, v.x, v.w);           // kz = 0
-        out[n + i] = make_float4(v.z, v.x, v.y, v.w);       // kz = 1
-        out[2 * n + i] = v;                                 // kz = 2
-    }
-}
-
 // ---- stage-level kernels (parity tests): one lane per input record
-// plain per-ray loop over the lean steps (the stage-level entry points run what the render kernels run)
-template <bool ANY>
-PT_DEV bool TraverseFast(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit, TraceCounters *cnt) {
-    FastRay fr;
-    FastRayInit(sc, sc.tri_perm, sc.tri_perm_stride, fr, o, d, tMax, st);
-    uint32_t steps = 0;
-    while (!fr.done()) {
-        if (++steps > (1u << 20)) { cnt->nodes = 0xffffffffu; fr.prim = TRAV_MISS; break; }   // non-termination guard (reported by the kernel)
-        const bool safe = st.sp > PT_LDS_STACK - PT_FAST_STACK_GUARD;
-        if (fr.atNode()) { if (safe) FastNodeStep<false, true, true>(sc, fr, st, cnt); else FastNodeStep<false, true, false>(sc, fr, st, cnt); }
-        else { if (safe) FastLeafStep<ANY, false, true>(sc, fr, st, cnt); else FastLeafStep<ANY, false, false>(sc, fr, st, cnt); }
-    }
-    *tHit = fr.prim != TRAV_MISS ? fr.tMax : 0; *primHit = fr.prim;
-    return fr.prim != TRAV_MISS;
-}
-template <bool ANY>
-PT_DEV bool TraverseC8(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack8 &st, Float *tHit, uint32_t *primHit, TraceCounters *cnt) {
-    Fast8Ray fr;
-    Fast8RayInit(sc, fr, o, d, tMax, st);
-    uint32_t steps = 0;
-    while (!fr.done()) {
-        if (++steps > (1u << 20)) { cnt->nodes = 0xffffffffu; fr.prim = TRAV_MISS; break; }   // non-termination guard (reported by the kernel)
-        if (fr.atNode()) Fast8NodeStep<false>(sc, fr, st, cnt);
-        else Fast8LeafStep<ANY, false>(sc, fr, st, cnt);
-    }
-    *tHit = fr.prim != TRAV_MISS ? fr.tMax : 0;
-    *primHit = fr.prim != TRAV_MISS ? sc.trav2prim[fr.prim] : TRAV_MISS;
-    return fr.prim != TRAV_MISS;
-}
-__global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect_c8(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
-    __shared__ StackEntry8 lds_stack[PT_LDS_STACK8 * PT_BLOCK];
-    TravStack8 st;
-    st.lds = (LdsStackEntry8 *)&lds_stack[threadIdx.x];
-    st.spill = reinterpret_cast<StackEntry8 *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
-    TraceCounters tc = {0, 0};
+// mi_intersect / mi_intersect_p run the SHIPPED traversal kernels (k_trace<0> / k_trace<2>, whichever instance the uploaded scene selects):
+// k_stage_fill_rays writes the rays into the path records and the segmented queue, k_stage_collect_hits turns PathRec::hit back into mi_hit
+// (barycentrics and normal recomputed from the hit primitive, as k_shade does).
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_fill_rays(PathState ps, const mi_ray *rays, int64_t n, int anyHit) {
     for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
-        mi_ray r = rays[i];
-        V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
-        Float t;
-        uint32_t prim;
-        if (occluded) occluded[i] = TraverseC8<true>(sc, o, d, r.tmax, st, &t, &prim, &tc) ? 1 : 0;
-        else {
-            mi_hit h;
-            h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
-            if (TraverseC8<false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
+        const mi_ray r = rays[i];
+        const float4 o4 = make_float4(r.o[0], r.o[1], r.o[2], r.tmax), d4 = make_float4(r.d[0], r.d[1], r.d[2], 0);
+        ps.rec[i].L = make_float4(0, 0, 0, 0);
+        ps.rec[i].hit = make_uint2(TRAV_MISS, 0u);
+        ps.rec[i].pad0 = TRAV_NO_INSTANCE;
+        if (anyHit) { ps.nee[i].sh_o = o4; ps.nee[i].sh_d = d4; ps.nee[i].sh_c = make_float4(1, 1, 1, 0); }
+        else { ps.rec[i].ray_o = o4; ps.rec[i].ray_d = d4; }
+        const uint32_t seg = (uint32_t)(i & 7), pos = (uint32_t)(i >> 3);
+        (anyHit ? ps.q_shadow : ps.q_ext[0])[(size_t)seg * ps.seg_cap + pos] = (uint32_t)i;
+    }
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_collect_hits(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
+        if (occluded) { occluded[i] = ps.rec[i].L.x == 0 ? 1 : 0; continue; }   // k_trace<2> adds sh_c = 1 to L when the segment is unoccluded
+        mi_hit h;
+        h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
+        const uint2 hr = ps.rec[i].hit;
+        if (hr.x != TRAV_MISS) {
+            const uint32_t prim = hr.x;
+            h.prim = (int32_t)prim; h.t = __uint_as_float(hr.y);
+            if (ps.rec[i].pad0 == TRAV_NO_INSTANCE) {   // (hits inside an instance: primitive and distance only)
+                const mi_ray r = rays[i];
+                V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
                 V3 p0, p1, p2;
                 uint32_t tf;
                 LoadTri(sc, prim, &p0, &p1, &p2, &tf);
                 TriHit th;
                 Isect is;
-                TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
-                BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
-                h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
-                h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
-            }
-            hits[i] = h;
-        }
-    }
-    if (tc.nodes == 0xffffffffu) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], 1ull);
-}
-template <bool FAST>
-__global__ void __launch_bounds__(PT_BLOCK) k_stage_intersect(DevScene sc, PathState ps, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
-    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
-    TravStack st;
-    st.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
-    st.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
-    TraceCounters tc = {0, 0};
-    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
-        mi_ray r = rays[i];
-        V3 o(r.o[0], r.o[1], r.o[2]), d(r.d[0], r.d[1], r.d[2]);
-        Float t;
-        uint32_t prim;
-        if (occluded) {
-            occluded[i] = (FAST ? TraverseFast<true>(sc, o, d, r.tmax, st, &t, &prim, &tc) : Traverse<true, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) ? 1 : 0;
-        } else {
-            mi_hit h;
-            h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0; h.n[0] = h.n[1] = h.n[2] = 0;
-            if (FAST ? TraverseFast<false>(sc, o, d, r.tmax, st, &t, &prim, &tc) : Traverse<false, false>(sc, o, d, r.tmax, st, &t, &prim, &tc)) {
-                V3 p0, p1, p2;
-                uint32_t tf;
-                LoadTri(sc, prim, &p0, &p1, &p2, &tf);
-                TriHit th;
-                Isect is;
-                if (tf & TRI_FLAG_SPHERE) { is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim); th.t = t; th.b0 = th.b1 = th.b2 = 0; }
+                if (tf & TRI_FLAG_SPHERE) { is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim); th.t = h.t; th.b0 = th.b1 = th.b2 = 0; }
                 else {
                     TriangleTest(p0, p1, p2, o, d, PT_INFINITY, &th);
                     BuildIsect(GeomTables(sc), prim, p0, p1, p2, th, d, &is);
                 }
-                h.prim = (int32_t)prim; h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
+                h.t = th.t; h.b0 = th.b0; h.b1 = th.b1; h.b2 = th.b2;
                 h.n[0] = is.n.x; h.n[1] = is.n.y; h.n[2] = is.n.z;
             }
-            hits[i] = h;
         }
+        hits[i] = h;
     }
-    if (tc.nodes == 0xffffffffu) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], 1ull);
 }
 __global__ void k_stage_triangles(const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1314,7 +1217,6 @@ struct mi_ctx {
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
-    // A/B layout: BVH8 traversal (pt_bvh8.h; PBRT_AMD_BVH8=1 at upload time, all-triangle scenes without masks only)
     bool hasInst = false;                    // two-level scene (the host's default): the k_trace / k_shade / k_shade_vol INST instances
     const DevInstance *instPtr = nullptr;
     bool hasNullMat = false;                 // some mesh has no material (medium interfaces): paths may outlive max_depth + 1 wavefront iterations
@@ -1323,12 +1225,6 @@ struct mi_ctx {
     size_t tilesCount = 0;
     bool rayBin = false;                     // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
-    bool useC8 = false;                      // lean steps over the compressed 8-wide BVH (pt_bvh8c.h): the default for plain scenes
-    bool useFast = false;                    // lean traversal steps (pt_trace_fast.h): all-triangle scenes without masks / instances
-    bool useBvh8 = false;
-    const BVH8Node *nodes8 = nullptr;
-    uint32_t nNodes8 = 0;
-    int stackNeed8 = 0, spill8 = 1;
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSDF-less interfaces / alpha masks / BSSRDF
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
@@ -1644,20 +1540,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         HIP_TRY(hipStreamSynchronize(c->stream));   // insts is a local
         c->instPtr = b.as<DevInstance>();
     }
-    c->useBvh8 = false;
-    {   // A/B layout: the quantised BVH8 next to the BVH4 (the k_trace<..., WIDE> instances read it through a copy of DevScene)
-        const char *e = std::getenv("PBRT_AMD_BVH8");
-        if (e && e[0] == '1' && d->n_bvh_nodes && !c->hasInst) {
-            bvh8::Builder b8;
-            if (!b8.run(d)) return fail("mi_scene_upload: BVH8 build: " + b8.error);
-            DevBuf &b = next();
-            if (upload(c, b, b8.out.data(), b8.out.size() * sizeof(BVH8Node))) return -1;
-            HIP_TRY(hipStreamSynchronize(c->stream));   // b8 is a local
-            c->nodes8 = b.as<BVH8Node>(); c->nNodes8 = (uint32_t)b8.out.size();
-            c->stackNeed8 = 7 * (b8.maxDepth + 1) + 1;
-            c->useBvh8 = true;
-        }
-    }
     // triangle records
     c->hasSpheres = false;
     std::vector<float4> tv(3 * (size_t)d->n_tris);
@@ -1724,26 +1606,13 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         tv[3 * (size_t)t + 2] = make_float4(p2[0], p2[1], p2[2], 0);
     }
     { DevBuf &b = next(); if (upload(c, b, tv.data(), tv.size() * sizeof(float4))) return -1; sc.tri_verts = b.as<float4>(); }
-    // lean traversal (pt_trace_fast.h): plain all-triangle scenes; PBRT_AMD_TRACE=general keeps the general steps (A/B, parity tests of both)
-    c->useFast = c->useC8 = false;
-    {   // Traversal layout.  Round 2 measured five on the 10 M-triangle frame (profiles/r02_*; Msamples/s of the 16 spp probe, all with the
-        // segmented queue counters):
-        //   bvh4q    general steps over the 64-byte quantised BVH4 (pt_bvh4q.h): 4 requests per step       254.5   <- default (single-level scenes)
-        //   general  TravNodeStep / TravLeafStep over the 128-byte BVH4 (round 1): 7 requests per step     214.3   (two-level scenes; PBRT_AMD_TRACE=general)
-        //   bvh4     lean straight-line steps over the 128-byte BVH4 (pt_trace_fast.h)                     209.5   (half the static instructions, MORE executed ones)
-        //   bvh8c    lean steps over the 80-byte compressed BVH8 (pt_bvh8c.h)                              ~185    (5 requests per 8-wide step, 3 x the arithmetic per ray)
-        //   PBRT_AMD_BVH8=1: round 1's 128-byte quantised BVH8                                              ~180
-        // What bounds these kernels is the per-lane vector-memory REQUEST count (profiles/r02_c_*: +3 requests per step = +31 % time; -63 % HBM
-        // traffic, half the instructions, 24 -> 16 waves per CU: no change).  All five are parity-tested (tests/test_gpu_parity.py TRACE_MODES).
+    {   // Traversal layout: the general steps over the 64-byte quantised BVH4 (pt_bvh4q.h; 4 vector-memory requests per interior step) for
+        // every single-level scene -- spheres and alpha masks only touch the leaf step; the full-precision 128-byte nodes (7 requests per
+        // step) serve two-level scenes and PBRT_AMD_TRACE=general.  Round 2 measured both and three more layouts on the 10 M-triangle frame
+        // (lean BVH4, 80-byte compressed BVH8, 128-byte BVH8: all slower, profiles/r02_a_*, r02_b_*; removed from the library in round 3).
         const char *e = std::getenv("PBRT_AMD_TRACE");
-        const bool wantC8 = e && std::strcmp(e, "bvh8c") == 0, wantBvh4 = e && std::strcmp(e, "bvh4") == 0;
-        const char *e8 = std::getenv("PBRT_AMD_BVH8");
-        const bool plain = !(e8 && e8[0] == '1') && !c->hasInst && !c->hasAlpha && !c->hasSpheres && d->n_tris > 0;
-        c->useFast = plain && wantBvh4;
-        c->useC8 = plain && wantC8;
-        // bvh4q: the same general steps with 64-byte quantised nodes -- any single-level scene (spheres and alpha masks only touch the leaf step)
         const bool wantGeneral = e && std::strcmp(e, "general") == 0;
-        c->useQ = !wantGeneral && !wantBvh4 && !wantC8 && !(e8 && e8[0] == '1') && !c->hasInst && d->n_bvh_nodes > 0;
+        c->useQ = !wantGeneral && !c->hasInst && d->n_bvh_nodes > 0;
     }
     sc.nodesq = nullptr;
     if (c->useQ) {
@@ -1754,28 +1623,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         if (upload(c, b, qn.data(), qn.size() * sizeof(BVH4QNode))) return -1;
         HIP_TRY(hipStreamSynchronize(c->stream));   // local
         sc.nodesq = b.as<BVH4QNode>();
-    }
-    sc.nodes8c = nullptr; sc.n_nodes8c = 0; sc.tri_trav = nullptr; sc.trav2prim = nullptr;
-    if (c->useC8) {
-        bvh8c::Builder b8;
-        if (!b8.run(d->bvh_nodes, d->n_bvh_nodes)) return fail("mi_scene_upload: BVH8C build: " + b8.error);
-        if (b8.triOrder.size() != d->n_tris) return fail("mi_scene_upload: BVH8C build lost primitives");
-        { DevBuf &b = next(); if (upload(c, b, b8.out.data(), b8.out.size() * sizeof(BVH8CNode))) return -1; sc.nodes8c = b.p; sc.n_nodes8c = (uint32_t)b8.out.size(); }
-        { DevBuf &b = next(); if (upload(c, b, b8.triOrder.data(), b8.triOrder.size() * sizeof(uint32_t))) return -1; sc.trav2prim = b.as<uint32_t>(); }
-        std::vector<float4> tt(tv.size());
-        for (size_t i = 0; i < b8.triOrder.size(); ++i) for (int k = 0; k < 3; ++k) tt[3 * i + k] = tv[3 * (size_t)b8.triOrder[i] + k];
-        { DevBuf &b = next(); if (upload(c, b, tt.data(), tt.size() * sizeof(float4))) return -1; sc.tri_trav = b.as<float4>(); }
-        HIP_TRY(hipStreamSynchronize(c->stream));   // locals
-        c->stackNeed8 = 7 * (b8.maxDepth + 1) + 1;
-    }
-    sc.tri_perm = nullptr; sc.tri_perm_stride = 0;
-    if (c->useFast) {   // three copies of the records with the vertices permuted for kz = 0, 1, 2 (Permute(p, kx, ky, kz), triangle.cpp:205-209), made on the device
-        DevBuf &b = next();
-        if (b.alloc(3 * tv.size() * sizeof(float4))) return -1;
-        sc.tri_perm = b.as<float4>(); sc.tri_perm_stride = tv.size();
-        unsigned gridp = (unsigned)std::min<size_t>((tv.size() + PT_BLOCK - 1) / PT_BLOCK, 65536);
-        hipLaunchKernelGGL(k_permute_tris, dim3(gridp), dim3(PT_BLOCK), 0, c->stream, sc.tri_verts, b.as<float4>(), tv.size());
-        HIP_TRY(hipGetLastError());
     }
     {   // per-triangle shading records (TriShade): vertex normals + uvs gathered through the index buffer
         std::vector<TriShade> tsd(d->n_tris);
@@ -2229,14 +2076,13 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
         }
     }
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
-    c->spill8 = std::max(1, c->stackNeed8 - PT_LDS_STACK8);
-    {   // one spill area serves whichever traversal runs (BVH4: 4-byte entries, BVH8: 8-byte entries)
-        size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4), words8 = (c->useBvh8 || c->useC8) ? (size_t)c->spill8 * 2 : 0;
-        ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
+    {
+        const size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4);
+        ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * words4);
         c->cursor2 = c->spill2 = nullptr;
         if (c->overlapNee) {
             c->cursor2 = (uint32_t *)A(sizeof(uint32_t) * QSEG * QC_STRIDE);
-            c->spill2 = (uint32_t *)A(sizeof(uint32_t) * (size_t)c->gridBlocks * PT_BLOCK * std::max(words4, words8));
+            c->spill2 = (uint32_t *)A(sizeof(uint32_t) * (size_t)c->gridBlocks * PT_BLOCK * words4);
             if (!c->cursor2 || !c->spill2) return -1;
         }
     }
@@ -2271,46 +2117,21 @@ static void harvest(mi_ctx *c) {
     c->evUsed = 0;
 }
 
+#define LAUNCH_TRACE_I(MODE, ...)                                                                                   \
+    do {                                                                                                            \
+        if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, __VA_ARGS__>), grid, block, 0, st, sc, ps, qin);     \
+        else hipLaunchKernelGGL((k_trace<MODE, false, __VA_ARGS__>), grid, block, 0, st, sc, ps, qin);              \
+    } while (0)
+// template arguments after COUNT: SPHERES, ALPHA, INST, QN
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
-        if (c->hasInst) { /* two-level scenes: the general instance (spheres, masks, instances) */                   \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true, false, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, true, true, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->useBvh8 && !c->hasAlpha && !c->hasSpheres) { /* A/B layout: quantised BVH8 nodes */                 \
-            DevScene sc8 = sc;                                                                                      \
-            sc8.nodes = reinterpret_cast<const BVH4Node *>(c->nodes8);                                              \
-            sc8.n_nodes = c->nNodes8;                                                                               \
-            PathState ps8 = ps;                                                                                     \
-            ps8.spill_per_thread = c->spill8;                                                                       \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, true>), grid, block, 0, st, sc8, ps8, qin);  \
-        } else if (c->useQ && c->hasAlpha) { /* quantised nodes, the general instance (spheres + masks) */                 \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, true, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->useQ && c->hasSpheres) {                                                                              \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->useQ) {                                                                                               \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->hasAlpha) { /* alpha-masked meshes: the general instance (spheres + masks) */                        \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, true, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else if (c->hasSpheres) {                                                                                        \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, true>), grid, block, 0, st, sc, ps, qin);        \
-            else hipLaunchKernelGGL((k_trace<MODE, false, true>), grid, block, 0, st, sc, ps, qin);                 \
-        } else if (c->useC8) { /* the default for plain scenes: lean steps over the 80-byte compressed 8-wide nodes */  \
-            PathState ps8 = ps;                                                                                     \
-            ps8.spill_per_thread = c->spill8;                                                                       \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, false, true>), grid, block, 0, st, sc, ps8, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, false, true>), grid, block, 0, st, sc, ps8, qin);           \
-        } else if (c->useFast) { /* PBRT_AMD_TRACE=bvh4: lean straight-line steps over the BVH4 */                   \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);  \
-            else hipLaunchKernelGGL((k_trace<MODE, false, false, false, false, false, true>), grid, block, 0, st, sc, ps, qin);           \
-        } else {                                                                                                    \
-            if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, false>), grid, block, 0, st, sc, ps, qin);       \
-            else hipLaunchKernelGGL((k_trace<MODE, false, false>), grid, block, 0, st, sc, ps, qin);                \
-        }                                                                                                           \
+        if (c->hasInst) LAUNCH_TRACE_I(MODE, true, true, true, false);        /* two-level scenes: the general instance (spheres, masks, instances) */ \
+        else if (c->useQ && c->hasAlpha) LAUNCH_TRACE_I(MODE, true, true, false, true);     /* quantised nodes; spheres + masks in the leaf step */     \
+        else if (c->useQ && c->hasSpheres) LAUNCH_TRACE_I(MODE, true, false, false, true);                             \
+        else if (c->useQ) LAUNCH_TRACE_I(MODE, false, false, false, true);    /* the default: all-triangle single-level scenes */                      \
+        else if (c->hasAlpha) LAUNCH_TRACE_I(MODE, true, true, false, false); /* PBRT_AMD_TRACE=general: full-precision nodes */                       \
+        else if (c->hasSpheres) LAUNCH_TRACE_I(MODE, true, false, false, false);                                       \
+        else LAUNCH_TRACE_I(MODE, false, false, false, false);                                                         \
     } while (0)
 // One pass of the wavefront pipeline over the paths generated by `pass`.
 static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm) {
@@ -2600,11 +2421,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film_add(float4 *dst, const float4
 
 int mi_trace_info(mi_ctx *c, int64_t out[4]) {
     if (!c || !out || !c->haveScene) return fail("mi_trace_info: no scene");
-    int mode = c->hasInst ? 4 : (c->useC8 ? 3 : (c->useFast ? 2 : ((c->useBvh8 && !c->hasAlpha && !c->hasSpheres) ? 1 : (c->useQ ? 5 : 0))));
+    int mode = c->hasInst ? 4 : (c->useQ ? 5 : 0);
     out[0] = mode;
-    out[1] = mode == 3 ? (int64_t)sizeof(BVH8CNode) : (mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128);
-    out[2] = mode == 3 ? c->sc.n_nodes8c : (mode == 1 ? c->nNodes8 : c->sc.n_nodes);
-    out[3] = (mode == 3 || mode == 1) ? PT_LDS_STACK8 : PT_LDS_STACK;
+    out[1] = mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128;
+    out[2] = c->sc.n_nodes;
+    out[3] = PT_LDS_STACK;
     return 0;
 }
 
@@ -2767,76 +2588,6 @@ int mi_sphere_intersect(int device, const mi_sphere *spheres, const mi_ray *rays
     HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(mi_sphere_hit), hipMemcpyDeviceToHost));
     return 0;
 }
-// Host-only groundwork of the next traversal layout (pt_bvh8.h): collapse the reference's BVH2 to BVH8 with quantised child boxes
-// (every quantised box checked against its reference box in exact arithmetic), then run the per-ray state machine of the future
-// kernel on the host for the given rays.  hits may be NULL (statistics only).  No GPU involved.
-int mi_bvh8_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
-    if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8_validate: null argument");
-    for (int i = 0; i < 8; ++i) stats[i] = 0;
-    if (d->n_instances) return fail("mi_bvh8_validate: two-level scenes are not handled (host flattening is the device's mode)");
-    bvh8::Builder bb;
-    if (!bb.run(d)) return fail("mi_bvh8_validate: " + bb.error);
-    // structural checks: every primitive in exactly one leaf reference, children inside the quantised box their parent holds for them
-    std::vector<uint8_t> covered(d->n_tris, 0);
-    int64_t leaves = 0;
-    std::vector<uint32_t> todo;
-    if (!bb.out.empty()) todo.push_back(0);
-    while (!todo.empty()) {
-        uint32_t ni = todo.back(); todo.pop_back();
-        if (ni >= bb.out.size()) return fail("mi_bvh8_validate: child index out of range");
-        const BVH8Node &nd = bb.out[ni];
-        for (int k = 0; k < 8; ++k) {
-            uint32_t c = nd.child[k];
-            if (c == bvh8::EMPTY) continue;
-            double lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) { lo[a] = (double)nd.p[a] + nd.qlo[a][k] * (double)nd.s[a]; hi[a] = (double)nd.p[a] + nd.qhi[a][k] * (double)nd.s[a]; }
-            if (c & bvh8::LEAF) {
-                uint32_t first = c & bvh8::FIRST_MASK, count = ((c >> 27) & 0xfu) + 1;
-                ++leaves;
-                if (first + count > d->n_tris) return fail("mi_bvh8_validate: bad leaf reference");
-                for (uint32_t t = first; t < first + count; ++t) {
-                    if (covered[t]++) return fail("mi_bvh8_validate: primitive referenced twice");
-                    const uint32_t *v = d->tri_indices + 3 * (size_t)t;
-                    if (v[0] == MI_PRIM_SPHERE) continue;
-                    for (int kk = 0; kk < 3; ++kk)
-                        for (int a = 0; a < 3; ++a) {
-                            double x = d->P[3 * (size_t)v[kk] + a];
-                            if (x < lo[a] || x > hi[a]) return fail("mi_bvh8_validate: primitive outside its quantised leaf box");
-                        }
-                }
-            } else {
-                const BVH8Node &ch = bb.out[c];
-                for (int j = 0; j < 8; ++j) {
-                    if (ch.child[j] == bvh8::EMPTY) continue;
-                    for (int a = 0; a < 3; ++a) {
-                        double clo = (double)ch.p[a] + ch.qlo[a][j] * (double)ch.s[a];
-                        // a child's own quantised boxes may stick out of the box its parent holds for it by less than one parent cell
-                        // (both contain the reference boxes; the traversal never relies on nesting of the QUANTISED boxes)
-                        if (clo < lo[a] - (double)nd.s[a] - (double)ch.s[a]) return fail("mi_bvh8_validate: child grid far outside its parent's box");
-                    }
-                }
-                todo.push_back(c);
-            }
-        }
-    }
-    int64_t ncov = 0;
-    for (uint8_t f : covered) ncov += f;
-    if (ncov != (int64_t)d->n_tris) return fail("mi_bvh8_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
-    bvh8::Stats st;
-    for (int64_t i = 0; i < n; ++i) {
-        uint32_t prim; float t, b[3];
-        bool hit = bvh8::traverse(d, bb.out, rays[i], any_hit != 0, &prim, &t, b, &st);
-        if (hits) {
-            std::memset(&hits[i], 0, sizeof(mi_hit));
-            hits[i].prim = hit ? (int32_t)prim : -1;
-            hits[i].t = hit ? t : 0; hits[i].b0 = b[0]; hits[i].b1 = b[1]; hits[i].b2 = b[2];
-        }
-    }
-    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
-    stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
-    if (st.mismatch) return fail("mi_bvh8_validate: the packed node step (Bvh8StepWords) and the struct form (Bvh8Step) disagree on " + std::to_string(st.mismatch) + " node visits");
-    return 0;
-}
 // stage-level BxDF evaluation: f / Pdf / Sample_f of one lobe per record, per-lane lobe records (the instantiation the textured shading
 // kernel uses; the constant-material kernel runs the same code on wave-uniform records)
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_bxdf(const mi_bxdf *b, const float *wo, const float *wi, const float *u, int64_t n, float *f, float *pdf, float *wi_s,
@@ -2952,6 +2703,25 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_hg(const mi_hg_query *q, int
     r.wi_s[0] = ws.x; r.wi_s[1] = ws.y; r.wi_s[2] = ws.z;
     out[i] = r;
 }
+// Stage entry for the libm restatement (csrc/pt_libm.h): routine `fn` over n floats -- the -m gpu test compares the device's results with the GPU box's own glibc.
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_libm(int fn, const float *a, const float *b, int64_t n, float *out, float *out2) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float r = 0, r2 = 0;
+    switch (fn) {
+    case MI_LIBM_SINF: r = pt_sinf(x); break;
+    case MI_LIBM_COSF: r = pt_cosf(x); break;
+    case MI_LIBM_SINCOSF: pt_sincosf(x, &r, &r2); break;
+    case MI_LIBM_EXPF: r = pt_expf(x); break;
+    case MI_LIBM_LOGF: r = pt_logf(x); break;
+    case MI_LIBM_ACOSF: r = pt_acosf(x); break;
+    case MI_LIBM_ATANF: r = pt_atanf(x); break;
+    case MI_LIBM_ATAN2F: r = pt_atan2f(x, b[i]); break;
+    }
+    out[i] = r;
+    if (out2) out2[i] = r2;
+}
 static int stage_device(int device_ordinal, const char *who) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) return fail(std::string(who) + ": no such HIP device (this library has no CPU fallback)");
@@ -2992,6 +2762,21 @@ int mi_phase_hg(int device_ordinal, const mi_hg_query *queries, int64_t n, mi_hg
     HIP_TRY(hipMemcpy(out, dr.p, (size_t)n * sizeof(mi_hg_result), hipMemcpyDeviceToHost));
     return 0;
 }
+int mi_libm_eval(int device_ordinal, int fn, const float *a, const float *b, int64_t n, float *out, float *out2) {
+    if (!a || !out || n < 0 || fn < MI_LIBM_SINF || fn > MI_LIBM_ATAN2F || (fn == MI_LIBM_ATAN2F && !b) || (fn == MI_LIBM_SINCOSF && !out2)) return fail("mi_libm_eval: bad argument");
+    if (n == 0) return 0;
+    if (stage_device(device_ordinal, "mi_libm_eval")) return -1;
+    DevBuf da, db, dr, dr2;
+    const size_t bytes = (size_t)n * sizeof(float);
+    if (da.alloc(bytes) || dr.alloc(bytes) || (b && db.alloc(bytes)) || (out2 && dr2.alloc(bytes))) return -1;
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_stage_libm, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, 0, fn, da.as<float>(), b ? db.as<float>() : nullptr, n, dr.as<float>(), out2 ? dr2.as<float>() : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dr.p, bytes, hipMemcpyDeviceToHost));
+    if (out2) HIP_TRY(hipMemcpy(out2, dr2.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
 // host check of the 64-byte quantised BVH4 (pt_bvh4q.h): quantisation in exact arithmetic + the kernel's per-ray state machine on the host
 int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
     if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh4q_validate: null argument");
@@ -3020,75 +2805,6 @@ int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int
         }
     }
     stats[0] = (int64_t)qn.size(); stats[2] = topDepth; stats[3] = (int64_t)st.maxStack; stats[4] = d->n_tris;
-    stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
-    return 0;
-}
-// the same for the 80-byte compressed layout the traversal kernels run (pt_bvh8c.h): build, structural checks in exact arithmetic, host emulation
-int mi_bvh8c_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, mi_hit *hits, int64_t stats[8]) {
-    if (!d || !stats || (n > 0 && !rays)) return fail("mi_bvh8c_validate: null argument");
-    for (int i = 0; i < 8; ++i) stats[i] = 0;
-    if (d->n_instances) return fail("mi_bvh8c_validate: two-level scenes are not handled");
-    bvh8c::Builder bb;
-    if (!bb.run(d->bvh_nodes, d->n_bvh_nodes)) return fail("mi_bvh8c_validate: " + bb.error);
-    std::vector<uint8_t> covered(d->n_tris, 0);
-    int64_t leaves = 0;
-    std::vector<uint32_t> todo;
-    if (!bb.out.empty()) todo.push_back(0);
-    std::vector<uint8_t> seenNode(bb.out.size(), 0);
-    while (!todo.empty()) {
-        uint32_t ni = todo.back(); todo.pop_back();
-        if (ni >= bb.out.size()) return fail("mi_bvh8c_validate: child index out of range");
-        if (seenNode[ni]++) return fail("mi_bvh8c_validate: node referenced twice");
-        const BVH8CNode &nd = bb.out[ni];
-        uint32_t words[20];
-        std::memcpy(words, &nd, 80);
-        for (int k = 0; k < 8; ++k) {
-            const bool interior = (nd.imask >> k) & 1u, leaf = (nd.meta[k] & 0x80u) != 0;
-            if (interior && leaf) return fail("mi_bvh8c_validate: child both interior and leaf");
-            if (!interior && !leaf) continue;
-            double lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) {
-                double s = std::ldexp(1.0, (int)nd.e[a] - 127);
-                lo[a] = (double)nd.p[a] + nd.qlo[a][k] * s; hi[a] = (double)nd.p[a] + nd.qhi[a][k] * s;
-            }
-            uint32_t c = Bvh8cChildRef(words, k);
-            if (leaf) {
-                uint32_t first = c & bvh8c::FIRST_MASK, count = ((c >> 27) & 0xfu) + 1;
-                ++leaves;
-                if (!(c & bvh8c::LEAF) || first + count > bb.triOrder.size() || count > BVH8C_LEAF_MAX) return fail("mi_bvh8c_validate: bad leaf reference");
-                for (uint32_t tt = first; tt < first + count; ++tt) {
-                    uint32_t t = bb.triOrder[tt];
-                    if (t >= d->n_tris) return fail("mi_bvh8c_validate: primitive index out of range");
-                    if (covered[t]++) return fail("mi_bvh8c_validate: primitive referenced twice");
-                    const uint32_t *v = d->tri_indices + 3 * (size_t)t;
-                    if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE) continue;
-                    for (int kk = 0; kk < 3; ++kk)
-                        for (int a = 0; a < 3; ++a) {
-                            double x = d->P[3 * (size_t)v[kk] + a];
-                            if (x < lo[a] || x > hi[a]) return fail("mi_bvh8c_validate: primitive outside its quantised leaf box");
-                        }
-                }
-            } else {
-                if (c & bvh8c::LEAF) return fail("mi_bvh8c_validate: interior reference with the leaf bit");
-                todo.push_back(c);
-            }
-        }
-    }
-    int64_t ncov = 0;
-    for (uint8_t f : covered) ncov += f;
-    if (ncov != (int64_t)d->n_tris) return fail("mi_bvh8c_validate: " + std::to_string((int64_t)d->n_tris - ncov) + " primitives not covered by any leaf");
-    for (uint8_t f : seenNode) if (!f) return fail("mi_bvh8c_validate: unreachable node");
-    bvh8c::Stats st;
-    for (int64_t i = 0; i < n; ++i) {
-        uint32_t prim; float t, b[3];
-        bool hit = bvh8c::traverse(d, bb.out, bb.triOrder, rays[i], any_hit != 0, &prim, &t, b, &st);
-        if (hits) {
-            std::memset(&hits[i], 0, sizeof(mi_hit));
-            hits[i].prim = hit ? (int32_t)prim : -1;
-            hits[i].t = hit ? t : 0; hits[i].b0 = b[0]; hits[i].b1 = b[1]; hits[i].b2 = b[2];
-        }
-    }
-    stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = bb.maxDepth; stats[3] = (int64_t)st.maxStack; stats[4] = ncov;
     stats[5] = (int64_t)st.nodes; stats[6] = (int64_t)st.tris; stats[7] = (int64_t)st.hits;
     return 0;
 }
@@ -3209,123 +2925,6 @@ int mi_gather_rate(mi_ctx *c, uint64_t bytes, int loads_per_record, double *greq
     *grequests_per_s = best;
     return 0;
 }
-// ---- the same chain of dependent random 64-byte record fetches, issued QUAD-COOPERATIVELY (measurement aid for the next traversal layout;
-// no rendering kernel uses this yet).  k_gather_probe reaches ~1.4 lane requests per clock and CU even on an L1-resident buffer, a quarter of
-// the 64 B/clk the L1 delivers to coalesced loads: every lane of a 16-byte-per-lane load touches its own cache line.  Here the four lanes of a
-// quad fetch the four 16-byte words of ONE record in one instruction (16 lines per wave instruction instead of 64); four such instructions cover
-// the records of all 64 lanes.
-//   MODE 1  "quad":      the address pattern only -- every lane consumes what it loaded (its word of four other lanes' records);
-//   MODE 2  "quad_lds":  the complete exchange -- the loads land in LDS through the LDS-DMA path (global_load_lds_dwordx4: wave-uniform
-//                        base + lane x 16, so a quad's words of one record are contiguous there), and every lane reads ITS record back with
-//                        4 x ds_read_b128 (the producers rotate the word order per group of four owner lanes: conflict-free reads, no selects).  Same per-lane results as
-//                        k_gather_probe<4>, which the host side checks.
-}   // extern "C"
-#ifndef PT_HOST_EMU   /* 64-lane exchange + LDS-DMA: nothing a one-lane x86 build of these sources (tools/hostemu) could mean */
-typedef __attribute__((address_space(3))) void *LdsPtr;
-typedef const __attribute__((address_space(1))) void *GlobalPtr;
-template <int MODE>
-__global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_coop(const uint4 *buf, uint32_t nrec, int iters, uint32_t *out_s, uint32_t *out_acc) {
-    __shared__ uint4 stage[PT_BLOCK / 64][4][64];   // per wave: 4 instructions x 64 lanes x 16 B = 4 KiB
-    const uint32_t tid = blockIdx.x * PT_BLOCK + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t s = tid * 2654435761u + 12345u;
-    uint32_t acc = 0;
-    for (int it = 0; it < iters; ++it) {
-        const uint32_t rec = (uint32_t)(((uint64_t)s * nrec) >> 32);
-        uint4 w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {   // instruction k serves the records of lanes 16 k .. 16 k + 15: lane L fetches word L & 3 of lane (L >> 2) + 16 k's record
-            const uint32_t owner = (lane >> 2) + 16u * k;
-            const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)rec);
-            // MODE 2: the producers rotate -- position j of the owner's LDS slot receives word (j + rot) & 3, rot = (owner >> 2) & 3 = (lane >> 4) & 3 -- so that
-            // the owner's four reads (positions (i - rot) & 3: 16 lanes on 16 distinct 16-byte bank groups) return words 0..3 in order, no selects
-            const uint4 *src = buf + (size_t)r * 4 + (MODE == 1 ? (lane & 3u) : ((lane & 3u) + (lane >> 4)) & 3u);
-            if (MODE == 1) w[k] = *src;
-            else __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)&stage[__builtin_amdgcn_readfirstlane(wave)][k][0], 16, 0, 0);
-        }
-        uint4 a, b, c, d;
-        if (MODE == 1) {
-            Pin(w[0]); Pin(w[1]); Pin(w[2]); Pin(w[3]);
-            a = w[0]; b = w[1]; c = w[2]; d = w[3];
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes of this wave have landed (nothing else orders a ds_read behind them)
-            const uint4 *mine = &stage[wave][lane >> 4][(lane & 15u) * 4];   // this lane's record: instruction lane / 16, slot lane % 16, 4 positions
-            const uint32_t rot = (lane >> 2) & 3u;
-            a = mine[(0 - rot) & 3u]; b = mine[(1 - rot) & 3u]; c = mine[(2 - rot) & 3u]; d = mine[(3 - rot) & 3u];
-            Pin(a); Pin(b); Pin(c); Pin(d);
-        }
-        acc += a.y ^ b.z ^ c.w ^ d.x;
-        s = s * 1664525u + a.x;
-    }
-    out_s[tid] = s; out_acc[tid] = acc;
-}
-#endif
-// k_gather_probe<4> with its per-lane results written out (the reference the quad_lds exchange is checked against)
-__global__ void __launch_bounds__(PT_BLOCK) k_gather_probe_ref(const uint4 *buf, uint32_t nrec, int iters, uint32_t *out_s, uint32_t *out_acc) {
-    const uint32_t tid = blockIdx.x * PT_BLOCK + threadIdx.x;
-    uint32_t s = tid * 2654435761u + 12345u;
-    uint32_t acc = 0;
-    for (int it = 0; it < iters; ++it) {
-        const uint32_t rec = (uint32_t)(((uint64_t)s * nrec) >> 32);
-        const uint4 *p = buf + (size_t)rec * 4;
-        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-        Pin(a); Pin(b); Pin(c); Pin(d);
-        acc += a.y ^ b.z ^ c.w ^ d.x;
-        s = s * 1664525u + a.x;
-    }
-    out_s[tid] = s; out_acc[tid] = acc;
-}
-extern "C" {
-int mi_gather_rate_coop(mi_ctx *c, uint64_t bytes, int mode, double *grequests_per_s, int64_t *lanes_equal, int64_t *lanes_total) {
-    if (!c || !grequests_per_s || bytes < 4096 || mode < 0 || mode > 2) return fail("mi_gather_rate_coop: bad argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const uint32_t nrec = (uint32_t)std::min<uint64_t>(bytes / 64, 0xffffffffull);
-    const size_t nthreads = (size_t)c->gridBlocks * PT_BLOCK;
-    DevBuf buf, outS, outA, refS, refA;
-    if (buf.alloc((size_t)nrec * 64) || outS.alloc(nthreads * 4) || outA.alloc(nthreads * 4) || refS.alloc(nthreads * 4) || refA.alloc(nthreads * 4)) return -1;
-    {
-        std::vector<uint32_t> h((size_t)nrec * 16);
-        uint32_t x = 2463534242u;
-        for (auto &w : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; w = x; }
-        HIP_TRY(hipMemcpyAsync(buf.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-    const int iters = 2048;
-    const dim3 grid(c->gridBlocks), block(PT_BLOCK);
-    double best = 0;
-    for (int it = 0; it < 4; ++it) {   // first launch = warm-up
-        HIP_TRY(hipEventRecord(a, c->stream));
-        if (mode == 0) hipLaunchKernelGGL(k_gather_probe_ref, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
-#ifndef PT_HOST_EMU
-        else if (mode == 1) hipLaunchKernelGGL(k_gather_probe_coop<1>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
-        else hipLaunchKernelGGL(k_gather_probe_coop<2>, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, outS.as<uint32_t>(), outA.as<uint32_t>());
-#else
-        else return fail("mi_gather_rate_coop: modes 1 and 2 need 64-lane waves");
-#endif
-        HIP_TRY(hipEventRecord(b, c->stream));
-        HIP_TRY(hipEventSynchronize(b));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, a, b));
-        if (it > 0 && ms > 0) best = std::max(best, (double)nthreads * iters * 4 / (ms * 1e-3) * 1e-9);
-    }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    if (lanes_equal && lanes_total) {   // the exchange of mode 2 must reproduce the plain probe lane for lane (mode 1 walks other chains by construction)
-        hipLaunchKernelGGL(k_gather_probe_ref, grid, block, 0, c->stream, buf.as<uint4>(), nrec, iters, refS.as<uint32_t>(), refA.as<uint32_t>());
-        std::vector<uint32_t> hs(nthreads), ha(nthreads), rs(nthreads), ra(nthreads);
-        HIP_TRY(hipMemcpyAsync(hs.data(), outS.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(ha.data(), outA.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(rs.data(), refS.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(ra.data(), refA.p, nthreads * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        int64_t eq = 0;
-        for (size_t i = 0; i < nthreads; ++i) eq += hs[i] == rs[i] && ha[i] == ra[i];
-        *lanes_equal = eq; *lanes_total = (int64_t)nthreads;
-    }
-    *grequests_per_s = best;
-    return 0;
-}
 int mi_counters_reset(mi_ctx *c) {
     if (!c) return fail("mi_counters_reset: null ctx");
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, PT_CNT_ALLOC * sizeof(uint64_t), c->stream));
@@ -3352,18 +2951,45 @@ static int stage_common(mi_ctx *c) {
     return ensure_state(c, std::max<uint32_t>(c->cap, 256 * 64));
 }
 
-int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
-    if (stage_common(c)) return -1;
+// rays -> queue -> the scene's own k_trace<0> (closest hit) or k_trace<2> (any hit) instance -> hits; in chunks of the path-state capacity
+static int stage_trace(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits, uint8_t *occluded) {
+    if (!c || !c->haveScene) return fail("no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
     if (n <= 0) return 0;
+    if (ensure_state(c, (uint32_t)std::max<int64_t>(c->cap, std::min<int64_t>(std::max<int64_t>(n, 256 * 64), 1 << 22)))) return -1;
+    PathState &ps = c->ps;
+    const DevScene &sc = c->sc;
+    hipStream_t st = c->stream;
+    dim3 grid(c->gridBlocks), block(PT_BLOCK);
+    const bool countWork = false;
+    const uint32_t qin = 0;
+    TableTurn turn(c);
+    if (c->hasTex || c->hasAlpha || c->hasInst) HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
+    if (c->hasInst) HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_instances), &c->instPtr, sizeof(c->instPtr), 0, hipMemcpyHostToDevice, st));
     DevBuf dr, dh;
-    if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n * sizeof(mi_hit))) return -1;
-    if (c->useC8) { PathState ps8 = c->ps; ps8.spill_per_thread = c->spill8; hipLaunchKernelGGL(k_stage_intersect_c8, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, ps8, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr); }
-    else if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
-    else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, dh.as<mi_hit>(), (uint8_t *)nullptr);
-    HIP_TRY(hipMemcpyAsync(hits, dh.p, (size_t)n * sizeof(mi_hit), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t chunk = (int64_t)c->cap;
+    if (dr.alloc((size_t)std::min(n, chunk) * sizeof(mi_ray)) || dh.alloc((size_t)std::min(n, chunk) * (occluded ? 1 : sizeof(mi_hit)))) return -1;
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t m = std::min(chunk, n - i0);
+        HIP_TRY(hipMemcpyAsync(dr.p, rays + i0, (size_t)m * sizeof(mi_ray), hipMemcpyHostToDevice, st));
+        uint32_t row[QSEG * QC_STRIDE] = {0};
+        for (uint32_t sg = 0; sg < QSEG; ++sg) row[sg * QC_STRIDE] = (uint32_t)((m - sg + 7) / 8);   // items sg, sg + 8, ...
+        HIP_TRY(hipMemcpyAsync(ps.qcount + QCI(occluded ? QC_SHADOW : qin, 0), row, sizeof(row), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_stage_fill_rays, grid, block, 0, st, ps, dr.as<mi_ray>(), m, occluded ? 1 : 0);
+        if (occluded) { LAUNCH_TRACE(2); } else { LAUNCH_TRACE(0); }
+        hipLaunchKernelGGL(k_stage_collect_hits, grid, block, 0, st, sc, ps, dr.as<mi_ray>(), m, occluded ? (mi_hit *)nullptr : dh.as<mi_hit>(), occluded ? dh.as<uint8_t>() : (uint8_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        if (occluded) HIP_TRY(hipMemcpyAsync(occluded + i0, dh.p, (size_t)m, hipMemcpyDeviceToHost, st));
+        else HIP_TRY(hipMemcpyAsync(hits + i0, dh.p, (size_t)m * sizeof(mi_hit), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));   // `row` and the staging buffers are reused by the next chunk
+    }
     dr.release(); dh.release();
     return 0;
+}
+int mi_intersect(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits) {
+    if (n > 0 && (!rays || !hits)) return fail("mi_intersect: null argument");
+    return stage_trace(c, rays, n, hits, nullptr);
 }
 int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *rays, int64_t n, mi_hit *hits) {
     if (n <= 0) return 0;
@@ -3380,17 +3006,8 @@ int mi_triangle_intersect(int device_ordinal, const float *tri9, const mi_ray *r
     return 0;
 }
 int mi_intersect_p(mi_ctx *c, const mi_ray *rays, int64_t n, uint8_t *occluded) {
-    if (stage_common(c)) return -1;
-    if (n <= 0) return 0;
-    DevBuf dr, dh;
-    if (upload(c, dr, rays, (size_t)n * sizeof(mi_ray)) || dh.alloc((size_t)n)) return -1;
-    if (c->useC8) { PathState ps8 = c->ps; ps8.spill_per_thread = c->spill8; hipLaunchKernelGGL(k_stage_intersect_c8, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, ps8, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>()); }
-    else if (c->useFast) hipLaunchKernelGGL(k_stage_intersect<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
-    else hipLaunchKernelGGL(k_stage_intersect<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, dr.as<mi_ray>(), n, (mi_hit *)nullptr, dh.as<uint8_t>());
-    HIP_TRY(hipMemcpyAsync(occluded, dh.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dr.release(); dh.release();
-    return 0;
+    if (n > 0 && (!rays || !occluded)) return fail("mi_intersect_p: null argument");
+    return stage_trace(c, rays, n, nullptr, occluded);
 }
 int mi_sobol(mi_ctx *c, int px, int py, int n_samples, int n_dims, float *out, uint64_t *index_out) {
     if (stage_common(c)) return -1;

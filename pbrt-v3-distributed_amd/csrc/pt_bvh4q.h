@@ -10,13 +10,13 @@
 //     child[4]             as BVH4Node::child;                                           16 B = one load
 // with ONE grid for the whole tree (g.lo = the root box's lower corner, g.cell = a power of two with extent / cell <= 65535 per axis: 1 mm
 // cells on a 40 m scene).  No per-node header: the folded slab constants A = cell / d, B = (g.lo - o) / d are per RAY.
-// The box test is t = q A + B with the explicit slack of the quantised BVH8 (pt_bvh8.h): delta = 16 eps (|B| + 65535 |A|) moved onto the
+// The box test is t = q A + B with explicit slack: delta = 16 eps (|B| + 65535 |A|) moved onto the
 // near / far offsets keeps it CONSERVATIVE with respect to Bounds3::IntersectP on the reference's boxes (evaluation error <= 2 eps q |A| +
 // 3 eps |B| + the reference's own (1 + 2 gamma(3)) on the far side): every box the reference enters is entered, the closest hit is the same.
 #pragma once
 #include <stdint.h>
 
-#include "pt_bvh8.h"   // PT_HD, Ray8 / Ray8Init (+-1e30 for zero direction components), host copy of the watertight test
+#include "pt_hostcheck.h"   // PT_HD, SlabRay / SlabRayInit (+-1e30 for zero direction components), host copy of the watertight test
 
 struct __attribute__((aligned(64))) BVH4QNode {
     uint16_t lo[3][4], hi[3][4];
@@ -107,12 +107,12 @@ inline bool traverse(const mi_scene_desc *d, const std::vector<BVH4QNode> &nodes
                      Stats *st) {
     std::vector<uint32_t> stack(4 * 96);
     int sp = 0;
-    Ray8 r8;
-    Ray8Init(r8, ray.o, ray.d);
+    SlabRay r8;
+    SlabRayInit(r8, ray.o, ray.d);
     Bvh4qRay qr;
     Bvh4qRayInit(qr, g, r8.o, r8.inv);
-    bvh8::Shear sh;
-    bvh8::shearInit(sh, ray.d);
+    hostcheck::Shear sh;
+    hostcheck::shearInit(sh, ray.d);
     float tMax = ray.tmax;
     uint32_t prim = EMPTY;
     float bary[3] = {0, 0, 0}, tHit = 0;
@@ -136,9 +136,9 @@ inline bool traverse(const mi_scene_desc *d, const std::vector<BVH4QNode> &nodes
             for (uint32_t t = first; t < first + count; ++t) {
                 ++st->tris;
                 const uint32_t *v = d->tri_indices + 3 * (size_t)t;
-                if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE || bvh8::triangleRejected(d, t)) continue;
+                if (v[0] == MI_PRIM_SPHERE || v[0] == MI_PRIM_INSTANCE || hostcheck::triangleRejected(d, t)) continue;
                 float th, b[3];
-                if (bvh8::triangleTest(d->P + 3 * (size_t)v[0], d->P + 3 * (size_t)v[1], d->P + 3 * (size_t)v[2], ray.o, sh, tMax, &th, b)) {
+                if (hostcheck::triangleTest(d->P + 3 * (size_t)v[0], d->P + 3 * (size_t)v[1], d->P + 3 * (size_t)v[2], ray.o, sh, tMax, &th, b)) {
                     prim = t; tHit = th; bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2];
                     tMax = th;
                     if (anyHit) { sp = 0; break; }

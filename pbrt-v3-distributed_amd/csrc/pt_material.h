@@ -79,7 +79,7 @@ __device__ __noinline__ IsectX SphereIsectTex(const mi_sphere *spp, const V3 ro,
     SphereHit h = SphereHitTest(sp, ro, rd, PT_INFINITY);
     if (!h.hit) return x;   // (cannot happen: the traversal found this hit with the same code)
     const V3 pHit = h.pHit;
-    Float phi = satan2f_(pHit.y, pHit.x);
+    Float phi = atan2f_(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PT_PI;
     const Float phiMax = sp.phi_max, dTheta = sp.theta_max - sp.theta_min;
     Float theta = acosf_(clampf(pHit.z / sp.radius, -1, 1));

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #define PT_DEV __device__ __forceinline__
+#include "pt_libm.h"
 
 typedef float Float;
 #define PT_PI 3.14159265358979323846f        /* core/pbrt.h:201 (rounded to float there too) */
@@ -30,13 +31,19 @@ PT_DEV Float clampf(Float v, Float lo, Float hi) { return v < lo ? lo : (v > hi 
 PT_DEV Float absf(Float v) { return __builtin_fabsf(v); }
 PT_DEV Float sqrtf_(Float v) { return __builtin_sqrtf(v); }
 
-// libm calls: evaluated in double and rounded once.  The reference calls glibc's float routines,
-// which return the correctly rounded result in all but a vanishing fraction of inputs; going
-// through ocml's double versions gets the same value almost always, unlike ocml's 1-2 ulp float paths.
-// sin and cos in double for the arguments this path produces (|x| < 2^20; the samplers hand over angles within a few pi): two-term
-// Cody-Waite reduction by pi/2 and the two fdlibm kernels (error < 1 ulp of DOUBLE, i.e. the same float after rounding as ocml's
-// sin((double)v) in all but ~1e-9 of the cases -- checked on 2e8 floats against it on the host) in ~35 double operations for the PAIR,
-// against ~2 x 90 for two ocml calls with their large-argument paths.  PT_OCML_TRIG=1 restores the library calls (A/B).
+// libm calls: the reference's std::sin / cos / acos / atan2 / exp / log on floats are glibc's float routines; pt_libm.h performs
+// the same operation sequences, so the device returns the same bits (all 2^32 inputs of each routine checked against the
+// installed libm: tools/libm_check, tests/test_libm.py).
+PT_DEV Float sinf_(Float v) { return pt_sinf(v); }
+PT_DEV Float cosf_(Float v) { return pt_cosf(v); }
+PT_DEV void sincosf_(Float v, Float *s, Float *c) { pt_sincosf(v, s, c); }
+PT_DEV Float acosf_(Float v) { return pt_acosf(v); }
+PT_DEV Float expf_(Float v) { return pt_expf(v); }
+PT_DEV Float logf_(Float v) { return pt_logf(v); }
+PT_DEV Float atan2f_(Float y, Float x) { return pt_atan2f(y, x); }
+// sin and cos of a DOUBLE (the one place the reference calls the double overloads on this path: TrowbridgeReitzSample11's first branch,
+// core/microfacet.cpp:243-248, |x| <= 2 pi): two-term Cody-Waite reduction by pi/2 and the two fdlibm kernels (error < 1 ulp of double; the
+// product with r is rounded to float afterwards, so a last-place difference from glibc's own < 1 ulp sin / cos shows in ~1e-9 of the cases).
 PT_DEV void SinCosD(double x, double *sn, double *cs) {
     const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
     const int n = (int)fn;
@@ -51,26 +58,6 @@ PT_DEV void SinCosD(double x, double *sn, double *cs) {
     *sn = (n & 2) ? -a : a;
     *cs = ((n + 1) & 2) ? -b : b;
 }
-#if defined(PT_F32_TRIG)   /* experiment only: ocml's 1-2 ulp float routines (not the parity build) */
-PT_DEV Float sinf_(Float v) { return sinf(v); }
-PT_DEV Float cosf_(Float v) { return cosf(v); }
-PT_DEV void sincosf_(Float v, Float *s, Float *c) { *s = sinf(v); *c = cosf(v); }
-#elif defined(PT_OCML_TRIG)
-PT_DEV Float sinf_(Float v) { return (Float)sin((double)v); }
-PT_DEV Float cosf_(Float v) { return (Float)cos((double)v); }
-PT_DEV void sincosf_(Float v, Float *s, Float *c) { *s = sinf_(v); *c = cosf_(v); }
-#else
-PT_DEV void sincosf_(Float v, Float *s, Float *c) {
-    if (!(absf(v) < 1048576.f)) { *s = (Float)sin((double)v); *c = (Float)cos((double)v); return; }   // (never on this path: huge / non-finite angles)
-    double sd, cd;
-    SinCosD((double)v, &sd, &cd);
-    *s = (Float)sd; *c = (Float)cd;
-}
-PT_DEV Float sinf_(Float v) { Float s, c; sincosf_(v, &s, &c); return s; }
-PT_DEV Float cosf_(Float v) { Float s, c; sincosf_(v, &s, &c); return c; }
-#endif
-PT_DEV Float acosf_(Float v) { return (Float)acos((double)v); }
-PT_DEV Float expf_(Float v) { return (Float)exp((double)v); }
 
 PT_DEV uint32_t f2u(Float f) { return __float_as_uint(f); }
 PT_DEV Float u2f(uint32_t u) { return __uint_as_float(u); }

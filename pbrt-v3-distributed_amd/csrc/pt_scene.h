@@ -3,7 +3,6 @@
 #include "pbrt_amd.h"
 #include "pt_math.h"
 #include "pt_sphere.h"
-#include "pt_bvh8.h"
 #include "pt_bvh4q.h"
 
 // ------------------------------------------------------------------ HBM layout
@@ -67,12 +66,6 @@ struct DevScene {
     const float4 *tri_verts;        // 3 per triangle
     const BVH4QNode *nodesq;        // the same tree as `nodes` with 16-bit planes on one grid (pt_bvh4q.h); null: not built
     Bvh4qGrid qgrid;
-    const void *nodes8c;            // BVH8CNode[] (pt_bvh8c.h), null: not built
-    uint32_t n_nodes8c;
-    const float4 *tri_trav;         // triangle records in the BVH8C's traversal order
-    const uint32_t *trav2prim;      // traversal order -> reference primitive index
-    const float4 *tri_perm;         // the same records three times, vertices permuted for kz = 0, 1, 2 (pt_trace_fast.h); null: not built
-    size_t tri_perm_stride;         // float4s per copy (3 * n_tris)
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const mi_material *materials;
@@ -529,7 +522,7 @@ struct TravStateQ : TravState {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         const float oo[3] = {o.x, o.y, o.z};
         const float inv[3] = {d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
-                              d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z};   // Ray8Init's convention for zero direction components
+                              d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z};   // SlabRayInit's convention for zero direction components
         Bvh4qRayInit(q, sc.qgrid, oo, inv);
         shear.init(d);
         st.sp = 0;
@@ -563,43 +556,6 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
     if (nh > 1) st.push(c1, t1);
     ts.cur = c0;
 }
-
-#ifndef PT_COOP_NODE_FETCH
-#define PT_COOP_NODE_FETCH 0   /* experiment build (-DPT_COOP_NODE_FETCH=1, lib/variants only): quad-cooperative node fetch through LDS, below */
-#endif
-#if PT_COOP_NODE_FETCH
-// ------------------------------------------------------------------ EXPERIMENT (not in the product library; written at the end of round 2, not yet run on a GPU)
-// Quad-cooperative fetch of the quantised nodes.  The plain step issues 4 x 16-byte loads per lane, every lane on its own cache line: 64
-// lines per wave instruction, and the CU serves ~1.4 such lane requests per clock whatever the cache level (mi_gather_rate) -- a quarter of
-// what the L1 delivers to coalesced loads.  Here the four lanes of a quad fetch the four words of ONE node in one instruction (16 lines per
-// wave instruction); instruction k serves the nodes of lanes 16 k .. 16 k + 15 and is skipped when none of them takes a step.  The words go
-// straight to LDS (LDS-DMA: wave-uniform base + lane x 16, so a node's words are contiguous there) and every stepping lane reads its node
-// back with 4 x ds_read_b128; the producers rotate the word order per group of four owner lanes (conflict-free reads, words arrive in order).  mi_gather_rate_coop measures the bare pattern.
-// All 64 lanes call CoopFetchNodesQ (wave-uniform control flow); `stage` = this wave's uint4[4][64] (4 KiB of LDS).
-typedef __attribute__((address_space(3))) void *PtLdsPtr;
-typedef const __attribute__((address_space(1))) void *PtGlobalPtr;
-PT_DEV void CoopFetchNodesQ(const BVH4QNode *nodes, uint32_t myNode /* any valid node (0) for lanes that take no step */, unsigned long long want,
-                            uint4 *stage /* wave-uniform */, uint32_t lane) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t owner = (lane >> 2) + 16u * k;
-        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)myNode);
-        if ((want >> (16 * k)) & 0xffffull) {   // wave-uniform
-            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + r) + (((lane & 3u) + (lane >> 4)) & 3u);   // producers rotate: position j <- word (j + rot_owner) & 3
-            __builtin_amdgcn_global_load_lds((PtGlobalPtr)src, (PtLdsPtr)(stage + 64 * k), 16, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing else orders the ds_reads below behind the LDS-DMA writes
-}
-template <bool COUNT>
-PT_DEV void TravNodeStepQCoop(TravStateQ &ts, TravStack &st, TraceCounters *cnt, const uint4 *stage, uint32_t lane) {
-    const uint4 *mine = stage + 64 * (lane >> 4) + 4 * (lane & 15u);
-    const uint32_t rot = (lane >> 2) & 3u;   // word i sits at position (i - rot) & 3: 16 lanes of a pass on 16 distinct 16-byte bank groups, words in order
-    uint4 w0 = mine[(0 - rot) & 3u], w1 = mine[(1 - rot) & 3u], w2 = mine[(2 - rot) & 3u], ch = mine[(3 - rot) & 3u];
-    Pin(w0); Pin(w1); Pin(w2); Pin(ch);
-    TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
-}
-#endif
 
 // ------------------------------------------------------------------ two-level instancing (the host's default since round 2; PBRT_AMD_INSTANCING=0 flattens)
 // TransformedPrimitive::Intersect / IntersectP (core/primitive.cpp:76-111) inside the per-lane state machine: meeting an instance
@@ -692,92 +648,4 @@ PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt)
     }
     if (left) ts.cur = BVH4_LEAF | ((left - 1) << 27) | (first + 1);
     else ts.cur = st.pop(ts.tMax);
-}
-
-// plain per-ray loop (stage-level entry points)
-template <bool ANY, bool COUNT>
-PT_DEV bool Traverse(const DevScene &sc, const V3 &o, const V3 &d, Float tMax, TravStack &st, Float *tHit, uint32_t *primHit,
-                     TraceCounters *cnt) {
-    TravState ts;
-    ts.init(sc, o, d, tMax, st);
-    while (!ts.done()) {
-        if (ts.atNode()) TravNodeStep<COUNT>(sc, ts, st, cnt);
-        else TravLeafStep<ANY, COUNT, true>(sc, ts, st, cnt);
-    }
-    *tHit = ts.tHit; *primHit = ts.prim;
-    return ts.prim != TRAV_MISS;
-}
-
-// ------------------------------------------------------------------ BVH8 traversal (csrc/pt_bvh8.h; an A/B layout, off unless PBRT_AMD_BVH8=1: measured slower than the quantised BVH4, profiles/r02_a_*)
-// Same per-lane state machine over the quantised 8-wide nodes.  Validated on the host (mi_bvh8_validate runs the same steps:
-// hits identical to the reference's BVH2 traversal); the kernels below were first compiled in round 1 and had not been run on a
-// GPU when that round's budget ended -- the default path is the BVH4 one above.
-#define PT_LDS_STACK8 12   /* 8-byte entries: the same 24 KiB of LDS per block as the BVH4 stack */
-typedef unsigned long long StackEntry8;   // child reference | entry distance bits << 32
-typedef __attribute__((address_space(3))) StackEntry8 LdsStackEntry8;
-struct TravStack8 {
-    LdsStackEntry8 *lds;
-    StackEntry8 *spill;
-    int sp;
-    PT_DEV void push(uint32_t v, Float t) {
-        StackEntry8 e = (StackEntry8)v | ((StackEntry8)__float_as_uint(t) << 32);
-        if (sp < PT_LDS_STACK8) lds[sp * PT_BLOCK] = e; else spill[sp - PT_LDS_STACK8] = e;
-        ++sp;
-    }
-    PT_DEV uint32_t pop(Float tMax) {   // a box entered beyond the hit found meanwhile is dropped unfetched
-        while (sp) {
-            --sp;
-            StackEntry8 e = (sp < PT_LDS_STACK8) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK8];
-            if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
-        }
-        return 0xFFFFFFFFu;
-    }
-};
-struct TravState8 {
-    V3 o, d, inv;          // inv as Ray8Init gives it (+-1e30 for zero direction components)
-    RayShear shear;
-    Float tMax, tHit;
-    uint32_t prim, cur;
-    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack8 &st) {
-        o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
-        inv = V3(d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
-                 d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z);
-        shear.init(d);
-        st.sp = 0;
-        cur = sc.n_nodes ? 0u : TRAV_DONE;
-    }
-    PT_DEV bool done() const { return cur == TRAV_DONE; }
-    PT_DEV bool atLeaf() const { return cur != TRAV_DONE && (cur & BVH4_LEAF); }
-    PT_DEV bool atNode() const { return !(cur & BVH4_LEAF); }
-};
-// one interior step (Bvh8Step of pt_bvh8.h, same operations in the same order, on a node held in registers): 7 x 16-byte loads of the
-// 128-byte line, folded plane distances t = q * A + B, nearest hit child next, the others pushed with their entry distances
-template <bool COUNT>
-PT_DEV void TravNodeStep8(const DevScene &sc, TravState8 &ts, TravStack8 &st, TraceCounters *cnt) {
-    const uint4 *w = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (size_t)ts.cur * 128u);
-    uint4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
-    Pin(w0); Pin(w1); Pin(w2); Pin(w3); Pin(w4); Pin(w5); Pin(w6);
-    if (COUNT) ++cnt->nodes;
-    // the step itself: Bvh8StepWords of pt_bvh8.h, the function the host emulation validates
-    const uint32_t wd[28] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w,
-                             w4.x, w4.y, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, w6.x, w6.y, w6.z, w6.w};
-    Float t[8];
-    const uint32_t mask = Bvh8StepWords(wd, ts.o.x, ts.o.y, ts.o.z, ts.inv.x, ts.inv.y, ts.inv.z, ts.tMax, t);
-    bool h[8];
-    const uint32_t cc[8] = {wd[6], wd[7], wd[8], wd[9], wd[10], wd[11], wd[12], wd[13]};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) h[k] = (mask >> k) & 1u;
-    int best = -1;
-    Float tb = PT_INFINITY;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (h[k] && (best < 0 || t[k] < tb)) { tb = t[k]; best = k; }
-    if (best < 0) { ts.cur = st.pop(ts.tMax); return; }
-    uint32_t nxt = cc[0];
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {
-        if (!h[k]) continue;
-        if (k == best) nxt = cc[k];
-        else st.push(cc[k], t[k]);
-    }
-    ts.cur = nxt;
 }

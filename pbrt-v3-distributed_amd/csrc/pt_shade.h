@@ -232,15 +232,10 @@ PT_DEV void TrowbridgeReitzSample11(Float cosTheta, Float U1, Float U2, Float *s
     if ((double)cosTheta > .9999) {
         Float r = (Float)sqrt((double)(U1 / (1 - U1)));
         Float phi = (Float)(6.28318530718 * (double)U2);
-#if defined(PT_OCML_TRIG) || defined(PT_F32_TRIG)
-        *slope_x = (Float)((double)r * cos((double)phi));
-        *slope_y = (Float)((double)r * sin((double)phi));
-#else
         double sd, cd;
         SinCosD((double)phi, &sd, &cd);   // phi in [0, 2 pi]
         *slope_x = (Float)((double)r * cd);
         *slope_y = (Float)((double)r * sd);
-#endif
         return;
     }
     Float sinTheta = sqrtf_(mx((Float)0, (Float)1 - cosTheta * cosTheta));
@@ -668,7 +663,6 @@ PT_DEV RGB EnvLookup(const DevEnvMap &e, Float s_, Float t_) {   // Lookup(st) =
 PT_DEV V3 Mul3(const V3 &r0, const V3 &r1, const V3 &r2, const V3 &v) {   // Transform::operator()(Vector3f), 3x3 part
     return V3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
 }
-PT_DEV Float atan2f_(Float y, Float x) { return (Float)atan2((double)y, (double)x); }
 PT_DEV Float SphericalTheta(const V3 &v) { return acosf_(clampf(v.z, -1, 1)); }                                   // geometry.h:1479-1481
 PT_DEV Float SphericalPhi(const V3 &v) { Float p = atan2f_(v.y, v.x); return (p < 0) ? (p + 2 * PT_PI) : p; }      // :1483-1486
 #define PT_INV_2PI 0.15915494309189533577f

@@ -84,7 +84,6 @@ PT_DEV V3 SXfVectorErr(const float *m, const V3 &v, V3 *absError) {
 PT_DEV V3 SXfNormal(const float *mInv, const V3 &n) {   // transpose of the inverse
     return V3(mInv[0] * n.x + mInv[4] * n.y + mInv[8] * n.z, mInv[1] * n.x + mInv[5] * n.y + mInv[9] * n.z, mInv[2] * n.x + mInv[6] * n.y + mInv[10] * n.z);
 }
-PT_DEV Float satan2f_(Float y, Float x) { return (Float)atan2((double)y, (double)x); }
 
 struct SphereHit { V3 o, d, pHit; Float t; bool hit; };   // object-space ray, refined hit point, tShapeHit
 // the hit test of Sphere::Intersect / IntersectP (shapes/sphere.cpp:48-110 == :164-217)
@@ -120,7 +119,7 @@ PT_DEV SphereHit SphereHitTest(const mi_sphere &sp, const V3 &ro, const V3 &rd, 
     pHit = o + d * tShapeHit.v;                                          \
     pHit = pHit * (radius / pHit.Length());                              \
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;             \
-    phi = satan2f_(pHit.y, pHit.x);                                      \
+    phi = atan2f_(pHit.y, pHit.x);                                      \
     if (phi < 0) phi += 2 * PT_PI;
     PT_SPHERE_POINT()
     if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) {

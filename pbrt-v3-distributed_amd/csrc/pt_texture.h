@@ -36,8 +36,6 @@ struct TexCtx {   // what textures read of a SurfaceInteraction
 };
 struct V2 { Float x, y; };
 
-PT_DEV Float logf_(Float v) { return (Float)log((double)v); }
-PT_DEV Float atan2f__(Float y, Float x) { return (Float)atan2((double)y, (double)x); }
 PT_DEV Float Log2T(Float x) { const Float invLog2 = 1.442695040888963387004650940071f; return logf_(x) * invLog2; }   // core/pbrt.h:324-327
 PT_DEV int ModT(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }                                 // core/pbrt.h:310-313
 
@@ -120,13 +118,13 @@ PT_DEV V3 XfVectorT(const float *m, const V3 &v) {   // core/transform.h:236-242
 PT_DEV V2 SphereST(const mi_texture *t, const V3 &P) {   // SphericalMapping2D::sphere :117-121
     V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
     Float theta = acosf_(clampf(vec.z, -1, 1));
-    Float phi = atan2f__(vec.y, vec.x);
+    Float phi = atan2f_(vec.y, vec.x);
     phi = (phi < 0) ? (phi + 2 * PT_PI) : phi;
     return V2{theta * PT_INV_PI, phi * 0.15915494309189533577f};
 }
 PT_DEV V2 CylinderST(const mi_texture *t, const V3 &P) {   // CylindricalMapping2D::cylinder texture.h:93-96
     V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
-    return V2{(PT_PI + atan2f__(vec.y, vec.x)) * 0.15915494309189533577f, vec.z};
+    return V2{(PT_PI + atan2f_(vec.y, vec.x)) * 0.15915494309189533577f, vec.z};
 }
 PT_DEV V2 DivV2(const V2 &a, const V2 &b, Float f) { Float inv = (Float)1 / f; return V2{(a.x - b.x) * inv, (a.y - b.y) * inv}; }
 struct Map2DOut { V2 st, dstdx, dstdy; };

@@ -53,7 +53,6 @@ struct VSampler : Sampler {
 };
 
 PT_DEV RGB ExpRGB(const RGB &s) { return RGB(expf_(s.r), expf_(s.g), expf_(s.b)); }   // Exp(Spectrum) core/spectrum.h:253-258
-PT_DEV Float logf1_(Float v) { return (Float)log((double)v); }
 
 // ------------------------------------------------------------------ HenyeyGreenstein (core/medium.h:69-72, medium.cpp:189-213)
 PT_DEV Float PhaseHG(Float cosTheta, Float g) {
@@ -146,7 +145,7 @@ __device__ __noinline__ RGB MediumTr(const DevScene *scp, const mi_medium *m, co
     Float Tr = 1, t = tMin;
     const Float sigma_t = m->sigma_t[0];
     while (true) {
-        t -= logf1_(1 - smp->Get1D(*scp)) * m->inv_max_density / sigma_t;
+        t -= logf_(1 - smp->Get1D(*scp)) * m->inv_max_density / sigma_t;
         if (t >= tEnd) break;
         Float density = GridDensity(m, ray.o + ray.d * t);
         Tr *= 1 - mx((Float)0, density * m->inv_max_density);
@@ -166,7 +165,7 @@ __device__ __noinline__ MediumSampleOut MediumSample(const DevScene *scp, const 
     if (m->type == MI_MEDIUM_HOMOGENEOUS) {
         const RGB sigma_t = rgb3(m->sigma_t), sigma_s = rgb3(m->sigma_s);
         int channel = mni((int)(smp->Get1D(*scp) * 3), 2);
-        Float dist = -logf1_(1 - smp->Get1D(*scp)) / m->sigma_t[channel];
+        Float dist = -logf_(1 - smp->Get1D(*scp)) / m->sigma_t[channel];
         Float t = mn(dist / rd.Length(), tMax);
         bool sampledMedium = t < tMax;
         if (sampledMedium) { out.valid = true; out.p = ro + rd * t; }
@@ -185,7 +184,7 @@ __device__ __noinline__ MediumSampleOut MediumSample(const DevScene *scp, const 
     const Float sigma_t = m->sigma_t[0];
     Float t = tMin;
     while (true) {
-        t -= logf1_(1 - smp->Get1D(*scp)) * m->inv_max_density / sigma_t;
+        t -= logf_(1 - smp->Get1D(*scp)) * m->inv_max_density / sigma_t;
         if (t >= tEnd) break;
         Float dens = GridDensity(m, ray.o + ray.d * t) * m->inv_max_density;
         if (dens > smp->Get1D(*scp)) {
