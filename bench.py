@@ -72,7 +72,7 @@ def _lib_id():
         return None
 
 
-def traffic_live(wl_args, workload):
+def traffic_live(wl_args, workload, pmc_steps=2):
     """HBM-side bytes per launch of the closest-hit kernel from a separate `rocprofv3 --pmc FETCH_SIZE` pass over the same
     workload (child process, plain frames only).  FETCH_SIZE is in KiB of 64-byte requests; gfx950 tallies the 128-byte
     requests of 16-byte-per-lane loads at 64 bytes, hence x2 (guides/MI355X_MICROARCH.md, HBM section)."""
@@ -83,7 +83,7 @@ def traffic_live(wl_args, workload):
         return None
     d = tempfile.mkdtemp(prefix="pbrt_amd_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + wl_args + \
-          ["--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--traffic", "none", "--pmc-child"]
+          ["--steps", str(pmc_steps), "--warmup", "0", "--cpu-seconds", "0", "--traffic", "none", "--pmc-child"]
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.time()
     try:
@@ -236,9 +236,10 @@ def main():
     ap.add_argument("--res", type=int, nargs=2, default=[1920, 1080])
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--scene", default=None, help="render this .pbrt instead of the generated stand-in")
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c3 = San-Miguel-class 1080p 64spp (default, the metric's workload); "
-                         "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30")
+                         "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30; "
+                         "c5 = the San-Miguel-class scene at 3840x2160, 512 spp (33-bit Sobol' indices, 32 passes of 2^27 paths; tile-sharded with --gpus N)")
     ap.add_argument("--textured", action="store_true", help="c3 only: the stand-in with image-mapped / bump-mapped materials (SURVEY.md s.8 row f2)")
     ap.add_argument("--volpath", action="store_true", help="c3 only: the stand-in inside a homogeneous medium, Integrator \"volpath\" (SURVEY.md s.8 row f4; k_shade_vol)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target length of the CPU baseline sample: the reference binary oracle/_ref/pbrt_ref on a centre crop of the same frame (0 = skip)")
@@ -258,6 +259,11 @@ def main():
         # same launch line the driver uses) and hand their exit code back; rank 0 of the child job prints the JSON line
         par0 = importlib.import_module("pbrt-v3-distributed_amd.parallel")
         raise SystemExit(par0.launch_ranks(args.gpus, __file__, sys.argv[1:]))
+    if args.config == "c5":   # configs[4]: the C3 scene at 4K / 512 spp
+        if args.res == [1920, 1080]:
+            args.res = [3840, 2160]
+        if args.spp == 64:
+            args.spp = 512
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -403,7 +409,7 @@ def main():
             wl_args += ["--max-paths", str(args.max_paths)]
         traffic = None
         if world == 1 and args.traffic == "live":
-            traffic = traffic_live(wl_args, workload)
+            traffic = traffic_live(wl_args, workload, 1 if args.config == "c5" else 2)
         if world == 1 and traffic is None and args.traffic in ("live", "file"):
             traffic = traffic_from_file(workload)
         if traffic and args.save_traffic and traffic.get("source", "").startswith("live"):

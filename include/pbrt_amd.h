@@ -589,6 +589,10 @@ int mi_sobol(mi_ctx *ctx, int px, int py, int n_samples, int n_dims, float *out,
  * perspective.cpp:95-144) for n (pixel, sample) pairs */
 int mi_camera_rays(mi_ctx *ctx, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n,
                    mi_ray *rays, float *p_film /* 2*n */);
+/* The offset rays of the same camera samples as the shading kernels rebuild them at the first hit of a textured scene:
+ * PerspectiveCamera::GenerateRayDifferential's rx / ry (perspective.cpp:118-141) after RayDifferential::ScaleDifferentials(1 / sqrt(spp))
+ * (integrator.cpp:262-263).  diffs[12 i ..] = rxOrigin, rxDirection, ryOrigin, ryDirection of pair i */
+int mi_camera_differentials(mi_ctx *ctx, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *diffs /* 12*n */);
 /* PathIntegrator::Li per camera sample, before the film: radiance rgb for n (pixel,sample) pairs */
 int mi_li(mi_ctx *ctx, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *L_rgb);
 

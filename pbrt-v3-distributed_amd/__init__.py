@@ -49,7 +49,7 @@ DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
     "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
-    "mi_camera_rays", "mi_li",
+    "mi_camera_rays", "mi_camera_differentials", "mi_li",
 ]
 
 _host = None
@@ -117,6 +117,7 @@ def device_lib():
         L.mi_sphere_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_sobol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mi_camera_differentials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_li.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _dev = L
     return _dev
@@ -325,6 +326,15 @@ class Context:
         self._chk(device_lib().mi_camera_rays(self._ctx, _ptr(pixels_xy), _ptr(sample_num), n, _ptr(rays), _ptr(pfilm)),
                   "mi_camera_rays")
         return rays, pfilm
+
+    def camera_differentials(self, pixels_xy, sample_num):
+        """rx / ry of the camera samples (scaled by 1 / sqrt(spp)): (n, 4, 3) = rxOrigin, rxDirection, ryOrigin, ryDirection"""
+        pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)
+        sample_num = np.ascontiguousarray(sample_num, dtype=np.int32)
+        n = len(sample_num)
+        out = np.zeros((n, 4, 3), dtype=np.float32)
+        self._chk(device_lib().mi_camera_differentials(self._ctx, _ptr(pixels_xy), _ptr(sample_num), n, _ptr(out)), "mi_camera_differentials")
+        return out
 
     def li(self, pixels_xy, sample_num):
         pixels_xy = np.ascontiguousarray(pixels_xy, dtype=np.int32)

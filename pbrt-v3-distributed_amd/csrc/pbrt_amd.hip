@@ -417,6 +417,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                 idle = __ballot(!active);
                 nIdle = __popcll(idle);
             }
+            waveIters = 0;   // the guard bounds the rounds BETWEEN two refills (and after the last one), not the whole persistent launch: independent of the frame size
         }
         if (!__any(active)) break;
         const bool mayRefill = segsTried < 8;
@@ -1169,6 +1170,19 @@ __global__ void k_stage_export_rays(PathState ps, int64_t n, mi_ray *rays, float
     float2 pf = ps.rec[i].pfilm;
     pfilm[2 * i] = pf.x; pfilm[2 * i + 1] = pf.y;
 }
+// camera-ray differentials as the shading kernels rebuild them at the first hit of a textured scene (CameraDifferentials, pt_material.h:
+// PerspectiveCamera::GenerateRayDifferential's rx / ry, perspective.cpp:118-141, after RayDifferential::ScaleDifferentials(1 / sqrt(spp)),
+// integrator.cpp:262-263): out[12 i ..] = rxOrigin, rxDirection, ryOrigin, ryDirection
+__global__ void k_stage_export_diffs(PathState ps, mi_camera cam, int spp, int64_t n, float *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 o = ps.rec[i].ray_o, d = ps.rec[i].ray_d;
+    float2 pf = ps.rec[i].pfilm, ln = ps.rec[i].lens;
+    RayDiffT r = CameraDifferentials(&cam, pf.x, pf.y, ln.x, ln.y, spp, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+    float *q = out + 12 * i;
+    q[0] = r.rxO.x; q[1] = r.rxO.y; q[2] = r.rxO.z; q[3] = r.rxD.x; q[4] = r.rxD.y; q[5] = r.rxD.z;
+    q[6] = r.ryO.x; q[7] = r.ryO.y; q[8] = r.ryO.z; q[9] = r.ryD.x; q[10] = r.ryD.y; q[11] = r.ryD.z;
+}
 __global__ void k_stage_export_L(PathState ps, int64_t n, float *L_rgb) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1618,11 +1632,17 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (c->useQ) {
         std::vector<BVH4QNode> qn;
         std::string err;
-        if (!bvh4q::quantise(bb.out, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, &qn, &sc.qgrid, &err)) return fail("mi_scene_upload: BVH4Q: " + err);
-        DevBuf &b = next();
-        if (upload(c, b, qn.data(), qn.size() * sizeof(BVH4QNode))) return -1;
-        HIP_TRY(hipStreamSynchronize(c->stream));   // local
-        sc.nodesq = b.as<BVH4QNode>();
+        // A grid the folded test cannot serve (non-finite / inconsistent bounds, or cells so large that cell * 1e30 -- the slab constant of a
+        // zero direction component -- overflows) is not an error: the scene takes the full-precision 128-byte nodes, which are always built.
+        bool okq = bvh4q::quantise(bb.out, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, &qn, &sc.qgrid, &err);
+        for (int a = 0; okq && a < 3; ++a) okq = std::isfinite(sc.qgrid.cell[a] * 1e30f * 65535.f) && std::isfinite(sc.qgrid.lo[a]);
+        if (!okq) c->useQ = false;
+        else {
+            DevBuf &b = next();
+            if (upload(c, b, qn.data(), qn.size() * sizeof(BVH4QNode))) return -1;
+            HIP_TRY(hipStreamSynchronize(c->stream));   // local
+            sc.nodesq = b.as<BVH4QNode>();
+        }
     }
     {   // per-triangle shading records (TriShade): vertex normals + uvs gathered through the index buffer
         std::vector<TriShade> tsd(d->n_tris);
@@ -2194,7 +2214,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
                 const dim3 gw(c->gridShade);
 #define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
-                const bool umat = !c->vol.textured;   // constant lobe lists only: wave-uniform material access
+                const bool umat = !c->vol.textured && !c->vol.bssrdf;   // constant lobe lists only: wave-uniform material access (the UMAT instance compiles the BSSRDF branch out)
                 if (c->volWave) {
                     if (c->hasInst) { if (umat) LAUNCH_VOL(true, true, true, gw); else LAUNCH_VOL(true, true, false, gw); }
                     else { if (umat) LAUNCH_VOL(true, false, true, gw); else LAUNCH_VOL(true, false, false, gw); }
@@ -2340,12 +2360,22 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     return 0;
 }
 
+// A traversal wave that hit the non-termination guard dropped its rays: every frame rendered since the last mi_counters_reset is
+// invalid.  mi_sync / mi_film_download / mi_film_gather report that as a FAILURE (no caller can hand out such a film by accident).
+static int guard_check(mi_ctx *c, const char *who) {
+    if (!c->counters.p) return 0;
+    uint64_t trips = 0;
+    HIP_TRY(hipMemcpyAsync(&trips, (const uint64_t *)c->counters.p + MI_CNT_TRACE_GUARD_TRIPS, sizeof(trips), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (trips) return fail(std::string(who) + ": " + std::to_string((unsigned long long)trips) + " traversal wave(s) hit the non-termination guard -- the frame is invalid");
+    return 0;
+}
 int mi_sync(mi_ctx *c) {
     if (!c) return fail("mi_sync: null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     harvest(c);
-    return 0;
+    return guard_check(c, "mi_sync");
 }
 
 int mi_film_clear(mi_ctx *c) {
@@ -2365,7 +2395,7 @@ int mi_film_download(mi_ctx *c, float *rgbw) {
     HIP_TRY(hipMemcpyAsync(rgbw, c->filmPtr, (size_t)c->filmPixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     harvest(c);
-    return 0;
+    return guard_check(c, "mi_film_download");
 }
 void *mi_film_device_ptr(mi_ctx *c) { return c ? (void *)c->filmPtr : nullptr; }
 
@@ -2443,14 +2473,18 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root) {
     for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; ++j) distinct &= devs[j] != devs[i]; }
     if (distinct) {
         std::string err;
+        static std::mutex rcclMutex;   // the cached communicators (g_rccl) are shared by every caller of this process
+        std::lock_guard<std::mutex> lock(rcclMutex);
         if (!g_rccl.load(&err) || !g_rccl.commsFor(devs, &err)) return fail("mi_film_gather: " + err);
         const int ncclFloat32_ = 7, ncclSum_ = 0;   // ncclDataType_t / ncclRedOp_t values of <rccl/rccl.h>
         int rc = g_rccl.GroupStart();
-        for (int i = 0; i < n && rc == 0; ++i) {
-            HIP_TRY(hipSetDevice(ctxs[i]->device));
-            rc = g_rccl.Reduce(ctxs[i]->filmPtr, ctxs[i]->filmPtr, count, ncclFloat32_, ncclSum_, root, g_rccl.comms[i], ctxs[i]->stream);
+        hipError_t he = hipSuccess;
+        for (int i = 0; i < n && rc == 0 && he == hipSuccess; ++i) {   // no early return inside the group: GroupEnd always runs
+            he = hipSetDevice(ctxs[i]->device);
+            if (he == hipSuccess) rc = g_rccl.Reduce(ctxs[i]->filmPtr, ctxs[i]->filmPtr, count, ncclFloat32_, ncclSum_, root, g_rccl.comms[i], ctxs[i]->stream);
         }
         int rc2 = g_rccl.GroupEnd();
+        if (he != hipSuccess) return fail(std::string("mi_film_gather: hipSetDevice: ") + hipGetErrorString(he));
         if (rc != 0 || rc2 != 0) return fail(std::string("mi_film_gather: ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"));
         for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
         return 0;
@@ -3023,7 +3057,7 @@ int mi_sobol(mi_ctx *c, int px, int py, int n_samples, int n_dims, float *out, u
     return 0;
 }
 static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, int64_t off, uint32_t cnt, bool trace,
-                     DevBuf &dxy, DevBuf &ds) {
+                     DevBuf &dxy, DevBuf &ds, bool keepLens = false) {
     (void)n;
     if (upload(c, dxy, pixels_xy + 2 * off, (size_t)cnt * 8) || upload(c, ds, sample_num + off, (size_t)cnt * 4)) return -1;
     PassInfo pass;
@@ -3032,7 +3066,8 @@ static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_
     pass.list_xy = dxy.as<int32_t>(); pass.list_s = ds.as<int32_t>();
     if (trace) return run_pass(c, pass, false, false);
     HIP_TRY(hipMemsetAsync(c->ps.qcount, 0, QC_WORDS * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_raygen<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
+    if (keepLens) hipLaunchKernelGGL(k_raygen<true>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
+    else hipLaunchKernelGGL(k_raygen<false>, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, c->sc, c->ps, pass, 0u);
     return 0;
 }
 int mi_camera_rays(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, mi_ray *rays, float *p_film) {
@@ -3048,6 +3083,21 @@ int mi_camera_rays(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_nu
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     dxy.release(); ds.release(); dr.release(); dp.release();
+    return 0;
+}
+int mi_camera_differentials(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *diffs) {
+    if (stage_common(c)) return -1;
+    if (!pixels_xy || !sample_num || !diffs || n < 0) return fail("mi_camera_differentials: bad argument");
+    DevBuf dxy, ds, dd;
+    for (int64_t off = 0; off < n; off += c->cap) {
+        uint32_t cnt = (uint32_t)std::min<int64_t>(c->cap, n - off);
+        if (list_pass(c, pixels_xy, sample_num, n, off, cnt, false, dxy, ds, true)) return -1;
+        if (dd.alloc((size_t)cnt * 48)) return -1;
+        hipLaunchKernelGGL(k_stage_export_diffs, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->ps, c->sc.camera, c->sc.spp, (int64_t)cnt, dd.as<float>());
+        HIP_TRY(hipMemcpyAsync(diffs + 12 * off, dd.p, (size_t)cnt * 48, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    dxy.release(); ds.release(); dd.release();
     return 0;
 }
 int mi_li(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, float *L_rgb) {

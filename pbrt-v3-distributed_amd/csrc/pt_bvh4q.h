@@ -31,8 +31,12 @@ PT_HD void Bvh4qRayInit(Bvh4qRay &r, const Bvh4qGrid &g, const float o[3], const
     const float K = 16 * 5.9604644775390625e-08f;
     for (int a = 0; a < 3; ++a) {
         r.A[a] = g.cell[a] * inv[a];
-        float B = (g.lo[a] - o[a]) * inv[a];
-        float delta = K * (__builtin_fabsf(B) + 65535 * __builtin_fabsf(r.A[a]));
+        // zero direction components come in as inv = +-1e30: B and the slack may overflow on huge scenes / far origins; clamped to the
+        // largest finite float they stay on the conservative side and inf - inf (NaN: every child culled) cannot occur.  A itself is
+        // finite for every grid mi_scene_upload accepts (cell * 1e30 finite), else the scene takes the full-precision nodes.
+        const float FM = 3.4028234663852886e+38f;
+        float B = __builtin_fminf(__builtin_fmaxf((g.lo[a] - o[a]) * inv[a], -FM), FM);
+        float delta = __builtin_fminf(K * (__builtin_fabsf(B) + 65535 * __builtin_fabsf(r.A[a])), FM);
         r.Bn[a] = B - delta; r.Bf[a] = B + delta;
         r.neg[a] = inv[a] < 0;
     }

@@ -816,6 +816,8 @@ void pbrtWorldEnd() {
     if (g_unsupportedCount > 0) {
         Error("%d unsupported parameter(s) above would change the image: not rendering", g_unsupportedCount);
         scene.reset(); integrator.reset();
+        g_renderFailed = true;    // sticky: the process exit code (main.cpp)
+        g_unsupportedCount = 0;   // per world block: a later, fully supported WorldBegin ... WorldEnd (or scene file) still renders
     }
     if (scene && integrator) {
         if (PbrtOptions.deferRender) {

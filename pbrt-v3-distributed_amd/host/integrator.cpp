@@ -433,6 +433,10 @@ void WavefrontPathIntegrator::Render(const Scene &scene) {
         if (ok && g_dev.counters(ctxs[r], c) == 0) for (int i = 0; i < MI_CNT_COUNT; ++i) total[i] += c[i];
         g_dev.ctx_destroy(ctxs[r]);
     }
+    if (ok && total[MI_CNT_TRACE_GUARD_TRIPS] != 0) {   // traversal waves dropped their rays (non-termination guard): those pixels are wrong
+        Error("%llu traversal wave(s) hit the non-termination guard: the frame is invalid", (unsigned long long)total[MI_CNT_TRACE_GUARD_TRIPS]);
+        ok = false;
+    }
     if (!ok) { Error("rendering failed: no image written"); g_renderFailed = true; return; }   // never an image with missing tiles
     film.MergeFilm(rgbw.data());
     film.WriteImage();

@@ -308,6 +308,7 @@ def test_device_sphere_intersect_matches_reference_vectors():
 @pytest.mark.parametrize("name,w,h,spp,strategy", [("cornell", 64, 64, 1, None), ("cornell", 64, 64, 8, None), ("materials", 96, 72, 1, None), ("materials", 96, 72, 16, None),
                                                     ("cornell", 64, 64, 4, "spatial"), ("materials", 96, 72, 4, "spatial"),
                                                     ("cornell", 64, 48, 4, "gaussian"), ("cornell", 64, 48, 4, "mitchell"),
+                                                    ("cornell", 64, 48, 4, "triangle"), ("cornell", 64, 48, 4, "sinc"),
                                                     ("cornell", 64, 64, 6, "halton"), ("materials", 96, 72, 5, "halton")])
 @pytest.mark.parametrize("mode", list(TRACE_MODES))
 def test_render_vs_reference_fixture(name, w, h, spp, strategy, mode):
@@ -802,6 +803,29 @@ def test_camera_rays_match_reference_classes():
             else:   # the lens sample goes through the device's own sin / cos (ConcentricSampleDisk): bit-exact expected, 1e-6 stated
                 assert (a == r[k]).mean() >= 0.9 and np.allclose(a, r[k], rtol=1e-6, atol=1e-6), (c, k)
 
+
+
+def test_camera_differentials_match_reference_classes():
+    """The offset rays rx / ry of PerspectiveCamera::GenerateRayDifferential (perspective.cpp:118-141) as the shading kernels rebuild them at the first
+    hit of a textured scene (CameraDifferentials), against the same reference-class records: the fixture holds the camera's own rx / ry, the device
+    hands out what Render makes of them, ScaleDifferentials(1 / sqrt(spp)) (integrator.cpp:262-263) -- applied here to the records in float32.
+    Pinhole: bit for bit; thin lens (the lens point goes through the device's sin / cos): >= 90 % bit for bit, 1e-6 stated."""
+    recs = np.load(os.path.join(ROOT, "tests", "golden", "camera_vectors.npz"))["camera_rays"]
+    import edge_scenes as es
+    for c in range(4):
+        r = recs[recs["cfg"] == c]
+        sc = pa.Scene(text=es.camera_kat_scene(r[0]))
+        ctx = pa.Context(sc)
+        got = ctx.camera_differentials(np.stack([r["px"], r["py"]], 1).astype(np.int32), r["s"])
+        ctx.close()
+        s = np.float32(1) / np.sqrt(np.float32(sc.info["spp"]))
+        for j, (k, base) in enumerate((("rx_o", "o"), ("rx_d", "d"), ("ry_o", "o"), ("ry_d", "d"))):
+            want = (r[base] + (r[k] - r[base]) * s).astype(np.float32)
+            a = np.ascontiguousarray(got[:, j])
+            if r["lensr"][0] == 0:
+                assert np.array_equal(a.view(np.uint32), want.view(np.uint32)), (c, k)
+            else:
+                assert (a == want).mean() >= 0.9 and np.allclose(a, want, rtol=1e-6, atol=1e-6), (c, k)
 
 
 def test_c5_regime_crop_tile_sharded():
