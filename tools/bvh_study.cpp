@@ -231,4 +231,80 @@ void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width,
     }
     out[0] = nodes; out[1] = tris; out[2] = hits; out[3] = (double)wn.size();
 }
+// ---- hot-node study (round 3): which share of the interior-node visits of the device's BVH4 lands on the K nodes a block could keep in LDS?
+// Two choices of the K nodes: the K most visited ones (an oracle: needs the rays) and the first K nodes of a largest-surface-area-first expansion from the
+// root (static: what mi_scene_upload can compute).  out[2 * i] / out[2 * i + 1] = share of the visits under choice one / two for K = Ks[i]; out[2 nK] = visits per ray.
+void bvh_study_hot(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int any_hit, const int *Ks, int nK, double *out) {
+    std::vector<WNode> wn;
+    std::vector<std::vector<uint8_t>> cnt;
+    if (!(d->n_bvh_nodes && d->bvh_nodes[0].n_prims == 0)) return;
+    buildWide(d->bvh_nodes, 0, 4, wn, cnt);
+    std::vector<uint64_t> visits(wn.size(), 0);
+    struct Ent { uint32_t ref; uint8_t count; double t; };
+    double total = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        double o[3] = {rays[r].o[0], rays[r].o[1], rays[r].o[2]}, dir[3] = {rays[r].d[0], rays[r].d[1], rays[r].d[2]}, tMax = rays[r].tmax;
+        double inv[3] = {1 / dir[0], 1 / dir[1], 1 / dir[2]};
+        std::vector<Ent> st;
+        Ent cur{0, 0, 0};
+        while (true) {
+            if (cur.ref & LEAF) {
+                uint32_t first = cur.ref & ~LEAF;
+                bool stop = false;
+                for (int i = 0; i < cur.count; ++i) { double t; if (triHit(d, first + i, o, dir, tMax, &t)) { tMax = t; if (any_hit) { stop = true; break; } } }
+                if (stop) break;
+            } else {
+                const WNode &w = wn[cur.ref];
+                ++visits[cur.ref]; ++total;
+                Ent h[8];
+                int nh = 0;
+                for (int k = 0; k < w.n; ++k) {
+                    double t0 = 0, t1 = tMax;
+                    bool ok = true;
+                    for (int a = 0; a < 3 && ok; ++a) {
+                        double tn = ((inv[a] < 0 ? w.hi[k][a] : w.lo[k][a]) - o[a]) * inv[a], tf = ((inv[a] < 0 ? w.lo[k][a] : w.hi[k][a]) - o[a]) * inv[a];
+                        if (tn > t0) t0 = tn;
+                        if (tf < t1) t1 = tf;
+                        if (t0 > t1) ok = false;
+                    }
+                    if (ok) h[nh++] = Ent{w.child[k], cnt[cur.ref][k], t0};
+                }
+                std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });
+                for (int k = 0; k < nh; ++k) st.push_back(h[k]);
+            }
+            bool got = false;
+            while (!st.empty()) { cur = st.back(); st.pop_back(); if (cur.t < tMax) { got = true; break; } }
+            if (!got) break;
+        }
+    }
+    std::vector<uint64_t> sorted(visits);
+    std::sort(sorted.begin(), sorted.end(), [](uint64_t a, uint64_t b) { return a > b; });
+    // static choice: expand from the root, largest child box first
+    int Kmax = 0;
+    for (int i = 0; i < nK; ++i) Kmax = std::max(Kmax, Ks[i]);
+    std::vector<uint32_t> order;
+    {
+        struct Q { float a; uint32_t node; bool operator<(const Q &o) const { return a < o.a; } };
+        std::vector<Q> heap;
+        heap.push_back(Q{1e38f, 0});
+        while (!heap.empty() && (int)order.size() < Kmax) {
+            std::pop_heap(heap.begin(), heap.end());
+            Q q = heap.back(); heap.pop_back();
+            order.push_back(q.node);
+            const WNode &w = wn[q.node];
+            for (int k = 0; k < w.n; ++k) if (!(w.child[k] & LEAF)) {
+                float dx = w.hi[k][0] - w.lo[k][0], dy = w.hi[k][1] - w.lo[k][1], dz = w.hi[k][2] - w.lo[k][2];
+                heap.push_back(Q{2 * (dx * dy + dx * dz + dy * dz), w.child[k]});
+                std::push_heap(heap.begin(), heap.end());
+            }
+        }
+    }
+    for (int i = 0; i < nK; ++i) {
+        double a = 0, b = 0;
+        for (int k = 0; k < Ks[i] && k < (int)sorted.size(); ++k) a += (double)sorted[k];
+        for (int k = 0; k < Ks[i] && k < (int)order.size(); ++k) b += (double)visits[order[k]];
+        out[2 * i] = total > 0 ? a / total : 0; out[2 * i + 1] = total > 0 ? b / total : 0;
+    }
+    out[2 * nK] = n > 0 ? total / (double)n : 0;
+}
 }

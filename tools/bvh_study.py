@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--rays", type=int, default=200000)
+    ap.add_argument("--hot", action="store_true", help="hot-node study: share of the BVH4 node visits on the K nodes a block could hold in LDS")
     args = ap.parse_args()
     import oracle_lib as ol
     pa = importlib.import_module("pbrt-v3-distributed_amd")
@@ -46,6 +47,19 @@ def main():
     sec = np.zeros(len(p), dtype=pa.RAY_DTYPE)
     sec["o"] = (p + n * 1e-3).astype(np.float32); sec["d"] = d.astype(np.float32); sec["tmax"] = np.inf
     print("scene: %d triangles, %d BVH2 nodes; %d camera rays, %d bounce rays" % (sc.info["n_tris"], sc.info["n_bvh_nodes"], len(cam), len(sec)))
+    if args.hot:
+        L.bvh_study_hot.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        Ks = np.array([64, 128, 256, 512, 768, 1024, 1536, 2048, 4096], dtype=np.int32)
+        print("share of the interior-node visits of the device's BVH4 (greedy-area collapse, cull on pop) that land on K nodes")
+        print("%-8s %-8s %9s | %s" % ("rays", "kind", "nodes/ray", "  ".join("K=%-5d" % k for k in Ks)))
+        sh = sec.copy(); sh["tmax"] = 3.0   # short any-hit rays, shadow-ray-like
+        for name, rays, anyhit in (("camera", cam, 0), ("bounce", sec, 0), ("bounce", sec, 1)):
+            rays = np.ascontiguousarray(rays)
+            out = np.zeros(2 * len(Ks) + 1)
+            L.bvh_study_hot(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), anyhit, Ks.ctypes.data_as(C.c_void_p), len(Ks), out.ctypes.data_as(C.c_void_p))
+            print("%-8s %-8s %9.2f | %s   <- the K most visited nodes (needs the rays)" % (name, "any" if anyhit else "closest", out[-1], "  ".join("%6.1f%%" % (100 * out[2 * i]) for i in range(len(Ks)))))
+            print("%-8s %-8s %9s | %s   <- first K of a largest-area-first expansion from the root (static)" % ("", "", "", "  ".join("%6.1f%%" % (100 * out[2 * i + 1]) for i in range(len(Ks)))))
+        return
     print("%-8s %-36s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
     for name, rays in (("camera", cam), ("bounce", sec)):
         rays = np.ascontiguousarray(rays)
