@@ -420,7 +420,10 @@ def main():
                     "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
                     "alg_bytes_per_launch": alg_bytes / max(1.0, launches_per_step), "l2_served_GBps": round(alg_rate, 1),
                     "nodes_per_ray": work["nodes_closest"] / max(1, ext_rays), "tris_per_ray": work["tris_closest"] / max(1, ext_rays),
-                    "layout": "%s: %d nodes x %d B" % (tinfo["name"], tinfo["nodes"], tinfo["node_bytes"])}
+                    "layout": "%s: %d nodes x %d B" % (tinfo["name"], tinfo["nodes"], tinfo["node_bytes"]),
+                    # interior steps served from the traversal blocks' LDS copy of the scene's most visited nodes (hot-node probe at upload)
+                    "hot_nodes_in_lds": tinfo.get("hot_nodes", 0), "hot_share_of_node_visits": round(work.get("nodes_hot_closest", 0) / max(1, work["nodes_closest"]), 4),
+                    "launch_shape": "%d threads x %d block(s) per CU" % (tinfo.get("block_threads", 256), tinfo.get("blocks_per_cu", 6))}
         if traffic:
             roofline["achieved"] = round(traffic["bytes_per_launch"] / (avg_launch_ms * 1e-3) * 1e-9, 1)
             roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
@@ -436,7 +439,8 @@ def main():
         # chains of dependent random fetches of records of the node size from a buffer of the node array's size, same launch shape, no arithmetic.
         try:
             loads = max(1, min(4, tinfo["node_bytes"] // 16))
-            req_per_step = work["nodes_closest"] * (tinfo["node_bytes"] // 16) + work["tris_closest"] * 3 + ext_rays * 3
+            # vector-memory lane requests: the node steps NOT served from LDS, the triangle vertices, the ray record
+            req_per_step = (work["nodes_closest"] - work.get("nodes_hot_closest", 0)) * (tinfo["node_bytes"] // 16) + work["tris_closest"] * 3 + ext_rays * 3
             ach = req_per_step / (t_closest_ms * 1e-3) * 1e-9 if t_closest_ms > 0 else 0.0
             node_mb = max(1, (tinfo["nodes"] * tinfo["node_bytes"]) >> 20)
             ladder = {}   # the same chain of dependent record fetches over working sets that sit in the L1s, the L2s, the Infinity Cache, HBM

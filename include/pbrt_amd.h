@@ -501,8 +501,10 @@ int mi_libm_eval(int device_ordinal, int fn, const float *a, const float *b, int
 /* which traversal kernels the uploaded scene runs: out[0] = 0 general steps over the full-precision 128-byte BVH4 (PBRT_AMD_TRACE=general),
  * 4 two-level (instanced) scene over the same nodes, 5 general steps over the 64-byte quantised BVH4 (the default for single-level scenes;
  * values 1-3 named layouts measured slower in round 2 and removed from the library);
- * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane */
-int mi_trace_info(mi_ctx *ctx, int64_t out[4]);
+ * out[1] = bytes per node, out[2] = nodes, out[3] = stack entries held in LDS per lane, out[4] = hot nodes each traversal block keeps in LDS
+ * (nodesq[0 .. n_hot): the most visited nodes of the hot-node probe at upload; 0: none), out[5] = share of the probe paths' node visits that fell
+ * on them, in 1e-6, out[6] = threads per block and out[7] = blocks per CU of the closest-hit / any-hit launches */
+int mi_trace_info(mi_ctx *ctx, int64_t out[8]);
 
 /* Work counters (names follow the reference's STAT_COUNTERs: integrator.cpp:48,
  * scene.cpp:40-42, triangle.cpp:45) */
@@ -518,6 +520,9 @@ enum mi_counter {
     MI_CNT_MIS_RAYS = 8,     /* the part of CLOSEST_RAYS traced by the MIS launches (integrator.cpp:202) */
     MI_CNT_NODES_MIS = 9,
     MI_CNT_TRIS_MIS = 10,
+    MI_CNT_NODES_HOT_CLOSEST = 11, /* the part of NODES_CLOSEST / NODES_ANY / NODES_MIS served from the traversal blocks' LDS copy of the scene's hot nodes */
+    MI_CNT_NODES_HOT_ANY = 12,
+    MI_CNT_NODES_HOT_MIS = 13,
     MI_CNT_TRACE_GUARD_TRIPS = 15, /* waves that hit the non-termination guard of the traversal kernels: must stay 0 */
     MI_CNT_COUNT = 16
 };

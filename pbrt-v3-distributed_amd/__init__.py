@@ -21,7 +21,7 @@ DEVICE_LIB = os.environ.get("PBRT_AMD_DEVICE_LIB", os.path.join(LIB_DIR, "libpbr
 MI_CNT_COUNT = 16
 MI_K_COUNT = 8
 COUNTER_NAMES = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any",
-                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis", "unused11", "unused12", "unused13", "unused14",
+                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis", "nodes_hot_closest", "nodes_hot_any", "nodes_hot_mis", "unused14",
                  "trace_guard_trips"]
 KERNEL_NAMES = ["raygen", "closest", "sort", "shade", "anyhit", "mis_closest", "film", "other"]
 
@@ -245,10 +245,11 @@ class Context:
         self._chk(device_lib().mi_film_bind(self._ctx, C.c_void_p(device_ptr) if device_ptr else None), "mi_film_bind")
 
     def trace_info(self):
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._chk(device_lib().mi_trace_info(self._ctx, _ptr(out)), "mi_trace_info")
         names = {0: "general steps over the 128-byte BVH4", 4: "two-level BVH4 (instanced scene)", 5: "general steps over the 64-byte quantised BVH4"}
-        return {"mode": int(out[0]), "name": names[int(out[0])], "node_bytes": int(out[1]), "nodes": int(out[2]), "lds_stack_entries": int(out[3])}
+        return {"mode": int(out[0]), "name": names[int(out[0])], "node_bytes": int(out[1]), "nodes": int(out[2]), "lds_stack_entries": int(out[3]),
+                "hot_nodes": int(out[4]), "hot_probe_share": out[5] * 1e-6, "block_threads": int(out[6]), "blocks_per_cu": int(out[7])}
 
     def counters(self):
         out = np.zeros(MI_CNT_COUNT, dtype=np.uint64)

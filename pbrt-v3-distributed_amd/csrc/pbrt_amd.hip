@@ -354,22 +354,52 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_GRID_PER_CU
 #define PT_GRID_PER_CU 6   /* persistent blocks per CU (6 x 24 KiB LDS stacks fit the 160 KiB LDS) */
 #endif
+// Quantised-node instances (round 3): the block keeps the scene's most visited nodes in LDS (TravNodeStepQ) beside its stacks.  The closest-hit and
+// any-hit instances without alpha masks (<= 128 VGPRs) run as ONE 1024-thread block per CU (16 waves; 4 and 6 blocks of 4 waves measured the same
+// in round 2): 24 stack entries x 1024 lanes x 4 B = 96 KiB + 1024 nodes x 64 B = 64 KiB = the CU's 160 KiB.  The MIS instance and the instances
+// that evaluate alpha masks in the leaf step need 150-190 VGPRs (a 1024-thread block would spill): they keep the 256-thread shape of round 2.
+// PT_HOT_NODES 0 = the round-2 shape everywhere (every node step through the vector-memory path).
+#ifndef PT_HOT_NODES
+#define PT_HOT_NODES 1024
+#endif
+#ifndef PT_TRACEQ_BLOCK
+#define PT_TRACEQ_BLOCK 1024
+#endif
+template <int MODE, bool ALPHA, bool QN> struct TraceShape {
+    static constexpr bool BIG = QN && PT_HOT_NODES > 0 && MODE != 1 && !ALPHA;
+    static constexpr int BLOCK = BIG ? PT_TRACEQ_BLOCK : PT_BLOCK;
+    static constexpr int HOT = BIG ? PT_HOT_NODES : 0;
+    static constexpr int LDS_BYTES = PT_LDS_STACK * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
+    static constexpr int PER_CU = BIG ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
+    static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
+    static_assert((size_t)PER_CU * BLOCK <= (size_t)PT_GRID_PER_CU * PT_BLOCK, "the spill slices are sized for gridBlocks x PT_BLOCK threads");
+};
 // SPHERES: the scene has Sphere primitives (separate instances keep the all-triangle traversal free of the call)
 // ALPHA: some mesh has an alpha / shadow-alpha mask (the leaf step then evaluates the mask texture at candidate hits)
 // INST: two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
 template <bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-struct TravTypesQ { typedef TravStateQ State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <int BLOCK> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 // QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
 // (the default for single-level scenes; the full-precision 128-byte nodes serve two-level scenes and PBRT_AMD_TRACE=general)
 template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
+__global__ void __launch_bounds__((TraceShape<MODE, ALPHA, QN>::BLOCK), PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
-    typedef typename std::conditional<QN, TravTypesQ, TravTypes<INST>>::type TT;
-    __shared__ typename TT::Entry lds_stack[TT::LDS * PT_BLOCK];
+    constexpr int BLOCK = TraceShape<MODE, ALPHA, QN>::BLOCK;
+    constexpr int HOT = TraceShape<MODE, ALPHA, QN>::HOT;
+    typedef typename std::conditional<QN, TravTypesQ<BLOCK>, TravTypes<INST>>::type TT;
+    __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
+    __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
+    if constexpr (HOT > 0) {   // the hot nodes as four word planes [word][node]; coalesced 16-byte reads of nodesq[0 .. n_hot)
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodesq);
+        const uint32_t nHot = sc.n_hot < (uint32_t)HOT ? sc.n_hot : (uint32_t)HOT;
+        for (uint32_t i = threadIdx.x; i < 4u * nHot; i += BLOCK) lds_hot[(i & 3u) * HOT + (i >> 2)] = src[i];
+        __syncthreads();   // the only barrier: from here on every wave runs its own loop
+    }
+    LdsNodeWord *hot = (LdsNodeWord *)lds_hot;
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
-    st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * ps.spill_per_thread;
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
     const uint32_t qrow = MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW);
     const bool contig = MODE == 0 && ps.trace_contig;                                     // binned queue: one array, cut into eighths here
@@ -383,7 +413,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     uint32_t slot = 0, lightNum = 0;
     typename TT::State ts;
     ts.cur = TRAV_DONE;
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
     uint32_t waveIters = 0;
     while (true) {
@@ -440,7 +470,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
                     if (wantNode) {
-                        if constexpr (QN) TravNodeStepQ<COUNT>(sc, ts, st, &tc);
+                        if constexpr (QN) TravNodeStepQ<COUNT, HOT>(sc, ts, st, &tc, hot);
                         else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
                     int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
@@ -509,6 +539,70 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(DevScene sc,
     if (COUNT) {
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : (MODE == 1 ? MI_CNT_NODES_MIS : MI_CNT_NODES_ANY)], tc.nodes);
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : (MODE == 1 ? MI_CNT_TRIS_MIS : MI_CNT_TRIS_ANY)], tc.tris);
+        if (HOT > 0) wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_HOT_CLOSEST : (MODE == 1 ? MI_CNT_NODES_HOT_MIS : MI_CNT_NODES_HOT_ANY)], tc.hot);
+    }
+}
+
+// ---- hot-node probe (round 3).  Which BVH4Q nodes should the traversal blocks keep in LDS?  Not the top of the tree: on the 10 M-triangle frame the
+// 1024 nodes with the largest boxes receive 28 % of the node visits, the 1024 most VISITED ones 75 % (tools/bvh_study.py --hot, profiles/r03_b_*) --
+// the camera sees a part of the scene and the paths stay near it.  So mi_scene_upload measures: this kernel walks a few thousand probe paths
+// (camera samples on a regular pixel grid, then cosine-distributed bounces off the geometric normal with a hash for random numbers) through the
+// quantised tree and counts the visits per node; the host renumbers the nodes so that the most visited ones are nodesq[0 .. n_hot).  The choice
+// only decides WHERE a node is read from, never what is read: hits are the same for every choice (the parity suite runs with it).
+PT_DEV uint32_t ProbeHash(uint32_t a, uint32_t b) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_hot_probe(DevScene sc, uint32_t nProbe, uint32_t npx, uint32_t npy, int bounces, uint32_t *visits, StackEntry *spill, int spillPerThread) {
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    const uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= nProbe) return;
+    TravStack st;
+    st.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    st.spill = spill + (size_t)i * spillPerThread;
+    const uint32_t W = (uint32_t)(sc.sample_max[0] - sc.sample_min[0]), H = (uint32_t)(sc.sample_max[1] - sc.sample_min[1]);
+    const uint32_t gx = i % npx, gy = (i / npx) % npy, s = (i / (npx * npy)) % (uint32_t)sc.spp;
+    const int x = sc.sample_min[0] + (int)(((uint64_t)gx * W + W / 2) / npx), y = sc.sample_min[1] + (int)(((uint64_t)gy * H + H / 2) / npy);
+    Sampler smp;
+    smp.Start(sc, x, y, s);
+    V3 o, d;
+    Float tMax, pfx, pfy, l0, l1;
+    GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy, &l0, &l1);
+    TraceCounters tc = {0, 0, 0};
+    for (int b = 0; b <= bounces; ++b) {
+        TravStateQ ts;
+        ts.init(sc, o, d, tMax, st);
+        while (!ts.done()) {
+            if (ts.atNode()) { atomicAdd(&visits[ts.cur], 1u); TravNodeStepQ<false>(sc, ts, st, &tc); }
+            else TravLeafStep<false, false, true, false, TravStateQ, TravStack, false>(sc, ts, st, &tc);
+        }
+        if (ts.prim == TRAV_MISS) break;
+        V3 p0, p1, p2;
+        uint32_t fl;
+        LoadTri(sc, ts.prim, &p0, &p1, &p2, &fl);
+        if (fl & TRI_FLAG_SPHERE) break;
+        V3 n = Cross(p1 - p0, p2 - p0);
+        const Float len = n.Length();
+        if (!(len > 0)) break;
+        n = n * (1 / len);
+        if (Dot(n, d) > 0) n = -n;
+        const V3 p = o + d * ts.tHit;
+        const Float u1 = (Float)(ProbeHash(i, 2u * (uint32_t)b) >> 8) * 0x1p-24f, u2 = (Float)(ProbeHash(i, 2u * (uint32_t)b + 1u) >> 8) * 0x1p-24f;
+        const Float r = sqrtf(u1), ph = 6.2831853f * u2, cz = sqrtf(mx((Float)0, 1 - u1));
+        const V3 a = absf(n.x) > 0.9f ? V3(0, 1, 0) : V3(1, 0, 0);
+        const V3 t1 = Normalize(Cross(n, a)), t2 = Cross(n, t1);
+        d = t1 * (r * cosf(ph)) + t2 * (r * sinf(ph)) + n * cz;
+        o = p + n * (1e-4f * mx(mx(absf(p.x), absf(p.y)), mx(absf(p.z), (Float)1)));
+        tMax = PT_INFINITY;
+    }
+}
+// dst[newIdx[i]] = src[i] with the interior child references renumbered the same way (leaf references and empty slots carry the leaf bit)
+__global__ void __launch_bounds__(PT_BLOCK) k_renumber_nodes(const BVH4QNode *src, BVH4QNode *dst, const uint32_t *newIdx, uint32_t n) {
+    for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += gridDim.x * PT_BLOCK) {
+        BVH4QNode nd = src[i];
+        for (int k = 0; k < 4; ++k) if (!(nd.child[k] & BVH4_LEAF)) nd.child[k] = newIdx[nd.child[k]];
+        dst[newIdx[i]] = nd;
     }
 }
 
@@ -682,6 +776,22 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_cdf(uint32_t nvox, uint32_
         if (fi == 0) for (int i = 1; i < n + 1; ++i) c[i] = Float(i) / Float(n);
         else for (int i = 1; i < n + 1; ++i) c[i] /= fi;
         funcInt[v] = fi;
+    }
+}
+
+// guide words of SpatialPick (pt_shade.h), one thread per voxel: two merges of the voxel's non-decreasing cdf against the M cell bounds
+__global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint32_t nl, uint32_t M, const float *cdf, uint32_t *guide) {
+    for (uint32_t v = blockIdx.x * PT_BLOCK + threadIdx.x; v < nvox; v += gridDim.x * PT_BLOCK) {
+        const float *c = cdf + (size_t)v * (nl + 1);
+        const uint32_t size = nl + 1;
+        uint32_t g = 0, h = 0;
+        const Float invM = 1 / (Float)M;   // exact: M is a power of two
+        for (uint32_t j = 0; j < M; ++j) {
+            const Float lo = (Float)j * invM, hi = (Float)(j + 1) * invM;
+            while (g < size && c[g] <= lo) ++g;   // G = #{cdf[k] <= j / M}
+            while (h < size && c[h] < hi) ++h;    // H = #{cdf[k] < (j + 1) / M}
+            guide[(size_t)v * M + j] = g | (h << 16);
+        }
     }
 }
 
@@ -865,9 +975,10 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
-                        const float *vcdf = cdf, *vfunc = sc.light_func;
                         Float funcInt = sc.light_func_int;
-                        if (sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL) {
+                        const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
+                        size_t vox = 0;
+                        if (spatial) {
                             V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
                             V3 off = isect.p - bmin;   // Bounds3::Offset geometry.h:786-792
                             if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
@@ -877,41 +988,24 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
                             v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
                             v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
-                            size_t vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
-                            vcdf = sc.sp_cdf + vox * (sc.n_lights + 1);
-                            vfunc = sc.sp_func + vox * sc.n_lights;
+                            vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
                             funcInt = sc.sp_func_int[vox];
                         }
                         PROBE(5)   // BSDF ctor + NumComponents + voxel lookup
                         Float ul = us[0];
                         ubase = 1;
-                        // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411): `first` = the
-                        // number of leading cdf entries <= u (the cdf is non-decreasing, so the reference's bisection finds exactly
-                        // that count).  Found here with up to 16 independent probes per round -- 2 memory round trips for a few
-                        // hundred lights instead of 8 dependent ones.
-                        int size = (int)sc.n_lights + 1, first = 0;
-                        {
-                            int lo = 0, hi = size;   // entries below lo are <= u; entries from hi on are > u
-                            while (lo < hi) {
-                                int step = (hi - lo + 15) >> 4;
-                                float pv[16];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) {
-                                    int idx = lo + (k + 1) * step - 1;
-                                    pv[k] = idx < hi ? vcdf[idx] : PT_INFINITY;
-                                }
-                                int cnt = 0;
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) cnt += (pv[k] <= ul) ? 1 : 0;   // a prefix of the probes
-                                int nlo = lo + cnt * step;
-                                int nhi = lo + (cnt + 1) * step - 1;
-                                hi = nhi < hi ? nhi : hi;
-                                lo = nlo < hi ? nlo : hi;
-                            }
-                            first = lo;
+                        // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411): `first` = the number of leading cdf
+                        // entries <= u (the cdf is non-decreasing, so the reference's bisection finds exactly that count).  Spatial tables: through the
+                        // voxel's guide word (SpatialPick); the one power / uniform table: up to 16 independent probes per round on the LDS copy.
+                        int lightNum;
+                        Float funcAt;
+                        if (spatial) SpatialPick(sc, vox, ul, &lightNum, &funcAt);
+                        else {
+                            const int size = (int)sc.n_lights + 1, first = CdfCountLE(cdf, size, ul);
+                            lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+                            funcAt = sc.light_func[lightNum];
                         }
-                        int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
-                        Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
+                        Float selPdf = (funcInt > 0) ? funcAt / (funcInt * (int)sc.n_lights) : 0;
                         if (selPdf != 0) {
                             Float uL0, uL1, uS0, uS1;
                             uL0 = us[1]; uL1 = us[2]; uS0 = us[3]; uS1 = us[4];
@@ -1229,6 +1323,7 @@ struct mi_ctx {
     hipEvent_t evShaded = nullptr, evNeeDone = nullptr;
     bool overlapNee = false;
     int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
+    double hotProbeShare = 0;   // share of the probe paths' node visits that fell on the nodes now in nodesq[0 .. n_hot)
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
     bool hasInst = false;                    // two-level scene (the host's default): the k_trace / k_shade / k_shade_vol INST instances
@@ -1517,7 +1612,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto &b : c->sceneBufs) b.release();
     c->sceneBufs.clear();
-    c->sceneBufs.resize(64 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images + (size_t)d->n_media + 5 * (size_t)d->n_bssrdf_tables);
+    c->sceneBufs.resize(80 + 6 * (size_t)d->n_envmaps + (size_t)d->n_images + (size_t)d->n_media + 5 * (size_t)d->n_bssrdf_tables);
     int nb = 0;
     auto next = [&]() -> DevBuf & { return c->sceneBufs[nb++]; };
     DevScene &sc = c->sc;
@@ -1629,6 +1724,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         c->useQ = !wantGeneral && !c->hasInst && d->n_bvh_nodes > 0;
     }
     sc.nodesq = nullptr;
+    DevBuf *qnBuf = nullptr;
     if (c->useQ) {
         std::vector<BVH4QNode> qn;
         std::string err;
@@ -1642,6 +1738,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             if (upload(c, b, qn.data(), qn.size() * sizeof(BVH4QNode))) return -1;
             HIP_TRY(hipStreamSynchronize(c->stream));   // local
             sc.nodesq = b.as<BVH4QNode>();
+            qnBuf = &b;
         }
     }
     {   // per-triangle shading records (TriShade): vertex normals + uvs gathered through the index buffer
@@ -1889,6 +1986,17 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         hipLaunchKernelGGL(k_spatial_contrib, dim3(gridc), dim3(PT_BLOCK), 0, c->stream, sc, bf.as<float>(), hbuf.as<float>(), total);
         unsigned gridv = (unsigned)std::min<uint64_t>((nvox + PT_BLOCK - 1) / PT_BLOCK, 65536);
         hipLaunchKernelGGL(k_spatial_cdf, dim3(gridv), dim3(PT_BLOCK), 0, c->stream, (uint32_t)nvox, (uint32_t)nl, bf.as<float>(), bc.as<float>(), bi.as<float>());
+        {   // guide table in front of the cdf search (SpatialPick): M = the power of two >= n_lights, at most 256 cells per voxel; PBRT_AMD_LIGHT_GUIDE=0: none
+            const char *eg = std::getenv("PBRT_AMD_LIGHT_GUIDE");
+            uint32_t M = 1;
+            while (M < nl && M < 256) M <<= 1;
+            if (!(eg && eg[0] == '0') && nl + 1 <= 65535 && nvox * M * 4 <= (8ull << 30)) {
+                DevBuf &bg = next();
+                if (bg.alloc(nvox * M * 4)) return -1;
+                hipLaunchKernelGGL(k_spatial_guide, dim3(gridv), dim3(PT_BLOCK), 0, c->stream, (uint32_t)nvox, (uint32_t)nl, M, bc.as<float>(), bg.as<uint32_t>());
+                sc.sp_guide = bg.as<uint32_t>(); sc.sp_guide_m = M;
+            }
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         hbuf.release();
@@ -1988,6 +2096,49 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         return fail("mi_scene_upload: sample bounds exceed 65535 pixels per axis");
     // worst-case Sobol' dimensions: 5 camera + 8 per bounce (the reference LOG(FATAL)s past 1024, sobol.cpp:48-51)
     if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
+    // hot nodes of the quantised tree (k_hot_probe): measured per scene AND camera, nodes renumbered on the device so that nodesq[0 .. n_hot) are the
+    // most visited ones (the root stays node 0: every probe path visits it; ties go to the lower index, so the numbering is a function of the
+    // scene alone).  PBRT_AMD_HOT=0 keeps the reference order and n_hot = 0 (every step through the vector-memory path; A/B and tests).
+    sc.n_hot = 0;
+    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
+        const char *e = std::getenv("PBRT_AMD_HOT");
+        if (!(e && e[0] == '0')) {
+            const uint32_t n = sc.n_nodes, K = std::min<uint32_t>(PT_HOT_NODES, n);
+            const uint32_t W = (uint32_t)(sc.sample_max[0] - sc.sample_min[0]), H = (uint32_t)(sc.sample_max[1] - sc.sample_min[1]);
+            uint32_t npx = std::min<uint32_t>(W, 256), npy = std::min<uint32_t>(H, 256);   // <= 65536 probe paths on a regular grid of pixels
+            uint32_t nProbe = npx * npy;
+            if (nProbe < 16384) nProbe = std::min<uint64_t>(16384, (uint64_t)npx * npy * (uint32_t)sc.spp);   // small films: several samples per pixel
+            nProbe = (nProbe / (npx * npy)) * (npx * npy);
+            const int spillPer = std::max(1, sc.stack_need - PT_LDS_STACK);
+            DevBuf dv, dsp, dni, dst;
+            if (dv.alloc((size_t)n * 4) || dsp.alloc((size_t)((nProbe + PT_BLOCK - 1) / PT_BLOCK) * PT_BLOCK * spillPer * sizeof(StackEntry)) || dni.alloc((size_t)n * 4) || dst.alloc((size_t)n * sizeof(BVH4QNode))) return -1;
+            HIP_TRY(hipMemsetAsync(dv.p, 0, (size_t)n * 4, c->stream));
+            hipLaunchKernelGGL(k_hot_probe, dim3((nProbe + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, c->stream, sc, nProbe, npx, npy, std::min(4, std::max(0, sc.max_depth)),
+                               dv.as<uint32_t>(), dsp.as<StackEntry>(), spillPer);
+            HIP_TRY(hipGetLastError());
+            std::vector<uint32_t> visits(n), order(n), newIdx(n);
+            HIP_TRY(hipMemcpyAsync(visits.data(), dv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (uint32_t i = 0; i < n; ++i) order[i] = i;
+            auto hotter = [&](uint32_t a, uint32_t b) { return visits[a] != visits[b] ? visits[a] > visits[b] : a < b; };
+            std::partial_sort(order.begin(), order.begin() + K, order.end(), hotter);
+            std::vector<uint8_t> isHot(n, 0);
+            for (uint32_t k = 0; k < K; ++k) { newIdx[order[k]] = k; isHot[order[k]] = 1; }
+            for (uint32_t i = 0, nextCold = K; i < n; ++i) if (!isHot[i]) newIdx[i] = nextCold++;   // the others keep their (depth-first) order
+            if (newIdx[0] != 0) return fail("mi_scene_upload: hot-node probe: the root is not the most visited node");
+            HIP_TRY(hipMemcpyAsync(dni.p, newIdx.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_renumber_nodes, dim3(std::min<uint32_t>((n + PT_BLOCK - 1) / PT_BLOCK, 65536u)), dim3(PT_BLOCK), 0, c->stream, sc.nodesq, dst.as<BVH4QNode>(), dni.as<uint32_t>(), n);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            *qnBuf = std::move(dst);
+            sc.nodesq = qnBuf->as<BVH4QNode>();
+            sc.n_hot = K;
+            uint64_t tot = 0, hot = 0;
+            for (uint32_t i = 0; i < n; ++i) tot += visits[i];
+            for (uint32_t k = 0; k < K; ++k) hot += visits[order[k]];
+            c->hotProbeShare = tot ? (double)hot / (double)tot : 0.0;
+        }
+    }
     // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
     std::memset(&c->vol, 0, sizeof(c->vol));
     c->scDev = nullptr;
@@ -2137,12 +2288,14 @@ static void harvest(mi_ctx *c) {
     c->evUsed = 0;
 }
 
-#define LAUNCH_TRACE_I(MODE, ...)                                                                                   \
+// template arguments after COUNT: SPHERES, ALPHA, INST, QN.  Every instance brings its own launch shape (TraceShape: threads per block, blocks per CU)
+#define LAUNCH_TRACE_I(MODE, SPH, ALP, INS, QNN)                                                                    \
     do {                                                                                                            \
-        if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, __VA_ARGS__>), grid, block, 0, st, sc, ps, qin);     \
-        else hipLaunchKernelGGL((k_trace<MODE, false, __VA_ARGS__>), grid, block, 0, st, sc, ps, qin);              \
+        typedef TraceShape<MODE, ALP, QNN> TS_;                                                                     \
+        const dim3 g_(((c->numCUs * TS_::PER_CU + 7) / 8) * 8), b_(TS_::BLOCK);   /* multiple of 8 for the XCD mapping */ \
+        if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, SPH, ALP, INS, QNN>), g_, b_, 0, st, sc, ps, qin);   \
+        else hipLaunchKernelGGL((k_trace<MODE, false, SPH, ALP, INS, QNN>), g_, b_, 0, st, sc, ps, qin);            \
     } while (0)
-// template arguments after COUNT: SPHERES, ALPHA, INST, QN
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
         if (c->hasInst) LAUNCH_TRACE_I(MODE, true, true, true, false);        /* two-level scenes: the general instance (spheres, masks, instances) */ \
@@ -2449,13 +2602,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film_add(float4 *dst, const float4
 }
 }  // namespace
 
-int mi_trace_info(mi_ctx *c, int64_t out[4]) {
+int mi_trace_info(mi_ctx *c, int64_t out[8]) {
     if (!c || !out || !c->haveScene) return fail("mi_trace_info: no scene");
     int mode = c->hasInst ? 4 : (c->useQ ? 5 : 0);
     out[0] = mode;
     out[1] = mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128;
     out[2] = c->sc.n_nodes;
     out[3] = PT_LDS_STACK;
+    out[4] = c->sc.n_hot;
+    out[5] = (int64_t)(c->hotProbeShare * 1e6);
+    out[6] = mode == 5 ? TraceShape<0, false, true>::BLOCK : PT_BLOCK;   // the instance all-triangle / sphere scenes run (masked scenes: the 256-thread shape)
+    out[7] = mode == 5 ? TraceShape<0, false, true>::PER_CU : PT_GRID_PER_CU;
     return 0;
 }
 

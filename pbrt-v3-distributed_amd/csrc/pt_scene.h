@@ -81,10 +81,13 @@ struct DevScene {
     float light_func_int;
     // SpatialLightDistribution (core/lightdistrib.cpp:96-300) as a dense table: one Distribution1D per voxel
     const float *sp_func, *sp_cdf, *sp_func_int;   // [nvox][n_lights], [nvox][n_lights + 1], [nvox]
+    const uint32_t *sp_guide;                      // [nvox][sp_guide_m]: cut points of the voxel's cdf at u = j / sp_guide_m (SpatialPick, pt_shade.h); null: none
+    uint32_t sp_guide_m;                           // a power of two
     int32_t light_strategy, sp_nvox[3];
     float sp_bmin[3], sp_bmax[3];                  // scene.WorldBound()
     float sp_bmin_all[3], sp_bmax_all[3];          // the same for every scene (sp_bmin / sp_bmax are set for the spatial light strategy only): ray binning
     uint32_t n_tris, n_nodes, n_lights, n_materials, n_infinite;
+    uint32_t n_hot;                 // nodesq[0 .. n_hot) are the scene's most visited nodes (hot-node probe at upload): the traversal blocks keep them in LDS
     int32_t stack_need;             // 3 * BVH4 depth + 1
     mi_camera camera;
     // film / sampler / integrator scalars
@@ -364,7 +367,7 @@ PT_DEV void LoadTri(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, u
 }
 
 // ------------------------------------------------------------------ BVH4 traversal
-struct TraceCounters { uint32_t nodes, tris; };
+struct TraceCounters { uint32_t nodes, tris, hot; };
 
 // Ray-box test.  Reference: Bounds3::IntersectP(ray, invDir, dirIsNeg) core/geometry.h:1412-1438 --
 //   tNear_a = (near_a - o_a) * invDir_a,  tFar_a = ((far_a - o_a) * invDir_a) * (1 + 2 gamma(3)),  accept iff the
@@ -407,7 +410,9 @@ typedef unsigned long long StackEntry;   // child reference | entry distance bit
 typedef uint32_t StackEntry;
 #endif
 typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
-struct TravStack {
+// STRIDE = threads per block of the kernel that owns the stack (the [entry][lane] rows are one block wide)
+template <int STRIDE>
+struct TravStackT {
     LdsStackEntry *lds;   // &stack[0][threadIdx.x]; typed as LDS so that pushes / pops are ds_write / ds_read, never flat
     StackEntry *spill;    // per-thread spill slice
     int sp;
@@ -417,14 +422,14 @@ struct TravStack {
 #else
         StackEntry e = v;
 #endif
-        if (sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = e; else spill[sp - PT_LDS_STACK] = e;
+        if (sp < PT_LDS_STACK) lds[sp * STRIDE] = e; else spill[sp - PT_LDS_STACK] = e;
         ++sp;
     }
     // next node / leaf to look at, or TRAV_DONE
     PT_DEV uint32_t pop(Float tMax) {
         while (sp) {
             --sp;
-            StackEntry e = (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : spill[sp - PT_LDS_STACK];
+            StackEntry e = (sp < PT_LDS_STACK) ? lds[sp * STRIDE] : spill[sp - PT_LDS_STACK];
 #if PT_STACK_T
             if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
 #else
@@ -434,6 +439,7 @@ struct TravStack {
         return 0xFFFFFFFFu;
     }
 };
+typedef TravStackT<PT_BLOCK> TravStack;
 
 // Traversal as a per-lane state machine, so that a wave can keep its lanes busy with DIFFERENT rays at
 // different stages (persistent lanes with dynamic ray fetch, see k_trace): `cur` is the next thing to
@@ -448,7 +454,7 @@ struct TravState {
     RayShear shear;
     Float tMax, tHit;
     uint32_t prim, cur;
-    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+    template <class ST> PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, ST &st) {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         box.init(o, V3(1 / d.x, 1 / d.y, 1 / d.z));
         shear.init(d);
@@ -518,7 +524,7 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
 // (mi_bvh4q_validate) checks against the oracle's BVH2 traversal.
 struct TravStateQ : TravState {
     Bvh4qRay q;
-    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+    template <class ST> PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, ST &st) {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         const float oo[3] = {o.x, o.y, o.z};
         const float inv[3] = {d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
@@ -529,17 +535,31 @@ struct TravStateQ : TravState {
         cur = sc.n_nodes ? 0u : TRAV_DONE;
     }
 };
-template <bool COUNT> PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, TravStack &st, TraceCounters *cnt);
-template <bool COUNT>
-PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, TravStack &st, TraceCounters *cnt) {
-    const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
-    uint4 w0 = w[0], w1 = w[1], w2 = w[2], ch = w[3];
-    Pin(w0); Pin(w1); Pin(w2); Pin(ch);
+// HOT > 0: the scene's sc.n_hot most visited nodes (indices 0 .. n_hot - 1 after mi_scene_upload's renumbering; pbrt_amd.hip: hot-node probe) sit in
+// the block's LDS as four word planes hot[word][node] (stride HOT; a wave's lanes read the SAME word of different nodes, so consecutive nodes lie in
+// consecutive 16-byte bank groups and lanes at the same node -- the root, its children -- are one broadcast): a step at such a node is
+// 4 x ds_read_b128 and leaves the vector-memory path alone.  The words are the node's own, so the step is the same either way.
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const U32x4 LdsNodeWord;
+template <bool COUNT, class ST> PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, ST &st, TraceCounters *cnt);
+template <bool COUNT, int HOT = 0, class ST = TravStack>
+PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt, LdsNodeWord *hot = nullptr) {
+    uint4 w0, w1, w2, ch;
+    if (HOT > 0 && ts.cur < sc.n_hot) {
+        LdsNodeWord *h = hot + ts.cur;
+        const U32x4 a = h[0], b = h[HOT], c = h[2 * HOT], e = h[3 * HOT];   // 4 x ds_read_b128
+        w0 = make_uint4(a.x, a.y, a.z, a.w); w1 = make_uint4(b.x, b.y, b.z, b.w); w2 = make_uint4(c.x, c.y, c.z, c.w); ch = make_uint4(e.x, e.y, e.z, e.w);
+        if (COUNT) ++cnt->hot;
+    } else {
+        const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
+        w0 = w[0]; w1 = w[1]; w2 = w[2]; ch = w[3];
+        Pin(w0); Pin(w1); Pin(w2); Pin(ch);
+    }
     TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
 }
 // the step on the node's four 16-byte words, however they were fetched
-template <bool COUNT>
-PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, TravStack &st, TraceCounters *cnt) {
+template <bool COUNT, class ST>
+PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, ST &st, TraceCounters *cnt) {
     if (COUNT) ++cnt->nodes;
     const uint32_t wd[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, ch.x, ch.y, ch.z, ch.w};
     Float t[4];
@@ -577,7 +597,7 @@ struct TravStateI : TravState {
     Float wtMax;
     uint32_t inst, hitInst;
     bool ihit;
-    PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, TravStack &st) {
+    template <class ST> PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, ST &st) {
         TravState::init(sc, o_, d_, tMax_, st);
         inst = hitInst = TRAV_NO_INSTANCE; ihit = false; wtMax = tMax_;
     }

@@ -647,6 +647,43 @@ PT_DEV int CdfCountLE(const float *cdf, int size, Float u) {
     return lo;
 }
 
+// Distribution1D::SampleDiscrete (core/sampling.h:90-100) on the voxel `vox` of the spatial light table (lightdistrib.cpp:139-152), with a guide
+// table in front of the search (round 3).  sp_guide[vox][j] = G | H << 16 for the cell u in [j / M, (j + 1) / M), M a power of two (so u * M and the
+// cell bounds are exact): G = #{cdf[k] <= j / M}, H = #{cdf[k] < (j + 1) / M}; the count `first` = #{cdf[k] <= u} that FindInterval's bisection finds
+// lies in [G, H] and only cdf[G .. H) decides it.  Round trip 1 = the guide word; round trip 2 = those (usually 0-2) cdf entries AND the candidates
+// for func[offset], which depend on G / H only -- two dependent fetches of a few words instead of the search's 24 probes in two rounds + func[offset].
+// Same comparisons on the same cdf values, so `offset` and func[offset] are the search's, bit for bit.
+PT_DEV void SpatialPick(const DevScene &sc, size_t vox, Float u, int *offset, Float *funcAt) {
+    const int size = (int)sc.n_lights + 1;
+    const float *cdf = sc.sp_cdf + vox * (size_t)size, *func = sc.sp_func + vox * (size_t)sc.n_lights;
+    int first;
+    if (sc.sp_guide_m) {
+        const uint32_t M = sc.sp_guide_m;
+        uint32_t j = (uint32_t)(u * (Float)M);
+        j = j < M - 1 ? j : M - 1;
+        const uint32_t gh = sc.sp_guide[vox * M + j];
+        const int lo = (int)(gh & 0xffffu), hi = (int)(gh >> 16);
+        if (hi - lo <= 4) {
+            float c[4], f[5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = lo + k < hi ? cdf[lo + k] : PT_INFINITY;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { int o = lo - 1 + k; o = o < 0 ? 0 : (o > size - 2 ? size - 2 : o); f[k] = func[o]; }
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cnt += (c[k] <= u) ? 1 : 0;   // the cdf is non-decreasing: a prefix
+            first = lo + cnt;
+            *offset = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+            *funcAt = cnt == 0 ? f[0] : (cnt == 1 ? f[1] : (cnt == 2 ? f[2] : (cnt == 3 ? f[3] : f[4])));
+            return;
+        }
+        first = lo + CdfCountLE(cdf + lo, hi - lo, u);
+    } else
+        first = CdfCountLE(cdf, size, u);
+    *offset = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+    *funcAt = func[*offset];
+}
+
 // ---- InfiniteAreaLight with a radiance map (lights/infinite.cpp:92-143)
 PT_DEV int ModI(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }   // core/pbrt.h:310-313
 PT_DEV RGB EnvTexel(const DevEnvMap &e, int s, int t) {   // MIPMap::Texel, ImageWrap::Repeat (mipmap.h:206-228)

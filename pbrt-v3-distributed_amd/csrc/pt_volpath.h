@@ -29,7 +29,7 @@ __device__ __noinline__ LaneHit TraceLane(LaneTracer *lt, const V3 o, const V3 d
     st.lds = lt->lds; st.spill = lt->spill;
     typename std::conditional<INST, TravStateI, TravState>::type ts;
     ts.init(sc, o, d, tMax, st);
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0};
     uint32_t steps = 0;
     while (!ts.done()) {
         if (++steps > (1u << 22)) { ++lt->guardTrips; ts.prim = TRAV_MISS; break; }   // non-termination guard, reported through MI_CNT_TRACE_GUARD_TRIPS
@@ -287,9 +287,10 @@ template <bool INST, class BS>
 __device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, int mIn, int mOut, const BS *bsdf, Float g) {
     const DevScene &sc = *cx.scp;
     if (sc.n_lights == 0) return RGB(0.f);
-    const float *vcdf = sc.light_cdf, *vfunc = sc.light_func;
     Float funcInt = sc.light_func_int;
-    if (sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL) {   // SpatialLightDistribution::Lookup lightdistrib.cpp:139-152; Bounds3::Offset geometry.h:786-792
+    const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
+    size_t vox = 0;
+    if (spatial) {   // SpatialLightDistribution::Lookup lightdistrib.cpp:139-152; Bounds3::Offset geometry.h:786-792
         V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
         V3 off = itp->p - bmin;
         if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
@@ -299,16 +300,19 @@ __device__ __noinline__ RGB UniformSampleOneLightD(VolCtx cx, const Isect *itp, 
         v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
         v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
         v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
-        size_t vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
-        vcdf = sc.sp_cdf + vox * (sc.n_lights + 1);
-        vfunc = sc.sp_func + vox * sc.n_lights;
+        vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
         funcInt = sc.sp_func_int[vox];
     }
     Float ul = cx.smp->Get1D(sc);
-    const int size = (int)sc.n_lights + 1;
-    int first = CdfCountLE(vcdf, size, ul);   // Distribution1D::SampleDiscrete core/sampling.h:90-100
-    int lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
-    Float selPdf = (funcInt > 0) ? vfunc[lightNum] / (funcInt * (int)sc.n_lights) : 0;
+    int lightNum;
+    Float funcAt;
+    if (spatial) SpatialPick(sc, vox, ul, &lightNum, &funcAt);   // Distribution1D::SampleDiscrete core/sampling.h:90-100
+    else {
+        const int size = (int)sc.n_lights + 1, first = CdfCountLE(sc.light_cdf, size, ul);
+        lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
+        funcAt = sc.light_func[lightNum];
+    }
+    Float selPdf = (funcInt > 0) ? funcAt / (funcInt * (int)sc.n_lights) : 0;
     if (selPdf == 0) return RGB(0.f);
     Float uL0, uL1, uS0, uS1;
     cx.smp->Get2D(sc, &uL0, &uL1);

@@ -14,13 +14,14 @@ SCENES = ["cornell.pbrt", "materials.pbrt"]
 # every traversal kernel instance the library ships runs the parity tests: "bvh4q" = the general steps over the 64-byte quantised BVH4
 # (csrc/pt_bvh4q.h; the default for single-level scenes, with or without spheres / masks), "general" = the same steps over the
 # full-precision 128-byte BVH4 (what two-level scenes use; PBRT_AMD_TRACE=general -- run here with ray binning on, PBRT_AMD_RAYBIN=1, so
-# that the binning kernels are covered too).  The variables are read by mi_scene_upload.
-TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general", "PBRT_AMD_RAYBIN": "1"}}
+# that the binning kernels are covered too), "bvh4q-cold" = the quantised tree in the reference's node order with no hot nodes in LDS
+# (PBRT_AMD_HOT=0: every interior step through the vector-memory path, the round-2 behaviour).  The variables are read by mi_scene_upload.
+TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general", "PBRT_AMD_RAYBIN": "1"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0"}}
 
 
 def make_ctx(sc, mode="bvh4q", **kw):
     env = TRACE_MODES[mode]
-    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_RAYBIN")}
+    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_RAYBIN", "PBRT_AMD_HOT")}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -82,6 +83,37 @@ def test_camera_rays_bit_exact(pair):
     assert np.array_equal(pfd.view(np.uint32), pfr.view(np.uint32))
     for k in ("o", "d"):
         assert np.array_equal(rd[k].view(np.uint32), rr[k].view(np.uint32)), k
+
+
+def test_hot_nodes_in_lds_change_nothing():
+    """The traversal blocks keep the scene's most visited BVH4Q nodes (hot-node probe at upload: nodes renumbered, nodesq[0 .. n_hot) staged into LDS) --
+    that decides where a node is read from, never what is read: per-sample radiance, hits and work counters equal the reference-order / no-LDS run
+    bit for bit (the film up to the order of its few atomic adds: box-filter samples that land exactly on a pixel edge)."""
+    sc = pa.Scene(os.path.join(ROOT, "scenes", "materials.pbrt"))
+    res = {}
+    for mode in ("bvh4q", "bvh4q-cold"):
+        ctx = make_ctx(sc, mode)
+        ti = ctx.trace_info()
+        ctx.counters_reset()
+        ctx.render(count_work=True)
+        film = ctx.film().copy()
+        cnt = ctx.counters()
+        xy, s = _pixels(sc, 20000, seed=5)
+        rays, _ = ol.camera_rays(sc, xy, s)
+        hits = ctx.intersect(rays)
+        li = ctx.li(xy[:6000], s[:6000])
+        res[mode] = (ti, film, cnt, hits, li)
+        ctx.close()
+    (ti, film, cnt, hits, li), (ti0, film0, cnt0, hits0, li0) = res["bvh4q"], res["bvh4q-cold"]
+    assert ti["mode"] == 5 and ti0["mode"] == 5
+    assert ti["hot_nodes"] > 0 and 0.2 < ti["hot_probe_share"] <= 1.0 and ti0["hot_nodes"] == 0
+    assert cnt["nodes_hot_closest"] > 0 and cnt["nodes_hot_any"] > 0 and cnt0["nodes_hot_closest"] == 0 and cnt0["nodes_hot_any"] == 0
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any", "tris_any", "trace_guard_trips"):
+        assert cnt[k] == cnt0[k], k
+    assert np.array_equal(li.view(np.uint32), li0.view(np.uint32))
+    assert np.allclose(film, film0, rtol=1e-6, atol=0)
+    for k in hits.dtype.names:
+        assert np.array_equal(hits[k], hits0[k]), k
 
 
 def test_closest_hit_matches_reference_traversal(pair):
