@@ -1,6 +1,7 @@
 // Reference-side binding of the MI355X path tracer, COMPILED AGAINST THE UNMODIFIED REFERENCE (libpbrt_ref.a):
 // the `WavefrontPathIntegrator : public Integrator` of INTEGRATION.md s.2 with a real FlattenScene, i.e. the code a pbrt-v3
-// maintainer adds to hand an already built `Scene` to include/pbrt_amd.h.  Test infrastructure (it lives under oracle/): the
+// maintainer adds to hand an already built `Scene` to include/pbrt_amd.h -- the boundary deliverable of SURVEY.md s.8 row b (built by
+// oracle/ref_build/Makefile into oracle/_ref/pbrt_ref_wavefront, because only that recipe compiles the reference).  The
 // CPU suite parses scenes with the REFERENCE's parser / API / BVH build, flattens the reference's own objects to a
 // mi_scene_desc here and renders that description with the backend named by PBRT_AMD_BACKEND --
 //     oracle (default)  liboracle.so's oracle_render: runs on the CPU box; the image must equal pbrt_ref's own render

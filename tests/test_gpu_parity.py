@@ -654,7 +654,7 @@ REF_STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
 @pytest.mark.parametrize("name", ["infinite", "spheres", "instances2", "tex_materials", "tex_bump", "tex_alpha", "vol_smoke", "vol_inst", "sss_coeff", "sss_inst"])
 def test_reference_host_drives_the_device(name, tmp_path):
     """The drop-in itself: pbrt-v3's unmodified main / parser / API state machine / shape and material factories / BVH build (libpbrt_ref.a) with
-    `Integrator "path"` / `"volpath"` bound to the reference-side stub of INTEGRATION.md s.2 (oracle/ref_build/wavefrontpath.cpp), which flattens
+    `Integrator "path"` / `"volpath"` bound to the reference-side stub of INTEGRATION.md s.2 (integration/wavefrontpath.cpp), which flattens
     the reference's own Scene to a mi_scene_desc and calls mi_ctx_create / mi_scene_upload / mi_render / mi_film_download of libpbrt_amd.so; the
     film goes back through the reference's Film::MergeFilmTile / WriteImage.  Compared with the reference's own render of the same file
     (committed fixture): the image criterion of this suite."""

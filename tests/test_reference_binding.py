@@ -1,6 +1,6 @@
 """CPU: the reference-side binding of INTEGRATION.md s.2, compiled for real (SURVEY.md s.8 row b).
 
-oracle/ref_build/wavefrontpath.cpp is the `WavefrontPathIntegrator : public Integrator` + FlattenScene a pbrt-v3 maintainer would add,
+integration/wavefrontpath.cpp is the `WavefrontPathIntegrator : public Integrator` + FlattenScene a pbrt-v3 maintainer would add,
 built against the UNMODIFIED reference (libpbrt_ref.a) into oracle/_ref/pbrt_ref_wavefront: the reference's own main, parser, API state
 machine, shape factories, Loop subdivision and BVH build run as they are, the stub flattens the reference's `Scene` / `BVHAccel` /
 `GeometricPrimitive` / `Material` (through the BxDFs its ComputeScatteringFunctions builds) / `Light` / camera / film / sampler objects

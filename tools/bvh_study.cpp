@@ -308,3 +308,130 @@ void bvh_study_hot(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int an
     out[2 * nK] = n > 0 ? total / (double)n : 0;
 }
 }
+
+// ---- tree study (round 3): the SAME triangles under a tree of our own instead of the reference's (12 buckets on the axis of the
+// largest centroid extent, bvh.cpp:236-420).  Builder: top-down SAH over all three axes -- `bins` buckets per axis for nodes above `sweepBelow`
+// primitives, the exact sweep (every split position of the centroid order) below --, leaves of at most `leafMax` primitives where the SAH says a
+// leaf is cheaper (cost model: cNode per interior visit, cTri per triangle).  The result replaces bvh_nodes / the triangle order of a COPY of the
+// scene description, so every counter of this file runs on it unchanged.  Closest hits do not depend on the tree (ties at equal t excepted).
+namespace {
+struct RB {
+    const mi_scene_desc *d;
+    std::vector<float> lo, hi, ce;       // per triangle: box, centroid (3 floats each)
+    std::vector<uint32_t> idx;           // permutation being sorted in place
+    std::vector<mi_bvh2_node> nodes;
+    int bins, sweepBelow, leafMax; float cNode, cTri;
+    static float areaOf(const float *a, const float *b) { float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2]; return dx < 0 ? 0.f : 2 * (dx * dy + dx * dz + dy * dz); }
+    uint32_t build(uint32_t begin, uint32_t end) {
+        uint32_t me = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        float bl[3] = {1e30f, 1e30f, 1e30f}, bh[3] = {-1e30f, -1e30f, -1e30f}, cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+        for (uint32_t i = begin; i < end; ++i) {
+            uint32_t t = idx[i];
+            for (int a = 0; a < 3; ++a) {
+                bl[a] = std::min(bl[a], lo[3 * t + a]); bh[a] = std::max(bh[a], hi[3 * t + a]);
+                cl[a] = std::min(cl[a], ce[3 * t + a]); ch[a] = std::max(ch[a], ce[3 * t + a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { nodes[me].bmin[a] = bl[a]; nodes[me].bmax[a] = bh[a]; }
+        const uint32_t n = end - begin;
+        const float A = areaOf(bl, bh);
+        auto makeLeaf = [&]() { nodes[me].offset = (int32_t)begin; nodes[me].n_prims = (uint16_t)n; nodes[me].axis = 0; return me; };
+        if (n == 1) return makeLeaf();
+        float bestCost = 1e38f; int bestAxis = -1; uint32_t bestMid = 0; float bestPos = 0; bool bestBinned = false;
+        if ((int)n > sweepBelow) {
+            for (int a = 0; a < 3; ++a) {
+                if (!(ch[a] > cl[a])) continue;
+                std::vector<uint32_t> cnt(bins, 0);
+                std::vector<float> bbl(3 * bins, 1e30f), bbh(3 * bins, -1e30f);
+                const float sc = bins / (ch[a] - cl[a]);
+                for (uint32_t i = begin; i < end; ++i) {
+                    uint32_t t = idx[i];
+                    int b = std::min(bins - 1, (int)((ce[3 * t + a] - cl[a]) * sc));
+                    ++cnt[b];
+                    for (int k = 0; k < 3; ++k) { bbl[3 * b + k] = std::min(bbl[3 * b + k], lo[3 * t + k]); bbh[3 * b + k] = std::max(bbh[3 * b + k], hi[3 * t + k]); }
+                }
+                std::vector<float> rA(bins, 0.f); std::vector<uint32_t> rN(bins, 0);
+                float rl[3] = {1e30f, 1e30f, 1e30f}, rh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t rn = 0;
+                for (int b = bins - 1; b > 0; --b) {
+                    for (int k = 0; k < 3; ++k) { rl[k] = std::min(rl[k], bbl[3 * b + k]); rh[k] = std::max(rh[k], bbh[3 * b + k]); }
+                    rn += cnt[b]; rA[b] = areaOf(rl, rh); rN[b] = rn;
+                }
+                float ll[3] = {1e30f, 1e30f, 1e30f}, lh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t ln = 0;
+                for (int b = 0; b < bins - 1; ++b) {
+                    for (int k = 0; k < 3; ++k) { ll[k] = std::min(ll[k], bbl[3 * b + k]); lh[k] = std::max(lh[k], bbh[3 * b + k]); }
+                    ln += cnt[b];
+                    if (ln == 0 || rN[b + 1] == 0) continue;
+                    float c = cNode + cTri * (areaOf(ll, lh) * ln + rA[b + 1] * rN[b + 1]) / A;
+                    if (c < bestCost) { bestCost = c; bestAxis = a; bestPos = cl[a] + (b + 1) / sc; bestBinned = true; }
+                }
+            }
+        } else {
+            std::vector<float> rA(n);
+            for (int a = 0; a < 3; ++a) {
+                std::sort(idx.begin() + begin, idx.begin() + end, [&](uint32_t x, uint32_t y) { return ce[3 * x + a] < ce[3 * y + a] || (ce[3 * x + a] == ce[3 * y + a] && x < y); });
+                float rl[3] = {1e30f, 1e30f, 1e30f}, rh[3] = {-1e30f, -1e30f, -1e30f};
+                for (uint32_t i = n - 1; i > 0; --i) {
+                    uint32_t t = idx[begin + i];
+                    for (int k = 0; k < 3; ++k) { rl[k] = std::min(rl[k], lo[3 * t + k]); rh[k] = std::max(rh[k], hi[3 * t + k]); }
+                    rA[i] = areaOf(rl, rh);
+                }
+                float ll[3] = {1e30f, 1e30f, 1e30f}, lh[3] = {-1e30f, -1e30f, -1e30f};
+                for (uint32_t i = 0; i + 1 < n; ++i) {
+                    uint32_t t = idx[begin + i];
+                    for (int k = 0; k < 3; ++k) { ll[k] = std::min(ll[k], lo[3 * t + k]); lh[k] = std::max(lh[k], hi[3 * t + k]); }
+                    float c = cNode + cTri * (areaOf(ll, lh) * (i + 1) + rA[i + 1] * (n - i - 1)) / A;
+                    if (c < bestCost) { bestCost = c; bestAxis = a; bestMid = begin + i + 1; bestBinned = false; }
+                }
+            }
+        }
+        const float leafCost = cTri * n;
+        if ((int)n <= leafMax && (bestAxis < 0 || leafCost <= bestCost)) return makeLeaf();
+        uint32_t mid;
+        if (bestAxis < 0) { mid = begin + n / 2; }   // all centroids equal
+        else if (bestBinned) {
+            const int a = bestAxis;
+            mid = (uint32_t)(std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t x) { return ce[3 * x + a] < bestPos; }) - idx.begin());
+            if (mid == begin || mid == end) { mid = begin + n / 2; std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end, [&](uint32_t x, uint32_t y) { return ce[3 * x + a] < ce[3 * y + a]; }); }
+        } else {
+            const int a = bestAxis;
+            if (a != 2) std::sort(idx.begin() + begin, idx.begin() + end, [&](uint32_t x, uint32_t y) { return ce[3 * x + a] < ce[3 * y + a] || (ce[3 * x + a] == ce[3 * y + a] && x < y); });
+            mid = bestMid;
+        }
+        nodes[me].n_prims = 0; nodes[me].axis = (uint8_t)std::max(0, bestAxis);
+        build(begin, mid);
+        uint32_t second = build(mid, end);
+        nodes[me].offset = (int32_t)second;
+        return me;
+    }
+};
+}  // namespace
+
+extern "C" {
+// counters of bvh_study on a rebuilt tree; out[4] = SAH cost of the new BVH2 relative to the reference's (same cost model), out[5] = leaves, out[6] = mean leaf size
+void bvh_study_rebuilt(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width, int cull_on_pop, int any_hit, int bins, int sweepBelow, int leafMax, float cNode, float cTri, double *out) {
+    RB rb; rb.d = d; rb.bins = bins; rb.sweepBelow = sweepBelow; rb.leafMax = std::min(leafMax, 255); rb.cNode = cNode; rb.cTri = cTri;
+    const uint32_t nt = d->n_tris;
+    rb.lo.resize(3 * (size_t)nt); rb.hi.resize(3 * (size_t)nt); rb.ce.resize(3 * (size_t)nt); rb.idx.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        rb.idx[t] = t;
+        for (int a = 0; a < 3; ++a) {
+            float x0 = d->P[3 * (size_t)v[0] + a], x1 = d->P[3 * (size_t)v[1] + a], x2 = d->P[3 * (size_t)v[2] + a];
+            rb.lo[3 * (size_t)t + a] = std::min(x0, std::min(x1, x2)); rb.hi[3 * (size_t)t + a] = std::max(x0, std::max(x1, x2));
+            rb.ce[3 * (size_t)t + a] = 0.5f * (rb.lo[3 * (size_t)t + a] + rb.hi[3 * (size_t)t + a]);   // the reference's centroid: of the box (bvh.cpp:59-62)
+        }
+    }
+    rb.nodes.reserve(2 * (size_t)nt);
+    rb.build(0, nt);
+    std::vector<uint32_t> tri(3 * (size_t)nt);
+    for (uint32_t i = 0; i < nt; ++i) for (int k = 0; k < 3; ++k) tri[3 * (size_t)i + k] = d->tri_indices[3 * (size_t)rb.idx[i] + k];
+    mi_scene_desc d2 = *d;
+    d2.bvh_nodes = rb.nodes.data(); d2.n_bvh_nodes = (uint32_t)rb.nodes.size(); d2.tri_indices = tri.data();
+    bvh_study(&d2, rays, n, width, cull_on_pop, any_hit, out);
+    auto sah = [&](const mi_bvh2_node *nd, size_t N) { double c = 0; const double A0 = area(nd[0]); for (size_t i = 0; i < N; ++i) c += area(nd[i]) / A0 * (nd[i].n_prims ? cTri * nd[i].n_prims : cNode); return c; };
+    out[4] = sah(rb.nodes.data(), rb.nodes.size()) / sah(d->bvh_nodes, d->n_bvh_nodes);
+    double leaves = 0; for (auto &x : rb.nodes) leaves += x.n_prims > 0;
+    out[5] = leaves; out[6] = nt / std::max(1.0, leaves);
+}
+}

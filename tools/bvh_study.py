@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--rays", type=int, default=200000)
+    ap.add_argument("--rebuild", action="store_true", help="tree study: the same triangles under an own SAH tree (3 axes, binned / exact sweep, leaf sizes) instead of the reference's")
     ap.add_argument("--hot", action="store_true", help="hot-node study: share of the BVH4 node visits on the K nodes a block could hold in LDS")
     args = ap.parse_args()
     import oracle_lib as ol
@@ -59,6 +60,29 @@ def main():
             L.bvh_study_hot(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), anyhit, Ks.ctypes.data_as(C.c_void_p), len(Ks), out.ctypes.data_as(C.c_void_p))
             print("%-8s %-8s %9.2f | %s   <- the K most visited nodes (needs the rays)" % (name, "any" if anyhit else "closest", out[-1], "  ".join("%6.1f%%" % (100 * out[2 * i]) for i in range(len(Ks)))))
             print("%-8s %-8s %9s | %s   <- first K of a largest-area-first expansion from the root (static)" % ("", "", "", "  ".join("%6.1f%%" % (100 * out[2 * i + 1]) for i in range(len(Ks)))))
+        return
+    if args.rebuild:
+        L.bvh_study_rebuilt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.bvh_study_collapse(0, C.c_float(1), C.c_float(1), 0)
+        print("BVH4Q (greedy-area collapse, cull on pop) over different BVH2 trees of the same triangles; requests/ray = 3 + 4 nodes + 3 triangles")
+        print("%-8s %-58s %9s %9s %9s %9s %9s" % ("rays", "tree", "nodes/ray", "tris/ray", "req/ray", "SAH rel.", "tris/leaf"))
+        for name, rays in (("camera", cam), ("bounce", sec)):
+            rays = np.ascontiguousarray(rays)
+            out = np.zeros(8)
+            L.bvh_study(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), 4, 1, 0, out.ctypes.data_as(C.c_void_p))
+            nr, tr = out[0] / len(rays), out[1] / len(rays)
+            base = 3 + 4 * nr + 3 * tr
+            print("%-8s %-58s %9.2f %9.2f %9.1f %9s %9s" % (name, "reference: 12 buckets on the widest centroid axis, leaves <= 4", nr, tr, base, "1.000", "-"))
+            for label, bins, sweep, leaf, cn, ct in (("3 axes x 16 bins, leaves <= 4", 16, 0, 4, 1, 1), ("3 axes x 32 bins, sweep below 256, leaves <= 4", 32, 256, 4, 1, 1),
+                                                     ("3 axes x 32 bins, sweep below 4096, leaves <= 4", 32, 4096, 4, 1, 1),
+                                                     ("same, leaves <= 2", 32, 4096, 2, 1, 1), ("same, leaves <= 8", 32, 4096, 8, 1, 1),
+                                                     ("same, leaves <= 8, cTri 0.5", 32, 4096, 8, 1, 0.5), ("same, leaves <= 16, cTri 0.5", 32, 4096, 16, 1, 0.5),
+                                                     ("same, leaves <= 4, cTri 2", 32, 4096, 4, 1, 2)):
+                out = np.zeros(8)
+                L.bvh_study_rebuilt(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), 4, 1, 0, bins, sweep, leaf, C.c_float(cn), C.c_float(ct), out.ctypes.data_as(C.c_void_p))
+                nr, tr = out[0] / len(rays), out[1] / len(rays)
+                req = 3 + 4 * nr + 3 * tr
+                print("%-8s %-58s %9.2f %9.2f %9.1f %9.3f %9.2f   (%+.1f %% requests)" % (name, label, nr, tr, req, out[4], out[6], 100 * (req / base - 1)))
         return
     print("%-8s %-36s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
     for name, rays in (("camera", cam), ("bounce", sec)):
