@@ -354,23 +354,34 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_GRID_PER_CU
 #define PT_GRID_PER_CU 6   /* persistent blocks per CU (6 x 24 KiB LDS stacks fit the 160 KiB LDS) */
 #endif
-// Quantised-node instances (round 3): the block keeps the scene's most visited nodes in LDS (TravNodeStepQ) beside its stacks.  The closest-hit and
-// any-hit instances without alpha masks (<= 128 VGPRs) run as ONE 1024-thread block per CU (16 waves; 4 and 6 blocks of 4 waves measured the same
-// in round 2): 24 stack entries x 1024 lanes x 4 B = 96 KiB + 1024 nodes x 64 B = 64 KiB = the CU's 160 KiB.  The MIS instance and the instances
-// that evaluate alpha masks in the leaf step need 150-190 VGPRs (a 1024-thread block would spill): they keep the 256-thread shape of round 2.
-// PT_HOT_NODES 0 = the round-2 shape everywhere (every node step through the vector-memory path).
+// Quantised-node instances (round 3): the block keeps the scene's most visited nodes in LDS (TravNodeStepQ) beside its stacks.  Measured on the
+// 10 M-triangle frame (profiles/r03_b_*, r03_c_*): the kernels need their 24 waves per CU (one 1024-thread block per CU with 1024 hot nodes: 69 % of
+// the node steps off the vector-memory path and still 22 % SLOWER than 6 x 256 threads without any), so the closest-hit and any-hit instances
+// of all-triangle scenes without alpha masks (80 VGPRs) run as TWO 768-thread blocks per CU: 16 stack entries x 768 lanes x 4 B = 48 KiB + 512 nodes x 64 B = 32 KiB
+// per block, 160 KiB per CU; deeper stack entries go to the per-thread HBM slice as before.  The MIS instance and the instances with spheres or
+// alpha masks in the leaf step need 125-190 VGPRs: they keep the 256-thread shape of round 2 and read every node through the vector-memory path.
+// PT_HOT_NODES 0 = that shape everywhere.
 #ifndef PT_HOT_NODES
-#define PT_HOT_NODES 1024
+#define PT_HOT_NODES 512
 #endif
 #ifndef PT_TRACEQ_BLOCK
-#define PT_TRACEQ_BLOCK 1024
+#define PT_TRACEQ_BLOCK 768
 #endif
-template <int MODE, bool ALPHA, bool QN> struct TraceShape {
-    static constexpr bool BIG = QN && PT_HOT_NODES > 0 && MODE != 1 && !ALPHA;
+#ifndef PT_TRACEQ_LDS_STACK
+#define PT_TRACEQ_LDS_STACK 16
+#endif
+#ifndef PT_TRACEQ_WAVES
+#define PT_TRACEQ_WAVES 6   /* waves per SIMD the register allocator must leave room for (2 blocks x 12 waves on 4 SIMDs) */
+#endif
+template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
+    static constexpr bool BIG = QN && PT_HOT_NODES > 0 && MODE != 1 && !ALPHA && !SPHERES;
     static constexpr int BLOCK = BIG ? PT_TRACEQ_BLOCK : PT_BLOCK;
     static constexpr int HOT = BIG ? PT_HOT_NODES : 0;
-    static constexpr int LDS_BYTES = PT_LDS_STACK * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
+    static constexpr int NLDS = BIG ? PT_TRACEQ_LDS_STACK : PT_LDS_STACK;
+    static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : PT_TRACE_WAVES;
+    static constexpr int LDS_BYTES = NLDS * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
     static constexpr int PER_CU = BIG ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
+    static_assert(NLDS >= PT_LDS_STACK_MIN, "the spill slices are sized for stack_need - PT_LDS_STACK_MIN entries");
     static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
     static_assert((size_t)PER_CU * BLOCK <= (size_t)PT_GRID_PER_CU * PT_BLOCK, "the spill slices are sized for gridBlocks x PT_BLOCK threads");
 };
@@ -379,15 +390,15 @@ template <int MODE, bool ALPHA, bool QN> struct TraceShape {
 // INST: two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
 template <bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <int BLOCK> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
+template <int BLOCK, int NLDS> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK, NLDS> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = NLDS }; };
 // QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
 // (the default for single-level scenes; the full-precision 128-byte nodes serve two-level scenes and PBRT_AMD_TRACE=general)
 template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false>
-__global__ void __launch_bounds__((TraceShape<MODE, ALPHA, QN>::BLOCK), PT_TRACE_WAVES) k_trace(DevScene sc, PathState ps, uint32_t qin) {
+__global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK), (TraceShape<MODE, SPHERES, ALPHA, QN>::WAVES)) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
-    constexpr int BLOCK = TraceShape<MODE, ALPHA, QN>::BLOCK;
-    constexpr int HOT = TraceShape<MODE, ALPHA, QN>::HOT;
-    typedef typename std::conditional<QN, TravTypesQ<BLOCK>, TravTypes<INST>>::type TT;
+    constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
+    constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
+    typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
     if constexpr (HOT > 0) {   // the hot nodes as four word planes [word][node]; coalesced 16-byte reads of nodesq[0 .. n_hot)
@@ -2098,9 +2109,10 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
     // hot nodes of the quantised tree (k_hot_probe): measured per scene AND camera, nodes renumbered on the device so that nodesq[0 .. n_hot) are the
     // most visited ones (the root stays node 0: every probe path visits it; ties go to the lower index, so the numbering is a function of the
-    // scene alone).  PBRT_AMD_HOT=0 keeps the reference order and n_hot = 0 (every step through the vector-memory path; A/B and tests).
+    // scene alone).  Only for scenes whose closest-hit / any-hit instances keep hot nodes (TraceShape::BIG: all-triangle, no alpha masks).
+    // PBRT_AMD_HOT=0 keeps the reference order and n_hot = 0 (every step through the vector-memory path; A/B and tests).
     sc.n_hot = 0;
-    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
+    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && !c->hasSpheres && !c->hasAlpha && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
         const char *e = std::getenv("PBRT_AMD_HOT");
         if (!(e && e[0] == '0')) {
             const uint32_t n = sc.n_nodes, K = std::min<uint32_t>(PT_HOT_NODES, n);
@@ -2109,7 +2121,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             uint32_t nProbe = npx * npy;
             if (nProbe < 16384) nProbe = std::min<uint64_t>(16384, (uint64_t)npx * npy * (uint32_t)sc.spp);   // small films: several samples per pixel
             nProbe = (nProbe / (npx * npy)) * (npx * npy);
-            const int spillPer = std::max(1, sc.stack_need - PT_LDS_STACK);
+            const int spillPer = std::max(1, sc.stack_need - PT_LDS_STACK);   // k_hot_probe: TravStack (PT_LDS_STACK entries in LDS)
             DevBuf dv, dsp, dni, dst;
             if (dv.alloc((size_t)n * 4) || dsp.alloc((size_t)((nProbe + PT_BLOCK - 1) / PT_BLOCK) * PT_BLOCK * spillPer * sizeof(StackEntry)) || dni.alloc((size_t)n * 4) || dst.alloc((size_t)n * sizeof(BVH4QNode))) return -1;
             HIP_TRY(hipMemsetAsync(dv.p, 0, (size_t)n * 4, c->stream));
@@ -2246,7 +2258,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
             ps.bin_scale[a] = hi > lo ? 8.0f / (hi - lo) : 0.0f;
         }
     }
-    ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK);
+    ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK_MIN);
     {
         const size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4);
         ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * words4);
@@ -2291,7 +2303,7 @@ static void harvest(mi_ctx *c) {
 // template arguments after COUNT: SPHERES, ALPHA, INST, QN.  Every instance brings its own launch shape (TraceShape: threads per block, blocks per CU)
 #define LAUNCH_TRACE_I(MODE, SPH, ALP, INS, QNN)                                                                    \
     do {                                                                                                            \
-        typedef TraceShape<MODE, ALP, QNN> TS_;                                                                     \
+        typedef TraceShape<MODE, SPH, ALP, QNN> TS_;                                                                     \
         const dim3 g_(((c->numCUs * TS_::PER_CU + 7) / 8) * 8), b_(TS_::BLOCK);   /* multiple of 8 for the XCD mapping */ \
         if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, SPH, ALP, INS, QNN>), g_, b_, 0, st, sc, ps, qin);   \
         else hipLaunchKernelGGL((k_trace<MODE, false, SPH, ALP, INS, QNN>), g_, b_, 0, st, sc, ps, qin);            \
@@ -2608,11 +2620,12 @@ int mi_trace_info(mi_ctx *c, int64_t out[8]) {
     out[0] = mode;
     out[1] = mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128;
     out[2] = c->sc.n_nodes;
-    out[3] = PT_LDS_STACK;
+    const bool big = mode == 5 && !c->hasSpheres && !c->hasAlpha && TraceShape<0, false, false, true>::BIG;
+    out[3] = big ? TraceShape<0, false, false, true>::NLDS : PT_LDS_STACK;
     out[4] = c->sc.n_hot;
     out[5] = (int64_t)(c->hotProbeShare * 1e6);
-    out[6] = mode == 5 ? TraceShape<0, false, true>::BLOCK : PT_BLOCK;   // the instance all-triangle / sphere scenes run (masked scenes: the 256-thread shape)
-    out[7] = mode == 5 ? TraceShape<0, false, true>::PER_CU : PT_GRID_PER_CU;
+    out[6] = big ? TraceShape<0, false, false, true>::BLOCK : PT_BLOCK;
+    out[7] = big ? TraceShape<0, false, false, true>::PER_CU : PT_GRID_PER_CU;
     return 0;
 }
 

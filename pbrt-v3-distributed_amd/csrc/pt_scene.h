@@ -410,9 +410,15 @@ typedef unsigned long long StackEntry;   // child reference | entry distance bit
 typedef uint32_t StackEntry;
 #endif
 typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
-// STRIDE = threads per block of the kernel that owns the stack (the [entry][lane] rows are one block wide)
-template <int STRIDE>
+// STRIDE = threads per block of the kernel that owns the stack (the [entry][lane] rows are one block wide); NLDS = entries held in LDS.  The spill
+// slices are sized for the shallowest LDS part any kernel uses (PT_LDS_STACK_MIN)
+#ifndef PT_LDS_STACK_MIN
+#define PT_LDS_STACK_MIN 16
+#endif
+template <int STRIDE, int NLDS = PT_LDS_STACK>
 struct TravStackT {
+    enum { LDS_ENTRIES = NLDS, STRIDE_ = STRIDE };
+    typedef LdsStackEntry *LdsPtr;
     LdsStackEntry *lds;   // &stack[0][threadIdx.x]; typed as LDS so that pushes / pops are ds_write / ds_read, never flat
     StackEntry *spill;    // per-thread spill slice
     int sp;
@@ -422,14 +428,14 @@ struct TravStackT {
 #else
         StackEntry e = v;
 #endif
-        if (sp < PT_LDS_STACK) lds[sp * STRIDE] = e; else spill[sp - PT_LDS_STACK] = e;
+        if (sp < NLDS) lds[sp * STRIDE] = e; else spill[sp - NLDS] = e;
         ++sp;
     }
     // next node / leaf to look at, or TRAV_DONE
     PT_DEV uint32_t pop(Float tMax) {
         while (sp) {
             --sp;
-            StackEntry e = (sp < PT_LDS_STACK) ? lds[sp * STRIDE] : spill[sp - PT_LDS_STACK];
+            StackEntry e = (sp < NLDS) ? lds[sp * STRIDE] : spill[sp - NLDS];
 #if PT_STACK_T
             if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
 #else
@@ -545,19 +551,27 @@ template <bool COUNT, class ST> PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w
 template <bool COUNT, int HOT = 0, class ST = TravStack>
 PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt, LdsNodeWord *hot = nullptr) {
     uint4 w0, w1, w2, ch;
-    if (HOT > 0 && ts.cur < sc.n_hot) {
+    const bool isHot = HOT > 0 && ts.cur < sc.n_hot;
+    if (isHot) {   // issued first: the LDS reads of the hot lanes are in flight while the others' global loads are
         LdsNodeWord *h = hot + ts.cur;
         const U32x4 a = h[0], b = h[HOT], c = h[2 * HOT], e = h[3 * HOT];   // 4 x ds_read_b128
         w0 = make_uint4(a.x, a.y, a.z, a.w); w1 = make_uint4(b.x, b.y, b.z, b.w); w2 = make_uint4(c.x, c.y, c.z, c.w); ch = make_uint4(e.x, e.y, e.z, e.w);
         if (COUNT) ++cnt->hot;
-    } else {
+    }
+    if (!isHot) {
         const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
         w0 = w[0]; w1 = w[1]; w2 = w[2]; ch = w[3];
-        Pin(w0); Pin(w1); Pin(w2); Pin(ch);
+        if (HOT == 0) { Pin(w0); Pin(w1); Pin(w2); Pin(ch); }   // with hot nodes the wait belongs after the join: LDS reads and global loads of a mixed wave overlap
     }
     TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
 }
 // the step on the node's four 16-byte words, however they were fetched
+// PT_LEAN_STEP (round 3: the traversal kernels are bound by VALU issue as much as by memory, profiles/r03_c_*): the tail of the step with fewer
+// instructions and the same decisions -- compare-exchanges as v_min / v_max on the distances + two selects on the references (the swap condition
+// is still tb < ta), and the up-to-three pushes as one address + three predicated LDS stores while the lane's stack stays inside its LDS part.
+#ifndef PT_LEAN_STEP
+#define PT_LEAN_STEP 1
+#endif
 template <bool COUNT, class ST>
 PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, ST &st, TraceCounters *cnt) {
     if (COUNT) ++cnt->nodes;
@@ -566,15 +580,44 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
     const uint32_t mask = Bvh4qStepWords(wd, ts.q, ts.tMax, t);
     Float t0 = (mask & 1u) ? t[0] : PT_INFINITY, t1 = (mask & 2u) ? t[1] : PT_INFINITY, t2 = (mask & 4u) ? t[2] : PT_INFINITY, t3 = (mask & 8u) ? t[3] : PT_INFINITY;
     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    const int nh = __builtin_popcount(mask);
+#if PT_LEAN_STEP && !PT_STACK_T
+    // v_min_f32 / v_max_f32 straight (the distances are never NaN; the builtins would first canonicalise both operands: two more instructions each)
+#ifdef PT_HOST_EMU
+#define PT_MINMAX(lo, hi, a, b) lo = (b) < (a) ? (b) : (a); hi = (b) < (a) ? (a) : (b);
+#else
+#define PT_MINMAX(lo, hi, a, b) asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b)); asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+#endif
+#define PT_CSWAP(ta, ca, tb, cb) { const bool sw_ = tb < ta; Float lo_, hi_; PT_MINMAX(lo_, hi_, ta, tb) const uint32_t cl_ = sw_ ? cb : ca, ch_ = sw_ ? ca : cb; ta = lo_; tb = hi_; ca = cl_; cb = ch_; }
+    PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+#undef PT_MINMAX
+    if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
+    ts.cur = c0;
+    if (nh > 1) {
+        if (st.sp + 3 <= ST::LDS_ENTRIES) {   // entries sp, sp + 1, sp + 2 <- the hit children far to near: c[nh - 1], c[nh - 2], c[nh - 3]
+            const uint32_t e0 = nh == 4 ? c3 : (nh == 3 ? c2 : c1), e1 = nh == 4 ? c2 : c1;
+            typename ST::LdsPtr base = st.lds + st.sp * ST::STRIDE_;
+            base[0] = e0;
+            if (nh > 2) base[ST::STRIDE_] = e1;
+            if (nh > 3) base[2 * ST::STRIDE_] = c1;
+            st.sp += nh - 1;
+        } else {
+            if (nh > 3) st.push(c3, t3);
+            if (nh > 2) st.push(c2, t2);
+            st.push(c1, t1);
+        }
+    }
+#else
 #define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
     PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
 #undef PT_CSWAP
-    const int nh = __builtin_popcount(mask);
     if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
     if (nh > 3) st.push(c3, t3);
     if (nh > 2) st.push(c2, t2);
     if (nh > 1) st.push(c1, t1);
     ts.cur = c0;
+#endif
 }
 
 // ------------------------------------------------------------------ two-level instancing (the host's default since round 2; PBRT_AMD_INSTANCING=0 flattens)

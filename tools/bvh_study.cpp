@@ -435,3 +435,119 @@ void bvh_study_rebuilt(const mi_scene_desc *d, const mi_ray *rays, int64_t n, in
     out[5] = leaves; out[6] = nt / std::max(1.0, leaves);
 }
 }
+
+// ---- wave-scheduling simulator (round 3): the per-lane state machine of k_trace run for 64-lane waves on the host, to count how many wave-level
+// node phases / leaf phases a policy needs and how many lanes take part in each (SIMT efficiency) -- the traversal kernels turned out to be bound by
+// VALU issue as much as by memory (profiles/r03_c_*: 47 % of the lanes active per VALU instruction), and policies can be compared here without a GPU.
+//   policy 0: k_trace today -- up to `nodeSteps` node phases while any lane wants one (stop early once `leafMin` lanes wait at a leaf), then ONE
+//             triangle per lane at a leaf; refill when `refill` lanes are idle
+//   policy 1: as 0, but a leaf phase walks ALL triangles of each lane's leaf (phases = the longest leaf among the lanes)
+//   policy 2: postponed leaves -- a lane reaching a leaf parks it (one slot) and keeps traversing; parked leaves are tested when `leafMin` lanes have
+//             one (or a lane needs its slot again / has nothing else to do).  Speculative: nodes are visited with the old tMax
+// out: [0] rays, [1] node phases, [2] lane node steps, [3] leaf phases, [4] lane triangle tests, [5] outer iterations
+extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int policy, int nodeSteps, int leafMin, int refill, double *out) {
+    std::vector<WNode> wn;
+    std::vector<std::vector<uint8_t>> cnt;
+    if (!(d->n_bvh_nodes && d->bvh_nodes[0].n_prims == 0)) return;
+    buildWide(d->bvh_nodes, 0, 4, wn, cnt);
+    const uint32_t DONE = 0xFFFFFFFFu;
+    struct Lane {
+        bool active = false; double o[3], dir[3], inv[3], tMax; uint32_t cur = 0xFFFFFFFFu; int left = 0;   // cur: node index, LEAF | first prim (left = triangles after this one), DONE
+        std::vector<std::pair<uint32_t, int>> st;   // (ref, count)
+        uint32_t parked = 0xFFFFFFFFu; int parkedCount = 0;
+    };
+    double phN = 0, laN = 0, phL = 0, laL = 0, iters = 0, nrays = 0;
+    for (int64_t base = 0; base < n;) {   // one wave at a time over a contiguous slice of the rays (a wave's batches come from one queue segment)
+        int64_t sliceEnd = std::min<int64_t>(n, base + 4096);
+        int64_t next = base;
+        Lane L[64];
+        auto pop = [&](Lane &l) { if (l.st.empty()) { l.cur = DONE; } else { l.cur = l.st.back().first; l.left = l.st.back().second - 1; l.st.pop_back(); } };
+        auto nodeStep = [&](Lane &l) {
+            const WNode &w = wn[l.cur];
+            struct H { uint32_t ref; int c; double t; } h[4]; int nh = 0;
+            for (int k = 0; k < w.n; ++k) {
+                double t0 = 0, t1 = l.tMax; bool ok = true;
+                for (int a = 0; a < 3 && ok; ++a) {
+                    double tn = ((l.inv[a] < 0 ? w.hi[k][a] : w.lo[k][a]) - l.o[a]) * l.inv[a], tf = ((l.inv[a] < 0 ? w.lo[k][a] : w.hi[k][a]) - l.o[a]) * l.inv[a];
+                    if (tn > t0) t0 = tn; if (tf < t1) t1 = tf; if (t0 > t1) ok = false;
+                }
+                if (ok) h[nh++] = H{w.child[k], cnt[l.cur][k], t0};
+            }
+            std::sort(h, h + nh, [](const H &a, const H &b) { return a.t < b.t; });
+            if (nh == 0) { pop(l); return; }
+            for (int k = nh - 1; k >= 1; --k) l.st.push_back({h[k].ref, h[k].c});
+            l.cur = h[0].ref; l.left = h[0].c - 1;
+        };
+        auto triStep = [&](Lane &l, uint32_t prim) { double t; if (triHit(d, prim, l.o, l.dir, l.tMax, &t)) l.tMax = t; };
+        auto atNode = [&](const Lane &l) { return l.active && !(l.cur & LEAF); };
+        auto atLeaf = [&](const Lane &l) { return l.active && l.cur != DONE && (l.cur & LEAF); };
+        while (true) {
+            int nIdle = 0; for (auto &l : L) nIdle += !l.active;
+            if (nIdle >= refill && next < sliceEnd) {
+                for (auto &l : L) if (!l.active && next < sliceEnd) {
+                    const mi_ray &r = rays[next++]; ++nrays;
+                    for (int a = 0; a < 3; ++a) { l.o[a] = r.o[a]; l.dir[a] = r.d[a]; l.inv[a] = 1.0 / r.d[a]; }
+                    l.tMax = r.tmax; l.cur = 0; l.left = 0; l.st.clear(); l.active = true; l.parked = DONE;
+                }
+            }
+            int nAct = 0; for (auto &l : L) nAct += l.active;
+            if (!nAct) break;
+            const bool mayRefill = next < sliceEnd;
+            while (true) {
+                ++iters;
+                if (policy == 2) {
+                    // node phases; a lane that reaches a leaf parks it and pops on (if its slot is free)
+                    for (int g = 0; g < nodeSteps; ++g) {
+                        int nWant = 0; for (auto &l : L) nWant += atNode(l);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (auto &l : L) if (atNode(l)) {
+                            nodeStep(l);
+                            if (atLeaf(l) && l.parked == DONE) { l.parked = l.cur; l.parkedCount = l.left + 1; pop(l); if (l.cur == DONE && l.parked != DONE) l.cur = LEAF | 0x7ffffffe; }   // sentinel: only the parked leaf is left
+                        }
+                        int nPark = 0, nBlocked = 0; for (auto &l : L) { nPark += l.active && l.parked != DONE; nBlocked += l.active && l.parked != DONE && (atLeaf(l)); }
+                        if (nPark >= leafMin || nBlocked >= leafMin / 2) break;
+                    }
+                    // leaf phases over the parked leaves (all triangles)
+                    int maxC = 0, nP = 0; for (auto &l : L) if (l.active && l.parked != DONE) { maxC = std::max(maxC, l.parkedCount); ++nP; }
+                    bool need = false; for (auto &l : L) if (l.active && l.parked != DONE && (atLeaf(l) || l.cur == DONE)) need = true;
+                    int nNode = 0; for (auto &l : L) nNode += atNode(l);
+                    if (nP && (nP >= leafMin || need || nNode == 0)) {
+                        for (int k = 0; k < maxC; ++k) { ++phL; for (auto &l : L) if (l.active && l.parked != DONE && k < l.parkedCount) { ++laL; triStep(l, (l.parked & ~LEAF) + k); } }
+                        for (auto &l : L) if (l.active && l.parked != DONE) {
+                            l.parked = DONE;
+                            if (l.cur == (LEAF | 0x7ffffffe)) l.cur = DONE;
+                            else if (atLeaf(l)) { l.parked = l.cur; l.parkedCount = l.left + 1; pop(l); if (l.cur == DONE) l.cur = LEAF | 0x7ffffffe; }
+                        }
+                    }
+                } else {
+                    int guard = 0;
+                    while (true) {
+                        int nWant = 0; for (auto &l : L) nWant += atNode(l);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (auto &l : L) if (atNode(l)) nodeStep(l);
+                        int nLeaf = 0; for (auto &l : L) nLeaf += atLeaf(l);
+                        if (nLeaf >= leafMin || ++guard >= nodeSteps) break;
+                    }
+                    int nLeaf = 0; for (auto &l : L) nLeaf += atLeaf(l);
+                    if (nLeaf) {
+                        if (policy == 0) {
+                            ++phL; laL += nLeaf;
+                            for (auto &l : L) if (atLeaf(l)) { uint32_t first = l.cur & ~LEAF; triStep(l, first); if (l.left) { l.cur = LEAF | (first + 1); --l.left; } else pop(l); }
+                        } else {
+                            int maxC = 0; for (auto &l : L) if (atLeaf(l)) maxC = std::max(maxC, l.left + 1);
+                            for (int k = 0; k < maxC; ++k) { ++phL; for (auto &l : L) if (atLeaf(l) && k <= l.left) { ++laL; triStep(l, (l.cur & ~LEAF) + k); } }
+                            for (auto &l : L) if (atLeaf(l)) pop(l);
+                        }
+                    }
+                }
+                for (auto &l : L) if (l.active && l.cur == DONE && l.parked == DONE) l.active = false;
+                nAct = 0; for (auto &l : L) nAct += l.active;
+                if (nAct == 0 || (mayRefill && nAct <= 64 - refill)) break;
+            }
+        }
+        base = sliceEnd;
+    }
+    out[0] = nrays; out[1] = phN; out[2] = laN; out[3] = phL; out[4] = laL; out[5] = iters;
+}

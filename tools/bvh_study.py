@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--rays", type=int, default=200000)
     ap.add_argument("--rebuild", action="store_true", help="tree study: the same triangles under an own SAH tree (3 axes, binned / exact sweep, leaf sizes) instead of the reference's")
+    ap.add_argument("--wavesim", action="store_true", help="wave-scheduling simulator: SIMT efficiency of k_trace's node / leaf phases under different policies")
     ap.add_argument("--hot", action="store_true", help="hot-node study: share of the BVH4 node visits on the K nodes a block could hold in LDS")
     args = ap.parse_args()
     import oracle_lib as ol
@@ -60,6 +61,28 @@ def main():
             L.bvh_study_hot(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), anyhit, Ks.ctypes.data_as(C.c_void_p), len(Ks), out.ctypes.data_as(C.c_void_p))
             print("%-8s %-8s %9.2f | %s   <- the K most visited nodes (needs the rays)" % (name, "any" if anyhit else "closest", out[-1], "  ".join("%6.1f%%" % (100 * out[2 * i]) for i in range(len(Ks)))))
             print("%-8s %-8s %9s | %s   <- first K of a largest-area-first expansion from the root (static)" % ("", "", "", "  ".join("%6.1f%%" % (100 * out[2 * i + 1]) for i in range(len(Ks)))))
+        return
+    if args.wavesim:
+        L.bvh_study_wavesim.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rng2 = np.random.RandomState(5)
+        rays = np.ascontiguousarray(sec[rng2.permutation(len(sec))])
+        CN, CL = 230.0, 300.0   # instructions of one node phase / one triangle phase of k_trace<0, QN> (gfx950 ISA, VALU + SALU)
+        print("64-lane waves over %d incoherent bounce rays; cost = node phases x %.0f + triangle phases x %.0f instructions" % (len(rays), CN, CL))
+        print("%-64s %9s %9s %8s %9s %9s %8s %10s" % ("policy", "nodePh/ray", "lanes/ph", "eff", "triPh/ray", "lanes/ph", "eff", "instr/ray"))
+        base = None
+        for label, pol, ns, lm, rf in (("k_trace today: <= 8 node phases, leaf phase at 24 lanes, 1 triangle, refill 16", 0, 8, 24, 16),
+                                        ("same, refill at 8 idle lanes", 0, 8, 24, 8), ("same, refill at 32", 0, 8, 24, 32),
+                                        ("<= 4 node phases", 0, 4, 24, 16), ("<= 16 node phases, leaf at 32", 0, 16, 32, 16), ("<= 32 node phases, leaf at 40", 0, 32, 40, 16),
+                                        ("<= 64 node phases, leaf at 48", 0, 64, 48, 16), ("<= 64 node phases, leaf at 56", 0, 64, 56, 16),
+                                        ("whole leaf per leaf phase, <= 8 / 24", 1, 8, 24, 16), ("whole leaf, <= 32 / 40", 1, 32, 40, 16), ("whole leaf, <= 64 / 56", 1, 64, 56, 16),
+                                        ("postponed leaves, <= 8 / 24", 2, 8, 24, 16), ("postponed leaves, <= 16 / 32", 2, 16, 32, 16), ("postponed leaves, <= 32 / 48", 2, 32, 48, 16)):
+            out = np.zeros(8)
+            L.bvh_study_wavesim(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), pol, ns, lm, rf, out.ctypes.data_as(C.c_void_p))
+            nr = out[0]
+            cost = (out[1] * CN + out[3] * CL) / (nr / 64.0) / 64.0
+            if base is None: base = cost
+            print("%-64s %9.2f %9.1f %7.1f%% %9.2f %9.1f %7.1f%% %10.0f (%+.1f %%)  nodes/ray %.2f tris/ray %.2f" % (label, out[1] * 64 / nr, out[2] / max(1, out[1]), 100 * out[2] / max(1, out[1]) / 64,
+                  out[3] * 64 / nr, out[4] / max(1, out[3]), 100 * out[4] / max(1, out[3]) / 64, cost, 100 * (cost / base - 1), out[2] / nr, out[4] / nr))
         return
     if args.rebuild:
         L.bvh_study_rebuilt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
