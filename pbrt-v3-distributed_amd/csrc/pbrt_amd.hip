@@ -2001,7 +2001,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             const char *eg = std::getenv("PBRT_AMD_LIGHT_GUIDE");
             uint32_t M = 1;
             while (M < nl && M < 256) M <<= 1;
-            if (!(eg && eg[0] == '0') && nl + 1 <= 65535 && nvox * M * 4 <= (8ull << 30)) {
+            // only where the search needs more than one round of 16 probes: with a handful of lights the guide word is one dependent fetch MORE
+            // (measured: k_shade +2..4 % on the one-light / few-light frames C2 and C4, -0.9 % on C3's 130 lights; profiles/r03_d_*)
+            if (!(eg && eg[0] == '0') && nl >= 32 && nl + 1 <= 65535 && nvox * M * 4 <= (8ull << 30)) {
                 DevBuf &bg = next();
                 if (bg.alloc(nvox * M * 4)) return -1;
                 hipLaunchKernelGGL(k_spatial_guide, dim3(gridv), dim3(PT_BLOCK), 0, c->stream, (uint32_t)nvox, (uint32_t)nl, M, bc.as<float>(), bg.as<uint32_t>());
