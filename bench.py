@@ -329,11 +329,17 @@ def main():
 
     pa = importlib.import_module("pbrt-v3-distributed_amd")
     par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
-    # every rank parses the scene and builds the (reference's) BVH itself: share the usable CPUs between the ranks of this node
-    os.environ.setdefault("PBRT_AMD_NTHREADS", str(max(1, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
-    t0 = time.time()
-    sc = pa.Scene(scene_file)
-    t_load = time.time() - t0
+    # one scene build per node (parallel.node_scene): local rank 0 parses the scene and builds the reference's BVH with every usable CPU and
+    # publishes the flattened scene as one file; the other ranks of the node map it (no N-fold parse / build / host copy of the geometry)
+    os.environ.setdefault("PBRT_AMD_NTHREADS", str(max(1, host_cpus())))
+    blob_dir = os.environ.get("PBRT_AMD_BLOB_DIR") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else bench_dir)   # tmpfs: the blob is a memcpy, not a disk write
+    blob = os.path.join(blob_dir, "pbrt_amd_scene_%d.blob" % os.getppid())   # the launcher's pid: unique per job
+    if world > 1:
+        sc, t_load, scene_source = par.node_scene(lambda: pa.Scene(scene_file), blob, local_rank)
+    else:
+        t0 = time.time()
+        sc = pa.Scene(scene_file)
+        t_load, scene_source = time.time() - t0, "built"
     t0 = time.time()
     ctx = pa.Context(sc, device=local_rank)
     t_upload = time.time() - t0
@@ -476,10 +482,16 @@ def main():
                "config": {"workload": workload, "tiles": "16x16 round-robin over ranks", "parallelism": "tile-sharded x%d" % world},
                "mrays_per_s": round(mrays, 2), "rays_per_sample": round(samples[1] / max(1.0, samples[0]), 3),
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
-               "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2)}}
+               "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2),
+                           "scene": "rank 0 of the node builds it once, the other ranks map the published blob" if world > 1 else "built"}}
         print(json.dumps(out), flush=True)
     frame.close()
     ctx.close()
+    if world > 1 and local_rank == 0:   # every rank has passed the final barrier of frame.close(): nobody still needs the file (mappings stay valid anyway)
+        try:
+            os.remove(blob)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

@@ -67,6 +67,9 @@ def host_lib():
         L.pbrt_amd_scene_load_crop.restype = C.c_void_p
         L.pbrt_amd_scene_load_crop.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_float)]
         L.pbrt_amd_scene_free.argtypes = [C.c_void_p]
+        L.pbrt_amd_scene_save_blob.argtypes = [C.c_void_p, C.c_char_p]
+        L.pbrt_amd_scene_map_blob.restype = C.c_void_p
+        L.pbrt_amd_scene_map_blob.argtypes = [C.c_char_p]
         L.pbrt_amd_scene_desc.restype = C.c_void_p
         L.pbrt_amd_scene_desc.argtypes = [C.c_void_p]
         L.pbrt_amd_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -134,11 +137,18 @@ class Scene:
                    "crop_x0", "crop_y0", "crop_x1", "crop_y1", "spp", "max_depth", "sobol_resolution",
                    "sobol_log2_resolution"]
 
-    def __init__(self, filename=None, text=None, quiet=True, outfile=None, cropwindow=None):
-        """cropwindow = (x0, x1, y0, y1): the command line's --cropwindow (overrides the Film's own, as in the reference)"""
+    def __init__(self, filename=None, text=None, quiet=True, outfile=None, cropwindow=None, blob=None):
+        """cropwindow = (x0, x1, y0, y1): the command line's --cropwindow (overrides the Film's own, as in the reference).
+        blob = a file written by save_blob(): the mi_scene_desc of a scene ANOTHER process parsed and built, mapped read-only (shared page
+        cache; one scene build per node instead of one per rank).  A mapped scene has no Film: film_image / write_image belong to the builder."""
         L = host_lib()
         src = text if text is not None else filename
-        if cropwindow is not None:
+        self.mapped = blob is not None
+        if blob is not None:
+            self._h = L.pbrt_amd_scene_map_blob(blob.encode())
+            if not self._h:
+                raise RuntimeError("scene blob %r: missing, truncated or written by another ABI version" % blob)
+        elif cropwindow is not None:
             cw = (C.c_float * 4)(*[float(v) for v in cropwindow])
             self._h = L.pbrt_amd_scene_load_crop(src.encode(), 1 if text is not None else 0, 1 if quiet else 0,
                                                  outfile.encode() if outfile else None, cw)
@@ -147,6 +157,10 @@ class Scene:
                                             outfile.encode() if outfile else None)
         if not self._h:
             raise RuntimeError("scene load failed: %r" % (filename or "<text>"))
+        self._finish_init()
+
+    def _finish_init(self):
+        L = host_lib()
         self.desc = L.pbrt_amd_scene_desc(self._h)
         info = (C.c_int64 * len(self.INFO_FIELDS))()
         L.pbrt_amd_scene_info(self._h, info)
@@ -158,6 +172,13 @@ class Scene:
         self.info.update(n_media=int(tinfo[0]), n_medium_transitions=int(tinfo[1]), camera_medium=int(tinfo[2]), integrator=("path", "volpath")[int(tinfo[3])])
         self.width = self.info["crop_x1"] - self.info["crop_x0"]
         self.height = self.info["crop_y1"] - self.info["crop_y0"]
+
+    def save_blob(self, path):
+        """Write the flattened scene (mi_scene_desc + every array it points to) to `path`, published atomically (rename): other ranks of the
+        node map it with Scene(blob=path) instead of parsing and building the scene themselves."""
+        rc = host_lib().pbrt_amd_scene_save_blob(self._h, path.encode())
+        if rc != 0:
+            raise RuntimeError("save_blob(%r) failed (%d)" % (path, rc))
 
     def light(self, i):
         """(type, emitted rgb) of light i of the flattened scene, as handed to mi_scene_upload"""
@@ -181,6 +202,8 @@ class Scene:
     def film_image(self, rgbw):
         """rgbw: (H, W, 4) float32 {contribSum rgb, filterWeightSum} -> final (H, W, 3) image."""
         L = host_lib()
+        if self.mapped:
+            raise RuntimeError("a scene mapped from a blob has no Film: the process that built the scene owns the image")
         rgbw = np.ascontiguousarray(rgbw, dtype=np.float32)
         L.pbrt_amd_film_clear(self._h)
         L.pbrt_amd_film_merge(self._h, _ptr(rgbw))

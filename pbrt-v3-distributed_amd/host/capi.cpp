@@ -4,10 +4,9 @@
 
 using namespace pbrt_amd;
 
-struct pbrt_amd_scene {
-    std::unique_ptr<BuiltScene> built;
-    std::unique_ptr<FlatScene> flat;
-};
+#include <sys/mman.h>
+
+#include "capi.h"
 
 extern "C" {
 
@@ -37,7 +36,10 @@ static pbrt_amd_scene *LoadScene(const char *filename_or_text, int is_text, int 
     s->built = std::move(built);
     return s;
 }
-void pbrt_amd_scene_free(pbrt_amd_scene *s) { delete s; }
+void pbrt_amd_scene_free(pbrt_amd_scene *s) {
+    if (s && s->map) { s->flat.reset(); ::munmap(s->map, s->mapBytes); }   // a mapped blob (host/blob.cpp)
+    delete s;
+}
 const mi_scene_desc *pbrt_amd_scene_desc(pbrt_amd_scene *s) { return &s->flat->desc; }
 int pbrt_amd_error_count() { return g_errorCount; }
 // n_verts n_tris n_meshes n_bvh_nodes n_materials n_lights xres yres crop(x0 y0 x1 y1) spp max_depth sobol_res log2res
@@ -70,14 +72,17 @@ int pbrt_amd_scene_light(pbrt_amd_scene *s, int i, int *type, float rgb[3]) {
 
 // Film: merge a downloaded FilmTilePixel array (4 floats per cropped pixel) and produce the
 // final RGB image exactly as Film::WriteImage would; optionally write it.
-int pbrt_amd_film_merge(pbrt_amd_scene *s, const float *rgbw) { s->built->integrator->camera->film->MergeFilm(rgbw); return 0; }
-int pbrt_amd_film_clear(pbrt_amd_scene *s) { s->built->integrator->camera->film->Clear(); return 0; }
+// (a scene mapped from a blob has no Film: the rank that built it owns the image -- these return -1 there)
+int pbrt_amd_film_merge(pbrt_amd_scene *s, const float *rgbw) { if (!s->built) return -1; s->built->integrator->camera->film->MergeFilm(rgbw); return 0; }
+int pbrt_amd_film_clear(pbrt_amd_scene *s) { if (!s->built) return -1; s->built->integrator->camera->film->Clear(); return 0; }
 int pbrt_amd_film_rgb(pbrt_amd_scene *s, float *rgb_out) {
+    if (!s->built) return -1;
     std::vector<Float> rgb = s->built->integrator->camera->film->FinalRGB();
     std::memcpy(rgb_out, rgb.data(), rgb.size() * sizeof(float));
     return 0;
 }
 int pbrt_amd_film_write(pbrt_amd_scene *s, const char *filename) {
+    if (!s->built) return -1;
     Film &f = *s->built->integrator->camera->film;
     if (filename && filename[0]) f.filename = filename;
     f.WriteImage();
@@ -98,9 +103,9 @@ void pbrt_amd_scene_media_info(pbrt_amd_scene *s, int64_t *out) {
     out[0] = d.n_media; out[1] = 0; out[2] = d.camera_medium; out[3] = d.integrator_type;
     if (d.mesh_medium) for (uint32_t m = 0; m < d.n_meshes; ++m) out[1] += d.mesh_medium[2 * m] != d.mesh_medium[2 * m + 1];
 }
-int pbrt_amd_scene_num_prims(pbrt_amd_scene *s) { return (int)s->built->scene->primitives.size(); }
+int pbrt_amd_scene_num_prims(pbrt_amd_scene *s) { return s->built ? (int)s->built->scene->primitives.size() : 0; }
 int pbrt_amd_scene_write_ply(pbrt_amd_scene *s, int prim, const char *filename) {
-    if (prim < 0 || prim >= (int)s->built->scene->primitives.size()) return -1;
+    if (!s->built || prim < 0 || prim >= (int)s->built->scene->primitives.size()) return -1;
     const TriangleMesh &m = *s->built->scene->primitives[prim].shape;
     FILE *f = std::fopen(filename, "wb");
     if (!f) return -2;

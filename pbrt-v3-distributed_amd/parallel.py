@@ -23,6 +23,25 @@ def combine_films(film, dst=0):
     return film
 
 
+def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
+    """One scene build per NODE: local rank 0 calls `load()` (parse + the reference's BVH build, with every CPU of the node: the other ranks only
+    wait) and publishes the flattened scene with Scene.save_blob(blob_path); the other local ranks map that file (Scene(blob=...): shared page
+    cache, no second copy of the geometry in host memory, no second BVH build).  `blob_path` must be unique per job (callers put the launcher's
+    pid into it) so that a blob left behind by an earlier job is never mapped.  Returns (scene, seconds, "built" | "mapped")."""
+    import importlib, os, time
+    pa = importlib.import_module(__package__)
+    t0 = time.time()
+    if local_rank == 0:
+        sc = load()
+        sc.save_blob(blob_path)
+        return sc, time.time() - t0, "built"
+    while not os.path.exists(blob_path):
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
+        time.sleep(0.1)
+    return pa.Scene(blob=blob_path), time.time() - t0, "mapped"
+
+
 def launch_ranks(n_ranks, script, argv, backend_env=None):
     """Start `script argv` as n_ranks processes of ONE node under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1 with a free port -- the launch line the round driver uses) and return the job's exit code.  Used by

@@ -20,7 +20,9 @@ def _worker(rank, world, port, scene_text, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
-    sc = pa.Scene(text=scene_text)
+    # one scene build per node: rank 0 parses + builds and publishes the flattened scene, rank 1 maps it (parallel.node_scene)
+    sc, _, how = par.node_scene(lambda: pa.Scene(text=scene_text), os.path.join(out_dir, "scene_%d.blob" % os.getppid()), rank)
+    assert how == ("built" if rank == 0 else "mapped") and sc.mapped == (rank != 0)
     rgbw, cnt, _ = ol.render(sc, nthreads=2, rank=rank, world=world)
     ntx, nty = (sc.width + 15) // 16, (sc.height + 15) // 16
     mine = par.owned_tiles(rank, world, ntx, nty)
@@ -46,7 +48,7 @@ def _scene_text(which):
         return text.replace('[400] "integer yresolution" [400]', '[80] "integer yresolution" [48]').replace('"integer pixelsamples" [8]', '"integer pixelsamples" [4]')
     sys.path.insert(0, os.path.join(ol.ROOT, "tests"))
     import edge_scenes
-    return edge_scenes.scene(which)   # a textured scene: every rank parses the scene and builds the image pyramids itself
+    return edge_scenes.scene(which)   # a textured scene: the image pyramids travel inside the blob
 
 
 @pytest.mark.parametrize("which", ["cornell", "tex_imagemap"])
