@@ -393,11 +393,16 @@ template <> struct TravTypes<true> { typedef TravStateI State; typedef TravStack
 template <int BLOCK, int NLDS> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK, NLDS> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = NLDS }; };
 // QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
 // (the default for single-level scenes; the full-precision 128-byte nodes serve two-level scenes and PBRT_AMD_TRACE=general)
+template <bool PEND, class TS> PT_DEV bool TraceDone(const TS &ts) {
+    if constexpr (PEND) return ts.cur == TRAV_DONE && ts.pend == TRAV_DONE;
+    else return ts.done();
+}
 template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false>
 __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK), (TraceShape<MODE, SPHERES, ALPHA, QN>::WAVES)) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
     constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
+    constexpr bool PEND = QN && PT_PEND_LEAF;
     typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
@@ -481,15 +486,23 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     int nWant = __popcll(__ballot(wantNode));
                     if (nWant == 0) break;
                     if (wantNode) {
-                        if constexpr (QN) TravNodeStepQ<COUNT, HOT>(sc, ts, st, &tc, hot);
-                        else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
+                        if constexpr (QN) {
+                            TravNodeStepQ<COUNT, HOT>(sc, ts, st, &tc, hot);
+                            if constexpr (PEND) TravParkLeaf(ts, st);   // arrived at a leaf: park it, go on with the stack
+                        } else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
-                    int nLeaf = __popcll(__ballot(active && ts.atLeaf()));
+                    int nLeaf;
+                    if constexpr (PEND) nLeaf = __popcll(__ballot(active && ts.pend != TRAV_DONE));
+                    else nLeaf = __popcll(__ballot(active && ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
-            if (active && ts.done()) {
+            if constexpr (PEND) {
+                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
+            } else {
+                if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
+            }
+            if (active && TraceDone<PEND>(ts)) {
                 if (MODE == 0) {
                     ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                     if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)

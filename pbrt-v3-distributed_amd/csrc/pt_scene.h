@@ -530,6 +530,7 @@ PT_DEV void TravNodeStep(const DevScene &sc, TravState &ts, TravStack &st, Trace
 // (mi_bvh4q_validate) checks against the oracle's BVH2 traversal.
 struct TravStateQ : TravState {
     Bvh4qRay q;
+    uint32_t pend;   // PT_PEND_LEAF: the leaf the lane still has triangles to test in (a leaf reference), TRAV_DONE: none
     template <class ST> PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, ST &st) {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         const float oo[3] = {o.x, o.y, o.z};
@@ -539,6 +540,7 @@ struct TravStateQ : TravState {
         shear.init(d);
         st.sp = 0;
         cur = sc.n_nodes ? 0u : TRAV_DONE;
+        pend = TRAV_DONE;
     }
 };
 // HOT > 0: the scene's sc.n_hot most visited nodes (indices 0 .. n_hot - 1 after mi_scene_upload's renumbering; pbrt_amd.hip: hot-node probe) sit in
@@ -711,4 +713,44 @@ PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt)
     }
     if (left) ts.cur = BVH4_LEAF | ((left - 1) << 27) | (first + 1);
     else ts.cur = st.pop(ts.tMax);
+}
+
+// PT_PEND_LEAF (round 3).  The traversal kernels are bound by VALU issue and a partially filled wave pays the full price per instruction
+// (tools/valu_probe: ~3 cycles per wave instruction whatever the EXEC mask; profiles/r03_c_*: 47 % of the lanes active per VALU instruction), and the
+// biggest idle group are lanes that reached a leaf and wait for the wave's next leaf phase.  With this option such a lane PARKS the leaf
+// (TravStateQ::pend) and goes on with node steps from its stack; leaf phases test one triangle of every parked leaf.  A second leaf waits until
+// the parked one is used up, so a ray's triangles are tested in the same order as before; node steps in between use the tMax of the moment
+// (a few more nodes are visited: +1.5 % in the wave simulator of tools/bvh_study, for -12 % wave instructions).  Quantised single-level scenes only.
+#ifndef PT_PEND_LEAF
+#define PT_PEND_LEAF 1
+#endif
+// if the lane stands at a leaf and has none parked: park it and take the next stack entry
+template <class ST> PT_DEV void TravParkLeaf(TravStateQ &ts, ST &st) {
+    if (ts.pend == TRAV_DONE && ts.cur != TRAV_DONE && (ts.cur & BVH4_LEAF)) { ts.pend = ts.cur; ts.cur = st.pop(ts.tMax); }
+}
+// one triangle of the parked leaf (TravLeafStep on ts.pend; the leaf's end frees the slot instead of popping)
+template <bool ANY, bool COUNT, bool SPHERES, bool ALPHA, class ST>
+PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt) {
+    const uint32_t first = ts.pend & BVH4_FIRST_MASK, left = (ts.pend >> 27) & 0xfu;
+    V3 p0, p1, p2;
+    uint32_t flags;
+    LoadTri(sc, first, &p0, &p1, &p2, &flags);
+    if (COUNT) ++cnt->tris;
+    TriHit th;
+    bool hitPrim;
+    if (SPHERES && (flags & TRI_FLAG_SPHERE)) {
+        th.t = SphereIntersectT(sc.spheres + __float_as_uint(p0.x), ts.o, ts.d, ts.tMax);
+        th.b0 = th.b1 = th.b2 = 0;
+        hitPrim = th.t >= 0;
+    } else
+        hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
+    if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
+    if (hitPrim) {
+        ts.prim = first;
+        ts.tHit = th.t;
+        if (ANY) { ts.cur = TRAV_DONE; ts.pend = TRAV_DONE; return; }
+        ts.tMax = th.t;
+    }
+    if (left) ts.pend = BVH4_LEAF | ((left - 1) << 27) | (first + 1);
+    else { ts.pend = TRAV_DONE; TravParkLeaf(ts, st); }
 }

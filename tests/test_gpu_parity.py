@@ -19,6 +19,15 @@ SCENES = ["cornell.pbrt", "materials.pbrt"]
 TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general", "PBRT_AMD_RAYBIN": "1"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0"}}
 
 
+def _report(key, **values):
+    """measured agreement figures (fractions of bit-identical values etc.) -> one JSON line each in $PBRT_AMD_PARITY_REPORT: the numbers DESIGN.md quotes"""
+    path = os.environ.get("PBRT_AMD_PARITY_REPORT")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": key, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()}}) + "\n")
+
+
 def make_ctx(sc, mode="bvh4q", **kw):
     env = TRACE_MODES[mode]
     saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_RAYBIN", "PBRT_AMD_HOT")}
@@ -189,6 +198,7 @@ def test_li_per_sample(pair):
     ref = ol.li(sc, xy, s)
     err = np.linalg.norm(dev - ref, axis=1)
     ok = err <= 1e-4 * (1 + np.linalg.norm(ref, axis=1))
+    _report("li_per_sample", samples=len(ref), within_tol=ok.mean(), bit_identical=(dev.view(np.uint32) == ref.view(np.uint32)).all(1).mean(), max_err=err.max())
     assert ok.mean() >= 0.995, (ok.mean(), err.max())
     assert abs(dev.mean() - ref.mean()) <= 2e-3 * ref.mean()
 
@@ -202,6 +212,7 @@ def test_render_image_vs_oracle(pair):
     ref_rgbw, rcnt, _ = ol.render(sc)
     ref = sc.film_image(ref_rgbw)
     frac, relmse = ol.image_metrics(img, ref)
+    _report("render_image_vs_oracle", pixels=int(img.shape[0] * img.shape[1]), within_tol=frac, relMSE=relmse, bit_identical_pixels=(img.view(np.uint32) == ref.view(np.uint32)).all(-1).mean())
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     cnt = ctx.counters()
     assert cnt["camera_rays"] == rcnt["camera_rays"]
@@ -296,6 +307,7 @@ def test_device_bxdfs_match_reference_classes():
         same = (a.view(np.uint32) == b.view(np.uint32)) | (a == b)
         exact += int(same.sum()); total += same.size
         assert np.allclose(a, b, rtol=5e-6, atol=1e-7), (k, float(np.abs(a - b).max()))
+    _report("device_bxdfs_vs_reference_classes", values=total, bit_identical=exact / total)
     assert exact / total >= 0.97, exact / total
 
 
@@ -355,6 +367,8 @@ def test_render_vs_reference_fixture(name, w, h, spp, strategy, mode):
     img = sc.film_image(ctx.film())
     ref = pa.read_pfm(os.path.join(G, "%s_%dx%d_%dspp%s.pfm" % (name, w, h, spp, "_" + strategy if strategy else "")))
     frac, relmse = ol.image_metrics(img, ref)
+    _report("render_vs_reference_fixture", scene="%s_%dx%d_%dspp%s" % (name, w, h, spp, "_" + strategy if strategy else ""), mode=mode, within_tol=frac, relMSE=relmse,
+            bit_identical_pixels=(img.view(np.uint32) == ref.view(np.uint32)).all(-1).mean())
     assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
     ctx.close()
 
@@ -392,6 +406,7 @@ def test_baseline_configs_reduced(name, mode, tmp_path):
     # device's float libm now returns glibc's own bits (csrc/pt_libm.h), so 30 specular bounces have no last-ulp differences left to amplify.
     min_frac, max_relmse = 0.995, 1e-4
     print("config %s/%s: pixels within tolerance %.5f, relMSE %.3g" % (name, mode, frac, relmse))
+    _report("baseline_configs_reduced", config=name, mode=mode, within_tol=frac, relMSE=relmse, bit_identical_pixels=(img.view(np.uint32) == ref.view(np.uint32)).all(-1).mean())
     assert frac >= min_frac and relmse <= max_relmse, (name, frac, relmse)
     assert cnt["camera_rays"] == rcnt["camera_rays"] and cnt["trace_guard_trips"] == 0
     assert abs(cnt["closest_rays"] - rcnt["closest_rays"]) <= 3e-3 * rcnt["closest_rays"]
@@ -402,6 +417,7 @@ def test_baseline_configs_reduced(name, mode, tmp_path):
     sn = np.full(len(xy), 3, dtype=np.int32)
     d, r = ctx.li(xy, sn), ol.li(sc, xy, sn)
     ok = np.linalg.norm(d - r, axis=1) <= 1e-4 * (1 + np.linalg.norm(r, axis=1))
+    _report("baseline_configs_reduced_li", config=name, mode=mode, within_tol=ok.mean(), bit_identical=(d.view(np.uint32) == r.view(np.uint32)).all(1).mean())
     assert ok.mean() >= 0.999, (name, ok.mean())
     ctx.close()
 
@@ -711,6 +727,8 @@ def test_device_light_sampling_matches_reference_classes():
     ex = recs["kind"] != 1
     same = sum(int((o[k][ex] == recs[k][ex]).sum()) for k in ("wi", "pdf", "Li", "ray_o", "ray_d"))
     total = sum(o[k][ex].size for k in ("wi", "pdf", "Li", "ray_o", "ray_d"))
+    _report("device_light_sampling_vs_reference_classes", values=total, bit_identical=same / total,
+            bit_identical_all_kinds=sum(int((o[k] == recs[k]).sum()) for k in ("wi", "pdf", "Li", "ray_o", "ray_d")) / sum(o[k].size for k in ("wi", "pdf", "Li", "ray_o", "ray_d")))
     assert same / total >= 0.99, same / total
 
 

@@ -520,6 +520,26 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                             else if (atLeaf(l)) { l.parked = l.cur; l.parkedCount = l.left + 1; pop(l); if (l.cur == DONE) l.cur = LEAF | 0x7ffffffe; }
                         }
                     }
+                } else if (policy == 3) {
+                    // one pending leaf per lane, tested ONE triangle per leaf phase while the lane goes on with node steps (speculative: stale tMax)
+                    auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };
+                    for (int g = 0; g < nodeSteps; ++g) {
+                        int nWant = 0; for (auto &l : L) nWant += atNode(l);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (auto &l : L) if (atNode(l)) { nodeStep(l); if (atLeaf(l) && l.parked == DONE) park(l); }
+                        int nPend = 0; for (auto &l : L) nPend += l.active && l.parked != DONE;
+                        if (nPend >= leafMin) break;
+                    }
+                    int nPend = 0, nNode = 0; for (auto &l : L) { nPend += l.active && l.parked != DONE; nNode += atNode(l); }
+                    if (nPend && (nPend >= leafMin || nNode == 0 || true)) {
+                        ++phL; laL += nPend;
+                        for (auto &l : L) if (l.active && l.parked != DONE) {
+                            triStep(l, l.parked);
+                            if (--l.parkedCount > 0) ++l.parked;
+                            else { l.parked = DONE; if (atLeaf(l)) park(l); }
+                        }
+                    }
                 } else {
                     int guard = 0;
                     while (true) {
