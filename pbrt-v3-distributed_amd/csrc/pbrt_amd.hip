@@ -433,6 +433,60 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     uint32_t nrays = 0;
     uint32_t waveIters = 0;
     while (true) {
+        // the rays that finished since the last refill hand their results over TOGETHER (one pass through this block with all of them, instead of
+        // one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the same for 1 lane or 64)
+        if (active && TraceDone<PEND>(ts)) {
+            if (MODE == 0) {
+                ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
+                if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
+                uint32_t key = sc.n_materials;                                   // escaped rays
+                if (ts.prim != TRAV_MISS) {
+                    int mat = (int)sc.tri_info[ts.prim].y;
+                    key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;         // null-BSDF surfaces: own bucket
+                }
+                ps.key[slot] = key;
+            } else if (MODE == 2) {
+                if (ts.prim == TRAV_MISS) {   // unoccluded: add the light-sampled term
+                    float4 c = ps.nee[slot].sh_c, L = ps.rec[slot].L;
+                    L.x += c.x; L.y += c.y; L.z += c.z;
+                    ps.rec[slot].L = L;
+                }
+            } else {
+                const DevLight &light = sc.lights[lightNum];
+                RGB Li(0.f);
+                const V3 ro = ts.o, rd = ts.d;   // the MIS ray
+                if (ts.prim != TRAV_MISS) {
+                    if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                        V3 p0, p1, p2;
+                        uint32_t tf;
+                        LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
+                        Isect li;
+                        if (SPHERES && (tf & TRI_FLAG_SPHERE)) li = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, ts.prim);
+                        else {
+                            TriHit th;
+                            TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);
+                            BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, rd, &li);
+                        }
+                        Li = AreaL(light, li.n, -rd);   // lightIsect.Le(-wi)
+                    }
+                } else if (light.type == MI_LIGHT_INFINITE)
+                    Li = InfiniteLe(&light, rd);   // light.Le(ray)
+                if (ps.vol_tr && !Li.IsBlack()) {   // Scene::IntersectTr's Tr for a homogeneous medium up to the first surface (core/scene.cpp:56-70, homogeneous.cpp:41-44)
+                    float4 sg = ps.nee[slot].pad[0];
+                    if (sg.x != 0 || sg.y != 0 || sg.z != 0) {
+                        Float th = PT_INFINITY;
+                        if (ts.prim != TRAV_MISS) th = ts.tHit;
+                        Li = Li * ExpRGB(-RGB(sg.x, sg.y, sg.z) * mn(th * rd.Length(), PT_MAX_FLOAT));
+                    }
+                }
+                if (!Li.IsBlack()) {
+                    float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
+                    L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
+                    ps.rec[slot].L = L;
+                }
+            }
+            active = false;
+        }
         unsigned long long idle = __ballot(!active);
         int nIdle = __popcll(idle);
         if (nIdle >= TRACE_REFILL && segsTried < 8) {
@@ -502,59 +556,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
             } else {
                 if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             }
-            if (active && TraceDone<PEND>(ts)) {
-                if (MODE == 0) {
-                    ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
-                    if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
-                    uint32_t key = sc.n_materials;                                   // escaped rays
-                    if (ts.prim != TRAV_MISS) {
-                        int mat = (int)sc.tri_info[ts.prim].y;
-                        key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;         // null-BSDF surfaces: own bucket
-                    }
-                    ps.key[slot] = key;
-                } else if (MODE == 2) {
-                    if (ts.prim == TRAV_MISS) {   // unoccluded: add the light-sampled term
-                        float4 c = ps.nee[slot].sh_c, L = ps.rec[slot].L;
-                        L.x += c.x; L.y += c.y; L.z += c.z;
-                        ps.rec[slot].L = L;
-                    }
-                } else {
-                    const DevLight &light = sc.lights[lightNum];
-                    RGB Li(0.f);
-                    const V3 ro = ts.o, rd = ts.d;   // the MIS ray
-                    if (ts.prim != TRAV_MISS) {
-                        if ((int)sc.tri_info[ts.prim].z == (int)lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
-                            V3 p0, p1, p2;
-                            uint32_t tf;
-                            LoadTri(sc, ts.prim, &p0, &p1, &p2, &tf);
-                            Isect li;
-                            if (SPHERES && (tf & TRI_FLAG_SPHERE)) li = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), ro, rd, ts.prim);
-                            else {
-                                TriHit th;
-                                TriangleTest(p0, p1, p2, ro, rd, PT_INFINITY, &th);
-                                BuildIsect(GeomTables(sc), ts.prim, p0, p1, p2, th, rd, &li);
-                            }
-                            Li = AreaL(light, li.n, -rd);   // lightIsect.Le(-wi)
-                        }
-                    } else if (light.type == MI_LIGHT_INFINITE)
-                        Li = InfiniteLe(&light, rd);   // light.Le(ray)
-                    if (ps.vol_tr && !Li.IsBlack()) {   // Scene::IntersectTr's Tr for a homogeneous medium up to the first surface (core/scene.cpp:56-70, homogeneous.cpp:41-44)
-                        float4 sg = ps.nee[slot].pad[0];
-                        if (sg.x != 0 || sg.y != 0 || sg.z != 0) {
-                            Float th = PT_INFINITY;
-                            if (ts.prim != TRAV_MISS) th = ts.tHit;
-                            Li = Li * ExpRGB(-RGB(sg.x, sg.y, sg.z) * mn(th * rd.Length(), PT_MAX_FLOAT));
-                        }
-                    }
-                    if (!Li.IsBlack()) {
-                        float4 c = ps.nee[slot].mi_c, L = ps.rec[slot].L;
-                        L.x += c.x * Li.r; L.y += c.y * Li.g; L.z += c.z * Li.b;
-                        ps.rec[slot].L = L;
-                    }
-                }
-                active = false;
-            }
-            int nAct = __popcll(__ballot(active));
+            int nAct = __popcll(__ballot(active && !TraceDone<PEND>(ts)));   // finished lanes keep their result until the next refill (top of the outer loop)
             if (nAct == 0 || (mayRefill && nAct <= 64 - TRACE_REFILL)) break;
         }
     }

@@ -520,6 +520,29 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                             else if (atLeaf(l)) { l.parked = l.cur; l.parkedCount = l.left + 1; pop(l); if (l.cur == DONE) l.cur = LEAF | 0x7ffffffe; }
                         }
                     }
+                } else if (policy == 4 || policy == 5) {
+                    // as 3 with a FIFO of 2 (policy 4) or 3 (policy 5) parked leaves per lane
+                    const size_t slots = policy == 4 ? 2 : 3;
+                    static thread_local std::vector<std::pair<uint32_t, int>> q[64];
+                    auto parkQ = [&](Lane &l, int li) { q[li].push_back({l.cur & ~LEAF, l.left + 1}); pop(l); };
+                    for (int g = 0; g < nodeSteps; ++g) {
+                        int nWant = 0; for (auto &l : L) nWant += atNode(l);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (int li = 0; li < 64; ++li) { Lane &l = L[li]; if (atNode(l)) { nodeStep(l); while (atLeaf(l) && q[li].size() < slots) parkQ(l, li); } }
+                        int nPend = 0; for (int li = 0; li < 64; ++li) nPend += L[li].active && !q[li].empty();
+                        if (nPend >= leafMin) break;
+                    }
+                    int nPend = 0; for (int li = 0; li < 64; ++li) nPend += L[li].active && !q[li].empty();
+                    if (nPend) {
+                        ++phL; laL += nPend;
+                        for (int li = 0; li < 64; ++li) { Lane &l = L[li]; if (l.active && !q[li].empty()) {
+                            triStep(l, q[li].front().first);
+                            if (--q[li].front().second > 0) ++q[li].front().first;
+                            else { q[li].erase(q[li].begin()); while (atLeaf(l) && q[li].size() < slots) parkQ(l, li); }
+                        } }
+                    }
+                    for (int li = 0; li < 64; ++li) { Lane &l = L[li]; l.parked = q[li].empty() ? DONE : 0u; }
                 } else if (policy == 3) {
                     // one pending leaf per lane, tested ONE triangle per leaf phase while the lane goes on with node steps (speculative: stale tMax)
                     auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };
