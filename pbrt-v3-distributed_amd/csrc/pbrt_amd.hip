@@ -345,6 +345,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef TRACE_LEAF_MIN
 #define TRACE_LEAF_MIN 24      /* run the leaf phase as soon as this many lanes wait at a leaf */
 #endif
+#ifndef PT_BATCH_FINALIZE
+#define PT_BATCH_FINALIZE 1
+#endif
 #ifndef PT_TRACE_GUARD_ITERS
 #define PT_TRACE_GUARD_ITERS (1u << 22)
 #endif
@@ -431,10 +434,8 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     ts.cur = TRAV_DONE;
     TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
-    uint32_t waveIters = 0;
-    while (true) {
-        // the rays that finished since the last refill hand their results over TOGETHER (one pass through this block with all of them, instead of
-        // one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the same for 1 lane or 64)
+    // hands a finished ray's result over (hit record + sort key / the unoccluded light term / the MIS term)
+    auto finalize = [&]() {
         if (active && TraceDone<PEND>(ts)) {
             if (MODE == 0) {
                 ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
@@ -487,6 +488,13 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
             }
             active = false;
         }
+    };
+    uint32_t waveIters = 0;
+    while (true) {
+        // PT_BATCH_FINALIZE: the rays that finished since the last refill hand their results over TOGETHER (one pass through the block with all of
+        // them, instead of one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the
+        // same for 1 lane or 64)
+        if (PT_BATCH_FINALIZE) finalize();
         unsigned long long idle = __ballot(!active);
         int nIdle = __popcll(idle);
         if (nIdle >= TRACE_REFILL && segsTried < 8) {
@@ -556,7 +564,8 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
             } else {
                 if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             }
-            int nAct = __popcll(__ballot(active && !TraceDone<PEND>(ts)));   // finished lanes keep their result until the next refill (top of the outer loop)
+            if (!PT_BATCH_FINALIZE) finalize();
+            int nAct = __popcll(__ballot(active && !TraceDone<PEND>(ts)));   // (batched: finished lanes keep their result until the next refill, top of the outer loop)
             if (nAct == 0 || (mayRefill && nAct <= 64 - TRACE_REFILL)) break;
         }
     }
