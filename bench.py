@@ -112,6 +112,45 @@ def traffic_live(wl_args, workload, pmc_steps=2):
             "source": "live: rocprofv3 --pmc FETCH_SIZE pass of this workload inside this bench run (x2: gfx950 correction)", "workload": workload, "lib": _lib_id()}
 
 
+def valu_live(wl_args, pmc_steps=1):
+    """What bounds the traversal kernels: VALU issue.  A separate `rocprofv3 --pmc` pass over the same workload with the SQ's
+    instruction counters -> per launch of the closest-hit kernel: VALU instructions, active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU /
+    SQ_ACTIVE_INST_VALU), waves.  None when the pass cannot run."""
+    import csv, glob, shutil, tempfile, collections
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="pbrt_amd_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "-d", d, "-o", "c", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__)] + wl_args + ["--steps", str(pmc_steps), "--warmup", "0", "--cpu-seconds", "0", "--traffic", "none", "--pmc-child"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    except Exception as e:
+        log("[bench] SQ counter pass failed to run: %s" % e)
+        return None
+    if r.returncode != 0:
+        log("[bench] SQ counter pass failed (rc %d): %s" % (r.returncode, r.stdout[-400:]))
+        shutil.rmtree(d, ignore_errors=True)
+        return None
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Kernel_Name"].startswith("void k_trace<0, false"):
+                agg[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+                disp[row["Kernel_Name"]].add(row["Dispatch_Id"])
+    shutil.rmtree(d, ignore_errors=True)
+    if not agg:
+        return None
+    k = max(agg, key=lambda n: agg[n].get("SQ_INSTS_VALU", 0))
+    n = max(1, len(disp[k]))
+    c = {a: b / n for a, b in agg[k].items()}
+    if not c.get("SQ_ACTIVE_INST_VALU") or not c.get("SQ_WAVES"):
+        return None
+    return {"valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "waves_per_launch": c["SQ_WAVES"], "lanes_active_per_valu_inst": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / c["SQ_ACTIVE_INST_VALU"], 2),
+            "valu_share_of_wave_lifetime": round(c["SQ_ACTIVE_INST_VALU"] / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4)}
+
+
 def traffic_from_file(workload):
     try:
         ent = json.load(open(TRAFFIC_FILE)).get("entries", {}).get(workload)
@@ -458,6 +497,20 @@ def main():
                                                         "traversal launch shape, no arithmetic; the traversal's own fetches are a MIX of these levels (upper tree levels are shared)" % loads}
         except Exception as e:   # measurement aid only
             log("[bench] request-rate ceiling not measured: %s" % e)
+        # ... and what does bound it: VALU issue.  issue_slots_frac = VALU instructions of a launch x the measured cycles per wave instruction
+        # (tools/valu_probe on this chip: ~3.0 at >= 4 waves per SIMD, whatever the EXEC mask) / (SIMDs x launch cycles)
+        if world == 1 and args.traffic == "live":
+            try:
+                vi = valu_live(wl_args, 1)
+                if vi:
+                    # CUs from the persistent launch itself: waves per launch = CUs x blocks per CU x waves per block
+                    simds = 4 * max(1, int(round(vi["waves_per_launch"] / (tinfo.get("blocks_per_cu", 6) * tinfo.get("block_threads", 256) / 64.0))))
+                    vi["cycles_per_wave_inst_assumed"] = 3.0
+                    vi["issue_slots_frac"] = round(vi["valu_insts_per_launch"] * 3.0 / (simds * avg_launch_ms * 1e-3 * 2.4e9), 4)
+                    vi["note"] = "SQ counters of a separate rocprofv3 --pmc pass of this workload; launch time from the unprofiled run; 2.4 GHz"
+                    roofline["valu_issue"] = vi
+            except Exception as e:   # measurement aid only
+                log("[bench] VALU issue figure not measured: %s" % e)
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the
