@@ -541,10 +541,11 @@ def main():
     frame.close()
     ctx.close()
     if world > 1 and local_rank == 0:   # every rank has passed the final barrier of frame.close(): nobody still needs the file (mappings stay valid anyway)
-        try:
-            os.remove(blob)
-        except OSError:
-            pass
+        for f in (blob, blob + ".failed"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

@@ -33,9 +33,14 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
     t0 = time.time()
     if local_rank == 0:
         sc = load()
-        sc.save_blob(blob_path)
+        try:
+            sc.save_blob(blob_path)
+        except Exception as e:   # no room in /dev/shm, read-only directory ...: the other ranks build the scene themselves instead of waiting for nothing
+            open(blob_path + ".failed", "w").write(str(e))
         return sc, time.time() - t0, "built"
     while not os.path.exists(blob_path):
+        if os.path.exists(blob_path + ".failed"):
+            return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
         if time.time() - t0 > timeout_s:
             raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
         time.sleep(0.1)
