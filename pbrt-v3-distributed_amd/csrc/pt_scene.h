@@ -292,6 +292,11 @@ PT_DEV void Pin(float4 &a, float4 &b, float4 &c) {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
 }
 
+#ifndef PT_TRI_SELECT
+#define PT_TRI_SELECT 1
+#endif
+PT_DEV void PinV3(V3 &a, V3 &b, V3 &c) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z)); }
+
 struct RayShear {
     int kz;
     Float Sx, Sy, Sz;
@@ -313,7 +318,18 @@ struct RayShear {
 // conservative t > delta_t test).  The per-triangle degeneracy rejection of :308-315 is the
 // TRI_FLAG_REJECT bit.  tMax is the ray's current tMax (accept t == tMax: :258-261).
 PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, const RayShear &rs, Float tMax, TriHit *h) {
+    // the three differences are formed once and pinned, then the axes are SELECTED (6 v_cndmask per vertex): written as rs.permute(p - o) the
+    // compiler sank the subtractions into three EXEC-masked branches per vertex, ~90 of the leaf step's ~300 instructions (round 3: VALU-bound)
+#if PT_TRI_SELECT
+    V3 d0 = p0 - o, d1 = p1 - o, d2 = p2 - o;
+    PinV3(d0, d1, d2);
+    const bool k0 = rs.kz == 0, k1 = rs.kz == 1;
+#define PT_PERM(d) V3(k0 ? d.y : (k1 ? d.z : d.x), k0 ? d.z : (k1 ? d.x : d.y), k0 ? d.x : (k1 ? d.y : d.z))
+    V3 p0t = PT_PERM(d0), p1t = PT_PERM(d1), p2t = PT_PERM(d2);
+#undef PT_PERM
+#else
     V3 p0t = rs.permute(p0 - o), p1t = rs.permute(p1 - o), p2t = rs.permute(p2 - o);
+#endif
     const Float Sx = rs.Sx, Sy = rs.Sy, Sz = rs.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;

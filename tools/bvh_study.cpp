@@ -4,6 +4,7 @@
 //   g++ -O2 -std=c++14 -shared -fPIC tools/bvh_study.cpp -Iinclude -o /tmp/libbvhstudy.so
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -456,7 +457,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
         std::vector<std::pair<uint32_t, int>> st;   // (ref, count)
         uint32_t parked = 0xFFFFFFFFu; int parkedCount = 0;
     };
-    double phN = 0, laN = 0, phL = 0, laL = 0, iters = 0, nrays = 0;
+    double phN = 0, laN = 0, phL = 0, laL = 0, iters = 0, nrays = 0, deep13 = 0, deep21 = 0, deepLanes = 0;
     for (int64_t base = 0; base < n;) {   // one wave at a time over a contiguous slice of the rays (a wave's batches come from one queue segment)
         int64_t sliceEnd = std::min<int64_t>(n, base + 4096);
         int64_t next = base;
@@ -550,6 +551,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                         int nWant = 0; for (auto &l : L) nWant += atNode(l);
                         if (!nWant) break;
                         ++phN; laN += nWant;
+                        { size_t mx = 0; for (auto &l : L) if (atNode(l)) mx = std::max(mx, l.st.size()); deep13 += mx > 13; deep21 += mx > 21; deepLanes += 0; for (auto &l : L) if (atNode(l)) deepLanes += l.st.size() > 13; }
                         for (auto &l : L) if (atNode(l)) { nodeStep(l); if (atLeaf(l) && l.parked == DONE) park(l); }
                         int nPend = 0; for (auto &l : L) nPend += l.active && l.parked != DONE;
                         if (nPend >= leafMin) break;
@@ -593,4 +595,6 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
         base = sliceEnd;
     }
     out[0] = nrays; out[1] = phN; out[2] = laN; out[3] = phL; out[4] = laL; out[5] = iters;
+    out[6] = deep13; out[7] = deep21;   // policy 3: node phases in which some stepping lane's stack holds more than 13 / 21 entries
+    if (policy == 3) std::fprintf(stderr, "[wavesim] policy 3: node phases with a lane deeper than 13 entries: %.1f %%, deeper than 21: %.1f %%; lane steps deeper than 13: %.2f %%\n", 100 * deep13 / std::max(1.0, phN), 100 * deep21 / std::max(1.0, phN), 100 * deepLanes / std::max(1.0, laN));
 }
