@@ -455,6 +455,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
     struct Lane {
         bool active = false; double o[3], dir[3], inv[3], tMax; uint32_t cur = 0xFFFFFFFFu; int left = 0;   // cur: node index, LEAF | first prim (left = triangles after this one), DONE
         std::vector<std::pair<uint32_t, int>> st;   // (ref, count)
+        std::vector<double> stT;                    // entry distance of each stack entry (cull-on-pop variants)
         uint32_t parked = 0xFFFFFFFFu; int parkedCount = 0;
     };
     double phN = 0, laN = 0, phL = 0, laL = 0, iters = 0, nrays = 0, deep13 = 0, deep21 = 0, deepLanes = 0;
@@ -462,7 +463,17 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
         int64_t sliceEnd = std::min<int64_t>(n, base + 4096);
         int64_t next = base;
         Lane L[64];
-        auto pop = [&](Lane &l) { if (l.st.empty()) { l.cur = DONE; } else { l.cur = l.st.back().first; l.left = l.st.back().second - 1; l.st.pop_back(); } };
+        const bool cullPop = nodeSteps >= 1000;   // nodeSteps + 1000: drop popped entries whose entry distance is not below the current tMax (PT_STACK_T)
+        if (cullPop) nodeSteps -= 1000;
+        auto pop = [&](Lane &l) {
+            while (true) {
+                if (l.st.empty()) { l.cur = DONE; return; }
+                l.cur = l.st.back().first; l.left = l.st.back().second - 1;
+                double t = l.stT.back();
+                l.st.pop_back(); l.stT.pop_back();
+                if (!cullPop || t < l.tMax) return;
+            }
+        };
         auto nodeStep = [&](Lane &l) {
             const WNode &w = wn[l.cur];
             struct H { uint32_t ref; int c; double t; } h[4]; int nh = 0;
@@ -476,7 +487,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
             }
             std::sort(h, h + nh, [](const H &a, const H &b) { return a.t < b.t; });
             if (nh == 0) { pop(l); return; }
-            for (int k = nh - 1; k >= 1; --k) l.st.push_back({h[k].ref, h[k].c});
+            for (int k = nh - 1; k >= 1; --k) { l.st.push_back({h[k].ref, h[k].c}); l.stT.push_back(h[k].t); }
             l.cur = h[0].ref; l.left = h[0].c - 1;
         };
         auto triStep = [&](Lane &l, uint32_t prim) { double t; if (triHit(d, prim, l.o, l.dir, l.tMax, &t)) l.tMax = t; };
@@ -488,7 +499,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                 for (auto &l : L) if (!l.active && next < sliceEnd) {
                     const mi_ray &r = rays[next++]; ++nrays;
                     for (int a = 0; a < 3; ++a) { l.o[a] = r.o[a]; l.dir[a] = r.d[a]; l.inv[a] = 1.0 / r.d[a]; }
-                    l.tMax = r.tmax; l.cur = 0; l.left = 0; l.st.clear(); l.active = true; l.parked = DONE;
+                    l.tMax = r.tmax; l.cur = 0; l.left = 0; l.st.clear(); l.stT.clear(); l.active = true; l.parked = DONE;
                 }
             }
             int nAct = 0; for (auto &l : L) nAct += l.active;
