@@ -607,5 +607,6 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
     }
     out[0] = nrays; out[1] = phN; out[2] = laN; out[3] = phL; out[4] = laL; out[5] = iters;
     out[6] = deep13; out[7] = deep21;   // policy 3: node phases in which some stepping lane's stack holds more than 13 / 21 entries
-    if (policy == 3) std::fprintf(stderr, "[wavesim] policy 3: node phases with a lane deeper than 13 entries: %.1f %%, deeper than 21: %.1f %%; lane steps deeper than 13: %.2f %%\n", 100 * deep13 / std::max(1.0, phN), 100 * deep21 / std::max(1.0, phN), 100 * deepLanes / std::max(1.0, laN));
+    static bool said = false;
+    if (policy == 3 && !said && (said = true)) std::fprintf(stderr, "[wavesim] policy 3: node phases with a lane deeper than 13 entries: %.1f %%, deeper than 21: %.1f %%; lane steps deeper than 13: %.2f %%\n", 100 * deep13 / std::max(1.0, phN), 100 * deep21 / std::max(1.0, phN), 100 * deepLanes / std::max(1.0, laN));
 }
