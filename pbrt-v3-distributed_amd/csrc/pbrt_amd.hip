@@ -857,14 +857,6 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
-// PT_SHADE_PREFETCH (round 3): k_shade is bound by its chain of dependent fetches (queue entry -> path record -> triangle / shading record ->
-// light tables -> light: seven round trips per vertex, three resident waves per SIMD to hide them; SQ counters: 47 % of the issue slots used).  While a
-// wave shades item i it warms the caches for item i + 64 of its grain: the next queue entry, through it the next path record's line, through that
-// record's hit the next triangle / shading records -- plain loads into registers that are only "used" by an empty asm at the end of the iteration,
-// so the compiler's wait counters see them.  Nothing the kernel computes changes.
-#ifndef PT_SHADE_PREFETCH
-#define PT_SHADE_PREFETCH 1
-#endif
 #ifndef PT_SHADE_DYN
 #define PT_SHADE_DYN 1   /* k_shade / k_shade_vol take their items through DynIter (dynamic, per wave); 0: the static ChunkIter partition (A/B) */
 #endif
@@ -907,23 +899,11 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         bool cont = false, wantShadow = false, wantMis = false;
         uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
-#if PT_SHADE_PREFETCH && PT_SHADE_DYN
-        uint32_t pfA = 0, pfB = 0, pfC = 0, pfD = 0;   // cache-warming loads for the wave's next item (consumed by an empty asm at the end of the iteration)
-#endif
         if (active) {
             slot = ps.q_sorted[i];
-#if PT_SHADE_PREFETCH && PT_SHADE_DYN
-            const bool haveN = i + PT_WAVE_SIZE < it.end;
-            uint32_t slotN = 0;
-            if (haveN) slotN = ps.q_sorted[i + PT_WAVE_SIZE];
-#endif
             uint2 hr = ps.rec[slot].hit;
             float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
             uint4 s4 = ps.rec[slot].smp;
-#if PT_SHADE_PREFETCH && PT_SHADE_DYN
-            uint32_t primN = MISS_PRIM;
-            if (haveN) primN = ps.rec[slotN].hit.x;   // the next path record's line (issued behind this item's own record loads)
-#endif
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             RGB beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
             Float etaScale = b4.w;
@@ -982,14 +962,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                 }
             }
             PROBE(3)   // triangle reload + BuildIsect
-#if PT_SHADE_PREFETCH && PT_SHADE_DYN
-            if (primN != MISS_PRIM) {   // the next item's triangle (48 B: up to two lines), shading record and info word
-                pfA = reinterpret_cast<const uint32_t *>(sc.tri_verts + 3 * (size_t)primN)[0];
-                pfB = reinterpret_cast<const uint32_t *>(sc.tri_verts + 3 * (size_t)primN)[11];
-                pfC = reinterpret_cast<const uint32_t *>(sc.tri_shade + primN)[0];
-                pfD = sc.tri_info[primN].x;
-            }
-#endif
             if (bounces == 0 || specularBounce) {
                 if (found) {
                     int li = (int)tinfo.z;
@@ -1176,9 +1148,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
         if (wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (wantMis) ps.q_mis[qbase + posM] = slot;
-#if PT_SHADE_PREFETCH && PT_SHADE_DYN
-        asm volatile("" :: "v"(pfA), "v"(pfB), "v"(pfC), "v"(pfD));   // the warming loads end here (long since returned)
-#endif
         PROBE(13)   // L store + queue appends
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
