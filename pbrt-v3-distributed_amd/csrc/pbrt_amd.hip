@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                         ComputeScatteringFunctionsT(sc.materials, matU, &isect, &ix, &laneMat);
                         matPtr = &laneMat;
                     }
-                    BS bsdf(isect, matPtr);
+                    BS bsdf(isect, matPtr, TEX ? nullptr : sc.mat_pack, matU);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
@@ -1810,6 +1810,22 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         sc.tri_info = b.as<uint4>();
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
+    {   // the BSDF's lobe header per material: count + the lobe types, 4 bits each (one scalar load instead of a chain through the lobe records)
+        std::vector<uint2> pack(std::max<uint32_t>(1, d->n_materials));
+        for (uint32_t m = 0; m < d->n_materials; ++m) {
+            const mi_material &mm = d->materials[m];
+            if (mm.n_bxdfs < 0 || mm.n_bxdfs > MI_MAX_BXDFS) return fail("mi_scene_upload: material with more than 8 BxDFs");
+            uint32_t t = 0;
+            for (int i = 0; i < mm.n_bxdfs; ++i) {
+                if (mm.bxdfs[i].type < 0 || mm.bxdfs[i].type > 15) return fail("mi_scene_upload: unknown BxDF type");
+                t |= (uint32_t)mm.bxdfs[i].type << (4 * i);
+            }
+            pack[m] = make_uint2((uint32_t)mm.n_bxdfs, t);
+        }
+        DevBuf &b = next();
+        if (upload(c, b, pack.data(), pack.size() * sizeof(uint2))) return -1;
+        sc.mat_pack = b.as<uint2>();
+    }
     std::memset(&c->tex, 0, sizeof(c->tex));
     if (c->hasInst && !(c->hasTex || c->hasAlpha)) {   // the INST shading instance is the general (textured) one: give it "no textured material" descriptors
         DevTex &tx = c->tex;

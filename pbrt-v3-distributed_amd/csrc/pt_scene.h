@@ -69,6 +69,7 @@ struct DevScene {
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
     const mi_material *materials;
+    const uint2 *mat_pack;          // per material: {n_bxdfs, the lobe types 4 bits each} -- the BSDF's lobe header (pt_shade.h, PT_LOBE_HEADER)
     const DevEnvMap *envmaps;
     const mi_sphere *spheres;
     const DevLight *lights;         // mi_light + (area lights) the triangle's vertices and mesh flags: no extra hops while sampling

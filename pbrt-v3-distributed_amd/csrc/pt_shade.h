@@ -529,18 +529,38 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
 // ------------------------------------------------------------------ BSDF (core/reflection.h:153-202)
 template <bool U> struct MatPtrOf { typedef MatConst type; };
 template <> struct MatPtrOf<false> { typedef const mi_material *type; };
+#ifndef PT_LOBE_HEADER
+#define PT_LOBE_HEADER 1
+#endif
 template <bool U> struct BSDF_T {
     typedef typename MatPtrOf<U>::type MatPtr;
     MatPtr m;   // U: wave-uniform (see above); !U: this lane's own record
     V3 ns, ng, ss, ts;
-    PT_DEV BSDF_T(const Isect &si, const mi_material *mat) : m((MatPtr)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) { ts = Cross(ns, ss); }
+    // the lobe count and the lobe TYPES of the material, 4 bits each (PT_LOBE_HEADER, round 3): every loop below asks "which lobes match" before it
+    // touches a lobe's parameters, and with the types only in the 100-byte lobe records each question was a chain of dependent scalar loads (one
+    // per lobe, each in its own cache line: NumComponents alone 1 + n round trips, three times per vertex).  U: one s_load_dwordx2 from the
+    // per-material table mi_scene_upload builds (DevScene::mat_pack); otherwise gathered once here.
+    int nb;
+    uint32_t tpk;
+    PT_DEV int LobeType(int i) const { return (int)((tpk >> (4 * i)) & 15u); }
+    PT_DEV BSDF_T(const Isect &si, const mi_material *mat, const uint2 *packTable = nullptr, int matIndex = 0)
+        : m((MatPtr)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) {
+        ts = Cross(ns, ss);
+        if (PT_LOBE_HEADER && U && packTable) {
+            const __attribute__((address_space(4))) uint32_t *pt = (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)packTable;
+            nb = (int)pt[2 * matIndex]; tpk = pt[2 * matIndex + 1];   // constant address space + wave-uniform index: one s_load_dwordx2
+        } else {
+            nb = m->n_bxdfs; tpk = 0;
+            for (int i = 0; i < nb; ++i) tpk |= (uint32_t)(m->bxdfs[i].type & 15) << (4 * i);
+        }
+    }
     PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     PT_DEV V3 LocalToWorld(const V3 &v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
     }
     PT_DEV int NumComponents(int flags) const {
         int n = 0;
-        for (int i = 0; i < m->n_bxdfs; ++i) if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) ++n;
+        for (int i = 0; i < nb; ++i) if (Matches(BxdfFlags(LobeType(i)), flags)) ++n;
         return n;
     }
     PT_DEV RGB f(const V3 &woW, const V3 &wiW, int flags) const {   // reflection.cpp:670-683
@@ -548,21 +568,21 @@ template <bool U> struct BSDF_T {
         if (wo.z == 0) return RGB(0.f);
         bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
         RGB f(0.f);
-        for (int i = 0; i < m->n_bxdfs; ++i) {
+        for (int i = 0; i < nb; ++i) {
             auto b = &m->bxdfs[i];
-            int t = BxdfFlags(b->type);
+            int t = BxdfFlags(LobeType(i));
             if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
         }
         return f;
     }
     PT_DEV Float Pdf(const V3 &woW, const V3 &wiW, int flags) const {   // reflection.cpp:770-785
-        if (m->n_bxdfs == 0) return 0.f;
+        if (nb == 0) return 0.f;
         V3 wo = WorldToLocal(woW), wi = WorldToLocal(wiW);
         if (wo.z == 0) return 0.f;
         Float pdf = 0.f;
         int matchingComps = 0;
-        for (int i = 0; i < m->n_bxdfs; ++i)
-            if (Matches(BxdfFlags(m->bxdfs[i].type), flags)) { ++matchingComps; pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi); }
+        for (int i = 0; i < nb; ++i)
+            if (Matches(BxdfFlags(LobeType(i)), flags)) { ++matchingComps; pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi); }
         return matchingComps > 0 ? pdf / matchingComps : 0.f;
     }
     PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
@@ -572,8 +592,8 @@ template <bool U> struct BSDF_T {
         // the comp-th matching lobe (per lane: u0 differs) -- found with a wave-uniform loop over the lobes
         int chosen = 0, count = comp;
         bool have = false;
-        for (int i = 0; i < m->n_bxdfs; ++i)
-            if (!have && Matches(BxdfFlags(m->bxdfs[i].type), type) && count-- == 0) { chosen = i; have = true; }
+        for (int i = 0; i < nb; ++i)
+            if (!have && Matches(BxdfFlags(LobeType(i)), type) && count-- == 0) { chosen = i; have = true; }
         Float ur0 = mn(u0 * matchingComps - comp, PT_ONE_MINUS_EPS);
         V3 wi, wo = WorldToLocal(woWorld);
         if (wo.z == 0) return RGB(0.f);
@@ -582,24 +602,24 @@ template <bool U> struct BSDF_T {
         RGB f(0.f);
         // lanes may have chosen different lobes: each lobe's sampling routine runs for the lanes that picked it,
         // every time with a wave-uniform lobe pointer
-        for (int i = 0; i < m->n_bxdfs; ++i)
+        for (int i = 0; i < nb; ++i)
             if (chosen == i) {
-                bt = BxdfFlags(m->bxdfs[i].type);
+                bt = BxdfFlags(LobeType(i));
                 BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
         if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
-            for (int i = 0; i < m->n_bxdfs; ++i)
-                if (i != chosen && Matches(BxdfFlags(m->bxdfs[i].type), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
+            for (int i = 0; i < nb; ++i)
+                if (i != chosen && Matches(BxdfFlags(LobeType(i)), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
         if (matchingComps > 1) *pdf /= matchingComps;
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
             f = RGB(0.f);
-            for (int i = 0; i < m->n_bxdfs; ++i) {
+            for (int i = 0; i < nb; ++i) {
                 auto b = &m->bxdfs[i];
-                int t = BxdfFlags(b->type);
+                int t = BxdfFlags(LobeType(i));
                 if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
             }
         }
