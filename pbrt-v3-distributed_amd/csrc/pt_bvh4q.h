@@ -48,27 +48,6 @@ PT_HD uint32_t Bvh4qStepWords(const uint32_t w[16], const Bvh4qRay &r, float tMa
     const uint32_t ny0 = r.neg[1] ? w[8] : w[2], ny1 = r.neg[1] ? w[9] : w[3], fy0 = r.neg[1] ? w[2] : w[8], fy1 = r.neg[1] ? w[3] : w[9];
     const uint32_t nz0 = r.neg[2] ? w[10] : w[4], nz1 = r.neg[2] ? w[11] : w[5], fz0 = r.neg[2] ? w[4] : w[10], fz1 = r.neg[2] ? w[5] : w[11];
     uint32_t mask = 0;
-#if defined(PT_PK_FMA) && PT_PK_FMA && defined(__HIP_DEVICE_COMPILE__)
-    // the two children of a word side by side: 12 v_pk_fma_f32 instead of 24 v_fma_f32 (each component is the same IEEE fma)
-    typedef float F2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const uint32_t wnx = p ? nx1 : nx0, wny = p ? ny1 : ny0, wnz = p ? nz1 : nz0, wfx = p ? fx1 : fx0, wfy = p ? fy1 : fy0, wfz = p ? fz1 : fz0;
-#define PT_Q2(w) (F2){(float)((w) & 65535u), (float)((w) >> 16)}
-        const F2 ex = __builtin_elementwise_fma(PT_Q2(wnx), (F2){r.A[0], r.A[0]}, (F2){r.Bn[0], r.Bn[0]}), ey = __builtin_elementwise_fma(PT_Q2(wny), (F2){r.A[1], r.A[1]}, (F2){r.Bn[1], r.Bn[1]}),
-                 ez = __builtin_elementwise_fma(PT_Q2(wnz), (F2){r.A[2], r.A[2]}, (F2){r.Bn[2], r.Bn[2]});
-        const F2 xx = __builtin_elementwise_fma(PT_Q2(wfx), (F2){r.A[0], r.A[0]}, (F2){r.Bf[0], r.Bf[0]}), xy = __builtin_elementwise_fma(PT_Q2(wfy), (F2){r.A[1], r.A[1]}, (F2){r.Bf[1], r.Bf[1]}),
-                 xz = __builtin_elementwise_fma(PT_Q2(wfz), (F2){r.A[2], r.A[2]}, (F2){r.Bf[2], r.Bf[2]});
-#undef PT_Q2
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 2 * p + h;
-            float e = __builtin_fmaxf(__builtin_fmaxf(ex[h], ey[h]), ez[h]), x = __builtin_fminf(__builtin_fminf(xx[h], xy[h]), xz[h]);
-            t[k] = e;
-            if ((e <= x) && (e < tMax) && (x > 0) && w[12 + k] != 0xFFFFFFFFu) mask |= 1u << k;
-        }
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int sh = 16 * (k & 1);
@@ -81,7 +60,6 @@ PT_HD uint32_t Bvh4qStepWords(const uint32_t w[16], const Bvh4qRay &r, float tMa
         t[k] = e;
         if ((e <= x) && (e < tMax) && (x > 0) && w[12 + k] != 0xFFFFFFFFu) mask |= 1u << k;
     }
-#endif
     return mask;
 }
 
