@@ -1370,6 +1370,7 @@ struct mi_ctx {
     bool rayBin = false;                     // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
+    bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSDF-less interfaces / alpha masks / BSSRDF
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -1596,7 +1597,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
     // row f4: Integrator "volpath" and materials with a BSSRDF are shaded by k_shade_vol (pt_volpath.h)
     c->volKernel = d->integrator_type == MI_INTEGRATOR_VOLPATH || d->material_bssrdf != nullptr;
-    c->volWave = false;
+    c->volWave = c->volTr = false;
     if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
     if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
     if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
@@ -2200,9 +2201,14 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
         v.camera_medium = v.handle_media ? d->camera_medium : -1;
-        c->volWave = v.handle_media && !d->material_bssrdf && !c->hasNullMat && !c->hasAlpha;
+        // wavefront form: all media homogeneous (their transmittance draws no sampler dimension), no BSSRDF, no alpha masks.  BSDF-less interfaces
+        // (round 3): the shadow / MIS rays then go through k_vol_tr, which steps through them, instead of k_trace<2> / <1> (DevVol::tr_queues)
+        c->volWave = v.handle_media && !d->material_bssrdf && !c->hasAlpha;
         for (uint32_t i = 0; i < d->n_media && c->volWave; ++i) c->volWave = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') c->volWave = false; }   // A/B and parity tests of the general form
+        { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && c->hasNullMat) c->volWave = false; }   // =0: interfaces keep the general form (A/B)
+        c->volTr = c->volWave && c->hasNullMat;
+        v.tr_queues = c->volTr ? 1 : 0;
         v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
         if (v.handle_media && d->n_media) {
             std::vector<mi_medium> med(d->media, d->media + d->n_media);
@@ -2382,7 +2388,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     while (true) {
         uint32_t qout = qin ^ 1;
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave);
+        const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr;
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
@@ -2468,6 +2474,15 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c, st);
             }
             HIP_TRY(hipEventRecord(c->evNeeDone, s2));
+        } else if (c->volTr) {   // wavefront form with BSDF-less interfaces: the direct-lighting rays walk through them (k_vol_tr)
+            tic(c, MI_K_ANYHIT);
+            if (c->hasInst) hipLaunchKernelGGL((k_vol_tr<2, true>), grid, block, 0, st, c->scDev, ps, c->vol);
+            else hipLaunchKernelGGL((k_vol_tr<2, false>), grid, block, 0, st, c->scDev, ps, c->vol);
+            toc(c);
+            tic(c, MI_K_MIS_CLOSEST);
+            if (c->hasInst) hipLaunchKernelGGL((k_vol_tr<1, true>), grid, block, 0, st, c->scDev, ps, c->vol);
+            else hipLaunchKernelGGL((k_vol_tr<1, false>), grid, block, 0, st, c->scDev, ps, c->vol);
+            toc(c);
         } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);
@@ -2497,7 +2512,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             if (left == 0 || iter > sc.max_depth + 4096) break;
         }
     }
-    if (c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));   // the last bounce's direct-lighting terms
+    if (c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));   // the last bounce's direct-lighting terms
     if (toFilm) {
         tic(c, MI_K_FILM);
         hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->filmPtr);

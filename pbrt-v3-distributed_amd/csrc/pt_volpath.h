@@ -151,6 +151,8 @@ struct NeeOut {
     RGB miTerm, miSigmaT;  // f weight / scatteringPdf; sigma_t of the medium the MIS ray travels in (0: vacuum)
     int lightNum;
     Float selPdf;
+    LightPoint lp;         // DevVol::tr_queues: the sampled point on the light (VisibilityTester::p1) and the media the two rays start in
+    int shMedium, miMedium;
 };
 struct VolCtx {
     const DevScene *scp;
@@ -163,7 +165,7 @@ struct VolCtx {
 // VisibilityTester::Tr (core/light.cpp:63-82) with media, VisibilityTester::Unoccluded (:59-61) without
 template <bool INST>
 __device__ __noinline__ RGB VisibilityTrD(VolCtx cx, V3 o, V3 d, Float tMax, int medium, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0,
-                                          Float u1, const V3 wi) {
+                                          Float u1, const V3 wi, const LightPoint *stored = nullptr) {
     if (!cx.vol->handle_media) {
         LaneHit h = TraceLane<true, INST>(cx.lt, o, d, tMax);
         return h.prim == TRAV_MISS ? RGB(1.f) : RGB(0.f);
@@ -177,7 +179,7 @@ __device__ __noinline__ RGB VisibilityTrD(VolCtx cx, V3 o, V3 d, Float tMax, int
         if (!hitSurface) break;
         VHit vh;
         HitToIsect(cx.scp, cx.vol, h.prim, o, d, h.inst, medium, false, &vh);
-        LightPoint lp = LightPointOf(cx.scp, dl, refP, refPError, refN, u0, u1, wi);
+        LightPoint lp = stored ? *stored : LightPointOf(cx.scp, dl, refP, refPError, refN, u0, u1, wi);
         ShadowRay sr = SpawnRayTo(vh.is, lp.p, lp.pError, lp.n);   // isect.SpawnRayTo(p1)
         o = sr.o; d = sr.d; tMax = sr.tMax;
         medium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, d);
@@ -237,13 +239,15 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
             RGB Li;
             if (cx.nee) {   // unoccluded transmittance in closed form (HomogeneousMedium::Tr); occlusion is k_trace<2>'s answer
                 Li = ls.Li;
-                if (shMedium >= 0) Li = Li * ExpRGB(-rgb3(cx.vol->media[shMedium].sigma_t) * mn(ls.shadow.tMax * ls.shadow.d.Length(), PT_MAX_FLOAT));
+                if (!cx.vol->tr_queues && shMedium >= 0) Li = Li * ExpRGB(-rgb3(cx.vol->media[shMedium].sigma_t) * mn(ls.shadow.tMax * ls.shadow.d.Length(), PT_MAX_FLOAT));
+                // tr_queues: the segment may cross BSDF-less interfaces into other media -- k_vol_tr<2> multiplies the transmittance in, interface by interface
             } else
                 Li = ls.Li * VisibilityTrD<INST>(cx, ls.shadow.o, ls.shadow.d, ls.shadow.tMax, shMedium, light, it.p, it.pError, it.n, uL0, uL1, ls.wi);
             if (cx.nee) {
                 if (!Li.IsBlack()) {
                     cx.nee->wantShadow = true;
                     cx.nee->sh = ls.shadow;
+                    if (cx.vol->tr_queues) { cx.nee->lp = LightPointOf(cx.scp, light, it.p, it.pError, it.n, uL0, uL1, ls.wi); cx.nee->shMedium = shMedium; }
                     cx.nee->shTerm = ls.delta ? f * Li / lightPdf : f * Li * PowerHeuristic(lightPdf, scatteringPdf) / lightPdf;
                 }
             } else if (!Li.IsBlack()) {
@@ -283,6 +287,7 @@ __device__ __noinline__ RGB EstimateDirectD(VolCtx cx, const Isect *itp, int mIn
                 cx.nee->miO = ro; cx.nee->miD = wi;
                 cx.nee->miTerm = f * weight / scatteringPdf;
                 cx.nee->miSigmaT = miMedium >= 0 ? rgb3(cx.vol->media[miMedium].sigma_t) : RGB(0.f);
+                cx.nee->miMedium = miMedium;
                 cx.nee->lightNum = lightNum;
                 return Ld;
             }
@@ -622,14 +627,19 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     RGB c = betaNee * (nee.shTerm / nee.selPdf);
                     ps.nee[slot].sh_o = make_float4(nee.sh.o.x, nee.sh.o.y, nee.sh.o.z, nee.sh.tMax);
                     ps.nee[slot].sh_d = make_float4(nee.sh.d.x, nee.sh.d.y, nee.sh.d.z, 0);
-                    ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, 0);
+                    ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, vol.tr_queues ? nee.lp.n.z : 0);
+                    if (vol.tr_queues) {   // the light point + start medium ride in the record's free words (k_vol_tr<2>)
+                        ps.nee[slot].sh_d.w = __int_as_float(nee.shMedium);
+                        ps.nee[slot].pad[0] = make_float4(nee.lp.p.x, nee.lp.p.y, nee.lp.p.z, nee.lp.pError.x);
+                        ps.nee[slot].pad[1] = make_float4(nee.lp.pError.y, nee.lp.pError.z, nee.lp.n.x, nee.lp.n.y);
+                    }
                 }
                 if (nee.wantMis) {
                     RGB c = betaNee * (nee.miTerm / nee.selPdf);
-                    ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, 0);
+                    ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, vol.tr_queues ? __int_as_float(nee.miMedium) : 0);
                     ps.nee[slot].mi_d = make_float4(nee.miD.x, nee.miD.y, nee.miD.z, __uint_as_float((uint32_t)nee.lightNum));
                     ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
-                    ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
+                    if (!vol.tr_queues) ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
                 }
             }
             if (cont) {
@@ -661,4 +671,66 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
 // Camera::medium onto the camera rays of a pass (Camera::GenerateRayDifferential sets ray->medium = medium, cameras/perspective.cpp:203)
 __global__ void __launch_bounds__(PT_BLOCK) k_vol_camera_medium(PathState ps, uint32_t n, int32_t medium) {
     for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += gridDim.x * PT_BLOCK) ps.rec[i].pad2 = make_float4(__uint_as_float((uint32_t)medium), 0, 0, 0);
+}
+
+// ---- the direct-lighting rays of the wavefront form when BSDF-less interfaces separate homogeneous media (DevVol::tr_queues; round 3).
+// k_trace<2> / k_trace<1> end a ray at the first surface; here a surface without a BSDF is stepped through instead: the lane multiplies the
+// medium's closed-form transmittance of the segment in (HomogeneousMedium::Tr draws no sampler dimension, so the dimension stream of the path
+// does not depend on these rays), re-aims at the light point (shadow rays: isect.SpawnRayTo(p1), core/light.cpp:63-82) or keeps its direction (MIS
+// rays: Scene::IntersectTr, core/scene.cpp:56-70) and goes on -- VisibilityTrD / IntersectTrD, the routines the general form runs inside the
+// shading kernel, run here over the shadow / MIS queues in a kernel that carries no shading state (10 waves per CU instead of 8 at 256 VGPRs).
+// MODE 2: shadow rays (adds sh_c * Tr when nothing with a BSDF lies in between).  MODE 1: the BSDF-sampled ray of the MIS estimator.
+template <int MODE, bool INST>
+__global__ void __launch_bounds__(PT_BLOCK) k_vol_tr(const DevScene *scp, PathState ps, DevVol vol) {
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    const DevScene &sc = *scp;
+    LaneTracer lt;
+    lt.scp = scp;
+    lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    lt.nClosest = lt.nAny = lt.guardTrips = 0;
+    VolCtx cx;
+    cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = nullptr; cx.nee = nullptr;
+    const uint32_t *queue = MODE == 1 ? ps.q_mis : ps.q_shadow;
+    for (SegIter it(ps.qcount, MODE == 1 ? QC_MIS : QC_SHADOW, ps.seg_cap); it.more(); it.next()) {
+        if (!it.valid()) continue;
+        const uint32_t slot = queue[it.item()];
+        if (MODE == 2) {
+            const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d, c4 = ps.nee[slot].sh_c, a4 = ps.nee[slot].pad[0], b4 = ps.nee[slot].pad[1];
+            LightPoint lp;
+            lp.p = V3(a4.x, a4.y, a4.z); lp.pError = V3(a4.w, b4.x, b4.y); lp.n = V3(b4.z, b4.w, c4.w);
+            const RGB Tr = VisibilityTrD<INST>(cx, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, __float_as_int(d4.w), nullptr, V3(), V3(), V3(), 0, 0, V3(), &lp);
+            if (!Tr.IsBlack()) {
+                float4 L = ps.rec[slot].L;
+                L.x += c4.x * Tr.r; L.y += c4.y * Tr.g; L.z += c4.z * Tr.b;
+                ps.rec[slot].L = L;
+            }
+        } else {
+            const float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d, c4 = ps.nee[slot].mi_c;
+            const int lightNum = (int)__float_as_uint(d4.w);
+            const DevLight *light = sc.lights + lightNum;
+            const V3 ro(o4.x, o4.y, o4.z), wi(d4.x, d4.y, d4.z);
+            RGB Tr(1.f);
+            V3 segO;
+            const LaneHit lh = IntersectTrD<INST>(cx, ro, wi, __float_as_int(o4.w), &Tr, &segO);
+            RGB Li(0.f);
+            if (lh.prim != TRAV_MISS) {
+                if ((int)sc.tri_info[lh.prim].z == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                    VHit vh;
+                    HitToIsect(scp, &vol, lh.prim, segO, wi, lh.inst, -1, false, &vh);
+                    Li = AreaL(*light, vh.is.n, -wi);
+                }
+            } else if (light->type == MI_LIGHT_INFINITE)
+                Li = InfiniteLe(light, wi);
+            Li = Li * Tr;
+            if (!Li.IsBlack()) {
+                float4 L = ps.rec[slot].L;
+                L.x += c4.x * Li.r; L.y += c4.y * Li.g; L.z += c4.z * Li.b;
+                ps.rec[slot].L = L;
+            }
+        }
+    }
+    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], lt.nClosest);   // as the general form counts them: every segment is a closest-hit query
+    wave_count(&ps.counters[MI_CNT_SHADOW_RAYS], lt.nAny);
+    if (lt.guardTrips) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], (unsigned long long)lt.guardTrips);
 }

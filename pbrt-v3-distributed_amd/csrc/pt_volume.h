@@ -23,7 +23,8 @@ struct DevVol {
     int32_t camera_medium;
     int32_t handle_media;            // Integrator "volpath": media attenuate and scatter (PathIntegrator ignores them)
     int32_t textured;                // some material is textured (c_tex.descs is set): lobe lists are built per hit
-    int32_t pad;
+    int32_t tr_queues;               // wavefront form with BSDF-less interfaces between homogeneous media: shadow / MIS rays carry their light point and start
+                                     // medium through the queues and k_vol_tr walks them interface by interface (pt_volpath.h)
 };
 
 // The path's sampler with the next PT_VOL_PRE dimensions drawn ahead in ONE batch (SamplerBatch: wave-uniform matrix rows through the scalar
