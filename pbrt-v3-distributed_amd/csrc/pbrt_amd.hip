@@ -59,9 +59,17 @@ struct __attribute__((aligned(128))) NeeRec {
     float4 mi_o, mi_d, mi_c;   // MIS ray: o | d.xyz,lightNum | contribution rgb
     float4 pad[2];
 };
+// state of a shadow ([0]) / MIS ([1]) ray that is walked through BSDF-less medium interfaces segment by segment (DevVol::tr_queues)
+struct __attribute__((aligned(64))) TrState {
+    float4 acc[2];   // transmittance so far (rgb)
+    uint4 hit[2];    // the segment's closest hit: prim, t bits, instance, -
+};
 struct PathState {
     PathRec *rec;
     NeeRec *nee;
+    TrState *trs;              // DevVol::tr_queues only, else null
+    uint32_t *q_tr[2];         // second shadow / MIS queues (the walk ping-pongs between q_shadow / q_mis and these)
+    uint32_t qrow_shadow, qrow_mis;   // counter rows of the queues k_trace<2> / <1> read (QC_SHADOW / QC_MIS unless a walk swapped them)
     uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
     uint2 *keyrank;            // because the sort kernels walk them in queue order, not per path
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
@@ -85,7 +93,7 @@ struct PathState {
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_ROWS = 6 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_ROWS = 8 };
 #define QSEG 8u
 #define QC_STRIDE 32u   /* words between counters: one 128-byte line each */
 #define QCI(q, seg) (((uint32_t)(q) * QSEG + (uint32_t)(seg)) * QC_STRIDE)
@@ -400,7 +408,9 @@ template <bool PEND, class TS> PT_DEV bool TraceDone(const TS &ts) {
     if constexpr (PEND) return ts.cur == TRAV_DONE && ts.pend == TRAV_DONE;
     else return ts.done();
 }
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false>
+// TR (MODE 1 / 2, DevVol::tr_queues): the ray is one SEGMENT of a shadow / MIS ray that is walked through BSDF-less medium interfaces -- closest hit
+// (also for shadow segments: the nearest surface decides whether the walk ends or goes on), result into TrState::hit; k_vol_tr_step does the rest
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false, bool TR = false>
 __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK), (TraceShape<MODE, SPHERES, ALPHA, QN>::WAVES)) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
     constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
@@ -419,8 +429,9 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     typename TT::Stack st;
     st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
     st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * ps.spill_per_thread;
+    static_assert(!TR || MODE != 0, "segment walks are for shadow / MIS rays");
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
-    const uint32_t qrow = MODE == 0 ? qin : (MODE == 1 ? QC_MIS : QC_SHADOW);
+    const uint32_t qrow = MODE == 0 ? qin : (MODE == 1 ? ps.qrow_mis : ps.qrow_shadow);
     const bool contig = MODE == 0 && ps.trace_contig;                                     // binned queue: one array, cut into eighths here
     const uint32_t nContig = contig ? ps.qcount[QCI(QC_BINNED, 0)] : 0u;
     const uint32_t segLen = contig ? ((((nContig + 7) / 8) + 63u) & ~63u) : ps.seg_cap;
@@ -437,7 +448,11 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     // hands a finished ray's result over (hit record + sort key / the unoccluded light term / the MIS term)
     auto finalize = [&]() {
         if (active && TraceDone<PEND>(ts)) {
-            if (MODE == 0) {
+            if constexpr (TR) {   // one segment of a walked shadow / MIS ray: the step kernel reads the hit
+                uint32_t hi = TRAV_NO_INSTANCE;
+                if constexpr (INST) hi = ts.hitInst;
+                ps.trs[slot].hit[MODE == 1 ? 1 : 0] = make_uint4(ts.prim, __float_as_uint(ts.tHit), hi, 0u);
+            } else if (MODE == 0) {
                 ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                 if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
                 uint32_t key = sc.n_materials;                                   // escaped rays
@@ -560,17 +575,17 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                 }
             }
             if constexpr (PEND) {
-                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
+                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
             } else {
-                if (active && ts.atLeaf()) TravLeafStep<MODE == 2, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
+                if (active && ts.atLeaf()) TravLeafStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             }
             if (!PT_BATCH_FINALIZE) finalize();
             int nAct = __popcll(__ballot(active && !TraceDone<PEND>(ts)));   // (batched: finished lanes keep their result until the next refill, top of the outer loop)
             if (nAct == 0 || (mayRefill && nAct <= 64 - TRACE_REFILL)) break;
         }
     }
-    wave_count(&ps.counters[MODE == 2 ? MI_CNT_SHADOW_RAYS : MI_CNT_CLOSEST_RAYS], nrays);
-    if (MODE == 1) wave_count(&ps.counters[MI_CNT_MIS_RAYS], nrays);
+    wave_count(&ps.counters[MODE == 2 && !TR ? MI_CNT_SHADOW_RAYS : MI_CNT_CLOSEST_RAYS], nrays);   // (walked segments: closest-hit queries, as the general form of k_shade_vol counts them)
+    if (MODE == 1 && !TR) wave_count(&ps.counters[MI_CNT_MIS_RAYS], nrays);
     if (COUNT) {
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : (MODE == 1 ? MI_CNT_NODES_MIS : MI_CNT_NODES_ANY)], tc.nodes);
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : (MODE == 1 ? MI_CNT_TRIS_MIS : MI_CNT_TRIS_ANY)], tc.tris);
@@ -2295,6 +2310,8 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, qcap);
     ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);
     ALLOC(q_sorted, uint32_t, qcap);
+    ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
+    if (c->volTr) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
@@ -2365,6 +2382,20 @@ static void harvest(mi_ctx *c) {
         else if (c->hasAlpha) LAUNCH_TRACE_I(MODE, true, true, false, false); /* PBRT_AMD_TRACE=general: full-precision nodes */                       \
         else if (c->hasSpheres) LAUNCH_TRACE_I(MODE, true, false, false, false);                                       \
         else LAUNCH_TRACE_I(MODE, false, false, false, false);                                                         \
+    } while (0)
+// the segment traversals of walked shadow / MIS rays (k_trace<..., TR>; volpath scenes with BSDF-less interfaces): three instances per mode
+#define LAUNCH_TRACE_TR_I(MODE, SPH, ALP, INS, QNN)                                                                 \
+    do {                                                                                                            \
+        typedef TraceShape<MODE, SPH, ALP, QNN> TS_;                                                                \
+        const dim3 g_(((c->numCUs * TS_::PER_CU + 7) / 8) * 8), b_(TS_::BLOCK);                                     \
+        if (countWork) hipLaunchKernelGGL((k_trace<MODE, true, SPH, ALP, INS, QNN, true>), g_, b_, 0, st, sc, ps, qin);   \
+        else hipLaunchKernelGGL((k_trace<MODE, false, SPH, ALP, INS, QNN, true>), g_, b_, 0, st, sc, ps, qin);            \
+    } while (0)
+#define LAUNCH_TRACE_TR(MODE)                                                                                       \
+    do {                                                                                                            \
+        if (c->hasInst) LAUNCH_TRACE_TR_I(MODE, true, true, true, false);                                           \
+        else if (c->useQ) LAUNCH_TRACE_TR_I(MODE, true, false, false, true);                                        \
+        else LAUNCH_TRACE_TR_I(MODE, true, false, false, false);                                                    \
     } while (0)
 // One pass of the wavefront pipeline over the paths generated by `pass`.
 static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm) {
@@ -2474,15 +2505,42 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c, st);
             }
             HIP_TRY(hipEventRecord(c->evNeeDone, s2));
-        } else if (c->volTr) {   // wavefront form with BSDF-less interfaces: the direct-lighting rays walk through them (k_vol_tr)
-            tic(c, MI_K_ANYHIT);
-            if (c->hasInst) hipLaunchKernelGGL((k_vol_tr<2, true>), grid, block, 0, st, c->scDev, ps, c->vol);
-            else hipLaunchKernelGGL((k_vol_tr<2, false>), grid, block, 0, st, c->scDev, ps, c->vol);
-            toc(c);
-            tic(c, MI_K_MIS_CLOSEST);
-            if (c->hasInst) hipLaunchKernelGGL((k_vol_tr<1, true>), grid, block, 0, st, c->scDev, ps, c->vol);
-            else hipLaunchKernelGGL((k_vol_tr<1, false>), grid, block, 0, st, c->scDev, ps, c->vol);
-            toc(c);
+        } else if (c->volTr) {
+            // wavefront form with BSDF-less interfaces between homogeneous media: the shadow and the MIS rays are WALKED through the interfaces, one
+            // segment per round -- closest hit of the segment by the persistent-lane kernel (k_trace<..., TR>), then k_vol_tr_step ends the ray or
+            // re-aims it behind the interface into the other queue.  Three rounds are queued blindly (a kernel on an empty queue returns at once),
+            // then the host looks at the counter (such scenes synchronise once per pass anyway, see below).
+            for (int which = 0; which < 2; ++which) {   // 0: shadow rays (MODE 2), 1: MIS rays (MODE 1)
+                tic(c, which ? MI_K_MIS_CLOSEST : MI_K_ANYHIT);
+                uint32_t rowIn = which ? QC_MIS : QC_SHADOW, rowOut = which ? QC_MIS2 : QC_SHADOW2;
+                uint32_t *qIn = which ? ps.q_mis : ps.q_shadow, *qOut = ps.q_tr[which];
+                for (int round = 0; round < 4096; ++round) {
+                    HIP_TRY(hipMemsetAsync(ps.qcount + QCI(rowOut, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    {
+                        PathState psRun = ps;
+                        if (which) { psRun.q_mis = qIn; psRun.qrow_mis = rowIn; } else { psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn; }
+                        PathState &ps = psRun;
+                        if (which) LAUNCH_TRACE_TR(1); else LAUNCH_TRACE_TR(2);
+                    }
+                    if (which) {
+                        if (c->hasInst) hipLaunchKernelGGL((k_vol_tr_step<1, true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                        else hipLaunchKernelGGL((k_vol_tr_step<1, false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                    } else {
+                        if (c->hasInst) hipLaunchKernelGGL((k_vol_tr_step<2, true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                        else hipLaunchKernelGGL((k_vol_tr_step<2, false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                    }
+                    std::swap(qIn, qOut); std::swap(rowIn, rowOut);
+                    if (round >= 2) {
+                        uint32_t left = 0, row[QSEG * QC_STRIDE];
+                        HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(rowIn, 0), sizeof(row), hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
+                        if (left == 0) break;
+                    }
+                }
+                toc(c);
+            }
         } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         tic(c, MI_K_ANYHIT);

@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     ps.nee[slot].sh_o = make_float4(nee.sh.o.x, nee.sh.o.y, nee.sh.o.z, nee.sh.tMax);
                     ps.nee[slot].sh_d = make_float4(nee.sh.d.x, nee.sh.d.y, nee.sh.d.z, 0);
                     ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, vol.tr_queues ? nee.lp.n.z : 0);
-                    if (vol.tr_queues) {   // the light point + start medium ride in the record's free words (k_vol_tr<2>)
+                    if (vol.tr_queues) {   // the light point + start medium ride in the record's free words (k_vol_tr_step<2>)
+                        ps.trs[slot].acc[0] = make_float4(1, 1, 1, 0);
                         ps.nee[slot].sh_d.w = __int_as_float(nee.shMedium);
                         ps.nee[slot].pad[0] = make_float4(nee.lp.p.x, nee.lp.p.y, nee.lp.p.z, nee.lp.pError.x);
                         ps.nee[slot].pad[1] = make_float4(nee.lp.pError.y, nee.lp.pError.z, nee.lp.n.x, nee.lp.n.y);
@@ -639,6 +640,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, vol.tr_queues ? __int_as_float(nee.miMedium) : 0);
                     ps.nee[slot].mi_d = make_float4(nee.miD.x, nee.miD.y, nee.miD.z, __uint_as_float((uint32_t)nee.lightNum));
                     ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
+                    if (vol.tr_queues) ps.trs[slot].acc[1] = make_float4(1, 1, 1, 0);
                     if (!vol.tr_queues) ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
                 }
             }
@@ -674,63 +676,90 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_camera_medium(PathState ps, ui
 }
 
 // ---- the direct-lighting rays of the wavefront form when BSDF-less interfaces separate homogeneous media (DevVol::tr_queues; round 3).
-// k_trace<2> / k_trace<1> end a ray at the first surface; here a surface without a BSDF is stepped through instead: the lane multiplies the
-// medium's closed-form transmittance of the segment in (HomogeneousMedium::Tr draws no sampler dimension, so the dimension stream of the path
-// does not depend on these rays), re-aims at the light point (shadow rays: isect.SpawnRayTo(p1), core/light.cpp:63-82) or keeps its direction (MIS
-// rays: Scene::IntersectTr, core/scene.cpp:56-70) and goes on -- VisibilityTrD / IntersectTrD, the routines the general form runs inside the
-// shading kernel, run here over the shadow / MIS queues in a kernel that carries no shading state (10 waves per CU instead of 8 at 256 VGPRs).
-// MODE 2: shadow rays (adds sh_c * Tr when nothing with a BSDF lies in between).  MODE 1: the BSDF-sampled ray of the MIS estimator.
+// k_trace<2> / k_trace<1> end a ray at the first surface; with interfaces a surface without a BSDF has to be stepped through instead
+// (VisibilityTester::Tr core/light.cpp:63-82, Scene::IntersectTr core/scene.cpp:56-70).  The rays are WALKED segment by segment through the queues:
+// k_trace<2 / 1, ..., TR> finds the segment's closest hit with the persistent-lane machinery (a first version that let every lane loop through
+// VisibilityTrD on its own cost what the shading kernel had saved: profiles/r03_o_*), this kernel multiplies the segment's closed-form transmittance
+// in (HomogeneousMedium::Tr draws no sampler dimension: the path's dimension stream does not depend on these rays), ends the ray -- an opaque
+// surface, the light, nothing -- or re-aims it behind the interface (shadow rays: isect.SpawnRayTo(p1); MIS rays: isect.SpawnRay(d)) and appends it
+// to the other queue for the next round.  Most rays end in the first round.
+// MODE 2: shadow rays (NeeRec::sh_*; light point in pad[0..1] + sh_c.w).  MODE 1: the BSDF-sampled ray of the MIS estimator (NeeRec::mi_*).
 template <int MODE, bool INST>
-__global__ void __launch_bounds__(PT_BLOCK) k_vol_tr(const DevScene *scp, PathState ps, DevVol vol) {
-    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+__global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn, uint32_t *qOut, uint32_t rowOut) {
     const DevScene &sc = *scp;
-    LaneTracer lt;
-    lt.scp = scp;
-    lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
-    lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
-    lt.nClosest = lt.nAny = lt.guardTrips = 0;
-    VolCtx cx;
-    cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = nullptr; cx.nee = nullptr;
-    const uint32_t *queue = MODE == 1 ? ps.q_mis : ps.q_shadow;
-    for (SegIter it(ps.qcount, MODE == 1 ? QC_MIS : QC_SHADOW, ps.seg_cap); it.more(); it.next()) {
-        if (!it.valid()) continue;
-        const uint32_t slot = queue[it.item()];
-        if (MODE == 2) {
-            const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d, c4 = ps.nee[slot].sh_c, a4 = ps.nee[slot].pad[0], b4 = ps.nee[slot].pad[1];
-            LightPoint lp;
-            lp.p = V3(a4.x, a4.y, a4.z); lp.pError = V3(a4.w, b4.x, b4.y); lp.n = V3(b4.z, b4.w, c4.w);
-            const RGB Tr = VisibilityTrD<INST>(cx, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, __float_as_int(d4.w), nullptr, V3(), V3(), V3(), 0, 0, V3(), &lp);
-            if (!Tr.IsBlack()) {
-                float4 L = ps.rec[slot].L;
-                L.x += c4.x * Tr.r; L.y += c4.y * Tr.g; L.z += c4.z * Tr.b;
-                ps.rec[slot].L = L;
-            }
-        } else {
-            const float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d, c4 = ps.nee[slot].mi_c;
-            const int lightNum = (int)__float_as_uint(d4.w);
-            const DevLight *light = sc.lights + lightNum;
-            const V3 ro(o4.x, o4.y, o4.z), wi(d4.x, d4.y, d4.z);
-            RGB Tr(1.f);
-            V3 segO;
-            const LaneHit lh = IntersectTrD<INST>(cx, ro, wi, __float_as_int(o4.w), &Tr, &segO);
-            RGB Li(0.f);
-            if (lh.prim != TRAV_MISS) {
-                if ((int)sc.tri_info[lh.prim].z == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
-                    VHit vh;
-                    HitToIsect(scp, &vol, lh.prim, segO, wi, lh.inst, -1, false, &vh);
-                    Li = AreaL(*light, vh.is.n, -wi);
+    const int w = MODE == 1 ? 1 : 0;
+    for (SegIter it(ps.qcount, rowIn, ps.seg_cap); it.more(); it.next()) {
+        const bool active = it.valid();
+        bool again = false;
+        uint32_t slot = 0;
+        if (active) {
+            slot = qIn[it.item()];
+            const uint4 hit = ps.trs[slot].hit[w];
+            const float4 acc = ps.trs[slot].acc[w];
+            RGB Tr(acc.x, acc.y, acc.z);
+            const bool hitSurface = hit.x != TRAV_MISS;
+            const Float tHit = __uint_as_float(hit.y);
+            const bool opaque = hitSurface && (int)sc.tri_info[hit.x].y >= 0;
+            if (MODE == 2) {
+                const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+                const V3 o(o4.x, o4.y, o4.z), d(d4.x, d4.y, d4.z);
+                const int medium = __float_as_int(d4.w);
+                if (!opaque) {   // (an opaque surface in between: the light sample contributes nothing)
+                    if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, d, hitSurface ? tHit : o4.w, nullptr);
+                    if (!hitSurface) {
+                        if (!Tr.IsBlack()) {
+                            const float4 c4 = ps.nee[slot].sh_c;
+                            float4 L = ps.rec[slot].L;
+                            L.x += c4.x * Tr.r; L.y += c4.y * Tr.g; L.z += c4.z * Tr.b;
+                            ps.rec[slot].L = L;
+                        }
+                    } else {   // a BSDF-less interface: re-aim at the light point from behind it
+                        VHit vh;
+                        HitToIsect(scp, &vol, hit.x, o, d, hit.z, medium, false, &vh);
+                        const float4 c4 = ps.nee[slot].sh_c, a4 = ps.nee[slot].pad[0], b4 = ps.nee[slot].pad[1];
+                        ShadowRay sr = SpawnRayTo(vh.is, V3(a4.x, a4.y, a4.z), V3(a4.w, b4.x, b4.y), V3(b4.z, b4.w, c4.w));
+                        ps.nee[slot].sh_o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.tMax);
+                        ps.nee[slot].sh_d = make_float4(sr.d.x, sr.d.y, sr.d.z, __int_as_float(GetMediumOf(vh.is.n, vh.mIn, vh.mOut, sr.d)));
+                        ps.trs[slot].acc[0] = make_float4(Tr.r, Tr.g, Tr.b, 0);
+                        again = true;
+                    }
                 }
-            } else if (light->type == MI_LIGHT_INFINITE)
-                Li = InfiniteLe(light, wi);
-            Li = Li * Tr;
-            if (!Li.IsBlack()) {
-                float4 L = ps.rec[slot].L;
-                L.x += c4.x * Li.r; L.y += c4.y * Li.g; L.z += c4.z * Li.b;
-                ps.rec[slot].L = L;
+            } else {
+                const float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d;
+                const V3 o(o4.x, o4.y, o4.z), wi(d4.x, d4.y, d4.z);
+                const int medium = __float_as_int(o4.w);
+                if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, wi, hitSurface ? tHit : PT_INFINITY, nullptr);
+                if (hitSurface && !opaque) {   // interface: isect.SpawnRay(ray.d), medium = isect.GetMedium(d)
+                    VHit vh;
+                    HitToIsect(scp, &vol, hit.x, o, wi, hit.z, medium, false, &vh);
+                    const V3 no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);
+                    ps.nee[slot].mi_o = make_float4(no.x, no.y, no.z, __int_as_float(GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi)));
+                    ps.trs[slot].acc[1] = make_float4(Tr.r, Tr.g, Tr.b, 0);
+                    again = true;
+                } else {
+                    const int lightNum = (int)__float_as_uint(d4.w);
+                    const DevLight *light = sc.lights + lightNum;
+                    RGB Li(0.f);
+                    if (hitSurface) {
+                        if ((int)sc.tri_info[hit.x].z == lightNum) {   // lightIsect.primitive->GetAreaLight() == &light (integrator.cpp:207)
+                            VHit vh;
+                            HitToIsect(scp, &vol, hit.x, o, wi, hit.z, -1, false, &vh);
+                            Li = AreaL(*light, vh.is.n, -wi);
+                        }
+                    } else if (light->type == MI_LIGHT_INFINITE)
+                        Li = InfiniteLe(light, wi);
+                    Li = Li * Tr;
+                    if (!Li.IsBlack()) {
+                        const float4 c4 = ps.nee[slot].mi_c;
+                        float4 L = ps.rec[slot].L;
+                        L.x += c4.x * Li.r; L.y += c4.y * Li.g; L.z += c4.z * Li.b;
+                        ps.rec[slot].L = L;
+                    }
+                }
             }
         }
+        const uint32_t qseg = blockIdx.x & 7;
+        const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
+        if (again) qOut[qseg * ps.seg_cap + pos] = slot;
     }
-    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], lt.nClosest);   // as the general form counts them: every segment is a closest-hit query
-    wave_count(&ps.counters[MI_CNT_SHADOW_RAYS], lt.nAny);
-    if (lt.guardTrips) atomicAdd(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], (unsigned long long)lt.guardTrips);
 }
