@@ -631,8 +631,8 @@ def test_volpath_and_subsurface_scenes_vs_reference_fixture(name):
 
 @pytest.mark.parametrize("name", ["vol_fog", "vol_glass", "vol_none", "vol_inst"])
 def test_volpath_general_form_on_homogeneous_scenes(name, monkeypatch):
-    """Scenes whose media are all homogeneous (and that have no BSDF-less interfaces, masks or BSSRDFs) send their shadow / MIS rays through
-    the wavefront queues (k_shade_vol<WAVE = true>, closed-form transmittance); PBRT_AMD_VOL_INLINE=1 runs them through the general form
+    """Scenes whose media are all homogeneous (and that have no masks or BSSRDFs) send their shadow / MIS rays through the wavefront queues
+    (k_shade_vol<WAVE = true>; closed-form transmittance, interfaces walked: test_walked_interfaces_...); PBRT_AMD_VOL_INLINE=1 runs them through the general form
     (every lane traces its own transmittance rays) -- both must reproduce the reference's render."""
     monkeypatch.setenv("PBRT_AMD_VOL_INLINE", "1")
     sc = pa.Scene(text=edge_scenes.scene(name))
@@ -641,6 +641,34 @@ def test_volpath_general_form_on_homogeneous_scenes(name, monkeypatch):
     frac, relmse = ol.image_metrics(sc.film_image(ctx.film()), pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name)))
     assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
     ctx.close()
+
+
+@pytest.mark.parametrize("flatten", [False, True])
+def test_walked_interfaces_match_the_general_form(flatten, monkeypatch):
+    """BSDF-less interfaces between homogeneous media in wavefront form (round 3): the shadow and MIS rays are walked through the interfaces segment by
+    segment through the queues (k_trace<..., TR> + k_vol_tr_step) instead of being traced by the shading lanes (PBRT_AMD_VOL_TR_QUEUES=0: the general
+    form).  vol_inst has instanced and top-level volumes behind BSDF-less boundaries: both forms reproduce the reference's render, with the same rays."""
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
+    fx = pa.read_pfm(os.path.join(G, "edge_vol_inst.pfm"))
+    out = {}
+    for form in ("walked", "general"):
+        if form == "general":
+            monkeypatch.setenv("PBRT_AMD_VOL_TR_QUEUES", "0")
+        else:
+            monkeypatch.delenv("PBRT_AMD_VOL_TR_QUEUES", raising=False)
+        sc = pa.Scene(text=edge_scenes.scene("vol_inst"))
+        ctx = pa.Context(sc)
+        ctx.timing_enable(True); ctx.counters_reset()
+        ctx.render()
+        t, cnt = ctx.timing(), ctx.counters()
+        img = sc.film_image(ctx.film())
+        frac, relmse = ol.image_metrics(img, fx)
+        assert (frac >= 0.995 and relmse <= 1e-4) if not flatten else (frac >= 0.99 and relmse <= 5e-4), (form, frac, relmse)
+        out[form] = (img, {k: v[1] for k, v in t.items() if v[1]}, cnt)
+        ctx.close()
+    assert "anyhit" in out["walked"][1] and "mis_closest" in out["walked"][1] and "anyhit" not in out["general"][1]   # the walk ran / the lanes traced their own rays
+    assert out["walked"][2]["closest_rays"] == out["general"][2]["closest_rays"] and out["walked"][2]["trace_guard_trips"] == 0   # segment for segment the same queries
+    assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["vol_inst", "sss_inst", "vol_glass"])
