@@ -1386,7 +1386,7 @@ struct mi_ctx {
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
-    bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSDF-less interfaces / alpha masks / BSSRDF
+    bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSSRDF (BSDF-less interfaces / alpha masks: volTr)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
     const DevScene *scDev = nullptr;         // DevScene in HBM: k_shade_vol's out-of-line routines take it by pointer
@@ -2216,13 +2216,15 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
         v.camera_medium = v.handle_media ? d->camera_medium : -1;
-        // wavefront form: all media homogeneous (their transmittance draws no sampler dimension), no BSSRDF, no alpha masks.  BSDF-less interfaces
-        // (round 3): the shadow / MIS rays then go through k_vol_tr, which steps through them, instead of k_trace<2> / <1> (DevVol::tr_queues)
-        c->volWave = v.handle_media && !d->material_bssrdf && !c->hasAlpha;
+        // wavefront form: all media homogeneous (their transmittance draws no sampler dimension) and no BSSRDF.  With BSDF-less interfaces or alpha
+        // masks (round 3) the shadow / MIS rays are WALKED segment by segment -- k_trace<..., TR> + k_vol_tr_step (DevVol::tr_queues) -- instead of going
+        // through k_trace<2> / <1>: the walk's closest-hit kernel steps through interfaces and evaluates alphaMask (not shadowAlphaMask) exactly where
+        // VisibilityTester::Tr's Scene::Intersect does (core/light.cpp:63-82, shapes/triangle.cpp:333-338)
+        c->volWave = v.handle_media && !d->material_bssrdf;
         for (uint32_t i = 0; i < d->n_media && c->volWave; ++i) c->volWave = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') c->volWave = false; }   // A/B and parity tests of the general form
-        { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && c->hasNullMat) c->volWave = false; }   // =0: interfaces keep the general form (A/B)
-        c->volTr = c->volWave && c->hasNullMat;
+        { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && (c->hasNullMat || c->hasAlpha)) c->volWave = false; }   // =0: such scenes keep the general form (A/B)
+        c->volTr = c->volWave && (c->hasNullMat || c->hasAlpha);
         v.tr_queues = c->volTr ? 1 : 0;
         v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
         if (v.handle_media && d->n_media) {
@@ -2383,7 +2385,7 @@ static void harvest(mi_ctx *c) {
         else if (c->hasSpheres) LAUNCH_TRACE_I(MODE, true, false, false, false);                                       \
         else LAUNCH_TRACE_I(MODE, false, false, false, false);                                                         \
     } while (0)
-// the segment traversals of walked shadow / MIS rays (k_trace<..., TR>; volpath scenes with BSDF-less interfaces): three instances per mode
+// the segment traversals of walked shadow / MIS rays (k_trace<..., TR>; volpath scenes with BSDF-less interfaces or alpha masks): five instances per mode
 #define LAUNCH_TRACE_TR_I(MODE, SPH, ALP, INS, QNN)                                                                 \
     do {                                                                                                            \
         typedef TraceShape<MODE, SPH, ALP, QNN> TS_;                                                                \
@@ -2394,7 +2396,9 @@ static void harvest(mi_ctx *c) {
 #define LAUNCH_TRACE_TR(MODE)                                                                                       \
     do {                                                                                                            \
         if (c->hasInst) LAUNCH_TRACE_TR_I(MODE, true, true, true, false);                                           \
+        else if (c->useQ && c->hasAlpha) LAUNCH_TRACE_TR_I(MODE, true, true, false, true);                          \
         else if (c->useQ) LAUNCH_TRACE_TR_I(MODE, true, false, false, true);                                        \
+        else if (c->hasAlpha) LAUNCH_TRACE_TR_I(MODE, true, true, false, false);                                    \
         else LAUNCH_TRACE_TR_I(MODE, true, false, false, false);                                                    \
     } while (0)
 // One pass of the wavefront pipeline over the paths generated by `pass`.

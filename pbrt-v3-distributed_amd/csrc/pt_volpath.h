@@ -139,10 +139,11 @@ __device__ __noinline__ LightPoint LightPointOf(const DevScene *scp, const DevLi
     return lp;
 }
 
-// Wavefront form of the two direct-lighting rays (k_shade_vol<true>): scenes whose media are all homogeneous and that have neither BSDF-less
-// interfaces, alpha masks nor BSSRDF materials draw no sampler dimension inside their visibility code, and the first surface a shadow / MIS ray
+// Wavefront form of the two direct-lighting rays (k_shade_vol<true>): scenes whose media are all homogeneous and that have no BSSRDF materials
+// draw no sampler dimension inside their visibility code.  Without BSDF-less interfaces and alpha masks the first surface a shadow / MIS ray
 // meets ends it -- so the rays go through the shadow and MIS queues to k_trace<2> / k_trace<1> as in k_shade, with the closed-form
-// transmittance folded into the shadow term here and applied over the hit distance by k_trace<1> (PathState::vol_tr).
+// transmittance folded into the shadow term here and applied over the hit distance by k_trace<1> (PathState::vol_tr); with them the rays are
+// walked segment by segment (DevVol::tr_queues: k_trace<..., TR> + k_vol_tr_step below).
 struct NeeOut {
     bool wantShadow, wantMis;
     ShadowRay sh;

@@ -81,6 +81,15 @@ def vol_scene(name):
         t = t.replace('WorldBegin\n', 'WorldBegin\nMediumInterface "" "fog"\n' + med, 1)
         return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.01 .015 .02] "rgb sigma_s" [.06 .05 .04] "float g" [.2]\n'
                                    'MediumInterface "" "fog"\nLookAt', 1)
+    if name == "vol_alpha_fog":  # alpha masks under volpath with HOMOGENEOUS media only: the wavefront form walks the shadow / MIS rays with the closest-hit kernel, which
+        t = tex_scene("tex_alpha")   # evaluates alphaMask (not shadowAlphaMask) exactly where VisibilityTester::Tr's Intersect does; + a dense homogeneous volume behind a BSDF-less box
+        t = t.replace('Integrator "path" "integer maxdepth" [4]', 'Integrator "volpath" "integer maxdepth" [4]')
+        box = "-1.5 0.1 -2  1.5 0.1 -2  1.5 0.1 0  -1.5 0.1 0  -1.5 2.1 -2  1.5 2.1 -2  1.5 2.1 0  -1.5 2.1 0"
+        med = ('MakeNamedMedium "puff" "string type" "homogeneous" "rgb sigma_a" [.2 .2 .25] "rgb sigma_s" [.9 .8 .7] "float g" [.1]\n'
+               'AttributeBegin\nMediumInterface "puff" "fog"\nMaterial ""\n%sAttributeEnd\n' % (_SMOKE_BOX % box))
+        t = t.replace('WorldBegin\n', 'WorldBegin\nMediumInterface "" "fog"\n' + med, 1)
+        return t.replace('LookAt', 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.01 .015 .02] "rgb sigma_s" [.06 .05 .04] "float g" [.2]\n'
+                                   'MediumInterface "" "fog"\nLookAt', 1)
     if name == "vol_inst":       # two-level instancing under volpath: instanced objects (one carrying its own inside medium behind a BSDF-less boundary, one of glass)
         # in fog, with rotations and a mirroring scale -- the per-lane transmittance / MIS rays of k_shade_vol enter and leave instances
         obj = ('ObjectBegin "cloud"\nMediumInterface "dense" "fog"\nMaterial ""\n'
@@ -102,7 +111,7 @@ def vol_scene(name):
     raise KeyError(name)
 
 
-VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none", "vol_alpha", "vol_inst"]
+VOL_NAMES = ["vol_fog", "vol_smoke", "vol_glass", "vol_none", "vol_alpha", "vol_inst", "vol_alpha_fog"]
 
 
 # ---- subsurface scattering: the BSSRDF branch of path / volpath

@@ -629,7 +629,7 @@ def test_volpath_and_subsurface_scenes_vs_reference_fixture(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["vol_fog", "vol_glass", "vol_none", "vol_inst"])
+@pytest.mark.parametrize("name", ["vol_fog", "vol_glass", "vol_none", "vol_inst", "vol_alpha_fog"])
 def test_volpath_general_form_on_homogeneous_scenes(name, monkeypatch):
     """Scenes whose media are all homogeneous (and that have no masks or BSSRDFs) send their shadow / MIS rays through the wavefront queues
     (k_shade_vol<WAVE = true>; closed-form transmittance, interfaces walked: test_walked_interfaces_...); PBRT_AMD_VOL_INLINE=1 runs them through the general form
@@ -643,20 +643,21 @@ def test_volpath_general_form_on_homogeneous_scenes(name, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("flatten", [False, True])
-def test_walked_interfaces_match_the_general_form(flatten, monkeypatch):
+@pytest.mark.parametrize("name,flatten", [("vol_inst", False), ("vol_inst", True), ("vol_alpha_fog", False)])
+def test_walked_interfaces_match_the_general_form(name, flatten, monkeypatch):
     """BSDF-less interfaces between homogeneous media in wavefront form (round 3): the shadow and MIS rays are walked through the interfaces segment by
     segment through the queues (k_trace<..., TR> + k_vol_tr_step) instead of being traced by the shading lanes (PBRT_AMD_VOL_TR_QUEUES=0: the general
-    form).  vol_inst has instanced and top-level volumes behind BSDF-less boundaries: both forms reproduce the reference's render, with the same rays."""
+    form).  vol_inst has instanced and top-level volumes behind BSDF-less boundaries, vol_alpha_fog alpha-masked quads in fog in front of one (the walk's
+    segments evaluate alphaMask like Scene::Intersect, shapes/triangle.cpp:333-338): both forms reproduce the reference's render, with the same rays."""
     monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
-    fx = pa.read_pfm(os.path.join(G, "edge_vol_inst.pfm"))
+    fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     out = {}
     for form in ("walked", "general"):
         if form == "general":
             monkeypatch.setenv("PBRT_AMD_VOL_TR_QUEUES", "0")
         else:
             monkeypatch.delenv("PBRT_AMD_VOL_TR_QUEUES", raising=False)
-        sc = pa.Scene(text=edge_scenes.scene("vol_inst"))
+        sc = pa.Scene(text=edge_scenes.scene(name))
         ctx = pa.Context(sc)
         ctx.timing_enable(True); ctx.counters_reset()
         ctx.render()
