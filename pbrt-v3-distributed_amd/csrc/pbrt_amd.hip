@@ -416,6 +416,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
     constexpr bool PEND = QN && PT_PEND_LEAF;
+    constexpr bool ADEFER = PEND && ALPHA && PT_ALPHA_DEFER;   // masks evaluated in wave-wide alpha phases (TravPendStep<..., DEFER>)
     typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
@@ -505,6 +506,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
         }
     };
     uint32_t waveIters = 0;
+    unsigned long long apend = 0;   // ADEFER: the lanes whose parked triangle waits for its mask (wave-uniform)
     while (true) {
         // PT_BATCH_FINALIZE: the rays that finished since the last refill hand their results over TOGETHER (one pass through the block with all of
         // them, instead of one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the
@@ -569,13 +571,25 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                         } else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
                     int nLeaf;
-                    if constexpr (PEND) nLeaf = __popcll(__ballot(active && ts.pend != TRAV_DONE));
+                    if constexpr (PEND) nLeaf = __popcll(__ballot(active && ts.pend != TRAV_DONE) & ~apend);
                     else nLeaf = __popcll(__ballot(active && ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
-            if constexpr (PEND) {
-                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA>(sc, ts, st, &tc);
+            if constexpr (ADEFER) {
+                bool cand = false;
+                if (active && ts.pend != TRAV_DONE && !((apend >> lane) & 1ull)) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::Stack, true>(sc, ts, st, &tc, &cand);
+                apend |= __ballot(cand);
+                if (apend) {
+                    const bool waits = (apend >> lane) & 1ull;
+                    const int nA = __popcll(apend), nGo = __popcll(__ballot(active && (ts.atNode() || (ts.pend != TRAV_DONE && !waits))));   // lanes with a step to take without a mask
+                    if (nA >= PT_ALPHA_MIN || nGo * PT_ALPHA_GO_MUL <= nA) {   // alpha phase: the same step again, this time through the mask
+                        if (waits) TravPendStep<MODE == 2 && !TR, false, SPHERES, ALPHA, typename TT::Stack, false>(sc, ts, st, &tc);
+                        apend = 0;
+                    }
+                }
+            } else if constexpr (PEND) {
+                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::Stack>(sc, ts, st, &tc);
             } else {
                 if (active && ts.atLeaf()) TravLeafStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             }

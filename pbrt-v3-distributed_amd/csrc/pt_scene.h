@@ -741,13 +741,27 @@ PT_DEV void TravLeafStep(const DevScene &sc, TS &ts, ST &st, TraceCounters *cnt)
 #ifndef PT_PEND_LEAF
 #define PT_PEND_LEAF 1
 #endif
+// PT_ALPHA_DEFER (round 3, masked scenes with parked leaves): alpha masks are evaluated in wave-wide alpha phases, run when PT_ALPHA_MIN lanes wait
+// for one or when the waiting lanes outnumber those that can go on without (a lane whose parked triangle waits for its mask still takes node steps)
+#ifndef PT_ALPHA_DEFER
+#define PT_ALPHA_DEFER 1
+#endif
+#ifndef PT_ALPHA_MIN
+#define PT_ALPHA_MIN 32
+#endif
+#ifndef PT_ALPHA_GO_MUL   // ... outnumber PT_ALPHA_GO_MUL x the lanes that can go on
+#define PT_ALPHA_GO_MUL 1
+#endif
 // if the lane stands at a leaf and has none parked: park it and take the next stack entry
 template <class ST> PT_DEV void TravParkLeaf(TravStateQ &ts, ST &st) {
     if (ts.pend == TRAV_DONE && ts.cur != TRAV_DONE && (ts.cur & BVH4_LEAF)) { ts.pend = ts.cur; ts.cur = st.pop(ts.tMax); }
 }
-// one triangle of the parked leaf (TravLeafStep on ts.pend; the leaf's end frees the slot instead of popping)
-template <bool ANY, bool COUNT, bool SPHERES, bool ALPHA, class ST>
-PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt) {
+// one triangle of the parked leaf (TravLeafStep on ts.pend; the leaf's end frees the slot instead of popping).
+// DEFER (PT_ALPHA_DEFER, masked scenes): a candidate hit on a masked triangle is not decided here -- *cand is set, the triangle stays parked, and the
+// wave's next ALPHA PHASE repeats this step with DEFER = false for all such lanes together (k_trace): the mask texture is an interpreter call of
+// hundreds of instructions, and in a kernel bound by VALU issue it costs the same for one lane as for sixty-four
+template <bool ANY, bool COUNT, bool SPHERES, bool ALPHA, class ST, bool DEFER = false>
+PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt, bool *cand = nullptr) {
     const uint32_t first = ts.pend & BVH4_FIRST_MASK, left = (ts.pend >> 27) & 0xfu;
     V3 p0, p1, p2;
     uint32_t flags;
@@ -761,7 +775,10 @@ PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounte
         hitPrim = th.t >= 0;
     } else
         hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
-    if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
+    if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) {
+        if constexpr (DEFER) { *cand = true; return; }   // (tMax cannot change before the alpha phase: only this lane's leaf steps shrink it)
+        hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
+    }
     if (hitPrim) {
         ts.prim = first;
         ts.tHit = th.t;

@@ -388,13 +388,15 @@ def _config_scene(name, tmp):
     out = os.path.join(tmp, name + ".pbrt")
     if name == "sanmiguel":      # configs[2]/[4]: San-Miguel-class stand-in, many lights + materials
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--out", out], stdout=subprocess.DEVNULL)
+    elif name == "sanmiguel_leafmask":   # the same with its leaf quads as alpha-masked meshes (bench.py --leafmask): the traversal's wave-wide alpha phases (PT_ALPHA_DEFER)
+        subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--leafmask", "--out", out], stdout=subprocess.DEVNULL)
     else:                        # configs[3]: bathroom-class, glass + mirror + deep paths (maxdepth 30)
         subprocess.check_call([sys.executable, gen, "bathroom", "--tris", "60000", "--res", "192", "108", "--spp", "16", "--out", out], stdout=subprocess.DEVNULL)
     return pa.Scene(out)
 
 
 @pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "general"), ("bathroom", "general"),
-                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q")])
+                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q"), ("sanmiguel_leafmask", "bvh4q"), ("sanmiguel_leafmask", "general")])
 def test_baseline_configs_reduced(name, mode, tmp_path):
     """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
     (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
