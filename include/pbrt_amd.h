@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 10
+#define MI_ABI_VERSION 11
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -287,6 +287,15 @@ typedef struct mi_film {     /* Film, core/film.cpp:45-86 */
 
 #define MI_SAMPLER_SOBOL 0
 #define MI_SAMPLER_HALTON 1
+/* ABI v11: the samplers whose values come from ONE PCG32 stream per 16x16 tile (Sampler::Clone(seed = tile index), integrator.cpp:246-248): a sample's
+ * values depend on how many numbers the tile's earlier samples drew, so the library walks each tile's pixels and samples in the reference's order, one
+ * path per tile in flight ("tile-serial" rounds: correct, slow -- DESIGN.md s.7).  RANDOM: samplers/random.cpp (every value from the stream).
+ * STRATIFIED / ZEROTWO: PixelSamplers (core/sampler.cpp:100-135) -- the first pixel_sampler_dims 1D and 2D dimensions of a pixel's samples are
+ * generated by StartPixel (samplers/stratified.cpp:43-70, zerotwosequence.cpp:53-68), later ones come from the stream. */
+#define MI_SAMPLER_RANDOM 2
+#define MI_SAMPLER_STRATIFIED 3
+#define MI_SAMPLER_ZEROTWO 4
+#define MI_SAMPLER_IS_TILE_SERIAL(s) ((s) >= MI_SAMPLER_RANDOM)
 
 typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t max_depth;          /* path.cpp:193, default 5 */
@@ -307,6 +316,10 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t halton_sample_stride;       /* baseScales[0] * baseScales[1] */
     int32_t halton_mult_inverse[2];
     int32_t halton_sample_at_center;    /* "samplepixelcenter" */
+    /* tile-serial samplers (ABI v11).  spp: RANDOM "pixelsamples" (default 4); STRATIFIED xsamples * ysamples; ZEROTWO RoundUpPow2("pixelsamples") */
+    int32_t pixel_sampler_dims;         /* "dimensions" (nSampledDimensions, default 4); 0 for RANDOM */
+    int32_t strat_samples[2];           /* "xsamples", "ysamples" (default 4 x 4) */
+    int32_t strat_jitter;               /* "jitter" (default true) */
 } mi_integrator;
 
 /* ---------------------------------------------------------------- the scene --------- */

@@ -697,6 +697,30 @@ static uint64_t multiplicativeInverse(int64_t a, int64_t n) {   // halton.cpp:49
     int64_t r = x - (x / n) * n;   // Mod(x, n) core/pbrt.h:310-313
     return (uint64_t)(r < 0 ? r + n : r);
 }
+TileSerialSampler::TileSerialSampler(Kind k, const ParamSet &ps, const int smin[2], const int smax[2]) {
+    kind = k;
+    for (int i = 0; i < 2; ++i) { sampleMin[i] = smin[i]; sampleMax[i] = smax[i]; }
+    if (k == Random) {   // CreateRandomSampler random.cpp:75-78
+        samplesPerPixel = ps.FindOneInt("pixelsamples", 4);
+        nSampledDimensions = 0;
+    } else if (k == Stratified) {   // CreateStratifiedSampler stratified.cpp:78-86
+        jitterSamples = ps.FindOneBool("jitter", true);
+        xPixelSamples = ps.FindOneInt("xsamples", 4);
+        yPixelSamples = ps.FindOneInt("ysamples", 4);
+        nSampledDimensions = ps.FindOneInt("dimensions", 4);
+        if (PbrtOptions.quickRender) xPixelSamples = yPixelSamples = 1;
+        samplesPerPixel = (int64_t)xPixelSamples * yPixelSamples;
+    } else {   // CreateZeroTwoSequenceSampler zerotwosequence.cpp:76-81, constructor :43-51
+        int nsamp = ps.FindOneInt("pixelsamples", 16);
+        nSampledDimensions = ps.FindOneInt("dimensions", 4);
+        if (PbrtOptions.quickRender) nsamp = 1;
+        samplesPerPixel = nsamp <= 1 ? 1 : (int64_t)RoundUpPow2((int32_t)nsamp);
+        if (!IsPowerOf2(nsamp))
+            Warning("Pixel samples being rounded up to power of 2 (from %d to %lld).", nsamp, (long long)samplesPerPixel);
+    }
+    if (samplesPerPixel < 1 || nSampledDimensions < 0) Error("Sampler: pixel samples / dimensions out of range");
+}
+
 HaltonSampler::HaltonSampler(int64_t spp, const int smin[2], const int smax[2], bool atCenter) {
     kind = Halton;
     samplesPerPixel = spp;
@@ -766,9 +790,14 @@ void pbrtWorldEnd() {
             if (renderOptions->SamplerName == "halton") {
                 bool atCenter = renderOptions->SamplerParams.FindOneBool("samplepixelcenter", false);
                 sampler = std::make_shared<HaltonSampler>(nsamp, smin, smax, atCenter);
+            } else if (renderOptions->SamplerName == "random" || renderOptions->SamplerName == "stratified" || renderOptions->SamplerName == "02sequence" ||
+                       renderOptions->SamplerName == "lowdiscrepancy") {
+                // one PCG32 stream per tile: the device walks the tiles' samples in the reference's order (ABI v11, "tile-serial" -- the reference's image, slowly)
+                Sampler::Kind k = renderOptions->SamplerName == "random" ? Sampler::Random : (renderOptions->SamplerName == "stratified" ? Sampler::Stratified : Sampler::ZeroTwo);
+                sampler = std::make_shared<TileSerialSampler>(k, renderOptions->SamplerParams, smin, smax);
             } else {
-                if (renderOptions->SamplerName != "sobol")
-                    Warning("Sampler \"%s\" is not implemented on the GPU path (\"sobol\" and \"halton\" are); rendering with \"sobol\" at %d spp.",
+                if (renderOptions->SamplerName != "sobol")   // "maxmindist" (its generator matrices are a table of the reference's) and unknown names
+                    Warning("Sampler \"%s\" is not implemented on the GPU path (\"sobol\", \"halton\", \"random\", \"stratified\" and \"02sequence\" are); rendering with \"sobol\" at %d spp.",
                             renderOptions->SamplerName.c_str(), nsamp);
                 sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
             }

@@ -345,7 +345,16 @@ std::unique_ptr<FlatScene> WavefrontPathIntegrator::Flatten(const Scene &scene) 
     d.integrator.max_depth = maxDepth; d.integrator.rr_threshold = rrThreshold;
     d.integrator.spp = (int32_t)sampler->samplesPerPixel;
     d.integrator.sobol_resolution = sampler->resolution; d.integrator.sobol_log2_resolution = sampler->log2Resolution;
-    d.integrator.sampler = sampler->kind == Sampler::Halton ? MI_SAMPLER_HALTON : MI_SAMPLER_SOBOL;
+    switch (sampler->kind) {
+    case Sampler::Halton: d.integrator.sampler = MI_SAMPLER_HALTON; break;
+    case Sampler::Random: d.integrator.sampler = MI_SAMPLER_RANDOM; break;
+    case Sampler::Stratified: d.integrator.sampler = MI_SAMPLER_STRATIFIED; break;
+    case Sampler::ZeroTwo: d.integrator.sampler = MI_SAMPLER_ZEROTWO; break;
+    default: d.integrator.sampler = MI_SAMPLER_SOBOL;
+    }
+    d.integrator.pixel_sampler_dims = sampler->nSampledDimensions;
+    d.integrator.strat_samples[0] = sampler->xPixelSamples; d.integrator.strat_samples[1] = sampler->yPixelSamples;
+    d.integrator.strat_jitter = sampler->jitterSamples ? 1 : 0;
     for (int i = 0; i < 2; ++i) {
         d.integrator.halton_base_scales[i] = sampler->baseScales[i]; d.integrator.halton_base_exponents[i] = sampler->baseExponents[i];
         d.integrator.halton_mult_inverse[i] = sampler->multInverse[i];

@@ -192,10 +192,15 @@ struct PerspectiveCamera {
 };
 PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &ps, const Transform &cam2world, Film *film);
 
-// ---- Samplers: the two GlobalSamplers the GPU path implements.  Only the constructor results are kept (the per-sample
-// work is the device's): SobolSampler (samplers/sobol.h:48-69) and HaltonSampler (samplers/halton.{h,cpp}, pbrt's default).
+// ---- Samplers.  Only the constructor results are kept (the per-sample work is the device's): the GlobalSamplers SobolSampler
+// (samplers/sobol.h:48-69) and HaltonSampler (samplers/halton.{h,cpp}, pbrt's default), and -- ABI v11 -- the samplers that draw from one
+// PCG32 stream per tile: RandomSampler (samplers/random.cpp), StratifiedSampler (samplers/stratified.cpp), ZeroTwoSequenceSampler
+// (samplers/zerotwosequence.cpp; "02sequence" / "lowdiscrepancy")
 struct Sampler {
-    enum Kind { Sobol, Halton } kind = Sobol;
+    enum Kind { Sobol, Halton, Random, Stratified, ZeroTwo } kind = Sobol;
+    // the tile-serial ones
+    int nSampledDimensions = 0, xPixelSamples = 1, yPixelSamples = 1;
+    bool jitterSamples = true;
     int64_t samplesPerPixel = 1;
     int sampleMin[2] = {0, 0}, sampleMax[2] = {0, 0};
     // Sobol
@@ -209,6 +214,9 @@ struct SobolSampler : Sampler {
 };
 struct HaltonSampler : Sampler {
     HaltonSampler(int64_t spp, const int sampleMin[2], const int sampleMax[2], bool sampleAtPixelCenter);
+};
+struct TileSerialSampler : Sampler {   // Random / Stratified / ZeroTwo: what their Create* functions read (random.cpp:75-78, stratified.cpp:78-86, zerotwosequence.cpp:76-81)
+    TileSerialSampler(Kind kind, const ParamSet &ps, const int sampleMin[2], const int sampleMax[2]);
 };
 
 // ---- Scene (core/scene.h:50-80)

@@ -144,7 +144,31 @@ def sss_scene(name):
 SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst"]
 
 
+# ---- the samplers that draw from one PCG32 stream per tile (ABI v11): RandomSampler, StratifiedSampler, ZeroTwoSequenceSampler
+def sampler_scene(name):
+    def with_sampler(text, line):
+        out, n = re.subn(r'Sampler "[a-z0-9]+"[^\n]*', line, text, count=1)
+        assert n == 1
+        return out
+    if name == "sampler_random":       # every value from the tile's stream; 72 x 48: partial tiles on the right
+        return with_sampler(scene("infinite"), 'Sampler "random" "integer pixelsamples" [3]')
+    if name == "sampler_stratified":   # 2 x 3 strata, jittered, 4 precomputed dimensions; dof: the lens sample is 2D dimension 1
+        return with_sampler(scene("dof"), 'Sampler "stratified" "integer xsamples" [2] "integer ysamples" [3]')
+    if name == "sampler_strat_d1":     # no jitter, ONE precomputed dimension: the lens sample and everything after it come from the stream (Point2f(a(), b()) order)
+        return with_sampler(scene("spot"), 'Sampler "stratified" "integer xsamples" [2] "integer ysamples" [2] "bool jitter" ["false"] "integer dimensions" [1]')
+    if name == "sampler_02sequence":   # crop window + pixel bounds: StartPixel runs for the pixels outside the bounds too (integrator.cpp:262-273)
+        return with_sampler(scene("crop"), 'Sampler "02sequence" "integer pixelsamples" [4]')
+    if name == "sampler_lowdisc_vol":  # "lowdiscrepancy" = 02sequence, 3 -> 4 samples; volpath in fog: data-dependent numbers of draws per path
+        return with_sampler(scene("vol_fog"), 'Sampler "lowdiscrepancy" "integer pixelsamples" [3] "integer dimensions" [2]')
+    raise KeyError(name)
+
+
+SAMPLER_NAMES = ["sampler_random", "sampler_stratified", "sampler_strat_d1", "sampler_02sequence", "sampler_lowdisc_vol"]
+
+
 def scene(name):
+    if name.startswith("sampler_"):
+        return sampler_scene(name)
     if name.startswith("tex_"):
         return tex_scene(name)
     if name.startswith("vol_"):

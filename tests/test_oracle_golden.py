@@ -179,6 +179,22 @@ def test_oracle_edge_cases_match_reference(built, name):
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), float(np.abs(img - ref).max())   # bit for bit
 
 
+@pytest.mark.parametrize("name", edge_scenes.SAMPLER_NAMES)
+def test_oracle_tile_serial_samplers_match_reference(built, name):
+    """Sampler "random" / "stratified" / "02sequence" ("lowdiscrepancy") -- ABI v11.  Their values come from ONE PCG32 stream per 16 x 16 tile
+    (sampler->Clone(seed = tile index), integrator.cpp:246-248; core/sampler.cpp:100-135, samplers/{random,stratified,zerotwosequence}.cpp,
+    core/rng.h): what a sample receives depends on how many numbers every earlier sample of its tile drew.  The oracle walks the tiles in the
+    reference's order; the renders (partial tiles, depth of field, crop window + pixel bounds, volpath in fog, one precomputed dimension only,
+    no jitter, 3 -> 4 samples) equal pbrt_ref's bit for bit -- including the order in which PixelSampler::Get2D's `Point2f(rng.UniformFloat(),
+    rng.UniformFloat())` draws its two numbers in a g++ build (second argument first)."""
+    sc = pa.Scene(text=edge_scenes.scene(name))
+    rgbw, _, _ = ol.render(sc, nthreads=4)
+    img = sc.film_image(rgbw)
+    ref = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    assert img.shape == ref.shape
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), float(np.abs(img - ref).max())
+
+
 @pytest.mark.parametrize("name", edge_scenes.VOL_NAMES)
 def test_oracle_volpath_matches_reference(built, name):
     """SURVEY.md s.8 row f4, Integrator "volpath" (integrators/volpath.cpp) with participating media: a chromatic homogeneous medium
