@@ -66,7 +66,10 @@
 #include "reflection.h"
 #include "sampler.h"
 #include "samplers/halton.h"
+#include "samplers/random.h"
 #include "samplers/sobol.h"
+#include "samplers/stratified.h"
+#include "samplers/zerotwosequence.h"
 #include "scene.h"
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
@@ -756,8 +759,18 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
         }
         d.integrator.halton_sample_stride = hs->sampleStride;
         d.integrator.halton_sample_at_center = hs->sampleAtPixelCenter ? 1 : 0;
+    } else if (dynamic_cast<RandomSampler *>(&sampler)) {   // ABI v11: the samplers with one PCG32 stream per tile (the library walks each tile's samples in this loop's order)
+        d.integrator.sampler = MI_SAMPLER_RANDOM;
+    } else if (auto st = dynamic_cast<StratifiedSampler *>(&sampler)) {
+        d.integrator.sampler = MI_SAMPLER_STRATIFIED;
+        d.integrator.pixel_sampler_dims = (int32_t)st->samples1D.size();
+        d.integrator.strat_samples[0] = st->xPixelSamples; d.integrator.strat_samples[1] = st->yPixelSamples;
+        d.integrator.strat_jitter = st->jitterSamples ? 1 : 0;
+    } else if (auto zt = dynamic_cast<ZeroTwoSequenceSampler *>(&sampler)) {
+        d.integrator.sampler = MI_SAMPLER_ZEROTWO;
+        d.integrator.pixel_sampler_dims = (int32_t)zt->samples1D.size();
     } else
-        return fail("sampler is neither sobol nor halton");
+        return fail("sampler is none of sobol, halton, random, stratified, 02sequence");
     return fs;
 }
 }  // namespace

@@ -121,6 +121,7 @@ struct PassInfo {
     uint32_t s0, ns;           // sample numbers [s0, s0+ns)
     const int32_t *list_xy;    // explicit (pixel, sample) list mode (mi_li / mi_camera_rays), else null
     const int32_t *list_s;
+    uint32_t serial = 0, w = 0;   // tile-serial round (MI_SAMPLER_RANDOM / STRATIFIED / ZEROTWO): path i = sample s0 of pixel w (0..255, row major) of owned tile i; npix = owned tiles, ns = 1
 };
 
 #define MISS_PRIM 0xffffffffu
@@ -245,7 +246,12 @@ PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
 }
 PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy, Float *lens0, Float *lens1) {
     Float u[5];
-    SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
+    if (Sampler::Pix(sc)) {   // Sampler::GetCameraSample core/sampler.cpp:44-50: pFilm = Get2D(), time = Get1D(), pLens = Get2D()
+        smp.PixGet2D(sc, &u[0], &u[1]);
+        u[2] = smp.PixGet1D(sc);
+        smp.PixGet2D(sc, &u[3], &u[4]);
+    } else
+        SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
     Float u0 = u[0], u1 = u[1];
     if (sc.sampler_type == MI_SAMPLER_SOBOL) {
         // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57); Halton's are in-pixel already
@@ -253,7 +259,7 @@ PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Fl
         u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
     }
     Float l0 = u[3], l1 = u[4];
-    smp.dimension = 5;
+    if (!Sampler::Pix(sc)) smp.dimension = 5;
     Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;   // static scene: the time sample (dim 2) is never read
     const mi_camera &cam = sc.camera;
     V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
@@ -284,6 +290,94 @@ PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Fl
     *o = wo_; *d = wd; *tMax = tm; *pfx = pFilmX; *pfy = pFilmY; *lens0 = l0; *lens1 = l1;
 }
 
+// ---- the tile-serial samplers (ABI v11).  `sampler->Clone(seed = tile.y * nTiles.x + tile.x)` gives every 16x16 tile ONE PCG32 stream
+// (integrator.cpp:246-248, random.cpp:54-58, stratified.cpp:72-76, zerotwosequence.cpp:70-74); k_pix_seed starts the streams of a frame,
+// k_pix_start_pixel is <Sampler>::StartPixel for pixel w of every owned tile -- one lane per tile, the tile's numbers drawn one after the other.
+__global__ void __launch_bounds__(PT_BLOCK) k_pix_seed(DevScene sc, const uint32_t *tiles, uint32_t nTiles) {
+    for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < nTiles; i += gridDim.x * PT_BLOCK) {
+        const uint32_t tile = tiles[i];
+        unsigned long long state = 0u, inc = ((unsigned long long)(long long)(int)tile << 1u) | 1u;   // RNG::SetSequence rng.h:128-134
+        Pcg32Next(state, inc);
+        state += 0x853c49e6748fea9bULL;
+        Pcg32Next(state, inc);
+        sc.pix_rng[2 * (size_t)tile] = state; sc.pix_rng[2 * (size_t)tile + 1] = inc;
+    }
+}
+template <int DIM> PT_DEV void PixShuffle(float *samp, int count, unsigned long long &state, unsigned long long inc) {   // Shuffle core/sampling.h:150-157
+    for (int i = 0; i < count; ++i) {
+        int other = i + (int)Pcg32Bounded(state, inc, (uint32_t)(count - i));
+        for (int j = 0; j < DIM; ++j) { float t = samp[DIM * i + j]; samp[DIM * i + j] = samp[DIM * other + j]; samp[DIM * other + j] = t; }
+    }
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_pix_start_pixel(DevScene sc, const uint32_t *tiles, uint32_t nTiles, uint32_t nTilesX, uint32_t w) {
+    for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < nTiles; i += gridDim.x * PT_BLOCK) {
+        const uint32_t tile = tiles[i];
+        const int x = sc.sample_min[0] + (int)(tile % nTilesX) * 16 + (int)(w & 15), y = sc.sample_min[1] + (int)(tile / nTilesX) * 16 + (int)(w >> 4);
+        if (x >= sc.sample_max[0] || y >= sc.sample_max[1]) continue;   // not a pixel of the (clipped) tile; pixels outside pixelBounds DO start (integrator.cpp:262-273)
+        unsigned long long state = sc.pix_rng[2 * (size_t)tile];
+        const unsigned long long inc = sc.pix_rng[2 * (size_t)tile + 1];
+        const int nd = sc.pix_nd, spp = sc.spp;
+        float *s1 = sc.pix_s1 + (size_t)tile * nd * spp, *s2 = sc.pix_s2 + 2 * (size_t)tile * nd * spp;
+        if (sc.sampler_type == MI_SAMPLER_STRATIFIED) {   // StratifiedSampler::StartPixel stratified.cpp:43-56
+            const int nx = sc.strat_nx, ny = sc.strat_ny, n = nx * ny;
+            const bool jitter = sc.strat_jitter != 0;
+            for (int d = 0; d < nd; ++d) {
+                float *p = s1 + (size_t)d * spp;
+                const Float invN = (Float)1 / n;   // StratifiedSample1D core/sampling.cpp:42-48
+                for (int k = 0; k < n; ++k) {
+                    Float delta = jitter ? Pcg32Float(state, inc) : 0.5f;
+                    Float v = (k + delta) * invN;
+                    p[k] = v < PT_ONE_MINUS_EPS ? v : PT_ONE_MINUS_EPS;
+                }
+                PixShuffle<1>(p, n, state, inc);
+            }
+            for (int d = 0; d < nd; ++d) {
+                float *p = s2 + 2 * (size_t)d * spp, *q = p;
+                const Float dx = (Float)1 / nx, dy = (Float)1 / ny;   // StratifiedSample2D core/sampling.cpp:50-60
+                for (int yy = 0; yy < ny; ++yy)
+                    for (int xx = 0; xx < nx; ++xx) {
+                        Float jx = jitter ? Pcg32Float(state, inc) : 0.5f;
+                        Float jy = jitter ? Pcg32Float(state, inc) : 0.5f;
+                        Float vx = (xx + jx) * dx, vy = (yy + jy) * dy;
+                        q[0] = vx < PT_ONE_MINUS_EPS ? vx : PT_ONE_MINUS_EPS;
+                        q[1] = vy < PT_ONE_MINUS_EPS ? vy : PT_ONE_MINUS_EPS;
+                        q += 2;
+                    }
+                PixShuffle<2>(p, n, state, inc);
+            }
+        } else if (sc.sampler_type == MI_SAMPLER_ZEROTWO) {   // ZeroTwoSequenceSampler::StartPixel zerotwosequence.cpp:53-60: VanDerCorput / Sobol2D (lowdiscrepancy.h:144-226), one value per pixel sample
+            for (int d = 0; d < nd; ++d) {
+                float *p = s1 + (size_t)d * spp;
+                uint32_t v = Pcg32Next(state, inc);   // scramble; GrayCodeSample (lowdiscrepancy.h:113-126) over CVanDerCorput[k] = 1 << (31 - k)
+                for (uint32_t k = 0; k < (uint32_t)spp; ++k) {
+                    Float f = v * (Float)0x1p-32;
+                    p[k] = f < PT_ONE_MINUS_EPS ? f : PT_ONE_MINUS_EPS;
+                    v ^= 0x80000000u >> __builtin_ctz(k + 1);
+                }
+                for (int k = 0; k < spp; ++k) PixShuffle<1>(p + k, 1, state, inc);   // Shuffle(samples + i, 1, 1, rng): one number each
+                PixShuffle<1>(p, spp, state, inc);
+            }
+            for (int d = 0; d < nd; ++d) {
+                float *p = s2 + 2 * (size_t)d * spp;
+                uint32_t v0 = Pcg32Next(state, inc), v1 = Pcg32Next(state, inc);
+                for (uint32_t k = 0; k < (uint32_t)spp; ++k) {
+                    Float f0 = v0 * (Float)0x1p-32, f1 = v1 * (Float)0x1p-32;
+                    p[2 * k] = f0 < PT_ONE_MINUS_EPS ? f0 : PT_ONE_MINUS_EPS;
+                    p[2 * k + 1] = f1 < PT_ONE_MINUS_EPS ? f1 : PT_ONE_MINUS_EPS;
+                    const int c = __builtin_ctz(k + 1);
+                    v0 ^= 0x80000000u >> c;
+                    uint32_t c1 = 0x80000000u;   // CSobol[1][c] (lowdiscrepancy.h:215-220): column k = column k-1 ^ (column k-1 >> 1) from 0x80000000
+                    for (int j = 0; j < c; ++j) c1 ^= c1 >> 1;
+                    v1 ^= c1;
+                }
+                for (int k = 0; k < spp; ++k) PixShuffle<2>(p + 2 * k, 1, state, inc);
+                PixShuffle<2>(p, spp, state, inc);
+            }
+        }   // RandomSampler::StartPixel: nothing to draw without requested sample arrays (random.cpp:63-73)
+        sc.pix_rng[2 * (size_t)tile] = state;
+    }
+}
+
 // TEX: the scene has textured materials -- keep the lens sample with the path
 template <bool TEX>
 __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, PassInfo pass, uint32_t qout) {
@@ -293,10 +387,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
         uint32_t i = it.item();
         bool active = i < n;
         int x = 0, y = 0;
-        uint32_t s = 0;
+        uint32_t s = 0, tileId = 0;
         if (active) {
             if (pass.list_xy) { x = pass.list_xy[2 * i]; y = pass.list_xy[2 * i + 1]; s = (uint32_t)pass.list_s[i]; }
-            else {
+            else if (pass.serial) {
+                tileId = pass.tiles[i];
+                s = pass.s0;
+                x = sc.sample_min[0] + (int)(tileId % pass.n_tiles_x) * 16 + (int)(pass.w & 15);
+                y = sc.sample_min[1] + (int)(tileId / pass.n_tiles_x) * 16 + (int)(pass.w >> 4);
+                active = x < sc.sample_max[0] && y < sc.sample_max[1] && x >= sc.pixel_min[0] && x < sc.pixel_max[0] &&
+                         y >= sc.pixel_min[1] && y < sc.pixel_max[1];
+            } else {
                 uint32_t p = i % pass.npix;
                 s = pass.s0 + i / pass.npix;
                 uint32_t k = pass.pix0 + p, tile = pass.tiles[k >> 8], w = k & 255;
@@ -313,7 +414,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
         }
         if (active) {
             Sampler smp;
-            smp.Start(sc, x, y, s);
+            if (pass.serial) smp.PixStart(tileId, s, x, y);
+            else smp.Start(sc, x, y, s);
             V3 o, d;
             Float tMax, pfx, pfy, lens0, lens1;
             GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy, &lens0, &lens1);
@@ -900,7 +1002,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #endif
 // INST: two-level scenes -- the hit primitive may have been reached through an instance (PathRec::pad0): the interaction is
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
-template <bool ENV, bool HALTON, bool TEX, bool INST = false>
+// SMP: 0 Sobol' / 1 Halton (the vertex's dimensions drawn in one batch) / 2 the tile-serial samplers (drawn call by call, in the reference's order: the
+// values come from the tile's stream)
+template <bool ENV, int SMP, bool TEX, bool INST = false>
 __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
@@ -946,7 +1050,11 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
             smp.px = smp.py = 0;   // only dimensions 0/1 (camera sample) look at the pixel
             // the (at most) 8 sample dimensions this vertex can consume: light pick, uLight, uScattering, BSDF, RR
             Float us[8];
-            if (HALTON) {
+            constexpr bool PIX = SMP == 2;
+            if (PIX) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) us[k] = 0;
+            } else if (SMP == 1) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) us[k] = HaltonSampleDimension(sc, smp.index, smp.dimension + k);
             } else
@@ -1056,7 +1164,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             funcInt = sc.sp_func_int[vox];
                         }
                         PROBE(5)   // BSDF ctor + NumComponents + voxel lookup
-                        Float ul = us[0];
+                        Float ul = PIX ? smp.PixGet1D(sc) : us[0];
                         ubase = 1;
                         // Distribution1D::SampleDiscrete (core/sampling.h:90-100) / FindInterval (core/pbrt.h:398-411): `first` = the number of leading cdf
                         // entries <= u (the cdf is non-decreasing, so the reference's bisection finds exactly that count).  Spatial tables: through the
@@ -1072,7 +1180,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                         Float selPdf = (funcInt > 0) ? funcAt / (funcInt * (int)sc.n_lights) : 0;
                         if (selPdf != 0) {
                             Float uL0, uL1, uS0, uS1;
-                            uL0 = us[1]; uL1 = us[2]; uS0 = us[3]; uS1 = us[4];
+                            if (PIX) { smp.PixGet2D(sc, &uL0, &uL1); smp.PixGet2D(sc, &uS0, &uS1); }
+                            else { uL0 = us[1]; uL1 = us[2]; uS0 = us[3]; uS1 = us[4]; }
                             ubase = 5;
                             // ---- EstimateDirect (core/integrator.cpp:108-215), handleMedia=false, specular=false
                             const DevLight &light = sc.lights[lightNum];
@@ -1132,9 +1241,12 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     V3 wo = -rd, wi;
                     Float pdf, u0, u1;
                     int flags;
-                    u0 = ubase == 0 ? us[0] : (ubase == 1 ? us[1] : us[5]);
-                    u1 = ubase == 0 ? us[1] : (ubase == 1 ? us[2] : us[6]);
-                    ui = ubase + 2;
+                    if (PIX) smp.PixGet2D(sc, &u0, &u1);
+                    else {
+                        u0 = ubase == 0 ? us[0] : (ubase == 1 ? us[1] : us[5]);
+                        u1 = ubase == 0 ? us[1] : (ubase == 1 ? us[2] : us[6]);
+                        ui = ubase + 2;
+                    }
                     RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
                     PROBE(11)   // path Sample_f
                     if (!(f.IsBlack() || pdf == 0.f)) {
@@ -1150,8 +1262,9 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                         RGB rrBeta = beta * etaScale;
                         if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
                             Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
-                            Float urr = ubase == 0 ? us[2] : (ubase == 1 ? us[3] : us[7]);
-                            ++ui;
+                            Float urr;
+                            if (PIX) urr = smp.PixGet1D(sc);
+                            else { urr = ubase == 0 ? us[2] : (ubase == 1 ? us[3] : us[7]); ++ui; }
                             if (urr < q) cont = false;
                             else beta = beta / (1 - q);
                         }
@@ -2113,7 +2226,22 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.sobol_resolution = d->integrator.sobol_resolution; sc.sobol_log2_resolution = d->integrator.sobol_log2_resolution;
     sc.rr_threshold = d->integrator.rr_threshold;
     sc.sampler_type = d->integrator.sampler;
-    if (sc.sampler_type != MI_SAMPLER_SOBOL && sc.sampler_type != MI_SAMPLER_HALTON) return fail("mi_scene_upload: unknown sampler");
+    if (sc.sampler_type < MI_SAMPLER_SOBOL || sc.sampler_type > MI_SAMPLER_ZEROTWO) return fail("mi_scene_upload: unknown sampler");
+    sc.pix_rng = nullptr; sc.pix_s1 = sc.pix_s2 = nullptr; sc.pix_nd = 0; sc.strat_nx = sc.strat_ny = 1; sc.strat_jitter = 0;
+    if (MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type)) {   // one PCG32 stream per tile + the current pixel's precomputed dimensions
+        const mi_integrator &in = d->integrator;
+        sc.pix_nd = sc.sampler_type == MI_SAMPLER_RANDOM ? 0 : in.pixel_sampler_dims;
+        sc.strat_nx = in.strat_samples[0]; sc.strat_ny = in.strat_samples[1]; sc.strat_jitter = in.strat_jitter;
+        if (sc.pix_nd < 0 || sc.pix_nd > 255 || sc.spp < 1) return fail("mi_scene_upload: pixel sampler dimensions out of range");
+        if (sc.sampler_type == MI_SAMPLER_STRATIFIED && (sc.strat_nx < 1 || sc.strat_ny < 1 || (int64_t)sc.strat_nx * sc.strat_ny != sc.spp))
+            return fail("mi_scene_upload: stratified sampler: spp != xsamples * ysamples");
+        if (sc.sampler_type == MI_SAMPLER_ZEROTWO && (sc.spp & (sc.spp - 1))) return fail("mi_scene_upload: 02sequence sampler: spp is not a power of two");
+        const size_t nTiles = (size_t)((d->film.sample_max[0] - d->film.sample_min[0] + 15) / 16) * (size_t)((d->film.sample_max[1] - d->film.sample_min[1] + 15) / 16);
+        { DevBuf &b = next(); if (b.alloc(std::max<size_t>(1, nTiles) * 2 * sizeof(unsigned long long))) return -1; sc.pix_rng = b.as<unsigned long long>(); }
+        const size_t nv = std::max<size_t>(1, nTiles * (size_t)sc.pix_nd * (size_t)sc.spp);
+        { DevBuf &b = next(); if (b.alloc(nv * sizeof(float))) return -1; sc.pix_s1 = b.as<float>(); }
+        { DevBuf &b = next(); if (b.alloc(2 * nv * sizeof(float))) return -1; sc.pix_s2 = b.as<float>(); }
+    }
     if (sc.sampler_type == MI_SAMPLER_HALTON) {
         for (int i = 0; i < 2; ++i) {
             sc.h_base_scales[i] = d->integrator.halton_base_scales[i]; sc.h_base_exps[i] = d->integrator.halton_base_exponents[i];
@@ -2472,7 +2600,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         }
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
-            const bool halton = sc.sampler_type == MI_SAMPLER_HALTON;
+            const bool halton = sc.sampler_type == MI_SAMPLER_HALTON, pixSmp = MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
             if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
                 const dim3 gw(c->gridShade);
 #define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
@@ -2485,19 +2613,18 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                     else { if (umat) LAUNCH_VOL(false, false, true, grid); else LAUNCH_VOL(false, false, false, grid); }
                 }
 #undef LAUNCH_VOL
-            } else if (c->hasInst) {   // two-level scenes: the general instance + interactions carried back from the object's space
-                if (halton) hipLaunchKernelGGL((k_shade<true, true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-            } else if (c->hasTex) {   // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
-                if (halton) hipLaunchKernelGGL((k_shade<true, true, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<true, false, true>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-            } else if (c->hasEnvMap || c->hasSpheres) {
-                if (halton) hipLaunchKernelGGL((k_shade<true, true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<true, false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-            } else {
-                if (halton) hipLaunchKernelGGL((k_shade<false, true, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
-                else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(c->gridShade), block, 0, st, sc, ps, qout);
             }
+#define LAUNCH_SHADE(ENV, TEX, ...)                                                                                                              \
+    do {                                                                                                                                         \
+        if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                   \
+        else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);               \
+        else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                           \
+    } while (0)
+            else if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
+            else if (c->hasTex) LAUNCH_SHADE(true, true);          // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
+            else if (c->hasEnvMap || c->hasSpheres) LAUNCH_SHADE(true, false);
+            else LAUNCH_SHADE(false, false);
+#undef LAUNCH_SHADE
         }
         toc(c);
         if (overlap) {
@@ -2623,6 +2750,32 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
         c->tilesRank = rank; c->tilesWorld = world;
     }
     if (c->tilesCount == 0) return 0;
+    if (MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type)) {
+        // Tile-serial rounds.  These samplers give every tile ONE PCG32 stream, and what a sample receives depends on how many numbers all earlier
+        // samples of its tile drew (path lengths, Russian roulette, specular flags ...): the reference's image needs each tile's pixels and samples in the
+        // reference's order (integrator.cpp:259-325), one path after the other.  So a pass here is ONE sample of ONE pixel position of every owned tile
+        // (tiles are independent: that is the parallelism there is) and a frame is 256 x spp passes -- correct and slow; Sobol' / Halton are the
+        // samplers to render with.
+        if (s0 != 0 || s1 != sc.spp) return fail("mi_render: the random / stratified / 02sequence samplers render whole frames only (spp_begin = 0, spp_end = spp)");
+        if (ensure_state(c, (uint32_t)std::max<uint64_t>(c->tilesCount, 256 * 64))) return -1;
+        const dim3 grid((unsigned)std::min<size_t>((c->tilesCount + PT_BLOCK - 1) / PT_BLOCK, (size_t)c->gridBlocks)), block(PT_BLOCK);
+        hipLaunchKernelGGL(k_pix_seed, grid, block, 0, c->stream, sc, c->tiles.as<uint32_t>(), (uint32_t)c->tilesCount);
+        for (uint32_t w = 0; w < 256; ++w) {
+            if ((int)(w & 15) >= ex || (int)(w >> 4) >= ey) continue;   // no tile has this pixel
+            hipLaunchKernelGGL(k_pix_start_pixel, grid, block, 0, c->stream, sc, c->tiles.as<uint32_t>(), (uint32_t)c->tilesCount, (uint32_t)nTx, w);
+            for (int s = 0; s < sc.spp; ++s) {
+                PassInfo pass;
+                pass.tiles = c->tiles.as<uint32_t>();
+                pass.n_tiles_x = (uint32_t)nTx;
+                pass.pix0 = 0; pass.npix = (uint32_t)c->tilesCount;
+                pass.s0 = (uint32_t)s; pass.ns = 1;
+                pass.list_xy = nullptr; pass.list_s = nullptr;
+                pass.serial = 1; pass.w = w;
+                if (run_pass(c, pass, rp->count_work != 0, true)) return -1;
+            }
+        }
+        return 0;
+    }
     uint64_t npixOwned = (uint64_t)c->tilesCount * 256;
     // Paths in flight per pass.  Every launch of the wavefront pipeline ends with a tail (the longest rays) and starts with
     // fixed costs, so the pool is made as large as the frame allows -- up to 2^27 paths (37 GB of path state) and at most
@@ -3361,6 +3514,7 @@ int mi_sobol(mi_ctx *c, int px, int py, int n_samples, int n_dims, float *out, u
 }
 static int list_pass(mi_ctx *c, const int32_t *pixels_xy, const int32_t *sample_num, int64_t n, int64_t off, uint32_t cnt, bool trace,
                      DevBuf &dxy, DevBuf &ds, bool keepLens = false) {
+    if (MI_SAMPLER_IS_TILE_SERIAL(c->sc.sampler_type)) return fail("per-sample queries (mi_li / mi_camera_rays / mi_camera_differentials) need a GlobalSampler: with random / stratified / 02sequence a sample's values depend on its tile's earlier samples");
     (void)n;
     if (upload(c, dxy, pixels_xy + 2 * off, (size_t)cnt * 8) || upload(c, ds, sample_num + off, (size_t)cnt * 4)) return -1;
     PassInfo pass;

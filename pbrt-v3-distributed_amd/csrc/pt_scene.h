@@ -102,7 +102,33 @@ struct DevScene {
     const uint16_t *h_perms;              // digit permutations of all 1000 prime bases, concatenated
     const uint4 *h_info;                  // per dimension: {prime, offset into h_perms, magic lo, magic hi}
     float rr_threshold;
+    // the tile-serial samplers (ABI v11: MI_SAMPLER_RANDOM / STRATIFIED / ZEROTWO): per 16x16 tile (global tile index) its PCG32 stream and the
+    // current pixel's precomputed dimensions (PixelSampler::samples1D / samples2D, core/sampler.h:118-121)
+    unsigned long long *pix_rng;          // [2 * tile]: state, inc
+    float *pix_s1;                        // [(tile * pix_nd + d) * spp + s]
+    float *pix_s2;                        // [2 * ((tile * pix_nd + d) * spp + s)]
+    int32_t pix_nd, strat_nx, strat_ny, strat_jitter;
 };
+
+// ------------------------------------------------------------------ PCG32 (RNG core/rng.h:64-144)
+PT_DEV uint32_t Pcg32Next(unsigned long long &state, unsigned long long inc) {
+    unsigned long long oldstate = state;
+    state = oldstate * 0x5851f42d4c957f2dULL + inc;
+    uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+PT_DEV uint32_t Pcg32Bounded(unsigned long long &state, unsigned long long inc, uint32_t b) {   // UniformUInt32(b) rng.h:72-78
+    uint32_t threshold = (~b + 1u) % b;
+    while (true) {
+        uint32_t r = Pcg32Next(state, inc);
+        if (r >= threshold) return r % b;
+    }
+}
+PT_DEV Float Pcg32Float(unsigned long long &state, unsigned long long inc) {   // UniformFloat rng.h:83-90
+    Float v = (Float)Pcg32Next(state, inc) * 0x1p-32f;
+    return v < PT_ONE_MINUS_EPS ? v : PT_ONE_MINUS_EPS;
+}
 
 // ------------------------------------------------------------------ Sobol' (integer, bit exact)
 #ifndef PBRT_AMD_SOBOL_NDIM
@@ -271,8 +297,42 @@ struct Sampler {   // GlobalSampler state per path (core/sampler.cpp:136-195) ov
         }
         return s;
     }
-    PT_DEV Float Get1D(const DevScene &sc) { return SampleDimension(sc, dimension++); }
+    // The tile-serial samplers (sc.sampler_type >= MI_SAMPLER_RANDOM): index = tile | sample << 32, dimension = current1DDimension | current2DDimension << 8.
+    // ONE path per tile is in flight (mi_render's tile-serial rounds), so the path's own lane is the only one touching the tile's stream.
+    PT_DEV static bool Pix(const DevScene &sc) { return sc.sampler_type >= MI_SAMPLER_RANDOM; }
+    PT_DEV void PixStart(uint32_t tile, uint32_t sampleNum, int x, int y) { index = (uint64_t)tile | ((uint64_t)sampleNum << 32); dimension = 0; px = x; py = y; }
+    PT_DEV Float PixGet1D(const DevScene &sc) {   // PixelSampler::Get1D core/sampler.cpp:118-125, RandomSampler::Get1D random.cpp:42-46
+        const uint32_t tile = (uint32_t)index, s = (uint32_t)(index >> 32);
+        const int c1 = dimension & 0xff;
+        if (c1 < sc.pix_nd) { dimension += 1; return sc.pix_s1[((size_t)tile * sc.pix_nd + c1) * sc.spp + s]; }
+        unsigned long long st = sc.pix_rng[2 * (size_t)tile];
+        Float v = Pcg32Float(st, sc.pix_rng[2 * (size_t)tile + 1]);
+        sc.pix_rng[2 * (size_t)tile] = st;
+        return v;
+    }
+    PT_DEV void PixGet2D(const DevScene &sc, Float *u0, Float *u1) {   // PixelSampler::Get2D core/sampler.cpp:127-134, RandomSampler::Get2D random.cpp:48-52
+        const uint32_t tile = (uint32_t)index, s = (uint32_t)(index >> 32);
+        const int c2 = (dimension >> 8) & 0xff;
+        if (c2 < sc.pix_nd) {
+            dimension += 0x100;
+            const float *p = sc.pix_s2 + 2 * (((size_t)tile * sc.pix_nd + c2) * sc.spp + s);
+            *u0 = p[0]; *u1 = p[1];
+            return;
+        }
+        unsigned long long st = sc.pix_rng[2 * (size_t)tile];
+        const unsigned long long inc = sc.pix_rng[2 * (size_t)tile + 1];
+        // RandomSampler: `return {a(), b()};` draws x first; PixelSampler: `return Point2f(a(), b());` -- the reference as built here (g++) evaluates the
+        // second argument first (oracle/pt_oracle.cpp Sampler::Get2D, pinned by tests/golden/edge_sampler_*.pfm)
+        if (sc.sampler_type == MI_SAMPLER_RANDOM) { *u0 = Pcg32Float(st, inc); *u1 = Pcg32Float(st, inc); }
+        else { *u1 = Pcg32Float(st, inc); *u0 = Pcg32Float(st, inc); }
+        sc.pix_rng[2 * (size_t)tile] = st;
+    }
+    PT_DEV Float Get1D(const DevScene &sc) {
+        if (Pix(sc)) return PixGet1D(sc);
+        return SampleDimension(sc, dimension++);
+    }
     PT_DEV void Get2D(const DevScene &sc, Float *u0, Float *u1) {
+        if (Pix(sc)) { PixGet2D(sc, u0, u1); return; }
         *u0 = SampleDimension(sc, dimension);
         *u1 = SampleDimension(sc, dimension + 1);
         dimension += 2;

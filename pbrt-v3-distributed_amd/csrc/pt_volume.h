@@ -37,12 +37,14 @@ struct VSampler : Sampler {
     Float pre[PT_VOL_PRE];
     int preBase, preN;
     PT_DEV void Prefetch(const DevScene &sc) {
+        if (Pix(sc)) { preBase = 0; preN = 0; return; }   // tile-serial samplers: nothing can be drawn ahead of a stream
         preBase = dimension;
         const int limit = sc.sampler_type == MI_SAMPLER_HALTON ? 1000 : PBRT_AMD_SOBOL_NDIM;
         preN = limit - dimension < PT_VOL_PRE ? (limit - dimension < 0 ? 0 : limit - dimension) : PT_VOL_PRE;
         if (preN > 0) SamplerBatch<PT_VOL_PRE>(sc, index, dimension, pre);   // (past the tables -- long tracking chains -- nothing is drawn ahead: SampleDimension clamps)
     }
     PT_DEV Float Get1D(const DevScene &sc) {
+        if (Pix(sc)) return PixGet1D(sc);
         const int k = dimension - preBase;
         Float v;
         if (k >= 0 && k < preN) v = pre[k];
@@ -50,7 +52,10 @@ struct VSampler : Sampler {
         ++dimension;
         return v;
     }
-    PT_DEV void Get2D(const DevScene &sc, Float *u0, Float *u1) { *u0 = Get1D(sc); *u1 = Get1D(sc); }
+    PT_DEV void Get2D(const DevScene &sc, Float *u0, Float *u1) {
+        if (Pix(sc)) { PixGet2D(sc, u0, u1); return; }
+        *u0 = Get1D(sc); *u1 = Get1D(sc);
+    }
 };
 
 PT_DEV RGB ExpRGB(const RGB &s) { return RGB(expf_(s.r), expf_(s.g), expf_(s.b)); }   // Exp(Spectrum) core/spectrum.h:253-258

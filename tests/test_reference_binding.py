@@ -56,6 +56,8 @@ def test_reference_scene_through_the_stub_equals_pbrt_ref(name, scene, extra, tm
 import edge_scenes
 
 EDGE_CASES = ["infinite", "infinite_only", "infinite_xf", "envmap", "envmap_power", "spot", "spheres", "dof", "crop", "clamp", "onetri",
+              # ABI v11: the reference's RandomSampler / StratifiedSampler / ZeroTwoSequenceSampler objects handed over (one PCG32 stream per tile)
+              "sampler_random", "sampler_stratified", "sampler_strat_d1", "sampler_02sequence", "sampler_lowdisc_vol",
               "vol_fog", "vol_smoke", "vol_glass", "vol_none",
               # two-level instancing: the reference's TransformedPrimitives and per-object BVHAccels handed over as mi_instance / mi_object
               "instances", "vol_inst", "instances_one",
