@@ -64,10 +64,13 @@ struct __attribute__((aligned(64))) TrState {
     float4 acc[2];   // transmittance so far (rgb)
     uint4 hit[2];    // the segment's closest hit: prim, t bits, instance, -
 };
+struct SssRec;   // pt_volpath.h
 struct PathState {
     PathRec *rec;
     NeeRec *nee;
-    TrState *trs;              // DevVol::tr_queues only, else null
+    TrState *trs;              // DevVol::tr_queues / sss_wave only, else null
+    SssRec *sss;               // DevVol::sss_wave only: parked subsurface paths (BSSRDF at po, probe chain)
+    uint32_t *q_sss;           // ... and the queue of the paths whose chain arrived at its chosen hit (row QC_SSS)
     uint32_t *q_tr[2];         // second shadow / MIS queues (the walk ping-pongs between q_shadow / q_mis and these)
     uint32_t qrow_shadow, qrow_mis;   // counter rows of the queues k_trace<2> / <1> read (QC_SHADOW / QC_MIS unless a walk swapped them)
     uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
@@ -93,7 +96,7 @@ struct PathState {
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_ROWS = 8 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_ROWS = 9 };
 #define QSEG 8u
 #define QC_STRIDE 32u   /* words between counters: one 128-byte line each */
 #define QCI(q, seg) (((uint32_t)(q) * QSEG + (uint32_t)(seg)) * QC_STRIDE)
@@ -1513,6 +1516,7 @@ struct mi_ctx {
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
+    bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSSRDF (BSDF-less interfaces / alpha masks: volTr)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -1739,7 +1743,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
     // row f4: Integrator "volpath" and materials with a BSSRDF are shaded by k_shade_vol (pt_volpath.h)
     c->volKernel = d->integrator_type == MI_INTEGRATOR_VOLPATH || d->material_bssrdf != nullptr;
-    c->volWave = c->volTr = false;
+    c->volWave = c->volTr = c->sssWave = false;
     if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
     if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
     if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
@@ -2368,6 +2372,15 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && (c->hasNullMat || c->hasAlpha)) c->volWave = false; }   // =0: such scenes keep the general form (A/B)
         c->volTr = c->volWave && (c->hasNullMat || c->hasAlpha);
         v.tr_queues = c->volTr ? 1 : 0;
+        // BSSRDF materials under Integrator "path" (round 3): Sample_S draws its numbers before the probe chain is traced, and without media no visibility
+        // query draws any -- the chains are walked through the queues and the vertex's direct-lighting rays take the plain shadow / MIS traversals
+        // (k_trace<2> / <1>: Unoccluded / Intersect, as k_shade's).  PBRT_AMD_VOL_INLINE=1 keeps the per-lane form (A/B, parity tests).
+        {
+            const char *e = std::getenv("PBRT_AMD_VOL_INLINE");
+            c->sssWave = d->material_bssrdf && !v.handle_media && !(e && e[0] == '1');
+            if (c->sssWave) c->volWave = true;
+            v.sss_wave = c->sssWave ? 1 : 0;
+        }
         v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
         if (v.handle_media && d->n_media) {
             std::vector<mi_medium> med(d->media, d->media + d->n_media);
@@ -2455,7 +2468,8 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);
     ALLOC(q_sorted, uint32_t, qcap);
     ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
-    if (c->volTr) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
+    if (c->volTr || c->sssWave) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
+    if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_sss, uint32_t, qcap); }
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
@@ -2565,7 +2579,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     while (true) {
         uint32_t qout = qin ^ 1;
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr;
+        const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && !c->sssWave;
+        if (c->sssWave) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW2, 0), 0, 3 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // probe queues (SHADOW2, MIS2) + QC_SSS
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
@@ -2700,6 +2715,64 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             LAUNCH_TRACE(1);
         }
         toc(c);
+        if (c->sssWave) {
+            // the subsurface paths k_shade_vol parked in this bounce: walk their probe chains (one segment per round: k_trace<2, ..., TR> finds its closest
+            // hit, k_sss_probe_step takes it into the chain), then shade the entry vertices and trace THEIR direct-lighting rays.  The vertex's own
+            // shadow / MIS rays are done (above): NeeRec::sh_* now carries the probe segments.
+            uint32_t row[QSEG * QC_STRIDE], left = 0;
+            HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(QC_SHADOW2, 0), sizeof(row), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
+            if (left) {
+                uint32_t rowIn = QC_SHADOW2, rowOut = QC_MIS2;
+                uint32_t *qIn = ps.q_tr[0], *qOut = ps.q_tr[1];
+                tic(c, MI_K_SHADE);
+                if (c->hasInst) hipLaunchKernelGGL((k_sss_probe_step<true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 1);
+                else hipLaunchKernelGGL((k_sss_probe_step<false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 1);
+                toc(c);
+                std::swap(qIn, qOut); std::swap(rowIn, rowOut);
+                tic(c, MI_K_MIS_CLOSEST);
+                for (int round = 0; round < 16384; ++round) {
+                    HIP_TRY(hipMemsetAsync(ps.qcount + QCI(rowOut, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    {
+                        PathState psRun = ps;
+                        psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn;
+                        PathState &ps = psRun;
+                        LAUNCH_TRACE_TR(2);
+                    }
+                    if (c->hasInst) hipLaunchKernelGGL((k_sss_probe_step<true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 0);
+                    else hipLaunchKernelGGL((k_sss_probe_step<false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 0);
+                    std::swap(qIn, qOut); std::swap(rowIn, rowOut);
+                    if (round >= 3) {   // (a chain has at least two hits per walk on a closed object: the first rounds are queued blindly)
+                        left = 0;
+                        HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(rowIn, 0), sizeof(row), hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
+                        if (left == 0) break;
+                    }
+                }
+                toc(c);
+                HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_SHADE);
+                if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                else hipLaunchKernelGGL((k_sss_entry<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                toc(c);
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_ANYHIT);
+                LAUNCH_TRACE(2);
+                toc(c);
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_MIS_CLOSEST);
+                {
+                    PathState psRun = ps;
+                    psRun.vol_tr = 1u;
+                    PathState &ps = psRun;
+                    LAUNCH_TRACE(1);
+                }
+                toc(c);
+            }
+        }
         }
         qin = qout;
         ++iter;
@@ -2715,7 +2788,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             if (left == 0 || iter > sc.max_depth + 4096) break;
         }
     }
-    if (c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));   // the last bounce's direct-lighting terms
+    if (c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && !c->sssWave && iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));   // the last bounce's direct-lighting terms
     if (toFilm) {
         tic(c, MI_K_FILM);
         hipLaunchKernelGGL((k_film<false>), grid, block, 0, st, sc, ps, pass, c->filmPtr);
@@ -2783,7 +2856,8 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     uint32_t cap = rp->max_paths_in_flight > 0 ? (uint32_t)rp->max_paths_in_flight : (1u << 27);
     if (rp->max_paths_in_flight <= 0) {
         size_t freeB = 0, totalB = 0;
-        const size_t perPath = sizeof(PathRec) + sizeof(NeeRec) + sizeof(uint32_t) * 6 + sizeof(uint2);
+        const size_t perPath = sizeof(PathRec) + sizeof(NeeRec) + sizeof(uint32_t) * 6 + sizeof(uint2) + ((c->volTr || c->sssWave) ? sizeof(TrState) + 2 * sizeof(uint32_t) : 0) +
+                               (c->sssWave ? sizeof(SssRec) + sizeof(uint32_t) : 0);
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
             size_t budget = freeB / 10 * 6 + (size_t)c->cap * perPath;   // what is allocated for path state now would be released
             cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(budget / perPath, 1u << 20));

@@ -380,11 +380,11 @@ __device__ __noinline__ void ComputeBSSRDFD(const DevVol *vol, int mat, const Is
     out->sigma_t = sig_a + sig_s;
     out->rho = RGB(out->sigma_t.r != 0 ? sig_s.r / out->sigma_t.r : 0, out->sigma_t.g != 0 ? sig_s.g / out->sigma_t.g : 0, out->sigma_t.b != 0 ? sig_s.b / out->sigma_t.b : 0);
 }
-// SeparableBSSRDF::Sample_Sp (core/bssrdf.cpp:249-326): a probe segment through the sphere of radius rMax around po; every hit on a primitive
-// of the same material object counts, one of them is chosen.  The reference collects the chain in a list; here the chain is walked twice
-// (count, then stop at the chosen one) -- the same rays, hence the same hits.
-template <bool INST>
-__device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Float u1, Float u20, Float u21, VHit *pi, Float *pdf) {
+// the probe segment of Sample_Sp (bssrdf.cpp:249-283): projection axis and spectral channel from u1, radius and angle from u2, the segment
+// baseP -> pTarget through the sphere of radius rMax; false: the sample yields nothing (r < 0 or r >= rMax).  *u1Left: u1 after the two remaps
+// (it picks among the chain's hits).  One function for the per-lane form and the walked form (k_shade_vol<WAVE> + k_sss_probe_step): same arithmetic
+struct SssProbe { V3 baseP, pTarget; Float u1Left; };
+PT_DEV bool BssrdfProbeSetup(const DevBSSRDF *bs, Float u1, Float u20, Float u21, SssProbe *pr) {
     V3 vx, vy, vz;
     if (u1 < .5f) { vx = bs->ss; vy = bs->ts; vz = bs->ns; u1 *= 2; }
     else if (u1 < .75f) { vx = bs->ts; vy = bs->ns; vz = bs->ss; u1 = (u1 - .5f) * 4; }
@@ -393,13 +393,25 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
     ch = ch < 0 ? 0 : (ch > 2 ? 2 : ch);
     u1 = u1 * 3 - ch;
     Float r = BssrdfSample_Sr(bs, ch, u20);
-    if (r < 0) return RGB(0.f);
+    if (r < 0) return false;
     Float phi = 2 * PT_PI * u21;
     Float rMax = BssrdfSample_Sr(bs, ch, 0.999f);
-    if (r >= rMax) return RGB(0.f);
+    if (r >= rMax) return false;
     Float l = 2 * sqrtf_(rMax * rMax - r * r);
-    const V3 baseP = bs->poP + r * (vx * cosf_(phi) + vy * sinf_(phi)) - l * vz * 0.5f;
-    const V3 pTarget = baseP + l * vz;
+    pr->baseP = bs->poP + r * (vx * cosf_(phi) + vy * sinf_(phi)) - l * vz * 0.5f;
+    pr->pTarget = pr->baseP + l * vz;
+    pr->u1Left = u1;
+    return true;
+}
+// SeparableBSSRDF::Sample_Sp (core/bssrdf.cpp:249-326): a probe segment through the sphere of radius rMax around po; every hit on a primitive
+// of the same material object counts, one of them is chosen.  The reference collects the chain in a list; here the chain is walked twice
+// (count, then stop at the chosen one) -- the same rays, hence the same hits.
+template <bool INST>
+__device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Float u1, Float u20, Float u21, VHit *pi, Float *pdf) {
+    SssProbe pr;
+    if (!BssrdfProbeSetup(bs, u1, u20, u21, &pr)) return RGB(0.f);
+    const V3 baseP = pr.baseP, pTarget = pr.pTarget;
+    u1 = pr.u1Left;
     int nFound = 0, selected = 0;
     for (int pass = 0; pass < 2; ++pass) {
         V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds, no media
@@ -427,6 +439,68 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
     }
     *pdf = BssrdfPdf_Sp(bs, pi->is.p, pi->is.n) / nFound;
     return BssrdfSr(bs, (bs->poP - pi->is.p).Length());   // Sp(pi) = Sr(Distance(po.p, pi.p))
+}
+
+// ---- BSSRDF probe chains in wavefront form (DevVol::sss_wave: Integrator "path" scenes with subsurface materials; round 3).
+// Sample_S draws its three numbers before the chain is traced and nothing while it is traced (bssrdf.cpp:249-326), so the dimension stream of a path
+// does not depend on the chain: the vertex's own direct-lighting rays go through the shadow / MIS queues as in every wavefront form, the path PARKS
+// (SssRec: the BSSRDF at po, the probe segment, the chain's state), k_sss_probe_step + k_trace<2, ..., TR> walk the chain hit by hit -- twice, like
+// BssrdfSample_Sp: count the hits on the material object, then stop at the chosen one -- and k_sss_entry shades the entry vertex pi (Sp, pdf, the
+// adapter lobe's light sample and continuation, Russian roulette).  Same rays, same arithmetic as the per-lane form (PBRT_AMD_VOL_INLINE=1).
+struct __attribute__((aligned(64))) SssRec {
+    float4 po_eta;       // po.p | eta
+    float4 ns_mat;       // po's shading normal | material slot (bits)
+    float4 ss_tab;       // po's shading tangent | table index (bits)
+    float4 sigt_u1;      // sigma_t | u1 after the axis / channel remaps (picks among the hits)
+    float4 rho_found;    // rho | hits of the first walk (bits)
+    float4 base_seen;    // baseP | hits seen in this walk, bit 31: second walk (bits)
+    float4 target_sel;   // pTarget | index of the chosen hit (bits)
+    float4 p_ex;         // the chain's current point p | pError.x
+    float4 e_n;          // pError.y, pError.z, n.x, n.y
+    float4 nz_pi;        // n.z | pi: primitive, instance (bits) | -
+    float4 pi_o, pi_d;   // the segment that found pi
+};
+PT_DEV void SssPark(SssRec *S, const DevVol &vol, const DevBSSRDF &b, const SssProbe &pr) {
+    S->po_eta = make_float4(b.poP.x, b.poP.y, b.poP.z, b.eta);
+    S->ns_mat = make_float4(b.ns.x, b.ns.y, b.ns.z, __uint_as_float((uint32_t)b.material));
+    S->ss_tab = make_float4(b.ss.x, b.ss.y, b.ss.z, __uint_as_float((uint32_t)(b.table - vol.tables)));
+    S->sigt_u1 = make_float4(b.sigma_t.r, b.sigma_t.g, b.sigma_t.b, pr.u1Left);
+    S->rho_found = make_float4(b.rho.r, b.rho.g, b.rho.b, __uint_as_float(0u));
+    S->base_seen = make_float4(pr.baseP.x, pr.baseP.y, pr.baseP.z, __uint_as_float(0u));
+    S->target_sel = make_float4(pr.pTarget.x, pr.pTarget.y, pr.pTarget.z, __uint_as_float(0u));
+}
+PT_DEV void SssBssrdfOf(const SssRec *S, const DevVol &vol, DevBSSRDF *b) {
+    const float4 a = S->po_eta, n = S->ns_mat, t = S->ss_tab, g = S->sigt_u1, r = S->rho_found;
+    b->poP = V3(a.x, a.y, a.z); b->eta = a.w;
+    b->ns = V3(n.x, n.y, n.z); b->material = (int)__float_as_uint(n.w);
+    b->ss = V3(t.x, t.y, t.z); b->table = vol.tables + __float_as_uint(t.w);
+    b->ts = Cross(b->ns, b->ss);   // as ComputeBSSRDFD formed it
+    b->sigma_t = RGB(g.x, g.y, g.z); b->rho = RGB(r.x, r.y, r.z);
+}
+
+// the two direct-lighting rays of a vertex into its NeeRec (wavefront forms): the terms are added by k_trace<2> iff unoccluded / by k_trace<1> times
+// Le times the transmittance up to the hit (or by k_vol_tr_step at the end of a walk)
+PT_DEV void WriteNeeRecords(const PathState &ps, const DevVol &vol, uint32_t slot, const NeeOut &nee, const RGB &betaNee) {
+    if (nee.wantShadow) {
+        RGB c = betaNee * (nee.shTerm / nee.selPdf);
+        ps.nee[slot].sh_o = make_float4(nee.sh.o.x, nee.sh.o.y, nee.sh.o.z, nee.sh.tMax);
+        ps.nee[slot].sh_d = make_float4(nee.sh.d.x, nee.sh.d.y, nee.sh.d.z, 0);
+        ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, vol.tr_queues ? nee.lp.n.z : 0);
+        if (vol.tr_queues) {   // the light point + start medium ride in the record's free words (k_vol_tr_step<2>)
+            ps.trs[slot].acc[0] = make_float4(1, 1, 1, 0);
+            ps.nee[slot].sh_d.w = __int_as_float(nee.shMedium);
+            ps.nee[slot].pad[0] = make_float4(nee.lp.p.x, nee.lp.p.y, nee.lp.p.z, nee.lp.pError.x);
+            ps.nee[slot].pad[1] = make_float4(nee.lp.pError.y, nee.lp.pError.z, nee.lp.n.x, nee.lp.n.y);
+        }
+    }
+    if (nee.wantMis) {
+        RGB c = betaNee * (nee.miTerm / nee.selPdf);
+        ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, vol.tr_queues ? __int_as_float(nee.miMedium) : 0);
+        ps.nee[slot].mi_d = make_float4(nee.miD.x, nee.miD.y, nee.miD.z, __uint_as_float((uint32_t)nee.lightNum));
+        ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
+        if (vol.tr_queues) ps.trs[slot].acc[1] = make_float4(1, 1, 1, 0);
+        if (!vol.tr_queues) ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
+    }
 }
 
 // The out-of-line routines this kernel shares with k_shade<..., TEX> (BSDF, texture and light code) are compiled ONCE, with the loosest
@@ -460,7 +534,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
         const uint32_t i = it.item();
         const bool active = i < n;
 #endif
-        bool cont = false;
+        bool cont = false, wantProbe = false;   // wantProbe (walked BSSRDF probes, DevVol::sss_wave): the path waits for its probe chain instead of continuing
         uint32_t slot = 0, rayKey = 0;
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
@@ -580,8 +654,17 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                                 smp.Get2D(sc, &u20, &u21);
                                 u1s = smp.Get1D(sc);
                                 VHit pi;
-                                RGB S = BssrdfSample_Sp<INST>(cx, &bssrdf, u1s, u20, u21, &pi, &spdf);
-                                if (S.IsBlack() || spdf == 0) alive = false;
+                                RGB S(0.f);
+                                if constexpr (WAVE) {
+                                    // walked form (DevVol::sss_wave): the probe chain goes through the queues (k_sss_probe_step + k_trace<2, ..., TR>) and the
+                                    // entry vertex is shaded by k_sss_entry, which also takes this iteration's Russian roulette and ++bounces
+                                    SssProbe pr;
+                                    if (!BssrdfProbeSetup(&bssrdf, u1s, u20, u21, &pr)) alive = false;
+                                    else { wantProbe = true; SssPark(&ps.sss[slot], vol, bssrdf, pr); }
+                                } else
+                                    S = BssrdfSample_Sp<INST>(cx, &bssrdf, u1s, u20, u21, &pi, &spdf);
+                                if constexpr (WAVE) {   // (k_sss_entry goes on from here)
+                                } else if (S.IsBlack() || spdf == 0) alive = false;
                                 else {
                                     beta = beta * (S / spdf);
                                     // the entry vertex (bssrdf.cpp:235-247): a BSDF of the adapter lobe alone on pi's own shading frame, wo = shading.n
@@ -611,7 +694,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     }
                 }
             }
-            if (alive && scattered) {   // Russian roulette (volpath.cpp:183-189 / path.cpp:176-184); the loop's ++bounces
+            if (alive && wantProbe) {   // parked: beta, etaScale, the sampler state and the bounce count as they are now (k_sss_entry resumes)
+                ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+            } else if (alive && scattered) {   // Russian roulette (volpath.cpp:183-189 / path.cpp:176-184); the loop's ++bounces
                 cont = true;
                 RGB rrBeta = beta * etaScale;
                 if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
@@ -623,28 +709,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             } else if (alive && nullCrossing)
                 cont = true;
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
-            if (WAVE) {   // added by k_trace<2> iff unoccluded / by k_trace<1> times Le times the transmittance up to the hit
-                if (nee.wantShadow) {
-                    RGB c = betaNee * (nee.shTerm / nee.selPdf);
-                    ps.nee[slot].sh_o = make_float4(nee.sh.o.x, nee.sh.o.y, nee.sh.o.z, nee.sh.tMax);
-                    ps.nee[slot].sh_d = make_float4(nee.sh.d.x, nee.sh.d.y, nee.sh.d.z, 0);
-                    ps.nee[slot].sh_c = make_float4(c.r, c.g, c.b, vol.tr_queues ? nee.lp.n.z : 0);
-                    if (vol.tr_queues) {   // the light point + start medium ride in the record's free words (k_vol_tr_step<2>)
-                        ps.trs[slot].acc[0] = make_float4(1, 1, 1, 0);
-                        ps.nee[slot].sh_d.w = __int_as_float(nee.shMedium);
-                        ps.nee[slot].pad[0] = make_float4(nee.lp.p.x, nee.lp.p.y, nee.lp.p.z, nee.lp.pError.x);
-                        ps.nee[slot].pad[1] = make_float4(nee.lp.pError.y, nee.lp.pError.z, nee.lp.n.x, nee.lp.n.y);
-                    }
-                }
-                if (nee.wantMis) {
-                    RGB c = betaNee * (nee.miTerm / nee.selPdf);
-                    ps.nee[slot].mi_o = make_float4(nee.miO.x, nee.miO.y, nee.miO.z, vol.tr_queues ? __int_as_float(nee.miMedium) : 0);
-                    ps.nee[slot].mi_d = make_float4(nee.miD.x, nee.miD.y, nee.miD.z, __uint_as_float((uint32_t)nee.lightNum));
-                    ps.nee[slot].mi_c = make_float4(c.r, c.g, c.b, 0);
-                    if (vol.tr_queues) ps.trs[slot].acc[1] = make_float4(1, 1, 1, 0);
-                    if (!vol.tr_queues) ps.nee[slot].pad[0] = make_float4(nee.miSigmaT.r, nee.miSigmaT.g, nee.miSigmaT.b, 0);
-                }
-            }
+            if (WAVE) WriteNeeRecords(ps, vol, slot, nee, betaNee);
             if (cont) {
                 if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
                 ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
@@ -661,6 +726,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
             if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
             if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
+            if constexpr (!UMAT) {
+                if (vol.sss_wave) {   // the probe chains of this bounce: first queue of the walk (k_sss_probe_step)
+                    const uint32_t posP = wave_append(&ps.qcount[QCI(QC_SHADOW2, qseg)], wantProbe);
+                    if (wantProbe) ps.q_tr[0][qbase + posP] = slot;
+                }
+            }
         } else {
             uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
             if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
@@ -762,5 +833,172 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
         const uint32_t qseg = blockIdx.x & 7;
         const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
         if (again) qOut[qseg * ps.seg_cap + pos] = slot;
+    }
+}
+
+// One round of the probe walk.  first: the paths k_shade_vol<WAVE> parked in this bounce (no segment traced yet); otherwise TrState::hit[0] holds the
+// closest hit of the segment in NeeRec::sh_o / sh_d (k_trace<2, ..., TR>: Scene::Intersect with tMax = 1 - ShadowEpsilon, alphaMask at candidate
+// hits).  Per path: take the hit into the chain (Interaction::SpawnRayTo(pTarget) from the hit point, interaction.h:68-72), count it if its primitive
+// carries the BSSRDF's material object (bssrdf.cpp:302), at the end of the first walk choose (bssrdf.cpp:311-314) and start the second; the second
+// walk ends at the chosen hit -> QC_SSS for k_sss_entry.  A chain without such a hit ends the path (path.cpp:160: S.IsBlack()).
+template <bool INST>
+__global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn, uint32_t *qOut, uint32_t rowOut, int first) {
+    for (SegIter it(ps.qcount, rowIn, ps.seg_cap); it.more(); it.next()) {
+        const bool active = it.valid();
+        bool again = false, done = false;
+        uint32_t slot = 0;
+        if (active) {
+            slot = qIn[it.item()];
+            SssRec *S = &ps.sss[slot];
+            const float4 bs4 = S->base_seen, tg4 = S->target_sel;
+            const V3 baseP(bs4.x, bs4.y, bs4.z), pTarget(tg4.x, tg4.y, tg4.z);
+            const int material = (int)__float_as_uint(S->ns_mat.w);
+            uint32_t seen = __float_as_uint(bs4.w) & 0x7fffffffu, pass = __float_as_uint(bs4.w) >> 31;
+            uint32_t nFound = __float_as_uint(S->rho_found.w), selected = __float_as_uint(tg4.w);
+            V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds
+            bool endOfWalk = false;
+            if (!first) {
+                const uint4 hit = ps.trs[slot].hit[0];
+                if (hit.x == TRAV_MISS) endOfWalk = true;
+                else {
+                    const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+                    VHit vh;
+                    HitToIsect(scp, &vol, hit.x, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), hit.z, -1, false, &vh);
+                    p = vh.is.p; pErr = vh.is.pError; n = vh.is.n;
+                    if ((int)vh.tinfo.y == material) {
+                        if (pass == 1 && seen == selected) {   // pi: k_sss_entry rebuilds the interaction from the segment and the primitive
+                            S->nz_pi = make_float4(0, __uint_as_float(hit.x), __uint_as_float(hit.z), 0);
+                            S->pi_o = o4; S->pi_d = d4;
+                            done = true;
+                        } else
+                            ++seen;
+                    }
+                }
+            }
+            if (!done) {
+                V3 dir = pTarget - p;
+                if (!endOfWalk && dir.x == 0 && dir.y == 0 && dir.z == 0) endOfWalk = true;
+                bool walking = !endOfWalk;
+                if (endOfWalk && pass == 0 && seen > 0) {   // choose, then the same walk again up to the chosen hit
+                    nFound = seen;
+                    int sel = (int)(S->sigt_u1.w * (int)nFound);
+                    selected = (uint32_t)(sel < 0 ? 0 : (sel > (int)nFound - 1 ? (int)nFound - 1 : sel));
+                    pass = 1; seen = 0;
+                    p = baseP; pErr = V3(); n = V3();
+                    dir = pTarget - p;
+                    walking = !(dir.x == 0 && dir.y == 0 && dir.z == 0);
+                }
+                if (walking) {
+                    const V3 origin = OffsetRayOrigin(p, pErr, n, dir);
+                    ps.nee[slot].sh_o = make_float4(origin.x, origin.y, origin.z, 1 - PT_SHADOW_EPS);
+                    ps.nee[slot].sh_d = make_float4(dir.x, dir.y, dir.z, 0);
+                    S->rho_found.w = __uint_as_float(nFound);
+                    S->base_seen.w = __uint_as_float(seen | (pass << 31));
+                    S->target_sel.w = __uint_as_float(selected);
+                    again = true;
+                }
+            }
+        }
+        const uint32_t qseg = blockIdx.x & 7;
+        const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
+        if (again) qOut[qseg * ps.seg_cap + pos] = slot;
+        const uint32_t posD = wave_append(&ps.qcount[QCI(QC_SSS, qseg)], done);
+        if (done) ps.q_sss[qseg * ps.seg_cap + posD] = slot;
+    }
+}
+
+// The entry vertex of a subsurface path (path.cpp:160-174 after Sample_S; bssrdf.cpp:235-247, 316-326): Sp and its pdf at the chosen hit, beta *= S / pdf,
+// one light sample for the adapter lobe on pi's own shading frame (its two rays into the shadow / MIS queues), the adapter's Sample_f for the
+// continuation, then the iteration's Russian roulette and ++bounces -- what the per-lane form does after BssrdfSample_Sp, from the parked state.
+template <bool INST>
+__global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
+    __shared__ StackEntry lds_stack[1];
+    const DevScene &sc = *scp;
+    LaneTracer lt;
+    lt.scp = scp; lt.lds = (LdsStackEntry *)&lds_stack[0]; lt.spill = nullptr;
+    lt.nClosest = lt.nAny = lt.guardTrips = 0;
+    for (SegIter it(ps.qcount, QC_SSS, ps.seg_cap); it.more(); it.next()) {
+        const bool active = it.valid();
+        bool cont = false;
+        uint32_t slot = 0, rayKey = 0;
+        NeeOut nee;
+        nee.wantShadow = nee.wantMis = false;
+        if (active) {
+            slot = ps.q_sss[it.item()];
+            const SssRec *S = &ps.sss[slot];
+            const float4 b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
+            const uint4 s4 = ps.rec[slot].smp;
+            RGB beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z), betaNee(0.f);
+            const Float etaScale = b4.w;
+            int bounces = (int)(s4.w & 0xffffu);
+            bool specularBounce = (s4.w >> 16) & 1u;
+            const bool noDiff = (s4.w >> 17) & 1u;
+            VSampler smp;
+            smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+            smp.dimension = (int)s4.z;
+            smp.px = smp.py = 0;
+            smp.Prefetch(sc);
+            VolCtx cx;
+            cx.scp = scp; cx.vol = &vol; cx.lt = &lt; cx.smp = &smp; cx.nee = &nee;
+            DevBSSRDF bssrdf;
+            SssBssrdfOf(S, vol, &bssrdf);
+            const float4 zp = S->nz_pi, po4 = S->pi_o, pd4 = S->pi_d;
+            const uint32_t nFound = __float_as_uint(S->rho_found.w);
+            VHit pi;
+            HitToIsect(scp, &vol, __float_as_uint(zp.y), V3(po4.x, po4.y, po4.z), V3(pd4.x, pd4.y, pd4.z), __float_as_uint(zp.z), -1, false, &pi);
+            const Float spdf = BssrdfPdf_Sp(&bssrdf, pi.is.p, pi.is.n) / (int)nFound;
+            const RGB Sp = BssrdfSr(&bssrdf, (bssrdf.poP - pi.is.p).Length());   // Sp(pi) = Sr(Distance(po.p, pi.p))
+            bool alive = !(Sp.IsBlack() || spdf == 0);
+            V3 no, nd;
+            if (alive) {
+                beta = beta * (Sp / spdf);
+                mi_material piMat;
+                piMat.n_bxdfs = 1; piMat.eta = 1;
+                __builtin_memset(&piMat.bxdfs[0], 0, sizeof(mi_bxdf));
+                piMat.bxdfs[0].type = MI_BXDF_BSSRDF_ADAPTER;
+                piMat.bxdfs[0].etaB = bssrdf.eta;
+                pi.is.wo = pi.is.ns;
+                LaneBSDF piBsdf(pi.is, &piMat);
+                L = L + beta * UniformSampleOneLightD<INST, LaneBSDF>(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
+                betaNee = beta;
+                Float u0, u1, pdf;
+                int flags;
+                V3 wi;
+                smp.Get2D(sc, &u0, &u1);
+                const RGB f = piBsdf.Sample_f(pi.is.wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                if (f.IsBlack() || pdf == 0) alive = false;
+                else {
+                    beta = beta * (f * AbsDot(wi, pi.is.ns) / pdf);
+                    specularBounce = (flags & BSDF_SPECULAR) != 0;
+                    no = OffsetRayOrigin(pi.is.p, pi.is.pError, pi.is.n, wi);   // pi.SpawnRay(wi)
+                    nd = wi;
+                }
+            }
+            if (alive) {   // Russian roulette (path.cpp:176-184); the loop's ++bounces
+                cont = true;
+                const RGB rrBeta = beta * etaScale;
+                if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
+                    const Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
+                    if (smp.Get1D(sc) < q) cont = false;
+                    else beta = beta / (1 - q);
+                }
+                ++bounces;
+            }
+            ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
+            WriteNeeRecords(ps, vol, slot, nee, betaNee);
+            if (cont) {
+                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
+                ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
+                ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+            }
+        }
+        const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
+        uint32_t posE, posS, posM;
+        PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, nee.wantShadow, nee.wantMis, &posE, &posS, &posM);
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
+        if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
     }
 }

@@ -25,6 +25,7 @@ struct DevVol {
     int32_t textured;                // some material is textured (c_tex.descs is set): lobe lists are built per hit
     int32_t tr_queues;               // wavefront form with BSDF-less interfaces between homogeneous media: shadow / MIS rays carry their light point and start
                                      // medium through the queues and k_vol_tr walks them interface by interface (pt_volpath.h)
+    int32_t sss_wave;                // wavefront form of scenes with BSSRDF materials under Integrator "path": probe chains walked through the queues (pt_volpath.h: SssRec)
 };
 
 // The path's sampler with the next PT_VOL_PRE dimensions drawn ahead in ONE batch (SamplerBatch: wave-uniform matrix rows through the scalar

@@ -674,6 +674,38 @@ def test_walked_interfaces_match_the_general_form(name, flatten, monkeypatch):
     assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_inst", False), ("sss_inst", True)])
+def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch):
+    """Subsurface materials under Integrator "path" in wavefront form (round 3): the vertex's shadow / MIS rays take the plain traversals, the path parks,
+    its probe chain is walked hit by hit through the queues (k_sss_probe_step + k_trace<2, ..., TR>: count, choose, walk again up to the chosen hit --
+    SeparableBSSRDF::Sample_Sp, core/bssrdf.cpp:249-326) and k_sss_entry shades the entry vertex (path.cpp:160-174).  PBRT_AMD_VOL_INLINE=1: the
+    per-lane form (every lane traces its own rays inside k_shade_vol).  Both reproduce the reference's render with the same rays; sss_inst walks
+    its chains through TransformedPrimitives."""
+    monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
+    fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    out = {}
+    for form in ("walked", "general"):
+        if form == "general":
+            monkeypatch.setenv("PBRT_AMD_VOL_INLINE", "1")
+        else:
+            monkeypatch.delenv("PBRT_AMD_VOL_INLINE", raising=False)
+        sc = pa.Scene(text=edge_scenes.scene(name))
+        ctx = pa.Context(sc)
+        ctx.timing_enable(True); ctx.counters_reset()
+        ctx.render()
+        t, cnt = ctx.timing(), ctx.counters()
+        img = sc.film_image(ctx.film())
+        frac, relmse = ol.image_metrics(img, fx)
+        assert (frac >= 0.995 and relmse <= 1e-4) if not flatten else (frac >= 0.99 and relmse <= 5e-4), (form, frac, relmse)
+        out[form] = (img, {k: v[1] for k, v in t.items() if v[1]}, cnt)
+        ctx.close()
+    assert "anyhit" in out["walked"][1] and "mis_closest" in out["walked"][1] and "anyhit" not in out["general"][1]   # the queues ran / the lanes traced their own rays
+    for k in ("closest_rays", "shadow_rays", "camera_rays"):
+        assert out["walked"][2][k] == out["general"][2][k], k   # query for query the same rays
+    assert out["walked"][2]["trace_guard_trips"] == 0
+    assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["vol_inst", "sss_inst", "vol_glass"])
 def test_volpath_and_subsurface_flattened_instances(name, monkeypatch):
     """the same scenes with PBRT_AMD_INSTANCING=0 (instances flattened on the host): single-level k_shade_vol instances"""

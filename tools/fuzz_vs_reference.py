@@ -295,7 +295,16 @@ class Gen:
         if g.chance(.15): cam += ' "float screenwindow" [%s]' % f([-g.u(.6, 1.2), g.u(.6, 1.2), -g.u(.6, 1.2), g.u(.6, 1.2)])
         s += 'Camera "perspective" %s\n' % cam
         spp = int(g.pick([1, 2, 3, 4]))
-        if g.chance(.5): s += 'Sampler "sobol" "integer pixelsamples" [%d]\n' % spp
+        if getattr(self, "pixel_samplers", False):   # --pixel-samplers: the samplers with one PCG32 stream per tile (own generator: the other choices of a seed stay what they were)
+            q = np.random.default_rng(self.seed + 991)
+            k = ["random", "stratified", "02sequence", "lowdiscrepancy"][int(q.integers(0, 4))]
+            if k == "stratified":
+                s += 'Sampler "stratified" "integer xsamples" [%d] "integer ysamples" [%d]%s%s\n' % (
+                    int(q.integers(1, 4)), int(q.integers(1, 3)), ' "bool jitter" ["false"]' if q.random() < .25 else "", ' "integer dimensions" [%d]' % int(q.integers(1, 7)) if q.random() < .5 else "")
+            elif k == "random": s += 'Sampler "random" "integer pixelsamples" [%d]\n' % int(q.integers(1, 6))
+            else: s += 'Sampler "%s" "integer pixelsamples" [%d]%s\n' % (k, int(q.integers(1, 6)), ' "integer dimensions" [%d]' % int(q.integers(1, 7)) if q.random() < .5 else "")
+            g.chance(.5)   # keep the main generator in step with the default branch
+        elif g.chance(.5): s += 'Sampler "sobol" "integer pixelsamples" [%d]\n' % spp
         else: s += 'Sampler "halton" "integer pixelsamples" [%d]%s\n' % (spp, ' "bool samplepixelcenter" ["true"]' if g.chance(.2) else "")
         s += g.pick(['PixelFilter "box"\n'] * 4 + ['PixelFilter "gaussian" "float xwidth" [%s] "float ywidth" [%s]\n' % (f(g.u(.8, 2)), f(g.u(.8, 2))),
                      'PixelFilter "mitchell"\n', 'PixelFilter "triangle" "float xwidth" [%s]\n' % f(g.u(.8, 2)), 'PixelFilter "sinc" "float tau" [%s]\n' % f(g.u(2, 4))])
@@ -395,7 +404,7 @@ def device_mode(a):
     bad = refused = done = invalid = 0
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        gen = Gen(seed); gen.sss = a.sss
+        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers
         text = gen.scene(a.res, a.media)
         if a.instanced_only and "ObjectInstance" not in text:
             continue
@@ -455,6 +464,7 @@ def main():
     ap.add_argument("--res", type=int, nargs=2, default=[40, 28])
     ap.add_argument("--sss", action="store_true", help="subsurface / kdsubsurface materials among the top-level ones (host + oracle vs reference; add --device on the GPU box for the device's BSSRDF branch)")
     ap.add_argument("--media", action="store_true", help="Integrator \"volpath\" with random participating media / medium interfaces (host + oracle vs reference; add --device on the GPU box for k_shade_vol)")
+    ap.add_argument("--pixel-samplers", action="store_true", help="Sampler \"random\" / \"stratified\" / \"02sequence\" / \"lowdiscrepancy\" with random parameters instead of sobol / halton (one PCG32 stream per tile: tile-serial rounds on the device)")
     ap.add_argument("--spectra", action="store_true", help="some \"rgb\" parameters become \"blackbody\" / inline \"spectrum\" parameters (the host's CIE conversion, host/spectrum.cpp)")
     ap.add_argument("--instanced-only", action="store_true", help="device mode: only the scenes that use ObjectInstance (two-level traversal)")
     ap.add_argument("--stub", action="store_true", help="the reference-side binding instead of this repository's host: oracle/_ref/pbrt_ref_wavefront (the reference's own parser / API / BVH build + FlattenScene of oracle/ref_build/wavefrontpath.cpp, oracle backend) against pbrt_ref")
@@ -472,7 +482,7 @@ def main():
     probes = {"rays": 0, "tex_nodes": 0}
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        gen = Gen(seed); gen.sss = a.sss
+        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers
         text = gen.scene(a.res, a.media)
         if a.spectra: text = with_spectra(text, seed)
         fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)
