@@ -2377,7 +2377,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         // (k_trace<2> / <1>: Unoccluded / Intersect, as k_shade's).  PBRT_AMD_VOL_INLINE=1 keeps the per-lane form (A/B, parity tests).
         {
             const char *e = std::getenv("PBRT_AMD_VOL_INLINE");
-            c->sssWave = d->material_bssrdf && !v.handle_media && !(e && e[0] == '1');
+            bool plain = !v.handle_media;   // ... or "volpath" with homogeneous media and nothing to walk NEE rays through (closed-form transmittance, as volWave without volTr)
+            if (v.handle_media && !c->hasNullMat && !c->hasAlpha) {
+                plain = true;
+                for (uint32_t i = 0; i < d->n_media && plain; ++i) plain = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
+            }
+            c->sssWave = d->material_bssrdf && plain && !(e && e[0] == '1');
             if (c->sssWave) c->volWave = true;
             v.sss_wave = c->sssWave ? 1 : 0;
         }

@@ -444,10 +444,14 @@ __device__ __noinline__ RGB BssrdfSample_Sp(VolCtx cx, const DevBSSRDF *bs, Floa
 // ---- BSSRDF probe chains in wavefront form (DevVol::sss_wave: Integrator "path" scenes with subsurface materials; round 3).
 // Sample_S draws its three numbers before the chain is traced and nothing while it is traced (bssrdf.cpp:249-326), so the dimension stream of a path
 // does not depend on the chain: the vertex's own direct-lighting rays go through the shadow / MIS queues as in every wavefront form, the path PARKS
-// (SssRec: the BSSRDF at po, the probe segment, the chain's state), k_sss_probe_step + k_trace<2, ..., TR> walk the chain hit by hit -- twice, like
-// BssrdfSample_Sp: count the hits on the material object, then stop at the chosen one -- and k_sss_entry shades the entry vertex pi (Sp, pdf, the
+// (SssRec: the BSSRDF at po, the probe segment, the chain's state), k_sss_probe_step + k_trace<2, ..., TR> walk the chain hit by hit -- count the hits on
+// the material object, choose; a second walk up to the chosen hit (BssrdfSample_Sp's two walks) only if it is not among the first few, which are kept --
+// and k_sss_entry shades the entry vertex pi (Sp, pdf, the
 // adapter lobe's light sample and continuation, Russian roulette).  Same rays, same arithmetic as the per-lane form (PBRT_AMD_VOL_INLINE=1).
-struct __attribute__((aligned(64))) SssRec {
+#ifndef PT_SSS_KEEP
+#define PT_SSS_KEEP 3
+#endif
+struct __attribute__((aligned(16))) SssRec {
     float4 po_eta;       // po.p | eta
     float4 ns_mat;       // po's shading normal | material slot (bits)
     float4 ss_tab;       // po's shading tangent | table index (bits)
@@ -457,8 +461,12 @@ struct __attribute__((aligned(64))) SssRec {
     float4 target_sel;   // pTarget | index of the chosen hit (bits)
     float4 p_ex;         // the chain's current point p | pError.x
     float4 e_n;          // pError.y, pError.z, n.x, n.y
-    float4 nz_pi;        // n.z | pi: primitive, instance (bits) | -
+    float4 nz_pi;        // n.z | pi: primitive, instance (bits) | the chain point's media: (mIn + 1) | (mOut + 1) << 16 (bits)
     float4 pi_o, pi_d;   // the segment that found pi
+    // the first PT_SSS_KEEP counted hits of the first walk (segment origin | primitive, segment direction | its medium, instance): when the chosen hit is
+    // among them -- a probe through a closed object has two -- the second walk is not needed (the reference keeps the whole chain in a list)
+    float4 keep_o[PT_SSS_KEEP], keep_d[PT_SSS_KEEP];
+    uint32_t keep_inst[4];
 };
 PT_DEV void SssPark(SssRec *S, const DevVol &vol, const DevBSSRDF &b, const SssProbe &pr) {
     S->po_eta = make_float4(b.poP.x, b.poP.y, b.poP.z, b.eta);
@@ -855,23 +863,31 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
             const int material = (int)__float_as_uint(S->ns_mat.w);
             uint32_t seen = __float_as_uint(bs4.w) & 0x7fffffffu, pass = __float_as_uint(bs4.w) >> 31;
             uint32_t nFound = __float_as_uint(S->rho_found.w), selected = __float_as_uint(tg4.w);
-            V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds
+            V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds, no media
+            int mIn = -1, mOut = -1;
             bool endOfWalk = false;
             if (!first) {
                 const uint4 hit = ps.trs[slot].hit[0];
                 if (hit.x == TRAV_MISS) endOfWalk = true;
                 else {
                     const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+                    const int rayMedium = __float_as_int(d4.w);   // GetMedium(dir) of the chain point the segment left from
                     VHit vh;
-                    HitToIsect(scp, &vol, hit.x, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), hit.z, -1, false, &vh);
-                    p = vh.is.p; pErr = vh.is.pError; n = vh.is.n;
+                    HitToIsect(scp, &vol, hit.x, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), hit.z, rayMedium, false, &vh);
+                    p = vh.is.p; pErr = vh.is.pError; n = vh.is.n; mIn = vh.mIn; mOut = vh.mOut;
                     if ((int)vh.tinfo.y == material) {
-                        if (pass == 1 && seen == selected) {   // pi: k_sss_entry rebuilds the interaction from the segment and the primitive
-                            S->nz_pi = make_float4(0, __uint_as_float(hit.x), __uint_as_float(hit.z), 0);
+                        if (pass == 1 && seen == selected) {   // pi: k_sss_entry rebuilds the interaction from the segment, its medium and the primitive
+                            S->nz_pi = make_float4(0, __uint_as_float(hit.x), __uint_as_float(hit.z), d4.w);
                             S->pi_o = o4; S->pi_d = d4;
                             done = true;
-                        } else
+                        } else {
+                            if (pass == 0 && seen < PT_SSS_KEEP) {
+                                S->keep_o[seen] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(hit.x));
+                                S->keep_d[seen] = d4;
+                                S->keep_inst[seen] = hit.z;
+                            }
                             ++seen;
+                        }
                     }
                 }
             }
@@ -883,15 +899,23 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
                     nFound = seen;
                     int sel = (int)(S->sigt_u1.w * (int)nFound);
                     selected = (uint32_t)(sel < 0 ? 0 : (sel > (int)nFound - 1 ? (int)nFound - 1 : sel));
-                    pass = 1; seen = 0;
-                    p = baseP; pErr = V3(); n = V3();
-                    dir = pTarget - p;
-                    walking = !(dir.x == 0 && dir.y == 0 && dir.z == 0);
+                    if (selected < PT_SSS_KEEP) {   // the chosen hit is one of the kept ones
+                        const float4 ko = S->keep_o[selected], kd = S->keep_d[selected];
+                        S->nz_pi = make_float4(0, ko.w, __uint_as_float(S->keep_inst[selected]), kd.w);
+                        S->pi_o = ko; S->pi_d = kd;
+                        S->rho_found.w = __uint_as_float(nFound);
+                        done = true;
+                    } else {
+                        pass = 1; seen = 0;
+                        p = baseP; pErr = V3(); n = V3(); mIn = mOut = -1;
+                        dir = pTarget - p;
+                        walking = !(dir.x == 0 && dir.y == 0 && dir.z == 0);
+                    }
                 }
-                if (walking) {
+                if (walking && !done) {
                     const V3 origin = OffsetRayOrigin(p, pErr, n, dir);
                     ps.nee[slot].sh_o = make_float4(origin.x, origin.y, origin.z, 1 - PT_SHADOW_EPS);
-                    ps.nee[slot].sh_d = make_float4(dir.x, dir.y, dir.z, 0);
+                    ps.nee[slot].sh_d = make_float4(dir.x, dir.y, dir.z, __int_as_float(GetMediumOf(n, mIn, mOut, dir)));
                     S->rho_found.w = __uint_as_float(nFound);
                     S->base_seen.w = __uint_as_float(seen | (pass << 31));
                     S->target_sel.w = __uint_as_float(selected);
@@ -945,11 +969,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
             const float4 zp = S->nz_pi, po4 = S->pi_o, pd4 = S->pi_d;
             const uint32_t nFound = __float_as_uint(S->rho_found.w);
             VHit pi;
-            HitToIsect(scp, &vol, __float_as_uint(zp.y), V3(po4.x, po4.y, po4.z), V3(pd4.x, pd4.y, pd4.z), __float_as_uint(zp.z), -1, false, &pi);
+            HitToIsect(scp, &vol, __float_as_uint(zp.y), V3(po4.x, po4.y, po4.z), V3(pd4.x, pd4.y, pd4.z), __float_as_uint(zp.z), __float_as_int(zp.w), false, &pi);
             const Float spdf = BssrdfPdf_Sp(&bssrdf, pi.is.p, pi.is.n) / (int)nFound;
             const RGB Sp = BssrdfSr(&bssrdf, (bssrdf.poP - pi.is.p).Length());   // Sp(pi) = Sr(Distance(po.p, pi.p))
             bool alive = !(Sp.IsBlack() || spdf == 0);
             V3 no, nd;
+            int nmedium = -1;
             if (alive) {
                 beta = beta * (Sp / spdf);
                 mi_material piMat;
@@ -972,9 +997,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
                     specularBounce = (flags & BSDF_SPECULAR) != 0;
                     no = OffsetRayOrigin(pi.is.p, pi.is.pError, pi.is.n, wi);   // pi.SpawnRay(wi)
                     nd = wi;
+                    nmedium = GetMediumOf(pi.is.n, pi.mIn, pi.mOut, wi);
                 }
             }
-            if (alive) {   // Russian roulette (path.cpp:176-184); the loop's ++bounces
+            if (alive) {   // Russian roulette (path.cpp:176-184 / volpath.cpp:183-189); the loop's ++bounces
                 cont = true;
                 const RGB rrBeta = beta * etaScale;
                 if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
@@ -992,6 +1018,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
                 ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
                 ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
                 ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+                if (vol.handle_media) ps.rec[slot].pad2 = make_float4(__uint_as_float((uint32_t)nmedium), 0, 0, 0);
             }
         }
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;

@@ -390,13 +390,15 @@ def _config_scene(name, tmp):
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--out", out], stdout=subprocess.DEVNULL)
     elif name == "sanmiguel_leafmask":   # the same with its leaf quads as alpha-masked meshes (bench.py --leafmask): the traversal's wave-wide alpha phases (PT_ALPHA_DEFER)
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--leafmask", "--out", out], stdout=subprocess.DEVNULL)
+    elif name == "sanmiguel_subsurface":   # the same with three kdsubsurface materials (bench.py --subsurface): BSSRDF probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+        subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--subsurface", "--out", out], stdout=subprocess.DEVNULL)
     else:                        # configs[3]: bathroom-class, glass + mirror + deep paths (maxdepth 30)
         subprocess.check_call([sys.executable, gen, "bathroom", "--tris", "60000", "--res", "192", "108", "--spp", "16", "--out", out], stdout=subprocess.DEVNULL)
     return pa.Scene(out)
 
 
 @pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "general"), ("bathroom", "general"),
-                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q"), ("sanmiguel_leafmask", "bvh4q"), ("sanmiguel_leafmask", "general")])
+                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q"), ("sanmiguel_leafmask", "bvh4q"), ("sanmiguel_leafmask", "general"), ("sanmiguel_subsurface", "bvh4q")])
 def test_baseline_configs_reduced(name, mode, tmp_path):
     """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
     (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
@@ -415,7 +417,10 @@ def test_baseline_configs_reduced(name, mode, tmp_path):
     _report("baseline_configs_reduced", config=name, mode=mode, within_tol=frac, relMSE=relmse, bit_identical_pixels=(img.view(np.uint32) == ref.view(np.uint32)).all(-1).mean())
     assert frac >= min_frac and relmse <= max_relmse, (name, frac, relmse)
     assert cnt["camera_rays"] == rcnt["camera_rays"] and cnt["trace_guard_trips"] == 0
-    assert abs(cnt["closest_rays"] - rcnt["closest_rays"]) <= 3e-3 * rcnt["closest_rays"]
+    if name == "sanmiguel_subsurface":   # probe chains with more than PT_SSS_KEEP counted hits (the quad soups) are walked a second time up to the chosen hit; the oracle keeps a list
+        assert -3e-3 * rcnt["closest_rays"] <= cnt["closest_rays"] - rcnt["closest_rays"] <= 2e-2 * rcnt["closest_rays"]
+    else:
+        assert abs(cnt["closest_rays"] - rcnt["closest_rays"]) <= 3e-3 * rcnt["closest_rays"]
     assert abs(cnt["shadow_rays"] - rcnt["shadow_rays"]) <= 3e-3 * rcnt["shadow_rays"]
     # per camera sample: >= 99.9 % within 1e-4 (1 + |L|)
     ys, xs = np.mgrid[0:sc.height, 0:sc.width]
@@ -674,13 +679,14 @@ def test_walked_interfaces_match_the_general_form(name, flatten, monkeypatch):
     assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_inst", False), ("sss_inst", True)])
+@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_inst", False), ("sss_inst", True)])
 def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch):
     """Subsurface materials under Integrator "path" in wavefront form (round 3): the vertex's shadow / MIS rays take the plain traversals, the path parks,
     its probe chain is walked hit by hit through the queues (k_sss_probe_step + k_trace<2, ..., TR>: count, choose, walk again up to the chosen hit --
     SeparableBSSRDF::Sample_Sp, core/bssrdf.cpp:249-326) and k_sss_entry shades the entry vertex (path.cpp:160-174).  PBRT_AMD_VOL_INLINE=1: the
     per-lane form (every lane traces its own rays inside k_shade_vol).  Both reproduce the reference's render with the same rays; sss_inst walks
-    its chains through TransformedPrimitives."""
+    its chains through TransformedPrimitives; sss_kd is a KdSubsurfaceMaterial under "volpath" in haze (homogeneous media, no interfaces: closed-form
+    transmittance on the queued rays, the chain carries its media for the entry vertex)."""
     monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
     fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     out = {}
@@ -700,8 +706,13 @@ def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch)
         out[form] = (img, {k: v[1] for k, v in t.items() if v[1]}, cnt)
         ctx.close()
     assert "anyhit" in out["walked"][1] and "mis_closest" in out["walked"][1] and "anyhit" not in out["general"][1]   # the queues ran / the lanes traced their own rays
-    for k in ("closest_rays", "shadow_rays", "camera_rays"):
-        assert out["walked"][2][k] == out["general"][2][k], k   # query for query the same rays
+    w, g = out["walked"][2], out["general"][2]
+    # the same rays -- minus the second walk of a chain whose chosen hit is among the first PT_SSS_KEEP counted ones (the walked form keeps those; the
+    # per-lane form always walks twice, the reference once with a list).  Under "volpath" the per-lane form's visibility queries are closest-hit queries.
+    wt, gt = w["closest_rays"] + w["shadow_rays"], g["closest_rays"] + g["shadow_rays"]
+    assert w["camera_rays"] == g["camera_rays"] and 0.9 * gt <= wt <= gt, (wt, gt)
+    if name != "sss_kd":
+        assert w["shadow_rays"] == g["shadow_rays"]
     assert out["walked"][2]["trace_guard_trips"] == 0
     assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
