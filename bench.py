@@ -280,6 +280,7 @@ def main():
                          "c2 = killeroo 1080p 128spp; c4 = bathroom-class 1080p 256spp maxdepth 30; "
                          "c5 = the San-Miguel-class scene at 3840x2160, 512 spp (33-bit Sobol' indices, 32 passes of 2^27 paths; tile-sharded with --gpus N)")
     ap.add_argument("--textured", action="store_true", help="c3 only: the stand-in with image-mapped / bump-mapped materials (SURVEY.md s.8 row f2)")
+    ap.add_argument("--smokebox", action="store_true", help="c3 only: a heterogeneous (grid) medium behind a BSDF-less box in the far half of the stand-in, VolPathIntegrator (split form of k_shade_vol: ratio tracking in the walked transmittance queries); PBRT_AMD_VOL_SPLIT=0 = the general form")
     ap.add_argument("--subsurface", action="store_true", help="c3 only: three of the stand-in's 24 materials become kdsubsurface (BSSRDF probe chains walked through the queues; SURVEY.md s.8 row f4); PBRT_AMD_VOL_INLINE=1 = the per-lane form")
     ap.add_argument("--leafmask", action="store_true", help="c3 only: the stand-in's leaf quads as alpha-masked meshes (a disc cut out of each by a float texture; SURVEY.md s.8 row f2 alpha masks), combinable with --volpath / --fogbox")
     ap.add_argument("--fogbox", action="store_true", help="c3 only: a bank of fog behind a BSDF-less box in the far half of the stand-in, Integrator \"volpath\" (medium interfaces: k_vol_tr)")
@@ -350,14 +351,14 @@ def main():
             time.sleep(0.2)
         workload = "Contemporary-Bathroom-class synthetic stand-in: glass/mirror/metal, %dx%d, %d spp, path maxdepth 30" % (args.res[0], args.res[1], spp)
     else:
-        key = "sanmiguel_synth_%dk_%dx%d_%dspp%s" % (args.tris // 1000, args.res[0], args.res[1], args.spp, ("_tex" if args.textured else "") + ("_haze" if args.volpath else "") + ("_fogbox" if args.fogbox else "") + ("_leafmask" if args.leafmask else "") + ("_sss" if args.subsurface else ""))
+        key = "sanmiguel_synth_%dk_%dx%d_%dspp%s" % (args.tris // 1000, args.res[0], args.res[1], args.spp, ("_tex" if args.textured else "") + ("_haze" if args.volpath else "") + ("_fogbox" if args.fogbox else "") + ("_leafmask" if args.leafmask else "") + ("_sss" if args.subsurface else "") + ("_smokebox" if args.smokebox else ""))
         d = os.path.join(bench_dir, key)
         scene_file = os.path.join(d, "sanmiguel_synth.pbrt")
         marker = os.path.join(d, ".done")
         if local_rank == 0 and not os.path.exists(marker):
             os.makedirs(d, exist_ok=True)
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris),
-                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", scene_file] + (["--textured"] if args.textured else []) + (["--haze"] if args.volpath else []) + (["--fogbox"] if args.fogbox else []) + (["--leafmask"] if args.leafmask else []) + (["--subsurface"] if args.subsurface else []),
+                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", scene_file] + (["--textured"] if args.textured else []) + (["--haze"] if args.volpath else []) + (["--fogbox"] if args.fogbox else []) + (["--leafmask"] if args.leafmask else []) + (["--subsurface"] if args.subsurface else []) + (["--smokebox"] if args.smokebox else []),
                                   stdout=sys.stderr)
             open(marker, "w").write("ok")
         while not os.path.exists(marker):
@@ -370,6 +371,8 @@ def main():
             workload = workload.replace("path maxdepth 5", "VOLPATH maxdepth 5 (row f4): camera and scene inside a homogeneous medium")
         if args.fogbox:
             workload = workload.replace("path maxdepth 5", "VOLPATH maxdepth 5 (row f4): a homogeneous medium behind a BSDF-less box in the far half of the scene")
+        if args.smokebox:
+            workload = workload.replace("path maxdepth 5", "VOLPATH maxdepth 5 (row f4): a heterogeneous (16 x 8 x 12 grid) medium behind a BSDF-less box in the far half of the scene")
         if args.subsurface:
             workload += "; SUBSURFACE variant (row f4): three of the 24 materials are kdsubsurface (BSSRDF probe chains)"
         if args.leafmask:
@@ -465,6 +468,8 @@ def main():
             wl_args += ["--leafmask"]
         if args.subsurface:
             wl_args += ["--subsurface"]
+        if args.smokebox:
+            wl_args += ["--smokebox"]
         if args.max_paths:
             wl_args += ["--max-paths", str(args.max_paths)]
         traffic = None

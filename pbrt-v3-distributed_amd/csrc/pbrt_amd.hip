@@ -1516,6 +1516,7 @@ struct mi_ctx {
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
+    bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSSRDF (BSDF-less interfaces / alpha masks: volTr)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
@@ -1743,7 +1744,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->n_tris && d->n_bvh_nodes == 0) return fail("mi_scene_upload: triangles without a BVH");
     // row f4: Integrator "volpath" and materials with a BSSRDF are shaded by k_shade_vol (pt_volpath.h)
     c->volKernel = d->integrator_type == MI_INTEGRATOR_VOLPATH || d->material_bssrdf != nullptr;
-    c->volWave = c->volTr = c->sssWave = false;
+    c->volWave = c->volTr = c->sssWave = c->volSplit = false;
     if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
     if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
     if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
@@ -2366,12 +2367,19 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         // masks (round 3) the shadow / MIS rays are WALKED segment by segment -- k_trace<..., TR> + k_vol_tr_step (DevVol::tr_queues) -- instead of going
         // through k_trace<2> / <1>: the walk's closest-hit kernel steps through interfaces and evaluates alphaMask (not shadowAlphaMask) exactly where
         // VisibilityTester::Tr's Scene::Intersect does (core/light.cpp:63-82, shapes/triangle.cpp:333-338)
+        // Grid media (round 3, split form): their Tr draws a data-dependent number of dimensions between the light sample and the continuation sample, so the
+        // vertex is shaded in two stages around the walks (DevVol::tr_dims; PBRT_AMD_VOL_SPLIT=0: such scenes keep the general form)
         c->volWave = v.handle_media && !d->material_bssrdf;
-        for (uint32_t i = 0; i < d->n_media && c->volWave; ++i) c->volWave = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
+        bool allHomogeneous = true;
+        for (uint32_t i = 0; i < d->n_media; ++i) allHomogeneous = allHomogeneous && d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
+        { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (!allHomogeneous && e && e[0] == '0') c->volWave = false; }
+        c->volSplit = c->volWave && !allHomogeneous;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') c->volWave = false; }   // A/B and parity tests of the general form
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && (c->hasNullMat || c->hasAlpha)) c->volWave = false; }   // =0: such scenes keep the general form (A/B)
-        c->volTr = c->volWave && (c->hasNullMat || c->hasAlpha);
+        c->volSplit = c->volSplit && c->volWave;
+        c->volTr = c->volWave && (c->hasNullMat || c->hasAlpha || c->volSplit);
         v.tr_queues = c->volTr ? 1 : 0;
+        v.tr_dims = c->volSplit ? 1 : 0;
         // BSSRDF materials under Integrator "path" (round 3): Sample_S draws its numbers before the probe chain is traced, and without media no visibility
         // query draws any -- the chains are walked through the queues and the vertex's direct-lighting rays take the plain shadow / MIS traversals
         // (k_trace<2> / <1>: Unoccluded / Intersect, as k_shade's).  PBRT_AMD_VOL_INLINE=1 keeps the per-lane form (A/B, parity tests).
@@ -2474,7 +2482,8 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(q_sorted, uint32_t, qcap);
     ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
     if (c->volTr || c->sssWave) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
-    if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_sss, uint32_t, qcap); }
+    if (c->sssWave) ALLOC(sss, SssRec, cap);
+    if (c->sssWave || c->volSplit) ALLOC(q_sss, uint32_t, qcap);
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
@@ -2586,6 +2595,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && !c->sssWave;
         if (c->sssWave) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW2, 0), 0, 3 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // probe queues (SHADOW2, MIS2) + QC_SSS
+        if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SSS, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // the vertices waiting for k_vol_continue
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
@@ -2704,6 +2714,12 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         if (left == 0) break;
                     }
                 }
+                toc(c);
+            }
+            if (c->volSplit) {   // second stage of the vertices whose direct-lighting rays have now consumed their dimensions
+                tic(c, MI_K_SHADE);
+                if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                else hipLaunchKernelGGL((k_vol_continue<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
                 toc(c);
             }
         } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)

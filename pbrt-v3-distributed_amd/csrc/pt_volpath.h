@@ -543,6 +543,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
         const bool active = i < n;
 #endif
         bool cont = false, wantProbe = false;   // wantProbe (walked BSSRDF probes, DevVol::sss_wave): the path waits for its probe chain instead of continuing
+        int wantSplit = 0;                      // split form (DevVol::tr_dims): 1 = a surface vertex, 2 = a medium vertex waits for its direct-lighting rays' transmittances (k_vol_continue)
+        V3 splitP;
         uint32_t slot = 0, rayKey = 0;
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
@@ -587,6 +589,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     const Float g = vol.media[medium].g;
                     L = L + beta * UniformSampleOneLightD<INST, LaneBSDF>(cx, &mi, medium, medium, nullptr, g);
                     betaNee = beta;
+                    if (WAVE && vol.tr_dims && (nee.wantShadow || nee.wantMis)) {   // split form: the visibility queries draw dimensions -- k_vol_continue samples the phase function after them
+                        wantSplit = 2; splitP = mi.p;
+                    } else {
                     Float u0, u1;
                     smp.Get2D(sc, &u0, &u1);
                     V3 wi;
@@ -595,6 +600,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     nd = wi;
                     specularBounce = false;
                     scattered = true;
+                    }
                 }
             } else if (alive) {
                 VHit vh;
@@ -639,11 +645,19 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                         if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST, SurfBSDF>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
                         betaNee = beta;
                         V3 wo = -rd, wi;
-                        Float pdf, u0, u1;
-                        int flags;
-                        smp.Get2D(sc, &u0, &u1);
-                        RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
-                        if (f.IsBlack() || pdf == 0.f) alive = false;
+                        Float pdf = 0, u0, u1;
+                        int flags = 0;
+                        RGB f(0.f);
+                        // split form (DevVol::tr_dims: a grid medium's Tr draws sampler dimensions, core/light.cpp:63-82, media/grid.cpp:89-118): the continuation is
+                        // sampled by k_vol_continue AFTER this vertex's shadow and MIS rays have been walked
+                        const bool split = WAVE && vol.tr_dims && (nee.wantShadow || nee.wantMis);
+                        if (split) wantSplit = 1;
+                        else {
+                            smp.Get2D(sc, &u0, &u1);
+                            f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                        }
+                        if (split) {
+                        } else if (f.IsBlack() || pdf == 0.f) alive = false;
                         else {
                             beta = beta * (f * AbsDot(wi, vh.is.ns) / pdf);
                             specularBounce = (flags & BSDF_SPECULAR) != 0;
@@ -702,9 +716,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                     }
                 }
             }
-            if (alive && wantProbe) {   // parked: beta, etaScale, the sampler state and the bounce count as they are now (k_sss_entry resumes)
+            if (!alive) wantSplit = 0;
+            if (alive && (wantProbe || wantSplit)) {   // parked: beta, etaScale, the sampler state and the bounce count as they are now (k_sss_entry / k_vol_continue resume)
                 ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
-                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17) | ((uint32_t)(wantSplit == 2) << 18));
+                if (wantSplit == 2) ps.rec[slot].pad2 = make_float4(__uint_as_float((uint32_t)medium), splitP.x, splitP.y, splitP.z);
             } else if (alive && scattered) {   // Russian roulette (volpath.cpp:183-189 / path.cpp:176-184); the loop's ++bounces
                 cont = true;
                 RGB rrBeta = beta * etaScale;
@@ -734,6 +750,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
             if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
             if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
+            if (vol.tr_dims) {   // split form: the vertices that wait for their transmittances (k_vol_continue's queue)
+                const uint32_t posB = wave_append(&ps.qcount[QCI(QC_SSS, qseg)], wantSplit != 0);
+                if (wantSplit) ps.q_sss[qbase + posB] = slot;
+            }
             if constexpr (!UMAT) {
                 if (vol.sss_wave) {   // the probe chains of this bounce: first queue of the walk (k_sss_probe_step)
                     const uint32_t posP = wave_append(&ps.qcount[QCI(QC_SHADOW2, qseg)], wantProbe);
@@ -780,12 +800,24 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
             const bool hitSurface = hit.x != TRAV_MISS;
             const Float tHit = __uint_as_float(hit.y);
             const bool opaque = hitSurface && (int)sc.tri_info[hit.x].y >= 0;
+            // split form (DevVol::tr_dims): Medium::Tr draws from the path's sampler (ratio tracking, media/grid.cpp:89-118) -- the shadow walk of a vertex runs
+            // to its end before its MIS walk starts (run_pass), k_vol_continue goes on from the dimension they leave behind
+            VSampler smp;
+            VSampler *sp = nullptr;
+            if (vol.tr_dims) {
+                const uint4 s4 = ps.rec[slot].smp;
+                smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+                smp.dimension = (int)s4.z;
+                smp.px = smp.py = 0;
+                smp.Prefetch(sc);
+                sp = &smp;
+            }
             if (MODE == 2) {
                 const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
                 const V3 o(o4.x, o4.y, o4.z), d(d4.x, d4.y, d4.z);
                 const int medium = __float_as_int(d4.w);
                 if (!opaque) {   // (an opaque surface in between: the light sample contributes nothing)
-                    if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, d, hitSurface ? tHit : o4.w, nullptr);
+                    if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, d, hitSurface ? tHit : o4.w, sp);
                     if (!hitSurface) {
                         if (!Tr.IsBlack()) {
                             const float4 c4 = ps.nee[slot].sh_c;
@@ -808,7 +840,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
                 const float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d;
                 const V3 o(o4.x, o4.y, o4.z), wi(d4.x, d4.y, d4.z);
                 const int medium = __float_as_int(o4.w);
-                if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, wi, hitSurface ? tHit : PT_INFINITY, nullptr);
+                if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, wi, hitSurface ? tHit : PT_INFINITY, sp);
                 if (hitSurface && !opaque) {   // interface: isect.SpawnRay(ray.d), medium = isect.GetMedium(d)
                     VHit vh;
                     HitToIsect(scp, &vol, hit.x, o, wi, hit.z, medium, false, &vh);
@@ -837,6 +869,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
                     }
                 }
             }
+            if (vol.tr_dims) ps.rec[slot].smp.z = (uint32_t)smp.dimension;
         }
         const uint32_t qseg = blockIdx.x & 7;
         const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
@@ -1027,5 +1060,106 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
         if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
         if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
+    }
+}
+
+// Second stage of a vertex in the split form (DevVol::tr_dims: some medium is a grid).  VolPathIntegrator::Li samples the continuation AFTER
+// UniformSampleOneLight (volpath.cpp:96-103, 125-135), and with a grid medium the visibility queries in between -- VisibilityTester::Tr, Scene::IntersectTr --
+// draw a data-dependent number of sampler dimensions (ratio tracking).  k_shade_vol<WAVE> therefore stops a vertex that has direct-lighting rays
+// after the light sample (beta, L, the sampler state and, for a medium vertex, the scattering point are parked in the PathRec; ray and hit are still
+// there), the walks consume their dimensions (k_vol_tr_step), and this kernel rebuilds the vertex the way k_shade_vol built it -- same code, same inputs --
+// and does the rest of the loop body: phase function / BSDF sample, throughput, eta scale, Russian roulette, ++bounces.
+template <bool INST>
+__global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
+    const DevScene &sc = *scp;
+    for (SegIter it(ps.qcount, QC_SSS, ps.seg_cap); it.more(); it.next()) {
+        const bool active = it.valid();
+        bool cont = false;
+        uint32_t slot = 0, rayKey = 0;
+        if (active) {
+            slot = ps.q_sss[it.item()];
+            const uint2 hr = ps.rec[slot].hit;
+            const float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, m4 = ps.rec[slot].pad2;
+            const uint4 s4 = ps.rec[slot].smp;
+            const V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            RGB beta(b4.x, b4.y, b4.z);
+            Float etaScale = b4.w;
+            int bounces = (int)(s4.w & 0xffffu);
+            bool specularBounce = false;
+            const bool noDiff = (s4.w >> 17) & 1u, mediumVertex = (s4.w >> 18) & 1u;
+            const int medium = (int)__float_as_uint(m4.x);
+            VSampler smp;
+            smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+            smp.dimension = (int)s4.z;
+            smp.px = smp.py = 0;
+            smp.Prefetch(sc);
+            V3 no, nd;
+            int nmedium = medium;
+            bool alive = true;
+            if (mediumVertex) {   // volpath.cpp:99-103
+                const V3 p(m4.y, m4.z, m4.w);
+                const Float g = vol.media[medium].g;
+                Float u0, u1;
+                smp.Get2D(sc, &u0, &u1);
+                V3 wi;
+                HGSample_p(g, -rd, &wi, u0, u1);
+                no = OffsetRayOrigin(p, V3(), V3(), wi);   // mi.SpawnRay(wi)
+                nd = wi;
+            } else {              // volpath.cpp:130-150
+                VHit vh;
+                HitToIsect(scp, &vol, hr.x, ro, rd, INST ? ps.rec[slot].pad0 : TRAV_NO_INSTANCE, medium, vol.textured != 0, &vh);
+                const int matIdx = (int)vh.tinfo.y;
+                mi_material laneMat;
+                if (vol.textured) {
+                    if (bounces == 0 && !noDiff) {
+                        float2 pf = ps.rec[slot].pfilm, ln = ps.rec[slot].lens;
+                        RayDiffT rdf = CameraDifferentials(&c_tex.camera, pf.x, pf.y, ln.x, ln.y, c_tex.spp, ro, rd);
+                        ComputeDifferentials(vh.is.p, vh.is.n, &vh.ix, rdf);
+                    }
+                    ComputeScatteringFunctionsT(sc.materials, matIdx, &vh.is, &vh.ix, &laneMat);
+                }
+                const mi_material *matPtr = vol.textured ? &laneMat : sc.materials + matIdx;
+                LaneBSDF bsdf(vh.is, matPtr);
+                const V3 wo = -rd;
+                V3 wi;
+                Float pdf, u0, u1;
+                int flags;
+                smp.Get2D(sc, &u0, &u1);
+                const RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                if (f.IsBlack() || pdf == 0.f) alive = false;
+                else {
+                    beta = beta * (f * AbsDot(wi, vh.is.ns) / pdf);
+                    specularBounce = (flags & BSDF_SPECULAR) != 0;
+                    if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                        Float eta = bsdf.m->eta;
+                        etaScale *= (Dot(wo, vh.is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                    }
+                    no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);   // isect.SpawnRay(wi)
+                    nd = wi;
+                    nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi);
+                }
+            }
+            if (alive) {   // Russian roulette (volpath.cpp:183-189); the loop's ++bounces
+                cont = true;
+                const RGB rrBeta = beta * etaScale;
+                if (rrBeta.MaxComponentValue() < sc.rr_threshold && bounces > 3) {
+                    const Float q = mx((Float).05, 1 - rrBeta.MaxComponentValue());
+                    if (smp.Get1D(sc) < q) cont = false;
+                    else beta = beta / (1 - q);
+                }
+                ++bounces;
+            }
+            if (cont) {
+                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
+                ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
+                ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
+                ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+                ps.rec[slot].pad2 = make_float4(__uint_as_float((uint32_t)nmedium), 0, 0, 0);
+            }
+        }
+        const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
+        const uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
     }
 }

@@ -25,6 +25,8 @@ struct DevVol {
     int32_t textured;                // some material is textured (c_tex.descs is set): lobe lists are built per hit
     int32_t tr_queues;               // wavefront form with BSDF-less interfaces between homogeneous media: shadow / MIS rays carry their light point and start
                                      // medium through the queues and k_vol_tr walks them interface by interface (pt_volpath.h)
+    int32_t tr_dims;                 // split form: some medium is a grid, whose Tr draws sampler dimensions -- tr_queues is on, k_vol_tr_step carries the path's sampler through the walks,
+                                     // k_shade_vol<WAVE> parks a vertex with direct-lighting rays after its light sample and k_vol_continue samples the continuation (pt_volpath.h)
     int32_t sss_wave;                // wavefront form of scenes with BSSRDF materials under Integrator "path": probe chains walked through the queues (pt_volpath.h: SssRec)
 };
 

@@ -390,6 +390,8 @@ def _config_scene(name, tmp):
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--out", out], stdout=subprocess.DEVNULL)
     elif name == "sanmiguel_leafmask":   # the same with its leaf quads as alpha-masked meshes (bench.py --leafmask): the traversal's wave-wide alpha phases (PT_ALPHA_DEFER)
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--leafmask", "--out", out], stdout=subprocess.DEVNULL)
+    elif name == "sanmiguel_smokebox":   # the same with a heterogeneous (grid) medium behind a BSDF-less box (bench.py --smokebox): the split form of k_shade_vol -- ratio tracking inside the walked transmittance queries, k_vol_continue
+        subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--smokebox", "--out", out], stdout=subprocess.DEVNULL)
     elif name == "sanmiguel_subsurface":   # the same with three kdsubsurface materials (bench.py --subsurface): BSSRDF probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
         subprocess.check_call([sys.executable, gen, "sanmiguel", "--tris", "200000", "--res", "240", "136", "--spp", "8", "--subsurface", "--out", out], stdout=subprocess.DEVNULL)
     else:                        # configs[3]: bathroom-class, glass + mirror + deep paths (maxdepth 30)
@@ -398,7 +400,7 @@ def _config_scene(name, tmp):
 
 
 @pytest.mark.parametrize("name,mode", [("killeroo", "general"), ("sanmiguel", "general"), ("bathroom", "general"),
-                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q"), ("sanmiguel_leafmask", "bvh4q"), ("sanmiguel_leafmask", "general"), ("sanmiguel_subsurface", "bvh4q")])
+                                       ("killeroo", "bvh4q"), ("sanmiguel", "bvh4q"), ("bathroom", "bvh4q"), ("sanmiguel_leafmask", "bvh4q"), ("sanmiguel_leafmask", "general"), ("sanmiguel_subsurface", "bvh4q"), ("sanmiguel_smokebox", "bvh4q")])
 def test_baseline_configs_reduced(name, mode, tmp_path):
     """GPU vs oracle on reduced-size versions of the BASELINE.json configs + ray accounting + a per-sample criterion
     (killeroo-simple has a Sphere light: it always runs the general kernel instance)."""
@@ -677,6 +679,35 @@ def test_walked_interfaces_match_the_general_form(name, flatten, monkeypatch):
     assert "anyhit" in out["walked"][1] and "mis_closest" in out["walked"][1] and "anyhit" not in out["general"][1]   # the walk ran / the lanes traced their own rays
     assert out["walked"][2]["closest_rays"] == out["general"][2]["closest_rays"] and out["walked"][2]["trace_guard_trips"] == 0   # segment for segment the same queries
     assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["vol_smoke", "vol_alpha"])
+def test_split_form_matches_the_general_form_on_grid_media(name, monkeypatch):
+    """Grid media in wavefront form (round 3): GridDensityMedium::Tr draws a data-dependent number of sampler dimensions (ratio tracking, media/grid.cpp:89-118)
+    between a vertex's light sample and its continuation sample.  k_shade_vol<WAVE> stops such a vertex after the light sample, its shadow ray is walked to
+    the end, then its MIS ray (k_trace<..., TR> + k_vol_tr_step with the path's sampler), then k_vol_continue samples the continuation from the dimension the
+    walks left behind.  PBRT_AMD_VOL_SPLIT=0: the general form (every lane traces its own rays).  Both reproduce the reference's render with the same
+    queries; a wrong order of draws would show at once (every later dimension of the path would change)."""
+    fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    out = {}
+    for form in ("split", "general"):
+        if form == "general":
+            monkeypatch.setenv("PBRT_AMD_VOL_SPLIT", "0")
+        else:
+            monkeypatch.delenv("PBRT_AMD_VOL_SPLIT", raising=False)
+        sc = pa.Scene(text=edge_scenes.scene(name))
+        ctx = pa.Context(sc)
+        ctx.timing_enable(True); ctx.counters_reset()
+        ctx.render()
+        t, cnt = ctx.timing(), ctx.counters()
+        img = sc.film_image(ctx.film())
+        frac, relmse = ol.image_metrics(img, fx)
+        assert frac >= 0.995 and relmse <= 1e-4, (form, frac, relmse)
+        out[form] = (img, {k: v[1] for k, v in t.items() if v[1]}, cnt)
+        ctx.close()
+    assert "anyhit" in out["split"][1] and "mis_closest" in out["split"][1] and "anyhit" not in out["general"][1]   # the walks ran / the lanes traced their own rays
+    assert out["split"][2]["closest_rays"] == out["general"][2]["closest_rays"] and out["split"][2]["trace_guard_trips"] == 0   # segment for segment the same queries
+    assert np.allclose(out["split"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_inst", False), ("sss_inst", True)])
