@@ -747,11 +747,24 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     d.film.max_sample_luminance = film.maxSampleLuminance;
     d.film.scale = film.scale;
     d.integrator.max_depth = maxDepth; d.integrator.rr_threshold = rrThreshold;
-    d.integrator.spp = (int32_t)sampler.samplesPerPixel;
-    if (auto ss = dynamic_cast<SobolSampler *>(&sampler)) {
+    // PBRT_AMD_FAST_SAMPLERS=1 (the CLI's --fast-samplers): the samplers with one random stream per tile render with the reference's SobolSampler at the same
+    // sample count -- wavefront speed instead of the reference's pixel values (the library would walk each tile serially)
+    Sampler *smp = &sampler;
+    std::unique_ptr<SobolSampler> fastSobol;
+    {
+        const char *fast = std::getenv("PBRT_AMD_FAST_SAMPLERS");
+        const bool tileSerial = dynamic_cast<RandomSampler *>(smp) || dynamic_cast<StratifiedSampler *>(smp) || dynamic_cast<ZeroTwoSequenceSampler *>(smp);
+        if (fast && fast[0] == '1' && tileSerial) {
+            fastSobol.reset(new SobolSampler(sampler.samplesPerPixel, sb));
+            smp = fastSobol.get();
+            Warning("PBRT_AMD_FAST_SAMPLERS: rendering with \"sobol\" at %d spp instead of the scene's sampler.", (int)smp->samplesPerPixel);
+        }
+    }
+    d.integrator.spp = (int32_t)smp->samplesPerPixel;
+    if (auto ss = dynamic_cast<SobolSampler *>(smp)) {
         d.integrator.sampler = MI_SAMPLER_SOBOL;
         d.integrator.sobol_resolution = ss->resolution; d.integrator.sobol_log2_resolution = ss->log2Resolution;
-    } else if (auto hs = dynamic_cast<HaltonSampler *>(&sampler)) {
+    } else if (auto hs = dynamic_cast<HaltonSampler *>(smp)) {
         d.integrator.sampler = MI_SAMPLER_HALTON;
         for (int i = 0; i < 2; ++i) {
             d.integrator.halton_base_scales[i] = hs->baseScales[i]; d.integrator.halton_base_exponents[i] = hs->baseExponents[i];
@@ -759,14 +772,14 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
         }
         d.integrator.halton_sample_stride = hs->sampleStride;
         d.integrator.halton_sample_at_center = hs->sampleAtPixelCenter ? 1 : 0;
-    } else if (dynamic_cast<RandomSampler *>(&sampler)) {   // ABI v11: the samplers with one PCG32 stream per tile (the library walks each tile's samples in this loop's order)
+    } else if (dynamic_cast<RandomSampler *>(smp)) {   // ABI v11: the samplers with one PCG32 stream per tile (the library walks each tile's samples in this loop's order)
         d.integrator.sampler = MI_SAMPLER_RANDOM;
-    } else if (auto st = dynamic_cast<StratifiedSampler *>(&sampler)) {
+    } else if (auto st = dynamic_cast<StratifiedSampler *>(smp)) {
         d.integrator.sampler = MI_SAMPLER_STRATIFIED;
         d.integrator.pixel_sampler_dims = (int32_t)st->samples1D.size();
         d.integrator.strat_samples[0] = st->xPixelSamples; d.integrator.strat_samples[1] = st->yPixelSamples;
         d.integrator.strat_jitter = st->jitterSamples ? 1 : 0;
-    } else if (auto zt = dynamic_cast<ZeroTwoSequenceSampler *>(&sampler)) {
+    } else if (auto zt = dynamic_cast<ZeroTwoSequenceSampler *>(smp)) {
         d.integrator.sampler = MI_SAMPLER_ZEROTWO;
         d.integrator.pixel_sampler_dims = (int32_t)zt->samples1D.size();
     } else

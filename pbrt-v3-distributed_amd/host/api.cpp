@@ -787,11 +787,21 @@ void pbrtWorldEnd() {
             if (PbrtOptions.quickRender) nsamp = 1;
             // MakeSampler (api.cpp:815-840): "halton" (pbrt's default) and "sobol" run on the GPU path
             std::shared_ptr<Sampler> sampler;
+            const char *fastEnv = std::getenv("PBRT_AMD_FAST_SAMPLERS");
+            const bool tileSerialName = renderOptions->SamplerName == "random" || renderOptions->SamplerName == "stratified" || renderOptions->SamplerName == "02sequence" ||
+                                        renderOptions->SamplerName == "lowdiscrepancy";
             if (renderOptions->SamplerName == "halton") {
                 bool atCenter = renderOptions->SamplerParams.FindOneBool("samplepixelcenter", false);
                 sampler = std::make_shared<HaltonSampler>(nsamp, smin, smax, atCenter);
-            } else if (renderOptions->SamplerName == "random" || renderOptions->SamplerName == "stratified" || renderOptions->SamplerName == "02sequence" ||
-                       renderOptions->SamplerName == "lowdiscrepancy") {
+            } else if (tileSerialName && (PbrtOptions.fastSamplers || (fastEnv && fastEnv[0] == '1'))) {
+                // the user's choice (--fast-samplers): an unbiased image of the same scene at wavefront speed, not the reference's pixel values
+                if (renderOptions->SamplerName == "stratified")
+                    nsamp = renderOptions->SamplerParams.FindOneInt("xsamples", 4) * renderOptions->SamplerParams.FindOneInt("ysamples", 4);
+                if (PbrtOptions.quickRender) nsamp = 1;
+                Warning("--fast-samplers: Sampler \"%s\" renders with \"sobol\" at %d spp (not the reference's image; without the flag the tile-serial rounds reproduce it).",
+                        renderOptions->SamplerName.c_str(), nsamp);
+                sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);
+            } else if (tileSerialName) {
                 // one PCG32 stream per tile: the device walks the tiles' samples in the reference's order (ABI v11, "tile-serial" -- the reference's image, slowly)
                 Sampler::Kind k = renderOptions->SamplerName == "random" ? Sampler::Random : (renderOptions->SamplerName == "stratified" ? Sampler::Stratified : Sampler::ZeroTwo);
                 sampler = std::make_shared<TileSerialSampler>(k, renderOptions->SamplerParams, smin, smax);

@@ -13,6 +13,8 @@ struct Options {   // core/pbrt.h:167-181 (the flags that make sense for this pa
     std::string imageFile;
     Float cropWindow[2][2] = {{0, 1}, {0, 1}};
     int nGpus = 1;               // --gpus N : tile-shard Render over N devices (in-process)
+    bool fastSamplers = false;   // --fast-samplers / PBRT_AMD_FAST_SAMPLERS=1: Sampler "random" / "stratified" / "02sequence" / "lowdiscrepancy" render with "sobol" at the same
+                                 // sample count (a warning says so) -- the wavefront pipeline at full speed instead of the reference's image through tile-serial rounds
     bool deferRender = false;    // WorldEnd keeps the built Scene/Integrator instead of rendering
 };
 

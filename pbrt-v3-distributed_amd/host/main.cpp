@@ -17,6 +17,8 @@ static void usage(const char *msg = nullptr) {
                          "  --help               Print this help text.\n"
                          "  --nthreads <num>     Host threads for scene construction (default: all cores).\n"
                          "  --outfile <filename> Write the final image to the given filename (.pfm, .exr).\n"
+                         "  --fast-samplers      Render scenes that name the random / stratified / 02sequence samplers with sobol (same sample count):\n"
+                         "                       full wavefront speed instead of the reference's exact image (one random stream per tile, walked serially).\n"
                          "  --quick              Automatically reduce a number of quality settings to render more quickly.\n"
                          "  --quiet              Suppress all text output other than error messages.\n");
     std::exit(msg ? 1 : 0);
@@ -36,6 +38,7 @@ int main(int argc, char *argv[]) {
             options.cropWindow[0][0] = std::atof(argv[++i]); options.cropWindow[0][1] = std::atof(argv[++i]);
             options.cropWindow[1][0] = std::atof(argv[++i]); options.cropWindow[1][1] = std::atof(argv[++i]);
         } else if (!std::strcmp(argv[i], "--quick") || !std::strcmp(argv[i], "-quick")) options.quickRender = true;
+        else if (!std::strcmp(argv[i], "--fast-samplers")) options.fastSamplers = true;
         else if (!std::strcmp(argv[i], "--quiet") || !std::strcmp(argv[i], "-quiet")) options.quiet = true;
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-help") || !std::strcmp(argv[i], "-h")) usage();
         else if (argv[i][0] == '-') usage((std::string("unknown option ") + argv[i]).c_str());

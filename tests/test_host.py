@@ -523,3 +523,19 @@ def test_beam_diffusion_table_matches_reference(built):
         assert L.pbrt_amd_bssrdf_table(float(t["g"]), float(t["eta"]), out.ctypes.data) == 0
         ref = np.concatenate([t["rho_samples"], t["radius_samples"], t["profile"], t["rho_eff"], t["profile_cdf"]])
         assert out.tobytes() == ref.tobytes(), (float(t["g"]), float(t["eta"]))
+
+
+def test_fast_samplers_option_renders_tile_serial_sampler_names_with_sobol(built, monkeypatch):
+    """--fast-samplers / PBRT_AMD_FAST_SAMPLERS=1 (host/api.cpp): scenes that name random / stratified / 02sequence / lowdiscrepancy are rendered with
+    sobol at the same sample count -- the user's choice of wavefront speed over the reference's pixel values.  Default: the tile-serial samplers."""
+    import edge_scenes
+    base = edge_scenes.scene("sampler_stratified")   # Sampler "stratified" xsamples x ysamples
+    import re
+    m = re.search(r'Sampler "stratified"[^\n]*', base)
+    nx, ny = (int(v) for v in re.findall(r'"integer [xy]samples" \[(\d+)\]', m.group(0)))
+    as_sobol = base.replace(m.group(0), 'Sampler "sobol" "integer pixelsamples" [%d]' % (nx * ny))
+    want = ol.render(pa.Scene(text=as_sobol), nthreads=4)[0]
+    default = ol.render(pa.Scene(text=base), nthreads=4)[0]
+    monkeypatch.setenv("PBRT_AMD_FAST_SAMPLERS", "1")
+    fast = ol.render(pa.Scene(text=base), nthreads=4)[0]
+    assert np.array_equal(fast, want) and not np.array_equal(default, want)

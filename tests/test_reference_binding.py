@@ -97,6 +97,29 @@ def test_edge_scene_through_the_stub_equals_pbrt_ref(name, tmp_path):
     assert (d == 0).mean() >= 0.995, float((d == 0).mean())
 
 
+def test_fast_samplers_through_the_stub_equals_pbrt_ref_with_sobol(tmp_path):
+    """PBRT_AMD_FAST_SAMPLERS=1 in the reference-side binding (integration/wavefrontpath.cpp): a scene that names the stratified sampler is handed over with
+    the reference's own SobolSampler at the same sample count -- the image equals pbrt_ref's render of the scene with Sampler "sobol" written into it."""
+    if not (os.access(REF, os.X_OK) and os.access(STUB, os.X_OK)):
+        pytest.skip("oracle/_ref/pbrt_ref[_wavefront] not built here (needs /root/reference)")
+    import re
+    base = edge_scenes.scene("sampler_stratified")
+    m = re.search(r'Sampler "stratified"[^\n]*', base)
+    nx, ny = (int(v) for v in re.findall(r'"integer [xy]samples" \[(\d+)\]', m.group(0)))
+    s1, s2 = str(tmp_path / "strat.pbrt"), str(tmp_path / "sobol.pbrt")
+    open(s1, "w").write(base)
+    open(s2, "w").write(base.replace(m.group(0), 'Sampler "sobol" "integer pixelsamples" [%d]' % (nx * ny)))
+    a, b = str(tmp_path / "stub.pfm"), str(tmp_path / "ref.pfm")
+    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_FAST_SAMPLERS="1")
+    r1 = subprocess.run([STUB, "--quiet", "--nthreads", "4", "--outfile", a, s1], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and os.path.exists(a), r1.stderr[-800:]
+    r2 = subprocess.run([REF, "--quiet", "--nthreads", "4", "--outfile", b, s2], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and os.path.exists(b), r2.stderr[-800:]
+    ia, ib = pa.read_pfm(a), pa.read_pfm(b)
+    d = np.abs(ia - ib).max(-1)
+    assert ia.shape == ib.shape and d.max() <= 5e-7 and (d == 0).mean() >= 0.995, (float(d.max()), float((d == 0).mean()))
+
+
 @pytest.mark.parametrize("name", edge_scenes.TEX_NAMES + ["tex_dof"])
 def test_texture_nodes_equal_the_reference_classes(name, tmp_path):
     """Row f2 at stage level against the reference's OWN texture classes: with PBRT_AMD_TEX_PROBE set the stub evaluates every Texture object the
