@@ -804,19 +804,22 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
             // to its end before its MIS walk starts (run_pass), k_vol_continue goes on from the dimension they leave behind
             VSampler smp;
             VSampler *sp = nullptr;
-            if (vol.tr_dims) {
-                const uint4 s4 = ps.rec[slot].smp;
-                smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
-                smp.dimension = (int)s4.z;
-                smp.px = smp.py = 0;
-                smp.Prefetch(sc);
-                sp = &smp;
-            }
+            auto samplerFor = [&](int m) {   // only a segment inside a grid medium draws: the others leave the path's sampler alone
+                if (vol.tr_dims && m >= 0 && vol.media[m].type != MI_MEDIUM_HOMOGENEOUS) {
+                    const uint4 s4 = ps.rec[slot].smp;
+                    smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
+                    smp.dimension = (int)s4.z;
+                    smp.px = smp.py = 0;
+                    smp.Prefetch(sc);
+                    sp = &smp;
+                }
+            };
             if (MODE == 2) {
                 const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
                 const V3 o(o4.x, o4.y, o4.z), d(d4.x, d4.y, d4.z);
                 const int medium = __float_as_int(d4.w);
                 if (!opaque) {   // (an opaque surface in between: the light sample contributes nothing)
+                    samplerFor(medium);
                     if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, d, hitSurface ? tHit : o4.w, sp);
                     if (!hitSurface) {
                         if (!Tr.IsBlack()) {
@@ -840,6 +843,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
                 const float4 o4 = ps.nee[slot].mi_o, d4 = ps.nee[slot].mi_d;
                 const V3 o(o4.x, o4.y, o4.z), wi(d4.x, d4.y, d4.z);
                 const int medium = __float_as_int(o4.w);
+                samplerFor(medium);
                 if (medium >= 0) Tr = Tr * MediumTr(scp, vol.media + medium, o, wi, hitSurface ? tHit : PT_INFINITY, sp);
                 if (hitSurface && !opaque) {   // interface: isect.SpawnRay(ray.d), medium = isect.GetMedium(d)
                     VHit vh;
@@ -869,7 +873,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
                     }
                 }
             }
-            if (vol.tr_dims) ps.rec[slot].smp.z = (uint32_t)smp.dimension;
+            if (sp) ps.rec[slot].smp.z = (uint32_t)smp.dimension;
         }
         const uint32_t qseg = blockIdx.x & 7;
         const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
