@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 11
+#define MI_ABI_VERSION 12
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -295,6 +295,10 @@ typedef struct mi_film {     /* Film, core/film.cpp:45-86 */
 #define MI_SAMPLER_RANDOM 2
 #define MI_SAMPLER_STRATIFIED 3
 #define MI_SAMPLER_ZEROTWO 4
+/* ABI v12: MaxMinDistSampler (samplers/maxmin.{h,cpp}) -- a PixelSampler like ZEROTWO whose FIRST 2D dimension is (i / spp, C i) with the generator matrix
+ * C = CMaxMinDist[log2 spp] (core/lowdiscrepancy.cpp: a table of matrices found by search, Gruenschloss et al.; it cannot be re-derived, so the caller
+ * passes the matrix it selected: the reference-side binding reads it from the reference's own sampler object).  spp: a power of two <= 2^16. */
+#define MI_SAMPLER_MAXMIN 5
 #define MI_SAMPLER_IS_TILE_SERIAL(s) ((s) >= MI_SAMPLER_RANDOM)
 
 typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
@@ -320,6 +324,7 @@ typedef struct mi_integrator { /* PathIntegrator + SobolSampler parameters */
     int32_t pixel_sampler_dims;         /* "dimensions" (nSampledDimensions, default 4); 0 for RANDOM */
     int32_t strat_samples[2];           /* "xsamples", "ysamples" (default 4 x 4) */
     int32_t strat_jitter;               /* "jitter" (default true) */
+    uint32_t maxmin_matrix[32];         /* MI_SAMPLER_MAXMIN: MaxMinDistSampler::CPixel[0..31] (the 32 columns of CMaxMinDist[Log2Int(spp)]) */
 } mi_integrator;
 
 /* ---------------------------------------------------------------- the scene --------- */

@@ -70,6 +70,7 @@
 #include "samplers/sobol.h"
 #include "samplers/stratified.h"
 #include "samplers/zerotwosequence.h"
+#include "samplers/maxmin.h"
 #include "scene.h"
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
@@ -753,7 +754,7 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     std::unique_ptr<SobolSampler> fastSobol;
     {
         const char *fast = std::getenv("PBRT_AMD_FAST_SAMPLERS");
-        const bool tileSerial = dynamic_cast<RandomSampler *>(smp) || dynamic_cast<StratifiedSampler *>(smp) || dynamic_cast<ZeroTwoSequenceSampler *>(smp);
+        const bool tileSerial = dynamic_cast<RandomSampler *>(smp) || dynamic_cast<StratifiedSampler *>(smp) || dynamic_cast<ZeroTwoSequenceSampler *>(smp) || dynamic_cast<MaxMinDistSampler *>(smp);
         if (fast && fast[0] == '1' && tileSerial) {
             fastSobol.reset(new SobolSampler(sampler.samplesPerPixel, sb));
             smp = fastSobol.get();
@@ -782,8 +783,12 @@ std::unique_ptr<Flat> FlattenScene(const Scene &scene, const Camera &cam, Sample
     } else if (auto zt = dynamic_cast<ZeroTwoSequenceSampler *>(smp)) {
         d.integrator.sampler = MI_SAMPLER_ZEROTWO;
         d.integrator.pixel_sampler_dims = (int32_t)zt->samples1D.size();
+    } else if (auto mm = dynamic_cast<MaxMinDistSampler *>(smp)) {   // ABI v12: the generator matrix the reference's sampler selected (CMaxMinDist[Log2Int(spp)], maxmin.h:74-77)
+        d.integrator.sampler = MI_SAMPLER_MAXMIN;
+        d.integrator.pixel_sampler_dims = (int32_t)mm->samples1D.size();
+        for (int i = 0; i < 32; ++i) d.integrator.maxmin_matrix[i] = mm->CPixel[i];
     } else
-        return fail("sampler is none of sobol, halton, random, stratified, 02sequence");
+        return fail("sampler is none of sobol, halton, random, stratified, 02sequence, maxmindist");
     return fs;
 }
 }  // namespace

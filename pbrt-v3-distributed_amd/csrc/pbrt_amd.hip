@@ -348,7 +348,19 @@ __global__ void __launch_bounds__(PT_BLOCK) k_pix_start_pixel(DevScene sc, const
                     }
                 PixShuffle<2>(p, n, state, inc);
             }
-        } else if (sc.sampler_type == MI_SAMPLER_ZEROTWO) {   // ZeroTwoSequenceSampler::StartPixel zerotwosequence.cpp:53-60: VanDerCorput / Sobol2D (lowdiscrepancy.h:144-226), one value per pixel sample
+        } else if (sc.sampler_type == MI_SAMPLER_ZEROTWO || sc.sampler_type == MI_SAMPLER_MAXMIN) {   // ZeroTwoSequenceSampler::StartPixel zerotwosequence.cpp:53-60: VanDerCorput / Sobol2D (lowdiscrepancy.h:144-226), one value per pixel sample
+            const bool maxmin = sc.sampler_type == MI_SAMPLER_MAXMIN;
+            if (maxmin) {   // MaxMinDistSampler::StartPixel maxmin.cpp:41-47: samples2D[0][i] = (i / spp, SampleGeneratorMatrix(CPixel, i)), shuffled FIRST; then as above from 2D dimension 1
+                const Float invSPP = (Float)1 / spp;
+                for (int k = 0; k < spp; ++k) {
+                    uint32_t v = 0;   // MultiplyGenerator lowdiscrepancy.h:128-133
+                    for (uint32_t a = (uint32_t)k, c = 0; a != 0; ++c, a >>= 1) if (a & 1u) v ^= sc.pix_maxmin[c];
+                    const Float f = v * (Float)0x1p-32;
+                    s2[2 * k] = k * invSPP;
+                    s2[2 * k + 1] = f < PT_ONE_MINUS_EPS ? f : PT_ONE_MINUS_EPS;
+                }
+                PixShuffle<2>(s2, spp, state, inc);
+            }
             for (int d = 0; d < nd; ++d) {
                 float *p = s1 + (size_t)d * spp;
                 uint32_t v = Pcg32Next(state, inc);   // scramble; GrayCodeSample (lowdiscrepancy.h:113-126) over CVanDerCorput[k] = 1 << (31 - k)
@@ -360,7 +372,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_pix_start_pixel(DevScene sc, const
                 for (int k = 0; k < spp; ++k) PixShuffle<1>(p + k, 1, state, inc);   // Shuffle(samples + i, 1, 1, rng): one number each
                 PixShuffle<1>(p, spp, state, inc);
             }
-            for (int d = 0; d < nd; ++d) {
+            for (int d = maxmin ? 1 : 0; d < nd; ++d) {
                 float *p = s2 + 2 * (size_t)d * spp;
                 uint32_t v0 = Pcg32Next(state, inc), v1 = Pcg32Next(state, inc);
                 for (uint32_t k = 0; k < (uint32_t)spp; ++k) {
@@ -2231,7 +2243,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.sobol_resolution = d->integrator.sobol_resolution; sc.sobol_log2_resolution = d->integrator.sobol_log2_resolution;
     sc.rr_threshold = d->integrator.rr_threshold;
     sc.sampler_type = d->integrator.sampler;
-    if (sc.sampler_type < MI_SAMPLER_SOBOL || sc.sampler_type > MI_SAMPLER_ZEROTWO) return fail("mi_scene_upload: unknown sampler");
+    if (sc.sampler_type < MI_SAMPLER_SOBOL || sc.sampler_type > MI_SAMPLER_MAXMIN) return fail("mi_scene_upload: unknown sampler");
+    sc.pix_maxmin = nullptr;
     sc.pix_rng = nullptr; sc.pix_s1 = sc.pix_s2 = nullptr; sc.pix_nd = 0; sc.strat_nx = sc.strat_ny = 1; sc.strat_jitter = 0;
     if (MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type)) {   // one PCG32 stream per tile + the current pixel's precomputed dimensions
         const mi_integrator &in = d->integrator;
@@ -2241,6 +2254,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         if (sc.sampler_type == MI_SAMPLER_STRATIFIED && (sc.strat_nx < 1 || sc.strat_ny < 1 || (int64_t)sc.strat_nx * sc.strat_ny != sc.spp))
             return fail("mi_scene_upload: stratified sampler: spp != xsamples * ysamples");
         if (sc.sampler_type == MI_SAMPLER_ZEROTWO && (sc.spp & (sc.spp - 1))) return fail("mi_scene_upload: 02sequence sampler: spp is not a power of two");
+        if (sc.sampler_type == MI_SAMPLER_MAXMIN) {   // maxmin.h:54-77: a power of two <= 2^16; samples2D[0] is written unconditionally -> at least one sampled dimension
+            if ((sc.spp & (sc.spp - 1)) || sc.spp > 65536 || sc.pix_nd < 1) return fail("mi_scene_upload: maxmindist sampler: spp must be a power of two <= 65536 and dimensions >= 1");
+            DevBuf &b = next();
+            if (upload(c, b, in.maxmin_matrix, sizeof(in.maxmin_matrix))) return -1;
+            sc.pix_maxmin = b.as<uint32_t>();
+        }
         const size_t nTiles = (size_t)((d->film.sample_max[0] - d->film.sample_min[0] + 15) / 16) * (size_t)((d->film.sample_max[1] - d->film.sample_min[1] + 15) / 16);
         { DevBuf &b = next(); if (b.alloc(std::max<size_t>(1, nTiles) * 2 * sizeof(unsigned long long))) return -1; sc.pix_rng = b.as<unsigned long long>(); }
         const size_t nv = std::max<size_t>(1, nTiles * (size_t)sc.pix_nd * (size_t)sc.spp);

@@ -105,6 +105,7 @@ struct DevScene {
     // the tile-serial samplers (ABI v11: MI_SAMPLER_RANDOM / STRATIFIED / ZEROTWO): per 16x16 tile (global tile index) its PCG32 stream and the
     // current pixel's precomputed dimensions (PixelSampler::samples1D / samples2D, core/sampler.h:118-121)
     unsigned long long *pix_rng;          // [2 * tile]: state, inc
+    const uint32_t *pix_maxmin;           // MI_SAMPLER_MAXMIN: the 32 columns of the generator matrix of the first 2D dimension (ABI v12)
     float *pix_s1;                        // [(tile * pix_nd + d) * spp + s]
     float *pix_s2;                        // [2 * ((tile * pix_nd + d) * spp + s)]
     int32_t pix_nd, strat_nx, strat_ny, strat_jitter;

@@ -806,7 +806,7 @@ void pbrtWorldEnd() {
                 Sampler::Kind k = renderOptions->SamplerName == "random" ? Sampler::Random : (renderOptions->SamplerName == "stratified" ? Sampler::Stratified : Sampler::ZeroTwo);
                 sampler = std::make_shared<TileSerialSampler>(k, renderOptions->SamplerParams, smin, smax);
             } else {
-                if (renderOptions->SamplerName != "sobol")   // "maxmindist" (its generator matrices are a table of the reference's) and unknown names
+                if (renderOptions->SamplerName != "sobol")   // "maxmindist" (ABI v12 takes its generator matrix from the caller: the reference-side binding has the reference's CMaxMinDist table, this host has not) and unknown names
                     Warning("Sampler \"%s\" is not implemented on the GPU path (\"sobol\", \"halton\", \"random\", \"stratified\" and \"02sequence\" are); rendering with \"sobol\" at %d spp.",
                             renderOptions->SamplerName.c_str(), nsamp);
                 sampler = std::make_shared<SobolSampler>(nsamp, smin, smax);

@@ -160,10 +160,14 @@ def sampler_scene(name):
         return with_sampler(scene("crop"), 'Sampler "02sequence" "integer pixelsamples" [4]')
     if name == "sampler_lowdisc_vol":  # "lowdiscrepancy" = 02sequence, 3 -> 4 samples; volpath in fog: data-dependent numbers of draws per path
         return with_sampler(scene("vol_fog"), 'Sampler "lowdiscrepancy" "integer pixelsamples" [3] "integer dimensions" [2]')
+    if name == "sampler_maxmin":       # MaxMinDistSampler (ABI v12): 6 -> 8 samples, 3 precomputed dimensions; depth of field: the lens sample is 2D dimension 1 (Sobol2D), the film
+        # sample 2D dimension 0 (the CMaxMinDist matrix).  Only through the reference-side binding: the matrix is the reference's (STUB_ONLY_SAMPLER_NAMES)
+        return with_sampler(scene("dof"), 'Sampler "maxmindist" "integer pixelsamples" [6] "integer dimensions" [3]')
     raise KeyError(name)
 
 
 SAMPLER_NAMES = ["sampler_random", "sampler_stratified", "sampler_strat_d1", "sampler_02sequence", "sampler_lowdisc_vol"]
+STUB_ONLY_SAMPLER_NAMES = ["sampler_maxmin"]   # this repository's own host has no CMaxMinDist table (it renders such scenes with sobol + a warning)
 
 
 def scene(name):

@@ -1017,3 +1017,10 @@ def test_baseline_config_reduced_with_subsurface_materials_and_with_a_grid_mediu
     """the reduced C3 stand-in with three kdsubsurface materials (bench.py --subsurface: walked probe chains) and with a heterogeneous medium behind a
     BSDF-less box (bench.py --smokebox: the split form), against the oracle -- same checks as test_baseline_configs_reduced"""
     test_baseline_configs_reduced(name, "bvh4q", tmp_path)
+
+
+def test_reference_host_drives_the_device_with_the_maxmindist_sampler(tmp_path):
+    """Sampler "maxmindist" (ABI v12, MI_SAMPLER_MAXMIN): the reference-side binding hands the generator matrix of the reference's own MaxMinDistSampler
+    (CMaxMinDist[log2 spp], samplers/maxmin.h:74-77) over with the scene; the device draws the first 2D dimension from it and the rest like 02sequence
+    (k_pix_start_pixel), tile-serially.  Fixture: pbrt_ref's render (tools/gen_golden.py)."""
+    test_reference_host_drives_the_device("sampler_maxmin", tmp_path)

@@ -57,7 +57,7 @@ import edge_scenes
 
 EDGE_CASES = ["infinite", "infinite_only", "infinite_xf", "envmap", "envmap_power", "spot", "spheres", "dof", "crop", "clamp", "onetri",
               # ABI v11: the reference's RandomSampler / StratifiedSampler / ZeroTwoSequenceSampler objects handed over (one PCG32 stream per tile)
-              "sampler_random", "sampler_stratified", "sampler_strat_d1", "sampler_02sequence", "sampler_lowdisc_vol",
+              "sampler_random", "sampler_stratified", "sampler_strat_d1", "sampler_02sequence", "sampler_lowdisc_vol", "sampler_maxmin",
               "vol_fog", "vol_smoke", "vol_glass", "vol_none",
               # two-level instancing: the reference's TransformedPrimitives and per-object BVHAccels handed over as mi_instance / mi_object
               "instances", "vol_inst", "instances_one",
@@ -93,6 +93,14 @@ def test_edge_scene_through_the_stub_equals_pbrt_ref(name, tmp_path):
     ia, ib = pa.read_pfm(a), pa.read_pfm(b)
     assert ia.shape == ib.shape
     d = np.abs(ia - ib).max(-1)
+    if name == "sampler_maxmin":
+        # MaxMinDistSampler's first film sample of every pixel sits EXACTLY on the pixel's left edge (i / spp with i = 0): under the box filter it also counts for
+        # the pixel to the left -- for the first column of a 16 x 16 tile that is a pixel of the NEIGHBOUR tile, whose FilmTile the reference converts to XYZ and
+        # merges separately (film.cpp:117-130: XYZ(a) + XYZ(b)), where one film of RGB sums converts once (XYZ(a + b)): the last column and the last row of each
+        # tile may differ by one ulp, every other pixel is bit-identical
+        border = (np.arange(ia.shape[1]) % 16 == 15)[None, :] | (np.arange(ia.shape[0]) % 16 == 15)[:, None]   # (the sample sits on the pixel's CORNER: C * 0 = 0 too)
+        assert (d[~border] == 0).all() and d.max() <= 1e-6 * max(1.0, float(np.abs(ib).max())), (float(d.max()), float((d[~border] == 0).mean()))
+        return
     assert d.max() <= 5e-7, float(d.max())
     assert (d == 0).mean() >= 0.995, float((d == 0).mean())
 

@@ -297,7 +297,8 @@ class Gen:
         spp = int(g.pick([1, 2, 3, 4]))
         if getattr(self, "pixel_samplers", False):   # --pixel-samplers: the samplers with one PCG32 stream per tile (own generator: the other choices of a seed stay what they were)
             q = np.random.default_rng(self.seed + 991)
-            k = ["random", "stratified", "02sequence", "lowdiscrepancy"][int(q.integers(0, 4))]
+            kinds = ["random", "stratified", "02sequence", "lowdiscrepancy"] + (["maxmindist", "maxmindist"] if getattr(self, "stub", False) else [])   # (the CMaxMinDist matrices are the reference's: only its own host can name that sampler)
+            k = kinds[int(q.integers(0, len(kinds)))]
             if k == "stratified":
                 s += 'Sampler "stratified" "integer xsamples" [%d] "integer ysamples" [%d]%s%s\n' % (
                     int(q.integers(1, 4)), int(q.integers(1, 3)), ' "bool jitter" ["false"]' if q.random() < .25 else "", ' "integer dimensions" [%d]' % int(q.integers(1, 7)) if q.random() < .5 else "")
@@ -404,7 +405,7 @@ def device_mode(a):
     bad = refused = done = invalid = 0
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers
+        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers; gen.stub = a.stub
         text = gen.scene(a.res, a.media)
         if a.instanced_only and "ObjectInstance" not in text:
             continue
@@ -482,7 +483,7 @@ def main():
     probes = {"rays": 0, "tex_nodes": 0}
     for i in range(a.n):
         seed = a.seed * 100000 + i
-        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers
+        gen = Gen(seed); gen.sss = a.sss; gen.pixel_samplers = a.pixel_samplers; gen.stub = a.stub
         text = gen.scene(a.res, a.media)
         if a.spectra: text = with_spectra(text, seed)
         fn = os.path.join(tmp, "s.pbrt"); open(fn, "w").write(text)

@@ -96,7 +96,7 @@ def edge_fixtures(tmp):
     and its textured scenes (image / procedural textures, mappings, bump maps, alpha masks, textured material parameters)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import edge_scenes
-    for name in edge_scenes.NAMES + edge_scenes.C5_NAMES + edge_scenes.TEX_NAMES + edge_scenes.TEX_ORACLE_ONLY + ["instances2"] + edge_scenes.VOL_NAMES + edge_scenes.SSS_NAMES + edge_scenes.SAMPLER_NAMES:
+    for name in edge_scenes.NAMES + edge_scenes.C5_NAMES + edge_scenes.TEX_NAMES + edge_scenes.TEX_ORACLE_ONLY + ["instances2"] + edge_scenes.VOL_NAMES + edge_scenes.SSS_NAMES + edge_scenes.SAMPLER_NAMES + edge_scenes.STUB_ONLY_SAMPLER_NAMES:
         f = os.path.join(tmp, "e.pbrt"); open(f, "w").write(edge_scenes.scene(name))
         out = os.path.join(OUT, "edge_%s.pfm" % name)
         subprocess.check_call([os.path.join(REF, "pbrt_ref"), "--quiet", "--nthreads", "1", "--outfile", out, f])
