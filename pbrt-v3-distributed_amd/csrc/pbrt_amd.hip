@@ -2793,6 +2793,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                     }
                 }
                 toc(c);
+                if (left) return fail("mi_render: a BSSRDF probe chain did not end within 16384 segments");   // (every segment starts behind the previous hit: no real chain comes near)
                 HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
                 tic(c, MI_K_SHADE);
                 if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);

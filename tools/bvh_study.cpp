@@ -462,7 +462,9 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
     for (int64_t base = 0; base < n;) {   // one wave at a time over a contiguous slice of the rays (a wave's batches come from one queue segment)
         int64_t sliceEnd = std::min<int64_t>(n, base + 4096);
         int64_t next = base;
-        Lane L[64];
+        const int S = policy == 6 ? 2 : 1;   // ray slots per lane
+        std::vector<Lane> L(64 * S);
+        int pref[64] = {0};
         const bool cullPop = nodeSteps >= 1000;   // nodeSteps + 1000: drop popped entries whose entry distance is not below the current tMax (PT_STACK_T)
         if (cullPop) nodeSteps -= 1000;
         auto pop = [&](Lane &l) {
@@ -495,7 +497,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
         auto atLeaf = [&](const Lane &l) { return l.active && l.cur != DONE && (l.cur & LEAF); };
         while (true) {
             int nIdle = 0; for (auto &l : L) nIdle += !l.active;
-            if (nIdle >= refill && next < sliceEnd) {
+            if (nIdle >= refill * S && next < sliceEnd) {
                 for (auto &l : L) if (!l.active && next < sliceEnd) {
                     const mi_ray &r = rays[next++]; ++nrays;
                     for (int a = 0; a < 3; ++a) { l.o[a] = r.o[a]; l.dir[a] = r.d[a]; l.inv[a] = 1.0 / r.d[a]; }
@@ -555,6 +557,38 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                         } }
                     }
                     for (int li = 0; li < 64; ++li) { Lane &l = L[li]; l.parked = q[li].empty() ? DONE : 0u; }
+                } else if (policy == 6) {
+                    // TWO rays per lane (slots 2 li, 2 li + 1), each with policy 3's state machine (one parked leaf per ray): in a node phase a lane steps ONE of its
+                    // rays that wants a node step, in a leaf phase it tests ONE parked triangle of one of its rays -- a lane idles only when NEITHER ray wants the
+                    // phase.  What it would cost on the device: the second ray's ~40 registers (or its state in LDS) and the selects between the two states.
+                    auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };
+                    for (int g = 0; g < nodeSteps; ++g) {
+                        int nWant = 0; for (int li = 0; li < 64; ++li) nWant += atNode(L[2 * li]) || atNode(L[2 * li + 1]);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (int li = 0; li < 64; ++li) {
+                            int s = 2 * li + pref[li];
+                            if (!atNode(L[s])) s ^= 1;
+                            if (!atNode(L[s])) continue;
+                            nodeStep(L[s]); if (atLeaf(L[s]) && L[s].parked == DONE) park(L[s]);
+                            pref[li] ^= 1;
+                        }
+                        int nPend = 0; for (int li = 0; li < 64; ++li) nPend += (L[2 * li].active && L[2 * li].parked != DONE) || (L[2 * li + 1].active && L[2 * li + 1].parked != DONE);
+                        if (nPend >= leafMin) break;
+                    }
+                    int nPend = 0; for (int li = 0; li < 64; ++li) nPend += (L[2 * li].active && L[2 * li].parked != DONE) || (L[2 * li + 1].active && L[2 * li + 1].parked != DONE);
+                    if (nPend) {
+                        ++phL; laL += nPend;
+                        for (int li = 0; li < 64; ++li) {
+                            int s = 2 * li + pref[li];
+                            if (!(L[s].active && L[s].parked != DONE)) s ^= 1;
+                            Lane &l = L[s];
+                            if (!(l.active && l.parked != DONE)) continue;
+                            triStep(l, l.parked);
+                            if (--l.parkedCount > 0) ++l.parked;
+                            else { l.parked = DONE; if (atLeaf(l)) park(l); }
+                        }
+                    }
                 } else if (policy == 3) {
                     // one pending leaf per lane, tested ONE triangle per leaf phase while the lane goes on with node steps (speculative: stale tMax)
                     auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };
@@ -600,7 +634,7 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                 }
                 for (auto &l : L) if (l.active && l.cur == DONE && l.parked == DONE) l.active = false;
                 nAct = 0; for (auto &l : L) nAct += l.active;
-                if (nAct == 0 || (mayRefill && nAct <= 64 - refill)) break;
+                if (nAct == 0 || (mayRefill && nAct <= (64 - refill) * S)) break;
             }
         }
         base = sliceEnd;

@@ -80,6 +80,8 @@ def main():
                                         ("pending leaf, <= 4 / 24, refill 8", 3, 4, 24, 8), ("pending leaf, <= 8 / 24, refill 8", 3, 8, 24, 8), ("pending leaf, <= 4 / 24, refill 24", 3, 4, 24, 24),
                                         ("2 pending leaves, <= 8 / 24", 4, 8, 24, 16), ("2 pending leaves, <= 4 / 24, refill 8", 4, 4, 24, 8), ("3 pending leaves, <= 8 / 24", 5, 8, 24, 16),
                                         ("pending leaf, <= 8 / 24 + entries beyond the hit dropped at pop", 3, 1008, 24, 16), ("today's policy + dropped at pop", 0, 1008, 24, 16),
+                                        ("TWO rays per lane, each with a pending leaf, <= 8 / 24, refill 16 lanes' worth", 6, 8, 24, 16), ("two rays per lane, <= 8 / 32", 6, 8, 32, 16), ("two rays per lane, <= 8 / 40", 6, 8, 40, 16),
+                                        ("two rays per lane, <= 8 / 48", 6, 8, 48, 16), ("two rays per lane, <= 16 / 48", 6, 16, 48, 16), ("two rays per lane, <= 8 / 40, refill 8", 6, 8, 40, 8), ("two rays per lane, <= 8 / 56", 6, 8, 56, 16),
                                         ("postponed leaves, <= 8 / 24", 2, 8, 24, 16), ("postponed leaves, <= 16 / 32", 2, 16, 32, 16), ("postponed leaves, <= 32 / 48", 2, 32, 48, 16)):
             out = np.zeros(8)
             L.bvh_study_wavesim(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), pol, ns, lm, rf, out.ctypes.data_as(C.c_void_p))
