@@ -1530,7 +1530,7 @@ struct mi_ctx {
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
-    bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>): homogeneous media only, no BSSRDF (BSDF-less interfaces / alpha masks: volTr)
+    bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
     const DevScene *scDev = nullptr;         // DevScene in HBM: k_shade_vol's out-of-line routines take it by pointer
@@ -2650,7 +2650,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON, pixSmp = MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
-            if (c->volKernel) {   // row f4: media / BSSRDF -- transmittance, MIS and probe rays are traced by the shading lanes themselves (pt_volpath.h)
+            if (c->volKernel) {   // row f4: media / BSSRDF (pt_volpath.h: the general form traces transmittance, MIS and probe rays in the shading lanes, the wavefront forms queue them)
                 const dim3 gw(c->gridShade);
 #define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
                 const bool umat = !c->vol.textured && !c->vol.bssrdf;   // constant lobe lists only: wave-uniform material access (the UMAT instance compiles the BSSRDF branch out)

@@ -3,13 +3,21 @@
 //
 // Place in the wavefront pipeline: path-extension rays still go through k_trace<0> and the material sort -- that is where the time
 // goes -- and this kernel replaces k_shade.  What differs from k_shade is WHERE the secondary rays are traced: the reference draws
-// sampler dimensions inside its visibility code (ratio tracking in Medium::Tr, core/light.cpp:63-82, core/scene.cpp:56-70) and inside
-// the BSSRDF probe, BEFORE the continuation direction is sampled, and the count is data dependent.  The dimension stream of a path is
-// therefore only reproducible if those rays are resolved in sequence.  In the general form (WAVE = false) every lane walks the same general
-// BVH4 steps the traversal kernels use (TravNodeStep / TravLeafStep with spheres, alpha masks and instances) for its own transmittance, MIS and
-// probe rays, on an LDS stack of its own; scenes whose media are all homogeneous and that have no BSDF-less interfaces, masks or BSSRDFs draw
-// nothing there and send those rays through the shadow / MIS queues instead (WAVE = true, see NeeOut).  Included by pbrt_amd.hip after
-// PathState / ChunkIter / DynIter / wave_append.
+// sampler dimensions inside its visibility code (ratio tracking in GridDensityMedium::Tr, core/light.cpp:63-82, core/scene.cpp:56-70), BEFORE the
+// continuation direction is sampled, and the count is data dependent; and a BSSRDF vertex traces a chain of probe rays before its entry vertex
+// is shaded.  Forms of the kernel (mi_scene_upload chooses):
+//   general (WAVE = false): every lane walks the general BVH4 steps the traversal kernels use (TravNodeStep / TravLeafStep with spheres, alpha
+//     masks and instances) for its own transmittance, MIS and probe rays, on an LDS stack of its own -- the rays are resolved in the
+//     reference's sequence by construction.  Left for BSSRDF materials combined with BSDF-less interfaces / masks / grid media, and as the
+//     A/B partner of the other forms (PBRT_AMD_VOL_INLINE=1, PBRT_AMD_VOL_TR_QUEUES=0, PBRT_AMD_VOL_SPLIT=0).
+//   wavefront (WAVE = true): the direct-lighting rays go through the shadow / MIS queues (NeeOut) --
+//     * homogeneous media only, no interfaces or masks: k_trace<2> / <1> as in k_shade, closed-form transmittance folded into the terms;
+//     * BSDF-less interfaces or alpha masks (DevVol::tr_queues): the rays are WALKED segment by segment, k_trace<..., TR> + k_vol_tr_step;
+//     * a grid medium (DevVol::tr_dims, the split form): the walk draws its ratio-tracking dimensions from the path's sampler, and a vertex
+//       with direct-lighting rays is shaded in two stages around it (this kernel up to the light sample, k_vol_continue for the rest);
+//     * BSSRDF materials (DevVol::sss_wave; "path", or "volpath" with homogeneous media and nothing to walk): the path parks at the subsurface
+//       vertex, its probe chain is walked through the queues (k_sss_probe_step) and k_sss_entry shades the entry vertex.
+// Included by pbrt_amd.hip after PathState / ChunkIter / DynIter / wave_append.
 #pragma once
 #include "pt_volume.h"
 
