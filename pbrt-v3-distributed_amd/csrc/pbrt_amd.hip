@@ -71,6 +71,7 @@ struct PathState {
     TrState *trs;              // DevVol::tr_queues / sss_wave only, else null
     SssRec *sss;               // DevVol::sss_wave only: parked subsurface paths (BSSRDF at po, probe chain)
     uint32_t *q_sss;           // ... and the queue of the paths whose chain arrived at its chosen hit (row QC_SSS)
+    uint32_t *q_probe[2];      // ... and the two queues the probe walk ping-pongs between (rows QC_PROBE0 / QC_PROBE1; the direct-lighting walk keeps q_tr)
     uint32_t *q_tr[2];         // second shadow / MIS queues (the walk ping-pongs between q_shadow / q_mis and these)
     uint32_t qrow_shadow, qrow_mis;   // counter rows of the queues k_trace<2> / <1> read (QC_SHADOW / QC_MIS unless a walk swapped them)
     uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
@@ -96,7 +97,7 @@ struct PathState {
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_ROWS = 9 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_ROWS = 11 };
 #define QSEG 8u
 #define QC_STRIDE 32u   /* words between counters: one 128-byte line each */
 #define QCI(q, seg) (((uint32_t)(q) * QSEG + (uint32_t)(seg)) * QC_STRIDE)
@@ -2382,37 +2383,29 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
         v.camera_medium = v.handle_media ? d->camera_medium : -1;
-        // wavefront form: all media homogeneous (their transmittance draws no sampler dimension) and no BSSRDF.  With BSDF-less interfaces or alpha
-        // masks (round 3) the shadow / MIS rays are WALKED segment by segment -- k_trace<..., TR> + k_vol_tr_step (DevVol::tr_queues) -- instead of going
-        // through k_trace<2> / <1>: the walk's closest-hit kernel steps through interfaces and evaluates alphaMask (not shadowAlphaMask) exactly where
-        // VisibilityTester::Tr's Scene::Intersect does (core/light.cpp:63-82, shapes/triangle.cpp:333-338)
-        // Grid media (round 3, split form): their Tr draws a data-dependent number of dimensions between the light sample and the continuation sample, so the
-        // vertex is shaded in two stages around the walks (DevVol::tr_dims; PBRT_AMD_VOL_SPLIT=0: such scenes keep the general form)
-        c->volWave = v.handle_media && !d->material_bssrdf;
+        // Which form (pt_volpath.h).  Wavefront unless the combination has none: BSSRDF materials together with a grid medium.
+        //  * "volpath", no BSSRDF: direct-lighting rays through the queues; WALKED segment by segment (volTr: k_trace<..., TR> + k_vol_tr_step; the walk's closest-hit kernel
+        //    steps through interfaces and evaluates alphaMask, not shadowAlphaMask, exactly where VisibilityTester::Tr's Scene::Intersect does, core/light.cpp:63-82,
+        //    shapes/triangle.cpp:333-338) with BSDF-less interfaces, alpha masks or a grid medium, whose Tr draws a
+        //    data-dependent number of dimensions between the light sample and the continuation sample -- the vertex is then shaded in two stages around the walk (volSplit)
+        //  * BSSRDF materials (sssWave): "path", or "volpath" with homogeneous media -- Sample_S draws its numbers before the probe chain is traced and nothing in between
+        //    does: the chain is walked through the queues; the direct-lighting rays take the plain traversals or, with interfaces / masks under "volpath", the walk
+        // PBRT_AMD_VOL_INLINE=1 keeps the general form everywhere, PBRT_AMD_VOL_TR_QUEUES=0 for interfaces / masks, PBRT_AMD_VOL_SPLIT=0 for grid media (A/B, parity tests)
         bool allHomogeneous = true;
         for (uint32_t i = 0; i < d->n_media; ++i) allHomogeneous = allHomogeneous && d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
-        { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (!allHomogeneous && e && e[0] == '0') c->volWave = false; }
-        c->volSplit = c->volWave && !allHomogeneous;
-        { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') c->volWave = false; }   // A/B and parity tests of the general form
-        { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && (c->hasNullMat || c->hasAlpha)) c->volWave = false; }   // =0: such scenes keep the general form (A/B)
-        c->volSplit = c->volSplit && c->volWave;
-        c->volTr = c->volWave && (c->hasNullMat || c->hasAlpha || c->volSplit);
+        const bool hasSss = d->material_bssrdf != nullptr;
+        bool wave = v.handle_media ? (hasSss ? allHomogeneous : true) : true;   // (!handle_media: volKernel only because of the BSSRDFs)
+        const bool split = v.handle_media && !hasSss && !allHomogeneous;
+        { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
+        { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
+        { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
+        c->volWave = wave;
+        c->volSplit = wave && split;
+        c->volTr = wave && v.handle_media && (c->hasNullMat || c->hasAlpha || c->volSplit);
+        c->sssWave = wave && hasSss;
         v.tr_queues = c->volTr ? 1 : 0;
         v.tr_dims = c->volSplit ? 1 : 0;
-        // BSSRDF materials under Integrator "path" (round 3): Sample_S draws its numbers before the probe chain is traced, and without media no visibility
-        // query draws any -- the chains are walked through the queues and the vertex's direct-lighting rays take the plain shadow / MIS traversals
-        // (k_trace<2> / <1>: Unoccluded / Intersect, as k_shade's).  PBRT_AMD_VOL_INLINE=1 keeps the per-lane form (A/B, parity tests).
-        {
-            const char *e = std::getenv("PBRT_AMD_VOL_INLINE");
-            bool plain = !v.handle_media;   // ... or "volpath" with homogeneous media and nothing to walk NEE rays through (closed-form transmittance, as volWave without volTr)
-            if (v.handle_media && !c->hasNullMat && !c->hasAlpha) {
-                plain = true;
-                for (uint32_t i = 0; i < d->n_media && plain; ++i) plain = d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
-            }
-            c->sssWave = d->material_bssrdf && plain && !(e && e[0] == '1');
-            if (c->sssWave) c->volWave = true;
-            v.sss_wave = c->sssWave ? 1 : 0;
-        }
+        v.sss_wave = c->sssWave ? 1 : 0;
         v.textured = c->hasTex ? 1 : 0;   // (alpha masks alone leave c_tex.descs null: the lobe lists stay the constant ones)
         if (v.handle_media && d->n_media) {
             std::vector<mi_medium> med(d->media, d->media + d->n_media);
@@ -2501,7 +2494,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ALLOC(q_sorted, uint32_t, qcap);
     ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
     if (c->volTr || c->sssWave) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
-    if (c->sssWave) ALLOC(sss, SssRec, cap);
+    if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_probe[0], uint32_t, qcap); ALLOC(q_probe[1], uint32_t, qcap); }
     if (c->sssWave || c->volSplit) ALLOC(q_sss, uint32_t, qcap);
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
@@ -2613,7 +2606,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         uint32_t qout = qin ^ 1;
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && !c->sssWave;
-        if (c->sssWave) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW2, 0), 0, 3 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // probe queues (SHADOW2, MIS2) + QC_SSS
+        if (c->sssWave) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SSS, 0), 0, 3 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // QC_SSS + the probe queues (QC_PROBE0, QC_PROBE1)
         if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SSS, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // the vertices waiting for k_vol_continue
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
@@ -2676,30 +2669,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
 #undef LAUNCH_SHADE
         }
         toc(c);
-        if (overlap) {
-            // The direct-lighting traversals of this bounce run on stream2 while the main stream goes on with the next bounce's path-extension
-            // traversal and material sort: they touch disjoint data (NeeRec + PathRec::L vs PathRec::hit / keys / queues), have their own fetch
-            // cursors and stack spill slices, and every persistent traversal launch ends in a tail of a few long rays that the other launch fills.
-            HIP_TRY(hipEventRecord(c->evShaded, st));
-            hipStream_t s2 = c->stream2;
-            HIP_TRY(hipStreamWaitEvent(s2, c->evShaded, 0));
-            PathState psNee = ps;
-            psNee.cursor = c->cursor2; psNee.spill = c->spill2;
-            psNee.vol_tr = c->volWave ? 1u : 0u;
-            {
-                hipStream_t st = s2;
-                PathState &ps = psNee;
-                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                tic(c, MI_K_ANYHIT, st);
-                LAUNCH_TRACE(2);
-                toc(c, st);
-                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                tic(c, MI_K_MIS_CLOSEST, st);
-                LAUNCH_TRACE(1);
-                toc(c, st);
-            }
-            HIP_TRY(hipEventRecord(c->evNeeDone, s2));
-        } else if (c->volTr) {
+        // the direct-lighting rays of a shading stage through the walk (volTr) or the plain any-hit / closest-hit traversals
+        auto nee_walk = [&]() -> int {
             // wavefront form with BSDF-less interfaces between homogeneous media: the shadow and the MIS rays are WALKED through the interfaces, one
             // segment per round -- closest hit of the segment by the persistent-lane kernel (k_trace<..., TR>), then k_vol_tr_step ends the ray or
             // re-aims it behind the interface into the other queue.  Three rounds are queued blindly (a kernel on an empty queue returns at once),
@@ -2735,6 +2706,49 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 }
                 toc(c);
             }
+            return 0;
+        };
+        auto nee_plain = [&]() -> int {
+            HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+            tic(c, MI_K_ANYHIT);
+            LAUNCH_TRACE(2);
+            toc(c);
+            HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+            tic(c, MI_K_MIS_CLOSEST);
+            {
+                PathState psRun = ps;
+                psRun.vol_tr = c->volWave ? 1u : 0u;
+                PathState &ps = psRun;
+                LAUNCH_TRACE(1);
+            }
+            toc(c);
+            return 0;
+        };
+        if (overlap) {
+            // The direct-lighting traversals of this bounce run on stream2 while the main stream goes on with the next bounce's path-extension
+            // traversal and material sort: they touch disjoint data (NeeRec + PathRec::L vs PathRec::hit / keys / queues), have their own fetch
+            // cursors and stack spill slices, and every persistent traversal launch ends in a tail of a few long rays that the other launch fills.
+            HIP_TRY(hipEventRecord(c->evShaded, st));
+            hipStream_t s2 = c->stream2;
+            HIP_TRY(hipStreamWaitEvent(s2, c->evShaded, 0));
+            PathState psNee = ps;
+            psNee.cursor = c->cursor2; psNee.spill = c->spill2;
+            psNee.vol_tr = c->volWave ? 1u : 0u;
+            {
+                hipStream_t st = s2;
+                PathState &ps = psNee;
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_ANYHIT, st);
+                LAUNCH_TRACE(2);
+                toc(c, st);
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_MIS_CLOSEST, st);
+                LAUNCH_TRACE(1);
+                toc(c, st);
+            }
+            HIP_TRY(hipEventRecord(c->evNeeDone, s2));
+        } else if (c->volTr) {
+            if (nee_walk()) return -1;
             if (c->volSplit) {   // second stage of the vertices whose direct-lighting rays have now consumed their dimensions
                 tic(c, MI_K_SHADE);
                 if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
@@ -2742,30 +2756,19 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c);
             }
         } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
-        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        tic(c, MI_K_ANYHIT);
-        LAUNCH_TRACE(2);
-        toc(c);
-        HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        tic(c, MI_K_MIS_CLOSEST);
-        {
-            PathState psRun = ps;
-            psRun.vol_tr = c->volWave ? 1u : 0u;
-            PathState &ps = psRun;
-            LAUNCH_TRACE(1);
+            if (nee_plain()) return -1;
         }
-        toc(c);
         if (c->sssWave) {
             // the subsurface paths k_shade_vol parked in this bounce: walk their probe chains (one segment per round: k_trace<2, ..., TR> finds its closest
             // hit, k_sss_probe_step takes it into the chain), then shade the entry vertices and trace THEIR direct-lighting rays.  The vertex's own
             // shadow / MIS rays are done (above): NeeRec::sh_* now carries the probe segments.
             uint32_t row[QSEG * QC_STRIDE], left = 0;
-            HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(QC_SHADOW2, 0), sizeof(row), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(QC_PROBE0, 0), sizeof(row), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
             if (left) {
-                uint32_t rowIn = QC_SHADOW2, rowOut = QC_MIS2;
-                uint32_t *qIn = ps.q_tr[0], *qOut = ps.q_tr[1];
+                uint32_t rowIn = QC_PROBE0, rowOut = QC_PROBE1;
+                uint32_t *qIn = ps.q_probe[0], *qOut = ps.q_probe[1];
                 tic(c, MI_K_SHADE);
                 if (c->hasInst) hipLaunchKernelGGL((k_sss_probe_step<true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 1);
                 else hipLaunchKernelGGL((k_sss_probe_step<false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 1);
@@ -2799,21 +2802,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
                 else hipLaunchKernelGGL((k_sss_entry<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
                 toc(c);
-                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                tic(c, MI_K_ANYHIT);
-                LAUNCH_TRACE(2);
-                toc(c);
-                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                tic(c, MI_K_MIS_CLOSEST);
-                {
-                    PathState psRun = ps;
-                    psRun.vol_tr = 1u;
-                    PathState &ps = psRun;
-                    LAUNCH_TRACE(1);
-                }
-                toc(c);
+                if (c->volTr ? nee_walk() : nee_plain()) return -1;   // the entry vertices' direct-lighting rays
             }
-        }
         }
         qin = qout;
         ++iter;
@@ -2898,7 +2888,7 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     if (rp->max_paths_in_flight <= 0) {
         size_t freeB = 0, totalB = 0;
         const size_t perPath = sizeof(PathRec) + sizeof(NeeRec) + sizeof(uint32_t) * 6 + sizeof(uint2) + ((c->volTr || c->sssWave) ? sizeof(TrState) + 2 * sizeof(uint32_t) : 0) +
-                               (c->sssWave ? sizeof(SssRec) + sizeof(uint32_t) : 0);
+                               (c->sssWave ? sizeof(SssRec) + 3 * sizeof(uint32_t) : 0);
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
             size_t budget = freeB / 10 * 6 + (size_t)c->cap * perPath;   // what is allocated for path state now would be released
             cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(budget / perPath, 1u << 20));

@@ -8,15 +8,16 @@
 // is shaded.  Forms of the kernel (mi_scene_upload chooses):
 //   general (WAVE = false): every lane walks the general BVH4 steps the traversal kernels use (TravNodeStep / TravLeafStep with spheres, alpha
 //     masks and instances) for its own transmittance, MIS and probe rays, on an LDS stack of its own -- the rays are resolved in the
-//     reference's sequence by construction.  Left for BSSRDF materials combined with BSDF-less interfaces / masks / grid media, and as the
+//     reference's sequence by construction.  Left for BSSRDF materials in a scene with a grid medium, and as the
 //     A/B partner of the other forms (PBRT_AMD_VOL_INLINE=1, PBRT_AMD_VOL_TR_QUEUES=0, PBRT_AMD_VOL_SPLIT=0).
 //   wavefront (WAVE = true): the direct-lighting rays go through the shadow / MIS queues (NeeOut) --
 //     * homogeneous media only, no interfaces or masks: k_trace<2> / <1> as in k_shade, closed-form transmittance folded into the terms;
 //     * BSDF-less interfaces or alpha masks (DevVol::tr_queues): the rays are WALKED segment by segment, k_trace<..., TR> + k_vol_tr_step;
 //     * a grid medium (DevVol::tr_dims, the split form): the walk draws its ratio-tracking dimensions from the path's sampler, and a vertex
 //       with direct-lighting rays is shaded in two stages around it (this kernel up to the light sample, k_vol_continue for the rest);
-//     * BSSRDF materials (DevVol::sss_wave; "path", or "volpath" with homogeneous media and nothing to walk): the path parks at the subsurface
-//       vertex, its probe chain is walked through the queues (k_sss_probe_step) and k_sss_entry shades the entry vertex.
+//     * BSSRDF materials (DevVol::sss_wave; "path", or "volpath" with homogeneous media): the path parks at the subsurface vertex, its probe
+//       chain is walked through the queues (k_sss_probe_step) and k_sss_entry shades the entry vertex; the direct-lighting rays of both vertices take
+//       the plain traversals or, with interfaces / masks under "volpath", the walk.
 // Included by pbrt_amd.hip after PathState / ChunkIter / DynIter / wave_append.
 #pragma once
 #include "pt_volume.h"
@@ -764,8 +765,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             }
             if constexpr (!UMAT) {
                 if (vol.sss_wave) {   // the probe chains of this bounce: first queue of the walk (k_sss_probe_step)
-                    const uint32_t posP = wave_append(&ps.qcount[QCI(QC_SHADOW2, qseg)], wantProbe);
-                    if (wantProbe) ps.q_tr[0][qbase + posP] = slot;
+                    const uint32_t posP = wave_append(&ps.qcount[QCI(QC_PROBE0, qseg)], wantProbe);
+                    if (wantProbe) ps.q_probe[0][qbase + posP] = slot;
                 }
             }
         } else {

@@ -133,6 +133,13 @@ def sss_scene(name):
                       'Texture "chk" "spectrum" "checkerboard" "float uscale" [3] "float vscale" [3] "rgb tex1" [.8 .3 .2] "rgb tex2" [.2 .5 .8]\n'
                       'Material "kdsubsurface" "texture Kd" "chk" "rgb mfp" [.4 .3 .2] "float eta" [1.4] "float scale" [.5]')
         return t.replace('LookAt', 'MakeNamedMedium "haze" "string type" "homogeneous" "rgb sigma_a" [.01 .01 .01] "rgb sigma_s" [.04 .04 .05]\nMediumInterface "" "haze"\nLookAt', 1)
+    if name == "sss_vol_iface":   # sss_kd + a bank of denser fog behind a BSDF-less box that cuts through the subsurface object: the vertices' shadow / MIS rays are WALKED through the
+        # interface, the probe chains cross it (its hits are not on the material object: not counted), the entry vertices sit in either medium
+        fog = ('MakeNamedMedium "fog2" "string type" "homogeneous" "rgb sigma_a" [.05 .05 .06] "rgb sigma_s" [.3 .3 .35] "float g" [.3]\n'
+               'AttributeBegin\nMediumInterface "fog2" "haze"\nMaterial ""\n'
+               'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+               '  "point P" [-2 .005 -1.2  -.2 .005 -1.2  -.2 .005 .1  -2 .005 .1  -2 1.3 -1.2  -.2 1.3 -1.2  -.2 1.3 .1  -2 1.3 .1]\nAttributeEnd\n')
+        return sss_scene("sss_kd").replace("WorldEnd", fog + "WorldEnd")
     if name == "sss_inst":     # a subsurface object INSTANTIATED twice (two-level instancing): probe-ray chains through TransformedPrimitives, under "path"
         obj = ('ObjectBegin "blob"\nMaterial "subsurface" "string name" "Ketchup" "float scale" [6] "float eta" [1.35]\n' + _bulge() + 'ObjectEnd\n')
         inst = "".join('AttributeBegin\nTranslate %g %g %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "blob"\nAttributeEnd\n' % a for a in
@@ -141,7 +148,7 @@ def sss_scene(name):
     raise KeyError(name)
 
 
-SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst"]
+SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst", "sss_vol_iface"]
 
 
 # ---- the samplers that draw from one PCG32 stream per tile (ABI v11): RandomSampler, StratifiedSampler, ZeroTwoSequenceSampler

@@ -974,14 +974,15 @@ def test_split_form_matches_the_general_form_on_grid_media(name, monkeypatch):
     assert np.allclose(out["split"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_inst", False), ("sss_inst", True)])
+@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_vol_iface", False), ("sss_inst", False), ("sss_inst", True)])
 def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch):
     """Subsurface materials under Integrator "path" in wavefront form (round 3): the vertex's shadow / MIS rays take the plain traversals, the path parks,
     its probe chain is walked hit by hit through the queues (k_sss_probe_step + k_trace<2, ..., TR>: count, choose, walk again up to the chosen hit --
     SeparableBSSRDF::Sample_Sp, core/bssrdf.cpp:249-326) and k_sss_entry shades the entry vertex (path.cpp:160-174).  PBRT_AMD_VOL_INLINE=1: the
     per-lane form (every lane traces its own rays inside k_shade_vol).  Both reproduce the reference's render with the same rays; sss_inst walks
     its chains through TransformedPrimitives; sss_kd is a KdSubsurfaceMaterial under "volpath" in haze (homogeneous media, no interfaces: closed-form
-    transmittance on the queued rays, the chain carries its media for the entry vertex)."""
+    transmittance on the queued rays, the chain carries its media for the entry vertex); sss_vol_iface adds a bank of fog behind a BSDF-less box that cuts
+    through the subsurface object (the direct-lighting rays of both vertices are walked through the interface, the chains cross it)."""
     monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
     fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     out = {}
