@@ -71,6 +71,7 @@ struct PathState {
     TrState *trs;              // DevVol::tr_queues / sss_wave only, else null
     SssRec *sss;               // DevVol::sss_wave only: parked subsurface paths (BSSRDF at po, probe chain)
     uint32_t *q_sss;           // ... and the queue of the paths whose chain arrived at its chosen hit (row QC_SSS)
+    uint32_t *q_cont;          // DevVol::tr_dims only: the vertices that wait for their transmittances (k_vol_continue's queue, row QC_CONT)
     uint32_t *q_probe[2];      // ... and the two queues the probe walk ping-pongs between (rows QC_PROBE0 / QC_PROBE1; the direct-lighting walk keeps q_tr)
     uint32_t *q_tr[2];         // second shadow / MIS queues (the walk ping-pongs between q_shadow / q_mis and these)
     uint32_t qrow_shadow, qrow_mis;   // counter rows of the queues k_trace<2> / <1> read (QC_SHADOW / QC_MIS unless a walk swapped them)
@@ -97,7 +98,7 @@ struct PathState {
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_ROWS = 11 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_CONT = 11, QC_ROWS = 12 };
 #define QSEG 8u
 #define QC_STRIDE 32u   /* words between counters: one 128-byte line each */
 #define QCI(q, seg) (((uint32_t)(q) * QSEG + (uint32_t)(seg)) * QC_STRIDE)
@@ -2383,19 +2384,19 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
         v.camera_medium = v.handle_media ? d->camera_medium : -1;
-        // Which form (pt_volpath.h).  Wavefront unless the combination has none: BSSRDF materials together with a grid medium.
+        // Which form (pt_volpath.h).  Every combination has a wavefront form; the general form is the A/B partner (environment switches below).
         //  * "volpath", no BSSRDF: direct-lighting rays through the queues; WALKED segment by segment (volTr: k_trace<..., TR> + k_vol_tr_step; the walk's closest-hit kernel
         //    steps through interfaces and evaluates alphaMask, not shadowAlphaMask, exactly where VisibilityTester::Tr's Scene::Intersect does, core/light.cpp:63-82,
         //    shapes/triangle.cpp:333-338) with BSDF-less interfaces, alpha masks or a grid medium, whose Tr draws a
         //    data-dependent number of dimensions between the light sample and the continuation sample -- the vertex is then shaded in two stages around the walk (volSplit)
-        //  * BSSRDF materials (sssWave): "path", or "volpath" with homogeneous media -- Sample_S draws its numbers before the probe chain is traced and nothing in between
-        //    does: the chain is walked through the queues; the direct-lighting rays take the plain traversals or, with interfaces / masks under "volpath", the walk
+        //  * BSSRDF materials (sssWave): Sample_S draws its numbers before the probe chain is traced and nothing in between does: the chain is walked through the queues; the
+        //    direct-lighting rays of the subsurface vertex and of the entry vertex take the plain traversals or the walk, and with a grid medium both are split like any vertex
         // PBRT_AMD_VOL_INLINE=1 keeps the general form everywhere, PBRT_AMD_VOL_TR_QUEUES=0 for interfaces / masks, PBRT_AMD_VOL_SPLIT=0 for grid media (A/B, parity tests)
         bool allHomogeneous = true;
         for (uint32_t i = 0; i < d->n_media; ++i) allHomogeneous = allHomogeneous && d->media[i].type == MI_MEDIUM_HOMOGENEOUS;
         const bool hasSss = d->material_bssrdf != nullptr;
-        bool wave = v.handle_media ? (hasSss ? allHomogeneous : true) : true;   // (!handle_media: volKernel only because of the BSSRDFs)
-        const bool split = v.handle_media && !hasSss && !allHomogeneous;
+        bool wave = true;
+        const bool split = v.handle_media && !allHomogeneous;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
@@ -2495,7 +2496,8 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
     if (c->volTr || c->sssWave) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
     if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_probe[0], uint32_t, qcap); ALLOC(q_probe[1], uint32_t, qcap); }
-    if (c->sssWave || c->volSplit) ALLOC(q_sss, uint32_t, qcap);
+    if (c->sssWave) ALLOC(q_sss, uint32_t, qcap);
+    if (c->volSplit) ALLOC(q_cont, uint32_t, qcap);
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
     ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
@@ -2607,7 +2609,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         HIP_TRY(hipMemsetAsync(ps.qcount + QCI(qout, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         const bool overlap = c->overlapNee && c->stream2 && (!c->volKernel || c->volWave) && !c->volTr && !c->sssWave;
         if (c->sssWave) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SSS, 0), 0, 3 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // QC_SSS + the probe queues (QC_PROBE0, QC_PROBE1)
-        if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SSS, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // the vertices waiting for k_vol_continue
+        if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_CONT, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // the vertices waiting for k_vol_continue
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
         bool binned = false;
@@ -2724,6 +2726,12 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             toc(c);
             return 0;
         };
+        auto vol_continue = [&]() {
+            tic(c, MI_K_SHADE);
+            if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+            else hipLaunchKernelGGL((k_vol_continue<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+            toc(c);
+        };
         if (overlap) {
             // The direct-lighting traversals of this bounce run on stream2 while the main stream goes on with the next bounce's path-extension
             // traversal and material sort: they touch disjoint data (NeeRec + PathRec::L vs PathRec::hit / keys / queues), have their own fetch
@@ -2749,12 +2757,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             HIP_TRY(hipEventRecord(c->evNeeDone, s2));
         } else if (c->volTr) {
             if (nee_walk()) return -1;
-            if (c->volSplit) {   // second stage of the vertices whose direct-lighting rays have now consumed their dimensions
-                tic(c, MI_K_SHADE);
-                if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
-                else hipLaunchKernelGGL((k_vol_continue<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
-                toc(c);
-            }
+            if (c->volSplit) vol_continue();   // second stage of the vertices whose direct-lighting rays have now consumed their dimensions
         } else if (!c->volKernel || c->volWave) {   // (k_shade_vol<false> traces its own shadow / MIS rays)
             if (nee_plain()) return -1;
         }
@@ -2798,11 +2801,13 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c);
                 if (left) return fail("mi_render: a BSSRDF probe chain did not end within 16384 segments");   // (every segment starts behind the previous hit: no real chain comes near)
                 HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_CONT, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // (k_vol_continue has served the bounce's first stage)
                 tic(c, MI_K_SHADE);
                 if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
                 else hipLaunchKernelGGL((k_sss_entry<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
                 toc(c);
                 if (c->volTr ? nee_walk() : nee_plain()) return -1;   // the entry vertices' direct-lighting rays
+                if (c->volSplit) vol_continue();   // ... and, in the split form, their continuation
             }
         }
         qin = qout;

@@ -8,16 +8,16 @@
 // is shaded.  Forms of the kernel (mi_scene_upload chooses):
 //   general (WAVE = false): every lane walks the general BVH4 steps the traversal kernels use (TravNodeStep / TravLeafStep with spheres, alpha
 //     masks and instances) for its own transmittance, MIS and probe rays, on an LDS stack of its own -- the rays are resolved in the
-//     reference's sequence by construction.  Left for BSSRDF materials in a scene with a grid medium, and as the
+//     reference's sequence by construction.  Every combination has a wavefront form by now; this one is the
 //     A/B partner of the other forms (PBRT_AMD_VOL_INLINE=1, PBRT_AMD_VOL_TR_QUEUES=0, PBRT_AMD_VOL_SPLIT=0).
 //   wavefront (WAVE = true): the direct-lighting rays go through the shadow / MIS queues (NeeOut) --
 //     * homogeneous media only, no interfaces or masks: k_trace<2> / <1> as in k_shade, closed-form transmittance folded into the terms;
 //     * BSDF-less interfaces or alpha masks (DevVol::tr_queues): the rays are WALKED segment by segment, k_trace<..., TR> + k_vol_tr_step;
 //     * a grid medium (DevVol::tr_dims, the split form): the walk draws its ratio-tracking dimensions from the path's sampler, and a vertex
 //       with direct-lighting rays is shaded in two stages around it (this kernel up to the light sample, k_vol_continue for the rest);
-//     * BSSRDF materials (DevVol::sss_wave; "path", or "volpath" with homogeneous media): the path parks at the subsurface vertex, its probe
-//       chain is walked through the queues (k_sss_probe_step) and k_sss_entry shades the entry vertex; the direct-lighting rays of both vertices take
-//       the plain traversals or, with interfaces / masks under "volpath", the walk.
+//     * BSSRDF materials (DevVol::sss_wave): the path parks at the subsurface vertex, its probe chain is walked through the queues
+//       (k_sss_probe_step) and k_sss_entry shades the entry vertex; the direct-lighting rays of both vertices take the plain traversals or the
+//       walk, and with a grid medium both vertices are split like any other (k_vol_continue finishes the subsurface vertex AND the entry vertex).
 // Included by pbrt_amd.hip after PathState / ChunkIter / DynIter / wave_append.
 #pragma once
 #include "pt_volume.h"
@@ -760,8 +760,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
             if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
             if (vol.tr_dims) {   // split form: the vertices that wait for their transmittances (k_vol_continue's queue)
-                const uint32_t posB = wave_append(&ps.qcount[QCI(QC_SSS, qseg)], wantSplit != 0);
-                if (wantSplit) ps.q_sss[qbase + posB] = slot;
+                const uint32_t posB = wave_append(&ps.qcount[QCI(QC_CONT, qseg)], wantSplit != 0);
+                if (wantSplit) ps.q_cont[qbase + posB] = slot;
             }
             if constexpr (!UMAT) {
                 if (vol.sss_wave) {   // the probe chains of this bounce: first queue of the walk (k_sss_probe_step)
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
     lt.nClosest = lt.nAny = lt.guardTrips = 0;
     for (SegIter it(ps.qcount, QC_SSS, ps.seg_cap); it.more(); it.next()) {
         const bool active = it.valid();
-        bool cont = false;
+        bool cont = false, wantSplit = false;
         uint32_t slot = 0, rayKey = 0;
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
@@ -1032,6 +1032,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
                 LaneBSDF piBsdf(pi.is, &piMat);
                 L = L + beta * UniformSampleOneLightD<INST, LaneBSDF>(cx, &pi.is, pi.mIn, pi.mOut, &piBsdf, 0);
                 betaNee = beta;
+                if (vol.tr_dims && (nee.wantShadow || nee.wantMis)) {   // split form: the entry vertex's visibility queries draw dimensions -- k_vol_continue samples the adapter lobe after them
+                    wantSplit = true;
+                    ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17) | (1u << 19));
+                    alive = false;
+                } else {
                 Float u0, u1, pdf;
                 int flags;
                 V3 wi;
@@ -1044,6 +1050,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
                     no = OffsetRayOrigin(pi.is.p, pi.is.pError, pi.is.n, wi);   // pi.SpawnRay(wi)
                     nd = wi;
                     nmedium = GetMediumOf(pi.is.n, pi.mIn, pi.mOut, wi);
+                }
                 }
             }
             if (alive) {   // Russian roulette (path.cpp:176-184 / volpath.cpp:183-189); the loop's ++bounces
@@ -1073,6 +1080,10 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
         if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
         if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
+        if (vol.tr_dims) {
+            const uint32_t posB = wave_append(&ps.qcount[QCI(QC_CONT, qseg)], wantSplit);
+            if (wantSplit) ps.q_cont[qbase + posB] = slot;
+        }
     }
 }
 
@@ -1085,12 +1096,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
 template <bool INST>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
     const DevScene &sc = *scp;
-    for (SegIter it(ps.qcount, QC_SSS, ps.seg_cap); it.more(); it.next()) {
+    for (SegIter it(ps.qcount, QC_CONT, ps.seg_cap); it.more(); it.next()) {
         const bool active = it.valid();
-        bool cont = false;
+        bool cont = false, wantProbe = false;
         uint32_t slot = 0, rayKey = 0;
         if (active) {
-            slot = ps.q_sss[it.item()];
+            slot = ps.q_cont[it.item()];
             const uint2 hr = ps.rec[slot].hit;
             const float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, m4 = ps.rec[slot].pad2;
             const uint4 s4 = ps.rec[slot].smp;
@@ -1099,7 +1110,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
             Float etaScale = b4.w;
             int bounces = (int)(s4.w & 0xffffu);
             bool specularBounce = false;
-            const bool noDiff = (s4.w >> 17) & 1u, mediumVertex = (s4.w >> 18) & 1u;
+            const bool noDiff = (s4.w >> 17) & 1u, mediumVertex = (s4.w >> 18) & 1u, entryVertex = (s4.w >> 19) & 1u;
             const int medium = (int)__float_as_uint(m4.x);
             VSampler smp;
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
@@ -1118,6 +1129,33 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
                 HGSample_p(g, -rd, &wi, u0, u1);
                 no = OffsetRayOrigin(p, V3(), V3(), wi);   // mi.SpawnRay(wi)
                 nd = wi;
+            } else if (entryVertex) {   // the entry vertex of a subsurface path, parked by k_sss_entry after its light sample (volpath.cpp:170-180): the adapter lobe's Sample_f
+                const SssRec *S = &ps.sss[slot];
+                DevBSSRDF bssrdf;
+                SssBssrdfOf(S, vol, &bssrdf);
+                const float4 zp = S->nz_pi, po4 = S->pi_o, pd4 = S->pi_d;
+                VHit pi;
+                HitToIsect(scp, &vol, __float_as_uint(zp.y), V3(po4.x, po4.y, po4.z), V3(pd4.x, pd4.y, pd4.z), __float_as_uint(zp.z), __float_as_int(zp.w), false, &pi);
+                mi_material piMat;
+                piMat.n_bxdfs = 1; piMat.eta = 1;
+                __builtin_memset(&piMat.bxdfs[0], 0, sizeof(mi_bxdf));
+                piMat.bxdfs[0].type = MI_BXDF_BSSRDF_ADAPTER;
+                piMat.bxdfs[0].etaB = bssrdf.eta;
+                pi.is.wo = pi.is.ns;
+                LaneBSDF piBsdf(pi.is, &piMat);
+                Float u0, u1, pdf;
+                int flags;
+                V3 wi;
+                smp.Get2D(sc, &u0, &u1);
+                const RGB f = piBsdf.Sample_f(pi.is.wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                if (f.IsBlack() || pdf == 0) alive = false;
+                else {
+                    beta = beta * (f * AbsDot(wi, pi.is.ns) / pdf);
+                    specularBounce = (flags & BSDF_SPECULAR) != 0;
+                    no = OffsetRayOrigin(pi.is.p, pi.is.pError, pi.is.n, wi);   // pi.SpawnRay(wi)
+                    nd = wi;
+                    nmedium = GetMediumOf(pi.is.n, pi.mIn, pi.mOut, wi);
+                }
             } else {              // volpath.cpp:130-150
                 VHit vh;
                 HitToIsect(scp, &vol, hr.x, ro, rd, INST ? ps.rec[slot].pad0 : TRAV_NO_INSTANCE, medium, vol.textured != 0, &vh);
@@ -1150,8 +1188,26 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
                     no = OffsetRayOrigin(vh.is.p, vh.is.pError, vh.is.n, wi);   // isect.SpawnRay(wi)
                     nd = wi;
                     nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi);
+                    if (vol.sss_wave && (flags & BSDF_TRANSMISSION)) {   // volpath.cpp:153-180: a BSSRDF here sends the path into its probe chain (as k_shade_vol<WAVE> does for a vertex it finishes itself)
+                        DevBSSRDF bssrdf;
+                        ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf);
+                        if (bssrdf.table) {
+                            Float u20, u21, u1s;
+                            smp.Get2D(sc, &u20, &u21);   // Sample_S(scene, sampler.Get1D(), sampler.Get2D(), ...): arguments evaluated right to left
+                            u1s = smp.Get1D(sc);
+                            SssProbe pr;
+                            if (!BssrdfProbeSetup(&bssrdf, u1s, u20, u21, &pr)) alive = false;
+                            else { wantProbe = true; SssPark(&ps.sss[slot], vol, bssrdf, pr); }
+                        }
+                    }
                 }
             }
+            if (alive && wantProbe) {   // parked for k_sss_probe_step / k_sss_entry, which also take this iteration's Russian roulette and ++bounces
+                ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
+                ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)smp.dimension, (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
+                alive = false;
+            } else
+                wantProbe = false;
             if (alive) {   // Russian roulette (volpath.cpp:183-189); the loop's ++bounces
                 cont = true;
                 const RGB rrBeta = beta * etaScale;
@@ -1174,5 +1230,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
         const uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
         if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (vol.sss_wave) {
+            const uint32_t posP = wave_append(&ps.qcount[QCI(QC_PROBE0, qseg)], wantProbe);
+            if (wantProbe) ps.q_probe[0][qbase + posP] = slot;
+        }
     }
 }

@@ -140,6 +140,15 @@ def sss_scene(name):
                'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
                '  "point P" [-2 .005 -1.2  -.2 .005 -1.2  -.2 .005 .1  -2 .005 .1  -2 1.3 -1.2  -.2 1.3 -1.2  -.2 1.3 .1  -2 1.3 .1]\nAttributeEnd\n')
         return sss_scene("sss_kd").replace("WorldEnd", fog + "WorldEnd")
+    if name == "sss_vol_smoke":   # sss_kd + a HETEROGENEOUS medium behind a BSDF-less box around the subsurface object: every transmittance query of the subsurface vertex and of the entry
+        # vertex draws ratio-tracking dimensions -- both vertices are shaded in two stages (split form), the probe chain in between
+        smoke = ('AttributeBegin\nTranslate -1.1 .005 0\n'
+                 'MakeNamedMedium "smoke" "string type" "heterogeneous" "rgb sigma_a" [.3 .3 .3] "rgb sigma_s" [1.5 1.5 1.5] "float g" [.2]\n'
+                 '  "integer nx" [4] "integer ny" [3] "integer nz" [4] "point p0" [-1 0 -1] "point p1" [1 1.5 1] "float density" [%s]\nAttributeEnd\n'
+                 'AttributeBegin\nMediumInterface "smoke" "haze"\nMaterial ""\n'
+                 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0]\n'
+                 '  "point P" [-2.1 .005 -1  -.1 .005 -1  -.1 .005 1  -2.1 .005 1  -2.1 1.505 -1  -.1 1.505 -1  -.1 1.505 1  -2.1 1.505 1]\nAttributeEnd\n') % _grid_density(4, 3, 4)
+        return sss_scene("sss_kd").replace("WorldEnd", smoke + "WorldEnd")
     if name == "sss_inst":     # a subsurface object INSTANTIATED twice (two-level instancing): probe-ray chains through TransformedPrimitives, under "path"
         obj = ('ObjectBegin "blob"\nMaterial "subsurface" "string name" "Ketchup" "float scale" [6] "float eta" [1.35]\n' + _bulge() + 'ObjectEnd\n')
         inst = "".join('AttributeBegin\nTranslate %g %g %g\nRotate %g 0 1 0\nScale %g %g %g\nObjectInstance "blob"\nAttributeEnd\n' % a for a in
@@ -148,7 +157,7 @@ def sss_scene(name):
     raise KeyError(name)
 
 
-SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst", "sss_vol_iface"]
+SSS_NAMES = ["sss_named", "sss_coeff", "sss_kd", "sss_inst", "sss_vol_iface", "sss_vol_smoke"]
 
 
 # ---- the samplers that draw from one PCG32 stream per tile (ABI v11): RandomSampler, StratifiedSampler, ZeroTwoSequenceSampler

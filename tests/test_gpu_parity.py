@@ -974,7 +974,7 @@ def test_split_form_matches_the_general_form_on_grid_media(name, monkeypatch):
     assert np.allclose(out["split"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_vol_iface", False), ("sss_inst", False), ("sss_inst", True)])
+@pytest.mark.parametrize("name,flatten", [("sss_named", False), ("sss_coeff", False), ("sss_kd", False), ("sss_vol_iface", False), ("sss_vol_smoke", False), ("sss_inst", False), ("sss_inst", True)])
 def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch):
     """Subsurface materials under Integrator "path" in wavefront form (round 3): the vertex's shadow / MIS rays take the plain traversals, the path parks,
     its probe chain is walked hit by hit through the queues (k_sss_probe_step + k_trace<2, ..., TR>: count, choose, walk again up to the chosen hit --
@@ -982,7 +982,8 @@ def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch)
     per-lane form (every lane traces its own rays inside k_shade_vol).  Both reproduce the reference's render with the same rays; sss_inst walks
     its chains through TransformedPrimitives; sss_kd is a KdSubsurfaceMaterial under "volpath" in haze (homogeneous media, no interfaces: closed-form
     transmittance on the queued rays, the chain carries its media for the entry vertex); sss_vol_iface adds a bank of fog behind a BSDF-less box that cuts
-    through the subsurface object (the direct-lighting rays of both vertices are walked through the interface, the chains cross it)."""
+    through the subsurface object (the direct-lighting rays of both vertices are walked through the interface, the chains cross it); sss_vol_smoke puts a GRID
+    medium around it: the subsurface vertex and the entry vertex are both shaded in two stages around their walks (k_vol_continue), the chain in between."""
     monkeypatch.setenv("PBRT_AMD_INSTANCING", "0" if flatten else "1")
     fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     out = {}

@@ -64,7 +64,7 @@ EDGE_CASES = ["infinite", "infinite_only", "infinite_xf", "envmap", "envmap_powe
               # rows f2 / f4: the reference's Texture / MIPMap / TextureMapping objects as mi_texture nodes and mi_image pyramids, material
               # parameters as mi_material_desc, TriangleMesh alpha masks, SubsurfaceMaterial / KdSubsurfaceMaterial with their BSSRDFTable
               "tex_imagemap", "tex_procedural", "tex_noise", "tex_mappings", "tex_bump", "tex_alpha", "tex_materials", "tex_spheres", "tex_dof",
-              "instances2", "vol_alpha", "sss_named", "sss_coeff", "sss_kd", "sss_inst", "sss_vol_iface"]
+              "instances2", "vol_alpha", "sss_named", "sss_coeff", "sss_kd", "sss_inst", "sss_vol_iface", "sss_vol_smoke"]
 
 
 def _edge_text(name):
