@@ -648,7 +648,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                         const mi_material *matPtr = (!UMAT && vol.textured) ? &laneMat : sc.materials + matU;   // constant lobe lists are read in place
                         DevBSSRDF bssrdf;
                         bssrdf.table = nullptr;
-                        if constexpr (!UMAT) { if (vol.bssrdf) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf); }
+                        // (si->bssrdf is a pure function of the interaction: evaluated below, only when the sampled lobe transmits -- the coefficient textures and the three
+                        //  spline inversions of a kdsubsurface material are wasted on every other vertex)
                         SurfBSDF bsdf(vh.is, matPtr);
                         // volpath.cpp:125-128 samples a light unconditionally; path.cpp:122 only for surfaces with a non-specular lobe
                         if (vol.handle_media || bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) L = L + beta * UniformSampleOneLightD<INST, SurfBSDF>(cx, &vh.is, vh.mIn, vh.mOut, &bsdf, 0);
@@ -678,6 +679,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
                             nd = wi;
                             nmedium = GetMediumOf(vh.is.n, vh.mIn, vh.mOut, wi);
                             scattered = true;
+                            if constexpr (!UMAT) { if (vol.bssrdf && (flags & BSDF_TRANSMISSION)) ComputeBSSRDFD(&vol, matIdx, &vh.is, &vh.ix, &bssrdf); }
                             if (!UMAT && bssrdf.table && (flags & BSDF_TRANSMISSION)) {   // path.cpp:153-174 / volpath.cpp:153-180
                                 // S = bssrdf->Sample_S(scene, sampler.Get1D(), sampler.Get2D(), ...): the two calls are function ARGUMENTS and
                                 // g++ evaluates them right to left -- the 2-D sample takes the earlier dimensions (pinned by the oracle's fixtures)
