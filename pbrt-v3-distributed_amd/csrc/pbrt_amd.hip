@@ -2690,13 +2690,15 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         PathState &ps = psRun;
                         if (which) LAUNCH_TRACE_TR(1); else LAUNCH_TRACE_TR(2);
                     }
+#define LAUNCH_TR_STEP(M, I, D) hipLaunchKernelGGL((k_vol_tr_step<M, I, D>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut)
                     if (which) {
-                        if (c->hasInst) hipLaunchKernelGGL((k_vol_tr_step<1, true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
-                        else hipLaunchKernelGGL((k_vol_tr_step<1, false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                        if (c->hasInst) { if (c->volSplit) LAUNCH_TR_STEP(1, true, true); else LAUNCH_TR_STEP(1, true, false); }
+                        else { if (c->volSplit) LAUNCH_TR_STEP(1, false, true); else LAUNCH_TR_STEP(1, false, false); }
                     } else {
-                        if (c->hasInst) hipLaunchKernelGGL((k_vol_tr_step<2, true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
-                        else hipLaunchKernelGGL((k_vol_tr_step<2, false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut);
+                        if (c->hasInst) { if (c->volSplit) LAUNCH_TR_STEP(2, true, true); else LAUNCH_TR_STEP(2, true, false); }
+                        else { if (c->volSplit) LAUNCH_TR_STEP(2, false, true); else LAUNCH_TR_STEP(2, false, false); }
                     }
+#undef LAUNCH_TR_STEP
                     std::swap(qIn, qOut); std::swap(rowIn, rowOut);
                     if (round >= 2) {
                         uint32_t left = 0, row[QSEG * QC_STRIDE];

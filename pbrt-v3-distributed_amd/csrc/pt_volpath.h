@@ -795,7 +795,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_camera_medium(PathState ps, ui
 // surface, the light, nothing -- or re-aims it behind the interface (shadow rays: isect.SpawnRayTo(p1); MIS rays: isect.SpawnRay(d)) and appends it
 // to the other queue for the next round.  Most rays end in the first round.
 // MODE 2: shadow rays (NeeRec::sh_*; light point in pad[0..1] + sh_c.w).  MODE 1: the BSDF-sampled ray of the MIS estimator (NeeRec::mi_*).
-template <int MODE, bool INST>
+// DIMS: the split form (DevVol::tr_dims) -- a separate instance, so that scenes with homogeneous media only keep the lean kernel that was measured (profiles/r03_q_bench_c3_fogbox.json)
+template <int MODE, bool INST, bool DIMS>
 __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn, uint32_t *qOut, uint32_t rowOut) {
     const DevScene &sc = *scp;
     const int w = MODE == 1 ? 1 : 0;
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
             VSampler smp;
             VSampler *sp = nullptr;
             auto samplerFor = [&](int m) {   // only a segment inside a grid medium draws: the others leave the path's sampler alone
-                if (vol.tr_dims && m >= 0 && vol.media[m].type != MI_MEDIUM_HOMOGENEOUS) {
+                if constexpr (DIMS) if (m >= 0 && vol.media[m].type != MI_MEDIUM_HOMOGENEOUS) {
                     const uint4 s4 = ps.rec[slot].smp;
                     smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
                     smp.dimension = (int)s4.z;
@@ -884,7 +885,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
                     }
                 }
             }
-            if (sp) ps.rec[slot].smp.z = (uint32_t)smp.dimension;
+            if constexpr (DIMS) { if (sp) ps.rec[slot].smp.z = (uint32_t)smp.dimension; }
         }
         const uint32_t qseg = blockIdx.x & 7;
         const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
