@@ -417,6 +417,10 @@ def main():
     step(count=True)
     sync_all()
     work = ctx.counters()
+    try:
+        trace_clk = ctx.trace_clock()   # shader clock inside the traversal launches of the counting pass (s_memtime / s_memrealtime per wave)
+    except Exception:
+        trace_clk = None
     for _ in range(max(0, args.warmup - 1)):
         step()
     sync_all()
@@ -531,6 +535,9 @@ def main():
                     roofline["valu_issue"] = vi
             except Exception as e:   # measurement aid only
                 log("[bench] VALU issue figure not measured: %s" % e)
+        if trace_clk and trace_clk.get("closest_GHz"):
+            roofline["shader_clock_GHz"] = {"closest": round(trace_clk["closest_GHz"], 3), "anyhit": round(trace_clk["anyhit_GHz"], 3),
+                                            "source": "s_memtime / s_memrealtime ticks per wave inside the launches of the counting pass (mi_trace_clock)"}
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the

@@ -581,6 +581,11 @@ int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
  * requests per second -- the memory-side ceiling of a BVH interior step (the traversal kernels are bound by the request rate of incoherent
  * 16-byte loads, not by HBM bandwidth: DESIGN.md s.5). */
 int mi_gather_rate(mi_ctx *ctx, uint64_t bytes, int loads_per_record, double *grequests_per_s);
+/* Measurement aid (bench.py's `roofline.valu_issue`): the shader clock the traversal kernels really ran at during the COUNTING passes since
+ * the last mi_counters_reset -- every wave stamps s_memtime (shader-clock ticks) and s_memrealtime (constant-rate ticks) when it starts and when it
+ * ends.  out[0] = GHz inside the closest-hit launches, out[1] = GHz inside the any-hit launches (0: no counting pass ran), out[2], out[3] = the
+ * summed wave lifetimes in shader cycles (closest, any). */
+int mi_trace_clock(mi_ctx *ctx, double out[4]);
 
 /* ---- stage-level entry points (the same kernels, exposed for ray-by-ray parity tests) ---- */
 

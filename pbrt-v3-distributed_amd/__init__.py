@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_trace_clock", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_camera_differentials", "mi_li",
 ]
 
@@ -114,6 +114,7 @@ def device_lib():
         L.mi_film_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+        L.mi_trace_clock.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_intersect_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_triangle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -290,6 +291,12 @@ class Context:
         n = np.zeros(MI_K_COUNT, dtype=np.uint64)
         self._chk(device_lib().mi_timing_get(self._ctx, _ptr(ms), _ptr(n)), "mi_timing_get")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    def trace_clock(self):
+        """shader clock (GHz) inside the closest-hit / any-hit launches of the counting passes since the last counters_reset"""
+        out = np.zeros(4, dtype=np.float64)
+        self._chk(device_lib().mi_trace_clock(self._ctx, _ptr(out)), "mi_trace_clock")
+        return {"closest_GHz": float(out[0]), "anyhit_GHz": float(out[1]), "closest_wave_cycles": float(out[2]), "anyhit_wave_cycles": float(out[3])}
 
     def stream_read_gbps(self, nbytes=4 << 30):
         """achievable HBM read rate (streaming read of nbytes), GB/s"""

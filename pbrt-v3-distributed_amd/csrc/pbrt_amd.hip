@@ -233,6 +233,8 @@ PT_DEV uint32_t wave_key_rank(uint32_t *keycount, uint32_t key, bool active) {
     }
     return rank;
 }
+// slots 64..67 (counting passes only, mi_trace_clock): per-wave s_memtime / s_memrealtime ticks spent inside the closest-hit and any-hit kernels
+#define PT_CNT_CLK 64
 PT_DEV void wave_count(unsigned long long *counter, uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
@@ -565,6 +567,8 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     ts.cur = TRAV_DONE;
     TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (COUNT) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }   // s_memtime / s_memrealtime: the shader clock this kernel really runs at (mi_trace_clock)
     // hands a finished ray's result over (hit record + sort key / the unoccluded light term / the MIS term)
     auto finalize = [&]() {
         if (active && TraceDone<PEND>(ts)) {
@@ -723,6 +727,10 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_CLOSEST : (MODE == 1 ? MI_CNT_NODES_MIS : MI_CNT_NODES_ANY)], tc.nodes);
         wave_count(&ps.counters[MODE == 0 ? MI_CNT_TRIS_CLOSEST : (MODE == 1 ? MI_CNT_TRIS_MIS : MI_CNT_TRIS_ANY)], tc.tris);
         if (HOT > 0) wave_count(&ps.counters[MODE == 0 ? MI_CNT_NODES_HOT_CLOSEST : (MODE == 1 ? MI_CNT_NODES_HOT_MIS : MI_CNT_NODES_HOT_ANY)], tc.hot);
+        if (MODE != 1 && lane == 0) {
+            atomicAdd(&ps.counters[PT_CNT_CLK + (MODE == 2 ? 2 : 0)], (unsigned long long)__builtin_readcyclecounter() - clk0);
+            atomicAdd(&ps.counters[PT_CNT_CLK + (MODE == 2 ? 3 : 1)], (unsigned long long)wall_clock64() - rt0);
+        }
     }
 }
 
@@ -981,7 +989,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #ifndef PT_SHADE_PROF
 #define PT_SHADE_PROF 0
 #endif
-#define PT_CNT_ALLOC 64
+#define PT_CNT_ALLOC 72
 #if PT_SHADE_PROF
 // developer instrumentation: wave time between consecutive probes (all memory drained at each probe)
 #define PROBE(k)                                                                                     \
@@ -3094,6 +3102,20 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     }
 #endif
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int mi_trace_clock(mi_ctx *c, double out[4]) {
+    if (!c || !out) return fail("mi_trace_clock: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t t[4];
+    HIP_TRY(hipMemcpyAsync(t, (const uint64_t *)c->counters.p + PT_CNT_CLK, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int wallKHz = 0;
+    if (hipDeviceGetAttribute(&wallKHz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || wallKHz <= 0) wallKHz = 100000;
+    out[0] = t[1] ? (double)t[0] / (double)t[1] * wallKHz * 1e-6 : 0.0;   // GHz, closest hit
+    out[1] = t[3] ? (double)t[2] / (double)t[3] * wallKHz * 1e-6 : 0.0;   // GHz, any hit
+    out[2] = (double)t[0];
+    out[3] = (double)t[2];
     return 0;
 }
 int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
