@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 12
+#define MI_ABI_VERSION 13   /* 13: mi_owned_tiles / mi_tile_owner (2-D lattice tile map), mi_trace_clock */
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -456,8 +456,33 @@ void mi_ctx_destroy(mi_ctx *ctx);
  * Builds the BVH4, triangle records and tables in HBM. */
 int mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 
+/* Tile -> rank map of an N-way tile-sharded frame (the ONE definition: mi_render, the reference-side bindings, parallel.py and the test
+ * checker all call it).  Tile (tx, ty) of the reference's 16x16 grid (integrator.cpp:233-240) belongs to rank (tx + skew(world) * ty) mod world:
+ * a skewed 2-D lattice, so that a rank's tiles are spread over the whole image in BOTH directions (the row-major t mod world of rounds 1-3 gave
+ * every rank full-height tile columns whenever world divides the tiles per row, e.g. 120 tiles per row at 1080p and world = 8).  skew(world) is
+ * the s in [0, world) whose lattice {(dx, dy): dx + s dy = 0 mod world} has the longest shortest vector (ties: the smallest s): 1 for world 2,
+ * 2 for 4 and 5, 3 for 8 (nearest same-rank tiles sqrt(8) tiles apart).  Any exact cover of the tiles renders the same image: the Sobol' /
+ * Halton sample of (pixel, k) is a function of the pixel and k alone. */
+static inline int mi_tile_skew(int world) {
+    int best = 0, bestLen = -1;
+    for (int s = 0; s < world; ++s) {
+        int len = 0x7fffffff;
+        for (int dy = 0; dy <= world; ++dy)
+            for (int dx = -world; dx <= world; ++dx) {
+                if ((dx == 0 && dy == 0) || ((dx + s * dy) % world + world) % world != 0) continue;
+                if (dx * dx + dy * dy < len) len = dx * dx + dy * dy;
+            }
+        if (len > bestLen) { bestLen = len; best = s; }
+    }
+    return best;
+}
+static inline int mi_tile_owner(int tx, int ty, int world, int skew) { return world <= 1 ? 0 : (int)(((int64_t)tx + (int64_t)skew * ty) % world); }
+/* the row-major tile ids (ty * n_tiles_x + tx, ascending) of `rank`; returns their number; `out` may be NULL (count only).  Exported by
+ * libpbrt_amd.so for callers that cannot include this header (pbrt-v3-distributed_amd/parallel.py). */
+int64_t mi_owned_tiles(int n_tiles_x, int n_tiles_y, int rank, int world, uint32_t *out);
+
 /* SamplerIntegrator::Render (integrator.cpp:228-339) over the 16x16 tiles owned by `rank` of
- * `world` (tile t -> rank t % world; integrator.cpp:235-240 gives the tile grid), samples
+ * `world` (mi_tile_owner above; integrator.cpp:235-240 gives the tile grid), samples
  * [spp_begin, spp_end) of every owned pixel, accumulated into the device film
  * (FilmTile::AddSample semantics, film.h:121-161).  Asynchronous on the ctx stream: the call returns when the launches are
  * queued (contexts on different GPUs render concurrently when driven from one host thread); mi_sync / mi_film_download wait.

@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_trace_clock", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_trace_clock", "mi_owned_tiles", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_camera_differentials", "mi_li",
 ]
 
@@ -171,6 +171,10 @@ class Scene:
         self.info.update(n_textures=int(tinfo[0]), n_images=int(tinfo[1]), n_textured_materials=int(tinfo[2]), n_masked_meshes=int(tinfo[3]))
         L.pbrt_amd_scene_media_info(self._h, tinfo)
         self.info.update(n_media=int(tinfo[0]), n_medium_transitions=int(tinfo[1]), camera_medium=int(tinfo[2]), integrator=("path", "volpath")[int(tinfo[3])])
+        finfo = (C.c_double * 6)()
+        L.pbrt_amd_scene_film_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.pbrt_amd_scene_film_info(self._h, finfo)
+        self.info.update(filter_radius=(float(finfo[0]), float(finfo[1])), sample_bounds=(int(finfo[2]), int(finfo[3]), int(finfo[4]), int(finfo[5])))
         self.width = self.info["crop_x1"] - self.info["crop_x0"]
         self.height = self.info["crop_y1"] - self.info["crop_y0"]
 

@@ -251,23 +251,8 @@ PT_DEV V3 XfPoint(const float *m, const V3 &p) {   // core/transform.h:223-234
     Float inv = (Float)1 / wp;
     return V3(inv * xp, inv * yp, inv * zp);
 }
-PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy, Float *lens0, Float *lens1) {
-    Float u[5];
-    if (Sampler::Pix(sc)) {   // Sampler::GetCameraSample core/sampler.cpp:44-50: pFilm = Get2D(), time = Get1D(), pLens = Get2D()
-        smp.PixGet2D(sc, &u[0], &u[1]);
-        u[2] = smp.PixGet1D(sc);
-        smp.PixGet2D(sc, &u[3], &u[4]);
-    } else
-        SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
-    Float u0 = u[0], u1 = u[1];
-    if (sc.sampler_type == MI_SAMPLER_SOBOL) {
-        // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57); Halton's are in-pixel already
-        u0 = clampf((u[0] * sc.sobol_resolution + sc.sample_min[0]) - smp.px, (Float)0, PT_ONE_MINUS_EPS);
-        u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
-    }
-    Float l0 = u[3], l1 = u[4];
-    if (!Sampler::Pix(sc)) smp.dimension = 5;
-    Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;   // static scene: the time sample (dim 2) is never read
+// the camera half of GenerateCameraRay: film position + lens sample -> world-space ray (cameras/perspective.cpp:95-144, transform.h:252-264)
+PT_DEV void CameraRayFromFilm(const DevScene &sc, Float pFilmX, Float pFilmY, Float l0, Float l1, V3 *o, V3 *d, Float *tMax) {
     const mi_camera &cam = sc.camera;
     V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
     V3 ro(0, 0, 0), rd = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
@@ -294,7 +279,27 @@ PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Fl
         wo_ = wo_ + wd * dt;
         tm -= dt;
     }
-    *o = wo_; *d = wd; *tMax = tm; *pfx = pFilmX; *pfy = pFilmY; *lens0 = l0; *lens1 = l1;
+    *o = wo_; *d = wd; *tMax = tm;
+}
+PT_DEV void GenerateCameraRay(const DevScene &sc, Sampler &smp, V3 *o, V3 *d, Float *tMax, Float *pfx, Float *pfy, Float *lens0, Float *lens1) {
+    Float u[5];
+    if (Sampler::Pix(sc)) {   // Sampler::GetCameraSample core/sampler.cpp:44-50: pFilm = Get2D(), time = Get1D(), pLens = Get2D()
+        smp.PixGet2D(sc, &u[0], &u[1]);
+        u[2] = smp.PixGet1D(sc);
+        smp.PixGet2D(sc, &u[3], &u[4]);
+    } else
+        SamplerBatch<5>(sc, smp.index, 0, u);   // dims 0,1 film offset, 2 time, 3,4 lens
+    Float u0 = u[0], u1 = u[1];
+    if (sc.sampler_type == MI_SAMPLER_SOBOL) {
+        // SobolSampler::SampleDimension remaps the two pixel dimensions (samplers/sobol.cpp:54-57); Halton's are in-pixel already
+        u0 = clampf((u[0] * sc.sobol_resolution + sc.sample_min[0]) - smp.px, (Float)0, PT_ONE_MINUS_EPS);
+        u1 = clampf((u[1] * sc.sobol_resolution + sc.sample_min[1]) - smp.py, (Float)0, PT_ONE_MINUS_EPS);
+    }
+    Float l0 = u[3], l1 = u[4];
+    if (!Sampler::Pix(sc)) smp.dimension = 5;
+    Float pFilmX = (Float)smp.px + u0, pFilmY = (Float)smp.py + u1;   // static scene: the time sample (dim 2) is never read
+    CameraRayFromFilm(sc, pFilmX, pFilmY, l0, l1, o, d, tMax);
+    *pfx = pFilmX; *pfy = pFilmY; *lens0 = l0; *lens1 = l1;
 }
 
 // ---- the tile-serial samplers (ABI v11).  `sampler->Clone(seed = tile.y * nTiles.x + tile.x)` gives every 16x16 tile ONE PCG32 stream
@@ -755,11 +760,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_hot_probe(DevScene sc, uint32_t nP
     const uint32_t W = (uint32_t)(sc.sample_max[0] - sc.sample_min[0]), H = (uint32_t)(sc.sample_max[1] - sc.sample_min[1]);
     const uint32_t gx = i % npx, gy = (i / npx) % npy, s = (i / (npx * npy)) % (uint32_t)sc.spp;
     const int x = sc.sample_min[0] + (int)(((uint64_t)gx * W + W / 2) / npx), y = sc.sample_min[1] + (int)(((uint64_t)gy * H + H / 2) / npy);
-    Sampler smp;
-    smp.Start(sc, x, y, s);
+    // the probe's own camera samples (a hash of the path number): it must not touch the scene's sampler state -- the tile-serial samplers keep one
+    // stream per tile in pix_rng / pix_s1 / pix_s2, not yet initialised at upload time and not indexable per probe lane
     V3 o, d;
-    Float tMax, pfx, pfy, l0, l1;
-    GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy, &l0, &l1);
+    Float tMax;
+    const Float h0 = (Float)(ProbeHash(i, 0x51u + s) >> 8) * 0x1p-24f, h1 = (Float)(ProbeHash(i, 0x52u + s) >> 8) * 0x1p-24f;
+    const Float h2 = (Float)(ProbeHash(i, 0x53u + s) >> 8) * 0x1p-24f, h3 = (Float)(ProbeHash(i, 0x54u + s) >> 8) * 0x1p-24f;
+    CameraRayFromFilm(sc, (Float)x + h0, (Float)y + h1, h2, h3, &o, &d, &tMax);
     TraceCounters tc = {0, 0, 0};
     for (int b = 0; b <= bounces; ++b) {
         TravStateQ ts;
@@ -2254,6 +2261,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     sc.rr_threshold = d->integrator.rr_threshold;
     sc.sampler_type = d->integrator.sampler;
     if (sc.sampler_type < MI_SAMPLER_SOBOL || sc.sampler_type > MI_SAMPLER_MAXMIN) return fail("mi_scene_upload: unknown sampler");
+    if (MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type)) sc.sobol_resolution = sc.sobol_log2_resolution = 0;   // not a GlobalSampler: whatever the caller left in the Sobol' fields is never an index
     sc.pix_maxmin = nullptr;
     sc.pix_rng = nullptr; sc.pix_s1 = sc.pix_s2 = nullptr; sc.pix_nd = 0; sc.strat_nx = sc.strat_ny = 1; sc.strat_jitter = 0;
     if (MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type)) {   // one PCG32 stream per tile + the current pixel's precomputed dimensions
@@ -2520,11 +2528,14 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK_MIN);
     {
         const size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4);
-        ALLOC(spill, uint32_t, (size_t)c->gridBlocks * PT_BLOCK * words4);
+        // slices for the largest number of threads any traversal launch has: the 256-thread shape launches gridBlocks x PT_BLOCK, a TraceShape<...>::BIG
+        // launch roundup8(numCUs x PER_CU) x BLOCK <= numCUs x PT_GRID_PER_CU x PT_BLOCK + 7 x BLOCK (the static_assert of TraceShape) -- hence the margin
+        const size_t spillThreads = (size_t)c->gridBlocks * PT_BLOCK + 8 * 1024;
+        ALLOC(spill, uint32_t, spillThreads * words4);
         c->cursor2 = c->spill2 = nullptr;
         if (c->overlapNee) {
             c->cursor2 = (uint32_t *)A(sizeof(uint32_t) * QSEG * QC_STRIDE);
-            c->spill2 = (uint32_t *)A(sizeof(uint32_t) * (size_t)c->gridBlocks * PT_BLOCK * words4);
+            c->spill2 = (uint32_t *)A(sizeof(uint32_t) * spillThreads * words4);
             if (!c->cursor2 || !c->spill2) return -1;
         }
     }
@@ -2689,6 +2700,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 tic(c, which ? MI_K_MIS_CLOSEST : MI_K_ANYHIT);
                 uint32_t rowIn = which ? QC_MIS : QC_SHADOW, rowOut = which ? QC_MIS2 : QC_SHADOW2;
                 uint32_t *qIn = which ? ps.q_mis : ps.q_shadow, *qOut = ps.q_tr[which];
+                bool drained = false;
                 for (int round = 0; round < 4096; ++round) {
                     HIP_TRY(hipMemsetAsync(ps.qcount + QCI(rowOut, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
                     HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
@@ -2713,10 +2725,11 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         HIP_TRY(hipMemcpyAsync(row, ps.qcount + QCI(rowIn, 0), sizeof(row), hipMemcpyDeviceToHost, st));
                         HIP_TRY(hipStreamSynchronize(st));
                         for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
-                        if (left == 0) break;
+                        if (left == 0) { drained = true; break; }
                     }
                 }
                 toc(c);
+                if (!drained) return fail("mi_render: a walked shadow / MIS ray crossed more than 4096 medium interfaces (direct-lighting terms would be missing)");
             }
             return 0;
         };
@@ -2856,14 +2869,15 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     if (rank < 0 || rank >= world) return fail("mi_render: rank out of range");
     int s0 = std::max(0, rp->spp_begin), s1 = rp->spp_end < 0 ? sc.spp : std::min(rp->spp_end, sc.spp);
     if (s1 <= s0) return 0;
-    // tile grid of SamplerIntegrator::Render (integrator.cpp:233-237); tile t belongs to rank t % world
+    // tile grid of SamplerIntegrator::Render (integrator.cpp:233-237); tile (tx, ty) belongs to rank mi_tile_owner(tx, ty, world) (include/pbrt_amd.h)
     const int tileSize = 16;
     int ex = sc.sample_max[0] - sc.sample_min[0], ey = sc.sample_max[1] - sc.sample_min[1];
     int nTx = (ex + tileSize - 1) / tileSize, nTy = (ey + tileSize - 1) / tileSize;
     if (c->tilesRank != rank || c->tilesWorld != world) {   // the owned-tile list changes only with the sharding: no allocation on repeated frames
         HIP_TRY(hipStreamSynchronize(c->stream));           // a pass still reading the old list / the host staging copy
         c->tilesHost.clear();
-        for (int t = rank; t < nTx * nTy; t += world) c->tilesHost.push_back((uint32_t)t);
+        c->tilesHost.resize((size_t)mi_owned_tiles(nTx, nTy, rank, world, nullptr));
+        mi_owned_tiles(nTx, nTy, rank, world, c->tilesHost.data());
         c->tilesCount = c->tilesHost.size();
         if (c->tilesCount && upload(c, c->tiles, c->tilesHost.data(), c->tilesCount * sizeof(uint32_t))) return -1;
         c->tilesRank = rank; c->tilesWorld = world;
@@ -2940,6 +2954,16 @@ static int guard_check(mi_ctx *c, const char *who) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (trips) return fail(std::string(who) + ": " + std::to_string((unsigned long long)trips) + " traversal wave(s) hit the non-termination guard -- the frame is invalid");
     return 0;
+}
+int64_t mi_owned_tiles(int n_tiles_x, int n_tiles_y, int rank, int world, uint32_t *out) {
+    if (world < 1) world = 1;
+    if (n_tiles_x <= 0 || n_tiles_y <= 0 || rank < 0 || rank >= world) return 0;
+    const int skew = mi_tile_skew(world);
+    int64_t n = 0;
+    for (int ty = 0; ty < n_tiles_y; ++ty)
+        for (int tx = 0; tx < n_tiles_x; ++tx)
+            if (mi_tile_owner(tx, ty, world, skew) == rank) { if (out) out[n] = (uint32_t)(ty * n_tiles_x + tx); ++n; }
+    return n;
 }
 int mi_sync(mi_ctx *c) {
     if (!c) return fail("mi_sync: null ctx");

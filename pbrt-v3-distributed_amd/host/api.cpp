@@ -795,8 +795,17 @@ void pbrtWorldEnd() {
                 sampler = std::make_shared<HaltonSampler>(nsamp, smin, smax, atCenter);
             } else if (tileSerialName && (PbrtOptions.fastSamplers || (fastEnv && fastEnv[0] == '1'))) {
                 // the user's choice (--fast-samplers): an unbiased image of the same scene at wavefront speed, not the reference's pixel values
+                // the sample count the reference's sampler of that name would use (random.cpp:60-63: 4; stratified.cpp:72-80: xsamples * ysamples, 4 x 4;
+                // zerotwosequence.cpp:41-50, 116-121: "pixelsamples" 16 rounded up to a power of two)
                 if (renderOptions->SamplerName == "stratified")
                     nsamp = renderOptions->SamplerParams.FindOneInt("xsamples", 4) * renderOptions->SamplerParams.FindOneInt("ysamples", 4);
+                else if (renderOptions->SamplerName == "random")
+                    nsamp = renderOptions->SamplerParams.FindOneInt("pixelsamples", 4);
+                else {
+                    int64_t p2 = 1;
+                    while (p2 < (int64_t)std::max(1, nsamp)) p2 <<= 1;
+                    nsamp = (int)p2;
+                }
                 if (PbrtOptions.quickRender) nsamp = 1;
                 Warning("--fast-samplers: Sampler \"%s\" renders with \"sobol\" at %d spp (not the reference's image; without the flag the tile-serial rounds reproduce it).",
                         renderOptions->SamplerName.c_str(), nsamp);

@@ -176,8 +176,8 @@ pbrt_amd_scene *pbrt_amd_scene_map_blob(const char *path) {
     struct stat st;
     BlobHeader hdr;
     if (::fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(hdr) || ::pread(fd, &hdr, sizeof(hdr), 0) != (ssize_t)sizeof(hdr) || std::memcmp(hdr.magic, kMagic, 8) != 0 ||
-        hdr.abi != MI_ABI_VERSION || hdr.headerBytes != sizeof(hdr) || hdr.totalBytes > (uint64_t)st.st_size || hdr.descOffset + sizeof(mi_scene_desc) > hdr.totalBytes ||
-        hdr.fixupOffset + hdr.nFixups * 8 > hdr.totalBytes) {
+        hdr.abi != MI_ABI_VERSION || hdr.headerBytes != sizeof(hdr) || hdr.totalBytes > (uint64_t)st.st_size || hdr.descOffset > hdr.totalBytes || sizeof(mi_scene_desc) > hdr.totalBytes - hdr.descOffset ||
+        hdr.fixupOffset > hdr.totalBytes || hdr.nFixups > (hdr.totalBytes - hdr.fixupOffset) / 8) {   // (no sum or product that could wrap)
         ::close(fd);
         return nullptr;
     }

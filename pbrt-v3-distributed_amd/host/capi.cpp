@@ -51,6 +51,13 @@ void pbrt_amd_scene_info(pbrt_amd_scene *s, int64_t *out) {
     for (int i = 0; i < 16; ++i) out[i] = v[i];
 }
 
+// the film's filter radius (pixels) and sample bounds -- what a tile-sharded frame needs to know which pixels OUTSIDE a rank's tiles its samples reach
+void pbrt_amd_scene_film_info(pbrt_amd_scene *s, double *out) {
+    const mi_film &f = s->flat->desc.film;
+    const double v[6] = {f.filter_radius[0], f.filter_radius[1], (double)f.sample_min[0], (double)f.sample_min[1], (double)f.sample_max[0], (double)f.sample_max[1]};
+    for (int i = 0; i < 6; ++i) out[i] = v[i];
+}
+
 // ComputeBeamDiffusionBSSRDF as the host restates it (host/bssrdf.cpp): the 100 x 64 table of a Subsurface / KdSubsurface material for (g, eta).
 // out: rho samples [100], radius samples [64], profile [6400], rhoEff [100], profileCDF [6400], in that order
 int pbrt_amd_bssrdf_table(float g, float eta, float *out) {

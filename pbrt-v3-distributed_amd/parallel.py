@@ -2,7 +2,8 @@
 
 The path shards naturally: image tiles (the reference's 16x16 tiles, core/integrator.cpp:233-240) are independent given
 the replicated scene, and the Sobol' sample of (pixel, k) is a pure function of the pixel and k (samplers/sobol.cpp:42-45).
-Tile t = ty * nTilesX + tx belongs to rank t % world (mi_render applies the same rule on the device).  The only exchange
+Tile (tx, ty) belongs to rank mi_tile_owner(tx, ty, world) of include/pbrt_amd.h -- a skewed 2-D lattice, so that every rank's tiles are
+spread over the whole image (mi_render applies the same rule on the device).  The only exchange
 is the FilmTilePixel buffers at the end of a frame: every rank holds a full-size film that is zero outside its tiles
 (plus, rarely, a neighbour pixel that a sample landing exactly on a pixel edge also contributes to), so a SUM reduction to
 rank 0 is exactly the gather of the owned tiles -- and stays exact for those edge pixels, which a plain gather would drop.
@@ -10,17 +11,95 @@ rank 0 is exactly the gather of the owned tiles -- and stays exact for those edg
 
 
 def owned_tiles(rank, world, n_tiles_x, n_tiles_y):
-    """tile ids of `rank`: round-robin over the row-major tile index (same rule as mi_render / oracle_render_sharded)"""
-    return list(range(rank, n_tiles_x * n_tiles_y, world))
+    """row-major tile ids of `rank`: mi_tile_owner of include/pbrt_amd.h (a skewed 2-D lattice over the tile grid), through the library's own
+    mi_owned_tiles so that mi_render, the reference-side bindings, the test checker and this module share ONE definition"""
+    import ctypes, importlib
+    import numpy as np
+    L = importlib.import_module(__package__).device_lib()
+    L.mi_owned_tiles.restype = ctypes.c_int64
+    L.mi_owned_tiles.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    n = L.mi_owned_tiles(n_tiles_x, n_tiles_y, rank, world, None)
+    out = np.zeros(max(1, n), dtype=np.uint32)
+    L.mi_owned_tiles(n_tiles_x, n_tiles_y, rank, world, out.ctypes.data_as(ctypes.c_void_p))
+    return [int(t) for t in out[:n]]
 
 
 def combine_films(film, dst=0):
-    """In-place SUM-reduce of the per-rank film tensors (float32, 4 per cropped pixel) onto rank `dst`.
-    Works for CPU tensors (gloo) and for device tensors (RCCL over xGMI)."""
+    """In-place SUM-reduce of the per-rank film tensors (float32, 4 per cropped pixel) onto rank `dst`: the dense form of the exchange
+    (every rank moves the whole film).  Works for CPU tensors (gloo) and for device tensors (RCCL over xGMI).  FilmExchange below is the sparse
+    form ShardedFrame uses."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
+
+
+def reach_pixels(rank, world, width, height, sample_bounds, crop_origin, filter_radius):
+    """Flat indices (row-major over the cropped film, ascending) of every film pixel the samples of `rank`'s tiles can contribute to: its tiles,
+    each grown by floor(radius + 1/2) pixels per axis and clipped to the film (Film::GetFilmTile core/film.cpp:95-106 computes the same reach for
+    one tile).  For the box filter (radius 1/2) that is the tile plus a one-pixel ring -- a sample that lands exactly on a pixel edge also counts
+    for the neighbour."""
+    import numpy as np
+    sx0, sy0, sx1, sy1 = sample_bounds
+    ntx, nty = (sx1 - sx0 + 15) // 16, (sy1 - sy0 + 15) // 16
+    hx, hy = int(np.floor(filter_radius[0] + 0.5)), int(np.floor(filter_radius[1] + 0.5))
+    mask = np.zeros((height, width), dtype=bool)
+    cx0, cy0 = crop_origin
+    for t in owned_tiles(rank, world, ntx, nty):
+        ty, tx = divmod(t, ntx)
+        x0, y0 = sx0 + 16 * tx - hx - cx0, sy0 + 16 * ty - hy - cy0
+        x1, y1 = min(sx0 + 16 * tx + 16, sx1) + hx - cx0, min(sy0 + 16 * ty + 16, sy1) + hy - cy0
+        mask[max(0, y0):max(0, min(height, y1)), max(0, x0):max(0, min(width, x1))] = True
+    return np.flatnonzero(mask.reshape(-1))
+
+
+class FilmExchange:
+    """The one exchange of the path, sparse: rank r sends the FilmTilePixels its samples can reach (reach_pixels: its own tiles + the filter's
+    ring, 16.6 MB x 1.27 per rank for a 4K film on 8 ranks under the box filter) to rank `dst`, which ADDS them into its film -- equal to the
+    SUM-reduce of the full films (133 MB per rank) because a rank's film is zero everywhere else, exact for every filter, and deterministic
+    (contributions are added in rank order).  One grouped send / recv per frame (RCCL over xGMI with backend "nccl": point-to-point links, so
+    the seven senders use seven different links into rank 0's GPU); gloo moves the packed buffers through host memory."""
+
+    def __init__(self, scene, rank, world, device, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world, self.dst = torch, dist, rank, world, dst
+        self.via_host = dist.get_backend() == "gloo"
+        info = scene.info
+        args = (scene.width, scene.height, info["sample_bounds"], (info["crop_x0"], info["crop_y0"]), info["filter_radius"])
+        ranks = [r for r in range(world) if r != dst] if rank == dst else [rank]
+        self.idx = {r: torch.from_numpy(reach_pixels(r, world, *args)).to(device) for r in ranks}
+        comm_dev = "cpu" if self.via_host else device
+        self.buf = {r: torch.empty((len(self.idx[r]), 4), dtype=torch.float32, device=comm_dev) for r in ranks}
+        self.bytes_moved = sum(b.numel() * 4 for b in self.buf.values())
+
+    def start(self, film):
+        """Enqueue the exchange of `film` (flat float32 tensor, 4 per pixel) and return what finish() waits for.  With RCCL nothing here blocks the
+        host: packing, the transfers and rank `dst`'s adds are stream-ordered on torch's current stream / RCCL's own (Work.wait() makes the
+        current STREAM wait), so the caller goes on -- ShardedFrame renders the next frame meanwhile.  gloo completes inside this call."""
+        torch, dist = self.torch, self.dist
+        px = film.view(-1, 4)
+        if self.rank != self.dst:
+            packed = px.index_select(0, self.idx[self.rank])
+            if self.via_host:
+                self.buf[self.rank].copy_(packed)
+                packed = self.buf[self.rank]
+            dist.isend(packed, dst=self.dst).wait()
+            self._keep = packed   # alive until the send has been consumed (finish)
+        else:
+            works = [(r, dist.irecv(self.buf[r], src=r)) for r in sorted(self.buf)]
+            for r, work in works:   # rank order: the sum is deterministic
+                work.wait()
+                px.index_add_(0, self.idx[r], self.buf[r].to(px.device) if self.via_host else self.buf[r])
+        if film.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            return ev
+        return None
+
+    def finish(self, pending):
+        if pending is not None:
+            pending.synchronize()
 
 
 def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
@@ -31,20 +110,61 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
     import importlib, os, time
     pa = importlib.import_module(__package__)
     t0 = time.time()
+    born = _launcher_start_time()   # a blob older than this job's launcher belongs to an earlier job whose pid was reused: never mapped
     if local_rank == 0:
-        sc = load()
+        for f in (blob_path, blob_path + ".failed"):   # leftovers of a crashed job with the same launcher pid
+            try:
+                os.remove(f)
+            except OSError:
+                pass
         try:
-            sc.save_blob(blob_path)
+            sc = load()
+        except BaseException as e:   # parse error, out of memory ...: tell the waiting ranks before re-raising, or they poll until the timeout
+            _write_failed(blob_path, "load failed: %r" % (e,))
+            raise
+        try:
+            sc.save_blob(blob_path + ".tmp")
+            os.rename(blob_path + ".tmp", blob_path)   # published complete or not at all
         except Exception as e:   # no room in /dev/shm, read-only directory ...: the other ranks build the scene themselves instead of waiting for nothing
-            open(blob_path + ".failed", "w").write(str(e))
+            _write_failed(blob_path, str(e))
         return sc, time.time() - t0, "built"
-    while not os.path.exists(blob_path):
-        if os.path.exists(blob_path + ".failed"):
-            return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
+    while True:
+        try:
+            if os.path.getmtime(blob_path) >= born:
+                break
+        except OSError:
+            pass
+        try:
+            if os.path.getmtime(blob_path + ".failed") >= born:
+                return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
+        except OSError:
+            pass
         if time.time() - t0 > timeout_s:
             raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
         time.sleep(0.1)
     return pa.Scene(blob=blob_path), time.time() - t0, "mapped"
+
+
+def _write_failed(blob_path, text):
+    try:
+        with open(blob_path + ".failed", "w") as f:
+            f.write(text)
+    except OSError:
+        pass
+
+
+def _launcher_start_time():
+    """Wall-clock start time of this process's parent (the launcher all local ranks share), from /proc; 0.0 when it cannot be read.  One second is
+    subtracted for the granularity of /proc's clock ticks and of file mtimes."""
+    import os
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])   # field 22: starttime, in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(float(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK") - 1.0
+    except Exception:
+        return 0.0
 
 
 def launch_ranks(n_ranks, script, argv, backend_env=None):
@@ -64,17 +184,20 @@ def launch_ranks(n_ranks, script, argv, backend_env=None):
 
 
 class ShardedFrame:
-    """One rank of the tile-sharded frame: the rank's device context renders the tiles t with t % world == rank into a film that
-    lives in a torch tensor, and `step()` ends with the only exchange of the path -- the SUM-reduce of the films onto rank 0
-    (RCCL ncclReduce over xGMI when the backend is "nccl").  world == 1: no torch, no collective.
+    """One rank of the tile-sharded frame: the rank's device context renders its tiles (mi_tile_owner) into a film that lives in a torch
+    tensor, and `step()` ends by STARTING the only exchange of the path -- FilmExchange: every rank's reachable pixels added into rank 0's film,
+    RCCL send / recv over xGMI when the backend is "nccl" -- which then runs while the next step renders into the second film buffer (the two
+    buffers alternate; a buffer is reused only after its exchange has finished).  world == 1: no torch, no exchange.
+    `exchange="reduce"` keeps round 3's dense form (SUM-reduce of the whole film, synchronous) as the A/B partner.
 
-        frame = ShardedFrame(ctx, scene, backend="nccl", one_device=False)   # reads RANK / WORLD_SIZE / LOCAL_RANK
-        frame.step(); frame.sync_all()
+        frame = ShardedFrame(ctx, scene, rank, world, local_rank, backend="nccl")
+        frame.step(); frame.step(); frame.sync_all(); img = frame.root_film()
     """
 
-    def __init__(self, ctx, scene, rank, world, local_rank, backend="nccl", one_device=False):
+    def __init__(self, ctx, scene, rank, world, local_rank, backend="nccl", one_device=False, exchange="sparse"):
         self.ctx, self.scene, self.rank, self.world = ctx, scene, rank, world
         self.torch = self.dist = self.film = None
+        self.films, self.pending, self.k, self.xchg, self.dense = [], [None, None], 0, None, exchange != "sparse"
         if world > 1:
             import torch
             import torch.distributed as dist
@@ -86,20 +209,41 @@ class ShardedFrame:
                     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
                 else:
                     dist.init_process_group(backend=backend)
-            self.film = torch.zeros(scene.height * scene.width * 4, dtype=torch.float32, device="cuda")
-            ctx.film_bind(self.film.data_ptr())   # mi_render accumulates straight into the tensor the collective reduces
+            n = scene.height * scene.width * 4
+            self.films = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(1 if self.dense else 2)]
+            self.film = self.films[0]
+            if not self.dense:
+                self.xchg = FilmExchange(scene, rank, world, torch.device("cuda", dev))
+            ctx.film_bind(self.film.data_ptr())   # mi_render accumulates straight into the tensor the exchange reads
+
+    def _finish(self, slot):
+        if self.pending[slot] is not None:
+            self.xchg.finish(self.pending[slot])   # the adds on rank 0 / the packing on the others: done before the buffer is cleared again
+            self.pending[slot] = None
 
     def step(self, count_work=False, max_paths=0):
+        if self.world > 1 and not self.dense:
+            slot = self.k % 2
+            self._finish(slot)                 # the exchange that last used this buffer (two steps ago)
+            self.film = self.films[slot]
+            self.ctx.film_bind(self.film.data_ptr())
         self.ctx.film_clear()
         self.ctx.render(rank=self.rank, world=self.world, count_work=count_work, max_paths=max_paths, sync=False)
         if self.world > 1:
             self.ctx.sync()                    # the ctx stream is not torch's current stream
-            combine_films(self.film, dst=0)
-            self.torch.cuda.synchronize()      # the reduction reads the film: done before the next step clears it
+            if self.dense:
+                combine_films(self.film, dst=0)
+                self.torch.cuda.synchronize()  # the reduction reads the film: done before the next step clears it
+            else:
+                self.pending[self.k % 2] = self.xchg.start(self.film)   # runs while the next step renders into the other buffer
+        self.k += 1
 
     def sync_all(self):
         self.ctx.sync()
         if self.world > 1:
+            if not self.dense:
+                for slot in ((self.k) % 2, (self.k + 1) % 2):   # older exchange first
+                    self._finish(slot)
             self.torch.cuda.synchronize()
             self.dist.barrier()
             self.torch.cuda.synchronize()
@@ -124,6 +268,8 @@ class ShardedFrame:
         """rank 0: the combined FilmTilePixel array (H, W, 4) after a step"""
         if self.world == 1:
             return self.ctx.film()
+        if not self.dense:
+            self._finish((self.k + 1) % 2)   # the last step's exchange
         return self.film.cpu().numpy().reshape(self.scene.height, self.scene.width, 4)
 
     def close(self):

@@ -722,13 +722,37 @@ def test_reference_host_drives_the_device(name, tmp_path):
     scene = str(tmp_path / "s.pbrt")
     open(scene, "w").write(edge_scenes.scene(name))
     out = str(tmp_path / "o.pfm")
-    env = dict(os.environ, PBRT_AMD_BACKEND="device", PBRT_AMD_BACKEND_LIB=pa.DEVICE_LIB)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PBRT_AMD_BACKEND")}   # the binding knows no backend switch: it binds mi_* or fails
+    env["PBRT_AMD_DEVICE_LIB"] = pa.DEVICE_LIB
     r = subprocess.run([REF_STUB, "--quiet", "--nthreads", "4", "--outfile", out, scene], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and os.path.exists(out), (r.stdout[-400:], r.stderr[-800:])
     img, ref = pa.read_pfm(out), pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
     assert img.shape == ref.shape
     frac, relmse = ol.image_metrics(img, ref)
     assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
+
+
+def test_reference_host_shards_tiles_over_gpu_contexts(tmp_path):
+    """`PBRT_AMD_GPUS=2` in the reference-side binding: one mi_ctx per rank, mi_render(rank r, world 2) each, one mi_film_gather onto rank 0 (the
+    reference's tile loop core/integrator.cpp:228-339 + the merge of film.cpp:117-130 across devices).  On a one-GPU box both contexts sit on
+    device 0 (PBRT_AMD_GPU_MAP=0,0) and the gather is the library's same-device sum; the image must equal the one-context render bit for bit
+    (box filter: disjoint tiles) and the reference's fixture by the suite's criterion."""
+    import subprocess
+    if not os.access(REF_STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built (it is built where /root/reference is present and travels with the snapshot)")
+    scene = str(tmp_path / "s.pbrt")
+    open(scene, "w").write(edge_scenes.scene("infinite"))
+    imgs = []
+    for gpus in ("1", "2"):
+        out = str(tmp_path / ("o%s.pfm" % gpus))
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PBRT_AMD_BACKEND")}
+        env.update(PBRT_AMD_DEVICE_LIB=pa.DEVICE_LIB, PBRT_AMD_GPUS=gpus, PBRT_AMD_GPU_MAP="0,0")
+        r = subprocess.run([REF_STUB, "--quiet", "--nthreads", "4", "--outfile", out, scene], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and os.path.exists(out), (r.stdout[-400:], r.stderr[-800:])
+        imgs.append(pa.read_pfm(out))
+    assert np.array_equal(imgs[0], imgs[1])
+    frac, relmse = ol.image_metrics(imgs[1], pa.read_pfm(os.path.join(G, "edge_infinite.pfm")))
+    assert frac >= 0.995 and relmse <= 1e-4, (frac, relmse)
 
 
 # ---------------------------------------------------------------- stage-level and scene tests added after the last GPU call of round 2

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N>1 path -- round-robin tile ownership + the film reduction of parallel.py -- with the
+"""CPU, world_size 2, gloo: the N>1 path -- tile ownership (mi_tile_owner) + the film exchange of parallel.py, dense and sparse -- with the
 oracle standing in for the device renderer (the sharding rule is the same function of (tile, rank, world) on both)."""
 import importlib
 import os
@@ -34,10 +34,18 @@ def _worker(rank, world, port, scene_text, out_dir):
     assert cnt["camera_rays"] == int(mask.sum()) * sc.info["spp"]
     outside = rgbw[~mask]
     assert (outside[..., 3] != 0).mean() < 0.02
+    # everything a rank's samples touched lies inside reach_pixels (its tiles + the filter's ring): the sparse exchange moves only those
+    reach = par.reach_pixels(rank, world, sc.width, sc.height, sc.info["sample_bounds"], (sc.info["crop_x0"], sc.info["crop_y0"]), sc.info["filter_radius"])
+    touched = np.flatnonzero((rgbw.reshape(-1, 4) != 0).any(1))
+    assert np.isin(touched, reach).all() and len(reach) < 0.75 * sc.width * sc.height
     film = torch.from_numpy(rgbw.reshape(-1).copy())
-    par.combine_films(film, dst=0)
+    sparse = film.clone()
+    par.combine_films(film, dst=0)                                  # dense: SUM-reduce of the whole films
+    xchg = par.FilmExchange(sc, rank, world, torch.device("cpu"))   # sparse: reachable pixels only, added on rank 0 (what ShardedFrame.step does)
+    xchg.finish(xchg.start(sparse))
     if rank == 0:
-        np.save(os.path.join(out_dir, "combined.npy"), film.numpy().reshape(sc.height, sc.width, 4))
+        assert np.array_equal(sparse.numpy().view(np.uint32), film.numpy().view(np.uint32))   # (two ranks: one addition per pixel either way)
+        np.save(os.path.join(out_dir, "combined.npy"), sparse.numpy().reshape(sc.height, sc.width, 4))
     dist.barrier()
     dist.destroy_process_group()
 

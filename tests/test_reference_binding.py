@@ -1,11 +1,12 @@
-"""CPU: the reference-side binding of INTEGRATION.md s.2, compiled for real (SURVEY.md s.8 row b).
+"""CPU: the hand-over half of the reference-side binding of INTEGRATION.md s.2, compiled for real (SURVEY.md s.8 row b).
 
-integration/wavefrontpath.cpp is the `WavefrontPathIntegrator : public Integrator` + FlattenScene a pbrt-v3 maintainer would add,
-built against the UNMODIFIED reference (libpbrt_ref.a) into oracle/_ref/pbrt_ref_wavefront: the reference's own main, parser, API state
-machine, shape factories, Loop subdivision and BVH build run as they are, the stub flattens the reference's `Scene` / `BVHAccel` /
-`GeometricPrimitive` / `Material` (through the BxDFs its ComputeScatteringFunctions builds) / `Light` / camera / film / sampler objects
-to a `mi_scene_desc`, and the backend renders THAT description -- here the CPU oracle (a GPU box sets PBRT_AMD_BACKEND=device and
-points PBRT_AMD_BACKEND_LIB at libpbrt_amd.so).  The resulting image goes through the reference's own Film::MergeFilmTile / WriteImage
+integration/flatten.h is the FlattenScene a pbrt-v3 maintainer would add (with integration/wavefrontpath.cpp, the `WavefrontPathIntegrator :
+public Integrator` that renders the flattened description on the MI355X through the mi_* entry points -- exercised on the GPU box by
+tests/test_gpu_parity.py::test_reference_host_drives_the_device).  Here its TEST-ONLY twin oracle/ref_build/flatcheck.cpp, built against the
+UNMODIFIED reference (libpbrt_ref.a) into oracle/_ref/pbrt_ref_flatcheck, runs on the CPU: the reference's own main, parser, API state machine,
+shape factories, Loop subdivision and BVH build run as they are, FlattenScene flattens the reference's `Scene` / `BVHAccel` /
+`GeometricPrimitive` / `Material` (through the BxDFs its ComputeScatteringFunctions builds) / `Light` / camera / film / sampler objects to a
+`mi_scene_desc`, and the CPU oracle renders THAT description.  The resulting image goes through the reference's own Film::MergeFilmTile / WriteImage
 and must equal what `pbrt_ref` renders for the same file up to the rounding of the film sum (a pixel that also receives an edge sample
 of a neighbour adds it in a different order: 1 ulp of the sum in < 0.1 % of the pixels)."""
 import os
@@ -20,7 +21,7 @@ import oracle_lib as ol
 pa = ol.pa
 ROOT = ol.ROOT
 REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
-STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
+STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_flatcheck")   # TEST-ONLY twin of the binding (oracle/ref_build/flatcheck.cpp): the same FlattenScene, rendered by the CPU checker
 ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
 
 CASES = [("cornell", os.path.join(ROOT, "scenes", "cornell.pbrt"), []),
@@ -32,11 +33,11 @@ CASES = [("cornell", os.path.join(ROOT, "scenes", "cornell.pbrt"), []),
 @pytest.mark.parametrize("name,scene,extra", CASES, ids=[c[0] for c in CASES])
 def test_reference_scene_through_the_stub_equals_pbrt_ref(name, scene, extra, tmp_path):
     if not (os.access(REF, os.X_OK) and os.access(STUB, os.X_OK)):
-        pytest.skip("oracle/_ref/pbrt_ref[_wavefront] not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref[_flatcheck] not built here (needs /root/reference)")
     if not os.path.exists(scene):
         pytest.skip("scene file not present: %s" % scene)
     a, b = str(tmp_path / "stub.pfm"), str(tmp_path / "ref.pfm")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE)
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE)
     cwd = os.path.dirname(scene)
     r1 = subprocess.run([STUB, "--quiet", "--nthreads", "4"] + extra + ["--outfile", a, scene], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0 and os.path.exists(a), r1.stderr[-800:]
@@ -81,11 +82,11 @@ def _edge_text(name):
 @pytest.mark.parametrize("name", EDGE_CASES)
 def test_edge_scene_through_the_stub_equals_pbrt_ref(name, tmp_path):
     if not (os.access(REF, os.X_OK) and os.access(STUB, os.X_OK)):
-        pytest.skip("oracle/_ref/pbrt_ref[_wavefront] not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref[_flatcheck] not built here (needs /root/reference)")
     scene = str(tmp_path / "s.pbrt")
     open(scene, "w").write(_edge_text(name))
     a, b = str(tmp_path / "stub.pfm"), str(tmp_path / "ref.pfm")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE)
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE)
     r1 = subprocess.run([STUB, "--quiet", "--nthreads", "4", "--outfile", a, scene], env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0 and os.path.exists(a), r1.stderr[-800:]
     r2 = subprocess.run([REF, "--quiet", "--nthreads", "4", "--outfile", b, scene], capture_output=True, text=True, timeout=600)
@@ -109,7 +110,7 @@ def test_fast_samplers_through_the_stub_equals_pbrt_ref_with_sobol(tmp_path):
     """PBRT_AMD_FAST_SAMPLERS=1 in the reference-side binding (integration/wavefrontpath.cpp): a scene that names the stratified sampler is handed over with
     the reference's own SobolSampler at the same sample count -- the image equals pbrt_ref's render of the scene with Sampler "sobol" written into it."""
     if not (os.access(REF, os.X_OK) and os.access(STUB, os.X_OK)):
-        pytest.skip("oracle/_ref/pbrt_ref[_wavefront] not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref[_flatcheck] not built here (needs /root/reference)")
     import re
     base = edge_scenes.scene("sampler_stratified")
     m = re.search(r'Sampler "stratified"[^\n]*', base)
@@ -118,7 +119,7 @@ def test_fast_samplers_through_the_stub_equals_pbrt_ref_with_sobol(tmp_path):
     open(s1, "w").write(base)
     open(s2, "w").write(base.replace(m.group(0), 'Sampler "sobol" "integer pixelsamples" [%d]' % (nx * ny)))
     a, b = str(tmp_path / "stub.pfm"), str(tmp_path / "ref.pfm")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_FAST_SAMPLERS="1")
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_FAST_SAMPLERS="1")
     r1 = subprocess.run([STUB, "--quiet", "--nthreads", "4", "--outfile", a, s1], env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0 and os.path.exists(a), r1.stderr[-800:]
     r2 = subprocess.run([REF, "--quiet", "--nthreads", "4", "--outfile", b, s2], capture_output=True, text=True, timeout=600)
@@ -135,11 +136,11 @@ def test_texture_nodes_equal_the_reference_classes(name, tmp_path):
     at 2048 random interactions (sub-texel to many-texel footprints) and the oracle evaluates the node that object was flattened to
     (oracle_texture_eval) at the same interactions: every value bit for bit."""
     if not os.access(STUB, os.X_OK):
-        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref_flatcheck not built here (needs /root/reference)")
     scene = str(tmp_path / "s.pbrt")
     open(scene, "w").write(edge_scenes.scene(name))
     rep = str(tmp_path / "probe.txt")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_TEX_PROBE=rep)
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_TEX_PROBE=rep)
     r = subprocess.run([STUB, "--quiet", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and os.path.exists(rep), r.stderr[-800:]
     rows = [l.split() for l in open(rep)]
@@ -161,7 +162,7 @@ def test_traversal_equals_the_reference_scene_intersect(name, tmp_path):
     edge scene (two-level instancing, spheres, masks, tessellated height fields / NURBS) and on the 66 k-triangle killeroo, a 200 k-triangle
     San-Miguel-class and a 60 k-triangle bathroom-class scene."""
     if not os.access(STUB, os.X_OK):
-        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref_flatcheck not built here (needs /root/reference)")
     if name.startswith("file:"):
         scene = os.path.join(ROOT, "scenes", name[5:] + ".pbrt")
     elif name.startswith("gen:"):
@@ -173,7 +174,7 @@ def test_traversal_equals_the_reference_scene_intersect(name, tmp_path):
         scene = str(tmp_path / "s.pbrt")
         open(scene, "w").write(edge_scenes.scene(name))
     rep = str(tmp_path / "hits.txt")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_HIT_PROBE=rep)
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_HIT_PROBE=rep)
     r = subprocess.run([STUB, "--quiet", "--quick", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=900)
     assert os.path.exists(rep), r.stderr[-800:]
     n, hits, same_flag, same_t, same_n, same_occ = [int(v) for v in open(rep).read().split()]
@@ -189,16 +190,36 @@ def test_bsdfs_at_hits_equal_the_reference_material_classes(name, tmp_path):
     the oracle does the same on the flattened description (oracle_bsdf_at_hit): hit state (miss / BSDF / null BSDF), number of components, f, Pdf and the
     sampled direction, pdf, value and lobe type -- all bit for bit."""
     if not os.access(STUB, os.X_OK):
-        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+        pytest.skip("oracle/_ref/pbrt_ref_flatcheck not built here (needs /root/reference)")
     if name.startswith("file:"):
         scene = os.path.join(ROOT, "scenes", name[5:] + ".pbrt")
     else:
         scene = str(tmp_path / "s.pbrt")
         open(scene, "w").write(edge_scenes.scene(name))
     rep = str(tmp_path / "bsdf.txt")
-    env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_BSDF_PROBE=rep)
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_BSDF_PROBE=rep)
     r = subprocess.run([STUB, "--quiet", "--quick", "--nthreads", "4", "--outfile", str(tmp_path / "o.pfm"), scene], env=env, capture_output=True, text=True, timeout=900)
     assert os.path.exists(rep), r.stderr[-800:]
     n, with_bsdf, same_state, same_count, same_f, same_pdf, same_sample = [int(v) for v in open(rep).read().split()]
     assert n == 20000 and same_state == n and (with_bsdf > 1000 or name == "empty")
     assert same_count == with_bsdf and same_f == with_bsdf and same_pdf == with_bsdf and same_sample == with_bsdf, (name, with_bsdf, same_count, same_f, same_pdf, same_sample)
+
+
+def test_the_binding_itself_has_no_cpu_render_path(tmp_path):
+    """integration/wavefrontpath.cpp binds the mi_* entry points and nothing else: handed the CPU checker as its library it refuses
+    ("lacks mi_ctx_create"), handed libpbrt_amd.so on a box without a GPU it reports mi_ctx_create's error; no image is written either way.  And
+    the sources under integration/ do not mention the checker at all."""
+    binding = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
+    if not os.access(binding, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_wavefront not built here (needs /root/reference)")
+    for f in os.listdir(os.path.join(ROOT, "integration")):
+        assert "oracle" not in open(os.path.join(ROOT, "integration", f)).read(), f
+    scene = os.path.join(ROOT, "scenes", "cornell.pbrt")
+    out = str(tmp_path / "o.pfm")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PBRT_AMD_")}
+    r = subprocess.run([binding, "--quiet", "--outfile", out, scene], env=dict(env, PBRT_AMD_DEVICE_LIB=ORACLE), capture_output=True, text=True, timeout=300)
+    assert "lacks mi_ctx_create" in (r.stderr + r.stdout) and not os.path.exists(out)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([binding, "--quiet", "--outfile", out, scene], env=dict(env, PBRT_AMD_DEVICE_LIB=pa.DEVICE_LIB), capture_output=True, text=True, timeout=300)
+        assert "no HIP device available" in (r.stderr + r.stdout) and not os.path.exists(out)

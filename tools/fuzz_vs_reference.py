@@ -468,7 +468,7 @@ def main():
     ap.add_argument("--pixel-samplers", action="store_true", help="Sampler \"random\" / \"stratified\" / \"02sequence\" / \"lowdiscrepancy\" with random parameters instead of sobol / halton (one PCG32 stream per tile: tile-serial rounds on the device)")
     ap.add_argument("--spectra", action="store_true", help="some \"rgb\" parameters become \"blackbody\" / inline \"spectrum\" parameters (the host's CIE conversion, host/spectrum.cpp)")
     ap.add_argument("--instanced-only", action="store_true", help="device mode: only the scenes that use ObjectInstance (two-level traversal)")
-    ap.add_argument("--stub", action="store_true", help="the reference-side binding instead of this repository's host: oracle/_ref/pbrt_ref_wavefront (the reference's own parser / API / BVH build + FlattenScene of oracle/ref_build/wavefrontpath.cpp, oracle backend) against pbrt_ref")
+    ap.add_argument("--stub", action="store_true", help="the reference-side binding instead of this repository's host: oracle/_ref/pbrt_ref_flatcheck (the reference's own parser / API / BVH build + FlattenScene of oracle/ref_build/wavefrontpath.cpp, oracle backend) against pbrt_ref")
     ap.add_argument("--probe", action="store_true", help="with --stub: also run the binding's probes on every scene -- the reference's own Scene::Intersect / IntersectP, Material + BSDF "
                     "and Texture classes against the oracle on 20 000 random rays / 2 048 random interactions (PBRT_AMD_HIT_PROBE, PBRT_AMD_BSDF_PROBE, PBRT_AMD_TEX_PROBE)")
     ap.add_argument("--device", action="store_true", help="GPU box: compare the DEVICE render with the oracle instead (image criterion of the GPU tests); no reference needed")
@@ -497,14 +497,14 @@ def main():
             if a.stub:
                 sout = os.path.join(tmp, "stub.pfm")
                 if os.path.exists(sout): os.remove(sout)
-                env = dict(os.environ, PBRT_AMD_BACKEND="oracle", PBRT_AMD_BACKEND_LIB=os.path.join(ROOT, "oracle", "liboracle.so"))
+                env = dict(os.environ, PBRT_AMD_BACKEND_LIB=os.path.join(ROOT, "oracle", "liboracle.so"))
                 reps = {}
                 if a.probe:
                     for k in ("HIT", "BSDF", "TEX"):
                         reps[k] = os.path.join(tmp, "probe_%s.txt" % k)
                         if os.path.exists(reps[k]): os.remove(reps[k])
                         env["PBRT_AMD_%s_PROBE" % k] = reps[k]
-                rs = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront"), "--quiet", "--nthreads", "4", "--outfile", sout, fn], env=env, capture_output=True, text=True)
+                rs = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_flatcheck"), "--quiet", "--nthreads", "4", "--outfile", sout, fn], env=env, capture_output=True, text=True)
                 if not os.path.exists(sout):
                     msg = (rs.stderr or "").strip()
                     if "without a device counterpart" in msg or "not carried by this path" in msg:
