@@ -233,6 +233,10 @@ PT_DEV uint32_t wave_key_rank(uint32_t *keycount, uint32_t key, bool active) {
     }
     return rank;
 }
+// Wave-wide vote on a PREDICATE: the lane mask straight from the compare.  HIP's __ballot(int) / __any(int) first materialise the predicate as a 0 / 1
+// integer and compare it again (v_cndmask + v_cmp_ne: two more VALU instructions per call, in a kernel bound by VALU issue).
+PT_DEV unsigned long long PtBallot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+PT_DEV bool PtAny(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // slots 64..67 (counting passes only, mi_trace_clock): per-wave s_memtime / s_memrealtime ticks spent inside the closest-hit and any-hit kernels
 #define PT_CNT_CLK 64
 PT_DEV void wave_count(unsigned long long *counter, uint32_t v) {
@@ -501,6 +505,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_HOT_NODES
 #define PT_HOT_NODES 512
 #endif
+// round 4: the BIG instances take the interior step with the cheaper tail (TravNodeStepQ2 / TravStackB, pt_scene.h); 0 = round 3's step (A/B)
+#ifndef PT_STEP2
+#define PT_STEP2 1
+#endif
 #ifndef PT_TRACEQ_BLOCK
 #define PT_TRACEQ_BLOCK 768
 #endif
@@ -518,6 +526,7 @@ template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
     static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : PT_TRACE_WAVES;
     static constexpr int LDS_BYTES = NLDS * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
     static constexpr int PER_CU = BIG ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
+    static constexpr bool STEP2 = BIG && PT_STEP2 && PT_PEND_LEAF && !PT_STACK_T;
     static_assert(NLDS >= PT_LDS_STACK_MIN, "the spill slices are sized for stack_need - PT_LDS_STACK_MIN entries");
     static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
     static_assert((size_t)PER_CU * BLOCK <= (size_t)PT_GRID_PER_CU * PT_BLOCK, "the spill slices are sized for gridBlocks x PT_BLOCK threads");
@@ -527,7 +536,8 @@ template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
 // INST: two-level scenes (TransformedPrimitive leaves, see TravStateI); BVH4 only
 template <bool INST> struct TravTypes { typedef TravState State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
 template <> struct TravTypes<true> { typedef TravStateI State; typedef TravStack Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = PT_LDS_STACK }; };
-template <int BLOCK, int NLDS> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK, NLDS> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = NLDS }; };
+template <int BLOCK, int NLDS, bool STEP2 = false> struct TravTypesQ { typedef TravStateQ State; typedef TravStackT<BLOCK, NLDS> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = NLDS }; };
+template <int BLOCK, int NLDS> struct TravTypesQ<BLOCK, NLDS, true> { typedef TravStateQ State; typedef TravStackB<BLOCK, NLDS> Stack; typedef StackEntry Entry; typedef LdsStackEntry LdsEntry; enum { LDS = NLDS }; };
 // QN: the general steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): four vector-memory requests per interior step instead of seven
 // (the default for single-level scenes; the full-precision 128-byte nodes serve two-level scenes and PBRT_AMD_TRACE=general)
 template <bool PEND, class TS> PT_DEV bool TraceDone(const TS &ts) {
@@ -543,7 +553,8 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
     constexpr bool PEND = QN && PT_PEND_LEAF;
     constexpr bool ADEFER = PEND && ALPHA && PT_ALPHA_DEFER;   // masks evaluated in wave-wide alpha phases (TravPendStep<..., DEFER>)
-    typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS>, TravTypes<INST>>::type TT;
+    constexpr bool STEP2 = TraceShape<MODE, SPHERES, ALPHA, QN>::STEP2 && !TR;
+    typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS, STEP2>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
     if constexpr (HOT > 0) {   // the hot nodes as four word planes [word][node]; coalesced 16-byte reads of nodesq[0 .. n_hot)
@@ -554,7 +565,12 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     }
     LdsNodeWord *hot = (LdsNodeWord *)lds_hot;
     typename TT::Stack st;
-    st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
+    if constexpr (STEP2) {
+        st.base = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
+        *st.base = TRAV_DONE;   // the sentinel under every lane's stack: popped last, ends the ray
+        st.reset();
+    } else
+        st.lds = (typename TT::LdsEntry *)&lds_stack[threadIdx.x];
     st.spill = reinterpret_cast<typename TT::Entry *>(ps.spill) + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * ps.spill_per_thread;
     static_assert(!TR || MODE != 0, "segment walks are for shadow / MIS rays");
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
@@ -570,6 +586,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     uint32_t slot = 0, lightNum = 0;
     typename TT::State ts;
     ts.cur = TRAV_DONE;
+    if constexpr (PEND) ts.pend = TRAV_DONE;
     TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
     unsigned long long clk0 = 0, rt0 = 0;
@@ -640,7 +657,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
         // them, instead of one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the
         // same for 1 lane or 64)
         if (PT_BATCH_FINALIZE) finalize();
-        unsigned long long idle = __ballot(!active);
+        unsigned long long idle = PtBallot(!active);
         int nIdle = __popcll(idle);
         if (nIdle >= TRACE_REFILL && segsTried < 8) {
             while (segsTried < 8 && nIdle > 0) {
@@ -667,12 +684,12 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     ++nrays;
                 }
                 poolNext += (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
-                idle = __ballot(!active);
+                idle = PtBallot(!active);
                 nIdle = __popcll(idle);
             }
             waveIters = 0;   // the guard bounds the rounds BETWEEN two refills (and after the last one), not the whole persistent launch: independent of the frame size
         }
-        if (!__any(active)) break;
+        if (!PtAny(active)) break;
         const bool mayRefill = segsTried < 8;
         while (true) {
             // safety net: a traversal that does not terminate (a corrupted stack / node reference) must not hang the GPU -- after
@@ -689,40 +706,41 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
             {
                 int guard = 0;
                 while (true) {
-                    bool wantNode = active && ts.atNode();
-                    int nWant = __popcll(__ballot(wantNode));
+                    bool wantNode = ts.atNode();   // (a lane without a ray stands at TRAV_DONE with nothing parked: no `active &&` in the votes of this loop)
+                    int nWant = __popcll(PtBallot(wantNode));
                     if (nWant == 0) break;
                     if (wantNode) {
                         if constexpr (QN) {
-                            TravNodeStepQ<COUNT, HOT>(sc, ts, st, &tc, hot);
+                            if constexpr (STEP2) TravNodeStepQ2<COUNT, HOT>(sc, ts, st, &tc, hot);
+                            else TravNodeStepQ<COUNT, HOT>(sc, ts, st, &tc, hot);
                             if constexpr (PEND) TravParkLeaf(ts, st);   // arrived at a leaf: park it, go on with the stack
                         } else TravNodeStep<COUNT, !(MODE == 2 && PT_ANY_NOSORT)>(sc, ts, st, &tc);
                     }
                     int nLeaf;
-                    if constexpr (PEND) nLeaf = __popcll(__ballot(active && ts.pend != TRAV_DONE) & ~apend);
-                    else nLeaf = __popcll(__ballot(active && ts.atLeaf()));
+                    if constexpr (PEND) nLeaf = __popcll(PtBallot(ts.pend != TRAV_DONE) & ~apend);
+                    else nLeaf = __popcll(PtBallot(ts.atLeaf()));
                     if (nLeaf >= TRACE_LEAF_MIN || ++guard >= TRACE_NODE_STEPS) break;
                 }
             }
             if constexpr (ADEFER) {
                 bool cand = false;
                 if (active && ts.pend != TRAV_DONE && !((apend >> lane) & 1ull)) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::Stack, true>(sc, ts, st, &tc, &cand);
-                apend |= __ballot(cand);
+                apend |= PtBallot(cand);
                 if (apend) {
                     const bool waits = (apend >> lane) & 1ull;
-                    const int nA = __popcll(apend), nGo = __popcll(__ballot(active && (ts.atNode() || (ts.pend != TRAV_DONE && !waits))));   // lanes with a step to take without a mask
+                    const int nA = __popcll(apend), nGo = __popcll(PtBallot(active && (ts.atNode() || (ts.pend != TRAV_DONE && !waits))));   // lanes with a step to take without a mask
                     if (nA >= PT_ALPHA_MIN || nGo * PT_ALPHA_GO_MUL <= nA) {   // alpha phase: the same step again, this time through the mask
                         if (waits) TravPendStep<MODE == 2 && !TR, false, SPHERES, ALPHA, typename TT::Stack, false>(sc, ts, st, &tc);
                         apend = 0;
                     }
                 }
             } else if constexpr (PEND) {
-                if (active && ts.pend != TRAV_DONE) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::Stack>(sc, ts, st, &tc);
+                if (ts.pend != TRAV_DONE) TravPendStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::Stack>(sc, ts, st, &tc);
             } else {
                 if (active && ts.atLeaf()) TravLeafStep<MODE == 2 && !TR, COUNT, SPHERES, ALPHA, typename TT::State, typename TT::Stack, INST>(sc, ts, st, &tc);
             }
             if (!PT_BATCH_FINALIZE) finalize();
-            int nAct = __popcll(__ballot(active && !TraceDone<PEND>(ts)));   // (batched: finished lanes keep their result until the next refill, top of the outer loop)
+            int nAct = __popcll(PtBallot(!TraceDone<PEND>(ts)));   // (batched: finished lanes keep their result until the next refill, top of the outer loop)
             if (nAct == 0 || (mayRefill && nAct <= 64 - TRACE_REFILL)) break;
         }
     }
@@ -1944,6 +1962,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         // zero direction component -- overflows) is not an error: the scene takes the full-precision 128-byte nodes, which are always built.
         bool okq = bvh4q::quantise(bb.out, d->bvh_nodes[0].bmin, d->bvh_nodes[0].bmax, &qn, &sc.qgrid, &err);
         for (int a = 0; okq && a < 3; ++a) okq = std::isfinite(sc.qgrid.cell[a] * 1e30f * 65535.f) && std::isfinite(sc.qgrid.lo[a]);
+        // TravNodeStepQ2 decides "child entered" by x >= e alone and relies on the INVERTED box of an empty slot to fail it, which holds for a ray that
+        // starts within ~5e5 grid extents of the grid (pt_bvh4q.h, Bvh4qStepEX).  Path vertices lie inside the root box; the camera is checked here (1e5).
+        for (int a = 0; okq && a < 3; ++a) {
+            const double ext = 65535.0 * (double)sc.qgrid.cell[a], camPos = d->camera.camera_to_world[4 * a + 3];
+            okq = std::fabs(camPos - (double)sc.qgrid.lo[a]) <= 1e5 * ext;
+        }
         if (!okq) c->useQ = false;
         else {
             DevBuf &b = next();

@@ -63,6 +63,28 @@ PT_HD uint32_t Bvh4qStepWords(const uint32_t w[16], const Bvh4qRay &r, float tMa
     return mask;
 }
 
+// The same node step in the form the round-4 traversal tail wants it (TravNodeStepQ2, pt_scene.h): per child the entry distance e = max3(near
+// planes) and the exit distance x = min3(far planes), nothing else.  The caller enters a child iff max(e, +0) <= min(x, pred(tMax)): Bvh4qStepWords' rule
+// with x > 0 relaxed to x >= +0 (a superset, still conservative with respect to Bounds3::IntersectP) and
+// WITHOUT the explicit empty-slot test: an empty slot (inverted box q_lo = 65535, q_hi = 0, reference 0xFFFFFFFF) fails e <= x by itself as long as the
+// ray starts within ~5e5 grid extents of the grid on some axis -- x - e <= -(65535 |A_a| - 2 delta_a) with delta_a = 16 eps (|B_a| + 65535 |A_a|) for every
+// axis a.  Path vertices lie inside the root box; mi_scene_upload checks the camera (else the scene takes the full-precision nodes).
+PT_HD void Bvh4qStepEX(const uint32_t w[16], const Bvh4qRay &r, float e[4], float x[4]) {
+    const uint32_t nx0 = r.neg[0] ? w[6] : w[0], nx1 = r.neg[0] ? w[7] : w[1], fx0 = r.neg[0] ? w[0] : w[6], fx1 = r.neg[0] ? w[1] : w[7];
+    const uint32_t ny0 = r.neg[1] ? w[8] : w[2], ny1 = r.neg[1] ? w[9] : w[3], fy0 = r.neg[1] ? w[2] : w[8], fy1 = r.neg[1] ? w[3] : w[9];
+    const uint32_t nz0 = r.neg[2] ? w[10] : w[4], nz1 = r.neg[2] ? w[11] : w[5], fz0 = r.neg[2] ? w[4] : w[10], fz1 = r.neg[2] ? w[5] : w[11];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 16 * (k & 1);
+        const uint32_t wnx = k < 2 ? nx0 : nx1, wny = k < 2 ? ny0 : ny1, wnz = k < 2 ? nz0 : nz1;
+        const uint32_t wfx = k < 2 ? fx0 : fx1, wfy = k < 2 ? fy0 : fy1, wfz = k < 2 ? fz0 : fz1;
+        e[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)((wnx >> sh) & 65535u), r.A[0], r.Bn[0]), __builtin_fmaf((float)((wny >> sh) & 65535u), r.A[1], r.Bn[1])),
+                               __builtin_fmaf((float)((wnz >> sh) & 65535u), r.A[2], r.Bn[2]));
+        x[k] = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)((wfx >> sh) & 65535u), r.A[0], r.Bf[0]), __builtin_fmaf((float)((wfy >> sh) & 65535u), r.A[1], r.Bf[1])),
+                               __builtin_fmaf((float)((wfz >> sh) & 65535u), r.A[2], r.Bf[2]));
+    }
+}
+
 // ---- host side: quantiser over an existing BVH4 (the collapse of the reference's BVH2), checks, emulation of the traversal
 #include <cmath>
 #include <string>

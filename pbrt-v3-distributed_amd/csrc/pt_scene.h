@@ -354,6 +354,39 @@ PT_DEV void Pin(float4 &a, float4 &b, float4 &c) {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
 }
 
+// gfx950-exact forms of a few small operations (device build: one instruction each, opaque to the optimiser; host build of this header: plain C++)
+PT_DEV float PtMinRaw(float a, float b) {   // v_min_f32 / v_max_f32 straight: the distances are never NaN, the builtins would first canonicalise both operands
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return b < a ? b : a;
+#endif
+}
+// max(|a|, |b|, |c|) of three non-NaN floats: MaxComponent(Abs(V3(a, b, c))) as ONE v_max3_f32 with abs source modifiers (the (a < b) ? b : a form
+// compiles to two compares, two selects and an AND per call; equal for every non-NaN input, signed zeros included since all operands are magnitudes)
+PT_DEV float PtMaxAbs3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    const float x = __builtin_fabsf(a), y = __builtin_fabsf(b), z = __builtin_fabsf(c), m = y < z ? z : y;
+    return x < m ? m : x;
+#endif
+}
+PT_DEV float PtMaxRaw(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return b < a ? a : b;
+#endif
+}
+// 0 / 0xffffffff from the sign bit, as ONE v_ashrrev_i32 the optimiser cannot turn back into a compare + select
+PT_DEV uint32_t PtSignMask(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r; asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(v)); return r;
+#else
+    return (uint32_t)((int32_t)v >> 31);
+#endif
+}
 #ifndef PT_TRI_SELECT
 #define PT_TRI_SELECT 1
 #endif
@@ -417,14 +450,14 @@ PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, 
     Float invDet = 1 / det;
     Float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
     Float t = tScaled * invDet;
-    Float maxZt = MaxComponent(Abs(V3(p0t.z, p1t.z, p2t.z)));
+    Float maxZt = PtMaxAbs3(p0t.z, p1t.z, p2t.z);   // MaxComponent(Abs(Vector3f(p0t.z, p1t.z, p2t.z)))
     Float deltaZ = gamma_n(3) * maxZt;
-    Float maxXt = MaxComponent(Abs(V3(p0t.x, p1t.x, p2t.x)));
-    Float maxYt = MaxComponent(Abs(V3(p0t.y, p1t.y, p2t.y)));
+    Float maxXt = PtMaxAbs3(p0t.x, p1t.x, p2t.x);
+    Float maxYt = PtMaxAbs3(p0t.y, p1t.y, p2t.y);
     Float deltaX = gamma_n(5) * (maxXt + maxZt);
     Float deltaY = gamma_n(5) * (maxYt + maxZt);
     Float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
-    Float maxE = MaxComponent(Abs(V3(e0, e1, e2)));
+    Float maxE = PtMaxAbs3(e0, e1, e2);
     Float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absf(invDet);
     if (t <= deltaT) return false;
     h->t = t; h->b0 = b0; h->b1 = b1; h->b2 = b2;
@@ -491,7 +524,7 @@ typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
 // STRIDE = threads per block of the kernel that owns the stack (the [entry][lane] rows are one block wide); NLDS = entries held in LDS.  The spill
 // slices are sized for the shallowest LDS part any kernel uses (PT_LDS_STACK_MIN)
 #ifndef PT_LDS_STACK_MIN
-#define PT_LDS_STACK_MIN 16
+#define PT_LDS_STACK_MIN 15   /* TravStackB<.., 16>: entry 0 is its sentinel */
 #endif
 template <int STRIDE, int NLDS = PT_LDS_STACK>
 struct TravStackT {
@@ -500,6 +533,7 @@ struct TravStackT {
     LdsStackEntry *lds;   // &stack[0][threadIdx.x]; typed as LDS so that pushes / pops are ds_write / ds_read, never flat
     StackEntry *spill;    // per-thread spill slice
     int sp;
+    PT_DEV void reset() { sp = 0; }
     PT_DEV void push(uint32_t v, Float t) {
 #if PT_STACK_T
         StackEntry e = (StackEntry)v | ((StackEntry)__float_as_uint(t) << 32);
@@ -542,7 +576,7 @@ struct TravState {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         box.init(o, V3(1 / d.x, 1 / d.y, 1 / d.z));
         shear.init(d);
-        st.sp = 0;
+        st.reset();
         cur = sc.n_nodes ? 0u : TRAV_DONE;   // the root is always an interior BVH4 node
     }
     PT_DEV bool done() const { return cur == TRAV_DONE; }
@@ -616,7 +650,7 @@ struct TravStateQ : TravState {
                               d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z};   // SlabRayInit's convention for zero direction components
         Bvh4qRayInit(q, sc.qgrid, oo, inv);
         shear.init(d);
-        st.sp = 0;
+        st.reset();
         cur = sc.n_nodes ? 0u : TRAV_DONE;
         pend = TRAV_DONE;
     }
@@ -663,11 +697,7 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
     const int nh = __builtin_popcount(mask);
 #if PT_LEAN_STEP && !PT_STACK_T
     // v_min_f32 / v_max_f32 straight (the distances are never NaN; the builtins would first canonicalise both operands: two more instructions each)
-#ifdef PT_HOST_EMU
-#define PT_MINMAX(lo, hi, a, b) lo = (b) < (a) ? (b) : (a); hi = (b) < (a) ? (a) : (b);
-#else
-#define PT_MINMAX(lo, hi, a, b) asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b)); asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-#endif
+#define PT_MINMAX(lo, hi, a, b) lo = PtMinRaw(a, b); hi = PtMaxRaw(a, b);
 #define PT_CSWAP(ta, ca, tb, cb) { const bool sw_ = tb < ta; Float lo_, hi_; PT_MINMAX(lo_, hi_, ta, tb) const uint32_t cl_ = sw_ ? cb : ca, ch_ = sw_ ? ca : cb; ta = lo_; tb = hi_; ca = cl_; cb = ch_; }
     PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
 #undef PT_CSWAP
@@ -698,6 +728,106 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
     if (nh > 1) st.push(c1, t1);
     ts.cur = c0;
 #endif
+}
+
+// ------------------------------------------------------------------ round 4: the interior step with a shorter tail (TraceShape::BIG instances of k_trace)
+// The traversal kernels are bound by VALU issue (profiles/r04_*: ~3.6 cycles of SIMD time per VALU instruction of the real mix, VALU busy ~95 % at 24 waves
+// per CU), and what counts is the NUMBER of VALU instructions: an A/B that moved a quarter of the step's instructions from the 4.1-cycle class of
+// tools/valu_probe/issue_probe (compares, selects, conversions) to the 2.3-cycle class (adds, logic) at equal count changed nothing
+// (profiles/r04_g_*).  The box arithmetic (12 plane selects, 24 conversions, 24 FMAs, 8 min3 / max3) and the 5-exchange sorting network are what the
+// node format prescribes; this form shortens everything around them:
+//   * entered <=> max(e, +0) <= min(x, pred(tMax)): ONE compare per child (was three compares + an empty-slot compare + two scalar ANDs), the sort key by one
+//     select, the hit count by one carry-add per child (was four selects, two ORs and a population count);
+//   * the stack pointer is the LDS byte ADDRESS of the lane's top entry and entry 0 of every lane holds TRAV_DONE, so a pop is `read, subtract` without an
+//     emptiness test and the new top is one expression, top + (hits - 1) entries, "nothing hit" included;
+//   * the three candidate pushes are UNCONDITIONAL ds_write_b32 at max(target, first free entry): a missed child lands in the first free entry and is
+//     overwritten by the valid entry that belongs there (LDS operations of one wave complete in order), or stays as garbage above the top;
+//   * the entry a pop would return is read speculatively with the node words, so "nothing hit" costs a select instead of an LDS round trip;
+//   * deep stacks (a lane within 4 entries of its LDS part: 2-3 % of the steps) take the branching generic tail -- decided per WAVE.
+// Same children entered as before up to one relaxed boundary case (x == +0 is accepted: a superset), same visiting order, same hits.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int32_t PtLdsInt;     // an LDS address is 32 bits wide on the device (SIGNED: an address a few entries below a lane's stack may be negative, never huge)
+#else
+typedef intptr_t PtLdsInt;    // host build of this header: the "LDS" arrays are ordinary memory
+#endif
+template <int STRIDE, int NLDS>
+struct TravStackB {
+    enum { LDS_ENTRIES = NLDS, STRIDE_ = STRIDE, SBYTES = STRIDE * 4 };
+    typedef LdsStackEntry *LdsPtr;
+    LdsStackEntry *tp;     // the lane's TOP entry ([entry][lane] rows, SBYTES apart); tp == base: only the sentinel is left
+    LdsStackEntry *base;   // entry 0 = TRAV_DONE, written once by the kernel
+    StackEntry *spill;     // entries beyond the LDS part, oldest first (non-empty only while the LDS part is full)
+    int nspill;
+    PT_DEV void reset() { tp = base; nspill = 0; }
+    PT_DEV bool deep() const { return tp > base + (NLDS - 4) * STRIDE; }   // fewer than three free LDS entries (or spilled ones): the generic tail
+    PT_DEV void push(uint32_t v, Float) {
+        if (tp < base + (NLDS - 1) * STRIDE) { tp += STRIDE; *tp = v; } else spill[nspill++] = v;
+    }
+    PT_DEV uint32_t pop(Float) {
+        if (nspill) return spill[--nspill];
+        const uint32_t v = *tp;
+        tp -= STRIDE;   // (below `base` after the sentinel went out: the lane's ray is finished, reset() comes before the next access)
+        return v;
+    }
+};
+template <bool COUNT, int HOT, class ST>
+PT_DEV void TravNodeStepQ2(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounters *cnt, LdsNodeWord *hot) {
+    const bool deepWave = __builtin_amdgcn_ballot_w64(st.deep()) != 0ull;   // over the lanes that take this step (EXEC): some lane is within three entries of its LDS part
+    uint4 w0, w1, w2, ch;
+    const bool isHot = HOT > 0 && ts.cur < sc.n_hot;
+    if (isHot) {
+        LdsNodeWord *h = hot + ts.cur;
+        const U32x4 a = h[0], b = h[HOT], c = h[2 * HOT], e = h[3 * HOT];   // 4 x ds_read_b128
+        w0 = make_uint4(a.x, a.y, a.z, a.w); w1 = make_uint4(b.x, b.y, b.z, b.w); w2 = make_uint4(c.x, c.y, c.z, c.w); ch = make_uint4(e.x, e.y, e.z, e.w);
+        if (COUNT) ++cnt->hot;
+    }
+    if (!isHot) {   // (a second `if`, not an `else`: the LDS reads are issued first and are in flight while the others' global loads are)
+        const uint4 *w = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur);
+        w0 = w[0]; w1 = w[1]; w2 = w[2]; ch = w[3];
+    }
+    const uint32_t spec = *st.tp;   // what a pop would return (valid whenever the fast tail runs: nothing spilled); in flight with the node words
+    if (COUNT) ++cnt->nodes;
+    const uint32_t wd[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, ch.x, ch.y, ch.z, ch.w};
+    Float e[4], x[4];
+    Bvh4qStepEX(wd, ts.q, e, x);
+    // entered <=> max(e, +0) <= min(x, pred(tMax)), i.e. e < tMax as the reference has it (a hit ON a box plane -- axis-aligned walls -- ends the
+    // search there): two min / max, ONE compare, one select for the key (+inf for a miss) and one carry-add for the count
+    const Float tMaxP = __uint_as_float(__float_as_uint(ts.tMax) - 1u);   // the float below tMax (tMax > 0; +inf -> FLT_MAX)
+    Float t0, t1, t2, t3;
+    uint32_t nh = 0;
+#define PT_HITKEY(i, tk)                                                        \
+    {                                                                           \
+        const Float ec = PtMaxRaw(e[i], 0.0f), xc = PtMinRaw(x[i], tMaxP);      \
+        const bool h = ec <= xc;                                                \
+        tk = h ? e[i] : PT_INFINITY;   /* (the unclamped distance orders boxes the ray starts in, as before) */ \
+        nh += h ? 1u : 0u;                                                      \
+    }
+    PT_HITKEY(0, t0) PT_HITKEY(1, t1) PT_HITKEY(2, t2) PT_HITKEY(3, t3)
+#undef PT_HITKEY
+    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define PT_CSWAP(ta, ca, tb, cb) { const bool sw_ = tb < ta; const Float lo_ = PtMinRaw(ta, tb), hi_ = PtMaxRaw(ta, tb); const uint32_t cl_ = sw_ ? cb : ca, ch_ = sw_ ? ca : cb; ta = lo_; tb = hi_; ca = cl_; cb = ch_; }
+    PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+    if (!deepWave) {
+        // sorted position i (1..3) is a hit iff nh > i and then belongs at entry top + (nh - i); a missed position is sent to the first free entry top + 1,
+        // written BEFORE the valid entry that belongs there (c3, c2, c1 in this order; LDS operations of one wave complete in order) or, when
+        // nothing is pushed, left as garbage above the top
+        constexpr uint32_t S = ST::SBYTES;
+        const PtLdsInt tp0 = (PtLdsInt)(uintptr_t)st.tp, free0 = tp0 + (PtLdsInt)S, T = tp0 + (PtLdsInt)(nh * S);
+        const PtLdsInt a3 = T - 3 * (PtLdsInt)S, a2 = T - 2 * (PtLdsInt)S, a1 = T - (PtLdsInt)S;
+        *(typename ST::LdsPtr)(uintptr_t)(a3 > free0 ? a3 : free0) = c3;
+        *(typename ST::LdsPtr)(uintptr_t)(a2 > free0 ? a2 : free0) = c2;
+        *(typename ST::LdsPtr)(uintptr_t)(a1 > free0 ? a1 : free0) = c1;
+        ts.cur = nh ? c0 : spec;                               // nothing hit: the speculative pop
+        st.tp = (typename ST::LdsPtr)(uintptr_t)a1;            // top + (hits - 1): one down when nothing was hit
+        return;
+    }
+    // generic tail (some lane of the wave is deep): the same decisions with per-lane branches
+    if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
+    ts.cur = c0;
+    if (nh > 3) st.push(c3, 0);
+    if (nh > 2) st.push(c2, 0);
+    if (nh > 1) st.push(c1, 0);
 }
 
 // ------------------------------------------------------------------ two-level instancing (the host's default since round 2; PBRT_AMD_INSTANCING=0 flattens)

@@ -65,6 +65,9 @@ static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); retur
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }   // one-lane waves
+
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_s_waitcnt(v) ((void)0)
 
@@ -95,6 +98,8 @@ enum { hipStreamNonBlocking = 1 };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; size_t totalGlobalMem; };
 static inline const char *hipGetErrorString(hipError_t) { return "host emulation error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+enum { hipDeviceAttributeWallClockRate = 10017 };
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 100000; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
