@@ -372,6 +372,20 @@ PT_DEV float PtMaxAbs3(float a, float b, float c) {
     return x < m ? m : x;
 #endif
 }
+PT_DEV float PtMin3Raw(float a, float b, float c) {   // min / max of three non-NaN floats as one v_min3_f32 / v_max3_f32
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    const float m = b < a ? b : a; return c < m ? c : m;
+#endif
+}
+PT_DEV float PtMax3Raw(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    const float m = b < a ? a : b; return c < m ? m : c;
+#endif
+}
 PT_DEV float PtMaxRaw(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
@@ -440,13 +454,19 @@ PT_DEV bool TriangleTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &o, 
         double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
         e2 = (float)(p1typ0tx - p1txp0ty);
     }
-    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    // The four rejections of :247-261 as ONE predicate and one branch (round 4: the traversal kernels are bound by the NUMBER of VALU instructions, and the
+    // nested early returns cost a compare pair, an EXEC save / restore and three register copies of the lane's running result per level, while a wave
+    // of 64 rays practically never leaves early as a whole).  Same decisions for every non-NaN input:
+    //   edge signs   (e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)   <=>   min3 < 0 && max3 > 0
+    //   range        det < 0: reject tScaled >= 0 || tScaled < tMax det;  det > 0: reject tScaled <= 0 || tScaled > tMax det
+    //                <=>  with both sides multiplied by sign(det) (a sign-bit flip, exact):  accept iff  0 < a && a <= b
+    const Float eMin = PtMin3Raw(e0, e1, e2), eMax = PtMax3Raw(e0, e1, e2);
     Float det = e0 + e1 + e2;
-    if (det == 0) return false;
     p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
     Float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return false;
-    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
+    const uint32_t detSign = __float_as_uint(det) & 0x80000000u;
+    const Float a = __uint_as_float(__float_as_uint(tScaled) ^ detSign), b = __uint_as_float(__float_as_uint(tMax * det) ^ detSign);
+    if (!(!(eMin < 0 && eMax > 0) && det != 0 && a > 0 && a <= b)) return false;
     Float invDet = 1 / det;
     Float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
     Float t = tScaled * invDet;
