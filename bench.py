@@ -27,6 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
 NODE_BYTES, TRI_BYTES, RAY_BYTES = 128, 48, 48   # algorithmic bytes: BVH4 node, triangle record, ray in + hit out
+# tools/valu_probe/valu_probe2 on the MI355X (profiles/r04_a_valu_probe2_issue_rate_and_clock.txt), 8 waves per SIMD, host-event time x measured clock:
+PROBE_MIX_CYCLES = 3.39   # cycles per wave instruction per SIMD of the box test's instruction mix (kind 3: 1.430 ns at 2.372 GHz)
+PROBE_FMA_CYCLES = 2.22   # ... of independent v_fma_f32 (kind 0: 1.049 ns at 2.114 GHz)
 
 
 def log(*a):
@@ -521,23 +524,37 @@ def main():
                                                         "traversal launch shape, no arithmetic; the traversal's own fetches are a MIX of these levels (upper tree levels are shared)" % loads}
         except Exception as e:   # measurement aid only
             log("[bench] request-rate ceiling not measured: %s" % e)
-        # ... and what does bound it: VALU issue.  issue_slots_frac = VALU instructions of a launch x the measured cycles per wave instruction
-        # (tools/valu_probe on this chip: ~3.0 at >= 4 waves per SIMD, whatever the EXEC mask) / (SIMDs x launch cycles)
+        # ... and what does bound it: VALU issue.  Everything here is measured: the launch's SIMD cycles = live launch time x the shader
+        # clock the kernel itself reports (s_memtime / s_memrealtime per wave, mi_trace_clock); its VALU instructions per SIMD from a separate rocprofv3 --pmc
+        # pass; the ceiling from tools/valu_probe (profiles/r04_a_valu_probe2_issue_rate_and_clock.txt: a SIMD issues the box test's instruction mix at
+        # 3.39 cycles per wave instruction with 8 waves resident, plain v_fma_f32 at 2.2; profiles/r04_c_issue_probe_instruction_costs.txt per instruction).
+        clk_ghz = (trace_clk or {}).get("closest_GHz") or 0.0
+        if clk_ghz:
+            roofline["shader_clock_GHz"] = {"closest": round(trace_clk["closest_GHz"], 3), "anyhit": round(trace_clk["anyhit_GHz"], 3),
+                                            "source": "s_memtime / s_memrealtime ticks per wave inside the launches of the counting pass (mi_trace_clock)"}
         if world == 1 and args.traffic == "live":
             try:
                 vi = valu_live(wl_args, 1)
-                if vi:
+                if vi and clk_ghz:
                     # CUs from the persistent launch itself: waves per launch = CUs x blocks per CU x waves per block
                     simds = 4 * max(1, int(round(vi["waves_per_launch"] / (tinfo.get("blocks_per_cu", 6) * tinfo.get("block_threads", 256) / 64.0))))
-                    vi["cycles_per_wave_inst_assumed"] = 3.0
-                    vi["issue_slots_frac"] = round(vi["valu_insts_per_launch"] * 3.0 / (simds * avg_launch_ms * 1e-3 * 2.4e9), 4)
-                    vi["note"] = "SQ counters of a separate rocprofv3 --pmc pass of this workload; launch time from the unprofiled run; 2.4 GHz"
+                    launch_cycles = avg_launch_ms * 1e-3 * clk_ghz * 1e9
+                    per_simd = vi["valu_insts_per_launch"] / simds
+                    vi["simd_cycles_per_valu_inst"] = round(launch_cycles / per_simd, 3)      # what one VALU instruction of this kernel costs its SIMD, all stalls included
+                    vi["probe_cycles_per_valu_inst"] = PROBE_MIX_CYCLES                        # the same SIMD saturated with the box test's mix (tools/valu_probe)
+                    vi["issue_frac"] = round(PROBE_MIX_CYCLES / vi["simd_cycles_per_valu_inst"], 4)
+                    vi["note"] = ("SQ counters of a separate rocprofv3 --pmc pass of this workload; launch time from the unprofiled run x the clock measured inside the kernel; "
+                                  "ceiling = tools/valu_probe2 kind 3 at 8 waves per SIMD (%.2f cycles per wave instruction; plain v_fma_f32 %.2f)" % (PROBE_MIX_CYCLES, PROBE_FMA_CYCLES))
                     roofline["valu_issue"] = vi
+                    roofline["frac_valu_lane_throughput"] = round(vi["issue_frac"] * vi["lanes_active_per_valu_inst"] / 64.0, 4)
             except Exception as e:   # measurement aid only
                 log("[bench] VALU issue figure not measured: %s" % e)
-        if trace_clk and trace_clk.get("closest_GHz"):
-            roofline["shader_clock_GHz"] = {"closest": round(trace_clk["closest_GHz"], 3), "anyhit": round(trace_clk["anyhit_GHz"], 3),
-                                            "source": "s_memtime / s_memrealtime ticks per wave inside the launches of the counting pass (mi_trace_clock)"}
+        # the three named fractions: SURVEY.md s.8(d)'s algorithmic bytes against the HBM peak (> 1: served by LDS / L2 / MALL, not an HBM
+        # quantity), the counter-measured HBM fraction (= `frac`; the north star's >= 0.40 target is NOT met and HBM is not the binding roof), and the roof
+        # that binds: VALU issue x lane occupancy
+        roofline["frac_alg_8d"] = round(roofline["alg_bytes_per_launch"] / (avg_launch_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4) if avg_launch_ms > 0 else None
+        roofline["frac_hbm_counter"] = roofline["frac"]
+        roofline["binding_roof"] = "VALU issue (frac_valu_lane_throughput = issue_frac x lanes_active / 64); HBM target of the north star (>= 0.40 of 8 TB/s in this kernel) unmet"
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the

@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_HOT_NODES
 #define PT_HOT_NODES 512
 #endif
-// round 4: the BIG instances take the interior step with the cheaper tail (TravNodeStepQ2 / TravStackB, pt_scene.h); 0 = round 3's step (A/B)
+// round 4: the quantised-node instances take the interior step with the shorter tail (TravNodeStepQ2 / TravStackB, pt_scene.h); 0 = round 3's step (A/B)
 #ifndef PT_STEP2
 #define PT_STEP2 1
 #endif
@@ -526,7 +526,7 @@ template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
     static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : PT_TRACE_WAVES;
     static constexpr int LDS_BYTES = NLDS * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
     static constexpr int PER_CU = BIG ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
-    static constexpr bool STEP2 = BIG && PT_STEP2 && PT_PEND_LEAF && !PT_STACK_T;
+    static constexpr bool STEP2 = QN && PT_STEP2 && PT_PEND_LEAF && !PT_STACK_T;   // every quantised-node instance (round 4; BIG or the 256-thread shape alike)
     static_assert(NLDS >= PT_LDS_STACK_MIN, "the spill slices are sized for stack_need - PT_LDS_STACK_MIN entries");
     static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
     static_assert((size_t)PER_CU * BLOCK <= (size_t)PT_GRID_PER_CU * PT_BLOCK, "the spill slices are sized for gridBlocks x PT_BLOCK threads");
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
     constexpr bool PEND = QN && PT_PEND_LEAF;
     constexpr bool ADEFER = PEND && ALPHA && PT_ALPHA_DEFER;   // masks evaluated in wave-wide alpha phases (TravPendStep<..., DEFER>)
-    constexpr bool STEP2 = TraceShape<MODE, SPHERES, ALPHA, QN>::STEP2 && !TR;
+    constexpr bool STEP2 = TraceShape<MODE, SPHERES, ALPHA, QN>::STEP2;
     typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS, STEP2>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
