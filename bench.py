@@ -6,9 +6,10 @@ workload is the San-Miguel-class synthetic stand-in of SURVEY.md s.8(d), generat
   python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
 
 A "step" = one full pass of the hot path (SamplerIntegrator::Render: 1920x1080 x 64 spp, path maxdepth 5)
-over the frame with the scene already resident in HBM.  With N>1 the 16x16 image tiles are sharded
-round-robin over the ranks (scene replicated, no collective on the data path) and the FilmTile buffers
-are combined on rank 0 with one RCCL reduction per step (disjoint tiles: sum == gather).
+over the frame with the scene already resident in HBM.  With N>1 the 16x16 image tiles are sharded over the
+ranks on a skewed 2-D lattice (mi_tile_owner; scene replicated, no collective on the data path) and every rank's
+reachable FilmTile pixels are added into rank 0's film with one grouped RCCL send / recv per step, overlapped with
+the next step's rendering (parallel.FilmExchange).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -576,7 +577,7 @@ def main():
         out = {"metric": "Msamples/sec (whole node), San Miguel 1080p", "value": round(msamples, 3), "unit": "Msamples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "tiles": "16x16 round-robin over ranks", "parallelism": "tile-sharded x%d" % world},
+               "config": {"workload": workload, "tiles": "16x16, 2-D lattice over ranks (mi_tile_owner)", "parallelism": "tile-sharded x%d" % world},
                "mrays_per_s": round(mrays, 2), "rays_per_sample": round(samples[1] / max(1.0, samples[0]), 3),
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
                "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2),

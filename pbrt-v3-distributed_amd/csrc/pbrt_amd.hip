@@ -1054,8 +1054,22 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
 // SMP: 0 Sobol' / 1 Halton (the vertex's dimensions drawn in one batch) / 2 the tile-serial samplers (drawn call by call, in the reference's order: the
 // values come from the tile's stream)
+#ifndef PT_SHADE_ARGPTR
+#define PT_SHADE_ARGPTR 0   /* A/B: k_shade takes the DevScene through a pointer that is laundered once per item, so that no scene field is kept in an SGPR across items */
+#endif
+#if PT_SHADE_ARGPTR
+#define PT_SHADE_SC_PARAM const DevScene *__restrict__ scp
+#define PT_SHADE_SC_ARG c->scDev
+#else
+#define PT_SHADE_SC_PARAM DevScene sc
+#define PT_SHADE_SC_ARG sc
+#endif
 template <bool ENV, int SMP, bool TEX, bool INST = false>
-__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
+__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
+#if PT_SHADE_ARGPTR
+    const DevScene &sc0 = *scp;
+#define sc sc0
+#endif
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
 #if PT_SHADE_PROF
@@ -1073,6 +1087,12 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         uint32_t i = it.item();
         PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = it.valid();
+#if PT_SHADE_ARGPTR
+#undef sc
+        const DevScene *scl = scp;
+        asm volatile("" : "+s"(scl));   // a new pointer as far as the optimiser knows: every scene field used by this item is (re)loaded inside the item
+        const DevScene &sc = *scl;
+#endif
 #else
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
@@ -2497,6 +2517,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+#if PT_SHADE_ARGPTR
+    if (!c->scDev) { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); HIP_TRY(hipStreamSynchronize(c->stream)); }
+#endif
     c->nkeys = d->n_materials + 2;
     if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
     // film
@@ -2703,9 +2726,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             }
 #define LAUNCH_SHADE(ENV, TEX, ...)                                                                                                              \
     do {                                                                                                                                         \
-        if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                   \
-        else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);               \
-        else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                           \
+        if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                   \
+        else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);               \
+        else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
     } while (0)
             else if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
             else if (c->hasTex) LAUNCH_SHADE(true, true);          // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)

@@ -1,5 +1,5 @@
 """What one rank of an N-GPU tile-sharded frame costs, measured on ONE GPU: mi_render(rank, world = N) renders exactly the tiles rank r of N owns
-(t % N == r), so its time on this device is the per-rank time of the N-GPU job (scene replicated, no collective on the data path); the film
+(mi_tile_owner of include/pbrt_amd.h: a skewed 2-D lattice over the tile grid), so its time on this device is the per-rank time of the N-GPU job (scene replicated, no collective on the data path); the film
 reduction that follows (33 MB at 1080p) is a sub-millisecond RCCL reduce.  Predicted strong-scaling speed-up = T(1) / max_r T(r, N)."""
 import argparse, importlib, json, os, subprocess, sys, time
 ap = argparse.ArgumentParser()
