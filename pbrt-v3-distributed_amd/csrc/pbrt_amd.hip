@@ -1584,6 +1584,7 @@ struct mi_ctx {
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
+    uint32_t sssTail = 65536;                // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
@@ -2458,6 +2459,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         bool wave = true;
         const bool split = v.handle_media && !allHomogeneous;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
+        { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
         c->volWave = wave;
@@ -2866,6 +2868,12 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         HIP_TRY(hipStreamSynchronize(st));
                         for (uint32_t sg = 0; sg < QSEG; ++sg) left += row[sg * QC_STRIDE];
                         if (left == 0) break;
+                        if (left <= c->sssTail) {   // the tail of the walk: the few long chains are finished by their own lanes in ONE launch (k_sss_probe_tail)
+                            if (c->hasInst) hipLaunchKernelGGL((k_sss_probe_tail<true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn);
+                            else hipLaunchKernelGGL((k_sss_probe_tail<false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn);
+                            left = 0;   // (a chain that does not end there trips the guard counter: mi_render's callers see MI_CNT_TRACE_GUARD_TRIPS)
+                            break;
+                        }
                     }
                 }
                 toc(c);

@@ -1,5 +1,12 @@
 // The float libm routines of the path, restated so that the device returns what the REFERENCE's build returns.
 //
+// Provenance / licence: the ALGORITHMS and constants below restate the GNU C Library 2.35 (sysdeps/ieee754/flt-32/{s_sinf,s_cosf,e_expf,e_logf,e_acosf,
+// s_atanf,e_atan2f}.c and s_sincosf.h; glibc is a THIRD party, not the reference).  glibc is distributed under the GNU Lesser General Public License
+// v2.1 or later; sinf / cosf / sincosf / expf / logf there derive from ARM's Optimized Routines (MIT / Apache-2.0 WITH LLVM-exception, contributed to
+// glibc under the LGPL) and acosf / atanf / atan2f from Sun Microsystems' FDLIBM ("Copyright (C) 1993 by Sun Microsystems, Inc.  Permission to use, copy,
+// modify, and distribute this software is freely granted, provided that this notice is preserved").  No glibc source text is copied here: the code was
+// written against the published algorithms and checked against the installed binary's bits (see "Proof" below).
+//
 // pbrt-v3 calls std::sin / cos / acos / atan2 / exp / log on `Float` = float (core/sampling.cpp:93-150, core/reflection.cpp:572,
 // core/microfacet.cpp:146-163, core/geometry.h:1463-1486, shapes/sphere.cpp:85-120, lights/infinite.cpp:109-172, core/texture.h:95,
 // media/homogeneous.cpp:56, media/grid.cpp:76-104, core/medium.cpp, textures/marble.h:66).  Compiled here (oracle/ref_build, g++ -O2) those

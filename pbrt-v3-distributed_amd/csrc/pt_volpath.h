@@ -898,6 +898,77 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
 // hits).  Per path: take the hit into the chain (Interaction::SpawnRayTo(pTarget) from the hit point, interaction.h:68-72), count it if its primitive
 // carries the BSSRDF's material object (bssrdf.cpp:302), at the end of the first walk choose (bssrdf.cpp:311-314) and start the second; the second
 // walk ends at the chosen hit -> QC_SSS for k_sss_entry.  A chain without such a hit ends the path (path.cpp:160: S.IsBlack()).
+// One probe-walk step of ONE path (the body of a round): *again = the chain goes on with the segment now in NeeRec::sh_o / sh_d, *done = pi is chosen (QC_SSS)
+template <bool INST>
+PT_DEV void SssProbeStepOne(const DevScene *scp, const PathState &ps, const DevVol &vol, uint32_t slot, bool first, bool *againOut, bool *doneOut) {
+    bool again = false, done = false;
+    SssRec *S = &ps.sss[slot];
+    const float4 bs4 = S->base_seen, tg4 = S->target_sel;
+    const V3 baseP(bs4.x, bs4.y, bs4.z), pTarget(tg4.x, tg4.y, tg4.z);
+    const int material = (int)__float_as_uint(S->ns_mat.w);
+    uint32_t seen = __float_as_uint(bs4.w) & 0x7fffffffu, pass = __float_as_uint(bs4.w) >> 31;
+    uint32_t nFound = __float_as_uint(S->rho_found.w), selected = __float_as_uint(tg4.w);
+    V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds, no media
+    int mIn = -1, mOut = -1;
+    bool endOfWalk = false;
+    if (!first) {
+        const uint4 hit = ps.trs[slot].hit[0];
+        if (hit.x == TRAV_MISS) endOfWalk = true;
+        else {
+            const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+            const int rayMedium = __float_as_int(d4.w);   // GetMedium(dir) of the chain point the segment left from
+            VHit vh;
+            HitToIsect(scp, &vol, hit.x, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), hit.z, rayMedium, false, &vh);
+            p = vh.is.p; pErr = vh.is.pError; n = vh.is.n; mIn = vh.mIn; mOut = vh.mOut;
+            if ((int)vh.tinfo.y == material) {
+                if (pass == 1 && seen == selected) {   // pi: k_sss_entry rebuilds the interaction from the segment, its medium and the primitive
+                    S->nz_pi = make_float4(0, __uint_as_float(hit.x), __uint_as_float(hit.z), d4.w);
+                    S->pi_o = o4; S->pi_d = d4;
+                    done = true;
+                } else {
+                    if (pass == 0 && seen < PT_SSS_KEEP) {
+                        S->keep_o[seen] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(hit.x));
+                        S->keep_d[seen] = d4;
+                        S->keep_inst[seen] = hit.z;
+                    }
+                    ++seen;
+                }
+            }
+        }
+    }
+    if (!done) {
+        V3 dir = pTarget - p;
+        if (!endOfWalk && dir.x == 0 && dir.y == 0 && dir.z == 0) endOfWalk = true;
+        bool walking = !endOfWalk;
+        if (endOfWalk && pass == 0 && seen > 0) {   // choose, then the same walk again up to the chosen hit
+            nFound = seen;
+            int sel = (int)(S->sigt_u1.w * (int)nFound);
+            selected = (uint32_t)(sel < 0 ? 0 : (sel > (int)nFound - 1 ? (int)nFound - 1 : sel));
+            if (selected < PT_SSS_KEEP) {   // the chosen hit is one of the kept ones
+                const float4 ko = S->keep_o[selected], kd = S->keep_d[selected];
+                S->nz_pi = make_float4(0, ko.w, __uint_as_float(S->keep_inst[selected]), kd.w);
+                S->pi_o = ko; S->pi_d = kd;
+                S->rho_found.w = __uint_as_float(nFound);
+                done = true;
+            } else {
+                pass = 1; seen = 0;
+                p = baseP; pErr = V3(); n = V3(); mIn = mOut = -1;
+                dir = pTarget - p;
+                walking = !(dir.x == 0 && dir.y == 0 && dir.z == 0);
+            }
+        }
+        if (walking && !done) {
+            const V3 origin = OffsetRayOrigin(p, pErr, n, dir);
+            ps.nee[slot].sh_o = make_float4(origin.x, origin.y, origin.z, 1 - PT_SHADOW_EPS);
+            ps.nee[slot].sh_d = make_float4(dir.x, dir.y, dir.z, __int_as_float(GetMediumOf(n, mIn, mOut, dir)));
+            S->rho_found.w = __uint_as_float(nFound);
+            S->base_seen.w = __uint_as_float(seen | (pass << 31));
+            S->target_sel.w = __uint_as_float(selected);
+            again = true;
+        }
+    }
+    *againOut = again; *doneOut = done;
+}
 template <bool INST>
 __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn, uint32_t *qOut, uint32_t rowOut, int first) {
     for (SegIter it(ps.qcount, rowIn, ps.seg_cap); it.more(); it.next()) {
@@ -906,71 +977,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
         uint32_t slot = 0;
         if (active) {
             slot = qIn[it.item()];
-            SssRec *S = &ps.sss[slot];
-            const float4 bs4 = S->base_seen, tg4 = S->target_sel;
-            const V3 baseP(bs4.x, bs4.y, bs4.z), pTarget(tg4.x, tg4.y, tg4.z);
-            const int material = (int)__float_as_uint(S->ns_mat.w);
-            uint32_t seen = __float_as_uint(bs4.w) & 0x7fffffffu, pass = __float_as_uint(bs4.w) >> 31;
-            uint32_t nFound = __float_as_uint(S->rho_found.w), selected = __float_as_uint(tg4.w);
-            V3 p = baseP, pErr, n;   // a plain Interaction: no normal, no error bounds, no media
-            int mIn = -1, mOut = -1;
-            bool endOfWalk = false;
-            if (!first) {
-                const uint4 hit = ps.trs[slot].hit[0];
-                if (hit.x == TRAV_MISS) endOfWalk = true;
-                else {
-                    const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
-                    const int rayMedium = __float_as_int(d4.w);   // GetMedium(dir) of the chain point the segment left from
-                    VHit vh;
-                    HitToIsect(scp, &vol, hit.x, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), hit.z, rayMedium, false, &vh);
-                    p = vh.is.p; pErr = vh.is.pError; n = vh.is.n; mIn = vh.mIn; mOut = vh.mOut;
-                    if ((int)vh.tinfo.y == material) {
-                        if (pass == 1 && seen == selected) {   // pi: k_sss_entry rebuilds the interaction from the segment, its medium and the primitive
-                            S->nz_pi = make_float4(0, __uint_as_float(hit.x), __uint_as_float(hit.z), d4.w);
-                            S->pi_o = o4; S->pi_d = d4;
-                            done = true;
-                        } else {
-                            if (pass == 0 && seen < PT_SSS_KEEP) {
-                                S->keep_o[seen] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(hit.x));
-                                S->keep_d[seen] = d4;
-                                S->keep_inst[seen] = hit.z;
-                            }
-                            ++seen;
-                        }
-                    }
-                }
-            }
-            if (!done) {
-                V3 dir = pTarget - p;
-                if (!endOfWalk && dir.x == 0 && dir.y == 0 && dir.z == 0) endOfWalk = true;
-                bool walking = !endOfWalk;
-                if (endOfWalk && pass == 0 && seen > 0) {   // choose, then the same walk again up to the chosen hit
-                    nFound = seen;
-                    int sel = (int)(S->sigt_u1.w * (int)nFound);
-                    selected = (uint32_t)(sel < 0 ? 0 : (sel > (int)nFound - 1 ? (int)nFound - 1 : sel));
-                    if (selected < PT_SSS_KEEP) {   // the chosen hit is one of the kept ones
-                        const float4 ko = S->keep_o[selected], kd = S->keep_d[selected];
-                        S->nz_pi = make_float4(0, ko.w, __uint_as_float(S->keep_inst[selected]), kd.w);
-                        S->pi_o = ko; S->pi_d = kd;
-                        S->rho_found.w = __uint_as_float(nFound);
-                        done = true;
-                    } else {
-                        pass = 1; seen = 0;
-                        p = baseP; pErr = V3(); n = V3(); mIn = mOut = -1;
-                        dir = pTarget - p;
-                        walking = !(dir.x == 0 && dir.y == 0 && dir.z == 0);
-                    }
-                }
-                if (walking && !done) {
-                    const V3 origin = OffsetRayOrigin(p, pErr, n, dir);
-                    ps.nee[slot].sh_o = make_float4(origin.x, origin.y, origin.z, 1 - PT_SHADOW_EPS);
-                    ps.nee[slot].sh_d = make_float4(dir.x, dir.y, dir.z, __int_as_float(GetMediumOf(n, mIn, mOut, dir)));
-                    S->rho_found.w = __uint_as_float(nFound);
-                    S->base_seen.w = __uint_as_float(seen | (pass << 31));
-                    S->target_sel.w = __uint_as_float(selected);
-                    again = true;
-                }
-            }
+            SssProbeStepOne<INST>(scp, ps, vol, slot, first != 0, &again, &done);
         }
         const uint32_t qseg = blockIdx.x & 7;
         const uint32_t pos = wave_append(&ps.qcount[QCI(rowOut, qseg)], again);
@@ -978,6 +985,41 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
         const uint32_t posD = wave_append(&ps.qcount[QCI(QC_SSS, qseg)], done);
         if (done) ps.q_sss[qseg * ps.seg_cap + posD] = slot;
     }
+}
+// The TAIL of the probe walk (round 4).  Chains have very different lengths: after a few rounds most paths are done and the queue holds the few whose probe ray
+// crosses many surfaces -- each further round is two launches and a host read-back for a handful of rays (915 ms of the 10 M-triangle
+// subsurface frame).  Once the queue is below PBRT_AMD_SSS_TAIL rays (default 65536) the host hands it to this kernel: every lane finishes its own chain --
+// the segment's closest hit by the per-lane tracer (TraceLane: Scene::Intersect with alphaMask at candidate hits, as k_trace<2, ..., TR> finds it), then
+// the same step (SssProbeStepOne) -- until pi is chosen or the chain ends.  Same rays, same arithmetic, same counters.
+template <bool INST>
+__global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_tail(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn) {
+    __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    LaneTracer lt;
+    lt.scp = scp;
+    lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
+    lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
+    lt.nClosest = lt.nAny = lt.guardTrips = 0;
+    for (SegIter it(ps.qcount, rowIn, ps.seg_cap); it.more(); it.next()) {
+        const bool active = it.valid();
+        bool done = false;
+        uint32_t slot = 0;
+        if (active) {
+            slot = qIn[it.item()];
+            bool again = true;
+            for (uint32_t seg = 0; again && seg < 16384u; ++seg) {   // (the host's own bound on the rounds of a walk)
+                const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+                const LaneHit h = TraceLane<false, INST>(&lt, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w);
+                ps.trs[slot].hit[0] = make_uint4(h.prim, __float_as_uint(h.t), h.inst, 0u);
+                SssProbeStepOne<INST>(scp, ps, vol, slot, false, &again, &done);
+            }
+            if (again) ++lt.guardTrips;   // a chain that did not end: reported like a traversal that did not (the host fails the render)
+        }
+        const uint32_t qseg = blockIdx.x & 7;
+        const uint32_t posD = wave_append(&ps.qcount[QCI(QC_SSS, qseg)], done);
+        if (done) ps.q_sss[qseg * ps.seg_cap + posD] = slot;
+    }
+    wave_count(&ps.counters[MI_CNT_CLOSEST_RAYS], lt.nClosest);
+    wave_count(&ps.counters[MI_CNT_TRACE_GUARD_TRIPS], lt.guardTrips);
 }
 
 // The entry vertex of a subsurface path (path.cpp:160-174 after Sample_S; bssrdf.cpp:235-247, 316-326): Sp and its pdf at the chosen hit, beta *= S / pdf,
