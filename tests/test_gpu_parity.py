@@ -705,6 +705,44 @@ def test_media_under_path_are_ignored():
     ctx.close()
 
 
+# ---------------------------------------------------------------- deep traversal stacks (round 4: TravStackB's generic tail + the spill slices)
+@pytest.mark.gpu
+def test_deep_stacks_take_the_generic_tail_and_spill():
+    """6 000 random triangles that all span the same cube: every child box of every node is entered, three pushes per level, and the host emulation of the
+    kernel's state machine (mi_bvh4q_validate) needs 24 stack entries -- more than the 15 a lane of the 768-thread traversal shape holds in LDS.  The
+    interior step's fast tail is only valid while no lane of the wave is within three entries of its LDS part; here waves go through the per-wave branch into
+    the generic tail and through the HBM spill slices all the time.  Hits and occlusion flags must equal the oracle's BVH2 walk bit for bit."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    P = rng.uniform(-1, 1, (3 * n, 3)).astype(np.float32)
+    text = ('LookAt 0 0 5  0 0 0  0 1 0\nCamera "perspective" "float fov" [40]\nSampler "sobol" "integer pixelsamples" [1]\n'
+            'Film "image" "integer xresolution" [32] "integer yresolution" [32] "string filename" ["x.pfm"]\nWorldBegin\nMaterial "matte"\n'
+            'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\nWorldEnd\n' % (" ".join(str(i) for i in range(3 * n)), " ".join("%.9g" % v for v in P.reshape(-1))))
+    sc = pa.Scene(text=text)
+    m = 4000
+    o = rng.uniform(-1, 1, (m, 3)).astype(np.float32)
+    d = rng.standard_normal((m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.zeros(m, dtype=pa.RAY_DTYPE)
+    rays["o"] = 3 * o
+    rays["d"] = -o / np.linalg.norm(o, axis=1)[:, None] + 0.3 * d
+    rays["tmax"] = np.inf
+    _, st = pa.bvh4q_validate(sc, rays, want_hits=False)
+    ctx = pa.Context(sc)
+    ti = ctx.trace_info()
+    assert st["max_stack"] > ti["lds_stack_entries"], (st, ti)   # the workload does leave the LDS part
+    dh = ctx.intersect(rays)
+    rh, _ = ol.intersect(sc, rays)
+    assert np.array_equal(dh["prim"], rh["prim"])
+    hit = rh["prim"] >= 0
+    assert hit.sum() > 3000
+    assert np.array_equal(dh["t"][hit].view(np.uint32), rh["t"][hit].view(np.uint32))
+    rays["tmax"] = rng.uniform(0.5, 4.0, m).astype(np.float32)
+    assert np.array_equal(ctx.intersect_p(rays), ol.intersect_p(sc, rays)[0])
+    assert ctx.counters()["trace_guard_trips"] == 0
+    ctx.close()
+
+
 # ---------------------------------------------------------------- the reference's own host driving the device (INTEGRATION.md s.2)
 REF_STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
 
