@@ -386,6 +386,13 @@ PT_DEV float PtMax3Raw(float a, float b, float c) {
     const float m = b < a ? a : b; return c < m ? m : c;
 #endif
 }
+PT_DEV float PtRcpBox(float x) {   // 1 / x for the quantised box test's per-ray constants only (see TravStateQ::init)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1 / x;
+#endif
+}
 PT_DEV float PtMaxRaw(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
@@ -666,8 +673,13 @@ struct TravStateQ : TravState {
     template <class ST> PT_DEV void init(const DevScene &sc, const V3 &o_, const V3 &d_, Float tMax_, ST &st) {
         o = o_; d = d_; tMax = tMax_; tHit = 0; prim = TRAV_MISS;
         const float oo[3] = {o.x, o.y, o.z};
-        const float inv[3] = {d.x == 0 ? __builtin_copysignf(1e30f, d.x) : 1 / d.x, d.y == 0 ? __builtin_copysignf(1e30f, d.y) : 1 / d.y,
-                              d.z == 0 ? __builtin_copysignf(1e30f, d.z) : 1 / d.z};   // SlabRayInit's convention for zero direction components
+        // SlabRayInit's convention for zero direction components.  The reciprocal may be v_rcp_f32's (1 ulp) instead of the IEEE division's twelve
+        // instructions: the folded box test is only required to be CONSERVATIVE, and its slack of 16 eps (|B| + 65535 |A|) covers the 3 eps a one-ulp
+        // reciprocal adds to the evaluation error of pt_bvh4q.h's header (~10 of 16 eps in total); the triangle test's shear constants stay exact
+        // (components below 1e-30 in magnitude are treated like zeros: their crossing times are beyond any tMax unless the origin is within 1e-27 of the
+        // plane, and v_rcp_f32 must not see a denormal)
+        const float inv[3] = {absf(d.x) < 1e-30f ? __builtin_copysignf(1e30f, d.x) : PtRcpBox(d.x), absf(d.y) < 1e-30f ? __builtin_copysignf(1e30f, d.y) : PtRcpBox(d.y),
+                              absf(d.z) < 1e-30f ? __builtin_copysignf(1e30f, d.z) : PtRcpBox(d.z)};
         Bvh4qRayInit(q, sc.qgrid, oo, inv);
         shear.init(d);
         st.reset();
