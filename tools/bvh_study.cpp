@@ -589,6 +589,30 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
                             else { l.parked = DONE; if (atLeaf(l)) park(l); }
                         }
                     }
+                } else if (policy == 7) {
+                    // as policy 3, but a leaf phase spreads the parked leaves' triangles over ALL 64 lanes: first every parked leaf's next triangle, then the second ones,
+                    // ... up to 4 per leaf and 64 tests per phase (idle lanes test triangles of other lanes' rays; what it would cost on the device: the pair
+                    // assignment, the ray's constants and the result through LDS -- priced by the caller as a dearer triangle phase)
+                    auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };
+                    for (int g = 0; g < nodeSteps; ++g) {
+                        int nWant = 0; for (auto &l : L) nWant += atNode(l);
+                        if (!nWant) break;
+                        ++phN; laN += nWant;
+                        for (auto &l : L) if (atNode(l)) { nodeStep(l); if (atLeaf(l) && l.parked == DONE) park(l); }
+                        int nPend = 0; for (auto &l : L) nPend += l.active && l.parked != DONE;
+                        if (nPend >= leafMin) break;
+                    }
+                    int nPend = 0; for (auto &l : L) nPend += l.active && l.parked != DONE;
+                    if (nPend) {
+                        int take[64] = {0}, total = 0;
+                        for (int k = 0; k < 4 && total < 64; ++k)
+                            for (int li = 0; li < 64 && total < 64; ++li) { Lane &l = L[li]; if (l.active && l.parked != DONE && l.parkedCount > k) { ++take[li]; ++total; } }
+                        ++phL; laL += total;
+                        for (int li = 0; li < 64; ++li) { Lane &l = L[li];
+                            for (int k = 0; k < take[li]; ++k) { triStep(l, l.parked); ++l.parked; --l.parkedCount; }
+                            if (take[li] && l.parkedCount == 0) { l.parked = DONE; if (atLeaf(l)) park(l); }
+                        }
+                    }
                 } else if (policy == 3) {
                     // one pending leaf per lane, tested ONE triangle per leaf phase while the lane goes on with node steps (speculative: stale tMax)
                     auto park = [&](Lane &l) { l.parked = l.cur & ~LEAF; l.parkedCount = l.left + 1; pop(l); };

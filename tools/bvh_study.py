@@ -66,7 +66,7 @@ def main():
         L.bvh_study_wavesim.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         rng2 = np.random.RandomState(5)
         rays = np.ascontiguousarray(sec[rng2.permutation(len(sec))])
-        CN, CL = 230.0, 300.0   # instructions of one node phase / one triangle phase of k_trace<0, QN> (gfx950 ISA, VALU + SALU)
+        CN, CL = 143.0, 163.0   # VALU instructions of one node phase / one triangle phase of k_trace<0, QN> (round 4: profiles/r04_h_isa_node_step.txt)
         print("64-lane waves over %d incoherent bounce rays; cost = node phases x %.0f + triangle phases x %.0f instructions" % (len(rays), CN, CL))
         print("%-64s %9s %9s %8s %9s %9s %8s %10s" % ("policy", "nodePh/ray", "lanes/ph", "eff", "triPh/ray", "lanes/ph", "eff", "instr/ray"))
         base = None
@@ -82,6 +82,7 @@ def main():
                                         ("pending leaf, <= 8 / 24 + entries beyond the hit dropped at pop", 3, 1008, 24, 16), ("today's policy + dropped at pop", 0, 1008, 24, 16),
                                         ("TWO rays per lane, each with a pending leaf, <= 8 / 24, refill 16 lanes' worth", 6, 8, 24, 16), ("two rays per lane, <= 8 / 32", 6, 8, 32, 16), ("two rays per lane, <= 8 / 40", 6, 8, 40, 16),
                                         ("two rays per lane, <= 8 / 48", 6, 8, 48, 16), ("two rays per lane, <= 16 / 48", 6, 16, 48, 16), ("two rays per lane, <= 8 / 40, refill 8", 6, 8, 40, 8), ("two rays per lane, <= 8 / 56", 6, 8, 56, 16),
+                                        ("SHARED triangle phases (parked triangles over all 64 lanes), <= 8 / 24", 7, 8, 24, 16), ("shared triangle phases, <= 8 / 32", 7, 8, 32, 16), ("shared triangle phases, <= 8 / 16", 7, 8, 16, 16),
                                         ("postponed leaves, <= 8 / 24", 2, 8, 24, 16), ("postponed leaves, <= 16 / 32", 2, 16, 32, 16), ("postponed leaves, <= 32 / 48", 2, 32, 48, 16)):
             out = np.zeros(8)
             L.bvh_study_wavesim(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), pol, ns, lm, rf, out.ctypes.data_as(C.c_void_p))
