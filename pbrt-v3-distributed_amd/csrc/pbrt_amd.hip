@@ -97,6 +97,11 @@ struct PathState {
     int spill_per_thread;
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
+    // Scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials (mi_ctx::sssRoute): the material sort puts those materials' keys LAST
+    // (key_remap, applied by k_keycount) and the sorted queue is shaded in two launches -- k_shade takes the keys below shade_split, k_shade_vol the rest.
+    const uint32_t *key_remap;   // [nkeys] or null
+    uint32_t shade_split;        // first key of the second part
+    uint32_t shade_part;         // 0: the whole queue; 1: keys < shade_split; 2: keys >= shade_split
 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_CONT = 11, QC_ROWS = 12 };
 #define QSEG 8u
@@ -159,6 +164,13 @@ struct ChunkIter {
 #ifndef PT_WAVE_SIZE
 #define PT_WAVE_SIZE 64u
 #endif
+// the part of the material-sorted queue a shading launch walks (PathState::shade_part): [base, base + n)
+PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
+    *base = 0;
+    *n = ps.qcount[QCI(QC_SORTED, 0)];
+    if (ps.shade_part == 1) *n = ps.keyoffset[ps.shade_split];
+    else if (ps.shade_part == 2) { *base = ps.keyoffset[ps.shade_split]; *n -= *base; }
+}
 struct DynIter {
     uint32_t segBeg, segEnd, cur, end;
     uint32_t *cursor;
@@ -903,6 +915,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
         if (active) {
             slot = ps.q_ext[qin][i];
             key = ps.key[slot];
+            if (ps.key_remap) key = ps.key_remap[key];
         }
         uint32_t rank = wave_key_rank(lhist, key, active);
         if (active) ps.keyrank[i] = make_uint2(key, rank);   // indexed by queue position: k_scatter walks the same chunks
@@ -1080,7 +1093,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     if (cdfInLds) for (uint32_t k = threadIdx.x; k < sc.n_lights + 1; k += PT_BLOCK) s_cdf[k] = sc.light_cdf[k];
     __syncthreads();
     const float *cdf = cdfInLds ? s_cdf : sc.light_cdf;
-    uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
+    uint32_t n, sbase;
+    ShadeRange(ps, &sbase, &n);
     uint32_t nseg = 0;
 #if PT_SHADE_DYN
     for (DynIter it(n, ps.cursor); it.more(); it.next()) {
@@ -1103,7 +1117,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
         if (active) {
-            slot = ps.q_sorted[i];
+            slot = ps.q_sorted[sbase + i];
             uint2 hr = ps.rec[slot].hit;
             float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
             uint4 s4 = ps.rec[slot].smp;
@@ -1586,6 +1600,9 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 65536;                // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+    bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
+    const uint32_t *keyRemap = nullptr;
+    uint32_t shadeSplit = 0;
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -2441,6 +2458,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
     std::memset(&c->vol, 0, sizeof(c->vol));
     c->scDev = nullptr;
+    c->sssRoute = false; c->keyRemap = nullptr; c->shadeSplit = 0;
     if (c->volKernel) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
@@ -2512,6 +2530,26 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             }
             { DevBuf &b = next(); if (upload(c, b, tabs.data(), tabs.size() * sizeof(DevBssrdfTable))) return -1; v.tables = b.as<DevBssrdfTable>(); }
             { DevBuf &b = next(); if (upload(c, b, d->material_bssrdf, (size_t)d->n_materials * sizeof(mi_bssrdf_desc))) return -1; v.bssrdf = b.as<mi_bssrdf_desc>(); }
+            // Routing (sssRoute).  Under Integrator "path" a vertex on a material WITHOUT a BSSRDF is PathIntegrator::Li's ordinary loop body: k_shade does it from the same
+            // PathRec / NeeRec fields at 3 waves per SIMD with wave-uniform lobe lists, where k_shade_vol (per-lane lobe lists, 2 waves) would treat it as the general case.
+            // The material sort orders the keys [materials without BSSRDF, escaped, null-BSDF | materials with BSSRDF]; k_shade takes the first part of the sorted
+            // queue and k_shade_vol the second.  Not with a walk or a split vertex (volTr / volSplit: "volpath" scenes): there NeeRec carries the walk's extra words.
+            bool route = c->sssWave && !v.handle_media && !c->volTr && !c->volSplit;
+            { const char *e = std::getenv("PBRT_AMD_SSS_ROUTE"); if (e && e[0] == '0') route = false; }
+            if (route) {
+                const uint32_t nk = d->n_materials + 2;
+                std::vector<uint32_t> remap(nk);
+                uint32_t plain = 0, nPlain = 0;
+                for (uint32_t m = 0; m < d->n_materials; ++m) nPlain += d->material_bssrdf[m].kind == MI_BSSRDF_NONE;
+                uint32_t sss = nPlain + 2;
+                for (uint32_t m = 0; m < d->n_materials; ++m) remap[m] = d->material_bssrdf[m].kind == MI_BSSRDF_NONE ? plain++ : sss++;
+                remap[d->n_materials] = nPlain; remap[d->n_materials + 1] = nPlain + 1;   // escaped rays, null-BSDF surfaces
+                if (nPlain + 2 < nk) {   // (some material does have a BSSRDF)
+                    DevBuf &b = next();
+                    if (upload(c, b, remap.data(), remap.size() * sizeof(uint32_t))) return -1;
+                    c->keyRemap = b.as<uint32_t>(); c->shadeSplit = nPlain + 2; c->sssRoute = true;
+                }
+            }
             HIP_TRY(hipStreamSynchronize(c->stream));   // local
         }
         // sampler dimensions: ratio / delta tracking in grid media draw a data-dependent number per segment; the reference aborts past its tables
@@ -2660,6 +2698,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     TableTurn turn(c);
+    ps.key_remap = c->sssRoute ? c->keyRemap : nullptr;
+    ps.shade_split = c->shadeSplit; ps.shade_part = 0;
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
     if (c->hasTex || c->hasAlpha || c->hasInst)   // the tables of THIS context's scene (stream ordered; contexts sharing a device take turns: TableTurn)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
@@ -2713,7 +2753,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         tic(c, MI_K_SHADE);
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON, pixSmp = MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
-            if (c->volKernel) {   // row f4: media / BSSRDF (pt_volpath.h: the general form traces transmittance, MIS and probe rays in the shading lanes, the wavefront forms queue them)
+            auto shade_vol = [&](const PathState &ps) {   // row f4: media / BSSRDF (pt_volpath.h: the general form traces transmittance, MIS and probe rays in the shading lanes, the wavefront forms queue them)
                 const dim3 gw(c->gridShade);
 #define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
                 const bool umat = !c->vol.textured && !c->vol.bssrdf;   // constant lobe lists only: wave-uniform material access (the UMAT instance compiles the BSSRDF branch out)
@@ -2725,18 +2765,31 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                     else { if (umat) LAUNCH_VOL(false, false, true, grid); else LAUNCH_VOL(false, false, false, grid); }
                 }
 #undef LAUNCH_VOL
-            }
+            };
 #define LAUNCH_SHADE(ENV, TEX, ...)                                                                                                              \
     do {                                                                                                                                         \
         if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                   \
         else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);               \
         else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
     } while (0)
-            else if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
-            else if (c->hasTex) LAUNCH_SHADE(true, true);          // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
-            else if (c->hasEnvMap || c->hasSpheres) LAUNCH_SHADE(true, false);
-            else LAUNCH_SHADE(false, false);
+            auto shade_plain = [&](const PathState &ps) {
+                if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
+                else if (c->hasTex) LAUNCH_SHADE(true, true);     // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
+                else if (c->hasEnvMap || c->hasSpheres) LAUNCH_SHADE(true, false);
+                else LAUNCH_SHADE(false, false);
+            };
 #undef LAUNCH_SHADE
+            if (c->sssRoute) {   // PathState::key_remap: the sorted queue's first part is ordinary vertices (k_shade), its second part the vertices on BSSRDF materials
+                PathState part = ps;
+                part.shade_part = 1;
+                shade_plain(part);
+                toc(c);   // (each part is its own entry of mi_timing_get's launch count)
+                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                tic(c, MI_K_SHADE);
+                part.shade_part = 2;
+                shade_vol(part);
+            } else if (c->volKernel) shade_vol(ps);
+            else shade_plain(ps);
         }
         toc(c);
         // the direct-lighting rays of a shading stage through the walk (volTr) or the plain any-hit / closest-hit traversals
@@ -2791,7 +2844,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             tic(c, MI_K_MIS_CLOSEST);
             {
                 PathState psRun = ps;
-                psRun.vol_tr = c->volWave ? 1u : 0u;
+                psRun.vol_tr = c->volWave && c->vol.handle_media ? 1u : 0u;   // (scenes without media: no sigma_t in NeeRec::pad[0] -- k_shade does not write it)
                 PathState &ps = psRun;
                 LAUNCH_TRACE(1);
             }
@@ -2813,7 +2866,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             HIP_TRY(hipStreamWaitEvent(s2, c->evShaded, 0));
             PathState psNee = ps;
             psNee.cursor = c->cursor2; psNee.spill = c->spill2;
-            psNee.vol_tr = c->volWave ? 1u : 0u;
+            psNee.vol_tr = c->volWave && c->vol.handle_media ? 1u : 0u;
             {
                 hipStream_t st = s2;
                 PathState &ps = psNee;

@@ -540,7 +540,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
     lt.lds = (LdsStackEntry *)&lds_stack[WAVE ? 0 : threadIdx.x];
     lt.spill = reinterpret_cast<StackEntry *>(ps.spill) + (size_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * ps.spill_per_thread;
     lt.nClosest = lt.nAny = lt.guardTrips = 0;
-    const uint32_t n = ps.qcount[QCI(QC_SORTED, 0)];
+    uint32_t n, sbase;
+    ShadeRange(ps, &sbase, &n);
     uint32_t nseg = 0;
 #if PT_SHADE_DYN
     for (DynIter it(n, ps.cursor); it.more(); it.next()) {
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
         if (active) {
-            slot = ps.q_sorted[i];
+            slot = ps.q_sorted[sbase + i];
             const uint2 hr = ps.rec[slot].hit;
             const float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
             const uint4 s4 = ps.rec[slot].smp;

@@ -1076,6 +1076,36 @@ def test_walked_bssrdf_probes_match_the_general_form(name, flatten, monkeypatch)
     assert np.allclose(out["walked"][0], out["general"][0], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["sss_named", "sss_coeff", "sss_inst"])
+def test_only_the_vertices_on_bssrdf_materials_go_to_the_volumetric_shading_kernel(name, monkeypatch):
+    """Round 4: under Integrator "path" the material sort puts the BSSRDF materials' keys last and the sorted queue is shaded in two launches -- k_shade for the
+    ordinary vertices (PathIntegrator::Li's loop body, path.cpp:64-188), k_shade_vol for the vertices on BSSRDF materials (path.cpp:153-174).  PBRT_AMD_SSS_ROUTE=0
+    sends every vertex through k_shade_vol as before: the same samples, the same rays, the same image."""
+    fx = pa.read_pfm(os.path.join(G, "edge_%s.pfm" % name))
+    out = {}
+    for form in ("routed", "all_vol"):
+        if form == "all_vol":
+            monkeypatch.setenv("PBRT_AMD_SSS_ROUTE", "0")
+        else:
+            monkeypatch.delenv("PBRT_AMD_SSS_ROUTE", raising=False)
+        sc = pa.Scene(text=edge_scenes.scene(name))
+        ctx = pa.Context(sc)
+        ctx.timing_enable(True); ctx.counters_reset()
+        ctx.render()
+        t, cnt = ctx.timing(), ctx.counters()
+        img = sc.film_image(ctx.film())
+        frac, relmse = ol.image_metrics(img, fx)
+        assert frac >= 0.995 and relmse <= 1e-4, (form, frac, relmse)
+        out[form] = (img, {k: v[1] for k, v in t.items() if v[1]}, cnt)
+        ctx.close()
+    assert out["routed"][1]["shade"] > out["all_vol"][1]["shade"]   # two shading launches per bounce instead of one
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "path_segments"):
+        assert out["routed"][2][k] == out["all_vol"][2][k], k
+    assert out["routed"][2]["trace_guard_trips"] == 0
+    assert np.allclose(out["routed"][0], out["all_vol"][0], rtol=1e-5, atol=1e-6)
+    print("routed vs all-vol: %.4f of the pixels bit-identical" % float((out["routed"][0].view(np.uint32) == out["all_vol"][0].view(np.uint32)).all(-1).mean()))
+
+
 @pytest.mark.parametrize("name", ["sanmiguel_subsurface", "sanmiguel_smokebox"])
 def test_baseline_config_reduced_with_subsurface_materials_and_with_a_grid_medium(name, tmp_path):
     """the reduced C3 stand-in with three kdsubsurface materials (bench.py --subsurface: walked probe chains) and with a heterogeneous medium behind a
