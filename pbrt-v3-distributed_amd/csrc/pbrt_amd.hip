@@ -1600,6 +1600,7 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 65536;                // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+    bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
     const uint32_t *keyRemap = nullptr;
     uint32_t shadeSplit = 0;
@@ -2536,6 +2537,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             // queue and k_shade_vol the second.  Not with a walk or a split vertex (volTr / volSplit: "volpath" scenes): there NeeRec carries the walk's extra words.
             bool route = c->sssWave && !v.handle_media && !c->volTr && !c->volSplit;
             { const char *e = std::getenv("PBRT_AMD_SSS_ROUTE"); if (e && e[0] == '0') route = false; }
+            { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
             if (route) {
                 const uint32_t nk = d->n_materials + 2;
                 std::vector<uint32_t> remap(nk);
@@ -2691,6 +2693,13 @@ static void harvest(mi_ctx *c) {
         else if (c->hasAlpha) LAUNCH_TRACE_TR_I(MODE, true, true, false, false);                                    \
         else LAUNCH_TRACE_TR_I(MODE, true, false, false, false);                                                    \
     } while (0)
+// The shadow-queue walks (MODE 2: the segments of walked shadow rays and of BSSRDF probe chains) of all-triangle single-level scenes without masks take the lean
+// instance: the 768-thread shape with hot nodes in LDS (TraceShape::BIG), as the plain traversals of such scenes do.  PBRT_AMD_TR_LEAN=0: the sphere-capable instance (A/B)
+#define LAUNCH_TRACE_TR_SHADOW                                                                                      \
+    do {                                                                                                            \
+        if (c->trLean && c->useQ && !c->hasAlpha && !c->hasInst && !c->hasSpheres) LAUNCH_TRACE_TR_I(2, false, false, false, true); \
+        else LAUNCH_TRACE_TR(2);                                                                                    \
+    } while (0)
 // One pass of the wavefront pipeline over the paths generated by `pass`.
 static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm) {
     PathState &ps = c->ps;
@@ -2810,7 +2819,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         PathState psRun = ps;
                         if (which) { psRun.q_mis = qIn; psRun.qrow_mis = rowIn; } else { psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn; }
                         PathState &ps = psRun;
-                        if (which) LAUNCH_TRACE_TR(1); else LAUNCH_TRACE_TR(2);
+                        if (which) LAUNCH_TRACE_TR(1); else LAUNCH_TRACE_TR_SHADOW;
                     }
 #define LAUNCH_TR_STEP(M, I, D) hipLaunchKernelGGL((k_vol_tr_step<M, I, D>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut)
                     if (which) {
@@ -2910,7 +2919,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                         PathState psRun = ps;
                         psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn;
                         PathState &ps = psRun;
-                        LAUNCH_TRACE_TR(2);
+                        LAUNCH_TRACE_TR_SHADOW;
                     }
                     if (c->hasInst) hipLaunchKernelGGL((k_sss_probe_step<true>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 0);
                     else hipLaunchKernelGGL((k_sss_probe_step<false>), grid, block, 0, st, c->scDev, ps, c->vol, (const uint32_t *)qIn, rowIn, qOut, rowOut, 0);
