@@ -1126,7 +1126,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
             Float etaScale = b4.w;
             int bounces = (int)(s4.w & 0xffffu);
             bool specularBounce = (s4.w >> 16) & 1u;
-            bool noDiff = TEX && ((s4.w >> 17) & 1u);   // a null-material surface was stepped through: the ray is a plain Ray from then on
+            bool noDiff = (s4.w >> 17) & 1u;   // a null-material surface was stepped through: the ray is a plain Ray from then on (read by the textured instances; every instance carries it -- a path may change kernels from vertex to vertex, mi_ctx::sssRoute)
             PROBE(1)   // queue + path record loads
             Sampler smp;
             smp.index = (uint64_t)s4.x | ((uint64_t)s4.y << 32);
@@ -1202,7 +1202,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                     if (ps.q_key) rayKey = RayBinKey(ps, no, rd);
                     cont = true;
-                    noDiff = TEX;
+                    noDiff = true;
                 } else {
                     PROBE(4)   // emission
                     // Lanes of a wave share a material almost always (sorted queue); at the boundary between two materials
@@ -1366,7 +1366,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
             }
             PROBE(12)   // RR + record stores
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
-            if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16) | (TEX ? (uint32_t)noDiff << 17 : 0u));
+            if (cont) ps.rec[slot].smp = make_uint4(s4.x, s4.y, (uint32_t)(smp.dimension + ui), (uint32_t)bounces | ((uint32_t)specularBounce << 16) | ((uint32_t)noDiff << 17));
         }
         uint32_t posE, posS, posM;
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;   // this block class's segment of the three queues
@@ -1600,6 +1600,7 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 65536;                // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+    bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
     const uint32_t *keyRemap = nullptr;
@@ -2539,6 +2540,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             { const char *e = std::getenv("PBRT_AMD_SSS_ROUTE"); if (e && e[0] == '0') route = false; }
             { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
             if (route) {
+                c->plainTex = false;
+                if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->plainTex |= d->material_descs[m].textured != 0 && d->material_bssrdf[m].kind == MI_BSSRDF_NONE;
                 const uint32_t nk = d->n_materials + 2;
                 std::vector<uint32_t> remap(nk);
                 uint32_t plain = 0, nPlain = 0;
@@ -2782,8 +2785,10 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
     } while (0)
             auto shade_plain = [&](const PathState &ps) {
+                // (routed subsurface scenes: the BSSRDF materials are always built per hit, mi_material_desc::textured -- what counts here are the materials k_shade sees)
+                const bool tex = c->sssRoute ? c->plainTex : c->hasTex;
                 if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
-                else if (c->hasTex) LAUNCH_SHADE(true, true);     // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
+                else if (tex) LAUNCH_SHADE(true, true);           // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
                 else if (c->hasEnvMap || c->hasSpheres) LAUNCH_SHADE(true, false);
                 else LAUNCH_SHADE(false, false);
             };
