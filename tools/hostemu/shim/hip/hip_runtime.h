@@ -69,6 +69,7 @@ static inline long long wall_clock64() { return 0; }
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }   // one-lane waves
 
 #define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) ((void)(src), (void)(dst))   /* cache-warming loads: nothing to emulate */
 #define __builtin_amdgcn_s_waitcnt(v) ((void)0)
 
 template <class T> static inline T emu_atomic_add_int(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
