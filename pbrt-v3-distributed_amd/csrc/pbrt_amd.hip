@@ -1067,16 +1067,6 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
 // SMP: 0 Sobol' / 1 Halton (the vertex's dimensions drawn in one batch) / 2 the tile-serial samplers (drawn call by call, in the reference's order: the
 // values come from the tile's stream)
-// k_shade is bound by its chain of dependent loads at 3 waves per SIMD: queue entry -> PathRec -> triangle records -> light tables.  A wave owns
-// PT_DYN_GRAIN consecutive items, so while it shades item i it knows item i + 64: the queue entries are read two groups ahead, the next item's hit record
-// one group ahead (a real load: it brings the item's whole PathRec line into the L2), and once that has arrived the next item's triangle records are touched by
-// loads that land in an LDS sink nobody reads (global_load_lds_dword: no VGPR, no wait).  The next item then finds its first three round trips in the L2.
-#ifndef PT_SHADE_PREFETCH
-#define PT_SHADE_PREFETCH 1
-#endif
-PT_DEV void TouchLine(const void *p, uint32_t *waveSink) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)waveSink, 4, 0, 0);
-}
 #ifndef PT_SHADE_ARGPTR
 #define PT_SHADE_ARGPTR 0   /* A/B: k_shade takes the DevScene through a pointer that is laundered once per item, so that no scene field is kept in an SGPR across items */
 #endif
@@ -1106,26 +1096,11 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     uint32_t n, sbase;
     ShadeRange(ps, &sbase, &n);
     uint32_t nseg = 0;
-#if PT_SHADE_DYN && PT_SHADE_PREFETCH
-    __shared__ uint32_t s_sink[PT_BLOCK];
-    uint32_t *const waveSink = &s_sink[threadIdx.x & ~63u];
-    uint32_t slotN = 0, slotNN = 0;   // queue entries of this wave's next two items (carried while the wave stays inside one grain)
-    bool carried = false;
-#endif
 #if PT_SHADE_DYN
     for (DynIter it(n, ps.cursor); it.more(); it.next()) {
         uint32_t i = it.item();
         PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = it.valid();
-#if PT_SHADE_PREFETCH
-        const bool next1 = i + PT_WAVE_SIZE < it.end, next2 = i + 2 * PT_WAVE_SIZE < it.end;
-        uint32_t slotCur;
-        if (!carried) { slotCur = active ? ps.q_sorted[sbase + i] : 0u; slotN = next1 ? ps.q_sorted[sbase + i + PT_WAVE_SIZE] : 0u; }
-        else { slotCur = slotN; slotN = slotNN; }
-        slotNN = next2 ? ps.q_sorted[sbase + i + 2 * PT_WAVE_SIZE] : 0u;
-        const uint32_t primN = next1 ? ps.rec[slotN].hit.x : MISS_PRIM;
-        carried = __builtin_amdgcn_readfirstlane(it.cur + PT_WAVE_SIZE < it.end ? 1 : 0) != 0;   // the next group is the same grain's
-#endif
 #if PT_SHADE_ARGPTR
 #undef sc
         const DevScene *scl = scp;
@@ -1142,11 +1117,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
         if (active) {
-#if PT_SHADE_DYN && PT_SHADE_PREFETCH
-            slot = slotCur;
-#else
             slot = ps.q_sorted[sbase + i];
-#endif
             uint2 hr = ps.rec[slot].hit;
             float4 o4 = ps.rec[slot].ray_o, d4 = ps.rec[slot].ray_d, b4 = ps.rec[slot].beta, L4 = ps.rec[slot].L;
             uint4 s4 = ps.rec[slot].smp;
@@ -1212,15 +1183,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                 }
             }
             PROBE(3)   // triangle reload + BuildIsect
-#if PT_SHADE_DYN && PT_SHADE_PREFETCH
-            if (primN != MISS_PRIM) {   // the next item's triangle: mesh words, shading record, vertices (48 bytes: first and last word, they may lie in two lines)
-                TouchLine(&sc.tri_info[primN], waveSink);
-                TouchLine(&sc.tri_shade[primN], waveSink);
-                const float4 *tv = sc.tri_verts + 3 * (size_t)primN;
-                TouchLine(tv, waveSink);
-                TouchLine(reinterpret_cast<const uint32_t *>(tv + 3) - 1, waveSink);
-            }
-#endif
             if (bounces == 0 || specularBounce) {
                 if (found) {
                     int li = (int)tinfo.z;
@@ -1636,7 +1598,7 @@ struct mi_ctx {
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
-    uint32_t sssTail = 65536;                // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
+    uint32_t sssTail = 131072;               // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
     bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW

@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
 }
 // The TAIL of the probe walk (round 4).  Chains have very different lengths: after a few rounds most paths are done and the queue holds the few whose probe ray
 // crosses many surfaces -- each further round is two launches and a host read-back for a handful of rays (915 ms of the 10 M-triangle
-// subsurface frame).  Once the queue is below PBRT_AMD_SSS_TAIL rays (default 65536) the host hands it to this kernel: every lane finishes its own chain --
+// subsurface frame).  Once the queue is below PBRT_AMD_SSS_TAIL rays (default 131072) the host hands it to this kernel: every lane finishes its own chain --
 // the segment's closest hit by the per-lane tracer (TraceLane: Scene::Intersect with alphaMask at candidate hits, as k_trace<2, ..., TR> finds it), then
 // the same step (SssProbeStepOne) -- until pi is chosen or the chain ends.  Same rays, same arithmetic, same counters.
 template <bool INST>
