@@ -2540,14 +2540,26 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             { const char *e = std::getenv("PBRT_AMD_SSS_ROUTE"); if (e && e[0] == '0') route = false; }
             { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
             if (route) {
+                // which materials k_shade_vol must see: those with a BSSRDF, and mix materials built on one -- MixMaterial evaluates m1 on *si itself (mixmat.cpp:45-64), so
+                // the mix's interaction carries m1's BSSRDF (ComputeBSSRDFD follows the m1 links); m2's is included for simplicity.  Sub-materials have smaller indices.
+                // (found by tools/fuzz_vs_reference.py --device --sss: a mix of two subsurface materials shaded by k_shade lost its BSSRDF bounce)
+                std::vector<char> needsVol(d->n_materials, 0);
+                for (uint32_t m = 0; m < d->n_materials; ++m) {
+                    needsVol[m] = d->material_bssrdf[m].kind != MI_BSSRDF_NONE;
+                    if (d->material_descs && d->material_descs[m].type == MI_MAT_MIX) {
+                        const int m1 = d->material_descs[m].m1, m2 = d->material_descs[m].m2;
+                        if (m1 >= 0 && (uint32_t)m1 < m) needsVol[m] |= needsVol[m1];
+                        if (m2 >= 0 && (uint32_t)m2 < m) needsVol[m] |= needsVol[m2];
+                    }
+                }
                 c->plainTex = false;
-                if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->plainTex |= d->material_descs[m].textured != 0 && d->material_bssrdf[m].kind == MI_BSSRDF_NONE;
+                if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->plainTex |= d->material_descs[m].textured != 0 && !needsVol[m];
                 const uint32_t nk = d->n_materials + 2;
                 std::vector<uint32_t> remap(nk);
                 uint32_t plain = 0, nPlain = 0;
-                for (uint32_t m = 0; m < d->n_materials; ++m) nPlain += d->material_bssrdf[m].kind == MI_BSSRDF_NONE;
+                for (uint32_t m = 0; m < d->n_materials; ++m) nPlain += !needsVol[m];
                 uint32_t sss = nPlain + 2;
-                for (uint32_t m = 0; m < d->n_materials; ++m) remap[m] = d->material_bssrdf[m].kind == MI_BSSRDF_NONE ? plain++ : sss++;
+                for (uint32_t m = 0; m < d->n_materials; ++m) remap[m] = !needsVol[m] ? plain++ : sss++;
                 remap[d->n_materials] = nPlain; remap[d->n_materials + 1] = nPlain + 1;   // escaped rays, null-BSDF surfaces
                 if (nPlain + 2 < nk) {   // (some material does have a BSSRDF)
                     DevBuf &b = next();
