@@ -1224,8 +1224,10 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             RayDiffT rdf = CameraDifferentials(&c_tex.camera, pf.x, pf.y, ln.x, ln.y, c_tex.spp, ro, rd);
                             ComputeDifferentials(isect.p, isect.n, &ix, rdf);
                         }
+                        PROBE(14)   // (textured instances) differentials of camera rays
                         ComputeScatteringFunctionsT(sc.materials, matU, &isect, &ix, &laneMat);
                         matPtr = &laneMat;
+                        PROBE(15)   // (textured instances) the material's textures / bump map -> per-lane lobe list
                     }
                     BS bsdf(isect, matPtr, TEX ? nullptr : sc.mat_pack, matU);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
