@@ -184,30 +184,6 @@ __device__ __noinline__ RGB MipTriangle(const DevImage *im, int level, Float s_,
     RGB a = MipTexel(im, level, s0, t0), b = MipTexel(im, level, s0, t0 + 1), c = MipTexel(im, level, s0 + 1, t0), d = MipTexel(im, level, s0 + 1, t0 + 1);
     return ((1 - ds) * (1 - dt)) * a + ((1 - ds) * dt) * b + (ds * (1 - dt)) * c + (ds * dt) * d;
 }
-#ifndef PT_EWA_BATCH
-#define PT_EWA_BATCH 4
-#endif
-// MipTexel of one pyramid level with the image's fields read once (MIPMap::Texel, mipmap.h:201-221); pyramid levels are powers of two wide (the constructor resamples,
-// mipmap.h:101-153), where Mod() is a mask -- the general form stays for anything else
-struct EwaImage {
-    const float *base;
-    int w, h, wrap, channels;
-    bool pow2;
-    PT_DEV EwaImage(const DevImage *im, int level) {
-        w = LevW(im, level); h = LevH(im, level); wrap = im->wrap; channels = im->channels;
-        base = im->texels + im->level_off[level];
-        pow2 = ((w & (w - 1)) | (h & (h - 1))) == 0;
-    }
-    PT_DEV RGB Texel(int s, int t) const {
-        if (wrap == 0) {
-            if (pow2) { s &= w - 1; t &= h - 1; }
-            else { s = ModT(s, w); t = ModT(t, h); }
-        } else if (wrap == 2) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
-        else if (s < 0 || s >= w || t < 0 || t >= h) return RGB(0.f);
-        const float *px = base + ((size_t)t * w + s) * channels;
-        return channels == 1 ? RGB(px[0]) : RGB(px[0], px[1], px[2]);
-    }
-};
 __device__ __noinline__ RGB MipEWA(const DevImage *im, int level, V2 st, V2 dst0, V2 dst1) {   // :309-353
     if (level >= im->levels) return MipTexel(im, im->levels - 1, 0, 0);
     int w = LevW(im, level), h = LevH(im, level);
@@ -226,32 +202,17 @@ __device__ __noinline__ RGB MipEWA(const DevImage *im, int level, V2 st, V2 dst0
     int t0 = (int)__builtin_ceilf(st.y - 2 * invDet * vSqrt), t1 = (int)__builtin_floorf(st.y + 2 * invDet * vSqrt);
     RGB sum(0.f);
     Float sumWts = 0;
-    // The reference walks the ellipse's bounding box row by row and adds the texels inside the ellipse in that order (mipmap.h:335-351) -- the order is part of the
-    // result.  Walked one texel at a time every fetch waits for the one before (the loop was 53 % of k_shade<..., TEX> on the textured 10 M-triangle frame: ~100 us per
-    // wave and vertex, profiles/r04_r_*): here PT_EWA_BATCH consecutive texels of the walk (across row ends) get their weights first, then their fetches back to back
-    // (independent loads), then the sums in the reference's order.  Same texels, same weights, same additions.
-    if (s1 >= s0 && t1 >= t0) {
-        const EwaImage ei(im, level);
-        int is = s0, it = t0;
-        while (it <= t1) {
-            Float wgt[PT_EWA_BATCH];
-            RGB tx[PT_EWA_BATCH];
-            uint32_t inside = 0;
-#pragma unroll
-            for (int k = 0; k < PT_EWA_BATCH; ++k) {
-                const Float ss = is - st.x, tt = it - st.y;
-                const Float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
-                wgt[k] = 0; tx[k] = RGB(0.f);
-                if (it <= t1 && r2 < 1) {
-                    wgt[k] = c_tex.ewa_lut[mni((int)(r2 * 128), 128 - 1)];
-                    tx[k] = ei.Texel(is, it);
-                    inside |= 1u << k;
-                }
-                if (++is > s1) { is = s0; ++it; }
+    for (int it = t0; it <= t1; ++it) {
+        Float tt = it - st.y;
+        for (int is = s0; is <= s1; ++is) {
+            Float ss = is - st.x;
+            Float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = mni((int)(r2 * 128), 128 - 1);
+                Float weight = c_tex.ewa_lut[index];
+                sum = sum + MipTexel(im, level, is, it) * weight;
+                sumWts += weight;
             }
-#pragma unroll
-            for (int k = 0; k < PT_EWA_BATCH; ++k)
-                if ((inside >> k) & 1u) { sum = sum + tx[k] * wgt[k]; sumWts += wgt[k]; }
         }
     }
     return sum / sumWts;
