@@ -2482,6 +2482,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         const bool split = v.handle_media && !allHomogeneous;
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
+        { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
         c->volWave = wave;
@@ -2540,7 +2541,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             // queue and k_shade_vol the second.  Not with a walk or a split vertex (volTr / volSplit: "volpath" scenes): there NeeRec carries the walk's extra words.
             bool route = c->sssWave && !v.handle_media && !c->volTr && !c->volSplit;
             { const char *e = std::getenv("PBRT_AMD_SSS_ROUTE"); if (e && e[0] == '0') route = false; }
-            { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
             if (route) {
                 // which materials k_shade_vol must see: those with a BSSRDF, and mix materials built on one -- MixMaterial evaluates m1 on *si itself (mixmat.cpp:45-64), so
                 // the mix's interaction carries m1's BSSRDF (ComputeBSSRDFD follows the m1 links); m2's is included for simplicity.  Sub-materials have smaller indices.
