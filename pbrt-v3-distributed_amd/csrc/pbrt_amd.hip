@@ -1225,7 +1225,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             ComputeDifferentials(isect.p, isect.n, &ix, rdf);
                         }
                         PROBE(14)   // (textured instances) differentials of camera rays
-                        ComputeScatteringFunctionsT(sc.materials, matU, &isect, &ix, &laneMat);
+                        ComputeScatteringFunctionsT<PT_TEX_UNIFORM != 0>(sc.materials, matU, &isect, &ix, &laneMat);   // (matU: wave-uniform inside the waterfall)
                         matPtr = &laneMat;
                         PROBE(15)   // (textured instances) the material's textures / bump map -> per-lane lobe list
                     }

@@ -183,19 +183,19 @@ PT_DEV TexCtx TexCtxOf(const Isect &si, const IsectX &x) {
     return c;
 }
 // Material::Bump core/material.cpp:46-83
-__device__ __noinline__ void BumpT(int tex, Isect *si, IsectX *x) {
+template <bool U> __device__ __noinline__ void BumpT(int tex, Isect *si, IsectX *x) {
     TexCtx ev = TexCtxOf(*si, *x);
     Float du = .5f * (absf(x->dudx) + absf(x->dudy));
     if (du == 0) du = .0005f;
     ev.p = si->p + du * si->dpdus;
     ev.u = x->u + du; ev.v = x->v + 0.f;
-    Float uDisplace = TexEval(tex, ev).r;
+    Float uDisplace = TexEval<U>(tex, ev).r;
     Float dv = .5f * (absf(x->dvdx) + absf(x->dvdy));
     if (dv == 0) dv = .0005f;
     ev.p = si->p + dv * x->dpdvs;
     ev.u = x->u + 0.f; ev.v = x->v + dv;
-    Float vDisplace = TexEval(tex, ev).r;
-    Float displace = TexEval(tex, TexCtxOf(*si, *x)).r;
+    Float vDisplace = TexEval<U>(tex, ev).r;
+    Float displace = TexEval<U>(tex, TexCtxOf(*si, *x)).r;
     V3 dpdu = si->dpdus + (uDisplace - displace) / du * si->ns + displace * x->dndus;
     V3 dpdv = x->dpdvs + (vDisplace - displace) / dv * si->ns + displace * x->dndvs;
     V3 sn = Normalize(Cross(dpdu, dpdv));   // SetShadingGeometry(..., false) core/interaction.cpp:73-92
@@ -255,29 +255,30 @@ PT_DEV void AddSpecT(mi_material *m, const RGB &t, Float etaA, Float etaB) {
     mi_bxdf *b = AddLobe(m, MI_BXDF_SPECULAR_T);
     Set3(b->T, t); b->etaA = etaA; b->etaB = etaB; b->fresnel = MI_FRESNEL_DIELECTRIC;
 }
-PT_DEV void CopyMaterial(mi_material *dst, const mi_material *src) {
-    const uint32_t *s = (const uint32_t *)src;
+template <bool U> PT_DEV void CopyMaterial(mi_material *dst, const mi_material *src) {
+    const typename UPtr<U, uint32_t>::P s = UPtr<U, uint32_t>::of(reinterpret_cast<const uint32_t *>(src));   // word 0 = n_bxdfs
     uint32_t *d = (uint32_t *)dst;
-    int words = 2 + src->n_bxdfs * (int)(sizeof(mi_bxdf) / 4);
+    int words = 2 + (int)s[0] * (int)(sizeof(mi_bxdf) / 4);
     for (int k = 0; k < words; ++k) d[k] = s[k];
 }
 
 // Material::ComputeScatteringFunctions(si, arena, TransportMode::Radiance, allowMultipleLobes = true) of material `mat`
 // into *out (n_bxdfs = 0, eta = 1 on entry).  D bounds the nesting of mix materials.
-template <int D> struct MaterialEvalD { static __device__ __noinline__ void eval(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out); };
-template <> struct MaterialEvalD<0> { static PT_DEV void eval(const mi_material *, int, Isect *, IsectX *, mi_material *) {} };
-template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out) {
-    const mi_material_desc *md = c_tex.descs + mat;
-    if (!md->textured) { CopyMaterial(out, materials + mat); return; }
+template <int D, bool U> struct MaterialEvalD { static __device__ __noinline__ void eval(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out); };
+template <bool U> struct MaterialEvalD<0, U> { static PT_DEV void eval(const mi_material *, int, Isect *, IsectX *, mi_material *) {} };
+template <int D, bool U> __device__ __noinline__ void MaterialEvalD<D, U>::eval(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out) {
+    mat = UIdx<U>(mat);
+    const typename UPtr<U, mi_material_desc>::P md = UPtr<U, mi_material_desc>::of(c_tex.descs + mat);
+    if (!md->textured) { CopyMaterial<U>(out, materials + mat); return; }
     if (md->type == MI_MAT_MIX) {   // mixmat.cpp:45-64
-        RGB s1 = ClampRGB(TexEval(md->amount, TexCtxOf(*si, *x)));
+        RGB s1 = ClampRGB(TexEval<U>(md->amount, TexCtxOf(*si, *x)));
         RGB s2 = ClampRGB(RGB(1.f) - s1);
         Isect si2 = *si;
         IsectX x2 = *x;
         mi_material l2;
         l2.n_bxdfs = 0; l2.eta = 1;
-        MaterialEvalD<D - 1>::eval(materials, md->m1, si, x, out);
-        MaterialEvalD<D - 1>::eval(materials, md->m2, &si2, &x2, &l2);
+        MaterialEvalD<D - 1, U>::eval(materials, md->m1, si, x, out);
+        MaterialEvalD<D - 1, U>::eval(materials, md->m2, &si2, &x2, &l2);
         for (int i = 0; i < out->n_bxdfs; ++i) {
             mi_bxdf *b = &out->bxdfs[i];
             if (b->scaled) { b->scale[0] = s1.r * b->scale[0]; b->scale[1] = s1.g * b->scale[1]; b->scale[2] = s1.b * b->scale[2]; }
@@ -291,13 +292,13 @@ template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_ma
         }
         return;
     }
-    if (md->bump >= 0) BumpT(md->bump, si, x);
+    if (md->bump >= 0) BumpT<U>(md->bump, si, x);
     const TexCtx tc = TexCtxOf(*si, *x);
     const bool remap = md->remap_roughness != 0;
     switch (md->type) {
     case MI_MAT_MATTE: {   // matte.cpp:45-62
-        RGB r = ClampRGB(TexEval(md->Kd, tc));
-        Float sig = clampf(TexEval(md->sigma, tc).r, 0, 90);
+        RGB r = ClampRGB(TexEval<U>(md->Kd, tc));
+        Float sig = clampf(TexEval<U>(md->sigma, tc).r, 0, 90);
         if (!r.IsBlack()) {
             if (sig == 0) Set3(AddLobe(out, MI_BXDF_LAMBERT_R)->R, r);
             else {   // OrenNayar ctor reflection.h:414-420
@@ -312,19 +313,19 @@ template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_ma
         break;
     }
     case MI_MAT_PLASTIC: {   // plastic.cpp:45-70
-        RGB kd = ClampRGB(TexEval(md->Kd, tc));
+        RGB kd = ClampRGB(TexEval<U>(md->Kd, tc));
         if (!kd.IsBlack()) Set3(AddLobe(out, MI_BXDF_LAMBERT_R)->R, kd);
-        RGB ks = ClampRGB(TexEval(md->Ks, tc));
+        RGB ks = ClampRGB(TexEval<U>(md->Ks, tc));
         if (!ks.IsBlack()) {
-            Float rough = TexEval(md->roughness, tc).r;
+            Float rough = TexEval<U>(md->roughness, tc).r;
             if (remap) rough = RoughnessToAlphaT(rough);
             AddMicroR(out, ks, rough, rough, MI_FRESNEL_DIELECTRIC, 1.5f, 1.f);
         }
         break;
     }
     case MI_MAT_GLASS: {   // glass.cpp:45-92
-        Float eta = TexEval(md->eta_f, tc).r, urough = TexEval(md->uroughness, tc).r, vrough = TexEval(md->vroughness, tc).r;
-        RGB R = ClampRGB(TexEval(md->Kr, tc)), T = ClampRGB(TexEval(md->Kt, tc));
+        Float eta = TexEval<U>(md->eta_f, tc).r, urough = TexEval<U>(md->uroughness, tc).r, vrough = TexEval<U>(md->vroughness, tc).r;
+        RGB R = ClampRGB(TexEval<U>(md->Kr, tc)), T = ClampRGB(TexEval<U>(md->Kt, tc));
         out->eta = eta;
         if (R.IsBlack() && T.IsBlack()) break;
         if (urough == 0 && vrough == 0) {
@@ -338,44 +339,44 @@ template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_ma
         break;
     }
     case MI_MAT_MIRROR: {   // mirror.cpp:45-56
-        RGB R = ClampRGB(TexEval(md->Kr, tc));
+        RGB R = ClampRGB(TexEval<U>(md->Kr, tc));
         if (!R.IsBlack()) AddSpecR(out, R, MI_FRESNEL_NOOP, 1, 1);
         break;
     }
     case MI_MAT_METAL: {   // metal.cpp:59-80
-        Float uRough = md->uroughness >= 0 ? TexEval(md->uroughness, tc).r : TexEval(md->roughness, tc).r;
-        Float vRough = md->vroughness >= 0 ? TexEval(md->vroughness, tc).r : TexEval(md->roughness, tc).r;
+        Float uRough = md->uroughness >= 0 ? TexEval<U>(md->uroughness, tc).r : TexEval<U>(md->roughness, tc).r;
+        Float vRough = md->vroughness >= 0 ? TexEval<U>(md->vroughness, tc).r : TexEval<U>(md->roughness, tc).r;
         if (remap) { uRough = RoughnessToAlphaT(uRough); vRough = RoughnessToAlphaT(vRough); }
-        RGB eta = TexEval(md->eta_s, tc), k = TexEval(md->k_s, tc);
+        RGB eta = TexEval<U>(md->eta_s, tc), k = TexEval<U>(md->k_s, tc);
         AddMicroR(out, RGB(1.f), uRough, vRough, MI_FRESNEL_CONDUCTOR, 1.f, 1.f);
         mi_bxdf *b = &out->bxdfs[out->n_bxdfs - 1];
         Set3(b->eta_c, eta); Set3(b->k_c, k);
         break;
     }
     case MI_MAT_UBER: {   // uber.cpp:45-101
-        Float e = TexEval(md->eta_f, tc).r;
-        RGB op = ClampRGB(TexEval(md->opacity, tc));
+        Float e = TexEval<U>(md->eta_f, tc).r;
+        RGB op = ClampRGB(TexEval<U>(md->opacity, tc));
         RGB t = ClampRGB(RGB(0.f) - op + RGB(1.f));
         if (!t.IsBlack()) { out->eta = 1.f; AddSpecT(out, t, 1.f, 1.f); }
         else out->eta = e;
-        RGB kd = op * ClampRGB(TexEval(md->Kd, tc));
+        RGB kd = op * ClampRGB(TexEval<U>(md->Kd, tc));
         if (!kd.IsBlack()) Set3(AddLobe(out, MI_BXDF_LAMBERT_R)->R, kd);
-        RGB ks = op * ClampRGB(TexEval(md->Ks, tc));
+        RGB ks = op * ClampRGB(TexEval<U>(md->Ks, tc));
         if (!ks.IsBlack()) {
-            Float roughu = md->uroughness >= 0 ? TexEval(md->uroughness, tc).r : TexEval(md->roughness, tc).r;
-            Float roughv = md->vroughness >= 0 ? TexEval(md->vroughness, tc).r : roughu;
+            Float roughu = md->uroughness >= 0 ? TexEval<U>(md->uroughness, tc).r : TexEval<U>(md->roughness, tc).r;
+            Float roughv = md->vroughness >= 0 ? TexEval<U>(md->vroughness, tc).r : roughu;
             if (remap) { roughu = RoughnessToAlphaT(roughu); roughv = RoughnessToAlphaT(roughv); }
             AddMicroR(out, ks, roughu, roughv, MI_FRESNEL_DIELECTRIC, 1.f, e);
         }
-        RGB kr = op * ClampRGB(TexEval(md->Kr, tc));
+        RGB kr = op * ClampRGB(TexEval<U>(md->Kr, tc));
         if (!kr.IsBlack()) AddSpecR(out, kr, MI_FRESNEL_DIELECTRIC, 1.f, e);
-        RGB kt = op * ClampRGB(TexEval(md->Kt, tc));
+        RGB kt = op * ClampRGB(TexEval<U>(md->Kt, tc));
         if (!kt.IsBlack()) AddSpecT(out, kt, 1.f, e);
         break;
     }
     case MI_MAT_SUBSTRATE: {   // substrate.cpp:45-65
-        RGB dd = ClampRGB(TexEval(md->Kd, tc)), ss = ClampRGB(TexEval(md->Ks, tc));
-        Float roughu = TexEval(md->uroughness, tc).r, roughv = TexEval(md->vroughness, tc).r;
+        RGB dd = ClampRGB(TexEval<U>(md->Kd, tc)), ss = ClampRGB(TexEval<U>(md->Ks, tc));
+        Float roughu = TexEval<U>(md->uroughness, tc).r, roughv = TexEval<U>(md->vroughness, tc).r;
         if (!dd.IsBlack() || !ss.IsBlack()) {
             if (remap) { roughu = RoughnessToAlphaT(roughu); roughv = RoughnessToAlphaT(roughv); }
             mi_bxdf *b = AddLobe(out, MI_BXDF_FRESNEL_BLEND);
@@ -386,16 +387,16 @@ template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_ma
     case MI_MAT_TRANSLUCENT: {   // translucent.cpp:45-80
         const Float eta = 1.5f;
         out->eta = eta;
-        RGB r = ClampRGB(TexEval(md->reflect, tc)), t = ClampRGB(TexEval(md->transmit, tc));
+        RGB r = ClampRGB(TexEval<U>(md->reflect, tc)), t = ClampRGB(TexEval<U>(md->transmit, tc));
         if (r.IsBlack() && t.IsBlack()) break;
-        RGB kd = ClampRGB(TexEval(md->Kd, tc));
+        RGB kd = ClampRGB(TexEval<U>(md->Kd, tc));
         if (!kd.IsBlack()) {
             if (!r.IsBlack()) Set3(AddLobe(out, MI_BXDF_LAMBERT_R)->R, r * kd);
             if (!t.IsBlack()) Set3(AddLobe(out, MI_BXDF_LAMBERT_T)->T, t * kd);
         }
-        RGB ks = ClampRGB(TexEval(md->Ks, tc));
+        RGB ks = ClampRGB(TexEval<U>(md->Ks, tc));
         if (!ks.IsBlack() && (!r.IsBlack() || !t.IsBlack())) {
-            Float rough = TexEval(md->roughness, tc).r;
+            Float rough = TexEval<U>(md->roughness, tc).r;
             if (remap) rough = RoughnessToAlphaT(rough);
             if (!r.IsBlack()) AddMicroR(out, r * ks, rough, rough, MI_FRESNEL_DIELECTRIC, 1.f, eta);
             if (!t.IsBlack()) AddMicroT(out, t * ks, rough, rough, 1.f, eta);
@@ -405,9 +406,10 @@ template <int D> __device__ __noinline__ void MaterialEvalD<D>::eval(const mi_ma
     }
 }
 #define PT_MIX_MAX_DEPTH 3
-PT_DEV void ComputeScatteringFunctionsT(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out) {
+// U: `mat` is the same in every active lane (k_shade's material waterfall; see UPtr in pt_texture.h)
+template <bool U = false> PT_DEV void ComputeScatteringFunctionsT(const mi_material *materials, int mat, Isect *si, IsectX *x, mi_material *out) {
     out->n_bxdfs = 0; out->eta = 1;
-    MaterialEvalD<PT_MIX_MAX_DEPTH>::eval(materials, mat, si, x, out);
+    MaterialEvalD<PT_MIX_MAX_DEPTH, U>::eval(materials, mat, si, x, out);
 }
 
 // ------------------------------------------------------------------ two-level instancing, shading side

@@ -36,6 +36,23 @@ struct TexCtx {   // what textures read of a SurfaceInteraction
 };
 struct V2 { Float x, y; };
 
+// Wave-uniform evaluation (U = true; round 4, measured in round 5: PT_TEX_UNIFORM).  k_shade<..., TEX> runs the material code once per distinct material of a wave
+// (waterfall loop), so inside it every active lane evaluates the SAME material, hence the same texture nodes, programs and images -- only the interaction differs
+// per lane.  The out-of-line routines below receive their node / image as ordinary (vector-register) arguments, which made every field of a node a 64-lane gather of one
+// address.  With U they take the argument from the first active lane and read the tables through the CONSTANT address space: scalar loads, scalar branches.
+// U = false: per-lane nodes (alpha masks inside the traversal, k_shade_vol's per-lane materials, mi_texture_eval).
+#ifndef PT_TEX_UNIFORM
+#define PT_TEX_UNIFORM 0
+#endif
+template <bool U, class T> struct UPtr { typedef const T *P; static PT_DEV P of(const T *p) { return p; } };
+template <class T> struct UPtr<true, T> {
+    typedef const __attribute__((address_space(4))) T *P;
+    static PT_DEV P of(const T *p) { return (P)(unsigned long long)UniformPtr(p); }
+};
+template <bool U> PT_DEV int UIdx(int i) { if constexpr (U) return UniformInt(i); else return i; }
+template <class A> PT_DEV RGB Rgb3P(A a) { return RGB(a[0], a[1], a[2]); }
+template <class A> PT_DEV V3 V3P(A a) { return V3(a[0], a[1], a[2]); }
+
 PT_DEV Float Log2T(Float x) { const Float invLog2 = 1.442695040888963387004650940071f; return logf_(x) * invLog2; }   // core/pbrt.h:324-327
 PT_DEV int ModT(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }                                 // core/pbrt.h:310-313
 
@@ -103,7 +120,7 @@ __device__ __noinline__ Float FBmT(const V3 p, const V3 dpdx, const V3 dpdy, Flo
 }
 
 // ---- texture mappings (core/texture.cpp:84-153)
-PT_DEV V3 XfPointT(const float *m, const V3 &p) {   // core/transform.h:223-234
+template <class M> PT_DEV V3 XfPointT(M m, const V3 &p) {   // core/transform.h:223-234
     Float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
     Float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
     Float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
@@ -112,23 +129,24 @@ PT_DEV V3 XfPointT(const float *m, const V3 &p) {   // core/transform.h:223-234
     Float inv = (Float)1 / wp;
     return V3(inv * xp, inv * yp, inv * zp);
 }
-PT_DEV V3 XfVectorT(const float *m, const V3 &v) {   // core/transform.h:236-242
+template <class M> PT_DEV V3 XfVectorT(M m, const V3 &v) {   // core/transform.h:236-242
     return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-PT_DEV V2 SphereST(const mi_texture *t, const V3 &P) {   // SphericalMapping2D::sphere :117-121
+template <class TP> PT_DEV V2 SphereST(TP t, const V3 &P) {   // SphericalMapping2D::sphere :117-121
     V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
     Float theta = acosf_(clampf(vec.z, -1, 1));
     Float phi = atan2f_(vec.y, vec.x);
     phi = (phi < 0) ? (phi + 2 * PT_PI) : phi;
     return V2{theta * PT_INV_PI, phi * 0.15915494309189533577f};
 }
-PT_DEV V2 CylinderST(const mi_texture *t, const V3 &P) {   // CylindricalMapping2D::cylinder texture.h:93-96
+template <class TP> PT_DEV V2 CylinderST(TP t, const V3 &P) {   // CylindricalMapping2D::cylinder texture.h:93-96
     V3 vec = Normalize(XfPointT(t->w2t, P) - V3(0, 0, 0));
     return V2{(PT_PI + atan2f_(vec.y, vec.x)) * 0.15915494309189533577f, vec.z};
 }
 PT_DEV V2 DivV2(const V2 &a, const V2 &b, Float f) { Float inv = (Float)1 / f; return V2{(a.x - b.x) * inv, (a.y - b.y) * inv}; }
 struct Map2DOut { V2 st, dstdx, dstdy; };
-__device__ __noinline__ Map2DOut Map2D(const mi_texture *t, const TexCtx si) {
+template <bool U> __device__ __noinline__ Map2DOut Map2D(const mi_texture *tp, const TexCtx si) {
+    const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(tp);
     Map2DOut o;
     switch (t->mapping) {
     case MI_MAP_SPHERICAL: {   // texture.cpp:96-115
@@ -150,7 +168,7 @@ __device__ __noinline__ Map2DOut Map2D(const mi_texture *t, const TexCtx si) {
         break;
     }
     case MI_MAP_PLANAR: {   // texture.cpp:142-148
-        V3 vs = v3(t->vs), vt = v3(t->vt);
+        V3 vs = V3P(t->vs), vt = V3P(t->vt);
         o.dstdx = V2{Dot(si.dpdx, vs), Dot(si.dpdx, vt)};
         o.dstdy = V2{Dot(si.dpdy, vs), Dot(si.dpdy, vt)};
         o.st = V2{t->du + Dot(si.p, vs), t->dv + Dot(si.p, vt)};
@@ -166,9 +184,9 @@ __device__ __noinline__ Map2DOut Map2D(const mi_texture *t, const TexCtx si) {
 }
 
 // ---- MIPMap<T> (core/mipmap.h:201-353)
-PT_DEV int LevW(const DevImage *im, int l) { int w = im->width >> l; return w < 1 ? 1 : w; }
-PT_DEV int LevH(const DevImage *im, int l) { int h = im->height >> l; return h < 1 ? 1 : h; }
-PT_DEV RGB MipTexel(const DevImage *im, int level, int s, int t) {   // :201-221
+template <class IP> PT_DEV int LevW(IP im, int l) { int w = im->width >> l; return w < 1 ? 1 : w; }
+template <class IP> PT_DEV int LevH(IP im, int l) { int h = im->height >> l; return h < 1 ? 1 : h; }
+template <class IP> PT_DEV RGB MipTexel(IP im, int level, int s, int t) {   // :201-221
     int w = LevW(im, level), h = LevH(im, level);
     if (im->wrap == 0) { s = ModT(s, w); t = ModT(t, h); }
     else if (im->wrap == 2) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
@@ -176,7 +194,8 @@ PT_DEV RGB MipTexel(const DevImage *im, int level, int s, int t) {   // :201-221
     const float *px = im->texels + im->level_off[level] + ((size_t)t * w + s) * im->channels;
     return im->channels == 1 ? RGB(px[0]) : RGB(px[0], px[1], px[2]);
 }
-__device__ __noinline__ RGB MipTriangle(const DevImage *im, int level, Float s_, Float t_) {   // :263-275
+template <bool U> __device__ __noinline__ RGB MipTriangle(const DevImage *imp, int level, Float s_, Float t_) {   // :263-275
+    const typename UPtr<U, DevImage>::P im = UPtr<U, DevImage>::of(imp);
     level = level < 0 ? 0 : (level > im->levels - 1 ? im->levels - 1 : level);
     Float s = s_ * LevW(im, level) - 0.5f, t = t_ * LevH(im, level) - 0.5f;
     int s0 = (int)__builtin_floorf(s), t0 = (int)__builtin_floorf(t);
@@ -184,7 +203,8 @@ __device__ __noinline__ RGB MipTriangle(const DevImage *im, int level, Float s_,
     RGB a = MipTexel(im, level, s0, t0), b = MipTexel(im, level, s0, t0 + 1), c = MipTexel(im, level, s0 + 1, t0), d = MipTexel(im, level, s0 + 1, t0 + 1);
     return ((1 - ds) * (1 - dt)) * a + ((1 - ds) * dt) * b + (ds * (1 - dt)) * c + (ds * dt) * d;
 }
-__device__ __noinline__ RGB MipEWA(const DevImage *im, int level, V2 st, V2 dst0, V2 dst1) {   // :309-353
+template <bool U> __device__ __noinline__ RGB MipEWA(const DevImage *imp, int level, V2 st, V2 dst0, V2 dst1) {   // :309-353
+    const typename UPtr<U, DevImage>::P im = UPtr<U, DevImage>::of(imp);
     if (level >= im->levels) return MipTexel(im, im->levels - 1, 0, 0);
     int w = LevW(im, level), h = LevH(im, level);
     st.x = st.x * w - 0.5f; st.y = st.y * h - 0.5f;
@@ -217,15 +237,16 @@ __device__ __noinline__ RGB MipEWA(const DevImage *im, int level, V2 st, V2 dst0
     }
     return sum / sumWts;
 }
-__device__ __noinline__ RGB MipLookup(const DevImage *im, V2 st, V2 dst0, V2 dst1) {   // :277-307 (and :223-241 for the trilinear case)
+template <bool U> __device__ __noinline__ RGB MipLookup(const DevImage *imp, V2 st, V2 dst0, V2 dst1) {   // :277-307 (and :223-241 for the trilinear case)
+    const typename UPtr<U, DevImage>::P im = UPtr<U, DevImage>::of(imp);
     if (im->trilinear) {
         Float width = 2 * mx(mx(absf(dst0.x), absf(dst0.y)), mx(absf(dst1.x), absf(dst1.y)));
         Float level = im->levels - 1 + Log2T(mx(width, (Float)1e-8));
-        if (level < 0) return MipTriangle(im, 0, st.x, st.y);
+        if (level < 0) return MipTriangle<U>(imp, 0, st.x, st.y);
         else if (level >= im->levels - 1) return MipTexel(im, im->levels - 1, 0, 0);
         int iLevel = (int)__builtin_floorf(level);
         Float delta = level - iLevel;
-        return (1 - delta) * MipTriangle(im, iLevel, st.x, st.y) + delta * MipTriangle(im, iLevel + 1, st.x, st.y);
+        return (1 - delta) * MipTriangle<U>(imp, iLevel, st.x, st.y) + delta * MipTriangle<U>(imp, iLevel + 1, st.x, st.y);
     }
     if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
     Float majorLength = sqrtf_(dst0.x * dst0.x + dst0.y * dst0.y);
@@ -235,11 +256,11 @@ __device__ __noinline__ RGB MipLookup(const DevImage *im, V2 st, V2 dst0, V2 dst
         dst1.x *= scale; dst1.y *= scale;
         minorLength *= scale;
     }
-    if (minorLength == 0) return MipTriangle(im, 0, st.x, st.y);
+    if (minorLength == 0) return MipTriangle<U>(imp, 0, st.x, st.y);
     Float lod = mx((Float)0, im->levels - (Float)1 + Log2T(minorLength));
     int ilod = (int)__builtin_floorf(lod);
     Float d = lod - ilod;
-    return (1 - d) * MipEWA(im, ilod, st, dst0, dst1) + d * MipEWA(im, ilod + 1, st, dst0, dst1);
+    return (1 - d) * MipEWA<U>(imp, ilod, st, dst0, dst1) + d * MipEWA<U>(imp, ilod + 1, st, dst0, dst1);
 }
 
 // ---- Texture<T>::Evaluate.  The node graph below a texture (scale / mix / checkerboard / dots refer to child textures)
@@ -250,26 +271,27 @@ __device__ __noinline__ RGB MipLookup(const DevImage *im, V2 st, V2 dst0, V2 dst
 // (A recursive formulation kept every level's live state in registers across the calls: 280 VGPRs at depth 6, one
 // wave per SIMD in the shading kernel; the flat loop needs what one node needs.)
 #define PT_TEX_MAX_PROG 24
-__device__ __noinline__ RGB EvalNode(const mi_texture *t, const RGB t1v, const RGB t2v, const RGB amtv, const TexCtx si) {
+template <bool U> __device__ __noinline__ RGB EvalNode(const mi_texture *tp, const RGB t1v, const RGB t2v, const RGB amtv, const TexCtx si) {
+    const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(tp);
     switch (t->type) {
-    case MI_TEX_CONSTANT: return rgb3(t->value);                     // constant.h:54
+    case MI_TEX_CONSTANT: return Rgb3P(t->value);                     // constant.h:54
     case MI_TEX_SCALE: return t1v * t2v;                             // scale.h:57-59
     case MI_TEX_MIX: {                                               // mix.h:58-62
         Float amt = amtv.r;
         return (1 - amt) * t1v + amt * t2v;
     }
     case MI_TEX_BILERP: {                                            // bilerp.h:57-62
-        Map2DOut m = Map2D(t, si);
+        Map2DOut m = Map2D<U>(tp, si);
         Float s = m.st.x, tt = m.st.y;
-        return ((1 - s) * (1 - tt)) * rgb3(t->v00) + ((1 - s) * (tt)) * rgb3(t->v01) + ((s) * (1 - tt)) * rgb3(t->v10) + ((s) * (tt)) * rgb3(t->v11);
+        return ((1 - s) * (1 - tt)) * Rgb3P(t->v00) + ((1 - s) * (tt)) * Rgb3P(t->v01) + ((s) * (1 - tt)) * Rgb3P(t->v10) + ((s) * (tt)) * Rgb3P(t->v11);
     }
     case MI_TEX_IMAGEMAP: {                                          // imagemap.h:87-94
-        Map2DOut m = Map2D(t, si);
+        Map2DOut m = Map2D<U>(tp, si);
         if (t->image < 0 || (uint32_t)t->image >= c_tex.n_images) return RGB(0.f);
-        return MipLookup(c_tex.images + t->image, m.st, m.dstdx, m.dstdy);
+        return MipLookup<U>(c_tex.images + t->image, m.st, m.dstdx, m.dstdy);
     }
     case MI_TEX_UV: {                                                // uv.h:54-60
-        Map2DOut m = Map2D(t, si);
+        Map2DOut m = Map2D<U>(tp, si);
         return RGB(m.st.x - __builtin_floorf(m.st.x), m.st.y - __builtin_floorf(m.st.y), 0);
     }
     case MI_TEX_CHECKERBOARD: {
@@ -277,7 +299,7 @@ __device__ __noinline__ RGB EvalNode(const mi_texture *t, const RGB t1v, const R
             V3 p = XfPointT(t->w2t, si.p);
             return (((int)__builtin_floorf(p.x) + (int)__builtin_floorf(p.y) + (int)__builtin_floorf(p.z)) % 2 == 0) ? t1v : t2v;
         }
-        Map2DOut m = Map2D(t, si);                                   // checkerboard.h:63-99
+        Map2DOut m = Map2D<U>(tp, si);                                   // checkerboard.h:63-99
         bool even = (((int)__builtin_floorf(m.st.x) + (int)__builtin_floorf(m.st.y)) % 2 == 0);
         if (t->aa == 0) return even ? t1v : t2v;
         Float ds = mx(absf(m.dstdx.x), absf(m.dstdy.x));
@@ -293,7 +315,7 @@ __device__ __noinline__ RGB EvalNode(const mi_texture *t, const RGB t1v, const R
         return (1 - area2) * t1v + area2 * t2v;
     }
     case MI_TEX_DOTS: {                                              // dots.h:59-80 (tex1 = outsideDot, tex2 = insideDot)
-        Map2DOut m = Map2D(t, si);
+        Map2DOut m = Map2D<U>(tp, si);
         int sCell = (int)__builtin_floorf(m.st.x + .5f), tCell = (int)__builtin_floorf(m.st.y + .5f);
         if (Noise3(sCell + .5f, tCell + .5f, .5f) > 0) {
             Float radius = .35f;
@@ -337,14 +359,24 @@ __device__ __noinline__ RGB EvalNode(const mi_texture *t, const RGB t1v, const R
     }
     return RGB(0.f);
 }
-__device__ __noinline__ RGB TexEval(int node, const TexCtx si) {
+template <bool U = false> __device__ __noinline__ RGB TexEval(int node, const TexCtx si) {
+    node = UIdx<U>(node);
     if (node < 0 || (uint32_t)node >= c_tex.n_nodes) return RGB(0.f);
-    const int off = c_tex.prog_off[node], len = c_tex.prog_off[node + 1] - off;
-    if (len == 1) return EvalNode(c_tex.nodes + node, RGB(0.f), RGB(0.f), RGB(0.f), si);   // a leaf (the common case: constants, image maps)
+    const typename UPtr<U, int32_t>::P progOff = UPtr<U, int32_t>::of(c_tex.prog_off);
+    const int off = progOff[node], len = progOff[node + 1] - off;
+    if (len == 1) return EvalNode<U>(c_tex.nodes + node, RGB(0.f), RGB(0.f), RGB(0.f), si);   // a leaf (the common case: constants, image maps)
     RGB val[PT_TEX_MAX_PROG];
-    for (int k = 0; k < len; ++k) {
-        const int4 st = c_tex.prog[off + k];
-        val[k] = EvalNode(c_tex.nodes + st.x, st.y >= 0 ? val[st.y] : RGB(0.f), st.z >= 0 ? val[st.z] : RGB(0.f), st.w >= 0 ? val[st.w] : RGB(0.f), si);
+    if constexpr (U) {
+        const typename UPtr<U, int32_t>::P prog = UPtr<U, int32_t>::of(reinterpret_cast<const int32_t *>(c_tex.prog));   // int4 steps, read word by word (scalar loads)
+        for (int k = 0; k < len; ++k) {
+            const int sx = prog[4 * (off + k)], sy = prog[4 * (off + k) + 1], sz = prog[4 * (off + k) + 2], sw = prog[4 * (off + k) + 3];
+            val[k] = EvalNode<U>(c_tex.nodes + sx, sy >= 0 ? val[sy] : RGB(0.f), sz >= 0 ? val[sz] : RGB(0.f), sw >= 0 ? val[sw] : RGB(0.f), si);
+        }
+    } else {
+        for (int k = 0; k < len; ++k) {
+            const int4 st = c_tex.prog[off + k];
+            val[k] = EvalNode<U>(c_tex.nodes + st.x, st.y >= 0 ? val[st.y] : RGB(0.f), st.z >= 0 ? val[st.z] : RGB(0.f), st.w >= 0 ? val[st.w] : RGB(0.f), si);
+        }
     }
     return val[len - 1];
 }
