@@ -99,6 +99,9 @@ struct PathState {
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
     // Scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials (mi_ctx::sssRoute): the material sort puts those materials' keys LAST
     // (key_remap, applied by k_keycount) and the sorted queue is shaded in two launches -- k_shade takes the keys below shade_split, k_shade_vol the rest.
+    float4 *sss_log_o, *sss_log_d;   // k_sss_probe_tail's lists of counted hits (SssLog, pt_volpath.h): sss_log_cap entries per thread for the first sss_log_threads threads of the launch; null: off
+    uint32_t *sss_log_inst;
+    uint32_t sss_log_threads, sss_log_cap;
     const uint32_t *key_remap;   // [nkeys] or null
     uint32_t shade_split;        // first key of the second part
     uint32_t shade_part;         // 0: the whole queue; 1: keys < shade_split; 2: keys >= shade_split
@@ -1602,6 +1605,7 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 131072;               // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+    bool sssLog = true;                      // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (PBRT_AMD_SSS_LOG=0: as before)
     bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
@@ -2483,6 +2487,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
         { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
+        { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = !(e && e[0] == '0'); }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
         c->volWave = wave;
@@ -2601,7 +2606,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->cap >= cap && !c->stateBufs.empty()) return 0;
     for (auto &b : c->stateBufs) b.release();
     c->stateBufs.clear();
-    c->stateBufs.resize(40);
+    c->stateBufs.resize(48);
     int nb = 0;
     PathState &ps = c->ps;
     std::memset(&ps, 0, sizeof(ps));
@@ -2619,6 +2624,11 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->volTr || c->sssWave) { ALLOC(trs, TrState, cap); ALLOC(q_tr[0], uint32_t, qcap); ALLOC(q_tr[1], uint32_t, qcap); }
     if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_probe[0], uint32_t, qcap); ALLOC(q_probe[1], uint32_t, qcap); }
     if (c->sssWave) ALLOC(q_sss, uint32_t, qcap);
+    if (c->sssWave && c->sssTail && c->sssLog) {   // one list per thread the tail launch can occupy when its queue is spread evenly over the eight segments (threads beyond walk twice)
+        const uint32_t threads = std::min<uint32_t>(c->sssTail, cap) + 8 * PT_BLOCK, lcap = 256;
+        ALLOC(sss_log_o, float4, (size_t)threads * lcap); ALLOC(sss_log_d, float4, (size_t)threads * lcap); ALLOC(sss_log_inst, uint32_t, (size_t)threads * lcap);
+        ps.sss_log_threads = threads; ps.sss_log_cap = lcap;
+    }
     if (c->volSplit) ALLOC(q_cont, uint32_t, qcap);
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);

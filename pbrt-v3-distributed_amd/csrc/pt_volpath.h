@@ -900,8 +900,16 @@ __global__ void __launch_bounds__(PT_BLOCK) k_vol_tr_step(const DevScene *scp, P
 // carries the BSSRDF's material object (bssrdf.cpp:302), at the end of the first walk choose (bssrdf.cpp:311-314) and start the second; the second
 // walk ends at the chosen hit -> QC_SSS for k_sss_entry.  A chain without such a hit ends the path (path.cpp:160: S.IsBlack()).
 // One probe-walk step of ONE path (the body of a round): *again = the chain goes on with the segment now in NeeRec::sh_o / sh_d, *done = pi is chosen (QC_SSS)
+// The tail kernel's own list of the counted hits of a first walk (k_sss_probe_tail): entry k = the (first + k)-th counted hit, in the format of SssRec::keep_*.  With it the
+// chain of a long probe ray is walked ONCE, as the reference walks it (bssrdf.cpp:285-314 keeps every hit in a list and steps to the chosen one): without, the walk is
+// repeated up to the chosen hit, on average half its length again -- and the tail launch lasts as long as its longest chain.
+struct SssLog {
+    float4 *o, *d;      // segment origin | primitive (bits), segment direction | its medium (bits)
+    uint32_t *inst;
+    uint32_t first, cap;
+};
 template <bool INST>
-PT_DEV void SssProbeStepOne(const DevScene *scp, const PathState &ps, const DevVol &vol, uint32_t slot, bool first, bool *againOut, bool *doneOut) {
+PT_DEV void SssProbeStepOne(const DevScene *scp, const PathState &ps, const DevVol &vol, uint32_t slot, bool first, bool *againOut, bool *doneOut, const SssLog *lg = nullptr) {
     bool again = false, done = false;
     SssRec *S = &ps.sss[slot];
     const float4 bs4 = S->base_seen, tg4 = S->target_sel;
@@ -932,6 +940,12 @@ PT_DEV void SssProbeStepOne(const DevScene *scp, const PathState &ps, const DevV
                         S->keep_d[seen] = d4;
                         S->keep_inst[seen] = hit.z;
                     }
+                    if (lg && pass == 0 && seen >= lg->first && seen - lg->first < lg->cap) {
+                        const uint32_t k = seen - lg->first;
+                        lg->o[k] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(hit.x));
+                        lg->d[k] = d4;
+                        lg->inst[k] = hit.z;
+                    }
                     ++seen;
                 }
             }
@@ -948,6 +962,13 @@ PT_DEV void SssProbeStepOne(const DevScene *scp, const PathState &ps, const DevV
             if (selected < PT_SSS_KEEP) {   // the chosen hit is one of the kept ones
                 const float4 ko = S->keep_o[selected], kd = S->keep_d[selected];
                 S->nz_pi = make_float4(0, ko.w, __uint_as_float(S->keep_inst[selected]), kd.w);
+                S->pi_o = ko; S->pi_d = kd;
+                S->rho_found.w = __uint_as_float(nFound);
+                done = true;
+            } else if (lg && selected >= lg->first && selected - lg->first < lg->cap) {   // ... or one the tail kernel listed
+                const uint32_t k = selected - lg->first;
+                const float4 ko = lg->o[k], kd = lg->d[k];
+                S->nz_pi = make_float4(0, ko.w, __uint_as_float(lg->inst[k]), kd.w);
                 S->pi_o = ko; S->pi_d = kd;
                 S->rho_found.w = __uint_as_float(nFound);
                 done = true;
@@ -1006,12 +1027,25 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_tail(const DevScene *scp
         uint32_t slot = 0;
         if (active) {
             slot = qIn[it.item()];
+            // this lane's list of counted hits (PathState::sss_log_*: one slice per thread of the launch, null beyond the slices or with PBRT_AMD_SSS_LOG=0), from the
+            // hit count the chain arrives with; a chain that arrives in its second walk has no use for one
+            SssLog lg;
+            const SssLog *lgp = nullptr;
+            const uint32_t thread = blockIdx.x * PT_BLOCK + threadIdx.x;
+            if (ps.sss_log_o && thread < ps.sss_log_threads) {
+                const uint32_t seenBits = __float_as_uint(ps.sss[slot].base_seen.w);
+                if ((seenBits >> 31) == 0) {
+                    lg.o = ps.sss_log_o + (size_t)thread * ps.sss_log_cap; lg.d = ps.sss_log_d + (size_t)thread * ps.sss_log_cap; lg.inst = ps.sss_log_inst + (size_t)thread * ps.sss_log_cap;
+                    lg.first = seenBits & 0x7fffffffu; lg.cap = ps.sss_log_cap;
+                    lgp = &lg;
+                }
+            }
             bool again = true;
             for (uint32_t seg = 0; again && seg < 16384u; ++seg) {   // (the host's own bound on the rounds of a walk)
                 const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
                 const LaneHit h = TraceLane<false, INST>(&lt, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w);
                 ps.trs[slot].hit[0] = make_uint4(h.prim, __float_as_uint(h.t), h.inst, 0u);
-                SssProbeStepOne<INST>(scp, ps, vol, slot, false, &again, &done);
+                SssProbeStepOne<INST>(scp, ps, vol, slot, false, &again, &done, lgp);
             }
             if (again) ++lt.guardTrips;   // a chain that did not end: reported like a traversal that did not (the host fails the render)
         }

@@ -1122,6 +1122,29 @@ def test_only_the_vertices_on_bssrdf_materials_go_to_the_volumetric_shading_kern
     print("routed vs all-vol: %.4f of the pixels bit-identical" % float((out["routed"][0].view(np.uint32) == out["all_vol"][0].view(np.uint32)).all(-1).mean()))
 
 
+def test_the_tail_of_the_probe_walk_lists_its_hits_instead_of_walking_twice(tmp_path, monkeypatch):
+    """k_sss_probe_tail keeps the counted hits of a chain's first walk in a per-thread list (SssLog) and steps to the chosen one, as the reference's linked list does
+    (bssrdf.cpp:285-314); PBRT_AMD_SSS_LOG=0 walks the chain a second time up to the chosen hit.  Same image bit for bit, fewer probe segments -- on the reduced
+    subsurface stand-in, whose quad soups give chains of tens of hits."""
+    out = {}
+    for form in ("list", "twice"):
+        if form == "twice":
+            monkeypatch.setenv("PBRT_AMD_SSS_LOG", "0")
+        else:
+            monkeypatch.delenv("PBRT_AMD_SSS_LOG", raising=False)
+        sc = _config_scene("sanmiguel_subsurface", str(tmp_path))
+        ctx = pa.Context(sc)
+        ctx.counters_reset()
+        ctx.render()
+        out[form] = (ctx.film().copy(), ctx.counters())
+        ctx.close()
+    assert np.array_equal(out["list"][0].view(np.uint32), out["twice"][0].view(np.uint32))
+    assert out["list"][1]["closest_rays"] < out["twice"][1]["closest_rays"]
+    assert out["list"][1]["trace_guard_trips"] == 0 and out["twice"][1]["trace_guard_trips"] == 0
+    for k in ("camera_rays", "shadow_rays", "path_segments"):
+        assert out["list"][1][k] == out["twice"][1][k], k
+
+
 @pytest.mark.parametrize("name", ["sanmiguel_subsurface", "sanmiguel_smokebox"])
 def test_baseline_config_reduced_with_subsurface_materials_and_with_a_grid_medium(name, tmp_path):
     """the reduced C3 stand-in with three kdsubsurface materials (bench.py --subsurface: walked probe chains) and with a heterogeneous medium behind a
