@@ -99,6 +99,8 @@ struct PathState {
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
     // Scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials (mi_ctx::sssRoute): the material sort puts those materials' keys LAST
     // (key_remap, applied by k_keycount) and the sorted queue is shaded in two launches -- k_shade takes the keys below shade_split, k_shade_vol the rest.
+    const DevScene *sc_dev;      // the DevScene / DevVol in HBM, for the out-of-line chain step of k_trace<2, ..., TR, WALK> (SssWalkStep); null otherwise
+    const struct DevVol *vol_dev;
     float4 *sss_log_o, *sss_log_d;   // k_sss_probe_tail's lists of counted hits (SssLog, pt_volpath.h): sss_log_cap entries per thread for the first sss_log_threads threads of the launch; null: off
     uint32_t *sss_log_inst;
     uint32_t sss_log_threads, sss_log_cap;
@@ -561,9 +563,15 @@ template <bool PEND, class TS> PT_DEV bool TraceDone(const TS &ts) {
 }
 // TR (MODE 1 / 2, DevVol::tr_queues): the ray is one SEGMENT of a shadow / MIS ray that is walked through BSDF-less medium interfaces -- closest hit
 // (also for shadow segments: the nearest surface decides whether the walk ends or goes on), result into TrState::hit; k_vol_tr_step does the rest
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false, bool TR = false>
+// WALK (MODE 2 + TR, the probe chains of BSSRDF materials; built in round 4, not yet measured: PBRT_AMD_SSS_WALK=1): the WHOLE chain is walked by the persistent lane -- a lane whose
+// segment has found its closest hit runs the chain step itself (SssWalkStep = SssProbeStepOne, out of line) and starts the next segment with the same path instead of handing
+// it back through a queue and a step launch; a finished chain goes to the QC_SSS queue for k_sss_entry.  One launch per bounce instead of ~15 rounds + a tail.
+// Returns 1: the chain goes on with the segment now in NeeRec::sh_o / sh_d; 2: pi is chosen; 0: the chain ended without one (the path ends, path.cpp:160)
+__device__ __noinline__ int SssWalkStep(const DevScene *scp, const DevVol *vol, SssRec *sss, TrState *trs, NeeRec *nee, uint32_t slot);
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false, bool TR = false, bool WALK = false>
 __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK), (TraceShape<MODE, SPHERES, ALPHA, QN>::WAVES)) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
+    static_assert(!WALK || (TR && MODE == 2 && !INST), "the walked chains are segments of the shadow queue; single-level scenes");
     constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
     constexpr bool PEND = QN && PT_PEND_LEAF;
@@ -604,6 +612,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     if constexpr (PEND) ts.pend = TRAV_DONE;
     TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
+    bool walkDone = false;   // WALK: this lane's chain has just arrived at its chosen hit (appended to QC_SSS after the hand-over pass)
     unsigned long long clk0 = 0, rt0 = 0;
     if (COUNT) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }   // s_memtime / s_memrealtime: the shader clock this kernel really runs at (mi_trace_clock)
     // hands a finished ray's result over (hit record + sort key / the unoccluded light term / the MIS term)
@@ -613,6 +622,16 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                 uint32_t hi = TRAV_NO_INSTANCE;
                 if constexpr (INST) hi = ts.hitInst;
                 ps.trs[slot].hit[MODE == 1 ? 1 : 0] = make_uint4(ts.prim, __float_as_uint(ts.tHit), hi, 0u);
+                if constexpr (WALK) {
+                    const int r = SssWalkStep(ps.sc_dev, ps.vol_dev, ps.sss, ps.trs, ps.nee, slot);
+                    if (r == 1) {   // the next segment of the same chain: the lane keeps its path
+                        const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
+                        ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, st);
+                        ++nrays;
+                        return;
+                    }
+                    walkDone = r == 2;
+                }
             } else if (MODE == 0) {
                 ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                 if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
@@ -672,6 +691,12 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
         // them, instead of one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the
         // same for 1 lane or 64)
         if (PT_BATCH_FINALIZE) finalize();
+        if constexpr (WALK) {   // the chains that arrived at their chosen hit -> k_sss_entry's queue (this block class's segment: a WALK launch does not steal from other segments)
+            const uint32_t qs = blockIdx.x & 7;
+            const uint32_t pos = wave_append(&ps.qcount[QCI(QC_SSS, qs)], walkDone);
+            if (walkDone) ps.q_sss[qs * ps.seg_cap + pos] = slot;
+            walkDone = false;
+        }
         unsigned long long idle = PtBallot(!active);
         int nIdle = __popcll(idle);
         if (nIdle >= TRACE_REFILL && segsTried < 8) {
@@ -683,7 +708,12 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     uint32_t segBeg = seg * segLen, segEnd;
                     if (contig) segEnd = segBeg + segLen < nContig ? segBeg + segLen : (segBeg < nContig ? nContig : segBeg);
                     else segEnd = segBeg + ps.qcount[QCI(qrow, seg)];
-                    if (segBeg + base >= segEnd) { seg = (seg + 1) & 7; ++segsTried; poolNext = poolEnd = 0; continue; }
+                    if (segBeg + base >= segEnd) {
+                        if constexpr (WALK) segsTried = 8;   // (its QC_SSS appends go to its own class's segment, which holds one entry per path of that segment)
+                        else { seg = (seg + 1) & 7; ++segsTried; }
+                        poolNext = poolEnd = 0;
+                        continue;
+                    }
                     poolNext = segBeg + base;
                     poolEnd = poolNext + TRACE_BATCH < segEnd ? poolNext + TRACE_BATCH : segEnd;
                 }
@@ -1386,6 +1416,15 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
 
 #include "pt_volpath.h"   // k_shade_vol: the shading kernel of "volpath" scenes and of scenes with BSSRDF materials
 
+__device__ __noinline__ int SssWalkStep(const DevScene *scp, const DevVol *vol, SssRec *sss, TrState *trs, NeeRec *nee, uint32_t slot) {
+    PathState ps;   // the three per-path records the step touches
+    __builtin_memset(&ps, 0, sizeof(ps));
+    ps.sss = sss; ps.trs = trs; ps.nee = nee;
+    bool again = false, done = false;
+    SssProbeStepOne<false>(scp, ps, *vol, slot, false, &again, &done);
+    return again ? 1 : (done ? 2 : 0);
+}
+
 // ---- film: the radiance guards of integrator.cpp:294-315 + FilmTile::AddSample (core/film.h:121-161).
 // One lane per owned pixel walks that pixel's samples of the pass in sample order.
 //   SPILL == false: only the lane's own pixel, as a plain running sum continued from the film value -- the
@@ -1605,6 +1644,8 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 131072;               // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
+    bool sssWalk = false;                    // the probe chains are walked inside the persistent traversal lanes (k_trace<2, ..., TR, WALK>; PBRT_AMD_SSS_WALK=1 -- built in round 4, unmeasured: off)
+    const DevVol *volDev = nullptr;          // DevVol in HBM (SssWalkStep)
     bool sssLog = true;                      // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (PBRT_AMD_SSS_LOG=0: as before)
     bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
@@ -2466,7 +2507,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
     std::memset(&c->vol, 0, sizeof(c->vol));
     c->scDev = nullptr;
-    c->sssRoute = false; c->keyRemap = nullptr; c->shadeSplit = 0;
+    c->sssRoute = false; c->keyRemap = nullptr; c->shadeSplit = 0; c->volDev = nullptr;
     if (c->volKernel) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
@@ -2488,6 +2529,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
         { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
         { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = !(e && e[0] == '0'); }
+        { const char *e = std::getenv("PBRT_AMD_SSS_WALK"); c->sssWalk = e && e[0] == '1'; }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
         c->volWave = wave;
@@ -2579,11 +2621,14 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         // sampler dimensions: ratio / delta tracking in grid media draw a data-dependent number per segment; the reference aborts past its tables
         // (sobol.cpp:48-51, halton.h:72-75) and the device clamps to the last dimension instead -- such paths are outside both samplers' range
         { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); }
+        { DevBuf &b = next(); if (upload(c, b, &c->vol, sizeof(DevVol))) return -1; c->volDev = b.as<DevVol>(); }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
 #if PT_SHADE_ARGPTR
     if (!c->scDev) { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); HIP_TRY(hipStreamSynchronize(c->stream)); }
 #endif
+    if (c->sssWalk && c->sssWave)   // (a developer switch: say what it did)
+        std::fprintf(stderr, "[pbrt_amd] PBRT_AMD_SSS_WALK=1: probe chains %s\n", c->useQ && !c->hasAlpha && !c->hasInst ? "walked inside the traversal lanes (k_trace<2, ..., TR, WALK>)" : "in rounds (two-level scene, masks or full-precision nodes: no WALK instance)");
     c->nkeys = d->n_materials + 2;
     if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
     // film
@@ -2734,6 +2779,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     TableTurn turn(c);
+    ps.sc_dev = c->scDev; ps.vol_dev = c->volDev;
     ps.key_remap = c->sssRoute ? c->keyRemap : nullptr;
     ps.shade_split = c->shadeSplit; ps.shade_part = 0;
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
@@ -2941,7 +2987,19 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c);
                 std::swap(qIn, qOut); std::swap(rowIn, rowOut);
                 tic(c, MI_K_MIS_CLOSEST);
-                for (int round = 0; round < 16384; ++round) {
+                // PBRT_AMD_SSS_WALK=1 (single-level scenes over quantised nodes without masks): ONE launch walks every chain to its end inside the persistent lanes
+                const bool walkInLanes = c->sssWalk && c->useQ && !c->hasAlpha && !c->hasInst;
+                if (walkInLanes) {
+                    HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    PathState psRun = ps;
+                    psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn;
+                    typedef TraceShape<2, true, false, true> TS_;
+                    const dim3 g_(((c->numCUs * TS_::PER_CU + 7) / 8) * 8), b_(TS_::BLOCK);
+                    if (countWork) hipLaunchKernelGGL((k_trace<2, true, true, false, false, true, true, true>), g_, b_, 0, st, sc, psRun, qin);
+                    else hipLaunchKernelGGL((k_trace<2, false, true, false, false, true, true, true>), g_, b_, 0, st, sc, psRun, qin);
+                    left = 0;
+                }
+                for (int round = 0; round < 16384 && !walkInLanes; ++round) {
                     HIP_TRY(hipMemsetAsync(ps.qcount + QCI(rowOut, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
                     HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
                     {
