@@ -1646,7 +1646,7 @@ struct mi_ctx {
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
     bool sssWalk = false;                    // the probe chains are walked inside the persistent traversal lanes (k_trace<2, ..., TR, WALK>; PBRT_AMD_SSS_WALK=1 -- built in round 4, unmeasured: off)
     const DevVol *volDev = nullptr;          // DevVol in HBM (SssWalkStep)
-    bool sssLog = true;                      // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (PBRT_AMD_SSS_LOG=0: as before)
+    bool sssLog = false;                     // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (PBRT_AMD_SSS_LOG=1; built after round 4's last GPU call: off until measured)
     bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
@@ -2528,7 +2528,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
         { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
-        { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = !(e && e[0] == '0'); }
+        { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = e && e[0] == '1'; }
         { const char *e = std::getenv("PBRT_AMD_SSS_WALK"); c->sssWalk = e && e[0] == '1'; }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }

@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_tail(const DevScene *scp
         uint32_t slot = 0;
         if (active) {
             slot = qIn[it.item()];
-            // this lane's list of counted hits (PathState::sss_log_*: one slice per thread of the launch, null beyond the slices or with PBRT_AMD_SSS_LOG=0), from the
+            // this lane's list of counted hits (PathState::sss_log_*: one slice per thread of the launch, null beyond the slices or without PBRT_AMD_SSS_LOG=1), from the
             // hit count the chain arrives with; a chain that arrives in its second walk has no use for one
             SssLog lg;
             const SssLog *lgp = nullptr;

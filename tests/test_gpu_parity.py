@@ -1124,14 +1124,11 @@ def test_only_the_vertices_on_bssrdf_materials_go_to_the_volumetric_shading_kern
 
 def test_the_tail_of_the_probe_walk_lists_its_hits_instead_of_walking_twice(tmp_path, monkeypatch):
     """k_sss_probe_tail keeps the counted hits of a chain's first walk in a per-thread list (SssLog) and steps to the chosen one, as the reference's linked list does
-    (bssrdf.cpp:285-314); PBRT_AMD_SSS_LOG=0 walks the chain a second time up to the chosen hit.  Same image bit for bit, fewer probe segments -- on the reduced
+    (bssrdf.cpp:285-314) with PBRT_AMD_SSS_LOG=1; without (the default until the list has been measured on the GPU) it walks the chain a second time up to the chosen hit.  Same image bit for bit, fewer probe segments -- on the reduced
     subsurface stand-in, whose quad soups give chains of tens of hits."""
     out = {}
     for form in ("list", "twice"):
-        if form == "twice":
-            monkeypatch.setenv("PBRT_AMD_SSS_LOG", "0")
-        else:
-            monkeypatch.delenv("PBRT_AMD_SSS_LOG", raising=False)
+        monkeypatch.setenv("PBRT_AMD_SSS_LOG", "1" if form == "list" else "0")
         sc = _config_scene("sanmiguel_subsurface", str(tmp_path))
         ctx = pa.Context(sc)
         ctx.counters_reset()
