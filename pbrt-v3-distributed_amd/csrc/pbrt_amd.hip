@@ -97,16 +97,16 @@ struct PathState {
     int spill_per_thread;
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
-    // Scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials (mi_ctx::sssRoute): the material sort puts those materials' keys LAST
-    // (key_remap, applied by k_keycount) and the sorted queue is shaded in two launches -- k_shade takes the keys below shade_split, k_shade_vol the rest.
+    // The material-sorted queue is shaded in PARTS, one launch each (mi_ctx::shadeParts): the sort orders its keys part by part (key_remap, applied by k_keycount) --
+    // first the material classes of k_shade<..., CLS> (pt_shade.h), then, in scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials
+    // (mi_ctx::sssRoute), those materials' keys LAST.  A launch walks the keys [shade_key_lo, shade_key_hi) of the sorted queue (ShadeRange).
     const DevScene *sc_dev;      // the DevScene / DevVol in HBM, for the out-of-line chain step of k_trace<2, ..., TR, WALK> (SssWalkStep); null otherwise
     const struct DevVol *vol_dev;
     float4 *sss_log_o, *sss_log_d;   // k_sss_probe_tail's lists of counted hits (SssLog, pt_volpath.h): sss_log_cap entries per thread for the first sss_log_threads threads of the launch; null: off
     uint32_t *sss_log_inst;
     uint32_t sss_log_threads, sss_log_cap;
     const uint32_t *key_remap;   // [nkeys] or null
-    uint32_t shade_split;        // first key of the second part
-    uint32_t shade_part;         // 0: the whole queue; 1: keys < shade_split; 2: keys >= shade_split
+    uint32_t shade_key_lo, shade_key_hi;   // the launch's part of the sorted queue in (remapped) keys; hi = 0xffffffff: to the end
 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_CONT = 11, QC_ROWS = 12 };
 #define QSEG 8u
@@ -169,12 +169,16 @@ struct ChunkIter {
 #ifndef PT_WAVE_SIZE
 #define PT_WAVE_SIZE 64u
 #endif
-// the part of the material-sorted queue a shading launch walks (PathState::shade_part): [base, base + n)
+// the part of the material-sorted queue a shading launch walks (PathState::shade_key_lo / _hi): [base, base + n).  Every launch cuts ITS part into eighths for the
+// eight block classes (DynIter), so a class appends up to n_part / 8 + PT_BLOCK entries per part to its queue segment: PathState::seg_cap carries that headroom
+// for PT_SHADE_PARTS_MAX parts (ensure_state).
+#define PT_SHADE_PARTS_MAX 6
 PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
-    *base = 0;
-    *n = ps.qcount[QCI(QC_SORTED, 0)];
-    if (ps.shade_part == 1) *n = ps.keyoffset[ps.shade_split];
-    else if (ps.shade_part == 2) { *base = ps.keyoffset[ps.shade_split]; *n -= *base; }
+    const uint32_t total = ps.qcount[QCI(QC_SORTED, 0)];
+    const uint32_t lo = ps.shade_key_lo ? ps.keyoffset[ps.shade_key_lo] : 0u;
+    const uint32_t hi = ps.shade_key_hi != 0xffffffffu ? ps.keyoffset[ps.shade_key_hi] : total;
+    *base = lo;
+    *n = hi - lo;
 }
 struct DynIter {
     uint32_t segBeg, segEnd, cur, end;
@@ -1110,8 +1114,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #define PT_SHADE_SC_PARAM DevScene sc
 #define PT_SHADE_SC_ARG sc
 #endif
-template <bool ENV, int SMP, bool TEX, bool INST = false>
-__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
+// CLS: the material class of the launch's part of the sorted queue (pt_shade.h, ClsHas; mi_ctx::shadeParts): 0 = any material (out-of-line BxDF routines), 1 matte, 2 diffuse /
+// glossy reflection, 3 specular only -- the class instances carry their lobe kinds in line and nothing else
+#ifndef PT_SHADE_CLS_WAVES
+#define PT_SHADE_CLS_WAVES 4
+#endif
+template <bool ENV, int SMP, bool TEX, bool INST = false, int CLS = 0>
+__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? PT_SHADE_CLS_WAVES : PT_SHADE_WAVES))) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
 #if PT_SHADE_ARGPTR
     const DevScene &sc0 = *scp;
 #define sc sc0
@@ -1208,7 +1217,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                 } else {
                     TriHit th;
                     TriangleTest(p0, p1, p2, iro, ird, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                    isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), ird, hr.x);
+                    if constexpr (CLS != 0) { isect = BuildIsectBody(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)); isect.wo = Normalize(-ird); isect.prim = hr.x; }   // (in line: MakeIsect's two fields)
+                    else isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), ird, hr.x);
                     if (TEX) ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
                 }
                 if constexpr (INST) {
@@ -1247,7 +1257,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     if (SameAs(matIdx, matU)) {
                     matTodo = false;
                     const mi_material *matPtr = sc.materials + matU;
-                    typedef BSDF_T<!TEX> BS;
+                    typedef BSDF_T<!TEX, CLS> BS;
                     mi_material laneMat;
                     if (TEX) {
                         // isect.ComputeScatteringFunctions(ray, arena, true) path.cpp:107: ComputeDifferentials (camera rays only: every
@@ -1264,7 +1274,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     }
                     BS bsdf(isect, matPtr, TEX ? nullptr : sc.mat_pack, matU);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
-                    if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
+                    if (CLS != 3 && bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {   // (class 3: specular lobes only -- no light is sampled)
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
                         Float funcInt = sc.light_func_int;
                         const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
@@ -1306,8 +1316,9 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
                             PROBE(6)   // light pick
-                            LightSample ls = ENV ? SampleLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
-                                                 : SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1);
+                            LightSample ls = ENV ? SampleLiAny<CLS != 0>(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
+                                                 : (CLS ? SampleLiBody(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
+                                                        : SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1));
                             PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
@@ -1339,7 +1350,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                                     Float weight = 1;
                                     bool ok = true;
                                     if (!sampledSpecular) {
-                                        lightPdf = ENV ? PdfLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi) : PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi);
+                                        lightPdf = ENV ? PdfLiAny<CLS != 0>(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi)
+                                                       : (CLS ? PdfLiBody(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi) : PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi));
                                         if (lightPdf == 0) ok = false;
                                         else weight = PowerHeuristic(scatteringPdf, lightPdf);
                                     }
@@ -1627,7 +1639,7 @@ struct mi_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t evShaded = nullptr, evNeeDone = nullptr;
     bool overlapNee = false;
-    int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
+    int numCUs = 256, gridBlocks = 1024, gridShade = 1024, gridShadeCls = 1024;
     double hotProbeShare = 0;   // share of the probe paths' node visits that fell on the nodes now in nodesq[0 .. n_hot)
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
@@ -1651,7 +1663,8 @@ struct mi_ctx {
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
     const uint32_t *keyRemap = nullptr;
-    uint32_t shadeSplit = 0;
+    struct ShadePart { int cls; uint32_t keyLo, keyHi; };   // cls: material class of k_shade<..., CLS> (pt_shade.h), -1: k_shade_vol; keys [keyLo, keyHi) of the remapped key space, keyHi = 0xffffffff: to the end
+    std::vector<ShadePart> shadeParts;       // the launches that shade the material-sorted queue, in key order (PBRT_AMD_SHADE_CLASSES=0: one k_shade launch for every material class)
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -1846,6 +1859,7 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     c->numCUs = prop.multiProcessorCount;
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     c->gridShade = ((c->numCUs * PT_SHADE_GRID_PER_CU + 7) / 8) * 8;   // k_shade: a multiple of what is resident at PT_SHADE_WAVES per SIMD
+    c->gridShadeCls = ((c->numCUs * 4 * PT_SHADE_CLS_WAVES + 7) / 8) * 8;   // the class instances of k_shade: the same four rounds of what is resident at THEIR waves per SIMD
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { mi_ctx_destroy(c); return -1; }
@@ -2507,7 +2521,8 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
     std::memset(&c->vol, 0, sizeof(c->vol));
     c->scDev = nullptr;
-    c->sssRoute = false; c->keyRemap = nullptr; c->shadeSplit = 0; c->volDev = nullptr;
+    c->sssRoute = false; c->keyRemap = nullptr; c->shadeParts.clear(); c->volDev = nullptr;
+    std::vector<char> needsVol(d->n_materials, 0);   // (sssRoute) the materials k_shade_vol must see
     if (c->volKernel) {
         DevVol &v = c->vol;
         v.handle_media = d->integrator_type == MI_INTEGRATOR_VOLPATH;
@@ -2592,7 +2607,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
                 // which materials k_shade_vol must see: those with a BSSRDF, and mix materials built on one -- MixMaterial evaluates m1 on *si itself (mixmat.cpp:45-64), so
                 // the mix's interaction carries m1's BSSRDF (ComputeBSSRDFD follows the m1 links); m2's is included for simplicity.  Sub-materials have smaller indices.
                 // (found by tools/fuzz_vs_reference.py --device --sss: a mix of two subsurface materials shaded by k_shade lost its BSSRDF bounce)
-                std::vector<char> needsVol(d->n_materials, 0);
+                bool any = false;
                 for (uint32_t m = 0; m < d->n_materials; ++m) {
                     needsVol[m] = d->material_bssrdf[m].kind != MI_BSSRDF_NONE;
                     if (d->material_descs && d->material_descs[m].type == MI_MAT_MIX) {
@@ -2600,21 +2615,11 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
                         if (m1 >= 0 && (uint32_t)m1 < m) needsVol[m] |= needsVol[m1];
                         if (m2 >= 0 && (uint32_t)m2 < m) needsVol[m] |= needsVol[m2];
                     }
+                    any = any || needsVol[m];
                 }
                 c->plainTex = false;
                 if (d->material_descs) for (uint32_t m = 0; m < d->n_materials; ++m) c->plainTex |= d->material_descs[m].textured != 0 && !needsVol[m];
-                const uint32_t nk = d->n_materials + 2;
-                std::vector<uint32_t> remap(nk);
-                uint32_t plain = 0, nPlain = 0;
-                for (uint32_t m = 0; m < d->n_materials; ++m) nPlain += !needsVol[m];
-                uint32_t sss = nPlain + 2;
-                for (uint32_t m = 0; m < d->n_materials; ++m) remap[m] = !needsVol[m] ? plain++ : sss++;
-                remap[d->n_materials] = nPlain; remap[d->n_materials + 1] = nPlain + 1;   // escaped rays, null-BSDF surfaces
-                if (nPlain + 2 < nk) {   // (some material does have a BSSRDF)
-                    DevBuf &b = next();
-                    if (upload(c, b, remap.data(), remap.size() * sizeof(uint32_t))) return -1;
-                    c->keyRemap = b.as<uint32_t>(); c->shadeSplit = nPlain + 2; c->sssRoute = true;
-                }
+                c->sssRoute = any;   // (some material does have a BSSRDF; the key order itself is built below with the shading parts)
             }
             HIP_TRY(hipStreamSynchronize(c->stream));   // local
         }
@@ -2629,6 +2634,66 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
 #endif
     if (c->sssWalk && c->sssWave)   // (a developer switch: say what it did)
         std::fprintf(stderr, "[pbrt_amd] PBRT_AMD_SSS_WALK=1: probe chains %s\n", c->useQ && !c->hasAlpha && !c->hasInst ? "walked inside the traversal lanes (k_trace<2, ..., TR, WALK>)" : "in rounds (two-level scene, masks or full-precision nodes: no WALK instance)");
+    // ---- the parts the material-sorted queue is shaded in (PathState::key_remap, ShadeRange).  Key order: [class 1 | class 2 | class 3 | class 0 materials, escaped rays,
+    // null-BSDF surfaces | (sssRoute) the materials k_shade_vol must see].  Classes (pt_shade.h, ClsHas): from the constant lobe lists, for the k_shade instances that read
+    // wave-uniform lobe lists and draw their dimensions in one batch -- no textured material among those k_shade sees, no two-level scene, Sobol' / Halton.
+    {
+        const uint32_t nm = d->n_materials, nk = nm + 2;
+        const bool volAll = c->volKernel && !c->sssRoute;   // k_shade_vol shades every vertex
+        bool classes = !volAll && !c->hasInst && !(c->sssRoute ? c->plainTex : c->hasTex) && !MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
+        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASSES"); if (e && e[0] == '0') classes = false; }
+        auto classify = [&](const mi_material &m) -> int {
+            if (m.n_bxdfs == 0) return 3;   // no lobe at all (e.g. a matte material with black Kd, the usual material of light sources): nothing to sample -- the leanest instance
+            if (m.n_bxdfs < 0 || m.n_bxdfs > 2) return 0;
+            bool lam = true, glossy = true, spec = true;
+            for (int i = 0; i < m.n_bxdfs; ++i) {
+                const mi_bxdf &b = m.bxdfs[i];
+                if (b.scaled) return 0;
+                lam = lam && b.type == MI_BXDF_LAMBERT_R;
+                glossy = glossy && (b.type == MI_BXDF_LAMBERT_R || b.type == MI_BXDF_MICROFACET_R);
+                spec = spec && (b.type == MI_BXDF_SPECULAR_R || b.type == MI_BXDF_SPECULAR_T || b.type == MI_BXDF_FRESNEL_SPEC);
+            }
+            if (lam && m.n_bxdfs == 1) return 1;
+            return glossy ? 2 : (spec ? 3 : 0);
+        };
+        std::vector<int> cls(nm, 0);
+        for (uint32_t m = 0; m < nm; ++m) cls[m] = (c->sssRoute && needsVol[m]) ? -1 : (classes ? classify(d->materials[m]) : 0);
+        std::vector<uint32_t> remap(nk);
+        uint32_t nextKey = 0;
+        bool identity = true;
+        const int order[4] = {1, 2, 3, 0};
+        for (int o = 0; o < 4 && !volAll; ++o) {
+            const uint32_t lo = nextKey;
+            for (uint32_t m = 0; m < nm; ++m) if (cls[m] == order[o]) remap[m] = nextKey++;
+            if (nextKey > lo) c->shadeParts.push_back({order[o], lo, nextKey});
+        }
+        if (!volAll) {   // escaped rays and null-BSDF surfaces: every k_shade instance handles them -- they ride with the last k_shade part
+            if (c->shadeParts.empty()) c->shadeParts.push_back({0, nextKey, nextKey});
+            remap[nm] = nextKey++; remap[nm + 1] = nextKey++;
+            c->shadeParts.back().keyHi = nextKey;
+        }
+        if (volAll || c->sssRoute) {
+            const uint32_t lo = nextKey;
+            for (uint32_t m = 0; m < nm; ++m) if (volAll || cls[m] == -1) remap[m] = nextKey++;
+            if (volAll) { remap[nm] = nextKey++; remap[nm + 1] = nextKey++; }
+            c->shadeParts.push_back({-1, lo, nextKey});
+        }
+        if (nextKey != nk) return fail("mi_scene_upload: internal error (shading parts do not cover the keys)");
+        c->shadeParts.back().keyHi = 0xffffffffu;
+        for (uint32_t k = 0; k < nk; ++k) identity = identity && remap[k] == k;
+        if ((int)c->shadeParts.size() > PT_SHADE_PARTS_MAX) return fail("mi_scene_upload: internal error (too many shading parts)");
+        if (!identity) {
+            DevBuf &b = next();
+            if (upload(c, b, remap.data(), remap.size() * sizeof(uint32_t))) return -1;
+            c->keyRemap = b.as<uint32_t>();
+            HIP_TRY(hipStreamSynchronize(c->stream));   // local
+        }
+        if (std::getenv("PBRT_AMD_VERBOSE")) {
+            std::fprintf(stderr, "[pbrt_amd] shading parts:");
+            for (auto &sp : c->shadeParts) std::fprintf(stderr, " [class %d: keys %u..%u)", sp.cls, sp.keyLo, sp.keyHi);
+            std::fprintf(stderr, "\n");
+        }
+    }
     c->nkeys = d->n_materials + 2;
     if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
     // film
@@ -2659,8 +2724,10 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
 #define ALLOC(field, type, count) do { ps.field = (type *)A(sizeof(type) * (size_t)(count)); if (!ps.field) return -1; } while (0)
     // queue segment capacity: a block class handles one contiguous eighth of the 256-item chunks of whatever it walks (ChunkIter) and
     // appends at most one entry per item to each queue
+    // (+ the shading launches' headroom: each of up to PT_SHADE_PARTS_MAX parts of the sorted queue is cut into eighths of its own, ceil(ceil(n_i / 256) / 8) * 256
+    // <= n_i / 8 + 256 items per class and part -- ADVICE r4: two parts could overrun a segment sized for one launch by up to 512 entries)
     const uint32_t chunks = (cap + PT_BLOCK - 1) / PT_BLOCK;
-    ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK;
+    ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK + PT_SHADE_PARTS_MAX * PT_BLOCK;
     const size_t qcap = (size_t)QSEG * ps.seg_cap;
     ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, qcap);
     ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);
@@ -2780,8 +2847,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     TableTurn turn(c);
     ps.sc_dev = c->scDev; ps.vol_dev = c->volDev;
-    ps.key_remap = c->sssRoute ? c->keyRemap : nullptr;
-    ps.shade_split = c->shadeSplit; ps.shade_part = 0;
+    ps.key_remap = c->keyRemap;
+    ps.shade_key_lo = 0; ps.shade_key_hi = 0xffffffffu;
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
     if (c->hasTex || c->hasAlpha || c->hasInst)   // the tables of THIS context's scene (stream ordered; contexts sharing a device take turns: TableTurn)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
@@ -2854,26 +2921,39 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);               \
         else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
     } while (0)
-            auto shade_plain = [&](const PathState &ps) {
+#define LAUNCH_SHADE_CLS(ENV, CLS_)                                                                                                              \
+    do {                                                                                                                                         \
+        const dim3 g_(c->gridShadeCls);                                                                                                          \
+        if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, false, false, CLS_>), g_, block, 0, st, PT_SHADE_SC_ARG, ps, qout);                      \
+        else hipLaunchKernelGGL((k_shade<ENV, 0, false, false, CLS_>), g_, block, 0, st, PT_SHADE_SC_ARG, ps, qout);                             \
+    } while (0)
+            auto shade_plain = [&](const PathState &ps, int cls) {
                 // (routed subsurface scenes: the BSSRDF materials are always built per hit, mi_material_desc::textured -- what counts here are the materials k_shade sees)
                 const bool tex = c->sssRoute ? c->plainTex : c->hasTex;
+                const bool env = c->hasEnvMap || c->hasSpheres;
                 if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
                 else if (tex) LAUNCH_SHADE(true, true);           // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
-                else if (c->hasEnvMap || c->hasSpheres) LAUNCH_SHADE(true, false);
+                else if (cls == 1) { if (env) LAUNCH_SHADE_CLS(true, 1); else LAUNCH_SHADE_CLS(false, 1); }   // (classes exist for Sobol' / Halton, untextured, single-level: mi_scene_upload)
+                else if (cls == 2) { if (env) LAUNCH_SHADE_CLS(true, 2); else LAUNCH_SHADE_CLS(false, 2); }
+                else if (cls == 3) { if (env) LAUNCH_SHADE_CLS(true, 3); else LAUNCH_SHADE_CLS(false, 3); }
+                else if (env) LAUNCH_SHADE(true, false);
                 else LAUNCH_SHADE(false, false);
             };
 #undef LAUNCH_SHADE
-            if (c->sssRoute) {   // PathState::key_remap: the sorted queue's first part is ordinary vertices (k_shade), its second part the vertices on BSSRDF materials
+#undef LAUNCH_SHADE_CLS
+            // one launch per part of the sorted queue (mi_ctx::shadeParts: material classes of k_shade, then the vertices k_shade_vol must see)
+            bool firstPart = true;
+            for (const mi_ctx::ShadePart &sp : c->shadeParts) {
+                if (!firstPart) {
+                    toc(c);   // (each part is its own entry of mi_timing_get's launch count)
+                    HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
+                    tic(c, MI_K_SHADE);
+                }
+                firstPart = false;
                 PathState part = ps;
-                part.shade_part = 1;
-                shade_plain(part);
-                toc(c);   // (each part is its own entry of mi_timing_get's launch count)
-                HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                tic(c, MI_K_SHADE);
-                part.shade_part = 2;
-                shade_vol(part);
-            } else if (c->volKernel) shade_vol(ps);
-            else shade_plain(ps);
+                part.shade_key_lo = sp.keyLo; part.shade_key_hi = sp.keyHi;
+                if (sp.cls < 0) shade_vol(part); else shade_plain(part, sp.cls);
+            }
         }
         toc(c);
         // the direct-lighting rays of a shading stage through the walk (volTr) or the plain any-hit / closest-hit traversals
