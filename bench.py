@@ -77,16 +77,19 @@ def _lib_id():
 
 
 def traffic_live(wl_args, workload, pmc_steps=2):
-    """HBM-side bytes per launch of the closest-hit kernel from a separate `rocprofv3 --pmc FETCH_SIZE` pass over the same
-    workload (child process, plain frames only).  FETCH_SIZE is in KiB of 64-byte requests; gfx950 tallies the 128-byte
-    requests of 16-byte-per-lane loads at 64 bytes, hence x2 (guides/MI355X_MICROARCH.md, HBM section)."""
+    """HBM-side bytes per launch of the closest-hit kernel from a separate `rocprofv3 --pmc` pass over the same workload (child process, plain frames only): the L2's
+    memory-side read requests BY SIZE, bytes = 32 n32 + 64 n64 + 128 n128 (TCC_EA0_RDREQ_32B / _64B / _128B).  Calibrated in round 5 on known byte counts
+    (profiles/r05_a_fetch_size_calibration.txt, r05_b_request_sizes.txt): a streaming read of 8.59 GB shows 6.711e7 128-byte requests = 8.59 GB exactly; FETCH_SIZE tallies
+    every request at 64 B (hence the guide's x2 on gfx950); chains of random 64-byte records fetch a whole 128-byte line per record (x2 of the useful bytes) -- every request
+    of the traversal kernels is a 128-byte one.  Infinity-Cache hits are included (a 64 MiB gather that never leaves the MALL shows the same counts): an upper bound on HBM."""
     import csv, glob, shutil, tempfile, collections
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         log("[bench] no rocprofv3: HBM traffic not measured live")
         return None
     d = tempfile.mkdtemp(prefix="pbrt_amd_pmc_", dir="/tmp")
-    cmd = [exe, "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + wl_args + \
+    names = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+    cmd = [exe, "--pmc"] + names + ["-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + wl_args + \
           ["--steps", str(pmc_steps), "--warmup", "0", "--cpu-seconds", "0", "--traffic", "none", "--pmc-child"]
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.time()
@@ -98,22 +101,27 @@ def traffic_live(wl_args, workload, pmc_steps=2):
     if r.returncode != 0:
         log("[bench] PMC pass failed (rc %d): %s" % (r.returncode, r.stdout[-600:]))
         return None
-    kb = collections.defaultdict(float)
+    cnt = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == "FETCH_SIZE" and row["Kernel_Name"].startswith("void k_trace<0, false"):
-                kb[row["Kernel_Name"]] += float(row["Counter_Value"])
+            if row.get("Counter_Name") in names and row["Kernel_Name"].startswith("void k_trace<0, false"):
+                cnt[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[row["Kernel_Name"]].add(row["Dispatch_Id"])
     shutil.rmtree(d, ignore_errors=True)
-    if not kb:
-        log("[bench] PMC pass produced no FETCH_SIZE rows for k_trace<0, false, ...>")
+    if not cnt:
+        log("[bench] PMC pass produced no TCC_EA0_RDREQ rows for k_trace<0, false, ...>")
         return None
-    k = max(kb, key=lambda n: kb[n])
-    per = kb[k] / len(disp[k])
-    log("[bench] PMC pass: %s, %d launches, FETCH_SIZE %.0f KiB per launch (%.0f s)" % (k.split("(")[0], len(disp[k]), per, time.time() - t0))
-    return {"kernel": k.split("(")[0].replace("void ", ""), "launches": len(disp[k]), "FETCH_SIZE_KiB_per_launch": per, "bytes_per_launch": per * 1024 * 2,
-            "source": "live: rocprofv3 --pmc FETCH_SIZE pass of this workload inside this bench run (x2: gfx950 correction)", "workload": workload, "lib": _lib_id()}
+    k = max(cnt, key=lambda n: cnt[n]["TCC_EA0_RDREQ_sum"])
+    n = len(disp[k])
+    c = {a: b / n for a, b in cnt[k].items()}
+    per = 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0) + 128.0 * c.get("TCC_EA0_RDREQ_128B_sum", 0)
+    log("[bench] PMC pass: %s, %d launches, %.3f GB per launch by request size (%.4g requests, %.4g of them 128-byte) (%.0f s)" %
+        (k.split("(")[0], n, per * 1e-9, c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_128B_sum", 0), time.time() - t0))
+    return {"kernel": k.split("(")[0].replace("void ", ""), "launches": n, "requests_per_launch": {a.replace("TCC_EA0_", "").replace("_sum", ""): b for a, b in c.items()},
+            "FETCH_SIZE_KiB_per_launch": c["TCC_EA0_RDREQ_sum"] * 64.0 / 1024.0, "bytes_per_launch": per,
+            "source": "live: rocprofv3 --pmc TCC_EA0_RDREQ{,_32B,_64B,_128B} pass of this workload inside this bench run; bytes by request size (calibrated: profiles/r05_a_fetch_size_calibration.txt, r05_b_request_sizes.txt; FETCH_SIZE = 64 B x requests would read half)",
+            "workload": workload, "lib": _lib_id()}
 
 
 def valu_live(wl_args, pmc_steps=1):
@@ -176,7 +184,7 @@ def traffic_save(workload, t):
     except Exception:
         doc = {"entries": {}}
     e = {k: t[k] for k in ("kernel", "launches", "FETCH_SIZE_KiB_per_launch", "bytes_per_launch", "lib")}
-    e["profile"] = "rocprofv3 --pmc FETCH_SIZE, own pass of `bench.py` on this workload; KiB x 1024 x 2 (gfx950 correction)"
+    e["profile"] = "rocprofv3 --pmc TCC_EA0_RDREQ{,_32B,_64B,_128B}, own pass of `bench.py` on this workload; bytes by request size"
     doc["entries"][workload] = e
     json.dump(doc, open(TRAFFIC_FILE, "w"), indent=1, sort_keys=True)
 
@@ -292,7 +300,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target length of the CPU baseline sample: the reference binary oracle/_ref/pbrt_ref on a centre crop of the same frame (0 = skip)")
     ap.add_argument("--cpu-port-seconds", type=float, default=6.0, help="length of the second CPU sample, the oracle port (0 = skip)")
     ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
-                    help="HBM bytes per launch of the dominant kernel: live = an extra rocprofv3 --pmc FETCH_SIZE pass of this workload run as a child process; "
+                    help="HBM bytes per launch of the dominant kernel: live = an extra rocprofv3 --pmc pass (memory-side read requests by size) of this workload run as a child process; "
                          "file = the committed profiles/traffic_closest.json entry of exactly this workload and kernel; none = null")
     ap.add_argument("--save-traffic", action="store_true", help="write the live PMC result into profiles/traffic_closest.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -451,8 +459,8 @@ def main():
         msamples = samples[0] / elapsed * 1e-6
         mrays = samples[1] / elapsed * 1e-6
         # ---- roofline of the dominant kernel (closest-hit traversal of path-extension rays), this rank.
-        # `achieved` = HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, x2: the gfx950 correction of
-        # guides/MI355X_MICROARCH.md) / the live average launch time (HIP events on the ctx stream): a true fraction of the
+        # `achieved` = HBM-side bytes per launch (rocprofv3 --pmc: the L2's memory-side read requests by size, traffic_live -- what the guide's
+        # "FETCH_SIZE x 2" amounts to on gfx950, calibrated in round 5) / the live average launch time (HIP events on the ctx stream): a true fraction of the
         # 8 TB/s peak.  The ALGORITHMIC byte rate of SURVEY.md s.8(d) (every node / triangle fetch counted, most of them
         # served by the XCD L2s) is reported beside it as l2_served_GBps -- it exceeds the HBM peak and bounds nothing.
         n_launch = max(1, timing["closest"][1])
@@ -556,6 +564,12 @@ def main():
         roofline["frac_alg_8d"] = round(roofline["alg_bytes_per_launch"] / (avg_launch_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4) if avg_launch_ms > 0 else None
         roofline["frac_hbm_counter"] = roofline["frac"]
         roofline["binding_roof"] = "VALU issue (frac_valu_lane_throughput = issue_frac x lanes_active / 64); HBM target of the north star (>= 0.40 of 8 TB/s in this kernel) unmet"
+        # the line itself says what is true: `bound` names the roof `frac` is quoted against (the contract's HBM figure, from calibrated counters),
+        # `bound_actual` the roof that binds, and the north star's >= 0.40 HBM target is reported as a boolean
+        roofline["bound_actual"] = "valu_issue"
+        roofline["hbm_target"] = {"north_star": ">= 0.40 of the 8 TB/s HBM peak in the traversal kernel", "met": bool(roofline.get("frac") is not None and roofline["frac"] >= 0.40),
+                                  "note": "frac counts the L2's memory-side requests by size; Infinity-Cache (MALL, 256 MiB) hits are included -- no counter of this tool separates them "
+                                          "(TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ) -- so true HBM utilisation is <= frac"}
         kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in timing.items() if v[1]}
 
         # ---- CPU baseline beside it (rank 0, N = 1): the REFERENCE's own multithreaded path -- oracle/_ref/pbrt_ref, built from the

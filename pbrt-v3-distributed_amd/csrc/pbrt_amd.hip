@@ -100,13 +100,16 @@ struct PathState {
     // The material-sorted queue is shaded in PARTS, one launch each (mi_ctx::shadeParts): the sort orders its keys part by part (key_remap, applied by k_keycount) --
     // first the material classes of k_shade<..., CLS> (pt_shade.h), then, in scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials
     // (mi_ctx::sssRoute), those materials' keys LAST.  A launch walks the keys [shade_key_lo, shade_key_hi) of the sorted queue (ShadeRange).
-    const DevScene *sc_dev;      // the DevScene / DevVol in HBM, for the out-of-line chain step of k_trace<2, ..., TR, WALK> (SssWalkStep); null otherwise
-    const struct DevVol *vol_dev;
     float4 *sss_log_o, *sss_log_d;   // k_sss_probe_tail's lists of counted hits (SssLog, pt_volpath.h): sss_log_cap entries per thread for the first sss_log_threads threads of the launch; null: off
     uint32_t *sss_log_inst;
     uint32_t sss_log_threads, sss_log_cap;
     const uint32_t *key_remap;   // [nkeys] or null
     uint32_t shade_key_lo, shade_key_hi;   // the launch's part of the sorted queue in (remapped) keys; hi = 0xffffffff: to the end
+    // Class parts pay for themselves only on long queues: every launch ends with a tail of its own (~one DynIter grab of the slowest wave), and deep bounces leave a few
+    // thousand paths (C4 at maxdepth 30: four parts per bounce cost +15 % of the shading time, profiles/r05_b_*).  The launches of a bounce therefore decide ON THE DEVICE,
+    // from the same counter: with fewer than shade_cls_min vertices for k_shade the class launches (shade_role 1) do nothing and the generic launch (shade_role 2) takes
+    // every k_shade key [0, shade_key_hi); otherwise each takes its own keys.  shade_role 0: no such decision (classes off, k_shade_vol's part).
+    uint32_t shade_cls_min, shade_role, shade_all_hi;   // (shade_all_hi: the key behind k_shade's last key, 0xffffffff = the end)
 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_CONT = 11, QC_ROWS = 12 };
 #define QSEG 8u
@@ -173,10 +176,16 @@ struct ChunkIter {
 // eight block classes (DynIter), so a class appends up to n_part / 8 + PT_BLOCK entries per part to its queue segment: PathState::seg_cap carries that headroom
 // for PT_SHADE_PARTS_MAX parts (ensure_state).
 #define PT_SHADE_PARTS_MAX 6
+PT_DEV uint32_t ShadeKeyPos(const PathState &ps, uint32_t key, uint32_t total) { return key == 0xffffffffu ? total : (key ? ps.keyoffset[key] : 0u); }   // first position of `key` in the sorted queue
 PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
     const uint32_t total = ps.qcount[QCI(QC_SORTED, 0)];
-    const uint32_t lo = ps.shade_key_lo ? ps.keyoffset[ps.shade_key_lo] : 0u;
-    const uint32_t hi = ps.shade_key_hi != 0xffffffffu ? ps.keyoffset[ps.shade_key_hi] : total;
+    uint32_t lo = ShadeKeyPos(ps, ps.shade_key_lo, total), hi = ShadeKeyPos(ps, ps.shade_key_hi, total);
+    if (ps.shade_role) {
+        const uint32_t nk = ShadeKeyPos(ps, ps.shade_all_hi, total);   // the vertices k_shade sees in this bounce
+        const bool few = nk < ps.shade_cls_min;
+        if (ps.shade_role == 1 && few) hi = lo;   // a class part: nothing to do
+        if (ps.shade_role == 2 && few) lo = 0;    // the generic part (the last of k_shade's parts): every k_shade key
+    }
     *base = lo;
     *n = hi - lo;
 }
@@ -567,15 +576,11 @@ template <bool PEND, class TS> PT_DEV bool TraceDone(const TS &ts) {
 }
 // TR (MODE 1 / 2, DevVol::tr_queues): the ray is one SEGMENT of a shadow / MIS ray that is walked through BSDF-less medium interfaces -- closest hit
 // (also for shadow segments: the nearest surface decides whether the walk ends or goes on), result into TrState::hit; k_vol_tr_step does the rest
-// WALK (MODE 2 + TR, the probe chains of BSSRDF materials; built in round 4, not yet measured: PBRT_AMD_SSS_WALK=1): the WHOLE chain is walked by the persistent lane -- a lane whose
-// segment has found its closest hit runs the chain step itself (SssWalkStep = SssProbeStepOne, out of line) and starts the next segment with the same path instead of handing
-// it back through a queue and a step launch; a finished chain goes to the QC_SSS queue for k_sss_entry.  One launch per bounce instead of ~15 rounds + a tail.
-// Returns 1: the chain goes on with the segment now in NeeRec::sh_o / sh_d; 2: pi is chosen; 0: the chain ended without one (the path ends, path.cpp:160)
-__device__ __noinline__ int SssWalkStep(const DevScene *scp, const DevVol *vol, SssRec *sss, TrState *trs, NeeRec *nee, uint32_t slot);
-template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false, bool TR = false, bool WALK = false>
+// (Round 4 also built the whole probe chain INTO these lanes -- k_trace<2, ..., TR, WALK> + SssWalkStep, 248 VGPRs; measured in round 5 against the rounds + tail kernel with the
+// hit list: 129.2 vs 133.1 Msamples/s on the subsurface C3, profiles/r05_a_* -- and removed.)
+template <int MODE, bool COUNT, bool SPHERES, bool ALPHA = false, bool INST = false, bool QN = false, bool TR = false>
 __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK), (TraceShape<MODE, SPHERES, ALPHA, QN>::WAVES)) k_trace(DevScene sc, PathState ps, uint32_t qin) {
     static_assert(!QN || !INST, "quantised nodes: single-level BVH4");
-    static_assert(!WALK || (TR && MODE == 2 && !INST), "the walked chains are segments of the shadow queue; single-level scenes");
     constexpr int BLOCK = TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK;
     constexpr int HOT = TraceShape<MODE, SPHERES, ALPHA, QN>::HOT;
     constexpr bool PEND = QN && PT_PEND_LEAF;
@@ -616,7 +621,6 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     if constexpr (PEND) ts.pend = TRAV_DONE;
     TraceCounters tc = {0, 0, 0};
     uint32_t nrays = 0;
-    bool walkDone = false;   // WALK: this lane's chain has just arrived at its chosen hit (appended to QC_SSS after the hand-over pass)
     unsigned long long clk0 = 0, rt0 = 0;
     if (COUNT) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }   // s_memtime / s_memrealtime: the shader clock this kernel really runs at (mi_trace_clock)
     // hands a finished ray's result over (hit record + sort key / the unoccluded light term / the MIS term)
@@ -626,16 +630,6 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                 uint32_t hi = TRAV_NO_INSTANCE;
                 if constexpr (INST) hi = ts.hitInst;
                 ps.trs[slot].hit[MODE == 1 ? 1 : 0] = make_uint4(ts.prim, __float_as_uint(ts.tHit), hi, 0u);
-                if constexpr (WALK) {
-                    const int r = SssWalkStep(ps.sc_dev, ps.vol_dev, ps.sss, ps.trs, ps.nee, slot);
-                    if (r == 1) {   // the next segment of the same chain: the lane keeps its path
-                        const float4 o4 = ps.nee[slot].sh_o, d4 = ps.nee[slot].sh_d;
-                        ts.init(sc, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, st);
-                        ++nrays;
-                        return;
-                    }
-                    walkDone = r == 2;
-                }
             } else if (MODE == 0) {
                 ps.rec[slot].hit = make_uint2(ts.prim, __float_as_uint(ts.tHit));
                 if constexpr (INST) ps.rec[slot].pad0 = ts.hitInst;   // which instance the hit primitive was reached through (TRAV_NO_INSTANCE: none)
@@ -695,12 +689,6 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
         // them, instead of one pass per scheduling round with a lane or two: the kernel is bound by VALU issue and a wave instruction costs the
         // same for 1 lane or 64)
         if (PT_BATCH_FINALIZE) finalize();
-        if constexpr (WALK) {   // the chains that arrived at their chosen hit -> k_sss_entry's queue (this block class's segment: a WALK launch does not steal from other segments)
-            const uint32_t qs = blockIdx.x & 7;
-            const uint32_t pos = wave_append(&ps.qcount[QCI(QC_SSS, qs)], walkDone);
-            if (walkDone) ps.q_sss[qs * ps.seg_cap + pos] = slot;
-            walkDone = false;
-        }
         unsigned long long idle = PtBallot(!active);
         int nIdle = __popcll(idle);
         if (nIdle >= TRACE_REFILL && segsTried < 8) {
@@ -713,8 +701,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     if (contig) segEnd = segBeg + segLen < nContig ? segBeg + segLen : (segBeg < nContig ? nContig : segBeg);
                     else segEnd = segBeg + ps.qcount[QCI(qrow, seg)];
                     if (segBeg + base >= segEnd) {
-                        if constexpr (WALK) segsTried = 8;   // (its QC_SSS appends go to its own class's segment, which holds one entry per path of that segment)
-                        else { seg = (seg + 1) & 7; ++segsTried; }
+                        seg = (seg + 1) & 7; ++segsTried;
                         poolNext = poolEnd = 0;
                         continue;
                     }
@@ -1117,7 +1104,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 // CLS: the material class of the launch's part of the sorted queue (pt_shade.h, ClsHas; mi_ctx::shadeParts): 0 = any material (out-of-line BxDF routines), 1 matte, 2 diffuse /
 // glossy reflection, 3 specular only -- the class instances carry their lobe kinds in line and nothing else
 #ifndef PT_SHADE_CLS_WAVES
-#define PT_SHADE_CLS_WAVES 4
+#define PT_SHADE_CLS_WAVES 3   /* measured (profiles/r05_b_*): 3 / 4 / 5 waves per SIMD = 168 / 128 / 96 VGPRs -> C3 shade 30.9 / 36.5 / 51.6 ms at 16 spp (one generic launch: 37.6): the spills cost more than the occupancy buys */
 #endif
 template <bool ENV, int SMP, bool TEX, bool INST = false, int CLS = 0>
 __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? PT_SHADE_CLS_WAVES : PT_SHADE_WAVES))) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
@@ -1428,15 +1415,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
 
 #include "pt_volpath.h"   // k_shade_vol: the shading kernel of "volpath" scenes and of scenes with BSSRDF materials
 
-__device__ __noinline__ int SssWalkStep(const DevScene *scp, const DevVol *vol, SssRec *sss, TrState *trs, NeeRec *nee, uint32_t slot) {
-    PathState ps;   // the three per-path records the step touches
-    __builtin_memset(&ps, 0, sizeof(ps));
-    ps.sss = sss; ps.trs = trs; ps.nee = nee;
-    bool again = false, done = false;
-    SssProbeStepOne<false>(scp, ps, *vol, slot, false, &again, &done);
-    return again ? 1 : (done ? 2 : 0);
-}
-
 // ---- film: the radiance guards of integrator.cpp:294-315 + FilmTile::AddSample (core/film.h:121-161).
 // One lane per owned pixel walks that pixel's samples of the pass in sample order.
 //   SPILL == false: only the lane's own pixel, as a plain running sum continued from the film value -- the
@@ -1656,15 +1634,15 @@ struct mi_ctx {
     bool volSplit = false;                   // ... with a grid medium (Tr draws sampler dimensions): split form, k_vol_continue samples the continuation after the walks (DevVol::tr_dims)
     uint32_t sssTail = 131072;               // walked BSSRDF probe chains: queue size below which the rest of the walk is one k_sss_probe_tail launch (PBRT_AMD_SSS_TAIL; 0: rounds to the end)
     bool sssWave = false;                    // BSSRDF materials under Integrator "path" in wavefront form: probe chains walked through the queues (k_sss_probe_step / k_sss_entry)
-    bool sssWalk = false;                    // the probe chains are walked inside the persistent traversal lanes (k_trace<2, ..., TR, WALK>; PBRT_AMD_SSS_WALK=1 -- built in round 4, unmeasured: off)
-    const DevVol *volDev = nullptr;          // DevVol in HBM (SssWalkStep)
-    bool sssLog = false;                     // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (PBRT_AMD_SSS_LOG=1; built after round 4's last GPU call: off until measured)
+    bool sssLog = true;                      // k_sss_probe_tail lists the counted hits of a first walk instead of walking the chain again (measured in round 5, profiles/r05_a_*: 81.3 -> 89.1 Msamples/s at 16 spp, 133.1 at 64 spp; PBRT_AMD_SSS_LOG=0: walk twice, the A/B partner of the parity tests)
     bool plainTex = false;                   // ... some material WITHOUT a BSSRDF is textured (else the first part takes the untextured k_shade instances)
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
     const uint32_t *keyRemap = nullptr;
-    struct ShadePart { int cls; uint32_t keyLo, keyHi; };   // cls: material class of k_shade<..., CLS> (pt_shade.h), -1: k_shade_vol; keys [keyLo, keyHi) of the remapped key space, keyHi = 0xffffffff: to the end
+    struct ShadePart { int cls; uint32_t keyLo, keyHi; int role; };   // role: PathState::shade_role   // cls: material class of k_shade<..., CLS> (pt_shade.h), -1: k_shade_vol; keys [keyLo, keyHi) of the remapped key space, keyHi = 0xffffffff: to the end
     std::vector<ShadePart> shadeParts;       // the launches that shade the material-sorted queue, in key order (PBRT_AMD_SHADE_CLASSES=0: one k_shade launch for every material class)
+    uint32_t shadeClsMin = 4u << 20;         // PathState::shade_cls_min (PBRT_AMD_SHADE_CLASS_MIN): class launches below this many k_shade vertices per bounce lose to their own tails
+    uint32_t shadeAllHi = 0xffffffffu;       // PathState::shade_all_hi
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -2521,7 +2499,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // row f4: media, medium interfaces, BSSRDF tables, and the DevScene itself in HBM for k_shade_vol
     std::memset(&c->vol, 0, sizeof(c->vol));
     c->scDev = nullptr;
-    c->sssRoute = false; c->keyRemap = nullptr; c->shadeParts.clear(); c->volDev = nullptr;
+    c->sssRoute = false; c->keyRemap = nullptr; c->shadeParts.clear();
     std::vector<char> needsVol(d->n_materials, 0);   // (sssRoute) the materials k_shade_vol must see
     if (c->volKernel) {
         DevVol &v = c->vol;
@@ -2543,8 +2521,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { const char *e = std::getenv("PBRT_AMD_VOL_INLINE"); if (e && e[0] == '1') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_SSS_TAIL"); if (e && e[0]) c->sssTail = (uint32_t)std::strtoul(e, nullptr, 10); }
         { const char *e = std::getenv("PBRT_AMD_TR_LEAN"); c->trLean = !(e && e[0] == '0'); }
-        { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = e && e[0] == '1'; }
-        { const char *e = std::getenv("PBRT_AMD_SSS_WALK"); c->sssWalk = e && e[0] == '1'; }
+        { const char *e = std::getenv("PBRT_AMD_SSS_LOG"); c->sssLog = !(e && e[0] == '0'); }
         { const char *e = std::getenv("PBRT_AMD_VOL_SPLIT"); if (split && e && e[0] == '0') wave = false; }
         { const char *e = std::getenv("PBRT_AMD_VOL_TR_QUEUES"); if (e && e[0] == '0' && v.handle_media && (c->hasNullMat || c->hasAlpha)) wave = false; }
         c->volWave = wave;
@@ -2626,14 +2603,11 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         // sampler dimensions: ratio / delta tracking in grid media draw a data-dependent number per segment; the reference aborts past its tables
         // (sobol.cpp:48-51, halton.h:72-75) and the device clamps to the last dimension instead -- such paths are outside both samplers' range
         { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); }
-        { DevBuf &b = next(); if (upload(c, b, &c->vol, sizeof(DevVol))) return -1; c->volDev = b.as<DevVol>(); }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
 #if PT_SHADE_ARGPTR
     if (!c->scDev) { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); HIP_TRY(hipStreamSynchronize(c->stream)); }
 #endif
-    if (c->sssWalk && c->sssWave)   // (a developer switch: say what it did)
-        std::fprintf(stderr, "[pbrt_amd] PBRT_AMD_SSS_WALK=1: probe chains %s\n", c->useQ && !c->hasAlpha && !c->hasInst ? "walked inside the traversal lanes (k_trace<2, ..., TR, WALK>)" : "in rounds (two-level scene, masks or full-precision nodes: no WALK instance)");
     // ---- the parts the material-sorted queue is shaded in (PathState::key_remap, ShadeRange).  Key order: [class 1 | class 2 | class 3 | class 0 materials, escaped rays,
     // null-BSDF surfaces | (sssRoute) the materials k_shade_vol must see].  Classes (pt_shade.h, ClsHas): from the constant lobe lists, for the k_shade instances that read
     // wave-uniform lobe lists and draw their dimensions in one batch -- no textured material among those k_shade sees, no two-level scene, Sobol' / Halton.
@@ -2662,24 +2636,34 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         uint32_t nextKey = 0;
         bool identity = true;
         const int order[4] = {1, 2, 3, 0};
+        bool anyClass = false;
         for (int o = 0; o < 4 && !volAll; ++o) {
             const uint32_t lo = nextKey;
             for (uint32_t m = 0; m < nm; ++m) if (cls[m] == order[o]) remap[m] = nextKey++;
-            if (nextKey > lo) c->shadeParts.push_back({order[o], lo, nextKey});
+            if (nextKey > lo) { c->shadeParts.push_back({order[o], lo, nextKey, order[o] ? 1 : 0}); anyClass = anyClass || order[o] != 0; }
         }
-        if (!volAll) {   // escaped rays and null-BSDF surfaces: every k_shade instance handles them -- they ride with the last k_shade part
-            if (c->shadeParts.empty()) c->shadeParts.push_back({0, nextKey, nextKey});
+        if (!volAll) {
+            // escaped rays and null-BSDF surfaces: every k_shade instance handles them -- they ride with the last k_shade part.  With class parts the LAST k_shade part
+            // is the generic one, which doubles as the short-queue fallback (PathState::shade_role 2); a scene without class-0 materials gets one with no keys of its own
+            if (c->shadeParts.empty()) c->shadeParts.push_back({0, nextKey, nextKey, 0});
             remap[nm] = nextKey++; remap[nm + 1] = nextKey++;
             c->shadeParts.back().keyHi = nextKey;
+            if (anyClass) {
+                if (c->shadeParts.back().cls != 0) c->shadeParts.push_back({0, nextKey, nextKey, 2});
+                else c->shadeParts.back().role = 2;
+            }
+            c->shadeAllHi = nextKey;
         }
         if (volAll || c->sssRoute) {
             const uint32_t lo = nextKey;
             for (uint32_t m = 0; m < nm; ++m) if (volAll || cls[m] == -1) remap[m] = nextKey++;
             if (volAll) { remap[nm] = nextKey++; remap[nm + 1] = nextKey++; }
-            c->shadeParts.push_back({-1, lo, nextKey});
+            c->shadeParts.push_back({-1, lo, nextKey, 0});
         }
         if (nextKey != nk) return fail("mi_scene_upload: internal error (shading parts do not cover the keys)");
-        c->shadeParts.back().keyHi = 0xffffffffu;
+        for (auto &sp : c->shadeParts) { if (sp.keyLo >= nk) sp.keyLo = 0xffffffffu; if (sp.keyHi >= nk) sp.keyHi = 0xffffffffu; }   // (keyoffset has nk entries: the end of the queue is the sorted total)
+        if (c->shadeAllHi >= nk) c->shadeAllHi = 0xffffffffu;
+        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASS_MIN"); if (e && e[0]) c->shadeClsMin = (uint32_t)std::strtoul(e, nullptr, 10); }
         for (uint32_t k = 0; k < nk; ++k) identity = identity && remap[k] == k;
         if ((int)c->shadeParts.size() > PT_SHADE_PARTS_MAX) return fail("mi_scene_upload: internal error (too many shading parts)");
         if (!identity) {
@@ -2690,7 +2674,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         }
         if (std::getenv("PBRT_AMD_VERBOSE")) {
             std::fprintf(stderr, "[pbrt_amd] shading parts:");
-            for (auto &sp : c->shadeParts) std::fprintf(stderr, " [class %d: keys %u..%u)", sp.cls, sp.keyLo, sp.keyHi);
+            for (auto &sp : c->shadeParts) std::fprintf(stderr, " [class %d%s: keys %u..%u)", sp.cls, sp.role == 2 ? " + short-queue fallback" : "", sp.keyLo, sp.keyHi);
             std::fprintf(stderr, "\n");
         }
     }
@@ -2712,6 +2696,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
 
 }  // extern "C"
 
+// k_sss_probe_tail's hit lists (PathState::sss_log_*): threads x PT_SSS_LOG_CAP entries of 36 bytes -- 1.2 GB at the default tail threshold; counted against the path-state budget (mi_render)
+#define PT_SSS_LOG_CAP 256u
+static uint32_t SssLogThreads(const mi_ctx *c, uint32_t cap) { return std::min<uint32_t>(c->sssTail, cap) + 8 * PT_BLOCK; }
+static size_t SssLogBytes(const mi_ctx *c, uint32_t cap) {
+    return (c->sssWave && c->sssTail && c->sssLog) ? (size_t)SssLogThreads(c, cap) * PT_SSS_LOG_CAP * (2 * sizeof(float4) + sizeof(uint32_t)) : 0;
+}
 static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->cap >= cap && !c->stateBufs.empty()) return 0;
     for (auto &b : c->stateBufs) b.release();
@@ -2737,7 +2727,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->sssWave) { ALLOC(sss, SssRec, cap); ALLOC(q_probe[0], uint32_t, qcap); ALLOC(q_probe[1], uint32_t, qcap); }
     if (c->sssWave) ALLOC(q_sss, uint32_t, qcap);
     if (c->sssWave && c->sssTail && c->sssLog) {   // one list per thread the tail launch can occupy when its queue is spread evenly over the eight segments (threads beyond walk twice)
-        const uint32_t threads = std::min<uint32_t>(c->sssTail, cap) + 8 * PT_BLOCK, lcap = 256;
+        const uint32_t threads = SssLogThreads(c, cap), lcap = PT_SSS_LOG_CAP;
         ALLOC(sss_log_o, float4, (size_t)threads * lcap); ALLOC(sss_log_d, float4, (size_t)threads * lcap); ALLOC(sss_log_inst, uint32_t, (size_t)threads * lcap);
         ps.sss_log_threads = threads; ps.sss_log_cap = lcap;
     }
@@ -2846,9 +2836,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     hipStream_t st = c->stream;
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     TableTurn turn(c);
-    ps.sc_dev = c->scDev; ps.vol_dev = c->volDev;
     ps.key_remap = c->keyRemap;
-    ps.shade_key_lo = 0; ps.shade_key_hi = 0xffffffffu;
+    ps.shade_key_lo = 0; ps.shade_key_hi = 0xffffffffu; ps.shade_role = 0; ps.shade_cls_min = 0; ps.shade_all_hi = 0xffffffffu;
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
     if (c->hasTex || c->hasAlpha || c->hasInst)   // the tables of THIS context's scene (stream ordered; contexts sharing a device take turns: TableTurn)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
@@ -2952,6 +2941,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 firstPart = false;
                 PathState part = ps;
                 part.shade_key_lo = sp.keyLo; part.shade_key_hi = sp.keyHi;
+                part.shade_role = (uint32_t)sp.role; part.shade_cls_min = c->shadeClsMin; part.shade_all_hi = c->shadeAllHi;
                 if (sp.cls < 0) shade_vol(part); else shade_plain(part, sp.cls);
             }
         }
@@ -3067,19 +3057,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 toc(c);
                 std::swap(qIn, qOut); std::swap(rowIn, rowOut);
                 tic(c, MI_K_MIS_CLOSEST);
-                // PBRT_AMD_SSS_WALK=1 (single-level scenes over quantised nodes without masks): ONE launch walks every chain to its end inside the persistent lanes
-                const bool walkInLanes = c->sssWalk && c->useQ && !c->hasAlpha && !c->hasInst;
-                if (walkInLanes) {
-                    HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-                    PathState psRun = ps;
-                    psRun.q_shadow = qIn; psRun.qrow_shadow = rowIn;
-                    typedef TraceShape<2, true, false, true> TS_;
-                    const dim3 g_(((c->numCUs * TS_::PER_CU + 7) / 8) * 8), b_(TS_::BLOCK);
-                    if (countWork) hipLaunchKernelGGL((k_trace<2, true, true, false, false, true, true, true>), g_, b_, 0, st, sc, psRun, qin);
-                    else hipLaunchKernelGGL((k_trace<2, false, true, false, false, true, true, true>), g_, b_, 0, st, sc, psRun, qin);
-                    left = 0;
-                }
-                for (int round = 0; round < 16384 && !walkInLanes; ++round) {
+                for (int round = 0; round < 16384; ++round) {
                     HIP_TRY(hipMemsetAsync(ps.qcount + QCI(rowOut, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
                     HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
                     {
@@ -3203,7 +3181,8 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
         const size_t perPath = sizeof(PathRec) + sizeof(NeeRec) + sizeof(uint32_t) * 6 + sizeof(uint2) + ((c->volTr || c->sssWave) ? sizeof(TrState) + 2 * sizeof(uint32_t) : 0) +
                                (c->sssWave ? sizeof(SssRec) + 3 * sizeof(uint32_t) : 0);
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-            size_t budget = freeB / 10 * 6 + (size_t)c->cap * perPath;   // what is allocated for path state now would be released
+            const size_t logB = SssLogBytes(c, cap);   // (the probe walk's hit lists do not scale with the pool: taken off the top -- ADVICE r4)
+            size_t budget = (freeB > logB ? freeB - logB : 0) / 10 * 6 + (size_t)c->cap * perPath;   // what is allocated for path state now would be released
             cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(budget / perPath, 1u << 20));
         }
     }

@@ -1124,7 +1124,7 @@ def test_only_the_vertices_on_bssrdf_materials_go_to_the_volumetric_shading_kern
 
 def test_the_tail_of_the_probe_walk_lists_its_hits_instead_of_walking_twice(tmp_path, monkeypatch):
     """k_sss_probe_tail keeps the counted hits of a chain's first walk in a per-thread list (SssLog) and steps to the chosen one, as the reference's linked list does
-    (bssrdf.cpp:285-314) with PBRT_AMD_SSS_LOG=1; without (the default until the list has been measured on the GPU) it walks the chain a second time up to the chosen hit.  Same image bit for bit, fewer probe segments -- on the reduced
+    (bssrdf.cpp:285-314; the default since round 5, measured in profiles/r05_a_*); with PBRT_AMD_SSS_LOG=0 it walks the chain a second time up to the chosen hit.  Same image bit for bit, fewer probe segments -- on the reduced
     subsurface stand-in, whose quad soups give chains of tens of hits."""
     out = {}
     for form in ("list", "twice"):
