@@ -1101,8 +1101,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #define PT_SHADE_SC_PARAM DevScene sc
 #define PT_SHADE_SC_ARG sc
 #endif
-// CLS: the material class of the launch's part of the sorted queue (pt_shade.h, ClsHas; mi_ctx::shadeParts): 0 = any material (out-of-line BxDF routines), 1 matte, 2 diffuse /
-// glossy reflection, 3 specular only -- the class instances carry their lobe kinds in line and nothing else
+// CLS: the material class of the launch's part of the sorted queue (pt_shade.h; mi_ctx::shadeParts): 0 = any material (out-of-line BxDF routines; also what class 2's part runs),
+// 1 matte, 3 specular only -- these two carry their lobe kinds in line and nothing else
 #ifndef PT_SHADE_CLS_WAVES
 #define PT_SHADE_CLS_WAVES 3   /* measured (profiles/r05_b_*): 3 / 4 / 5 waves per SIMD = 168 / 128 / 96 VGPRs -> C3 shade 30.9 / 36.5 / 51.6 ms at 16 spp (one generic launch: 37.6): the spills cost more than the occupancy buys */
 #endif
@@ -1643,6 +1643,7 @@ struct mi_ctx {
     std::vector<ShadePart> shadeParts;       // the launches that shade the material-sorted queue, in key order (PBRT_AMD_SHADE_CLASSES=0: one k_shade launch for every material class)
     uint32_t shadeClsMin = 4u << 20;         // PathState::shade_cls_min (PBRT_AMD_SHADE_CLASS_MIN): class launches below this many k_shade vertices per bounce lose to their own tails
     uint32_t shadeAllHi = 0xffffffffu;       // PathState::shade_all_hi
+    bool shadeClsGeneric = false;            // PBRT_AMD_SHADE_CLASSES=generic (measurement aid): the parts of the classes, each shaded by the GENERIC instance -- what a class's vertices cost without its instance
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -2615,7 +2616,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         const uint32_t nm = d->n_materials, nk = nm + 2;
         const bool volAll = c->volKernel && !c->sssRoute;   // k_shade_vol shades every vertex
         bool classes = !volAll && !c->hasInst && !(c->sssRoute ? c->plainTex : c->hasTex) && !MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
-        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASSES"); if (e && e[0] == '0') classes = false; }
+        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASSES"); if (e && e[0] == '0') classes = false; c->shadeClsGeneric = e && e[0] == 'g'; }
         auto classify = [&](const mi_material &m) -> int {
             if (m.n_bxdfs == 0) return 3;   // no lobe at all (e.g. a matte material with black Kd, the usual material of light sources): nothing to sample -- the leanest instance
             if (m.n_bxdfs < 0 || m.n_bxdfs > 2) return 0;
@@ -2922,8 +2923,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 const bool env = c->hasEnvMap || c->hasSpheres;
                 if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
                 else if (tex) LAUNCH_SHADE(true, true);           // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
-                else if (cls == 1) { if (env) LAUNCH_SHADE_CLS(true, 1); else LAUNCH_SHADE_CLS(false, 1); }   // (classes exist for Sobol' / Halton, untextured, single-level: mi_scene_upload)
-                else if (cls == 2) { if (env) LAUNCH_SHADE_CLS(true, 2); else LAUNCH_SHADE_CLS(false, 2); }
+                else if (cls == 1) { if (env) LAUNCH_SHADE_CLS(true, 1); else LAUNCH_SHADE_CLS(false, 1); }   // (classes exist for Sobol' / Halton, untextured, single-level: mi_scene_upload; class 2's part takes the generic instance below)
                 else if (cls == 3) { if (env) LAUNCH_SHADE_CLS(true, 3); else LAUNCH_SHADE_CLS(false, 3); }
                 else if (env) LAUNCH_SHADE(true, false);
                 else LAUNCH_SHADE(false, false);
@@ -2942,7 +2942,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 PathState part = ps;
                 part.shade_key_lo = sp.keyLo; part.shade_key_hi = sp.keyHi;
                 part.shade_role = (uint32_t)sp.role; part.shade_cls_min = c->shadeClsMin; part.shade_all_hi = c->shadeAllHi;
-                if (sp.cls < 0) shade_vol(part); else shade_plain(part, sp.cls);
+                if (sp.cls < 0) shade_vol(part); else shade_plain(part, c->shadeClsGeneric ? 0 : sp.cls);
             }
         }
         toc(c);

@@ -308,17 +308,20 @@ template <bool U> PT_DEV void LoadBxdf(mi_bxdf &dst, const mi_bxdf *p) {
     else dst = *p;
 }
 PT_DEV const mi_bxdf *Generic(const mi_bxdf *b) { return b; }
-// Material CLASSES of the shading kernel (k_shade<..., CLS>, round 5).  The material sort orders its keys class by class (mi_ctx::shadeParts) and each class's part of the
-// sorted queue is shaded by an instance that was compiled with the lobe kinds of that class ONLY, everything in line: no calls, no lobe switch over nine kinds, and a
-// register allocation that is the class's own instead of the worst case of all materials.  The arithmetic per lobe is the generic routines' (same bodies, below).
-//   0  every material (the round-4 kernel: out-of-line BxDF routines)
-//   1  matte: exactly one unscaled LambertianReflection lobe
-//   2  diffuse / glossy reflection: 1-2 unscaled lobes out of {LambertianReflection, MicrofacetReflection} (plastic, uber without Kr / Kt / opacity, metal)
+// Material CLASSES of the shading kernel (round 5).  The material sort orders its keys class by class (mi_ctx::shadeParts) and each class's part of the sorted queue is
+// shaded by its own launch.  What that buys was measured on the MI355X (profiles/r05_e_*): waves that run concurrently then execute the SAME lobe code -- k_shade with
+// its out-of-line routines is ~120 KB against a 64 KB instruction cache -- and C3's shading drops 38 -> 33.6 ms at 16 spp with the generic instance alone; a class instance
+// pays where it is SMALL (class 1: 33 KB in line, equal to the generic instance on its part; class 3: no light sampling at all) and loses where in-lining multiplies code
+// (class 2 in line = 150 KB: 5.5 ms per bounce against the generic instance's 4.0 -- removed).  The arithmetic per lobe is the generic routines' (same bodies, below).
+//   0  every other material: the generic instance (out-of-line BxDF routines)
+//   1  matte: exactly one unscaled LambertianReflection lobe -- k_shade<..., CLS = 1>, everything in line
+//   2  diffuse / glossy reflection: 1-2 unscaled lobes out of {LambertianReflection, MicrofacetReflection} (plastic, uber without Kr / Kt / opacity, metal): a part of its own,
+//      shaded by the generic instance
 //   3  specular only: 0-2 unscaled lobes out of {SpecularReflection, SpecularTransmission, FresnelSpecular} (mirror, smooth glass; materials without any lobe, e.g. the
-//      black matte of light sources): no light sampling at all
+//      black matte of light sources): k_shade<..., CLS = 3>, no light sampling at all
 #define PT_CLS_COUNT 4
 template <int CLS> PT_DEV constexpr bool ClsHas(int type) {
-    return CLS == 0 || (CLS == 1 && type == MI_BXDF_LAMBERT_R) || (CLS == 2 && (type == MI_BXDF_LAMBERT_R || type == MI_BXDF_MICROFACET_R)) ||
+    return CLS == 0 || (CLS == 1 && type == MI_BXDF_LAMBERT_R) ||
            (CLS == 3 && (type == MI_BXDF_SPECULAR_R || type == MI_BXDF_SPECULAR_T || type == MI_BXDF_FRESNEL_SPEC));
 }
 template <bool U, int CLS> PT_DEV RGB BxdfF_body(const mi_bxdf *bp, const V3 &wo, const V3 &wi) {
@@ -330,17 +333,6 @@ template <bool U, int CLS> PT_DEV RGB BxdfF_body(const mi_bxdf *bp, const V3 &wo
     const int type = CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)b.type;
     if constexpr (ClsHas<CLS>(MI_BXDF_LAMBERT_R)) if (type == MI_BXDF_LAMBERT_R) return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     if constexpr (CLS == 1 || CLS == 3) return RGB(0.f);   // (class 3: specular lobes evaluate to zero)
-    if constexpr (CLS == 2) {
-        // MicrofacetReflection::f reflection.cpp:226-236
-        Distrib dist{b.alphax, b.alphay, b.distrib};
-        Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
-        V3 wh = wi + wo;
-        if (cosThetaI == 0 || cosThetaO == 0) return RGB(0.f);
-        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return RGB(0.f);
-        wh = Normalize(wh);
-        RGB F = FresnelEvaluate(b, Dot(wi, wh));
-        return rgb3(b.R) * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
-    }
     switch (type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
@@ -414,12 +406,6 @@ template <bool U, int CLS> PT_DEV Float BxdfPdf_body(const mi_bxdf *bp, const V3
     const int type = CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)b.type;
     if constexpr (ClsHas<CLS>(MI_BXDF_LAMBERT_R)) if (type == MI_BXDF_LAMBERT_R) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     if constexpr (CLS == 1 || CLS == 3) return 0;
-    if constexpr (CLS == 2) {   // MicrofacetReflection::Pdf :418-423
-        if (!SameHemisphere(wo, wi)) return 0;
-        Distrib dist{b.alphax, b.alphay, b.distrib};
-        V3 wh = Normalize(wo + wi);
-        return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
-    }
     switch (type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
@@ -498,16 +484,6 @@ template <bool U, int CLS> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const
             *wi = CosineSampleHemisphere(u0, u1);
             if (wo.z < 0) wi->z *= -1;
             *pdf = BxdfPdf_body<U, CLS>(bp, wo, *wi);
-            if (needF) f = BxdfF_body<U, CLS>(bp, wo, *wi);
-            return f;
-        }
-        if constexpr (CLS == 2) {   // MicrofacetReflection::Sample_f :405-416
-            if (wo.z == 0) return RGB(0.f);
-            Distrib dist{b.alphax, b.alphay, b.distrib};
-            V3 wh = dist.Sample_wh(wo, u0, u1);
-            *wi = Reflect(wo, wh);
-            if (!SameHemisphere(wo, *wi)) return RGB(0.f);
-            *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
             if (needF) f = BxdfF_body<U, CLS>(bp, wo, *wi);
             return f;
         }
@@ -661,7 +637,7 @@ template <bool U, int CLS = 0> struct BSDF_T {
             nb = m->n_bxdfs; tpk = 0;
             for (int i = 0; i < nb; ++i) tpk |= (uint32_t)(m->bxdfs[i].type & 15) << (4 * i);
         }
-        if constexpr (CLS >= 2) __builtin_assume(nb >= 0 && nb <= 2);   // (classes 2 and 3: at most two lobes; class 3 also takes the materials without any lobe)
+        if constexpr (CLS == 3) __builtin_assume(nb >= 0 && nb <= 2);   // (class 3: at most two lobes, also the materials without any lobe)
     }
     PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     PT_DEV V3 LocalToWorld(const V3 &v) const {
