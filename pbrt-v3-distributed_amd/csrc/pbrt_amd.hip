@@ -189,14 +189,20 @@ PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
     *base = lo;
     *n = hi - lo;
 }
+#ifndef PT_DYN_INTERLEAVE
+#define PT_DYN_INTERLEAVE 1   /* block class x takes the grains x, x + 8, x + 16, ... of the range instead of its x-th contiguous eighth (0: round 2's partition, the A/B partner) */
+#endif
 struct DynIter {
-    uint32_t segBeg, segEnd, cur, end;
+    // Round 5: the eighths are INTERLEAVED, grain by grain.  The range is the material-sorted queue, and a contiguous eighth handed XCD x the vertices of three or four
+    // materials -- whose cost differs by 2x between matte and the microfacet materials: the XCDs with the expensive eighths finished last (no stealing across classes) and
+    // identical runs differed by 17 % (profiles/r05_e_*, r05_f_*: equal wave cycles, equal instruction-cache hit rates, 38.2-44.7 ms in one launch against 33.6 when the queue
+    // was shaded class by class).  Grain g goes to class g mod 8, so every XCD shades the same mix of materials.  Capacity: a class takes ceil(grains / 8) grains <= n / 8 + one
+    // grain of items, as before (PathState::seg_cap).
+    uint32_t n, seg, cur, end;
     uint32_t *cursor;
-    PT_DEV DynIter(uint32_t n, uint32_t *cursor_) {
-        const uint32_t seg = blockIdx.x & 7;
-        const uint32_t per = ((((n + PT_BLOCK - 1) / PT_BLOCK + 7) / 8) * PT_BLOCK);   // the eighth ChunkIter gives the class: <= seg_cap items
-        segBeg = seg * per;
-        segEnd = segBeg + per < n ? segBeg + per : (segBeg < n ? n : segBeg);
+    PT_DEV DynIter(uint32_t n_, uint32_t *cursor_) {
+        seg = blockIdx.x & 7;
+        n = n_;
         cursor = cursor_ + seg * QC_STRIDE;
         cur = end = 0;
     }
@@ -205,9 +211,19 @@ struct DynIter {
         uint32_t base = 0;
         if (__lane_id() == 0) base = atomicAdd(cursor, PT_DYN_GRAIN);
         base = __shfl(base, 0);
+#if PT_DYN_INTERLEAVE
+        const uint32_t first = (base * 8u) + seg * PT_DYN_GRAIN;   // grain (base / GRAIN) * 8 + seg
+        if (base >= 0x1fffffffu - PT_DYN_GRAIN || first >= n) return false;
+        cur = first;
+        end = cur + PT_DYN_GRAIN < n ? cur + PT_DYN_GRAIN : n;
+#else
+        const uint32_t per = ((((n + PT_BLOCK - 1) / PT_BLOCK + 7) / 8) * PT_BLOCK);   // the eighth ChunkIter gives the class: <= seg_cap items
+        const uint32_t segBeg = seg * per;
+        const uint32_t segEnd = segBeg + per < n ? segBeg + per : (segBeg < n ? n : segBeg);
         if (segBeg + base >= segEnd) return false;
         cur = segBeg + base;
         end = cur + PT_DYN_GRAIN < segEnd ? cur + PT_DYN_GRAIN : segEnd;
+#endif
         return true;
     }
     PT_DEV uint32_t item() const { return cur + __lane_id(); }
@@ -2615,7 +2631,9 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     {
         const uint32_t nm = d->n_materials, nk = nm + 2;
         const bool volAll = c->volKernel && !c->sssRoute;   // k_shade_vol shades every vertex
-        bool classes = !volAll && !c->hasInst && !(c->sssRoute ? c->plainTex : c->hasTex) && !MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
+        // (textured scenes: parts by the KIND of material -- the per-lane evaluation of matte / plastic + uber + metal / the rest; every part takes the generic textured instance)
+        const bool texParts = c->sssRoute ? c->plainTex : c->hasTex;
+        bool classes = !volAll && !c->hasInst && !MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
         { const char *e = std::getenv("PBRT_AMD_SHADE_CLASSES"); if (e && e[0] == '0') classes = false; c->shadeClsGeneric = e && e[0] == 'g'; }
         auto classify = [&](const mi_material &m) -> int {
             if (m.n_bxdfs == 0) return 3;   // no lobe at all (e.g. a matte material with black Kd, the usual material of light sources): nothing to sample -- the leanest instance
@@ -2632,7 +2650,12 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
             return glossy ? 2 : (spec ? 3 : 0);
         };
         std::vector<int> cls(nm, 0);
-        for (uint32_t m = 0; m < nm; ++m) cls[m] = (c->sssRoute && needsVol[m]) ? -1 : (classes ? classify(d->materials[m]) : 0);
+        auto classifyTex = [&](uint32_t m) -> int {
+            const mi_material_desc &md = d->material_descs[m];
+            if (!md.textured) return classify(d->materials[m]);
+            return md.type == MI_MAT_MATTE ? 1 : ((md.type == MI_MAT_PLASTIC || md.type == MI_MAT_UBER || md.type == MI_MAT_METAL) ? 2 : 0);
+        };
+        for (uint32_t m = 0; m < nm; ++m) cls[m] = (c->sssRoute && needsVol[m]) ? -1 : (classes ? (texParts && d->material_descs ? classifyTex(m) : classify(d->materials[m])) : 0);
         std::vector<uint32_t> remap(nk);
         uint32_t nextKey = 0;
         bool identity = true;
@@ -2718,7 +2741,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     // (+ the shading launches' headroom: each of up to PT_SHADE_PARTS_MAX parts of the sorted queue is cut into eighths of its own, ceil(ceil(n_i / 256) / 8) * 256
     // <= n_i / 8 + 256 items per class and part -- ADVICE r4: two parts could overrun a segment sized for one launch by up to 512 entries)
     const uint32_t chunks = (cap + PT_BLOCK - 1) / PT_BLOCK;
-    ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK + PT_SHADE_PARTS_MAX * PT_BLOCK;
+    ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK + PT_SHADE_PARTS_MAX * (PT_DYN_GRAIN > PT_BLOCK ? PT_DYN_GRAIN : PT_BLOCK);   // (DynIter hands a class whole grains: up to one grain beyond n_i / 8 per part)
     const size_t qcap = (size_t)QSEG * ps.seg_cap;
     ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, qcap);
     ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);

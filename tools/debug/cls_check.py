@@ -33,7 +33,8 @@ if not scenes:
     scenes = [os.path.join(ROOT, "scenes", "cornell.pbrt"), os.path.join(ROOT, "scenes", "materials.pbrt"),
               gen("sanmiguel", os.path.join(tmp, "sm.pbrt"), "--tris", "60000", "--res", "96", "64", "--spp", "8"),
               gen("sanmiguel", os.path.join(tmp, "sm_sss.pbrt"), "--tris", "60000", "--res", "96", "64", "--spp", "4", "--subsurface"),
-              gen("bathroom", os.path.join(tmp, "bath.pbrt"), "--tris", "20000", "--res", "96", "64", "--spp", "8", "--maxdepth", "12")]
+              gen("bathroom", os.path.join(tmp, "bath.pbrt"), "--tris", "20000", "--res", "96", "64", "--spp", "8", "--maxdepth", "12"),
+              gen("sanmiguel", os.path.join(tmp, "sm_tex.pbrt"), "--tris", "60000", "--res", "96", "64", "--spp", "4", "--textured", "--leafmask")]
 bad = 0
 for s in scenes:
     a, ca = render(s, {"PBRT_AMD_SHADE_CLASSES": "0"})
