@@ -97,19 +97,16 @@ struct PathState {
     int spill_per_thread;
     uint32_t cap;
     uint32_t vol_tr;           // k_trace<1> only: "volpath" scenes in wavefront form -- the MIS term is attenuated by the homogeneous medium's transmittance over the hit distance (NeeRec::pad[0] = sigma_t)
-    // The material-sorted queue is shaded in PARTS, one launch each (mi_ctx::shadeParts): the sort orders its keys part by part (key_remap, applied by k_keycount) --
-    // first the material classes of k_shade<..., CLS> (pt_shade.h), then, in scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF materials
-    // (mi_ctx::sssRoute), those materials' keys LAST.  A launch walks the keys [shade_key_lo, shade_key_hi) of the sorted queue (ShadeRange).
+    // The material-sorted queue is shaded in PARTS, one launch each (mi_ctx::shadeParts): in scenes under Integrator "path" whose only reason for k_shade_vol are BSSRDF
+    // materials (mi_ctx::sssRoute) the sort puts those materials' keys LAST (key_remap, applied by k_keycount), k_shade takes the first part, k_shade_vol the second.  A
+    // launch walks the keys [shade_key_lo, shade_key_hi) of the sorted queue (ShadeRange).  (Round 5 also built parts per material CLASS with in-line instances -- matte,
+    // diffuse + glossy, specular-only -- and measured them against one launch over the interleaved DynIter partition: +0.9 % / -3.4 % / 0 on C3 / C2 / C4,
+    // profiles/r05_cde_*, r05_fg_*: removed.)
     float4 *sss_log_o, *sss_log_d;   // k_sss_probe_tail's lists of counted hits (SssLog, pt_volpath.h): sss_log_cap entries per thread for the first sss_log_threads threads of the launch; null: off
     uint32_t *sss_log_inst;
     uint32_t sss_log_threads, sss_log_cap;
     const uint32_t *key_remap;   // [nkeys] or null
     uint32_t shade_key_lo, shade_key_hi;   // the launch's part of the sorted queue in (remapped) keys; hi = 0xffffffff: to the end
-    // Class parts pay for themselves only on long queues: every launch ends with a tail of its own (~one DynIter grab of the slowest wave), and deep bounces leave a few
-    // thousand paths (C4 at maxdepth 30: four parts per bounce cost +15 % of the shading time, profiles/r05_b_*).  The launches of a bounce therefore decide ON THE DEVICE,
-    // from the same counter: with fewer than shade_cls_min vertices for k_shade the class launches (shade_role 1) do nothing and the generic launch (shade_role 2) takes
-    // every k_shade key [0, shade_key_hi); otherwise each takes its own keys.  shade_role 0: no such decision (classes off, k_shade_vol's part).
-    uint32_t shade_cls_min, shade_role, shade_all_hi;   // (shade_all_hi: the key behind k_shade's last key, 0xffffffff = the end)
 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHADOW = 2, QC_MIS = 3, QC_SORTED = 4, QC_BINNED = 5, QC_SHADOW2 = 6, QC_MIS2 = 7, QC_SSS = 8, QC_PROBE0 = 9, QC_PROBE1 = 10, QC_CONT = 11, QC_ROWS = 12 };
 #define QSEG 8u
@@ -167,25 +164,19 @@ struct ChunkIter {
 // classes: a class appends to ITS segment of the output queues, whose capacity is one eighth of the items (ensure_state).
 // Static partitions leave the machine part-empty while the slowest blocks finish (k_shade: 2.2 of 3 resident waves per SIMD on average, SQ counters).
 #ifndef PT_DYN_GRAIN
-#define PT_DYN_GRAIN 256u   /* measured on the C3 frame (profiles/r02_h_*): 64 / 128 / 256 / 512 / 1024 / 4096 -> shade 39.4 / 39.1 / 39.3 / 40.0 / 39.9 / 44.0 ms, static 40.7 */
+#define PT_DYN_GRAIN 64u   /* one wave's worth per grab.  Re-measured in round 5 over the interleaved partition (profiles/r05_h_*): 64 / 128 / 256 / 512 -> shade 31.2 / 31.1 / 31.1 / 31.4 ms on C3 (16 spp), 28.6 / 28.4 / 29.4 / 28.7 on C2 (32 spp), 79.6 / 82.2 / 89.2 / 103.4 on C4 (32 spp, maxdepth 30: the short queues of deep bounces end in a tail of one grab); round 2 over contiguous eighths: flat between 64 and 256 */
 #endif
 #ifndef PT_WAVE_SIZE
 #define PT_WAVE_SIZE 64u
 #endif
-// the part of the material-sorted queue a shading launch walks (PathState::shade_key_lo / _hi): [base, base + n).  Every launch cuts ITS part into eighths for the
-// eight block classes (DynIter), so a class appends up to n_part / 8 + PT_BLOCK entries per part to its queue segment: PathState::seg_cap carries that headroom
+// the part of the material-sorted queue a shading launch walks (PathState::shade_key_lo / _hi): [base, base + n).  Every launch deals ITS part out to the eight block
+// classes grain by grain (DynIter), so a class appends up to n_part / 8 + one grain of entries per part to its queue segment: PathState::seg_cap carries that headroom
 // for PT_SHADE_PARTS_MAX parts (ensure_state).
-#define PT_SHADE_PARTS_MAX 6
+#define PT_SHADE_PARTS_MAX 2
 PT_DEV uint32_t ShadeKeyPos(const PathState &ps, uint32_t key, uint32_t total) { return key == 0xffffffffu ? total : (key ? ps.keyoffset[key] : 0u); }   // first position of `key` in the sorted queue
 PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
     const uint32_t total = ps.qcount[QCI(QC_SORTED, 0)];
     uint32_t lo = ShadeKeyPos(ps, ps.shade_key_lo, total), hi = ShadeKeyPos(ps, ps.shade_key_hi, total);
-    if (ps.shade_role) {
-        const uint32_t nk = ShadeKeyPos(ps, ps.shade_all_hi, total);   // the vertices k_shade sees in this bounce
-        const bool few = nk < ps.shade_cls_min;
-        if (ps.shade_role == 1 && few) hi = lo;   // a class part: nothing to do
-        if (ps.shade_role == 2 && few) lo = 0;    // the generic part (the last of k_shade's parts): every k_shade key
-    }
     *base = lo;
     *n = hi - lo;
 }
@@ -1117,13 +1108,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #define PT_SHADE_SC_PARAM DevScene sc
 #define PT_SHADE_SC_ARG sc
 #endif
-// CLS: the material class of the launch's part of the sorted queue (pt_shade.h; mi_ctx::shadeParts): 0 = any material (out-of-line BxDF routines; also what class 2's part runs),
-// 1 matte, 3 specular only -- these two carry their lobe kinds in line and nothing else
-#ifndef PT_SHADE_CLS_WAVES
-#define PT_SHADE_CLS_WAVES 3   /* measured (profiles/r05_b_*): 3 / 4 / 5 waves per SIMD = 168 / 128 / 96 VGPRs -> C3 shade 30.9 / 36.5 / 51.6 ms at 16 spp (one generic launch: 37.6): the spills cost more than the occupancy buys */
-#endif
-template <bool ENV, int SMP, bool TEX, bool INST = false, int CLS = 0>
-__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? PT_SHADE_CLS_WAVES : PT_SHADE_WAVES))) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
+template <bool ENV, int SMP, bool TEX, bool INST = false>
+__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
 #if PT_SHADE_ARGPTR
     const DevScene &sc0 = *scp;
 #define sc sc0
@@ -1220,8 +1206,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
                 } else {
                     TriHit th;
                     TriangleTest(p0, p1, p2, iro, ird, PT_INFINITY, &th);   // same code, same inputs as the traversal: same b0,b1,b2,t
-                    if constexpr (CLS != 0) { isect = BuildIsectBody(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)); isect.wo = Normalize(-ird); isect.prim = hr.x; }   // (in line: MakeIsect's two fields)
-                    else isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), ird, hr.x);
+                    isect = MakeIsect(BuildIsectPre(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2)), ird, hr.x);
                     if (TEX) ix = BuildIsectTex(tinfo.x, tsr, p0, p1, p2, V3(th.b0, th.b1, th.b2));
                 }
                 if constexpr (INST) {
@@ -1260,7 +1245,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
                     if (SameAs(matIdx, matU)) {
                     matTodo = false;
                     const mi_material *matPtr = sc.materials + matU;
-                    typedef BSDF_T<!TEX, CLS> BS;
+                    typedef BSDF_T<!TEX> BS;
                     mi_material laneMat;
                     if (TEX) {
                         // isect.ComputeScatteringFunctions(ray, arena, true) path.cpp:107: ComputeDifferentials (camera rays only: every
@@ -1277,7 +1262,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
                     }
                     BS bsdf(isect, matPtr, TEX ? nullptr : sc.mat_pack, matU);
                     // ---- UniformSampleOneLight (core/integrator.cpp:85-106)
-                    if (CLS != 3 && bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {   // (class 3: specular lobes only -- no light is sampled)
+                    if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
                         Float funcInt = sc.light_func_int;
                         const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
@@ -1319,9 +1304,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
                             const DevLight &light = sc.lights[lightNum];
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
                             PROBE(6)   // light pick
-                            LightSample ls = ENV ? SampleLiAny<CLS != 0>(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
-                                                 : (CLS ? SampleLiBody(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
-                                                        : SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1));
+                            LightSample ls = ENV ? SampleLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1)
+                                                 : SampleLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, uL0, uL1);
                             PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
@@ -1353,8 +1337,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : (CLS ? P
                                     Float weight = 1;
                                     bool ok = true;
                                     if (!sampledSpecular) {
-                                        lightPdf = ENV ? PdfLiAny<CLS != 0>(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi)
-                                                       : (CLS ? PdfLiBody(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi) : PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi));
+                                        lightPdf = ENV ? PdfLiAny(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi) : PdfLi(GeomTables(sc), &light, isect.p, isect.pError, isect.n, wi);
                                         if (lightPdf == 0) ok = false;
                                         else weight = PowerHeuristic(scatteringPdf, lightPdf);
                                     }
@@ -1633,7 +1616,7 @@ struct mi_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t evShaded = nullptr, evNeeDone = nullptr;
     bool overlapNee = false;
-    int numCUs = 256, gridBlocks = 1024, gridShade = 1024, gridShadeCls = 1024;
+    int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
     double hotProbeShare = 0;   // share of the probe paths' node visits that fell on the nodes now in nodesq[0 .. n_hot)
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
@@ -1655,11 +1638,8 @@ struct mi_ctx {
     bool trLean = true;                      // LAUNCH_TRACE_TR_SHADOW
     bool sssRoute = false;                   // ... under Integrator "path" with plain direct-lighting rays: only the vertices on BSSRDF materials go to k_shade_vol, the others to k_shade (PathState::key_remap; PBRT_AMD_SSS_ROUTE=0: k_shade_vol shades everything)
     const uint32_t *keyRemap = nullptr;
-    struct ShadePart { int cls; uint32_t keyLo, keyHi; int role; };   // role: PathState::shade_role   // cls: material class of k_shade<..., CLS> (pt_shade.h), -1: k_shade_vol; keys [keyLo, keyHi) of the remapped key space, keyHi = 0xffffffff: to the end
-    std::vector<ShadePart> shadeParts;       // the launches that shade the material-sorted queue, in key order (PBRT_AMD_SHADE_CLASSES=0: one k_shade launch for every material class)
-    uint32_t shadeClsMin = 4u << 20;         // PathState::shade_cls_min (PBRT_AMD_SHADE_CLASS_MIN): class launches below this many k_shade vertices per bounce lose to their own tails
-    uint32_t shadeAllHi = 0xffffffffu;       // PathState::shade_all_hi
-    bool shadeClsGeneric = false;            // PBRT_AMD_SHADE_CLASSES=generic (measurement aid): the parts of the classes, each shaded by the GENERIC instance -- what a class's vertices cost without its instance
+    struct ShadePart { bool vol; uint32_t keyLo, keyHi; };   // vol: k_shade_vol's part; keys [keyLo, keyHi) of the remapped key space, 0xffffffff = the end of the queue
+    std::vector<ShadePart> shadeParts;       // the launches that shade the material-sorted queue, in key order
     bool volWave = false;                    // ... and its direct-lighting rays go through the shadow / MIS queues (k_shade_vol<true>; walked: volTr, grid media: volSplit, BSSRDF materials: sssWave)
     bool volKernel = false;                  // Integrator "volpath" or materials with a BSSRDF: k_shade_vol shades (row f4)
     DevVol vol;                              // its extra tables (device pointers)
@@ -1854,7 +1834,6 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     c->numCUs = prop.multiProcessorCount;
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     c->gridShade = ((c->numCUs * PT_SHADE_GRID_PER_CU + 7) / 8) * 8;   // k_shade: a multiple of what is resident at PT_SHADE_WAVES per SIMD
-    c->gridShadeCls = ((c->numCUs * 4 * PT_SHADE_CLS_WAVES + 7) / 8) * 8;   // the class instances of k_shade: the same four rounds of what is resident at THEIR waves per SIMD
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { mi_ctx_destroy(c); return -1; }
@@ -2625,82 +2604,26 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
 #if PT_SHADE_ARGPTR
     if (!c->scDev) { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); HIP_TRY(hipStreamSynchronize(c->stream)); }
 #endif
-    // ---- the parts the material-sorted queue is shaded in (PathState::key_remap, ShadeRange).  Key order: [class 1 | class 2 | class 3 | class 0 materials, escaped rays,
-    // null-BSDF surfaces | (sssRoute) the materials k_shade_vol must see].  Classes (pt_shade.h, ClsHas): from the constant lobe lists, for the k_shade instances that read
-    // wave-uniform lobe lists and draw their dimensions in one batch -- no textured material among those k_shade sees, no two-level scene, Sobol' / Halton.
+    // ---- the parts the material-sorted queue is shaded in (PathState::key_remap, ShadeRange): one, or with sssRoute two -- key order [materials k_shade sees, escaped
+    // rays, null-BSDF surfaces | the materials k_shade_vol must see]
     {
         const uint32_t nm = d->n_materials, nk = nm + 2;
-        const bool volAll = c->volKernel && !c->sssRoute;   // k_shade_vol shades every vertex
-        // (textured scenes: parts by the KIND of material -- the per-lane evaluation of matte / plastic + uber + metal / the rest; every part takes the generic textured instance)
-        const bool texParts = c->sssRoute ? c->plainTex : c->hasTex;
-        bool classes = !volAll && !c->hasInst && !MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
-        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASSES"); if (e && e[0] == '0') classes = false; c->shadeClsGeneric = e && e[0] == 'g'; }
-        auto classify = [&](const mi_material &m) -> int {
-            if (m.n_bxdfs == 0) return 3;   // no lobe at all (e.g. a matte material with black Kd, the usual material of light sources): nothing to sample -- the leanest instance
-            if (m.n_bxdfs < 0 || m.n_bxdfs > 2) return 0;
-            bool lam = true, glossy = true, spec = true;
-            for (int i = 0; i < m.n_bxdfs; ++i) {
-                const mi_bxdf &b = m.bxdfs[i];
-                if (b.scaled) return 0;
-                lam = lam && b.type == MI_BXDF_LAMBERT_R;
-                glossy = glossy && (b.type == MI_BXDF_LAMBERT_R || b.type == MI_BXDF_MICROFACET_R);
-                spec = spec && (b.type == MI_BXDF_SPECULAR_R || b.type == MI_BXDF_SPECULAR_T || b.type == MI_BXDF_FRESNEL_SPEC);
-            }
-            if (lam && m.n_bxdfs == 1) return 1;
-            return glossy ? 2 : (spec ? 3 : 0);
-        };
-        std::vector<int> cls(nm, 0);
-        auto classifyTex = [&](uint32_t m) -> int {
-            const mi_material_desc &md = d->material_descs[m];
-            if (!md.textured) return classify(d->materials[m]);
-            return md.type == MI_MAT_MATTE ? 1 : ((md.type == MI_MAT_PLASTIC || md.type == MI_MAT_UBER || md.type == MI_MAT_METAL) ? 2 : 0);
-        };
-        for (uint32_t m = 0; m < nm; ++m) cls[m] = (c->sssRoute && needsVol[m]) ? -1 : (classes ? (texParts && d->material_descs ? classifyTex(m) : classify(d->materials[m])) : 0);
-        std::vector<uint32_t> remap(nk);
-        uint32_t nextKey = 0;
-        bool identity = true;
-        const int order[4] = {1, 2, 3, 0};
-        bool anyClass = false;
-        for (int o = 0; o < 4 && !volAll; ++o) {
-            const uint32_t lo = nextKey;
-            for (uint32_t m = 0; m < nm; ++m) if (cls[m] == order[o]) remap[m] = nextKey++;
-            if (nextKey > lo) { c->shadeParts.push_back({order[o], lo, nextKey, order[o] ? 1 : 0}); anyClass = anyClass || order[o] != 0; }
-        }
-        if (!volAll) {
-            // escaped rays and null-BSDF surfaces: every k_shade instance handles them -- they ride with the last k_shade part.  With class parts the LAST k_shade part
-            // is the generic one, which doubles as the short-queue fallback (PathState::shade_role 2); a scene without class-0 materials gets one with no keys of its own
-            if (c->shadeParts.empty()) c->shadeParts.push_back({0, nextKey, nextKey, 0});
+        if (c->sssRoute) {
+            std::vector<uint32_t> remap(nk);
+            uint32_t nextKey = 0;
+            for (uint32_t m = 0; m < nm; ++m) if (!needsVol[m]) remap[m] = nextKey++;
             remap[nm] = nextKey++; remap[nm + 1] = nextKey++;
-            c->shadeParts.back().keyHi = nextKey;
-            if (anyClass) {
-                if (c->shadeParts.back().cls != 0) c->shadeParts.push_back({0, nextKey, nextKey, 2});
-                else c->shadeParts.back().role = 2;
-            }
-            c->shadeAllHi = nextKey;
-        }
-        if (volAll || c->sssRoute) {
-            const uint32_t lo = nextKey;
-            for (uint32_t m = 0; m < nm; ++m) if (volAll || cls[m] == -1) remap[m] = nextKey++;
-            if (volAll) { remap[nm] = nextKey++; remap[nm + 1] = nextKey++; }
-            c->shadeParts.push_back({-1, lo, nextKey, 0});
-        }
-        if (nextKey != nk) return fail("mi_scene_upload: internal error (shading parts do not cover the keys)");
-        for (auto &sp : c->shadeParts) { if (sp.keyLo >= nk) sp.keyLo = 0xffffffffu; if (sp.keyHi >= nk) sp.keyHi = 0xffffffffu; }   // (keyoffset has nk entries: the end of the queue is the sorted total)
-        if (c->shadeAllHi >= nk) c->shadeAllHi = 0xffffffffu;
-        { const char *e = std::getenv("PBRT_AMD_SHADE_CLASS_MIN"); if (e && e[0]) c->shadeClsMin = (uint32_t)std::strtoul(e, nullptr, 10); }
-        for (uint32_t k = 0; k < nk; ++k) identity = identity && remap[k] == k;
-        if ((int)c->shadeParts.size() > PT_SHADE_PARTS_MAX) return fail("mi_scene_upload: internal error (too many shading parts)");
-        if (!identity) {
+            const uint32_t split = nextKey;
+            for (uint32_t m = 0; m < nm; ++m) if (needsVol[m]) remap[m] = nextKey++;
+            if (nextKey != nk) return fail("mi_scene_upload: internal error (shading parts do not cover the keys)");
+            c->shadeParts.push_back({false, 0u, split});
+            c->shadeParts.push_back({true, split, 0xffffffffu});
             DevBuf &b = next();
             if (upload(c, b, remap.data(), remap.size() * sizeof(uint32_t))) return -1;
             c->keyRemap = b.as<uint32_t>();
             HIP_TRY(hipStreamSynchronize(c->stream));   // local
-        }
-        if (std::getenv("PBRT_AMD_VERBOSE")) {
-            std::fprintf(stderr, "[pbrt_amd] shading parts:");
-            for (auto &sp : c->shadeParts) std::fprintf(stderr, " [class %d%s: keys %u..%u)", sp.cls, sp.role == 2 ? " + short-queue fallback" : "", sp.keyLo, sp.keyHi);
-            std::fprintf(stderr, "\n");
-        }
+        } else
+            c->shadeParts.push_back({c->volKernel, 0u, 0xffffffffu});
     }
     c->nkeys = d->n_materials + 2;
     if (c->nkeys > 12288) return fail("mi_scene_upload: more than 12286 distinct materials (LDS histogram of the material sort)");
@@ -2861,7 +2784,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
     dim3 grid(c->gridBlocks), block(PT_BLOCK);
     TableTurn turn(c);
     ps.key_remap = c->keyRemap;
-    ps.shade_key_lo = 0; ps.shade_key_hi = 0xffffffffu; ps.shade_role = 0; ps.shade_cls_min = 0; ps.shade_all_hi = 0xffffffffu;
+    ps.shade_key_lo = 0; ps.shade_key_hi = 0xffffffffu;
     HIP_TRY(hipMemsetAsync(ps.qcount, 0, QC_WORDS * sizeof(uint32_t), st));
     if (c->hasTex || c->hasAlpha || c->hasInst)   // the tables of THIS context's scene (stream ordered; contexts sharing a device take turns: TableTurn)
         HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tex), &c->tex, sizeof(DevTex), 0, hipMemcpyHostToDevice, st));
@@ -2934,26 +2857,17 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);               \
         else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
     } while (0)
-#define LAUNCH_SHADE_CLS(ENV, CLS_)                                                                                                              \
-    do {                                                                                                                                         \
-        const dim3 g_(c->gridShadeCls);                                                                                                          \
-        if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, false, false, CLS_>), g_, block, 0, st, PT_SHADE_SC_ARG, ps, qout);                      \
-        else hipLaunchKernelGGL((k_shade<ENV, 0, false, false, CLS_>), g_, block, 0, st, PT_SHADE_SC_ARG, ps, qout);                             \
-    } while (0)
-            auto shade_plain = [&](const PathState &ps, int cls) {
+            auto shade_plain = [&](const PathState &ps) {
                 // (routed subsurface scenes: the BSSRDF materials are always built per hit, mi_material_desc::textured -- what counts here are the materials k_shade sees)
                 const bool tex = c->sssRoute ? c->plainTex : c->hasTex;
                 const bool env = c->hasEnvMap || c->hasSpheres;
                 if (c->hasInst) LAUNCH_SHADE(true, true, true);   // two-level scenes: the general instance + interactions carried back from the object's space
                 else if (tex) LAUNCH_SHADE(true, true);           // textured materials: the general instance (radiance maps, spheres, per-lane lobe lists)
-                else if (cls == 1) { if (env) LAUNCH_SHADE_CLS(true, 1); else LAUNCH_SHADE_CLS(false, 1); }   // (classes exist for Sobol' / Halton, untextured, single-level: mi_scene_upload; class 2's part takes the generic instance below)
-                else if (cls == 3) { if (env) LAUNCH_SHADE_CLS(true, 3); else LAUNCH_SHADE_CLS(false, 3); }
                 else if (env) LAUNCH_SHADE(true, false);
                 else LAUNCH_SHADE(false, false);
             };
 #undef LAUNCH_SHADE
-#undef LAUNCH_SHADE_CLS
-            // one launch per part of the sorted queue (mi_ctx::shadeParts: material classes of k_shade, then the vertices k_shade_vol must see)
+            // one launch per part of the sorted queue (mi_ctx::shadeParts: k_shade's vertices, then those k_shade_vol must see)
             bool firstPart = true;
             for (const mi_ctx::ShadePart &sp : c->shadeParts) {
                 if (!firstPart) {
@@ -2964,8 +2878,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 firstPart = false;
                 PathState part = ps;
                 part.shade_key_lo = sp.keyLo; part.shade_key_hi = sp.keyHi;
-                part.shade_role = (uint32_t)sp.role; part.shade_cls_min = c->shadeClsMin; part.shade_all_hi = c->shadeAllHi;
-                if (sp.cls < 0) shade_vol(part); else shade_plain(part, c->shadeClsGeneric ? 0 : sp.cls);
+                if (sp.vol) shade_vol(part); else shade_plain(part);
             }
         }
         toc(c);

@@ -308,32 +308,13 @@ template <bool U> PT_DEV void LoadBxdf(mi_bxdf &dst, const mi_bxdf *p) {
     else dst = *p;
 }
 PT_DEV const mi_bxdf *Generic(const mi_bxdf *b) { return b; }
-// Material CLASSES of the shading kernel (round 5).  The material sort orders its keys class by class (mi_ctx::shadeParts) and each class's part of the sorted queue is
-// shaded by its own launch.  What that buys was measured on the MI355X (profiles/r05_e_*): waves that run concurrently then execute the SAME lobe code -- k_shade with
-// its out-of-line routines is ~120 KB against a 64 KB instruction cache -- and C3's shading drops 38 -> 33.6 ms at 16 spp with the generic instance alone; a class instance
-// pays where it is SMALL (class 1: 33 KB in line, equal to the generic instance on its part; class 3: no light sampling at all) and loses where in-lining multiplies code
-// (class 2 in line = 150 KB: 5.5 ms per bounce against the generic instance's 4.0 -- removed).  The arithmetic per lobe is the generic routines' (same bodies, below).
-//   0  every other material: the generic instance (out-of-line BxDF routines)
-//   1  matte: exactly one unscaled LambertianReflection lobe -- k_shade<..., CLS = 1>, everything in line
-//   2  diffuse / glossy reflection: 1-2 unscaled lobes out of {LambertianReflection, MicrofacetReflection} (plastic, uber without Kr / Kt / opacity, metal): a part of its own,
-//      shaded by the generic instance
-//   3  specular only: 0-2 unscaled lobes out of {SpecularReflection, SpecularTransmission, FresnelSpecular} (mirror, smooth glass; materials without any lobe, e.g. the
-//      black matte of light sources): k_shade<..., CLS = 3>, no light sampling at all
-#define PT_CLS_COUNT 4
-template <int CLS> PT_DEV constexpr bool ClsHas(int type) {
-    return CLS == 0 || (CLS == 1 && type == MI_BXDF_LAMBERT_R) ||
-           (CLS == 3 && (type == MI_BXDF_SPECULAR_R || type == MI_BXDF_SPECULAR_T || type == MI_BXDF_FRESNEL_SPEC));
-}
-template <bool U, int CLS> PT_DEV RGB BxdfF_body(const mi_bxdf *bp, const V3 &wo, const V3 &wi) {
+template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
     if constexpr (!U) {   // SeparableBSSRDFAdapter::f core/bssrdf.h:162-167 (TransportMode::Radiance): only per-lane lobe lists carry it (k_shade_vol)
         if (b.type == MI_BXDF_BSSRDF_ADAPTER) { RGB f(BssrdfSw(b.etaB, wi)); return f * (b.etaB * b.etaB); }
     }
-    const int type = CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)b.type;
-    if constexpr (ClsHas<CLS>(MI_BXDF_LAMBERT_R)) if (type == MI_BXDF_LAMBERT_R) return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
-    if constexpr (CLS == 1 || CLS == 3) return RGB(0.f);   // (class 3: specular lobes evaluate to zero)
-    switch (type) {
+    switch (b.type) {
     case MI_BXDF_LAMBERT_R: return rgb3(b.R) * PT_INV_PI;   // reflection.cpp:178
     case MI_BXDF_LAMBERT_T: return rgb3(b.T) * PT_INV_PI;   // :187
     case MI_BXDF_OREN_NAYAR: {                              // :197-219
@@ -392,21 +373,15 @@ template <bool U, int CLS> PT_DEV RGB BxdfF_body(const mi_bxdf *bp, const V3 &wo
     default: return RGB(0.f);   // specular lobes evaluate to zero
     }
 }
-template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) { return BxdfF_body<U, 0>(bp, wo, wi); }
-// (the lobes of class 1-3 materials are unscaled: mi_scene_upload's classification)
-template <bool U = true, int CLS = 0, class BP = BxdfConst> PT_DEV RGB BxdfF(BP b, const V3 &wo, const V3 &wi) {
-    if constexpr (CLS != 0) return BxdfF_body<U, CLS>(Generic(b), wo, wi);
+template <bool U = true, class BP = BxdfConst> PT_DEV RGB BxdfF(BP b, const V3 &wo, const V3 &wi) {
     RGB f = BxdfF_unscaled<U>(Generic(b), wo, wi);
     return b->scaled ? RGB(b->scale[0], b->scale[1], b->scale[2]) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
 }
-template <bool U, int CLS> PT_DEV Float BxdfPdf_body(const mi_bxdf *bp, const V3 &wo, const V3 &wi) {
+template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
     if constexpr (!U) { if (b.type == MI_BXDF_BSSRDF_ADAPTER) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0; }   // BxDF::Pdf reflection.cpp:387-389
-    const int type = CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)b.type;
-    if constexpr (ClsHas<CLS>(MI_BXDF_LAMBERT_R)) if (type == MI_BXDF_LAMBERT_R) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
-    if constexpr (CLS == 1 || CLS == 3) return 0;
-    switch (type) {
+    switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
     case MI_BXDF_LAMBERT_T: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;                          // :400-403
     case MI_BXDF_MICROFACET_R: {                                                                                       // :418-423
@@ -434,28 +409,14 @@ template <bool U, int CLS> PT_DEV Float BxdfPdf_body(const mi_bxdf *bp, const V3
     default: return 0;
     }
 }
-template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) { return BxdfPdf_body<U, 0>(bp, wo, wi); }
-template <bool U, int CLS> PT_DEV Float BxdfPdfC(const mi_bxdf *bp, const V3 &wo, const V3 &wi) {
-    if constexpr (CLS != 0) return BxdfPdf_body<U, CLS>(bp, wo, wi);
-    return BxdfPdf<U>(bp, wo, wi);
-}
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
 struct BxdfSample { RGB f; V3 wi; Float pdf; int sampledType; };
-template <bool U, int CLS = 0> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
+template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
 template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const V3 wo, Float u0, Float u1, int sampledTypeIn) {   // by value: registers, no scratch
     BxdfSample r;
     r.wi = V3(); r.pdf = 0; r.sampledType = sampledTypeIn;
     r.f = BxdfSample_f_impl<U>(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
     return r;
-}
-template <bool U, int CLS> PT_DEV BxdfSample BxdfSample_fC(const mi_bxdf *bp, const V3 &wo, Float u0, Float u1, int sampledTypeIn) {
-    if constexpr (CLS != 0) {
-        BxdfSample r;
-        r.wi = V3(); r.pdf = 0; r.sampledType = sampledTypeIn;
-        r.f = BxdfSample_f_impl<U, CLS>(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
-        return r;
-    }
-    return BxdfSample_f<U>(bp, wo, u0, u1, sampledTypeIn);
 }
 // PT_SAMPLE_SKIP_F in *sampledType: the caller (BSDF::Sample_f) discards the f of a non-specular lobe -- it re-evaluates f over all matching
 // lobes afterwards (reflection.cpp:747-763) -- so the lobe's own f (one more D, G and Fresnel evaluation for the microfacet lobes) is not computed
@@ -464,7 +425,7 @@ template <bool U, int CLS> PT_DEV BxdfSample BxdfSample_fC(const mi_bxdf *bp, co
 #else
 #define PT_SAMPLE_SKIP_F 0x100
 #endif
-template <bool U, int CLS> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
+template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
     const bool needF = !(*sampledType & PT_SAMPLE_SKIP_F);
@@ -477,50 +438,6 @@ template <bool U, int CLS> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const
             *pdf = BxdfPdf<U>(bp, wo, *wi);
             return BxdfF_unscaled<U>(bp, wo, *wi);
         }
-    }
-    if constexpr (CLS != 0) {   // the class instances: the same statements as the cases below, lobe kinds outside the class compiled out (unscaled lobes)
-        const int type = CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)b.type;
-        if constexpr (ClsHas<CLS>(MI_BXDF_LAMBERT_R)) if (type == MI_BXDF_LAMBERT_R) {   // BxDF::Sample_f reflection.cpp:378-385
-            *wi = CosineSampleHemisphere(u0, u1);
-            if (wo.z < 0) wi->z *= -1;
-            *pdf = BxdfPdf_body<U, CLS>(bp, wo, *wi);
-            if (needF) f = BxdfF_body<U, CLS>(bp, wo, *wi);
-            return f;
-        }
-        if constexpr (CLS == 3) {
-            if (type == MI_BXDF_SPECULAR_R) {                  // :136-143
-                *wi = V3(-wo.x, -wo.y, wo.z);
-                *pdf = 1;
-                return FresnelEvaluate(b, CosTheta(*wi)) * rgb3(b.R) / AbsCosTheta(*wi);
-            }
-            if (type == MI_BXDF_SPECULAR_T) {                  // :150-166
-                bool entering = CosTheta(wo) > 0;
-                Float etaI = entering ? b.etaA : b.etaB, etaT = entering ? b.etaB : b.etaA;
-                if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return RGB(0.f);
-                *pdf = 1;
-                RGB ft = rgb3(b.T) * (RGB(1.f) - RGB(FrDielectric(CosTheta(*wi), b.etaA, b.etaB)));
-                ft = ft * ((etaI * etaI) / (etaT * etaT));
-                return ft / AbsCosTheta(*wi);
-            }
-            {                                                  // FresnelSpecular :477-511
-                Float F = FrDielectric(CosTheta(wo), b.etaA, b.etaB);
-                if (u0 < F) {
-                    *wi = V3(-wo.x, -wo.y, wo.z);
-                    *sampledType = BSDF_SPECULAR | BSDF_REFLECTION;
-                    *pdf = F;
-                    return F * rgb3(b.R) / AbsCosTheta(*wi);
-                }
-                bool entering = CosTheta(wo) > 0;
-                Float etaI = entering ? b.etaA : b.etaB, etaT = entering ? b.etaB : b.etaA;
-                if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return RGB(0.f);
-                RGB ft = rgb3(b.T) * (1 - F);
-                ft = ft * ((etaI * etaI) / (etaT * etaT));
-                *sampledType = BSDF_SPECULAR | BSDF_TRANSMISSION;
-                *pdf = 1 - F;
-                return ft / AbsCosTheta(*wi);
-            }
-        }
-        return f;
     }
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
@@ -615,7 +532,7 @@ template <> struct MatPtrOf<false> { typedef const mi_material *type; };
 #ifndef PT_LOBE_HEADER
 #define PT_LOBE_HEADER 1
 #endif
-template <bool U, int CLS = 0> struct BSDF_T {
+template <bool U> struct BSDF_T {
     typedef typename MatPtrOf<U>::type MatPtr;
     MatPtr m;   // U: wave-uniform (see above); !U: this lane's own record
     V3 ns, ng, ss, ts;
@@ -625,11 +542,10 @@ template <bool U, int CLS = 0> struct BSDF_T {
     // per-material table mi_scene_upload builds (DevScene::mat_pack); otherwise gathered once here.
     int nb;
     uint32_t tpk;
-    PT_DEV int LobeType(int i) const { return CLS == 1 ? (int)MI_BXDF_LAMBERT_R : (int)((tpk >> (4 * i)) & 15u); }
+    PT_DEV int LobeType(int i) const { return (int)((tpk >> (4 * i)) & 15u); }
     PT_DEV BSDF_T(const Isect &si, const mi_material *mat, const uint2 *packTable = nullptr, int matIndex = 0)
         : m((MatPtr)(unsigned long long)mat), ns(si.ns), ng(si.n), ss(Normalize(si.dpdus)) {
         ts = Cross(ns, ss);
-        if constexpr (CLS == 1) { nb = 1; tpk = MI_BXDF_LAMBERT_R; return; }   // (class 1: one LambertianReflection lobe, known at compile time)
         if (PT_LOBE_HEADER && U && packTable) {
             const __attribute__((address_space(4))) uint32_t *pt = (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)packTable;
             nb = (int)pt[2 * matIndex]; tpk = pt[2 * matIndex + 1];   // constant address space + wave-uniform index: one s_load_dwordx2
@@ -637,7 +553,6 @@ template <bool U, int CLS = 0> struct BSDF_T {
             nb = m->n_bxdfs; tpk = 0;
             for (int i = 0; i < nb; ++i) tpk |= (uint32_t)(m->bxdfs[i].type & 15) << (4 * i);
         }
-        if constexpr (CLS == 3) __builtin_assume(nb >= 0 && nb <= 2);   // (class 3: at most two lobes, also the materials without any lobe)
     }
     PT_DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     PT_DEV V3 LocalToWorld(const V3 &v) const {
@@ -656,7 +571,7 @@ template <bool U, int CLS = 0> struct BSDF_T {
         for (int i = 0; i < nb; ++i) {
             auto b = &m->bxdfs[i];
             int t = BxdfFlags(LobeType(i));
-            if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U, CLS>(b, wo, wi);
+            if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
         }
         return f;
     }
@@ -667,7 +582,7 @@ template <bool U, int CLS = 0> struct BSDF_T {
         Float pdf = 0.f;
         int matchingComps = 0;
         for (int i = 0; i < nb; ++i)
-            if (Matches(BxdfFlags(LobeType(i)), flags)) { ++matchingComps; pdf += BxdfPdfC<U, CLS>(Generic(&m->bxdfs[i]), wo, wi); }
+            if (Matches(BxdfFlags(LobeType(i)), flags)) { ++matchingComps; pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi); }
         return matchingComps > 0 ? pdf / matchingComps : 0.f;
     }
     PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
@@ -690,14 +605,14 @@ template <bool U, int CLS = 0> struct BSDF_T {
         for (int i = 0; i < nb; ++i)
             if (chosen == i) {
                 bt = BxdfFlags(LobeType(i));
-                BxdfSample bs = BxdfSample_fC<U, CLS>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
+                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
         if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
             for (int i = 0; i < nb; ++i)
-                if (i != chosen && Matches(BxdfFlags(LobeType(i)), type)) *pdf += BxdfPdfC<U, CLS>(Generic(&m->bxdfs[i]), wo, wi);
+                if (i != chosen && Matches(BxdfFlags(LobeType(i)), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
         if (matchingComps > 1) *pdf /= matchingComps;
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
@@ -705,7 +620,7 @@ template <bool U, int CLS = 0> struct BSDF_T {
             for (int i = 0; i < nb; ++i) {
                 auto b = &m->bxdfs[i];
                 int t = BxdfFlags(LobeType(i));
-                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U, CLS>(b, wo, wi);
+                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
             }
         }
         return f;
@@ -863,7 +778,7 @@ PT_DEV LightRegs LoadLight(const DevLight *dl) {
 PT_DEV RGB AreaL(const LightRegs &l, const V3 &n, const V3 &w) { return (l.two_sided || Dot(n, w) > 0) ? l.L : RGB(0.f); }
 
 // Light::Sample_Li.  ref*: the reference point's p, pError, n (what Sample_Li and VisibilityTester's SpawnRayTo use).
-PT_DEV LightSample SampleLiBody(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, Float u0, Float u1) {
+PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1) {
     LightSample lsv;
     LightSample *ls = &lsv;
     Isect ref;
@@ -963,12 +878,8 @@ PT_DEV LightSample SampleLiBody(const GeomTables sc, const DevLight *dl, const V
     return lsv;
 }
 
-PT_FN LightSample SampleLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1) {
-    return SampleLiBody(sc, dl, refP, refPError, refN, u0, u1);
-}
-
 // Light::Pdf_Li
-PT_DEV Float PdfLiBody(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, const V3 &wi) {
+PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, const V3 wi) {
     const LightRegs l = LoadLight(dl);
     if (l.type == MI_LIGHT_AREA_TRI) {   // Shape::Pdf(ref, wi) core/shape.cpp:72-87: intersect that one triangle
         V3 o = OffsetRayOrigin(refP, refPError, refN, wi);
@@ -977,7 +888,7 @@ PT_DEV Float PdfLiBody(const GeomTables sc, const DevLight *dl, const V3 &refP, 
         if ((l.mesh_flags & 0x80000000u) || !TriangleTest(p0, p1, p2, o, wi, PT_INFINITY, &th)) return 0;   // bit 31: TRI_FLAG_REJECT of that triangle
         // Of the interaction Triangle::Intersect builds (shapes/triangle.cpp:293-421) the pdf reads the hit point and |n . wi|: the point is the barycentric sum and the
         // normal Normalize(Cross(dp02, dp12)) up to its SIGN (shading normals / ReverseOrientation only flip it, :346-421), which AbsDot drops -- the same values bit for
-        // bit as through BuildIsect (round 4), without the shading record's fetch, dpdu / dpdv and the shading frame.
+        // bit as through BuildIsect (rounds 1-4), without the shading record's fetch, dpdu / dpdv and the shading frame (round 5).
         const V3 lp = th.b0 * p0 + th.b1 * p1 + th.b2 * p2;
         const V3 ln = Normalize(Cross(p0 - p2, p1 - p2));
         Float pdf = DistanceSquared(refP, lp) / (AbsDot(ln, -wi) * l.area);
@@ -1002,8 +913,6 @@ PT_DEV Float PdfLiBody(const GeomTables sc, const DevLight *dl, const V3 &refP, 
     return 0;
 }
 
-PT_FN Float PdfLi(const GeomTables sc, const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, const V3 wi) { return PdfLiBody(sc, dl, refP, refPError, refN, wi); }
-
 // DiffuseAreaLight on a Sphere: Sample_Li (lights/diffuse.cpp:68-81 over Sphere::Sample(ref, u)) and Pdf_Li.  Separate
 // out-of-line routines, dispatched on the light type by the caller, so that SampleLi / PdfLi keep their register budget.
 PT_FN LightSample SampleLiSphere(const DevLight *dl, const V3 refP, const V3 refPError, const V3 refN, Float u0, Float u1) {
@@ -1021,14 +930,11 @@ PT_FN LightSample SampleLiSphere(const DevLight *dl, const V3 refP, const V3 ref
     ls->Li = AreaL(*dl, ss.n, -ls->wi);
     return lsv;
 }
-// INL: the class instances of k_shade take the light routines in line (no call: one register allocation over the whole vertex)
-template <bool INL = false> PT_DEV LightSample SampleLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, Float u0, Float u1) {
+PT_DEV LightSample SampleLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, Float u0, Float u1) {
     if (dl->type == MI_LIGHT_AREA_SPHERE) return SampleLiSphere(dl, refP, refPError, refN, u0, u1);
-    if constexpr (INL) return SampleLiBody(sc, dl, refP, refPError, refN, u0, u1);
     return SampleLi(sc, dl, refP, refPError, refN, u0, u1);
 }
-template <bool INL = false> PT_DEV Float PdfLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, const V3 &wi) {
+PT_DEV Float PdfLiAny(const GeomTables sc, const DevLight *dl, const V3 &refP, const V3 &refPError, const V3 &refN, const V3 &wi) {
     if (dl->type == MI_LIGHT_AREA_SPHERE) return SpherePdf((const mi_sphere *)dl->ext, refP, refPError, refN, wi);
-    if constexpr (INL) return PdfLiBody(sc, dl, refP, refPError, refN, wi);
     return PdfLi(sc, dl, refP, refPError, refN, wi);
 }
