@@ -42,7 +42,7 @@ struct V2 { Float x, y; };
 // address.  With U they take the argument from the first active lane and read the tables through the CONSTANT address space: scalar loads, scalar branches.
 // U = false: per-lane nodes (alpha masks inside the traversal, k_shade_vol's per-lane materials, mi_texture_eval).
 #ifndef PT_TEX_UNIFORM
-#define PT_TEX_UNIFORM 0
+#define PT_TEX_UNIFORM 1   /* measured twice: shade -2.3 % (profiles/r04_v_*), -3 % (r05_i_*); 0 = per-lane gathers of the same tables (A/B) */
 #endif
 template <bool U, class T> struct UPtr { typedef const T *P; static PT_DEV P of(const T *p) { return p; } };
 template <class T> struct UPtr<true, T> {
@@ -145,7 +145,9 @@ template <class TP> PT_DEV V2 CylinderST(TP t, const V3 &P) {   // CylindricalMa
 }
 PT_DEV V2 DivV2(const V2 &a, const V2 &b, Float f) { Float inv = (Float)1 / f; return V2{(a.x - b.x) * inv, (a.y - b.y) * inv}; }
 struct Map2DOut { V2 st, dstdx, dstdy; };
-template <bool U> __device__ __noinline__ Map2DOut Map2D(const mi_texture *tp, const TexCtx si) {
+// (TexCtx travels BY REFERENCE through the out-of-line texture routines since round 5: by value its 22 words were copied to the callee's stack frame at every call --
+// TexEval -> EvalNode -> Map2D -- while a routine reads two to six of them; the caller's copy lives in its frame once)
+template <bool U> __device__ __noinline__ Map2DOut Map2DAny(const mi_texture *tp, const TexCtx &si) {
     const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(tp);
     Map2DOut o;
     switch (t->mapping) {
@@ -181,6 +183,18 @@ template <bool U> __device__ __noinline__ Map2DOut Map2D(const mi_texture *tp, c
         break;
     }
     return o;
+}
+// the (u, v) mapping in line -- what nearly every image map uses; the three other mappings stay out of line
+template <bool U> PT_DEV Map2DOut Map2D(const mi_texture *tp, const TexCtx &si) {
+    const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(tp);
+    if (t->mapping == MI_MAP_UV) {   // UVMapping2D texture.cpp:86-94
+        Map2DOut o;
+        o.dstdx = V2{t->su * si.dudx, t->sv * si.dvdx};
+        o.dstdy = V2{t->su * si.dudy, t->sv * si.dvdy};
+        o.st = V2{t->su * si.u + t->du, t->sv * si.v + t->dv};
+        return o;
+    }
+    return Map2DAny<U>(tp, si);
 }
 
 // ---- MIPMap<T> (core/mipmap.h:201-353)
@@ -271,7 +285,7 @@ template <bool U> __device__ __noinline__ RGB MipLookup(const DevImage *imp, V2 
 // (A recursive formulation kept every level's live state in registers across the calls: 280 VGPRs at depth 6, one
 // wave per SIMD in the shading kernel; the flat loop needs what one node needs.)
 #define PT_TEX_MAX_PROG 24
-template <bool U> __device__ __noinline__ RGB EvalNode(const mi_texture *tp, const RGB t1v, const RGB t2v, const RGB amtv, const TexCtx si) {
+template <bool U> __device__ __noinline__ RGB EvalNode(const mi_texture *tp, const RGB t1v, const RGB t2v, const RGB amtv, const TexCtx &si) {
     const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(tp);
     switch (t->type) {
     case MI_TEX_CONSTANT: return Rgb3P(t->value);                     // constant.h:54
@@ -359,24 +373,36 @@ template <bool U> __device__ __noinline__ RGB EvalNode(const mi_texture *tp, con
     }
     return RGB(0.f);
 }
-template <bool U = false> __device__ __noinline__ RGB TexEval(int node, const TexCtx si) {
+template <bool U = false> __device__ __noinline__ RGB TexEvalAny(int node, const TexCtx &si) {
     node = UIdx<U>(node);
     if (node < 0 || (uint32_t)node >= c_tex.n_nodes) return RGB(0.f);
     const typename UPtr<U, int32_t>::P progOff = UPtr<U, int32_t>::of(c_tex.prog_off);
     const int off = progOff[node], len = progOff[node + 1] - off;
     if (len == 1) return EvalNode<U>(c_tex.nodes + node, RGB(0.f), RGB(0.f), RGB(0.f), si);   // a leaf (the common case: constants, image maps)
-    RGB val[PT_TEX_MAX_PROG];
+    Float val[3 * PT_TEX_MAX_PROG];   // (plain words, left uninitialised: every step is written before a later step reads it)
+    auto get = [&](int k) { return k >= 0 ? RGB(val[3 * k], val[3 * k + 1], val[3 * k + 2]) : RGB(0.f); };
+    auto put = [&](int k, const RGB &v) { val[3 * k] = v.r; val[3 * k + 1] = v.g; val[3 * k + 2] = v.b; };
     if constexpr (U) {
         const typename UPtr<U, int32_t>::P prog = UPtr<U, int32_t>::of(reinterpret_cast<const int32_t *>(c_tex.prog));   // int4 steps, read word by word (scalar loads)
         for (int k = 0; k < len; ++k) {
             const int sx = prog[4 * (off + k)], sy = prog[4 * (off + k) + 1], sz = prog[4 * (off + k) + 2], sw = prog[4 * (off + k) + 3];
-            val[k] = EvalNode<U>(c_tex.nodes + sx, sy >= 0 ? val[sy] : RGB(0.f), sz >= 0 ? val[sz] : RGB(0.f), sw >= 0 ? val[sw] : RGB(0.f), si);
+            put(k, EvalNode<U>(c_tex.nodes + sx, get(sy), get(sz), get(sw), si));
         }
     } else {
         for (int k = 0; k < len; ++k) {
             const int4 st = c_tex.prog[off + k];
-            val[k] = EvalNode<U>(c_tex.nodes + st.x, st.y >= 0 ? val[st.y] : RGB(0.f), st.z >= 0 ? val[st.z] : RGB(0.f), st.w >= 0 ? val[st.w] : RGB(0.f), si);
+            put(k, EvalNode<U>(c_tex.nodes + st.x, get(st.y), get(st.z), get(st.w), si));
         }
     }
-    return val[len - 1];
+    return get(len - 1);
+}
+// Texture<T>::Evaluate of node `node`.  A CONSTANT node -- most parameters of most materials -- is answered in line from the node table (EvalNode's own statement for it,
+// constant.h:54): no call, no frame.  Everything else goes through the out-of-line program loop.
+template <bool U = false> PT_DEV RGB TexEval(int node, const TexCtx &si) {
+    const int nu = UIdx<U>(node);
+    if (nu >= 0 && (uint32_t)nu < c_tex.n_nodes) {
+        const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(c_tex.nodes + nu);
+        if (t->type == MI_TEX_CONSTANT) return Rgb3P(t->value);
+    }
+    return TexEvalAny<U>(node, si);
 }
