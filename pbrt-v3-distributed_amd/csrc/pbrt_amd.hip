@@ -555,14 +555,28 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_TRACEQ_WAVES
 #define PT_TRACEQ_WAVES 6   /* waves per SIMD the register allocator must leave room for (2 blocks x 12 waves on 4 SIMDs) */
 #endif
+// Round 5, MID: the closest-hit / any-hit instances of all-triangle scenes WITH alpha masks.  The mask interpreter behind the wave-wide alpha phase needs ~100 VGPRs beside the
+// traversal's own state: at round 2's shape (6 x 256 threads, no register cap) the instance took 149 VGPRs = 3 waves per SIMD and had no hot nodes.  MID = two 512-thread
+// blocks per CU (16 stack entries x 512 x 4 B = 32 KiB + the 512 hot nodes = 64 KiB per block), 4 waves per SIMD: a 128-VGPR cap under which the compiler spills what lives
+// across the (rare) interpreter call, and every node step of the hot nodes leaves the vector-memory path as in the plain instances.
+#ifndef PT_TRACE_MID
+#define PT_TRACE_MID 1   /* 0: round 2's shape for the masked instances (A/B) */
+#endif
+#ifndef PT_TRACE_MID_BLOCK
+#define PT_TRACE_MID_BLOCK 512
+#endif
+#ifndef PT_TRACE_MID_WAVES
+#define PT_TRACE_MID_WAVES 4
+#endif
 template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
     static constexpr bool BIG = QN && PT_HOT_NODES > 0 && MODE != 1 && !ALPHA && !SPHERES;
-    static constexpr int BLOCK = BIG ? PT_TRACEQ_BLOCK : PT_BLOCK;
-    static constexpr int HOT = BIG ? PT_HOT_NODES : 0;
-    static constexpr int NLDS = BIG ? PT_TRACEQ_LDS_STACK : PT_LDS_STACK;
-    static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : PT_TRACE_WAVES;
+    static constexpr bool MID = QN && PT_HOT_NODES > 0 && MODE != 1 && ALPHA && !SPHERES && PT_TRACE_MID;
+    static constexpr int BLOCK = BIG ? PT_TRACEQ_BLOCK : (MID ? PT_TRACE_MID_BLOCK : PT_BLOCK);
+    static constexpr int HOT = (BIG || MID) ? PT_HOT_NODES : 0;
+    static constexpr int NLDS = (BIG || MID) ? PT_TRACEQ_LDS_STACK : PT_LDS_STACK;
+    static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : (MID ? PT_TRACE_MID_WAVES : PT_TRACE_WAVES);
     static constexpr int LDS_BYTES = NLDS * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
-    static constexpr int PER_CU = BIG ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
+    static constexpr int PER_CU = (BIG || MID) ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
     static constexpr bool STEP2 = QN && PT_STEP2 && PT_PEND_LEAF && !PT_STACK_T;   // every quantised-node instance (round 4; BIG or the 256-thread shape alike)
     static_assert(NLDS >= PT_LDS_STACK_MIN, "the spill slices are sized for stack_need - PT_LDS_STACK_MIN entries");
     static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
@@ -2450,10 +2464,11 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (5 + 8 * (int64_t)(sc.max_depth + 1) > PBRT_AMD_SOBOL_NDIM) return fail("mi_scene_upload: maxdepth needs more than 1024 Sobol' dimensions");
     // hot nodes of the quantised tree (k_hot_probe): measured per scene AND camera, nodes renumbered on the device so that nodesq[0 .. n_hot) are the
     // most visited ones (the root stays node 0: every probe path visits it; ties go to the lower index, so the numbering is a function of the
-    // scene alone).  Only for scenes whose closest-hit / any-hit instances keep hot nodes (TraceShape::BIG: all-triangle, no alpha masks).
+    // scene alone).  Only for scenes whose closest-hit / any-hit instances keep hot nodes (TraceShape::BIG / MID: all-triangle scenes; the probe itself ignores alpha masks --
+    // it only ranks nodes).
     // PBRT_AMD_HOT=0 keeps the reference order and n_hot = 0 (every step through the vector-memory path; A/B and tests).
     sc.n_hot = 0;
-    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && !c->hasSpheres && !c->hasAlpha && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
+    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && !c->hasSpheres && (!c->hasAlpha || PT_TRACE_MID) && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
         const char *e = std::getenv("PBRT_AMD_HOT");
         if (!(e && e[0] == '0')) {
             const uint32_t n = sc.n_nodes, K = std::min<uint32_t>(PT_HOT_NODES, n);
@@ -2746,6 +2761,7 @@ static void harvest(mi_ctx *c) {
 #define LAUNCH_TRACE(MODE)                                                                                          \
     do {                                                                                                            \
         if (c->hasInst) LAUNCH_TRACE_I(MODE, true, true, true, false);        /* two-level scenes: the general instance (spheres, masks, instances) */ \
+        else if (c->useQ && c->hasAlpha && !c->hasSpheres) LAUNCH_TRACE_I(MODE, false, true, false, true);   /* masks, no spheres: TraceShape::MID */          \
         else if (c->useQ && c->hasAlpha) LAUNCH_TRACE_I(MODE, true, true, false, true);     /* quantised nodes; spheres + masks in the leaf step */     \
         else if (c->useQ && c->hasSpheres) LAUNCH_TRACE_I(MODE, true, false, false, true);                             \
         else if (c->useQ) LAUNCH_TRACE_I(MODE, false, false, false, true);    /* the default: all-triangle single-level scenes */                      \
@@ -3249,12 +3265,13 @@ int mi_trace_info(mi_ctx *c, int64_t out[8]) {
     out[0] = mode;
     out[1] = mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128;
     out[2] = c->sc.n_nodes;
-    const bool big = mode == 5 && !c->hasSpheres && !c->hasAlpha && TraceShape<0, false, false, true>::BIG;
+    const bool mid = mode == 5 && !c->hasSpheres && c->hasAlpha && TraceShape<0, false, true, true>::MID;
+    const bool big = mid || (mode == 5 && !c->hasSpheres && !c->hasAlpha && TraceShape<0, false, false, true>::BIG);
     out[3] = big ? TraceShape<0, false, false, true>::NLDS : PT_LDS_STACK;
     out[4] = c->sc.n_hot;
     out[5] = (int64_t)(c->hotProbeShare * 1e6);
-    out[6] = big ? TraceShape<0, false, false, true>::BLOCK : PT_BLOCK;
-    out[7] = big ? TraceShape<0, false, false, true>::PER_CU : PT_GRID_PER_CU;
+    out[6] = mid ? TraceShape<0, false, true, true>::BLOCK : (big ? TraceShape<0, false, false, true>::BLOCK : PT_BLOCK);
+    out[7] = mid ? TraceShape<0, false, true, true>::PER_CU : (big ? TraceShape<0, false, false, true>::PER_CU : PT_GRID_PER_CU);
     return 0;
 }
 

@@ -1000,6 +1000,9 @@ PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounte
         hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
     if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) {
         if constexpr (DEFER) { *cand = true; return; }   // (tMax cannot change before the alpha phase: only this lane's leaf steps shrink it)
+#ifdef PT_ALPHA_TWICE   /* measurement aid: the mask evaluated twice -- the time difference to the plain build is what the mask evaluations cost */
+        { Float b0x = th.b0; asm volatile("" : "+v"(b0x)); if (TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, b0x, th.b1, th.b2, ANY)) asm volatile("s_nop 0"); }
+#endif
         hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
     }
     if (hitPrim) {

@@ -382,17 +382,20 @@ template <bool U = false> __device__ __noinline__ RGB TexEvalAny(int node, const
     Float val[3 * PT_TEX_MAX_PROG];   // (plain words, left uninitialised: every step is written before a later step reads it)
     auto get = [&](int k) { return k >= 0 ? RGB(val[3 * k], val[3 * k + 1], val[3 * k + 2]) : RGB(0.f); };
     auto put = [&](int k, const RGB &v) { val[3 * k] = v.r; val[3 * k + 1] = v.g; val[3 * k + 2] = v.b; };
+    // one step: the three node kinds that are plain arithmetic on their children -- CONSTANT, SCALE, MIX: EvalNode's own statements -- in line, the others out of line
+    auto step = [&](int k, int sx, int sy, int sz, int sw) {
+        const typename UPtr<U, mi_texture>::P t = UPtr<U, mi_texture>::of(c_tex.nodes + sx);
+        const int type = t->type;
+        if (type == MI_TEX_CONSTANT) put(k, Rgb3P(t->value));                                   // constant.h:54
+        else if (type == MI_TEX_SCALE) put(k, get(sy) * get(sz));                               // scale.h:57-59
+        else if (type == MI_TEX_MIX) { const RGB t1v = get(sy), t2v = get(sz); const Float amt = get(sw).r; put(k, (1 - amt) * t1v + amt * t2v); }   // mix.h:58-62
+        else put(k, EvalNode<U>(c_tex.nodes + sx, get(sy), get(sz), get(sw), si));
+    };
     if constexpr (U) {
         const typename UPtr<U, int32_t>::P prog = UPtr<U, int32_t>::of(reinterpret_cast<const int32_t *>(c_tex.prog));   // int4 steps, read word by word (scalar loads)
-        for (int k = 0; k < len; ++k) {
-            const int sx = prog[4 * (off + k)], sy = prog[4 * (off + k) + 1], sz = prog[4 * (off + k) + 2], sw = prog[4 * (off + k) + 3];
-            put(k, EvalNode<U>(c_tex.nodes + sx, get(sy), get(sz), get(sw), si));
-        }
+        for (int k = 0; k < len; ++k) step(k, prog[4 * (off + k)], prog[4 * (off + k) + 1], prog[4 * (off + k) + 2], prog[4 * (off + k) + 3]);
     } else {
-        for (int k = 0; k < len; ++k) {
-            const int4 st = c_tex.prog[off + k];
-            put(k, EvalNode<U>(c_tex.nodes + st.x, get(st.y), get(st.z), get(st.w), si));
-        }
+        for (int k = 0; k < len; ++k) { const int4 st = c_tex.prog[off + k]; step(k, st.x, st.y, st.z, st.w); }
     }
     return get(len - 1);
 }

@@ -13,6 +13,6 @@ sed -i -E '/^PT_DEV const mi_bxdf \*Generic\(const mi_bxdf \*b\) \{ return b; \}
 sed -i -E 's/extern __shared__ uint32_t lhist\[\];/uint32_t *lhist = (uint32_t *)emu_dyn_lds;/' $B/src/pbrt_amd.cpp
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 $CXX -x c++ -std=c++17 ${EMU_OPT:--O1} -g -fPIC -shared -ffp-contract=off -Wno-everything \
-  -DPT_TRACEQ_BLOCK=1 -DTRACE_REFILL=1 -DTRACE_LEAF_MIN=1 -DTRACE_BATCH=1u -DPT_HOST_EMU=1 -DPT_WAVE_SIZE=1u ${EMU_DEFS} -DPT_WAVE_APPEND3=emu_wave_append3 \
+  -DPT_TRACEQ_BLOCK=1 -DPT_TRACE_MID_BLOCK=1 -DTRACE_REFILL=1 -DTRACE_LEAF_MIN=1 -DTRACE_BATCH=1u -DPT_HOST_EMU=1 -DPT_WAVE_SIZE=1u ${EMU_DEFS} -DPT_WAVE_APPEND3=emu_wave_append3 \
   -I$HERE/shim -I$ROOT/include -I$B/src $B/src/pbrt_amd.cpp $HERE/emu_globals.cpp -o $B/libpbrt_amd_hostemu.so -lpthread -ldl
 echo built $B/libpbrt_amd_hostemu.so
