@@ -163,6 +163,25 @@ def valu_live(wl_args, pmc_steps=1):
             "valu_share_of_wave_lifetime": round(c["SQ_ACTIVE_INST_VALU"] / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4)}
 
 
+def secondary_line(extra):
+    """bench.py itself on a variant workload, 3 steps after 1 warm-up, with a short pbrt_ref crop at full spp; returns the fields of its JSON line worth keeping"""
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--steps", "3", "--warmup", "1", "--traffic", "none", "--cpu-seconds", "8", "--cpu-port-seconds", "0", "--secondary", "off"]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+        line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+    except Exception as e:
+        log("[bench] secondary line failed to run: %s" % e)
+        return {"error": str(e)}
+    if not line:
+        log("[bench] secondary line failed (rc %d): %s" % (r.returncode, (r.stderr or "")[-600:]))
+        return {"error": "rc %d" % r.returncode}
+    log("[bench] secondary line (%s): %.1f Msamples/s, %.1f ms per step (%.0f s)" % (" ".join(extra[:2]), line["value"], line["ms_per_step"], time.time() - t0))
+    return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"], "kernel_ms_per_step": line.get("kernel_ms_per_step"),
+            "workload": line["config"]["workload"], "rays_per_sample": line.get("rays_per_sample"),
+            "parity_crop": (line.get("cpu_baseline") or {}).get("parity_crop"), "cpu_baseline_value": (line.get("cpu_baseline") or {}).get("value")}
+
+
 def traffic_from_file(workload):
     try:
         ent = json.load(open(TRAFFIC_FILE)).get("entries", {}).get(workload)
@@ -304,6 +323,9 @@ def main():
                          "file = the committed profiles/traffic_closest.json entry of exactly this workload and kernel; none = null")
     ap.add_argument("--save-traffic", action="store_true", help="write the live PMC result into profiles/traffic_closest.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--secondary", default="auto", choices=["auto", "on", "off"],
+                    help="also render the San-Miguel-like variant of the default workload (--textured --leafmask: image-mapped / bump-mapped materials, alpha-masked leaf quads) "
+                         "for 3 steps in a child process and report it as secondary.textured_leafmask inside the one JSON line; auto = with the default C3 workload on one GPU")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses GPU 0")
@@ -596,9 +618,23 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
                "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2),
                            "scene": "rank 0 of the node builds it once, the other ranks map the published blob" if world > 1 else "built"}}
-        print(json.dumps(out), flush=True)
     frame.close()
     ctx.close()
+    if rank == 0:
+        # ---- the San-Miguel-like variant beside the headline: what the real scene is -- textured, bump-mapped materials and alpha-masked foliage --
+        # rendered by a child process once this process has released the GPU memory of the headline frame; the headline workload itself is unchanged
+        plain_c3 = args.config == "c3" and not (args.textured or args.leafmask or args.volpath or args.fogbox or args.subsurface or args.smokebox or args.scene)
+        if world == 1 and (args.secondary == "on" or (args.secondary == "auto" and plain_c3 and args.spp == 64 and args.tris == 10_000_000 and args.cpu_seconds > 0)):
+            out["secondary"] = {"textured_leafmask": secondary_line(["--textured", "--leafmask", "--tris", str(args.tris), "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp)])}
+        print(json.dumps(out), flush=True)
+        # parity at full size is part of the measurement: a frame that does not match the reference's is not a result
+        bad = []
+        for name, line in [("headline", out)] + [("secondary." + k, v) for k, v in (out.get("secondary") or {}).items()]:
+            pc = ((line or {}).get("cpu_baseline") or {}).get("parity_crop") if name == "headline" else (line or {}).get("parity_crop")
+            if pc and "pixels_within_tol" in pc and (pc["pixels_within_tol"] < 0.995 or not (pc.get("relMSE", 0) <= 1e-4)):
+                bad.append("%s: %.5f of the crop's pixels within tolerance, relMSE %.3g" % (name, pc["pixels_within_tol"], pc.get("relMSE", float("nan"))))
+        if bad:
+            raise SystemExit("bench.py: the frame does NOT match pbrt_ref's crop -- " + "; ".join(bad))
     if world > 1 and local_rank == 0:   # every rank has passed the final barrier of frame.close(): nobody still needs the file (mappings stay valid anyway)
         for f in (blob, blob + ".failed"):
             try:

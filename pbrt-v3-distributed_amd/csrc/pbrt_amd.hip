@@ -1270,6 +1270,9 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             ComputeDifferentials(isect.p, isect.n, &ix, rdf);
                         }
                         PROBE(14)   // (textured instances) differentials of camera rays
+#ifdef PT_MAT_TWICE   /* measurement aid: the per-lane material evaluation done twice (on copies) -- the time difference to the plain build is what it costs */
+                        { Isect is2 = isect; IsectX ix2 = ix; mi_material lm2; ComputeScatteringFunctionsT<PT_TEX_UNIFORM != 0>(sc.materials, matU, &is2, &ix2, &lm2); if (lm2.n_bxdfs == 12345) L = L + RGB(1.f); }
+#endif
                         ComputeScatteringFunctionsT<PT_TEX_UNIFORM != 0>(sc.materials, matU, &isect, &ix, &laneMat);   // (matU: wave-uniform inside the waterfall)
                         matPtr = &laneMat;
                         PROBE(15)   // (textured instances) the material's textures / bump map -> per-lane lobe list
