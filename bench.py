@@ -636,11 +636,7 @@ def main():
         if bad:
             raise SystemExit("bench.py: the frame does NOT match pbrt_ref's crop -- " + "; ".join(bad))
     if world > 1 and local_rank == 0:   # every rank has passed the final barrier of frame.close(): nobody still needs the file (mappings stay valid anyway)
-        for f in (blob, blob + ".failed"):
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+        par.node_scene_cleanup()
 
 
 if __name__ == "__main__":

@@ -78,18 +78,14 @@ struct PathState {
     uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
     uint2 *keyrank;            // because the sort kernels walk them in queue order, not per path
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
-    uint32_t *q_key;           // spatial bin (RayBinKey) of every path-extension ray k_shade queues, parallel to q_ext[qout]; null: binning off
-    float bin_min[3], bin_scale[3];   // scene bound -> 8 cells per axis
     // Queues are cut into QSEG segments (one per XCD-aligned block class, blockIdx & 7), each with its own fill counter in its own
     // 128-byte line: qcount[QCI(queue, seg)].  A single counter per queue made every wave of the chip hit ONE word -- the L2 serialises
     // same-address atomics at ~88 per microsecond, which is exactly what k_raygen cost (2.07 M wave appends = 24 ms per frame) and most
     // of k_shade's launch time.  Segment `seg` of a queue occupies [seg * seg_cap, seg * seg_cap + count): producers append to the segment
-    // of their own block class, consumers walk (k_keycount / k_scatter / k_raybin_*) or pull from (k_trace) the segments.
-    uint32_t *qcount;          // rows: [0],[1] extension queues, [2] shadow, [3] mis; [4] the material-sorted total, [5] the binned total
+    // of their own block class, consumers walk (k_keycount / k_scatter) or pull from (k_trace) the segments.
+    uint32_t *qcount;          // rows: [0],[1] extension queues, [2] shadow, [3] mis; [4] the material-sorted total
     uint32_t seg_cap;          // entries per queue segment
-    uint32_t trace_contig;     // k_trace<0> only: the queue it is handed is one contiguous array of qcount[QCI(QC_BINNED, 0)] entries (ray binning)
     uint32_t *keycount, *keyoffset;
-    uint32_t *bin_total, *bin_offset;   // [PT_RAYBIN_KEYS]
     uint32_t *blockhist;       // [gridBlocks][nkeys]
     uint32_t *cursor;          // [QSEG * QC_STRIDE] per-segment fetch cursors of k_trace, one 128-byte line each
     unsigned long long *counters;
@@ -180,9 +176,6 @@ PT_DEV void ShadeRange(const PathState &ps, uint32_t *base, uint32_t *n) {
     *base = lo;
     *n = hi - lo;
 }
-#ifndef PT_DYN_INTERLEAVE
-#define PT_DYN_INTERLEAVE 1   /* block class x takes the grains x, x + 8, x + 16, ... of the range instead of its x-th contiguous eighth (0: round 2's partition, the A/B partner) */
-#endif
 struct DynIter {
     // Round 5: the eighths are INTERLEAVED, grain by grain.  The range is the material-sorted queue, and a contiguous eighth handed XCD x the vertices of three or four
     // materials -- whose cost differs by 2x between matte and the microfacet materials: the XCDs with the expensive eighths finished last (no stealing across classes) and
@@ -202,19 +195,10 @@ struct DynIter {
         uint32_t base = 0;
         if (__lane_id() == 0) base = atomicAdd(cursor, PT_DYN_GRAIN);
         base = __shfl(base, 0);
-#if PT_DYN_INTERLEAVE
         const uint32_t first = (base * 8u) + seg * PT_DYN_GRAIN;   // grain (base / GRAIN) * 8 + seg
         if (base >= 0x1fffffffu - PT_DYN_GRAIN || first >= n) return false;
         cur = first;
         end = cur + PT_DYN_GRAIN < n ? cur + PT_DYN_GRAIN : n;
-#else
-        const uint32_t per = ((((n + PT_BLOCK - 1) / PT_BLOCK + 7) / 8) * PT_BLOCK);   // the eighth ChunkIter gives the class: <= seg_cap items
-        const uint32_t segBeg = seg * per;
-        const uint32_t segEnd = segBeg + per < n ? segBeg + per : (segBeg < n ? n : segBeg);
-        if (segBeg + base >= segEnd) return false;
-        cur = segBeg + base;
-        end = cur + PT_DYN_GRAIN < segEnd ? cur + PT_DYN_GRAIN : segEnd;
-#endif
         return true;
     }
     PT_DEV uint32_t item() const { return cur + __lane_id(); }
@@ -542,10 +526,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_HOT_NODES
 #define PT_HOT_NODES 512
 #endif
-// round 4: the quantised-node instances take the interior step with the shorter tail (TravNodeStepQ2 / TravStackB, pt_scene.h); 0 = round 3's step (A/B)
-#ifndef PT_STEP2
-#define PT_STEP2 1
-#endif
+// (round 4: the quantised-node instances of k_trace take the interior step with the shorter tail, TravNodeStepQ2 / TravStackB, pt_scene.h; round 3's step TravNodeStepQ serves
+// the hot-node probe and k_shade_vol's per-lane tracer)
 #ifndef PT_TRACEQ_BLOCK
 #define PT_TRACEQ_BLOCK 768
 #endif
@@ -577,7 +559,7 @@ template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
     static constexpr int WAVES = BIG ? PT_TRACEQ_WAVES : (MID ? PT_TRACE_MID_WAVES : PT_TRACE_WAVES);
     static constexpr int LDS_BYTES = NLDS * BLOCK * (int)sizeof(StackEntry) + HOT * 64;
     static constexpr int PER_CU = (BIG || MID) ? (160 * 1024) / LDS_BYTES : PT_GRID_PER_CU;
-    static constexpr bool STEP2 = QN && PT_STEP2 && PT_PEND_LEAF && !PT_STACK_T;   // every quantised-node instance (round 4; BIG or the 256-thread shape alike)
+    static constexpr bool STEP2 = QN && PT_PEND_LEAF;   // every quantised-node instance (round 4; BIG or the 256-thread shape alike)
     static_assert(NLDS >= PT_LDS_STACK_MIN, "the spill slices are sized for stack_need - PT_LDS_STACK_MIN entries");
     static_assert(PER_CU >= 1, "stacks + hot nodes of one block exceed the CU's 160 KiB of LDS");
     static_assert((size_t)PER_CU * BLOCK <= (size_t)PT_GRID_PER_CU * PT_BLOCK, "the spill slices are sized for gridBlocks x PT_BLOCK threads");
@@ -628,9 +610,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     static_assert(!TR || MODE != 0, "segment walks are for shadow / MIS rays");
     const uint32_t *queue = MODE == 0 ? ps.q_ext[qin] : (MODE == 1 ? ps.q_mis : ps.q_shadow);
     const uint32_t qrow = MODE == 0 ? qin : (MODE == 1 ? ps.qrow_mis : ps.qrow_shadow);
-    const bool contig = MODE == 0 && ps.trace_contig;                                     // binned queue: one array, cut into eighths here
-    const uint32_t nContig = contig ? ps.qcount[QCI(QC_BINNED, 0)] : 0u;
-    const uint32_t segLen = contig ? ((((nContig + 7) / 8) + 63u) & ~63u) : ps.seg_cap;
+    const uint32_t segLen = ps.seg_cap;
     const uint32_t lane = lane_id();
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     uint32_t seg = blockIdx.x & 7, segsTried = 0;
@@ -719,8 +699,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     if (lane == 0) base = atomicAdd(&ps.cursor[seg * QC_STRIDE], TRACE_BATCH);   // one cache line per segment cursor
                     base = __shfl(base, 0);
                     uint32_t segBeg = seg * segLen, segEnd;
-                    if (contig) segEnd = segBeg + segLen < nContig ? segBeg + segLen : (segBeg < nContig ? nContig : segBeg);
-                    else segEnd = segBeg + ps.qcount[QCI(qrow, seg)];
+                    segEnd = segBeg + ps.qcount[QCI(qrow, seg)];
                     if (segBeg + base >= segEnd) {
                         seg = (seg + 1) & 7; ++segsTried;
                         poolNext = poolEnd = 0;
@@ -879,70 +858,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_renumber_nodes(const BVH4QNode *sr
     }
 }
 
-// ---- ray binning before traversal (round 2).  The traversal kernels are bound by the memory side: incoherent rays pull 96 GB through
-// the L2s per launch for a 1.25 GB working set (profiles/r02_*: L2 hit rate 72 %, 113 M misses per launch).  Path-extension rays are
-// therefore binned by WHERE THEY START AND WHICH WAY THEY GO -- 8 x 8 x 8 cells of the scene bound (Morton order) x direction octant =
-// 4096 bins -- with one counting sort per bounce (the queue is order-free: results do not depend on it).  k_trace cuts the queue into
-// 8 contiguous XCD segments, so each XCD's 4 MiB L2 serves one octant of the scene, and the 64 rays a wave pulls come from one cell
-// and one direction octant: they walk the same subtree (hits in L1 / L2 instead of HBM) and take similar numbers of steps.
-#define PT_RAYBIN_KEYS 4096u
-PT_DEV uint32_t RayBinKey(const PathState &ps, const V3 &o, const V3 &d) {
-    int cx = (int)((o.x - ps.bin_min[0]) * ps.bin_scale[0]), cy = (int)((o.y - ps.bin_min[1]) * ps.bin_scale[1]), cz = (int)((o.z - ps.bin_min[2]) * ps.bin_scale[2]);
-    cx = cx < 0 ? 0 : (cx > 7 ? 7 : cx); cy = cy < 0 ? 0 : (cy > 7 ? 7 : cy); cz = cz < 0 ? 0 : (cz > 7 ? 7 : cz);
-    uint32_t m = 0;   // 9-bit Morton code
-#pragma unroll
-    for (int b = 0; b < 3; ++b) m |= (((uint32_t)cx >> b) & 1u) << (3 * b) | (((uint32_t)cy >> b) & 1u) << (3 * b + 1) | (((uint32_t)cz >> b) & 1u) << (3 * b + 2);
-    uint32_t oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
-    return (m << 3) | oct;
-}
-// histogram of the bins per block (LDS atomics; rank of every ray inside its block and bin), as k_keycount does for materials
-__global__ void __launch_bounds__(PT_BLOCK) k_raybin_count(PathState ps, uint32_t qin) {
-    __shared__ uint32_t lhist[PT_RAYBIN_KEYS];
-    for (uint32_t k = threadIdx.x; k < PT_RAYBIN_KEYS; k += PT_BLOCK) lhist[k] = 0;
-    __syncthreads();
-    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
-        if (it.valid()) {
-            uint32_t i = it.item();
-            uint32_t key = ps.q_key[i];
-            uint32_t rank = atomicAdd(&lhist[key], 1u);
-            ps.keyrank[i] = make_uint2(key, rank);
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < PT_RAYBIN_KEYS; k += PT_BLOCK) ps.blockhist[(size_t)blockIdx.x * PT_RAYBIN_KEYS + k] = lhist[k];
-}
-// per bin: exclusive scan over the blocks (in place) + the bin's total; one thread per bin
-__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scan_blocks(PathState ps, uint32_t nblocks) {
-    uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (k >= PT_RAYBIN_KEYS) return;
-    uint32_t acc = 0;
-    for (uint32_t b = 0; b < nblocks; ++b) { uint32_t h = ps.blockhist[(size_t)b * PT_RAYBIN_KEYS + k]; ps.blockhist[(size_t)b * PT_RAYBIN_KEYS + k] = acc; acc += h; }
-    ps.bin_total[k] = acc;
-}
-// exclusive scan over the 4096 bin totals (one block: 16 bins per thread, block scan in LDS)
-__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scan_bins(PathState ps) {
-    __shared__ uint32_t part[PT_BLOCK];
-    const uint32_t per = PT_RAYBIN_KEYS / PT_BLOCK, k0 = threadIdx.x * per;
-    uint32_t acc = 0;
-    for (uint32_t j = 0; j < per; ++j) acc += ps.bin_total[k0 + j];
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < PT_BLOCK; ++t) { uint32_t v = part[t]; part[t] = run; run += v; } }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (uint32_t j = 0; j < per; ++j) { uint32_t v = ps.bin_total[k0 + j]; ps.bin_offset[k0 + j] = run; run += v; }
-    if (threadIdx.x == PT_BLOCK - 1) ps.qcount[QCI(QC_BINNED, 0)] = run;   // the binned queue's length
-}
-__global__ void __launch_bounds__(PT_BLOCK) k_raybin_scatter(PathState ps, uint32_t qin) {
-    for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
-        if (it.valid()) {
-            uint32_t i = it.item();
-            uint2 kr = ps.keyrank[i];
-            ps.q_sorted[ps.bin_offset[kr.x] + ps.blockhist[(size_t)blockIdx.x * PT_RAYBIN_KEYS + kr.x] + kr.y] = ps.q_ext[qin][i];
-        }
-    }
-}
-
+// (Round 2 also binned the path-extension rays by origin cell x direction octant before the traversal -- k_raybin_*: -63 % HBM traffic and -48 % L2 misses in k_trace at
+// UNCHANGED kernel time, profiles/r02_b_* -- the evidence that the traversal is not bound by memory; it cost 3 % of the frame, stayed off, and was removed in round 5.)
 // ---- counting sort of the traced paths by material key, without global atomics:
 //   k_keycount : every (persistent) block histograms the keys of ITS chunks in LDS -- wave ballots merge equal
 //                keys, so an LDS atomic is issued per (wave, distinct key) -- and records each path's rank inside
@@ -1096,9 +1013,6 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
-#ifndef PT_SHADE_DYN
-#define PT_SHADE_DYN 1   /* k_shade / k_shade_vol take their items through DynIter (dynamic, per wave); 0: the static ChunkIter partition (A/B) */
-#endif
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (4 * PT_SHADE_WAVES)   /* four rounds of resident blocks: evens out the static chunk partition (measured best of 1, 2, 4) */
 #endif
@@ -1112,22 +1026,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 // built in the object's space from the transformed ray and carried back to world space (only instantiated together with ENV and TEX)
 // SMP: 0 Sobol' / 1 Halton (the vertex's dimensions drawn in one batch) / 2 the tile-serial samplers (drawn call by call, in the reference's order: the
 // values come from the tile's stream)
-#ifndef PT_SHADE_ARGPTR
-#define PT_SHADE_ARGPTR 0   /* A/B: k_shade takes the DevScene through a pointer that is laundered once per item, so that no scene field is kept in an SGPR across items */
-#endif
-#if PT_SHADE_ARGPTR
-#define PT_SHADE_SC_PARAM const DevScene *__restrict__ scp
-#define PT_SHADE_SC_ARG c->scDev
-#else
-#define PT_SHADE_SC_PARAM DevScene sc
-#define PT_SHADE_SC_ARG sc
-#endif
 template <bool ENV, int SMP, bool TEX, bool INST = false>
-__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(PT_SHADE_SC_PARAM, PathState ps, uint32_t qout) {
-#if PT_SHADE_ARGPTR
-    const DevScene &sc0 = *scp;
-#define sc sc0
-#endif
+__global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
 #if PT_SHADE_PROF
@@ -1141,25 +1041,11 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     uint32_t n, sbase;
     ShadeRange(ps, &sbase, &n);
     uint32_t nseg = 0;
-#if PT_SHADE_DYN
     for (DynIter it(n, ps.cursor); it.more(); it.next()) {
         uint32_t i = it.item();
         PROBE(0)   // loop overhead / queue bookkeeping of the previous item
         bool active = it.valid();
-#if PT_SHADE_ARGPTR
-#undef sc
-        const DevScene *scl = scp;
-        asm volatile("" : "+s"(scl));   // a new pointer as far as the optimiser knows: every scene field used by this item is (re)loaded inside the item
-        const DevScene &sc = *scl;
-#endif
-#else
-    for (ChunkIter it(n); it.more(); it.next()) {
-        uint32_t i = it.item();
-        PROBE(0)   // loop overhead / queue bookkeeping of the previous item
-        bool active = i < n;
-#endif
         bool cont = false, wantShadow = false, wantMis = false;
-        uint32_t rayKey = 0;   // spatial bin of the continuation ray (ray binning, see RayBinKey)
         uint32_t slot = 0;
         if (active) {
             slot = ps.q_sorted[sbase + i];
@@ -1245,7 +1131,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     // null BSDF: step through the surface, same bounce count, no sampler use (path.cpp:108-113)
                     V3 no = OffsetRayOrigin(isect.p, isect.pError, isect.n, rd);
                     ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
-                    if (ps.q_key) rayKey = RayBinKey(ps, no, rd);
                     cont = true;
                     noDiff = true;
                 } else {
@@ -1270,10 +1155,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             ComputeDifferentials(isect.p, isect.n, &ix, rdf);
                         }
                         PROBE(14)   // (textured instances) differentials of camera rays
-#ifdef PT_MAT_TWICE   /* measurement aid: the per-lane material evaluation done twice (on copies) -- the time difference to the plain build is what it costs */
-                        { Isect is2 = isect; IsectX ix2 = ix; mi_material lm2; ComputeScatteringFunctionsT<PT_TEX_UNIFORM != 0>(sc.materials, matU, &is2, &ix2, &lm2); if (lm2.n_bxdfs == 12345) L = L + RGB(1.f); }
-#endif
-                        ComputeScatteringFunctionsT<PT_TEX_UNIFORM != 0>(sc.materials, matU, &isect, &ix, &laneMat);   // (matU: wave-uniform inside the waterfall)
+                        ComputeScatteringFunctionsT<true>(sc.materials, matU, &isect, &ix, &laneMat);   // (matU: wave-uniform inside the waterfall)
                         matPtr = &laneMat;
                         PROBE(15)   // (textured instances) the material's textures / bump map -> per-lane lobe list
                     }
@@ -1403,7 +1285,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             else beta = beta / (1 - q);
                         }
                         if (cont) {
-                            if (ps.q_key) rayKey = RayBinKey(ps, no, wi);
                             ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                             ps.rec[slot].ray_d = make_float4(wi.x, wi.y, wi.z, 0);
                             ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -1421,7 +1302,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         uint32_t posE, posS, posM;
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;   // this block class's segment of the three queues
         PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, wantShadow, wantMis, &posE, &posS, &posM);
-        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (cont) ps.q_ext[qout][qbase + posE] = slot;
         if (wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (wantMis) ps.q_mis[qbase + posM] = slot;
         PROBE(13)   // L store + queue appends
@@ -1643,7 +1524,6 @@ struct mi_ctx {
     int tilesRank = -1, tilesWorld = -1;     // the tile list resident in `tiles` (re-uploaded only when the sharding changes)
     std::vector<uint32_t> tilesHost;         // kept alive: the upload is asynchronous
     size_t tilesCount = 0;
-    bool rayBin = false;                     // bin path-extension rays by origin cell x direction octant before traversal (PBRT_AMD_RAYBIN=0: off)
     bool useQ = false;                       // interior steps over the 64-byte quantised BVH4 nodes (pt_bvh4q.h): single-level scenes
     DevTex tex;                              // host copy of c_tex for this scene (device pointers)
     bool volTr = false;                      // ... with BSDF-less interfaces: the shadow / MIS queues are served by k_vol_tr (pt_volpath.h)
@@ -1887,9 +1767,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     if (d->integrator_type != MI_INTEGRATOR_PATH && d->integrator_type != MI_INTEGRATOR_VOLPATH) return fail("mi_scene_upload: unknown integrator type");
     if (d->n_media && (!d->media || (d->integrator_type == MI_INTEGRATOR_VOLPATH && d->camera_medium >= (int32_t)d->n_media))) return fail("mi_scene_upload: bad medium table");
     if (d->material_bssrdf && (!d->bssrdf_tables || !d->material_descs || !d->textures)) return fail("mi_scene_upload: BSSRDF materials without tables / material descriptions");
-    // ray binning before traversal: measured -63 % HBM traffic and -48 % L2 misses in the closest-hit kernel at UNCHANGED kernel time
-    // (profiles/r02_b_*: the traversal is not bound by HBM) plus ~3 % of the frame for the sort -> off unless PBRT_AMD_RAYBIN=1
-    { const char *e = std::getenv("PBRT_AMD_RAYBIN"); c->rayBin = e && e[0] == '1'; }
     {   // PBRT_AMD_OVERLAP=1: the shadow / MIS traversals of a bounce on a second stream, overlapping the next bounce's path-extension traversal
         const char *e = std::getenv("PBRT_AMD_OVERLAP");
         c->overlapNee = e && e[0] == '1';
@@ -2619,9 +2496,6 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-#if PT_SHADE_ARGPTR
-    if (!c->scDev) { DevBuf &b = next(); if (upload(c, b, &sc, sizeof(DevScene))) return -1; c->scDev = b.as<DevScene>(); HIP_TRY(hipStreamSynchronize(c->stream)); }
-#endif
     // ---- the parts the material-sorted queue is shaded in (PathState::key_remap, ShadeRange): one, or with sssRoute two -- key order [materials k_shade sees, escaped
     // rays, null-BSDF surfaces | the materials k_shade_vol must see]
     {
@@ -2699,15 +2573,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     if (c->volSplit) ALLOC(q_cont, uint32_t, qcap);
     ALLOC(qcount, uint32_t, QC_WORDS);
     ALLOC(keycount, uint32_t, c->nkeys); ALLOC(keyoffset, uint32_t, c->nkeys); ALLOC(cursor, uint32_t, QSEG * QC_STRIDE);
-    ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * std::max<uint32_t>(c->nkeys, c->rayBin ? PT_RAYBIN_KEYS : 0u));
-    if (c->rayBin) {
-        ALLOC(q_key, uint32_t, qcap); ALLOC(bin_total, uint32_t, PT_RAYBIN_KEYS); ALLOC(bin_offset, uint32_t, PT_RAYBIN_KEYS);
-        for (int a = 0; a < 3; ++a) {   // 8 cells per axis over scene.WorldBound() (the root box of the reference's BVH)
-            float lo = c->sc.sp_bmin_all[a], hi = c->sc.sp_bmax_all[a];
-            ps.bin_min[a] = lo;
-            ps.bin_scale[a] = hi > lo ? 8.0f / (hi - lo) : 0.0f;
-        }
-    }
+    ALLOC(blockhist, uint32_t, (size_t)c->gridBlocks * c->nkeys);
     ps.spill_per_thread = std::max(1, c->sc.stack_need - PT_LDS_STACK_MIN);
     {
         const size_t words4 = (size_t)ps.spill_per_thread * (sizeof(StackEntry) / 4);
@@ -2824,21 +2690,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_CONT, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // the vertices waiting for k_vol_continue
         if (!overlap) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));   // shadow + mis (overlap: after the join below)
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-        bool binned = false;
-        if (c->rayBin && iter > 0) {   // camera rays (iter 0) come out of k_raygen tile by tile: coherent already
-            tic(c, MI_K_SORT);
-            hipLaunchKernelGGL(k_raybin_count, grid, block, 0, st, ps, qin);
-            hipLaunchKernelGGL(k_raybin_scan_blocks, dim3(PT_RAYBIN_KEYS / PT_BLOCK), block, 0, st, ps, (uint32_t)c->gridBlocks);
-            hipLaunchKernelGGL(k_raybin_scan_bins, dim3(1), block, 0, st, ps);
-            hipLaunchKernelGGL(k_raybin_scatter, grid, block, 0, st, ps, qin);
-            toc(c);
-            binned = true;
-        }
         tic(c, MI_K_CLOSEST);
         {
-            PathState psRun = ps;   // the traversal walks the binned copy of the queue; the material sort below reads the original (same set of paths)
-            if (binned) { psRun.q_ext[qin] = ps.q_sorted; psRun.trace_contig = 1; }
-            PathState &ps = psRun;
             LAUNCH_TRACE(0);
         }
         toc(c);
@@ -2847,9 +2700,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         hipLaunchKernelGGL(k_scan_keys, dim3(1), block, 0, st, ps, c->nkeys, (uint32_t)c->gridBlocks);
         hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
-#if PT_SHADE_DYN
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));
-#endif
         if (overlap) {   // join: the previous bounce's shadow / MIS traversals (stream2) add into PathRec::L and read the queues k_shade refills
             if (iter > 0) HIP_TRY(hipStreamWaitEvent(st, c->evNeeDone, 0));
             HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
@@ -2872,9 +2723,9 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
             };
 #define LAUNCH_SHADE(ENV, TEX, ...)                                                                                                              \
     do {                                                                                                                                         \
-        if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                   \
-        else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);               \
-        else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, PT_SHADE_SC_ARG, ps, qout);                           \
+        if (pixSmp) hipLaunchKernelGGL((k_shade<ENV, 2, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                   \
+        else if (halton) hipLaunchKernelGGL((k_shade<ENV, 1, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);               \
+        else hipLaunchKernelGGL((k_shade<ENV, 0, TEX, ##__VA_ARGS__>), dim3(c->gridShade), block, 0, st, sc, ps, qout);                           \
     } while (0)
             auto shade_plain = [&](const PathState &ps) {
                 // (routed subsurface scenes: the BSSRDF materials are always built per hit, mi_material_desc::textured -- what counts here are the materials k_shade sees)

@@ -532,21 +532,11 @@ struct RayBox {
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][lane] layout: a
 // lane's entries sit in one bank column, so pushes/pops of a whole wave are conflict free whatever
 // the per-lane depth), deeper entries spill to a per-thread slice of an HBM buffer (rare).
-// PT_STACK_T = 1: an entry also carries the child's entry distance, so a node whose box lies beyond the hit found in
-// the meantime is dropped at pop time without fetching it -- the test the reference makes when it visits the node
-// (bvh.cpp:672 with the shrunken ray.tMax), made earlier.
-#ifndef PT_STACK_T
-#define PT_STACK_T 0
-#endif
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK (PT_STACK_T ? 12 : 24)
+#define PT_LDS_STACK 24
 #endif
 #define PT_BLOCK 256
-#if PT_STACK_T
-typedef unsigned long long StackEntry;   // child reference | entry distance bits << 32
-#else
 typedef uint32_t StackEntry;
-#endif
 typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
 // STRIDE = threads per block of the kernel that owns the stack (the [entry][lane] rows are one block wide); NLDS = entries held in LDS.  The spill
 // slices are sized for the shallowest LDS part any kernel uses (PT_LDS_STACK_MIN)
@@ -562,11 +552,7 @@ struct TravStackT {
     int sp;
     PT_DEV void reset() { sp = 0; }
     PT_DEV void push(uint32_t v, Float t) {
-#if PT_STACK_T
-        StackEntry e = (StackEntry)v | ((StackEntry)__float_as_uint(t) << 32);
-#else
         StackEntry e = v;
-#endif
         if (sp < NLDS) lds[sp * STRIDE] = e; else spill[sp - NLDS] = e;
         ++sp;
     }
@@ -575,11 +561,7 @@ struct TravStackT {
         while (sp) {
             --sp;
             StackEntry e = (sp < NLDS) ? lds[sp * STRIDE] : spill[sp - NLDS];
-#if PT_STACK_T
-            if (__uint_as_float((uint32_t)(e >> 32)) < tMax) return (uint32_t)e;
-#else
             return e;
-#endif
         }
         return 0xFFFFFFFFu;
     }
@@ -712,12 +694,9 @@ PT_DEV void TravNodeStepQ(const DevScene &sc, TravStateQ &ts, ST &st, TraceCount
     TravNodeStepQWords<COUNT>(w0, w1, w2, ch, ts, st, cnt);
 }
 // the step on the node's four 16-byte words, however they were fetched
-// PT_LEAN_STEP (round 3: the traversal kernels are bound by VALU issue as much as by memory, profiles/r03_c_*): the tail of the step with fewer
-// instructions and the same decisions -- compare-exchanges as v_min / v_max on the distances + two selects on the references (the swap condition
+// (round 3: the traversal kernels are bound by VALU issue as much as by memory, profiles/r03_c_*) the tail of the step with few
+// instructions -- compare-exchanges as v_min / v_max on the distances + two selects on the references (the swap condition
 // is still tb < ta), and the up-to-three pushes as one address + three predicated LDS stores while the lane's stack stays inside its LDS part.
-#ifndef PT_LEAN_STEP
-#define PT_LEAN_STEP 1
-#endif
 template <bool COUNT, class ST>
 PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravStateQ &ts, ST &st, TraceCounters *cnt) {
     if (COUNT) ++cnt->nodes;
@@ -727,7 +706,6 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
     Float t0 = (mask & 1u) ? t[0] : PT_INFINITY, t1 = (mask & 2u) ? t[1] : PT_INFINITY, t2 = (mask & 4u) ? t[2] : PT_INFINITY, t3 = (mask & 8u) ? t[3] : PT_INFINITY;
     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
     const int nh = __builtin_popcount(mask);
-#if PT_LEAN_STEP && !PT_STACK_T
     // v_min_f32 / v_max_f32 straight (the distances are never NaN; the builtins would first canonicalise both operands: two more instructions each)
 #define PT_MINMAX(lo, hi, a, b) lo = PtMinRaw(a, b); hi = PtMaxRaw(a, b);
 #define PT_CSWAP(ta, ca, tb, cb) { const bool sw_ = tb < ta; Float lo_, hi_; PT_MINMAX(lo_, hi_, ta, tb) const uint32_t cl_ = sw_ ? cb : ca, ch_ = sw_ ? ca : cb; ta = lo_; tb = hi_; ca = cl_; cb = ch_; }
@@ -750,16 +728,6 @@ PT_DEV void TravNodeStepQWords(uint4 w0, uint4 w1, uint4 w2, uint4 ch, TravState
             st.push(c1, t1);
         }
     }
-#else
-#define PT_CSWAP(ta, ca, tb, cb) if (tb < ta) { Float tt = ta; ta = tb; tb = tt; uint32_t cc = ca; ca = cb; cb = cc; }
-    PT_CSWAP(t0, c0, t1, c1) PT_CSWAP(t2, c2, t3, c3) PT_CSWAP(t0, c0, t2, c2) PT_CSWAP(t1, c1, t3, c3) PT_CSWAP(t1, c1, t2, c2)
-#undef PT_CSWAP
-    if (nh == 0) { ts.cur = st.pop(ts.tMax); return; }
-    if (nh > 3) st.push(c3, t3);
-    if (nh > 2) st.push(c2, t2);
-    if (nh > 1) st.push(c1, t1);
-    ts.cur = c0;
-#endif
 }
 
 // ------------------------------------------------------------------ round 4: the interior step with a shorter tail (TraceShape::BIG instances of k_trace)
@@ -1000,9 +968,6 @@ PT_DEV void TravPendStep(const DevScene &sc, TravStateQ &ts, ST &st, TraceCounte
         hitPrim = !(flags & TRI_FLAG_REJECT) && TriangleTest(p0, p1, p2, ts.o, ts.shear, ts.tMax, &th);
     if (ALPHA && hitPrim && (flags & TRI_FLAG_ALPHA)) {
         if constexpr (DEFER) { *cand = true; return; }   // (tMax cannot change before the alpha phase: only this lane's leaf steps shrink it)
-#ifdef PT_ALPHA_TWICE   /* measurement aid: the mask evaluated twice -- the time difference to the plain build is what the mask evaluations cost */
-        { Float b0x = th.b0; asm volatile("" : "+v"(b0x)); if (TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, b0x, th.b1, th.b2, ANY)) asm volatile("s_nop 0"); }
-#endif
         hitPrim = !TriAlphaRejects(sc.tri_info, sc.tri_shade, first, p0, p1, p2, th.b0, th.b1, th.b2, ANY);
     }
     if (hitPrim) {

@@ -420,11 +420,7 @@ template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const 
 }
 // PT_SAMPLE_SKIP_F in *sampledType: the caller (BSDF::Sample_f) discards the f of a non-specular lobe -- it re-evaluates f over all matching
 // lobes afterwards (reflection.cpp:747-763) -- so the lobe's own f (one more D, G and Fresnel evaluation for the microfacet lobes) is not computed
-#ifdef PT_NO_SKIP_F   /* A/B: always compute the lobe's own f */
-#define PT_SAMPLE_SKIP_F 0
-#else
 #define PT_SAMPLE_SKIP_F 0x100
-#endif
 template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);

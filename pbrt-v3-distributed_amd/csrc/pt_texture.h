@@ -36,14 +36,11 @@ struct TexCtx {   // what textures read of a SurfaceInteraction
 };
 struct V2 { Float x, y; };
 
-// Wave-uniform evaluation (U = true; round 4, measured in round 5: PT_TEX_UNIFORM).  k_shade<..., TEX> runs the material code once per distinct material of a wave
+// Wave-uniform evaluation (U = true; built in round 4, measured -2.3 % / -3 % of the textured shading time in profiles/r04_v_*, r05_i_*, on since round 5).  k_shade<..., TEX> runs the material code once per distinct material of a wave
 // (waterfall loop), so inside it every active lane evaluates the SAME material, hence the same texture nodes, programs and images -- only the interaction differs
 // per lane.  The out-of-line routines below receive their node / image as ordinary (vector-register) arguments, which made every field of a node a 64-lane gather of one
 // address.  With U they take the argument from the first active lane and read the tables through the CONSTANT address space: scalar loads, scalar branches.
 // U = false: per-lane nodes (alpha masks inside the traversal, k_shade_vol's per-lane materials, mi_texture_eval).
-#ifndef PT_TEX_UNIFORM
-#define PT_TEX_UNIFORM 1   /* measured twice: shade -2.3 % (profiles/r04_v_*), -3 % (r05_i_*); 0 = per-lane gathers of the same tables (A/B) */
-#endif
 template <bool U, class T> struct UPtr { typedef const T *P; static PT_DEV P of(const T *p) { return p; } };
 template <class T> struct UPtr<true, T> {
     typedef const __attribute__((address_space(4))) T *P;

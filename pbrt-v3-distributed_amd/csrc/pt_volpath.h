@@ -543,19 +543,13 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
     uint32_t n, sbase;
     ShadeRange(ps, &sbase, &n);
     uint32_t nseg = 0;
-#if PT_SHADE_DYN
     for (DynIter it(n, ps.cursor); it.more(); it.next()) {
         const uint32_t i = it.item();
         const bool active = it.valid();
-#else
-    for (ChunkIter it(n); it.more(); it.next()) {
-        const uint32_t i = it.item();
-        const bool active = i < n;
-#endif
         bool cont = false, wantProbe = false;   // wantProbe (walked BSSRDF probes, DevVol::sss_wave): the path waits for its probe chain instead of continuing
         int wantSplit = 0;                      // split form (DevVol::tr_dims): 1 = a surface vertex, 2 = a medium vertex waits for its direct-lighting rays' transmittances (k_vol_continue)
         V3 splitP;
-        uint32_t slot = 0, rayKey = 0;
+        uint32_t slot = 0;
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
         if (active) {
@@ -747,7 +741,6 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
             if (WAVE) WriteNeeRecords(ps, vol, slot, nee, betaNee);
             if (cont) {
-                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
                 ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                 ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
                 ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -759,7 +752,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
         if (WAVE) {
             uint32_t posE, posS, posM;
             PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, nee.wantShadow, nee.wantMis, &posE, &posS, &posM);
-            if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+            if (cont) { ps.q_ext[qout][qbase + posE] = slot; }
             if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
             if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
             if (vol.tr_dims) {   // split form: the vertices that wait for their transmittances (k_vol_continue's queue)
@@ -774,7 +767,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(cons
             }
         } else {
             uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
-            if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+            if (cont) { ps.q_ext[qout][qbase + posE] = slot; }
         }
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
@@ -1070,7 +1063,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
     for (SegIter it(ps.qcount, QC_SSS, ps.seg_cap); it.more(); it.next()) {
         const bool active = it.valid();
         bool cont = false, wantSplit = false;
-        uint32_t slot = 0, rayKey = 0;
+        uint32_t slot = 0;
         NeeOut nee;
         nee.wantShadow = nee.wantMis = false;
         if (active) {
@@ -1146,7 +1139,6 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
             ps.rec[slot].L = make_float4(L.r, L.g, L.b, 0);
             WriteNeeRecords(ps, vol, slot, nee, betaNee);
             if (cont) {
-                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
                 ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                 ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
                 ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -1157,7 +1149,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
         uint32_t posE, posS, posM;
         PT_WAVE_APPEND3(&ps.qcount[QCI(qout, qseg)], &ps.qcount[QCI(QC_SHADOW, qseg)], &ps.qcount[QCI(QC_MIS, qseg)], cont, nee.wantShadow, nee.wantMis, &posE, &posS, &posM);
-        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; }
         if (nee.wantShadow) ps.q_shadow[qbase + posS] = slot;
         if (nee.wantMis) ps.q_mis[qbase + posM] = slot;
         if (vol.tr_dims) {
@@ -1179,7 +1171,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
     for (SegIter it(ps.qcount, QC_CONT, ps.seg_cap); it.more(); it.next()) {
         const bool active = it.valid();
         bool cont = false, wantProbe = false;
-        uint32_t slot = 0, rayKey = 0;
+        uint32_t slot = 0;
         if (active) {
             slot = ps.q_cont[it.item()];
             const uint2 hr = ps.rec[slot].hit;
@@ -1299,7 +1291,6 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
                 ++bounces;
             }
             if (cont) {
-                if (ps.q_key) rayKey = RayBinKey(ps, no, nd);
                 ps.rec[slot].ray_o = make_float4(no.x, no.y, no.z, PT_INFINITY);
                 ps.rec[slot].ray_d = make_float4(nd.x, nd.y, nd.z, 0);
                 ps.rec[slot].beta = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -1309,7 +1300,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(c
         }
         const uint32_t qseg = blockIdx.x & 7, qbase = qseg * ps.seg_cap;
         const uint32_t posE = wave_append(&ps.qcount[QCI(qout, qseg)], cont);
-        if (cont) { ps.q_ext[qout][qbase + posE] = slot; if (ps.q_key) ps.q_key[qbase + posE] = rayKey; }
+        if (cont) { ps.q_ext[qout][qbase + posE] = slot; }
         if (vol.sss_wave) {
             const uint32_t posP = wave_append(&ps.qcount[QCI(QC_PROBE0, qseg)], wantProbe);
             if (wantProbe) ps.q_probe[0][qbase + posP] = slot;

@@ -13,15 +13,28 @@ rank 0 is exactly the gather of the owned tiles -- and stays exact for those edg
 def owned_tiles(rank, world, n_tiles_x, n_tiles_y):
     """row-major tile ids of `rank`: mi_tile_owner of include/pbrt_amd.h (a skewed 2-D lattice over the tile grid), through the library's own
     mi_owned_tiles so that mi_render, the reference-side bindings, the test checker and this module share ONE definition"""
-    import ctypes, importlib
+    import ctypes
     import numpy as np
-    L = importlib.import_module(__package__).device_lib()
-    L.mi_owned_tiles.restype = ctypes.c_int64
-    L.mi_owned_tiles.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    n = L.mi_owned_tiles(n_tiles_x, n_tiles_y, rank, world, None)
+    f = _owned_tiles_fn()
+    n = f(n_tiles_x, n_tiles_y, rank, world, None)
     out = np.zeros(max(1, n), dtype=np.uint32)
-    L.mi_owned_tiles(n_tiles_x, n_tiles_y, rank, world, out.ctypes.data_as(ctypes.c_void_p))
+    f(n_tiles_x, n_tiles_y, rank, world, out.ctypes.data_as(ctypes.c_void_p))
     return [int(t) for t in out[:n]]
+
+
+_OWNED_TILES = None
+
+
+def _owned_tiles_fn():
+    """mi_owned_tiles of the device library, bound once"""
+    global _OWNED_TILES
+    if _OWNED_TILES is None:
+        import ctypes, importlib
+        L = importlib.import_module(__package__).device_lib()
+        L.mi_owned_tiles.restype = ctypes.c_int64
+        L.mi_owned_tiles.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _OWNED_TILES = L.mi_owned_tiles
+    return _OWNED_TILES
 
 
 def combine_films(film, dst=0):
@@ -57,8 +70,9 @@ class FilmExchange:
     """The one exchange of the path, sparse: rank r sends the FilmTilePixels its samples can reach (reach_pixels: its own tiles + the filter's
     ring, 16.6 MB x 1.27 per rank for a 4K film on 8 ranks under the box filter) to rank `dst`, which ADDS them into its film -- equal to the
     SUM-reduce of the full films (133 MB per rank) because a rank's film is zero everywhere else, exact for every filter, and deterministic
-    (contributions are added in rank order).  One grouped send / recv per frame (RCCL over xGMI with backend "nccl": point-to-point links, so
-    the seven senders use seven different links into rank 0's GPU); gloo moves the packed buffers through host memory."""
+    (contributions are added in rank order).  ONE group of point-to-point operations per frame -- dist.batch_isend_irecv, i.e. ncclGroupStart / End with
+    backend "nccl": rank 0's N - 1 receives are posted together and proceed concurrently over the N - 1 xGMI links into its GPU (separate irecv calls
+    ran them one after the other on RCCL's stream: ADVICE r4); gloo moves the packed buffers through host memory."""
 
     def __init__(self, scene, rank, world, device, dst=0):
         import torch
@@ -84,12 +98,14 @@ class FilmExchange:
             if self.via_host:
                 self.buf[self.rank].copy_(packed)
                 packed = self.buf[self.rank]
-            dist.isend(packed, dst=self.dst).wait()
+            for work in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, self.dst)]):
+                work.wait()
             self._keep = packed   # alive until the send has been consumed (finish)
         else:
-            works = [(r, dist.irecv(self.buf[r], src=r)) for r in sorted(self.buf)]
-            for r, work in works:   # rank order: the sum is deterministic
+            srcs = sorted(self.buf)
+            for work in dist.batch_isend_irecv([dist.P2POp(dist.irecv, self.buf[r], r) for r in srcs]):   # one group: the receives run concurrently
                 work.wait()
+            for r in srcs:   # rank order: the sum is deterministic
                 px.index_add_(0, self.idx[r], self.buf[r].to(px.device) if self.via_host else self.buf[r])
         if film.is_cuda:
             ev = torch.cuda.Event()
@@ -110,6 +126,12 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
     import importlib, os, time
     pa = importlib.import_module(__package__)
     t0 = time.time()
+    #  the name carries a nonce every rank of THIS job derives alike -- the rendezvous' port and run id, and the number of the call within the job -- so
+    # that a waiting rank can never map the blob of an earlier node_scene call or of another job started from the same long-lived parent process
+    global _NODE_SCENE_CALLS
+    _NODE_SCENE_CALLS += 1
+    blob_path = "%s.%s_%s_%d" % (blob_path, os.environ.get("MASTER_PORT", "0"), "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24], _NODE_SCENE_CALLS)
+    _NODE_SCENE_FILES.append(blob_path)
     born = _launcher_start_time()   # a blob older than this job's launcher belongs to an earlier job whose pid was reused: never mapped
     if local_rank == 0:
         for f in (blob_path, blob_path + ".failed"):   # leftovers of a crashed job with the same launcher pid
@@ -143,6 +165,22 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
             raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
         time.sleep(0.1)
     return pa.Scene(blob=blob_path), time.time() - t0, "mapped"
+
+
+_NODE_SCENE_CALLS = 0
+_NODE_SCENE_FILES = []
+
+
+def node_scene_cleanup():
+    """remove the files node_scene published in this process (local rank 0, once every rank has mapped its scene: mappings stay valid)"""
+    import os
+    for f in _NODE_SCENE_FILES:
+        for g in (f, f + ".failed", f + ".tmp"):
+            try:
+                os.remove(g)
+            except OSError:
+                pass
+    del _NODE_SCENE_FILES[:]
 
 
 def _write_failed(blob_path, text):
