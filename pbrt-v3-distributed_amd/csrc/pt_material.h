@@ -233,10 +233,9 @@ PT_DEV void Set3(float *d, const RGB &c) { d[0] = c.r; d[1] = c.g; d[2] = c.b; }
 PT_DEV mi_bxdf *AddLobe(mi_material *m, int type) {
     int i = m->n_bxdfs < MI_MAX_BXDFS ? m->n_bxdfs++ : MI_MAX_BXDFS - 1;
     mi_bxdf *b = &m->bxdfs[i];
-    uint32_t *w = (uint32_t *)b;
-    for (int k = 0; k < (int)(sizeof(mi_bxdf) / 4); ++k) w[k] = 0;
-    b->type = type;
-    b->scale[0] = b->scale[1] = b->scale[2] = 1;
+    // the header words every consumer reads; the parameters a lobe kind reads are written by the code that adds it, the others are never looked at (a ScaledBxDF's
+    // scale is set where `scaled` is).  Rounds 1-4 zero-filled all 25 words of the record in private memory per lobe and hit.
+    b->type = type; b->fresnel = 0; b->scaled = 0; b->distrib = 0;
     return b;
 }
 PT_DEV void AddMicroR(mi_material *m, const RGB &r, Float ax, Float ay, int fresnel, Float etaI, Float etaT) {
