@@ -509,12 +509,14 @@ void *mi_film_device_ptr(mi_ctx *ctx); /* float4 per cropped pixel, for RCCL by 
 int mi_film_bind(mi_ctx *ctx, void *device_float4_buffer);
 int64_t mi_film_pixel_count(mi_ctx *ctx);
 /* The exchange step of the tile-sharded render (replaces Film::MergeFilmTile, film.cpp:117-130, across GPUs):
- * sums the films of the n contexts (one per GPU, same scene, rendered with rank = i, world = n) into ctxs[root]'s film with
- * ONE grouped ncclReduce(sum, fp32) over xGMI -- RCCL, loaded at first use (librccl.so), one communicator per device set,
- * cached.  Owned tiles are disjoint, so the sum equals a gather and is exact; with a filter wider than the box the
- * overlapping border samples add in ring order (last-ulp differences between runs, as documented there).
- * Waits for the renders of all contexts first and returns when the root film is complete.  n == 1 is a no-op; contexts that
- * share a device (testing on a one-GPU box) are summed by a device kernel instead, since RCCL refuses duplicate devices. */
+ * adds the films of the n contexts (one per GPU, same scene, rendered with rank = i, world = n) into ctxs[root]'s film.  SPARSE
+ * since round 5: context i packs the FilmTilePixels its samples can reach -- its tiles (mi_tile_owner) grown by the filter's ring,
+ * what Film::GetFilmTile computes per tile (film.cpp:95-106) -- and the root adds the packed lists in context order: exact for
+ * every filter (a context's film is zero elsewhere) and deterministic.  One context per GPU: the lists travel in ONE group of
+ * ncclSend / ncclRecv over xGMI (RCCL, loaded at first use from librccl.so; one communicator per device set, cached).  Contexts
+ * that share a device (testing on a one-GPU box; RCCL refuses duplicate devices) hand their lists over directly.  A context whose
+ * last mi_render was not a shard (world 1) is added whole.  Waits for the renders of all contexts first and returns when the root
+ * film is complete; n == 1 is a no-op. */
 int mi_film_gather(mi_ctx **ctxs, int n, int root);
 /* Stage-level BSDF lobes (core/reflection.cpp:703-785 building blocks): BxDF::f, Pdf and Sample_f(wo, u) of bxdfs[i] for record i
  * (wo, wi in the shading frame) -- replays the vectors dumped from the reference's own BxDF classes on the device. */

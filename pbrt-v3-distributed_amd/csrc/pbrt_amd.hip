@@ -3075,6 +3075,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Reduce)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int /*ncclDataType_t*/, int /*peer*/, ncclComm_t_, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::vector<int> devs;
     std::vector<ncclComm_t_> comms;
@@ -3090,8 +3092,10 @@ struct Rccl {
         GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
         Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
+        Send = (decltype(Send))dlsym(lib, "ncclSend");
+        Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce) { *err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !Send || !Recv) { *err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
         return true;
     }
     bool commsFor(const std::vector<int> &d, std::string *err) {
@@ -3105,6 +3109,16 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
+// the sparse film exchange (mi_film_gather): pack the FilmTilePixels a context's samples can reach / add a packed list into the root film
+__global__ void __launch_bounds__(PT_BLOCK) k_film_pack(const float4 *film, const uint32_t *idx, int64_t n, float4 *out) {
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) out[i] = film[idx[i]];
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_film_add_packed(float4 *film, const uint32_t *idx, int64_t n, const float4 *in) {   // idx ascending and unique: no two threads touch one pixel
+    for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
+        float4 a = film[idx[i]], b = in[i];
+        film[idx[i]] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
 __global__ void __launch_bounds__(PT_BLOCK) k_film_add(float4 *dst, const float4 *src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) {
         float4 a = dst[i], b = src[i];
@@ -3129,6 +3143,31 @@ int mi_trace_info(mi_ctx *c, int64_t out[8]) {
     return 0;
 }
 
+// The FilmTilePixels the samples of rank `rank` of `world` can contribute to, as ascending indices into the cropped film: its tiles (mi_tile_owner) grown by
+// floor(radius + 1/2) pixels per axis and clipped to the film -- what Film::GetFilmTile computes for one tile (core/film.cpp:95-106); parallel.reach_pixels is the same rule.
+static void reach_indices(const DevScene &sc, int rank, int world, std::vector<uint32_t> *out) {
+    const int sx0 = sc.sample_min[0], sy0 = sc.sample_min[1], sx1 = sc.sample_max[0], sy1 = sc.sample_max[1];
+    const int ntx = (sx1 - sx0 + 15) / 16, nty = (sy1 - sy0 + 15) / 16;
+    const int W = sc.crop_max[0] - sc.crop_min[0], H = sc.crop_max[1] - sc.crop_min[1];
+    const int hx = (int)std::floor(sc.filter_radius[0] + 0.5f), hy = (int)std::floor(sc.filter_radius[1] + 0.5f);
+    std::vector<uint8_t> mask((size_t)std::max(0, W) * (size_t)std::max(0, H), 0);
+    const int skew = mi_tile_skew(world);
+    for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx) {
+            if (mi_tile_owner(tx, ty, world, skew) != rank) continue;
+            const int x0 = std::max(0, sx0 + 16 * tx - hx - sc.crop_min[0]), y0 = std::max(0, sy0 + 16 * ty - hy - sc.crop_min[1]);
+            const int x1 = std::min(W, std::min(sx0 + 16 * tx + 16, sx1) + hx - sc.crop_min[0]), y1 = std::min(H, std::min(sy0 + 16 * ty + 16, sy1) + hy - sc.crop_min[1]);
+            for (int y = y0; y < y1; ++y) for (int x = x0; x < x1; ++x) mask[(size_t)y * W + x] = 1;
+        }
+    out->clear();
+    for (size_t i = 0; i < mask.size(); ++i) if (mask[i]) out->push_back((uint32_t)i);
+}
+
+// Round 5: the exchange is SPARSE, like parallel.FilmExchange -- context i packs the pixels its samples can reach (its tiles of the last mi_render + the filter's ring: 1.27 / N
+// of the film under the box filter) and the root adds them into its film in context order, exact for every filter because a context's film is zero everywhere else.  Contexts
+// on distinct devices move the packed lists with ONE group of ncclSend / ncclRecv (N - 1 point-to-point transfers over N - 1 xGMI links into the root's GPU; rounds 1-4:
+// ncclReduce of N full films); contexts sharing a device (one-GPU boxes) hand the root their packed list directly, contexts on another device without a full set of distinct
+// devices through hipMemcpyPeer.  A context that has not rendered a shard (world 1) takes the dense add.
 int mi_film_gather(mi_ctx **ctxs, int n, int root) {
     if (!ctxs || n < 1 || root < 0 || root >= n) return fail("mi_film_gather: bad argument");
     for (int i = 0; i < n; ++i) {
@@ -3137,45 +3176,86 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root) {
     }
     for (int i = 0; i < n; ++i) if (mi_sync(ctxs[i])) return -1;   // the renders (each on its own ctx stream)
     if (n == 1) return 0;
-    const size_t count = (size_t)ctxs[root]->filmPixels * 4;       // floats
+    mi_ctx *r = ctxs[root];
     std::vector<int> devs(n);
     bool distinct = true;
     for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; ++j) distinct &= devs[j] != devs[i]; }
-    if (distinct) {
-        std::string err;
-        static std::mutex rcclMutex;   // the cached communicators (g_rccl) are shared by every caller of this process
-        std::lock_guard<std::mutex> lock(rcclMutex);
-        if (!g_rccl.load(&err) || !g_rccl.commsFor(devs, &err)) return fail("mi_film_gather: " + err);
-        const int ncclFloat32_ = 7, ncclSum_ = 0;   // ncclDataType_t / ncclRedOp_t values of <rccl/rccl.h>
-        int rc = g_rccl.GroupStart();
-        hipError_t he = hipSuccess;
-        for (int i = 0; i < n && rc == 0 && he == hipSuccess; ++i) {   // no early return inside the group: GroupEnd always runs
-            he = hipSetDevice(ctxs[i]->device);
-            if (he == hipSuccess) rc = g_rccl.Reduce(ctxs[i]->filmPtr, ctxs[i]->filmPtr, count, ncclFloat32_, ncclSum_, root, g_rccl.comms[i], ctxs[i]->stream);
-        }
-        int rc2 = g_rccl.GroupEnd();
-        if (he != hipSuccess) return fail(std::string("mi_film_gather: hipSetDevice: ") + hipGetErrorString(he));
-        if (rc != 0 || rc2 != 0) return fail(std::string("mi_film_gather: ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"));
-        for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
-        return 0;
-    }
-    // contexts sharing a device (one-GPU test boxes): plain device-side sums into the root film; contexts on other devices through a staged peer copy
-    mi_ctx *r = ctxs[root];
-    HIP_TRY(hipSetDevice(r->device));
-    DevBuf stage;
+    // per sender: the reach list on its own device and on the root's, the packed pixels, the root's receive buffer
+    struct Part { std::vector<uint32_t> idx; DevBuf dIdxSrc, dIdxRoot, packed, recv; bool dense = false; };
+    std::vector<Part> parts(n);
     for (int i = 0; i < n; ++i) {
         if (i == root) continue;
-        const float4 *src = ctxs[i]->filmPtr;
-        if (ctxs[i]->device != r->device) {
-            if (!stage.p && stage.alloc(count * sizeof(float))) return -1;
-            HIP_TRY(hipMemcpyPeerAsync(stage.p, r->device, ctxs[i]->filmPtr, ctxs[i]->device, count * sizeof(float), r->stream));
-            src = stage.as<float4>();
-        }
-        hipLaunchKernelGGL(k_film_add, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, src, (int64_t)r->filmPixels);
+        mi_ctx *c = ctxs[i];
+        Part &p = parts[i];
+        p.dense = c->tilesWorld <= 1 || c->tilesRank < 0;   // (no shard rendered: the whole film may carry samples)
+        if (p.dense) continue;
+        reach_indices(c->sc, c->tilesRank, c->tilesWorld, &p.idx);
+        if (p.idx.empty()) continue;
+        HIP_TRY(hipSetDevice(c->device));
+        if (upload(c, p.dIdxSrc, p.idx.data(), p.idx.size() * sizeof(uint32_t)) || p.packed.alloc(p.idx.size() * sizeof(float4))) return -1;
+        hipLaunchKernelGGL(k_film_pack, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, (const float4 *)c->filmPtr, p.dIdxSrc.as<uint32_t>(), (int64_t)p.idx.size(), p.packed.as<float4>());
         HIP_TRY(hipGetLastError());
-        if (ctxs[i]->device != r->device) HIP_TRY(hipStreamSynchronize(r->stream));   // the staging buffer is reused
+        HIP_TRY(hipSetDevice(r->device));
+        if (c->device != r->device) {
+            if (upload(r, p.dIdxRoot, p.idx.data(), p.idx.size() * sizeof(uint32_t)) || p.recv.alloc(p.idx.size() * sizeof(float4))) return -1;
+        }
     }
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }   // packed lists and index uploads are in place
+    bool viaRccl = false;
+    if (distinct) {
+        bool anySparse = false;
+        for (int i = 0; i < n; ++i) anySparse = anySparse || (i != root && !parts[i].dense && !parts[i].idx.empty());
+        if (anySparse) {
+            std::string err;
+            static std::mutex rcclMutex;   // the cached communicators (g_rccl) are shared by every caller of this process
+            std::lock_guard<std::mutex> lock(rcclMutex);
+            if (!g_rccl.load(&err) || !g_rccl.commsFor(devs, &err)) return fail("mi_film_gather: " + err);
+            const int ncclFloat32_ = 7;   // ncclDataType_t value of <rccl/rccl.h>
+            int rc = g_rccl.GroupStart();
+            hipError_t he = hipSuccess;
+            for (int i = 0; i < n && rc == 0 && he == hipSuccess; ++i) {   // no early return inside the group: GroupEnd always runs
+                if (i == root || parts[i].dense || parts[i].idx.empty()) continue;
+                const size_t count = parts[i].idx.size() * 4;
+                he = hipSetDevice(ctxs[i]->device);
+                if (he == hipSuccess) rc = g_rccl.Send(parts[i].packed.p, count, ncclFloat32_, root, g_rccl.comms[i], ctxs[i]->stream);
+                if (he == hipSuccess && rc == 0) he = hipSetDevice(r->device);
+                if (he == hipSuccess && rc == 0) rc = g_rccl.Recv(parts[i].recv.p, count, ncclFloat32_, i, g_rccl.comms[root], r->stream);
+            }
+            int rc2 = g_rccl.GroupEnd();
+            if (he != hipSuccess) return fail(std::string("mi_film_gather: hipSetDevice: ") + hipGetErrorString(he));
+            if (rc != 0 || rc2 != 0) return fail(std::string("mi_film_gather: ncclSend / ncclRecv: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"));
+            viaRccl = true;
+        }
+    }
+    HIP_TRY(hipSetDevice(r->device));
+    DevBuf stage;
+    const size_t count = (size_t)r->filmPixels * 4;   // floats of a whole film (dense parts)
+    for (int i = 0; i < n; ++i) {   // context order: the sum is deterministic
+        if (i == root) continue;
+        mi_ctx *c = ctxs[i];
+        Part &p = parts[i];
+        if (p.dense) {
+            const float4 *src = c->filmPtr;
+            if (c->device != r->device) {
+                if (!stage.p && stage.alloc(count * sizeof(float))) return -1;
+                HIP_TRY(hipMemcpyPeerAsync(stage.p, r->device, c->filmPtr, c->device, count * sizeof(float), r->stream));
+                src = stage.as<float4>();
+            }
+            hipLaunchKernelGGL(k_film_add, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, src, (int64_t)r->filmPixels);
+            HIP_TRY(hipGetLastError());
+            if (c->device != r->device) HIP_TRY(hipStreamSynchronize(r->stream));   // the staging buffer is reused
+            continue;
+        }
+        if (p.idx.empty()) continue;
+        const uint32_t *idx = c->device == r->device ? p.dIdxSrc.as<uint32_t>() : p.dIdxRoot.as<uint32_t>();
+        const float4 *in = c->device == r->device ? p.packed.as<float4>() : p.recv.as<float4>();
+        if (c->device != r->device && !viaRccl) HIP_TRY(hipMemcpyPeerAsync(p.recv.p, r->device, p.packed.p, c->device, p.idx.size() * sizeof(float4), r->stream));
+        hipLaunchKernelGGL(k_film_add_packed, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, idx, (int64_t)p.idx.size(), in);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
+    HIP_TRY(hipSetDevice(r->device));
+    for (Part &p : parts) { p.dIdxSrc.release(); p.dIdxRoot.release(); p.packed.release(); p.recv.release(); }
     stage.release();
     return 0;
 }
@@ -3674,6 +3754,14 @@ static int stage_trace(mi_ctx *c, const mi_ray *rays, int64_t n, mi_hit *hits, u
     if (!c || !c->haveScene) return fail("no scene uploaded");
     HIP_TRY(hipSetDevice(c->device));
     if (n <= 0) return 0;
+    if (c->useQ) {   //  the quantised interior step serves rays that start within 1e5 grid extents of the scene (mi_scene_upload checks the camera the same way): caller's rays are checked here
+        for (int a = 0; a < 3; ++a) {
+            const double ext = 65535.0 * (double)c->sc.qgrid.cell[a], lo = (double)c->sc.qgrid.lo[a];
+            for (int64_t i = 0; i < n; ++i)
+                if (!(std::fabs((double)rays[i].o[a] - lo) <= 1e5 * ext))
+                    return fail("mi_intersect / mi_intersect_p: a ray starts farther than 1e5 scene extents from the scene (or at a non-finite point): outside the range of the quantised BVH4 traversal -- upload the scene with PBRT_AMD_TRACE=general for such rays");
+        }
+    }
     if (ensure_state(c, (uint32_t)std::max<int64_t>(c->cap, std::min<int64_t>(std::max<int64_t>(n, 256 * 64), 1 << 22)))) return -1;
     PathState &ps = c->ps;
     const DevScene &sc = c->sc;

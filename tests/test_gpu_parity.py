@@ -243,22 +243,31 @@ def test_tile_sharding_is_exact(pair):
     assert np.allclose(acc, whole, rtol=1e-6, atol=1e-7)
 
 
-def test_film_gather_of_two_contexts_equals_the_single_render():
-    """mi_film_gather (the exchange step of the tile-sharded render): two contexts render the tiles of rank 0 / rank 1 of 2 -- both calls
-    return before the GPU has finished (mi_render is asynchronous), so the two renders overlap -- and the gather sums them into the
-    root film.  On this one-GPU box the contexts share device 0, so the sum runs as a device kernel (RCCL refuses duplicate devices);
-    with one context per GPU the same call issues one grouped ncclReduce."""
-    sc = pa.Scene(os.path.join(ROOT, "scenes", "materials.pbrt"))
+@pytest.mark.parametrize("flt", ["box", "gaussian"])
+def test_film_gather_of_two_contexts_equals_the_single_render(flt):
+    """mi_film_gather (the exchange step of the tile-sharded render): contexts render the tiles of rank r of N -- the calls return before the GPU
+    has finished (mi_render is asynchronous), so the renders overlap -- and the gather adds what each context's samples can REACH (its tiles + the
+    filter's ring, packed; round 5) into the root film, in context order.  On this one-GPU box the contexts share device 0, so the packed lists are
+    handed over directly (RCCL refuses duplicate devices); with one context per GPU the same call issues one group of ncclSend / ncclRecv.  A wide
+    filter (gaussian, radius 2: overlapping footprints across tile borders) and three contexts cover the ring and the order of the adds."""
+    text = open(os.path.join(ROOT, "scenes", "materials.pbrt")).read()
+    if flt == "gaussian":
+        text = text.replace("WorldBegin", 'PixelFilter "gaussian" "float xwidth" [2] "float ywidth" [2]\nWorldBegin', 1)
+    sc = pa.Scene(text=text)
     whole = pa.Context(sc); whole.render(); ref = whole.film(); whole.close()
-    a, b = pa.Context(sc), pa.Context(sc)
-    a.render(rank=0, world=2, sync=False)
-    b.render(rank=1, world=2, sync=False)
-    pa.film_gather([a, b], root=0)
-    got = a.film()
-    own_only = ref[..., 3] == sc.info["spp"]
-    assert np.array_equal(got[own_only].view(np.uint32), ref[own_only].view(np.uint32))
-    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
-    a.close(); b.close()
+    world = 2 if flt == "box" else 3
+    ctxs = [pa.Context(sc) for _ in range(world)]
+    for r, c in enumerate(ctxs):
+        c.render(rank=r, world=world, sync=False)
+    pa.film_gather(ctxs, root=0)
+    got = ctxs[0].film()
+    if flt == "box":
+        own_only = ref[..., 3] == sc.info["spp"]
+        assert np.array_equal(got[own_only].view(np.uint32), ref[own_only].view(np.uint32))
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(got[..., 3] != 0, ref[..., 3] != 0)   # no pixel's contributions were left behind
+    for c in ctxs:
+        c.close()
 
 
 def test_bench_two_ranks_self_launch_end_to_end(tmp_path):
