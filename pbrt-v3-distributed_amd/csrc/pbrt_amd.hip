@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1602,9 +1603,14 @@ struct TableTurn {
 };
 }  // namespace
 
-// ---- BVH2 -> BVH4 collapse (host).  Every BVH4 child box is a reference node box.
+// ---- BVH2 -> BVH4 collapse (host).  Every BVH4 child box is a node box of the binary tree it is given: the reference's, or (single-level scenes, round 5) the library's
+// own topology over the reference's leaves (pt_treebuild.h).
+#include "pt_treebuild.h"
 namespace {
 struct B4Builder {
+    bool ownTopology = false;            // rebuild the top-level tree's interior over the reference's leaves (treebuild::RebuildOverLeaves)
+    bool rebuilt = false;                // ... and it was
+    std::vector<mi_bvh2_node> own;
     const mi_bvh2_node *n2;
     uint32_t primBase = 0;   // added to every primitive offset: 0 for the top-level tree, mi_object::first_prim for an instanced object's
     std::vector<BVH4Node> out;
@@ -1689,7 +1695,11 @@ struct B4Builder {
     bool buildScene(const mi_scene_desc *d, std::vector<uint32_t> *objRoot, int *topDepth, int *objDepth, std::string *err) {
         *topDepth = *objDepth = 0;
         objRoot->clear();
-        if (d->n_bvh_nodes) { buildTree(d->bvh_nodes, 0); *topDepth = maxDepth; }
+        if (d->n_bvh_nodes) {
+            rebuilt = ownTopology && !d->n_instances && treebuild::RebuildOverLeaves(d->bvh_nodes, d->n_bvh_nodes, &own);
+            buildTree(rebuilt ? own.data() : d->bvh_nodes, 0);
+            *topDepth = maxDepth;
+        }
         if (!d->n_instances) return true;
         objRoot->resize(d->n_objects);
         for (uint32_t o = 0; o < d->n_objects; ++o) {
@@ -1822,8 +1832,16 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     std::vector<uint32_t> objRoot;
     std::vector<DevInstance> insts;
     {
+        // single-level scenes traverse the library's own topology over the reference's leaves (pt_treebuild.h); PBRT_AMD_TREE=reference keeps the tree as handed over
+        // (A/B, and one of the parity suite's traversal modes)
+        const char *e = std::getenv("PBRT_AMD_TREE");
+        bb.ownTopology = !(e && e[0] == 'r') && !c->hasInst;
         std::string err;
+        const auto t0 = std::chrono::steady_clock::now();
         if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_scene_upload: " + err);
+        if (std::getenv("PBRT_AMD_VERBOSE"))
+            std::fprintf(stderr, "[pbrt_amd] BVH4 over %s: %zu nodes, depth %d, %.2f s\n", bb.rebuilt ? "the library's own topology (reference leaves)" : "the reference's tree",
+                         bb.out.size(), topDepth, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     if (c->hasInst) {
         insts.resize(d->n_instances);

@@ -16,7 +16,9 @@ SCENES = ["cornell.pbrt", "materials.pbrt"]
 # full-precision 128-byte BVH4 (what two-level scenes use; PBRT_AMD_TRACE=general -- run here with ray binning on, PBRT_AMD_RAYBIN=1, so
 # that the binning kernels are covered too), "bvh4q-cold" = the quantised tree in the reference's node order with no hot nodes in LDS
 # (PBRT_AMD_HOT=0: every interior step through the vector-memory path, the round-2 behaviour).  The variables are read by mi_scene_upload.
-TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general", "PBRT_AMD_RAYBIN": "1"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0"}}
+# traversal layouts that ship: bvh4q = the default (64-byte quantised BVH4 over the library's own topology of the reference's leaves, hot nodes in LDS); general = full-precision
+# 128-byte nodes; bvh4q-cold = reference node order, nothing in LDS, AND the reference's own interior nodes (PBRT_AMD_TREE=reference: the tree exactly as handed over)
+TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0", "PBRT_AMD_TREE": "reference"}}
 
 
 def _report(key, **values):
@@ -30,7 +32,7 @@ def _report(key, **values):
 
 def make_ctx(sc, mode="bvh4q", **kw):
     env = TRACE_MODES[mode]
-    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_RAYBIN", "PBRT_AMD_HOT")}
+    saved = {k: os.environ.get(k) for k in ("PBRT_AMD_TRACE", "PBRT_AMD_TREE", "PBRT_AMD_HOT")}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(env)
