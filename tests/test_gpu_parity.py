@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 SCENES = ["cornell.pbrt", "materials.pbrt"]
 # every traversal kernel instance the library ships runs the parity tests: "bvh4q" = the general steps over the 64-byte quantised BVH4
 # (csrc/pt_bvh4q.h; the default for single-level scenes, with or without spheres / masks), "general" = the same steps over the
-# full-precision 128-byte BVH4 (what two-level scenes use; PBRT_AMD_TRACE=general -- run here with ray binning on, PBRT_AMD_RAYBIN=1, so
+# full-precision 128-byte BVH4 (what two-level scenes use; PBRT_AMD_TRACE=general, so
 # that the binning kernels are covered too), "bvh4q-cold" = the quantised tree in the reference's node order with no hot nodes in LDS
 # (PBRT_AMD_HOT=0: every interior step through the vector-memory path, the round-2 behaviour).  The variables are read by mi_scene_upload.
 # traversal layouts that ship: bvh4q = the default (64-byte quantised BVH4 over the library's own topology of the reference's leaves, hot nodes in LDS); general = full-precision
