@@ -11,11 +11,7 @@ ROOT = ol.ROOT
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell.pbrt", "materials.pbrt"]
-# every traversal kernel instance the library ships runs the parity tests: "bvh4q" = the general steps over the 64-byte quantised BVH4
-# (csrc/pt_bvh4q.h; the default for single-level scenes, with or without spheres / masks), "general" = the same steps over the
-# full-precision 128-byte BVH4 (what two-level scenes use; PBRT_AMD_TRACE=general, so
-# that the binning kernels are covered too), "bvh4q-cold" = the quantised tree in the reference's node order with no hot nodes in LDS
-# (PBRT_AMD_HOT=0: every interior step through the vector-memory path, the round-2 behaviour).  The variables are read by mi_scene_upload.
+# every traversal kernel instance the library ships runs the parity tests (the variables are read by mi_scene_upload):
 # traversal layouts that ship: bvh4q = the default (64-byte quantised BVH4 over the library's own topology of the reference's leaves, hot nodes in LDS); general = full-precision
 # 128-byte nodes; bvh4q-cold = reference node order, nothing in LDS, AND the reference's own interior nodes (PBRT_AMD_TREE=reference: the tree exactly as handed over)
 TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0", "PBRT_AMD_TREE": "reference"}}
