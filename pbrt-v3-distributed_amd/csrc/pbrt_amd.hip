@@ -2083,7 +2083,27 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         }
         if (c->hasTex) { DevBuf &b = next(); if (upload(c, b, d->material_descs, (size_t)d->n_materials * sizeof(mi_material_desc))) return -1; tx.descs = b.as<mi_material_desc>(); }
         if (c->hasAlpha) { DevBuf &b = next(); if (upload(c, b, d->mesh_alpha, 2 * (size_t)d->n_meshes * sizeof(int32_t))) return -1; tx.mesh_alpha = b.as<int32_t>(); }
-        HIP_TRY(hipStreamSynchronize(c->stream));   // `imgs` is a local
+        std::vector<DevMaskFast> maskFast;
+        if (c->hasAlpha) {   // the masks pre-resolved per mesh (DevMaskFast, pt_texture.h)
+            maskFast.resize(2 * (size_t)d->n_meshes);
+            auto isConst = [&](int n) { return n >= 0 && (uint32_t)n < d->n_textures && d->textures[n].type == MI_TEX_CONSTANT; };
+            for (size_t k = 0; k < maskFast.size(); ++k) {
+                DevMaskFast &mf = maskFast[k];
+                std::memset(&mf, 0, sizeof(mf));
+                const int n = d->mesh_alpha[k];
+                if (n < 0 || (uint32_t)n >= d->n_textures) { mf.kind = n < 0 ? 0 : 1; continue; }   // (an index beyond the table: TexEval answers 0, as before)
+                const mi_texture &t = d->textures[n];
+                mf.kind = 1; mf.image = -1;
+                mf.su = t.su; mf.sv = t.sv; mf.du = t.du; mf.dv = t.dv;
+                if (t.type == MI_TEX_CONSTANT) { mf.kind = 2; mf.v_out = t.value[0]; }
+                else if (t.type == MI_TEX_DOTS && t.mapping == MI_MAP_UV && isConst(t.tex1) && isConst(t.tex2)) { mf.kind = 3; mf.v_out = d->textures[t.tex1].value[0]; mf.v_in = d->textures[t.tex2].value[0]; }
+                else if (t.type == MI_TEX_IMAGEMAP && t.mapping == MI_MAP_UV) { mf.kind = 4; mf.image = t.image; }
+            }
+            DevBuf &b = next();
+            if (upload(c, b, maskFast.data(), maskFast.size() * sizeof(DevMaskFast))) return -1;
+            tx.mask_fast = b.as<DevMaskFast>();
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));   // `imgs`, `maskFast` are locals
         tx.camera = d->camera;
         tx.spp = d->integrator.spp;
         for (int i = 0; i < 128; ++i) {   // MIPMap::weightLut, mipmap.h:187-195

@@ -206,11 +206,24 @@ template <bool U> __device__ __noinline__ void BumpT(int tex, Isect *si, IsectX 
 
 // Triangle::Intersect / IntersectP alpha tests (shapes/triangle.cpp:333-338, 532-570): alphaMask for every ray,
 // shadowAlphaMask for IntersectP only; the local interaction has no differentials (point-sampled / level-0 lookups)
+// (round 5: through the per-mesh DevMaskFast records -- constants, `dots` and image maps over (u, v) are answered without the node / program tables)
+PT_DEV Float MaskValue(const DevMaskFast &m, int node, const TexCtx &tc) {
+    if (m.kind == 2) return m.v_out;
+    if (m.kind == 3) return DotsInside(m.su * tc.u + m.du, m.sv * tc.v + m.dv) ? m.v_in : m.v_out;   // UVMapping2D texture.cpp:86-94 + dots.h:59-80
+    if (m.kind == 4) {                                                                                // imagemap.h:87-94 with zero differentials
+        if (m.image < 0 || (uint32_t)m.image >= c_tex.n_images) return 0;
+        const V2 st{m.su * tc.u + m.du, m.sv * tc.v + m.dv};
+        return MipLookup<false>(c_tex.images + m.image, st, V2{m.su * tc.dudx, m.sv * tc.dvdx}, V2{m.su * tc.dudy, m.sv * tc.dvdy}).r;
+    }
+    return TexEval(node, tc).r;
+}
 __device__ __noinline__ bool TriAlphaRejects(const uint4 *tri_info, const TriShade *tri_shade, uint32_t prim, const V3 p0, const V3 p1, const V3 p2, Float b0,
                                              Float b1, Float b2, bool anyHit) {
     uint32_t mesh = tri_info[prim].w;
-    int at = c_tex.mesh_alpha[2 * mesh], sat = anyHit ? c_tex.mesh_alpha[2 * mesh + 1] : -1;
-    if (at < 0 && sat < 0) return false;
+    const DevMaskFast ma = c_tex.mask_fast[2 * mesh];
+    DevMaskFast ms = c_tex.mask_fast[2 * mesh + 1];
+    if (!anyHit) ms.kind = 0;
+    if (ma.kind == 0 && ms.kind == 0) return false;
     TriShadeRegs tsr = LoadTriShade(tri_shade, prim);
     TexCtx tc;
     tc.p = b0 * p0 + b1 * p1 + b2 * p2;
@@ -218,8 +231,8 @@ __device__ __noinline__ bool TriAlphaRejects(const uint4 *tri_info, const TriSha
     tc.v = b0 * tsr.c.z + b1 * tsr.d.x + b2 * tsr.d.z;
     tc.dpdx = tc.dpdy = V3(0, 0, 0);
     tc.dudx = tc.dvdx = tc.dudy = tc.dvdy = 0;
-    if (at >= 0 && TexEval(at, tc).r == 0) return true;
-    if (sat >= 0 && TexEval(sat, tc).r == 0) return true;
+    if (ma.kind != 0 && MaskValue(ma, ma.kind == 1 ? c_tex.mesh_alpha[2 * mesh] : -1, tc) == 0) return true;
+    if (ms.kind != 0 && MaskValue(ms, ms.kind == 1 ? c_tex.mesh_alpha[2 * mesh + 1] : -1, tc) == 0) return true;
     return false;
 }
 

@@ -14,7 +14,13 @@ struct DevImage {   // mi_image + per-level offsets (in floats) into `texels`
     const float *texels;
     uint32_t level_off[16];
 };
+// What an alpha mask evaluates to at a candidate hit, pre-resolved per mesh at upload (round 5).  The traversal's alpha phase reached a mask through a chain of DEPENDENT
+// fetches -- tri_info -> mesh_alpha -> node type -> program offsets -> program steps -> node fields -- before any arithmetic; for the mask kinds real scenes use the record
+// below carries everything after the first hop.  kind: 0 no mask, 1 any other texture graph (TexEval as before), 2 a constant, 3 `dots` over the (u, v) mapping with constant
+// children, 4 an image map over the (u, v) mapping (point lookup: the hit has no differentials).  The values are EvalNode's, by the same statements.
+struct DevMaskFast { int32_t kind, image; float su, sv, du, dv, v_out, v_in; };   // 32 bytes
 struct DevTex {
+    const DevMaskFast *mask_fast;    // 2 per mesh (alphaMask, shadowAlphaMask), beside mesh_alpha; NULL when no mesh has a mask
     const mi_texture *nodes;
     const DevImage *images;
     const mi_material_desc *descs;   // per material; NULL when no material is textured
@@ -88,6 +94,19 @@ __device__ __noinline__ Float Noise3(Float x, Float y, Float z) {   // texture.c
     Float x00 = Lerp(wx, w000, w100), x10 = Lerp(wx, w010, w110), x01 = Lerp(wx, w001, w101), x11 = Lerp(wx, w011, w111);
     Float y0 = Lerp(wy, x00, x10), y1 = Lerp(wy, x01, x11);
     return Lerp(wz, y0, y1);
+}
+// DotsTexture::Evaluate's decision (textures/dots.h:59-80): is (s, t) inside the cell's dot?
+PT_DEV bool DotsInside(Float s, Float t) {
+    int sCell = (int)__builtin_floorf(s + .5f), tCell = (int)__builtin_floorf(t + .5f);
+    if (Noise3(sCell + .5f, tCell + .5f, .5f) > 0) {
+        Float radius = .35f;
+        Float maxShift = 0.5f - radius;
+        Float sCenter = sCell + maxShift * Noise3(sCell + 1.5f, tCell + 2.8f, .5f);
+        Float tCenter = tCell + maxShift * Noise3(sCell + 4.5f, tCell + 9.8f, .5f);
+        Float dx = s - sCenter, dy = t - tCenter;
+        if (dx * dx + dy * dy < radius * radius) return true;
+    }
+    return false;
 }
 PT_DEV Float SmoothStepT(Float lo, Float hi, Float value) {   // texture.cpp:41-44
     Float v = clampf((value - lo) / (hi - lo), 0, 1);
@@ -327,16 +346,7 @@ template <bool U> __device__ __noinline__ RGB EvalNode(const mi_texture *tp, con
     }
     case MI_TEX_DOTS: {                                              // dots.h:59-80 (tex1 = outsideDot, tex2 = insideDot)
         Map2DOut m = Map2D<U>(tp, si);
-        int sCell = (int)__builtin_floorf(m.st.x + .5f), tCell = (int)__builtin_floorf(m.st.y + .5f);
-        if (Noise3(sCell + .5f, tCell + .5f, .5f) > 0) {
-            Float radius = .35f;
-            Float maxShift = 0.5f - radius;
-            Float sCenter = sCell + maxShift * Noise3(sCell + 1.5f, tCell + 2.8f, .5f);
-            Float tCenter = tCell + maxShift * Noise3(sCell + 4.5f, tCell + 9.8f, .5f);
-            Float dx = m.st.x - sCenter, dy = m.st.y - tCenter;
-            if (dx * dx + dy * dy < radius * radius) return t2v;
-        }
-        return t1v;
+        return DotsInside(m.st.x, m.st.y) ? t2v : t1v;
     }
     case MI_TEX_FBM: case MI_TEX_WRINKLED: {                         // fbm.h:57-61, wrinkled.h:56-60
         V3 P = XfPointT(t->w2t, si.p);
