@@ -886,25 +886,31 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) ps.blockhist[(size_t)blockIdx.x * nkeys + k] = lhist[k];
 }
+// (round 5: one BLOCK per key scans that key's column of the block histograms -- rounds 1-4 walked the column with one thread, ~1 500 dependent fetches = 0.3 ms per bounce
+// whatever the queue held: 2.4 % of the maxdepth-30 frame -- and a second, one-block launch turns the per-key totals into the key offsets)
 __global__ void __launch_bounds__(PT_BLOCK) k_scan_keys(PathState ps, uint32_t nkeys, uint32_t nblocks) {
-    __shared__ uint32_t total[PT_BLOCK];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ uint32_t part[PT_BLOCK];
+    const uint32_t k = blockIdx.x;
+    if (k >= nkeys) return;
+    const uint32_t per = (nblocks + PT_BLOCK - 1) / PT_BLOCK, b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += ps.blockhist[(size_t)b * nkeys + k];
+    part[threadIdx.x] = sum;
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < nkeys; k0 += PT_BLOCK) {   // keys in groups of 256
-        uint32_t k = k0 + threadIdx.x, acc = 0;
-        if (k < nkeys)
-            for (uint32_t b = 0; b < nblocks; ++b) { uint32_t h = ps.blockhist[(size_t)b * nkeys + k]; ps.blockhist[(size_t)b * nkeys + k] = acc; acc += h; }
-        total[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = carry;
-            for (uint32_t j = 0; j < PT_BLOCK && k0 + j < nkeys; ++j) { ps.keyoffset[k0 + j] = run; run += total[j]; }
-            carry = run;
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) {   // exclusive prefix over the 256 partial sums (serial: 256 LDS reads)
+        uint32_t run = 0;
+        for (uint32_t j = 0; j < PT_BLOCK; ++j) { uint32_t v = part[j]; part[j] = run; run += v; }
+        ps.keycount[k] = run;   // this key's total
     }
-    if (threadIdx.x == 0) ps.qcount[QCI(QC_SORTED, 0)] = carry;
+    __syncthreads();
+    uint32_t acc = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; ++b) { uint32_t h = ps.blockhist[(size_t)b * nkeys + k]; ps.blockhist[(size_t)b * nkeys + k] = acc; acc += h; }
+}
+__global__ void __launch_bounds__(PT_BLOCK) k_scan_keys_total(PathState ps, uint32_t nkeys) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < nkeys; ++k) { ps.keyoffset[k] = run; run += ps.keycount[k]; }
+    ps.qcount[QCI(QC_SORTED, 0)] = run;
 }
 __global__ void __launch_bounds__(PT_BLOCK) k_scatter(PathState ps, uint32_t qin, uint32_t nkeys) {
     for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
@@ -2735,7 +2741,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         toc(c);
         tic(c, MI_K_SORT);
         hipLaunchKernelGGL(k_keycount, grid, block, c->nkeys * sizeof(uint32_t), st, sc, ps, qin, c->nkeys);
-        hipLaunchKernelGGL(k_scan_keys, dim3(1), block, 0, st, ps, c->nkeys, (uint32_t)c->gridBlocks);
+        hipLaunchKernelGGL(k_scan_keys, dim3(c->nkeys), block, 0, st, ps, c->nkeys, (uint32_t)c->gridBlocks);
+        hipLaunchKernelGGL(k_scan_keys_total, dim3(1), block, 0, st, ps, c->nkeys);
         hipLaunchKernelGGL(k_scatter, grid, block, 0, st, ps, qin, c->nkeys);
         toc(c);
         HIP_TRY(hipMemsetAsync(ps.cursor, 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -49,7 +50,9 @@ struct Builder {
         std::vector<std::thread> th;
         for (unsigned t = 1; t < T; ++t) {
             const uint32_t c0 = std::min<uint64_t>(b, (uint64_t)a + (uint64_t)t * per), c1 = std::min<uint64_t>(b, (uint64_t)c0 + per);
-            if (c0 < c1) th.emplace_back([=]() { f(c0, c1, t); });
+            if (c0 >= c1) continue;
+            try { th.emplace_back([=]() { f(c0, c1, t); }); }
+            catch (const std::system_error &) { f(c0, c1, t); }   // no thread to be had: the chunk on this one
         }
         f(a, std::min<uint64_t>(b, (uint64_t)a + per), 0u);
         for (auto &x : th) x.join();
@@ -76,11 +79,18 @@ struct Builder {
         nd->n_prims = 0; nd->axis = (uint8_t)axis;
         const uint32_t left = at + 1, right = at + 1 + (2 * (mid - a) - 1);
         nd->offset = (int32_t)right;
+        bool forked = false;
         if (depthLeft > 0 && b - a > 65536) {   // the two halves in parallel near the top of the tree
-            std::thread t([=]() { build(a, mid, left, depthLeft - 1); });
-            build(mid, b, right, depthLeft - 1);
-            t.join();
-        } else {
+            try {
+                std::thread t([=]() { build(a, mid, left, depthLeft - 1); });
+                forked = true;
+                build(mid, b, right, depthLeft - 1);
+                t.join();
+            } catch (const std::system_error &) {   // no more threads to be had: this subtree serially
+                if (forked) throw;                  // (only the constructor throws before `forked`; anything later is not ours to swallow)
+            }
+        }
+        if (!forked) {
             build(a, mid, left, 0);
             build(mid, b, right, 0);
         }
