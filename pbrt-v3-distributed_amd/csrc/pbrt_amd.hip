@@ -1521,7 +1521,7 @@ struct mi_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t evShaded = nullptr, evNeeDone = nullptr;
     bool overlapNee = false;
-    int numCUs = 256, gridBlocks = 1024, gridShade = 1024;
+    int numCUs = 256, gridBlocks = 1024, gridShade = 1024, gridShadeVol = 1024;
     double hotProbeShare = 0;   // share of the probe paths' node visits that fell on the nodes now in nodesq[0 .. n_hot)
     bool hasEnvMap = false, hasSpheres = false;
     bool hasTex = false, hasAlpha = false;   // textured materials / alpha-masked meshes (row f2)
@@ -1747,6 +1747,7 @@ int mi_ctx_create(int device_ordinal, void *stream, mi_ctx **out) {
     c->numCUs = prop.multiProcessorCount;
     c->gridBlocks = ((c->numCUs * PT_GRID_PER_CU + 7) / 8) * 8;   // multiple of 8 for the XCD mapping
     c->gridShade = ((c->numCUs * PT_SHADE_GRID_PER_CU + 7) / 8) * 8;   // k_shade: a multiple of what is resident at PT_SHADE_WAVES per SIMD
+    c->gridShadeVol = ((c->numCUs * 12 + 7) / 8) * 8;   // k_shade_vol and its companions keep rounds 1-4's twelve blocks per CU: one round measured +6 % on the subsurface C3's shading (profiles/r05_v_*)
     std::memset(&c->sc, 0, sizeof(c->sc));
     std::memset(&c->ps, 0, sizeof(c->ps));
     if (c->counters.alloc(PT_CNT_ALLOC * sizeof(uint64_t))) { mi_ctx_destroy(c); return -1; }
@@ -2754,7 +2755,7 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         {   // compile-time variants keep the common case (Sobol', no radiance map) free of the other paths' registers
             const bool halton = sc.sampler_type == MI_SAMPLER_HALTON, pixSmp = MI_SAMPLER_IS_TILE_SERIAL(sc.sampler_type);
             auto shade_vol = [&](const PathState &ps) {   // row f4: media / BSSRDF (pt_volpath.h: the general form traces transmittance, MIS and probe rays in the shading lanes, the wavefront forms queue them)
-                const dim3 gw(c->gridShade);
+                const dim3 gw(c->gridShadeVol);
 #define LAUNCH_VOL(W, I, U, G) hipLaunchKernelGGL((k_shade_vol<W, I, U>), G, block, 0, st, c->scDev, ps, c->vol, qout)
                 const bool umat = !c->vol.textured && !c->vol.bssrdf;   // constant lobe lists only: wave-uniform material access (the UMAT instance compiles the BSSRDF branch out)
                 if (c->volWave) {
@@ -2858,8 +2859,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
         };
         auto vol_continue = [&]() {
             tic(c, MI_K_SHADE);
-            if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
-            else hipLaunchKernelGGL((k_vol_continue<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+            if (c->hasInst) hipLaunchKernelGGL((k_vol_continue<true>), dim3(c->gridShadeVol), block, 0, st, c->scDev, ps, c->vol, qout);
+            else hipLaunchKernelGGL((k_vol_continue<false>), dim3(c->gridShadeVol), block, 0, st, c->scDev, ps, c->vol, qout);
             toc(c);
         };
         if (overlap) {
@@ -2939,8 +2940,8 @@ static int run_pass(mi_ctx *c, const PassInfo &pass, bool countWork, bool toFilm
                 HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_SHADOW, 0), 0, 2 * QSEG * QC_STRIDE * sizeof(uint32_t), st));
                 if (c->volSplit) HIP_TRY(hipMemsetAsync(ps.qcount + QCI(QC_CONT, 0), 0, QSEG * QC_STRIDE * sizeof(uint32_t), st));   // (k_vol_continue has served the bounce's first stage)
                 tic(c, MI_K_SHADE);
-                if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
-                else hipLaunchKernelGGL((k_sss_entry<false>), dim3(c->gridShade), block, 0, st, c->scDev, ps, c->vol, qout);
+                if (c->hasInst) hipLaunchKernelGGL((k_sss_entry<true>), dim3(c->gridShadeVol), block, 0, st, c->scDev, ps, c->vol, qout);
+                else hipLaunchKernelGGL((k_sss_entry<false>), dim3(c->gridShadeVol), block, 0, st, c->scDev, ps, c->vol, qout);
                 toc(c);
                 if (c->volTr ? nee_walk() : nee_plain()) return -1;   // the entry vertices' direct-lighting rays
                 if (c->volSplit) vol_continue();   // ... and, in the split form, their continuation
