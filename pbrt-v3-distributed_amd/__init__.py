@@ -496,7 +496,8 @@ def bvh4_validate(scene):
     L = device_lib()
     if L.mi_bvh4_validate(scene.desc, _ptr(st)) != 0:
         raise RuntimeError("mi_bvh4_validate: %s" % L.mi_last_error().decode())
-    return {"nodes": int(st[0]), "leaf_refs": int(st[1]), "depth": int(st[2]), "stack_need": int(st[3]), "prims": int(st[4]), "objects": int(st[5])}
+    return {"nodes": int(st[0]), "leaf_refs": int(st[1]), "depth": int(st[2]), "stack_need": int(st[3]), "prims": int(st[4]), "objects": int(st[5]),
+            "own_topology": bool(st[6])}   # the library's own topology over the reference's leaves (the default for single-level scenes; PBRT_AMD_TREE=reference: the tree as handed over)
 
 
 def sphere_intersect(spheres, rays, device=0):

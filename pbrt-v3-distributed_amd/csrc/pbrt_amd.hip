@@ -1697,6 +1697,8 @@ struct B4Builder {
         }
         return build(0, 0);
     }
+    // what mi_scene_upload decides: single-level scenes traverse the library's own topology unless PBRT_AMD_TREE=reference (the host-side validators build the same tree)
+    static bool wantOwnTopology(bool twoLevel) { const char *e = std::getenv("PBRT_AMD_TREE"); return !(e && e[0] == 'r') && !twoLevel; }
     // the top-level tree (root = node 0) and, for two-level scenes, one tree per instanced object behind it
     bool buildScene(const mi_scene_desc *d, std::vector<uint32_t> *objRoot, int *topDepth, int *objDepth, std::string *err) {
         *topDepth = *objDepth = 0;
@@ -1841,8 +1843,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     {
         // single-level scenes traverse the library's own topology over the reference's leaves (pt_treebuild.h); PBRT_AMD_TREE=reference keeps the tree as handed over
         // (A/B, and one of the parity suite's traversal modes)
-        const char *e = std::getenv("PBRT_AMD_TREE");
-        bb.ownTopology = !(e && e[0] == 'r') && !c->hasInst;
+        bb.ownTopology = B4Builder::wantOwnTopology(c->hasInst);
         std::string err;
         const auto t0 = std::chrono::steady_clock::now();
         if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_scene_upload: " + err);
@@ -3343,6 +3344,7 @@ int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
     for (int i = 0; i < 8; ++i) stats[i] = 0;
     if (!d->n_bvh_nodes) return 0;
     B4Builder bb;
+    bb.ownTopology = B4Builder::wantOwnTopology(d->n_instances > 0);   // the tree mi_scene_upload would build
     int topDepth = 0, objDepth = 0;
     std::vector<uint32_t> objRoot;
     {
@@ -3397,6 +3399,7 @@ int mi_bvh4_validate(const mi_scene_desc *d, int64_t stats[8]) {
     if (maxDepth != std::max(topDepth, objDepth)) return fail("mi_bvh4_validate: depth bookkeeping differs from the tree");
     stats[0] = (int64_t)bb.out.size(); stats[1] = leaves; stats[2] = maxDepth; stats[3] = B4Builder::stackNeed(topDepth, objDepth, d->n_instances > 0); stats[4] = ncov;
     stats[5] = (int64_t)objRoot.size();
+    stats[6] = bb.rebuilt ? 1 : 0;   // the library's own topology over the reference's leaves (pt_treebuild.h)
     return 0;
 }
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_spheres(const mi_sphere *spheres, const mi_ray *rays, int64_t n, mi_sphere_hit *hits) {
@@ -3631,6 +3634,7 @@ int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int
         return 0;
     }
     B4Builder bb;
+    bb.ownTopology = B4Builder::wantOwnTopology(false);   // the tree mi_scene_upload would build
     int topDepth = 0, objDepth = 0;
     std::vector<uint32_t> objRoot;
     { std::string err; if (!bb.buildScene(d, &objRoot, &topDepth, &objDepth, &err)) return fail("mi_bvh4q_validate: " + err); }

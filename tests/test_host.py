@@ -153,6 +153,34 @@ def test_bvh4_collapse_invariants(built, tmp_path):
         assert st["prims"] == sc.info["n_tris"] and st["stack_need"] == 3 * (st["depth"] + 1) + 1, (acc, st)
 
 
+@pytest.mark.parametrize("tree", ["own", "reference"])
+def test_own_topology_over_the_reference_leaves(built, tree, tmp_path, monkeypatch):
+    """Round 5: single-level scenes traverse the library's own topology over the reference's leaves (csrc/pt_treebuild.h); PBRT_AMD_TREE=reference
+    keeps the tree as handed over.  Host only: under either, the collapsed tree passes its structural checks (every primitive in exactly one leaf,
+    boxes nested) with the SAME leaf references -- the leaves are the contract -- and the per-ray state machine of the quantised traversal gives the
+    hits of the oracle's BVH2 traversal bit for bit (closest and any hit)."""
+    import subprocess, sys
+    monkeypatch.setenv("PBRT_AMD_TREE", tree)
+    out = str(tmp_path / "sm.pbrt")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", "150000", "--res", "96", "54", "--spp", "1", "--out", out], stdout=subprocess.DEVNULL)
+    for sc in (pa.Scene(os.path.join(ROOT, "scenes", "materials.pbrt")), pa.Scene(out)):
+        st = pa.bvh4_validate(sc)
+        assert st["prims"] == sc.info["n_tris"] and st["own_topology"] == (tree == "own")
+        monkeypatch.setenv("PBRT_AMD_TREE", "reference")
+        st_ref = pa.bvh4_validate(sc)
+        monkeypatch.setenv("PBRT_AMD_TREE", tree)
+        assert st["leaf_refs"] == st_ref["leaf_refs"]   # same leaves, however the interior is arranged
+        rays = _study_rays(sc, 20000, 3)
+        ref, _ = ol.intersect(sc, rays)
+        h, _ = pa.bvh4q_validate(sc, rays)
+        assert np.array_equal(h["prim"], ref["prim"])
+        for k in ("t", "b1", "b2"):
+            assert np.array_equal(h[k].view(np.uint32), ref[k].view(np.uint32)), k
+        occ, _ = ol.intersect_p(sc, rays)
+        h2, _ = pa.bvh4q_validate(sc, rays, any_hit=True)
+        assert np.array_equal((h2["prim"] >= 0).astype(np.uint8), occ)
+
+
 @pytest.mark.parametrize("name", ["instances", "instances2"])
 def test_bvh4_collapse_two_level(built, name, monkeypatch):
     """Two-level scenes (PBRT_AMD_INSTANCING=1): mi_scene_upload collapses the top-level BVH2 and every instanced object's own BVH2 into
