@@ -181,6 +181,34 @@ def test_own_topology_over_the_reference_leaves(built, tree, tmp_path, monkeypat
         assert np.array_equal((h2["prim"] >= 0).astype(np.uint8), occ)
 
 
+@pytest.mark.parametrize("tree", ["own", "reference"])
+def test_coplanar_duplicated_triangles_resolve_as_in_the_reference(built, tree, monkeypatch):
+    """Ties at exactly equal t: a wall of 64 quads, every quad present TWICE as separate shapes in shuffled order -- each ray
+    that hits the wall hits two coincident triangles at the same t, bit for bit.  The reference keeps the one it tests last (`t > ray.tMax` rejects,
+    triangle.cpp:258-261); the per-ray state machine of the quantised traversal must report the same primitive under either topology."""
+    import random
+    monkeypatch.setenv("PBRT_AMD_TREE", tree)
+    random.seed(1)
+    quad = lambda x0, y0: ('Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [%g %g 1 %g %g 1 %g %g 1 %g %g 1]\n' % (x0, y0, x0 + .5, y0, x0 + .5, y0 + .5, x0, y0 + .5))
+    order = [(-2 + .5 * i, -2 + .5 * j) for i in range(8) for j in range(8)] * 2
+    random.shuffle(order)
+    text = ('LookAt 0 0 -5 0 0 0 0 1 0\nCamera "perspective" "float fov" [40]\nSampler "sobol" "integer pixelsamples" [1]\n'
+            'Film "image" "integer xresolution" [64] "integer yresolution" [64] "string filename" "t.pfm"\nWorldBegin\nMaterial "matte"\n' + "".join(quad(*q) for q in order) +
+            'AttributeBegin\nAreaLightSource "diffuse" "rgb L" [5 5 5]\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 3 0 1 3 0 0 3 1]\nAttributeEnd\nWorldEnd\n')
+    sc = pa.Scene(text=text)
+    rng = np.random.default_rng(3)
+    n = 20000
+    rays = np.zeros(n, dtype=pa.RAY_DTYPE)
+    rays["o"] = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.full(n, -5.0)], 1).astype(np.float32)
+    rays["d"] = np.stack([rng.uniform(-.05, .05, n), rng.uniform(-.05, .05, n), np.ones(n)], 1).astype(np.float32)
+    rays["tmax"] = np.inf
+    ref, _ = ol.intersect(sc, rays)
+    assert (ref["prim"] >= 0).sum() > n // 2
+    h, _ = pa.bvh4q_validate(sc, rays)
+    assert np.array_equal(h["prim"], ref["prim"])
+    assert np.array_equal(h["t"].view(np.uint32), ref["t"].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["instances", "instances2"])
 def test_bvh4_collapse_two_level(built, name, monkeypatch):
     """Two-level scenes (PBRT_AMD_INSTANCING=1): mi_scene_upload collapses the top-level BVH2 and every instanced object's own BVH2 into
