@@ -1021,7 +1021,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #define PT_SHADE_WAVES 3   /* 168 VGPRs -> 3 waves per SIMD: measured best of 2..5 (profiles/r01 notes) */
 #endif
 #ifndef PT_SHADE_GRID_PER_CU
-#define PT_SHADE_GRID_PER_CU PT_SHADE_WAVES   /* one round of resident blocks: DynIter hands the items out dynamically.  (Rounds 1-4: four rounds, which evened out the STATIC chunk partition; re-measured over the dynamic, interleaved one in round 5, profiles/r05_tu_*: 3 / 6 / 12 blocks per CU within 0.3 % on C3, C2, C4 and the textured C3) */
+#define PT_SHADE_GRID_PER_CU PT_SHADE_WAVES   /* one round of resident blocks: DynIter hands the items out dynamically.  (Rounds 1-4: four rounds, which evened out the STATIC chunk partition; re-measured over the dynamic, interleaved one in round 5, profiles/r05_tux_*: 3 / 6 / 12 blocks per CU within 0.3 % on C3, C2, C4 and the textured C3) */
 #endif
 // ENV ("rich" scenes): an infinite light with a radiance map (escaped rays look it up) or Sphere primitives; plain scenes run the leaner instance
 // TEX: some material has image / procedural textures or a bump map -- every material's lobe list is then a per-lane record
