@@ -121,18 +121,19 @@ class FilmExchange:
 def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
     """One scene build per NODE: local rank 0 calls `load()` (parse + the reference's BVH build, with every CPU of the node: the other ranks only
     wait) and publishes the flattened scene with Scene.save_blob(blob_path); the other local ranks map that file (Scene(blob=...): shared page
-    cache, no second copy of the geometry in host memory, no second BVH build).  `blob_path` must be unique per job (callers put the launcher's
-    pid into it) so that a blob left behind by an earlier job is never mapped.  Returns (scene, seconds, "built" | "mapped")."""
+    cache, no second copy of the geometry in host memory, no second BVH build).  The file name gets a per-job, per-call suffix (below), so that a blob left behind by
+    an earlier job is never mapped.  Returns (scene, seconds, "built" | "mapped")."""
     import importlib, os, time
     pa = importlib.import_module(__package__)
     t0 = time.time()
-    # (ADVICE r4) the name carries a nonce every rank of THIS job derives alike -- the rendezvous' port and run id, and the number of the call within the job -- so
-    # that a waiting rank can never map the blob of an earlier node_scene call or of another job started from the same long-lived parent process
+    # (ADVICE r4) the name carries a nonce every rank of THIS job derives alike -- the launcher's pid AND start time (a reused pid gets another start time), the
+    # rendezvous' port and run id, and the number of the call within the job -- so that a waiting rank can never map the blob of an earlier node_scene call, of an
+    # earlier job whose launcher pid was reused, or of another job started from the same long-lived parent process.  Whatever exists under this name is this call's
+    # blob: the waiting ranks test for existence only (no comparison of file times with process start times, which a stepped clock could turn into an hour's wait).
     global _NODE_SCENE_CALLS
     _NODE_SCENE_CALLS += 1
-    blob_path = "%s.%s_%s_%d" % (blob_path, os.environ.get("MASTER_PORT", "0"), "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24], _NODE_SCENE_CALLS)
+    blob_path = "%s.%s.%s_%s_%d" % (blob_path, _launcher_id(), os.environ.get("MASTER_PORT", "0"), "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24], _NODE_SCENE_CALLS)
     _NODE_SCENE_FILES.append(blob_path)
-    born = _launcher_start_time()   # a blob older than this job's launcher belongs to an earlier job whose pid was reused: never mapped
     if local_rank == 0:
         for f in (blob_path, blob_path + ".failed"):   # leftovers of a crashed job with the same launcher pid
             try:
@@ -150,17 +151,9 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
         except Exception as e:   # no room in /dev/shm, read-only directory ...: the other ranks build the scene themselves instead of waiting for nothing
             _write_failed(blob_path, str(e))
         return sc, time.time() - t0, "built"
-    while True:
-        try:
-            if os.path.getmtime(blob_path) >= born:
-                break
-        except OSError:
-            pass
-        try:
-            if os.path.getmtime(blob_path + ".failed") >= born:
-                return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
-        except OSError:
-            pass
+    while not os.path.exists(blob_path):   # (published by rename: complete or absent)
+        if os.path.exists(blob_path + ".failed"):
+            return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
         if time.time() - t0 > timeout_s:
             raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
         time.sleep(0.1)
@@ -191,18 +184,16 @@ def _write_failed(blob_path, text):
         pass
 
 
-def _launcher_start_time():
-    """Wall-clock start time of this process's parent (the launcher all local ranks share), from /proc; 0.0 when it cannot be read.  One second is
-    subtracted for the granularity of /proc's clock ticks and of file mtimes."""
+def _launcher_id():
+    """pid and start time (clock ticks since boot, /proc/<pid>/stat field 22) of this process's parent -- the launcher all local ranks share: unique per job on a node,
+    also when the pid is reused.  Without /proc: the pid alone."""
     import os
+    ppid = os.getppid()
     try:
-        with open("/proc/%d/stat" % os.getppid()) as f:
-            ticks = float(f.read().rsplit(")", 1)[1].split()[19])   # field 22: starttime, in clock ticks since boot
-        with open("/proc/stat") as f:
-            btime = next(float(l.split()[1]) for l in f if l.startswith("btime"))
-        return btime + ticks / os.sysconf("SC_CLK_TCK") - 1.0
+        with open("/proc/%d/stat" % ppid) as f:
+            return "%d_%s" % (ppid, f.read().rsplit(")", 1)[1].split()[19])
     except Exception:
-        return 0.0
+        return "%d_0" % ppid
 
 
 def launch_ranks(n_ranks, script, argv, backend_env=None):

@@ -71,3 +71,44 @@ def test_two_rank_tile_sharding_and_film_reduce(built, tmp_path, which):
     own_only = whole[..., 3] == sc.info["spp"]
     assert np.array_equal(combined[own_only].view(np.uint32), whole[own_only].view(np.uint32))   # N-rank image == 1-rank image, bit for bit
     assert np.allclose(combined, whole, rtol=1e-6, atol=1e-7)
+
+
+def _node_scene_worker(rank, port, texts, out_dir):
+    os.environ["MASTER_PORT"] = str(port)
+    par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
+    base = os.path.join(out_dir, "scene.blob")
+    hows = []
+    for k, text in enumerate(texts):   # two calls of one job under the same base name: the second must never map the first's blob
+        sc, _, how = par.node_scene(lambda: pa.Scene(text=text), base, rank)
+        hows.append((how, sc.width, sc.height))
+    # third call: rank 0's load fails -- it says so to the waiting rank (which then builds the scene itself) and re-raises
+    if rank == 0:
+        def boom():
+            raise ValueError("no such scene")
+        with pytest.raises(ValueError):
+            par.node_scene(boom, base, rank)
+        hows.append(("raised", 0, 0))
+    else:
+        sc, _, how = par.node_scene(lambda: pa.Scene(text=texts[0]), base, rank, timeout_s=120.0)
+        hows.append((how, sc.width, sc.height))
+    np.save(os.path.join(out_dir, "hows_%d.npy" % rank), np.array([h[0] for h in hows]))
+    np.save(os.path.join(out_dir, "dims_%d.npy" % rank), np.array([[h[1], h[2]] for h in hows]))
+
+
+def test_node_scene_names_are_per_job_and_per_call_and_failures_are_announced(built, tmp_path):
+    """parallel.node_scene: the published file's name carries the launcher's pid + start time, the rendezvous port and the call number, and the waiting ranks test for
+    existence only.  Two calls with different scenes under one base name: the waiting rank maps each call's own blob (a stale file of another job under the OLD naming
+    scheme, planted here, is ignored); a load that fails on rank 0 reaches the waiting rank as a '.failed' note instead of a timeout."""
+    import torch.multiprocessing as mp
+    a = _scene_text("cornell")
+    b = a.replace('[80] "integer yresolution" [48]', '[64] "integer yresolution" [32]')
+    open(tmp_path / "scene.blob", "wb").write(b"stale")   # what an earlier job might have left under the bare base name
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_node_scene_worker, args=(port, [a, b], str(tmp_path)), nprocs=2, join=True)
+    h0, h1 = np.load(tmp_path / "hows_0.npy"), np.load(tmp_path / "hows_1.npy")
+    d0, d1 = np.load(tmp_path / "dims_0.npy"), np.load(tmp_path / "dims_1.npy")
+    assert list(h0) == ["built", "built", "raised"]
+    assert list(h1[:2]) == ["mapped", "mapped"] and h1[2].startswith("built (rank 0 could not publish")
+    assert d0[:2].tolist() == [[80, 48], [64, 32]] and d1.tolist() == [[80, 48], [64, 32], [80, 48]]
+    par = importlib.import_module("pbrt-v3-distributed_amd.parallel")
+    assert par._launcher_id().startswith("%d_" % os.getppid())
