@@ -44,7 +44,11 @@ def _worker(rank, world, port, scene_text, out_dir):
     xchg = par.FilmExchange(sc, rank, world, torch.device("cpu"))   # sparse: reachable pixels only, added on rank 0 (what ShardedFrame.step does)
     xchg.finish(xchg.start(sparse))
     if rank == 0:
-        assert np.array_equal(sparse.numpy().view(np.uint32), film.numpy().view(np.uint32))   # (two ranks: one addition per pixel either way)
+        if world == 2:
+            assert np.array_equal(sparse.numpy().view(np.uint32), film.numpy().view(np.uint32))   # (two ranks: one addition per pixel either way)
+        else:   # more senders: rank 0's N - 1 receives are one group, added in rank order; a pixel three ranks reach may round differently from gloo's reduction tree
+            assert np.allclose(sparse.numpy(), film.numpy(), rtol=1e-6, atol=1e-7)
+            assert (sparse.numpy().view(np.uint32) == film.numpy().view(np.uint32)).mean() > 0.999
         np.save(os.path.join(out_dir, "combined.npy"), sparse.numpy().reshape(sc.height, sc.width, 4))
     dist.barrier()
     dist.destroy_process_group()
@@ -59,12 +63,13 @@ def _scene_text(which):
     return edge_scenes.scene(which)   # a textured scene: the image pyramids travel inside the blob
 
 
-@pytest.mark.parametrize("which", ["cornell", "tex_imagemap"])
-def test_two_rank_tile_sharding_and_film_reduce(built, tmp_path, which):
+@pytest.mark.parametrize("which,world", [("cornell", 2), ("tex_imagemap", 2), ("cornell", 4)])
+def test_two_rank_tile_sharding_and_film_reduce(built, tmp_path, which, world):
+    """(world 4: three senders -- the grouped receives of FilmExchange and the rank-order adds with more than one source, the shape of the driver's N = 4 / 8 runs)"""
     import torch.multiprocessing as mp
     text = _scene_text(which)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, text, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, text, str(tmp_path)), nprocs=world, join=True)
     combined = np.load(tmp_path / "combined.npy")
     sc = pa.Scene(text=text)
     whole, _, _ = ol.render(sc, nthreads=2)
