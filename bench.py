@@ -37,6 +37,49 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_T0 = time.time()
+_RANK = int(os.environ.get("RANK", "0"))
+_TRACE = int(os.environ.get("WORLD_SIZE", "1")) > 1 or bool(os.environ.get("PBRT_AMD_BENCH_TRACE"))
+
+
+def phase(name):
+    """one stderr line per rank and phase of a multi-rank run (scene / ctx / init_pg / step / exchange / barrier): a stalled job says where it stalled"""
+    if _TRACE:
+        log("[bench r%d +%.1fs] %s" % (_RANK, time.time() - _T0, name))
+
+
+def wait_for(path, timeout_s, what):
+    """bounded wait for a file another local rank publishes"""
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout_s:
+            raise SystemExit("bench.py (rank %d): %s did not appear within %.0f s (%s)" % (_RANK, path, timeout_s, what))
+        time.sleep(0.1)
+
+
+def publish_dir(d, make, leader, timeout_s, what):
+    """A generated scene directory, published complete or not at all: the node's leader (local rank 0) has `make(tmpdir)` fill a fresh private directory,
+    stamps it and renames it to `d`; every rank then waits (bounded) for d/.done.  Nobody ever reads a file that is still being written."""
+    import shutil
+    marker = os.path.join(d, ".done")
+    if leader and not os.path.exists(marker):
+        tmp = "%s.tmp.%d" % (d, os.getpid())
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        make(tmp)
+        with open(os.path.join(tmp, ".done"), "w") as f:
+            f.write("ok")
+        try:
+            os.rename(tmp, d)
+        except OSError:
+            if os.path.exists(marker):          # another job published the same scene meanwhile: identical by construction
+                shutil.rmtree(tmp, ignore_errors=True)
+            else:                                # an unstamped leftover of an interrupted run
+                shutil.rmtree(d, ignore_errors=True)
+                os.rename(tmp, d)
+    wait_for(marker, timeout_s, what)
+
+
 def host_cpus():
     """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU box shows 256 hardware
     threads but grants a container 16 CPUs' worth of time -- more threads than that only throttle each other)."""
@@ -328,7 +371,8 @@ def main():
                          "for 3 steps in a child process and report it as secondary.textured_leafmask inside the one JSON line; auto = with the default C3 workload on one GPU")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on a 1-GPU box)")
-    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses GPU 0")
+    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses GPU 0 (device ordinal only: local rank 0 still builds the scene alone, the others map it)")
+    ap.add_argument("--dump-film", default=None, help="rank 0 saves the combined FilmTilePixel array (H, W, 4 float32: contribSum rgb, filterWeightSum) of the last timed step as .npy")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -346,8 +390,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
 
-    if world > 1 and args.one_device:
-        local_rank = 0
+    # --one-device moves every rank's DEVICE ORDINAL to GPU 0 and nothing else: local rank 0 alone generates / builds / publishes the scene, the others map it
+    dev_ordinal = 0 if (world > 1 and args.one_device) else local_rank
+    if world > 1:
+        import faulthandler
+        faulthandler.enable()
+        faulthandler.dump_traceback_later(float(os.environ.get("PBRT_AMD_BENCH_STACKS_S", "120")), repeat=True)   # a stalled rank shows its stack
+    wait_s = float(os.environ.get("PBRT_AMD_BENCH_WAIT_S", "1800"))
+    phase("start: rank %d of %d, local rank %d, device %d, pid %d" % (rank, world, local_rank, dev_ordinal, os.getpid()))
 
     # ---- scene (generated once per node by local rank 0)
     bench_dir = os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench")
@@ -366,8 +416,7 @@ def main():
             text = text.replace("killeroo_geo/", os.path.join(ROOT, "scenes", "killeroo_geo") + "/")
             open(scene_file + ".tmp", "w").write(text)
             os.rename(scene_file + ".tmp", scene_file)
-        while not os.path.exists(scene_file):
-            time.sleep(0.2)
+        wait_for(scene_file, wait_s, "the c2 scene file, written by local rank 0")
         workload = "killeroo-simple.pbrt as the reference ships it (Sphere area light, Halton sampler; geometry pre-subdivided to PLY): 66.5 k triangles, %dx%d, %d spp, path maxdepth 5" % (args.res[0], args.res[1], spp)
     elif args.config == "c4":
         spp = args.spp if args.spp != 64 else 256
@@ -375,28 +424,19 @@ def main():
         key = "bathroom_synth_%dk_%dx%d_%dspp" % (tris // 1000, args.res[0], args.res[1], spp)
         d = os.path.join(bench_dir, key)
         scene_file = os.path.join(d, "bathroom_synth.pbrt")
-        marker = os.path.join(d, ".done")
-        if local_rank == 0 and not os.path.exists(marker):
-            os.makedirs(d, exist_ok=True)
-            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "bathroom", "--tris", str(tris),
-                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(spp), "--out", scene_file], stdout=sys.stderr)
-            open(marker, "w").write("ok")
-        while not os.path.exists(marker):
-            time.sleep(0.2)
+        publish_dir(d, lambda tmp: subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "bathroom", "--tris", str(tris),
+                                                          "--res", str(args.res[0]), str(args.res[1]), "--spp", str(spp), "--out", os.path.join(tmp, "bathroom_synth.pbrt")], stdout=sys.stderr),
+                    local_rank == 0, wait_s, "the c4 scene, generated by local rank 0")
         workload = "Contemporary-Bathroom-class synthetic stand-in: glass/mirror/metal, %dx%d, %d spp, path maxdepth 30" % (args.res[0], args.res[1], spp)
     else:
         key = "sanmiguel_synth_%dk_%dx%d_%dspp%s" % (args.tris // 1000, args.res[0], args.res[1], args.spp, ("_tex" if args.textured else "") + ("_haze" if args.volpath else "") + ("_fogbox" if args.fogbox else "") + ("_leafmask" if args.leafmask else "") + ("_sss" if args.subsurface else "") + ("_smokebox" if args.smokebox else ""))
         d = os.path.join(bench_dir, key)
         scene_file = os.path.join(d, "sanmiguel_synth.pbrt")
-        marker = os.path.join(d, ".done")
-        if local_rank == 0 and not os.path.exists(marker):
-            os.makedirs(d, exist_ok=True)
-            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris),
-                                   "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", scene_file] + (["--textured"] if args.textured else []) + (["--haze"] if args.volpath else []) + (["--fogbox"] if args.fogbox else []) + (["--leafmask"] if args.leafmask else []) + (["--subsurface"] if args.subsurface else []) + (["--smokebox"] if args.smokebox else []),
-                                  stdout=sys.stderr)
-            open(marker, "w").write("ok")
-        while not os.path.exists(marker):
-            time.sleep(0.2)
+        variant = (["--textured"] if args.textured else []) + (["--haze"] if args.volpath else []) + (["--fogbox"] if args.fogbox else []) + (["--leafmask"] if args.leafmask else []) + \
+                  (["--subsurface"] if args.subsurface else []) + (["--smokebox"] if args.smokebox else [])
+        publish_dir(d, lambda tmp: subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "sanmiguel", "--tris", str(args.tris),
+                                                          "--res", str(args.res[0]), str(args.res[1]), "--spp", str(args.spp), "--out", os.path.join(tmp, "sanmiguel_synth.pbrt")] + variant, stdout=sys.stderr),
+                    local_rank == 0, wait_s, "the c3 scene, generated by local rank 0")
         workload = "San-Miguel-class synthetic stand-in (SURVEY.md s.8d): %d triangles, %dx%d, %d spp, path maxdepth 5, sobol, box filter" % (
             args.tris, args.res[0], args.res[1], args.spp)
         if args.textured:
@@ -419,21 +459,30 @@ def main():
     os.environ.setdefault("PBRT_AMD_NTHREADS", str(max(1, host_cpus())))
     blob_dir = os.environ.get("PBRT_AMD_BLOB_DIR") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else bench_dir)   # tmpfs: the blob is a memcpy, not a disk write
     blob = os.path.join(blob_dir, "pbrt_amd_scene_%d.blob" % os.getppid())   # the launcher's pid: unique per job
+    phase("scene files in place: %s" % scene_file)
     if world > 1:
-        sc, t_load, scene_source = par.node_scene(lambda: pa.Scene(scene_file), blob, local_rank)
+        sc, t_load, scene_source = par.node_scene(lambda: pa.Scene(scene_file, strict=True), blob, local_rank, timeout_s=wait_s)
     else:
         t0 = time.time()
-        sc = pa.Scene(scene_file)
+        sc = pa.Scene(scene_file, strict=True)
         t_load, scene_source = time.time() - t0, "built"
     t0 = time.time()
-    ctx = pa.Context(sc, device=local_rank)
+    phase("scene %s in %.1f s: %d tris" % (scene_source, t_load, sc.info["n_tris"]))
+    ctx = pa.Context(sc, device=dev_ordinal)
     t_upload = time.time() - t0
+    phase("device context on GPU %d in %.1f s" % (dev_ordinal, t_upload))
     if rank == 0:
         log("[bench] scene %s: %d tris, %d BVH2 nodes, %d materials, %d lights; parse+BVH %.1f s, upload+BVH4 %.1f s" %
             (workload, sc.info["n_tris"], sc.info["n_bvh_nodes"], sc.info["n_materials"], sc.info["n_lights"], t_load, t_upload))
 
     # one rank of the tile-sharded frame (pbrt-v3-distributed_amd/parallel.py): film in a torch tensor, RCCL reduce onto rank 0 per step
-    frame = par.ShardedFrame(ctx, sc, rank, world, local_rank, backend=args.backend, one_device=args.one_device)
+    frame = par.ShardedFrame(ctx, sc, rank, world, dev_ordinal, backend=args.backend, trace=phase)
+    phase("process group up (%s)" % args.backend)
+    scene_sources = None
+    if world > 1:   # how every rank got its scene ("built" on local rank 0, "mapped" elsewhere): part of the line, so a test can tell the blob path really ran
+        import torch.distributed as dist
+        scene_sources = [None] * world
+        dist.all_gather_object(scene_sources, scene_source)
     sync_all = frame.sync_all
 
     def step(count=False):
@@ -451,6 +500,7 @@ def main():
     step(count=True)
     sync_all()
     work = ctx.counters()
+    phase("counting pass done")
     try:
         trace_clk = ctx.trace_clock()   # shader clock inside the traversal launches of the counting pass (s_memtime / s_memrealtime per wave)
     except Exception:
@@ -468,6 +518,9 @@ def main():
         step()
     sync_all()
     elapsed = frame.max_over_ranks(time.perf_counter() - t0)
+    phase("%d timed step(s) done: %.1f ms per step" % (args.steps, elapsed / max(1, args.steps) * 1e3))
+    if args.dump_film and rank == 0:
+        np.save(args.dump_film, frame.root_film())
     timing = ctx.timing()
     cnt = ctx.counters()
     if cnt.get("trace_guard_trips", 0):
@@ -618,8 +671,12 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
                "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2),
                            "scene": "rank 0 of the node builds it once, the other ranks map the published blob" if world > 1 else "built"}}
+        if world > 1:
+            out["setup_s"]["scene_by_rank"] = scene_sources
+    phase("closing")
     frame.close()
     ctx.close()
+    phase("closed")
     if rank == 0:
         # ---- the San-Miguel-like variant beside the headline: what the real scene is -- textured, bump-mapped materials and alpha-masked foliage --
         # rendered by a child process once this process has released the GPU memory of the headline frame; the headline workload itself is unchanged

@@ -138,13 +138,17 @@ class Scene:
                    "crop_x0", "crop_y0", "crop_x1", "crop_y1", "spp", "max_depth", "sobol_resolution",
                    "sobol_log2_resolution"]
 
-    def __init__(self, filename=None, text=None, quiet=True, outfile=None, cropwindow=None, blob=None):
+    def __init__(self, filename=None, text=None, quiet=True, outfile=None, cropwindow=None, blob=None, strict=False):
         """cropwindow = (x0, x1, y0, y1): the command line's --cropwindow (overrides the Film's own, as in the reference).
+        strict = True: any Error() the loader logged while reading the scene (a missing or cut-off PLY file, a bad parameter -- things the reference logs and
+        renders WITHOUT, main/pbrt.cpp keeps going) raises instead: a benchmark or a rank of a sharded job must never render a different scene.  `errors` = their count.
         blob = a file written by save_blob(): the mi_scene_desc of a scene ANOTHER process parsed and built, mapped read-only (shared page
         cache; one scene build per node instead of one per rank).  A mapped scene has no Film: film_image / write_image belong to the builder."""
         L = host_lib()
         src = text if text is not None else filename
         self.mapped = blob is not None
+        L.pbrt_amd_error_count.restype = C.c_int
+        errors0 = L.pbrt_amd_error_count()
         if blob is not None:
             self._h = L.pbrt_amd_scene_map_blob(blob.encode())
             if not self._h:
@@ -158,6 +162,10 @@ class Scene:
                                             outfile.encode() if outfile else None)
         if not self._h:
             raise RuntimeError("scene load failed: %r" % (filename or "<text>"))
+        self.errors = L.pbrt_amd_error_count() - errors0
+        if strict and self.errors:
+            self.close()
+            raise RuntimeError("scene %r: the loader reported %d error(s) (see stderr); strict mode does not render a scene that differs from the file" % (filename or "<text>", self.errors))
         self._finish_init()
 
     def _finish_init(self):

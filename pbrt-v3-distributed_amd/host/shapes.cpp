@@ -2,6 +2,7 @@
 // Reference: shapes/triangle.cpp:60-110 (TriangleMesh ctor: vertices/normals/tangents are
 // transformed to world space once), :648-744 (CreateTriangleMeshShape parameter handling),
 // shapes/plymesh.cpp:157-290 (PLY loading; quads split (0,1,2),(3,0,2), :141-147).
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -137,13 +138,25 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
     bool hasN = false, hasUV = false;
 
     std::istringstream as;
-    const unsigned char *bp = (const unsigned char *)data.data() + pos;
-    if (ascii) as.str(data.substr(pos));
+    const unsigned char *bp = (const unsigned char *)data.data() + std::min(pos, data.size());
+    const unsigned char *const bend = (const unsigned char *)data.data() + data.size();
+    if (ascii) as.str(data.substr(std::min(pos, data.size())));
+    // a file shorter than its header promises (cut off, or still being written by somebody else) is an error, never a smaller mesh: every value read is
+    // checked against the end of the file (plymesh.cpp:196-202: rply's ply_read fails the same way and the shape is dropped with an Error)
+    bool truncated = false;
     auto readVal = [&](const std::string &type) -> double {
-        if (ascii) { double v = 0; as >> v; return v; }
+        if (truncated) return 0;
+        if (ascii) { double v = 0; if (!(as >> v)) truncated = true; return v; }
+        int n = plyTypeSize(type);
+        if (n == 0 || bend - bp < n) { truncated = true; return 0; }
         return plyReadBinary(bp, type, swap);
     };
+    auto cutOff = [&]() {
+        Error("Unable to read the contents of PLY file \"%s\": the file ends before the %ld vertices / %ld faces its header declares", filename.c_str(), vertexCount, faceCount);
+        return nullptr;
+    };
     for (auto &e : elems) {
+        if (truncated) break;
         if (e.name == "vertex") {
             int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
             for (size_t k = 0; k < e.props.size(); ++k) {
@@ -158,9 +171,10 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
             hasUV = iu >= 0 && iv >= 0;
             if (hasN) N.resize(vertexCount);
             if (hasUV) UV.resize(2 * vertexCount);
-            for (long i = 0; i < e.count; ++i)
+            if (e.count != vertexCount) return cutOff();   // two vertex elements
+            for (long i = 0; i < e.count && !truncated; ++i)
                 for (size_t k = 0; k < e.props.size(); ++k) {
-                    if (e.props[k].isList) { long n = (long)readVal(e.props[k].countType); for (long j = 0; j < n; ++j) readVal(e.props[k].itemType); continue; }
+                    if (e.props[k].isList) { long n = (long)readVal(e.props[k].countType); for (long j = 0; j < n && !truncated; ++j) readVal(e.props[k].itemType); continue; }
                     float v = (float)readVal(e.props[k].type);
                     if ((int)k == ix) P[i].x = v; else if ((int)k == iy) P[i].y = v; else if ((int)k == iz) P[i].z = v;
                     else if (hasN && (int)k == inx) N[i].x = v; else if (hasN && (int)k == iny) N[i].y = v;
@@ -168,12 +182,14 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
                     else if (hasUV && (int)k == iu) UV[2 * i] = v; else if (hasUV && (int)k == iv) UV[2 * i + 1] = v;
                 }
         } else if (e.name == "face") {
-            for (long i = 0; i < e.count; ++i)
+            for (long i = 0; i < e.count && !truncated; ++i)
                 for (auto &p : e.props) {
                     if (!p.isList) { readVal(p.type); continue; }
                     long n = (long)readVal(p.countType);
+                    if (truncated || n < 0 || n > (1 << 24)) { truncated = true; break; }
                     std::vector<int> face(n);
                     for (long j = 0; j < n; ++j) face[j] = (int)readVal(p.itemType);
+                    if (truncated) break;
                     if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
                     if (n != 3 && n != 4) { Warning("plymesh: Ignoring face with %i vertices (only triangles and quads are supported!)", (int)n); continue; }
                     for (long j = 0; j < n; ++j)
@@ -185,13 +201,14 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool ro, const
                     if (n == 4) indices.insert(indices.end(), {face[3], face[0], face[2]});
                 }
         } else {   // skip unknown elements
-            for (long i = 0; i < e.count; ++i)
+            for (long i = 0; i < e.count && !truncated; ++i)
                 for (auto &p : e.props) {
-                    if (p.isList) { long n = (long)readVal(p.countType); for (long j = 0; j < n; ++j) readVal(p.itemType); }
+                    if (p.isList) { long n = (long)readVal(p.countType); for (long j = 0; j < n && !truncated; ++j) readVal(p.itemType); }
                     else readVal(p.type);
                 }
         }
     }
+    if (truncated) return cutOff();
     return CreateTriangleMesh(o2w, ro, (int)indices.size() / 3, indices.data(), (int)vertexCount, P.data(), nullptr,
                               hasN ? N.data() : nullptr, hasUV ? UV.data() : nullptr);
 }

@@ -118,7 +118,7 @@ class FilmExchange:
             pending.synchronize()
 
 
-def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
+def node_scene(load, blob_path, local_rank, timeout_s=1800.0):
     """One scene build per NODE: local rank 0 calls `load()` (parse + the reference's BVH build, with every CPU of the node: the other ranks only
     wait) and publishes the flattened scene with Scene.save_blob(blob_path); the other local ranks map that file (Scene(blob=...): shared page
     cache, no second copy of the geometry in host memory, no second BVH build).  The file name gets a per-job, per-call suffix (below), so that a blob left behind by
@@ -132,9 +132,29 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
     # blob: the waiting ranks test for existence only (no comparison of file times with process start times, which a stepped clock could turn into an hour's wait).
     global _NODE_SCENE_CALLS
     _NODE_SCENE_CALLS += 1
-    blob_path = "%s.%s.%s_%s_%d" % (blob_path, _launcher_id(), os.environ.get("MASTER_PORT", "0"), "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24], _NODE_SCENE_CALLS)
-    _NODE_SCENE_FILES.append(blob_path)
+    blob_base = blob_path
+    blob_path = "%s.%s.%s_%s_%s_%d" % (blob_path, _launcher_id(), os.environ.get("MASTER_PORT", "0"), "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24],
+                                       os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _NODE_SCENE_CALLS)
+    launcher = os.getppid()
     if local_rank == 0:
+        if os.path.isdir("/proc/self"):
+            _sweep_stale(blob_base)
+        _NODE_SCENE_FILES.append(blob_path)
+        global _CLEANUP_REGISTERED
+        if not _CLEANUP_REGISTERED:   #  an exit that skips node_scene_cleanup -- exception, SIGTERM from a launcher's timeout -- must not leave a multi-GB blob in /dev/shm
+            import atexit, signal
+            _CLEANUP_REGISTERED = True
+            atexit.register(node_scene_cleanup)
+            try:
+                prev = signal.getsignal(signal.SIGTERM)
+                def _on_term(signum, frame):
+                    node_scene_cleanup()
+                    if callable(prev):
+                        prev(signum, frame)
+                    raise SystemExit(128 + signum)
+                signal.signal(signal.SIGTERM, _on_term)
+            except ValueError:   # not the main thread
+                pass
         for f in (blob_path, blob_path + ".failed"):   # leftovers of a crashed job with the same launcher pid
             try:
                 os.remove(f)
@@ -153,27 +173,57 @@ def node_scene(load, blob_path, local_rank, timeout_s=3600.0):
         return sc, time.time() - t0, "built"
     while not os.path.exists(blob_path):   # (published by rename: complete or absent)
         if os.path.exists(blob_path + ".failed"):
+            try:
+                why = open(blob_path + ".failed").read()
+            except OSError:
+                why = ""
+            if why.startswith("load failed"):   # the scene itself is bad: this rank would fail the same way (or, worse, load something different)
+                raise RuntimeError("node_scene: local rank 0 could not load the scene -- %s" % why)
             return load(), time.time() - t0, "built (rank 0 could not publish the scene)"
         if time.time() - t0 > timeout_s:
             raise RuntimeError("node_scene: %s was not published within %.0f s" % (blob_path, timeout_s))
+        if os.getppid() != launcher:   # the launcher is gone (killed at a timeout): nobody will publish anything
+            raise RuntimeError("node_scene: the launcher (pid %d) exited while waiting for %s" % (launcher, blob_path))
         time.sleep(0.1)
     return pa.Scene(blob=blob_path), time.time() - t0, "mapped"
 
 
 _NODE_SCENE_CALLS = 0
 _NODE_SCENE_FILES = []
+_CLEANUP_REGISTERED = False
 
 
 def node_scene_cleanup():
-    """remove the files node_scene published in this process (local rank 0, once every rank has mapped its scene: mappings stay valid)"""
+    """remove the files node_scene published in this process (local rank 0, once every rank has mapped its scene: mappings stay valid; also registered for the
+    exits that skip the explicit call).  A '.failed' note (a few bytes) stays for the ranks still waiting; the next job's sweep removes it."""
     import os
     for f in _NODE_SCENE_FILES:
-        for g in (f, f + ".failed", f + ".tmp"):
+        for g in (f, f + ".tmp"):
             try:
                 os.remove(g)
             except OSError:
                 pass
     del _NODE_SCENE_FILES[:]
+
+
+def _sweep_stale(blob_base):
+    """remove what node_scene calls of DEAD jobs left under this base name (a crash or SIGKILL skips every cleanup): files whose name carries a launcher pid that no
+    longer exists, or exists with another start time"""
+    import glob, os, re
+    for f in glob.glob(glob.escape(blob_base) + ".*"):
+        m = re.match(r"\.(\d+)_(\d+)\.", f[len(blob_base):])
+        if not m:
+            continue
+        try:
+            with open("/proc/%s/stat" % m.group(1)) as st:
+                alive = m.group(2) == "0" or st.read().rsplit(")", 1)[1].split()[19] == m.group(2)
+        except Exception:
+            alive = False
+        if not alive:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 def _write_failed(blob_path, text):
@@ -196,11 +246,13 @@ def _launcher_id():
         return "%d_0" % ppid
 
 
-def launch_ranks(n_ranks, script, argv, backend_env=None):
+def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
     """Start `script argv` as n_ranks processes of ONE node under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1 with a free port -- the launch line the round driver uses) and return the job's exit code.  Used by
-    `python bench.py --gpus N` when it was not started by a launcher itself."""
-    import os, socket, subprocess, sys
+    `python bench.py --gpus N` when it was not started by a launcher itself.  The job runs in its own session (process group): at `timeout_s`
+    ($PBRT_AMD_LAUNCH_TIMEOUT_S, default none), on SIGTERM / SIGINT to this process and on any exit of this function the WHOLE group is killed, so no rank
+    outlives its launcher on the GPU (a timed-out job left two ranks behind and the next process waited 171 s for the device)."""
+    import os, signal, socket, subprocess, sys
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -209,7 +261,40 @@ def launch_ranks(n_ranks, script, argv, backend_env=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
     env.update(backend_env or {})
-    return subprocess.call(cmd, env=env)
+    if timeout_s is None and os.environ.get("PBRT_AMD_LAUNCH_TIMEOUT_S"):
+        timeout_s = float(os.environ["PBRT_AMD_LAUNCH_TIMEOUT_S"])
+    p = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def kill_group(sig=signal.SIGKILL):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, frame):
+        kill_group()
+        raise SystemExit(128 + signum)
+
+    saved = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            saved[sg] = signal.signal(sg, on_signal)
+        except ValueError:
+            pass
+    try:
+        try:
+            return p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("launch_ranks: the %d-rank job did not finish within %.0f s -- killing its process group\n" % (n_ranks, timeout_s))
+            return 124
+    finally:
+        kill_group()   # also after a normal exit: a rank that ignored the launcher's SIGTERM does not stay on the GPU
+        try:
+            p.wait(timeout=10)
+        except Exception:
+            pass
+        for sg, h in saved.items():
+            signal.signal(sg, h)
 
 
 class ShardedFrame:
@@ -223,27 +308,40 @@ class ShardedFrame:
         frame.step(); frame.step(); frame.sync_all(); img = frame.root_film()
     """
 
-    def __init__(self, ctx, scene, rank, world, local_rank, backend="nccl", one_device=False, exchange="sparse"):
+    def __init__(self, ctx, scene, rank, world, device, backend="nccl", exchange="sparse", trace=None, timeout_s=None):
+        """`device` = this rank's GPU ordinal (its local rank; every rank 0 only to exercise the N > 1 path on a one-GPU box, backend "gloo").  Every wait of the
+        process group is bounded by `timeout_s` ($PBRT_AMD_PG_TIMEOUT_S, default 300): a rank that never arrives fails the job instead of hanging it."""
         self.ctx, self.scene, self.rank, self.world = ctx, scene, rank, world
+        self.trace = trace or (lambda s: None)
         self.torch = self.dist = self.film = None
         self.films, self.pending, self.k, self.xchg, self.dense = [], [None, None], 0, None, exchange != "sparse"
         if world > 1:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
-            dev = 0 if one_device else local_rank
+            import datetime, os
+            dev = device
             torch.cuda.set_device(dev)
+            self.trace("torch imported, device %d selected" % dev)
             if not dist.is_initialized():
+                if timeout_s is None:
+                    timeout_s = float(os.environ.get("PBRT_AMD_PG_TIMEOUT_S", "300"))
+                to = datetime.timedelta(seconds=timeout_s)
                 if backend == "nccl":
-                    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+                    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev), timeout=to)
                 else:
-                    dist.init_process_group(backend=backend)
+                    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                        # one node: gloo's pairs go over loopback, not over whatever address the container's hostname happens to resolve to (it may not resolve at all)
+                        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                    dist.init_process_group(backend=backend, timeout=to)
+            self.trace("init_process_group(%s) returned" % backend)
             n = scene.height * scene.width * 4
             self.films = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(1 if self.dense else 2)]
             self.film = self.films[0]
             if not self.dense:
                 self.xchg = FilmExchange(scene, rank, world, torch.device("cuda", dev))
             ctx.film_bind(self.film.data_ptr())   # mi_render accumulates straight into the tensor the exchange reads
+            self.trace("film buffers and exchange lists ready")
 
     def _finish(self, slot):
         if self.pending[slot] is not None:
@@ -259,12 +357,15 @@ class ShardedFrame:
         self.ctx.film_clear()
         self.ctx.render(rank=self.rank, world=self.world, count_work=count_work, max_paths=max_paths, sync=False)
         if self.world > 1:
+            self.trace("step %d: render enqueued" % self.k)
             self.ctx.sync()                    # the ctx stream is not torch's current stream
+            self.trace("step %d: rendered, exchange starts" % self.k)
             if self.dense:
                 combine_films(self.film, dst=0)
                 self.torch.cuda.synchronize()  # the reduction reads the film: done before the next step clears it
             else:
                 self.pending[self.k % 2] = self.xchg.start(self.film)   # runs while the next step renders into the other buffer
+            self.trace("step %d: exchange enqueued" % self.k)
         self.k += 1
 
     def sync_all(self):
@@ -274,8 +375,10 @@ class ShardedFrame:
                 for slot in ((self.k) % 2, (self.k + 1) % 2):   # older exchange first
                     self._finish(slot)
             self.torch.cuda.synchronize()
+            self.trace("sync_all: device idle, barrier")
             self.dist.barrier()
             self.torch.cuda.synchronize()
+            self.trace("sync_all: barrier passed")
 
     def max_over_ranks(self, value):
         if self.world == 1:

@@ -273,23 +273,6 @@ def test_film_gather_of_two_contexts_equals_the_single_render(flt):
         c.close()
 
 
-def test_bench_two_ranks_self_launch_end_to_end(tmp_path):
-    """`python bench.py --gpus 2` starts its own two ranks (torch.distributed.run, one process per GPU) -- here both on GPU 0 with the gloo
-    backend, since this box has one GPU and RCCL refuses duplicate devices -- shards the tiles, reduces the films onto rank 0 and prints
-    ONE JSON line for the whole job.  Checked: the line, the whole-job sample count (every pixel rendered exactly once across the ranks)."""
-    import json, subprocess, sys
-    env = dict(os.environ, PBRT_AMD_BENCH_DIR=str(tmp_path))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--steps", "1", "--warmup", "1",
-                        "--tris", "200000", "--res", "320", "192", "--spp", "4", "--cpu-seconds", "0", "--traffic", "none"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-1500:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-500:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["unit"] == "Msamples/s"
-    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 - 320 * 192 * 4) <= 0.01 * 320 * 192 * 4   # all samples of the frame, once
-
-
 # ---------------------------------------------------------------- against the committed reference fixtures
 G = os.path.join(ROOT, "tests", "golden")
 
@@ -589,6 +572,7 @@ def test_textured_scenes_vs_reference_fixture(name):
 
 
 # ---------------------------------------------------------------- the command-line renderer end to end (parser -> BVH -> device -> Film -> file)
+@pytest.mark.launches_processes
 def test_cli_render_matches_reference_fixture(tmp_path):
     import subprocess, importlib.util
     spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tools", "gen_golden.py"))
@@ -758,6 +742,7 @@ def test_deep_stacks_take_the_generic_tail_and_spill():
 REF_STUB = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref_wavefront")
 
 
+@pytest.mark.launches_processes
 @pytest.mark.parametrize("name", ["infinite", "spheres", "instances2", "tex_materials", "tex_bump", "tex_alpha", "vol_smoke", "vol_inst", "sss_coeff", "sss_inst"])
 def test_reference_host_drives_the_device(name, tmp_path):
     """The drop-in itself: pbrt-v3's unmodified main / parser / API state machine / shape and material factories / BVH build (libpbrt_ref.a) with
@@ -781,6 +766,7 @@ def test_reference_host_drives_the_device(name, tmp_path):
     assert frac >= 0.995 and relmse <= 1e-4, (name, frac, relmse)
 
 
+@pytest.mark.launches_processes
 def test_reference_host_shards_tiles_over_gpu_contexts(tmp_path):
     """`PBRT_AMD_GPUS=2` in the reference-side binding: one mi_ctx per rank, mi_render(rank r, world 2) each, one mi_film_gather onto rank 0 (the
     reference's tile loop core/integrator.cpp:228-339 + the merge of film.cpp:117-130 across devices).  On a one-GPU box both contexts sit on
@@ -1160,6 +1146,7 @@ def test_baseline_config_reduced_with_subsurface_materials_and_with_a_grid_mediu
     test_baseline_configs_reduced(name, "bvh4q", tmp_path)
 
 
+@pytest.mark.launches_processes
 def test_reference_host_drives_the_device_with_the_maxmindist_sampler(tmp_path):
     """Sampler "maxmindist" (ABI v12, MI_SAMPLER_MAXMIN): the reference-side binding hands the generator matrix of the reference's own MaxMinDistSampler
     (CMaxMinDist[log2 spp], samplers/maxmin.h:74-77) over with the scene; the device draws the first 2D dimension from it and the rest like 02sequence

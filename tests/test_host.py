@@ -595,3 +595,28 @@ def test_fast_samplers_option_renders_tile_serial_sampler_names_with_sobol(built
     monkeypatch.setenv("PBRT_AMD_FAST_SAMPLERS", "1")
     fast = ol.render(pa.Scene(text=base), nthreads=4)[0]
     assert np.array_equal(fast, want) and not np.array_equal(default, want)
+
+
+@pytest.mark.parametrize("keep", [0.999, 0.6, 0.05])
+def test_a_cut_off_ply_file_is_an_error_never_a_smaller_mesh(built, tmp_path, keep):
+    """CreatePLYMesh on a file that ends before the vertices / faces its header declares (cut off, or caught while another process is still writing it): every
+    read is checked against the end of the file, the shape is dropped with the reference's own error (plymesh.cpp:196-202: rply's ply_read fails), the scene's
+    error count says so and a strict load raises -- round 5's reader ran past the buffer and built a mesh of whatever it found."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_scenes", os.path.join(ol.ROOT, "tools", "gen_scenes.py"))
+    gs = importlib.util.module_from_spec(spec); spec.loader.exec_module(gs)
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-1, 1, (3000, 3)); f = rng.integers(0, 3000, (5000, 3))
+    ply = tmp_path / "m.ply"
+    gs.write_ply(str(ply), v, f, normals=v, uvs=v[:, :2])
+    text = ('LookAt 0 0 -5 0 0 0 0 1 0\nCamera "perspective"\nFilm "image" "integer xresolution" [16] "integer yresolution" [16]\nWorldBegin\n'
+            'LightSource "point"\nShape "plymesh" "string filename" "%s"\nShape "sphere"\nWorldEnd\n' % ply)
+    sc = ol.pa.Scene(text=text)
+    assert sc.errors == 0 and sc.info["n_tris"] == 5001   # + the sphere
+    size = ply.stat().st_size
+    with open(ply, "r+b") as fh:
+        fh.truncate(int(size * keep))
+    sc = ol.pa.Scene(text=text)
+    assert sc.errors >= 1 and sc.info["n_tris"] == 1   # the reference's behaviour: an Error, the shape dropped, the rest of the scene kept
+    with pytest.raises(RuntimeError, match="strict mode"):
+        ol.pa.Scene(text=text, strict=True)
