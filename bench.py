@@ -394,6 +394,9 @@ def main():
     dev_ordinal = 0 if (world > 1 and args.one_device) else local_rank
     if world > 1:
         import faulthandler
+        importlib.import_module("pbrt-v3-distributed_amd.parallel").die_with_parent()   # the launcher starts ranks in sessions of their own: a killed launcher must not leave them on the GPU
+        if os.getppid() == 1:
+            raise SystemExit("bench.py (rank %d): the launcher is already gone" % rank)
         faulthandler.enable()
         faulthandler.dump_traceback_later(float(os.environ.get("PBRT_AMD_BENCH_STACKS_S", "120")), repeat=True)   # a stalled rank shows its stack
     wait_s = float(os.environ.get("PBRT_AMD_BENCH_WAIT_S", "1800"))

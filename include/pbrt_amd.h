@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 13   /* 13: mi_owned_tiles / mi_tile_owner (2-D lattice tile map), mi_trace_clock */
+#define MI_ABI_VERSION 14   /* 14: MI_CNT_FILM_GATHER_BUILDS, film contents tracked for mi_film_gather, mi_rccl_probe; 13: mi_owned_tiles / mi_tile_owner (2-D lattice tile map), mi_trace_clock */
 
 /* ---------------------------------------------------------------- geometry ---------- */
 
@@ -514,9 +514,12 @@ int64_t mi_film_pixel_count(mi_ctx *ctx);
  * what Film::GetFilmTile computes per tile (film.cpp:95-106) -- and the root adds the packed lists in context order: exact for
  * every filter (a context's film is zero elsewhere) and deterministic.  One context per GPU: the lists travel in ONE group of
  * ncclSend / ncclRecv over xGMI (RCCL, loaded at first use from librccl.so; one communicator per device set, cached).  Contexts
- * that share a device (testing on a one-GPU box; RCCL refuses duplicate devices) hand their lists over directly.  A context whose
- * last mi_render was not a shard (world 1) is added whole.  Waits for the renders of all contexts first and returns when the root
- * film is complete; n == 1 is a no-op. */
+ * that share a device (testing on a one-GPU box; RCCL refuses duplicate devices) hand their lists over directly.  The library tracks
+ * what a context's film holds: ONE sharding since the last mi_film_clear -> sparse; no shard (world 1), a second sharding accumulated
+ * into the same film, or a buffer bound with mi_film_bind and not cleared since -> the whole film is added (nothing is ever dropped).
+ * The reach lists, index and exchange buffers are kept in the sender's context and rebuilt only when the sharding, the film size or
+ * the root's device changes (MI_CNT_FILM_GATHER_BUILDS): repeated frames allocate and upload nothing.  Waits for the renders of all
+ * contexts first and returns when the root film is complete; n == 1 is a no-op. */
 int mi_film_gather(mi_ctx **ctxs, int n, int root);
 /* Stage-level BSDF lobes (core/reflection.cpp:703-785 building blocks): BxDF::f, Pdf and Sample_f(wo, u) of bxdfs[i] for record i
  * (wo, wi in the shading frame) -- replays the vectors dumped from the reference's own BxDF classes on the device. */
@@ -568,6 +571,8 @@ enum mi_counter {
     MI_CNT_NODES_HOT_CLOSEST = 11, /* the part of NODES_CLOSEST / NODES_ANY / NODES_MIS served from the traversal blocks' LDS copy of the scene's hot nodes */
     MI_CNT_NODES_HOT_ANY = 12,
     MI_CNT_NODES_HOT_MIS = 13,
+    MI_CNT_FILM_GATHER_BUILDS = 14, /* times mi_film_gather had to (re)build this context's reach list and exchange buffers (host-side, cumulative, not reset by
+                                     * mi_counters_reset): 1 after any number of frames of one sharding */
     MI_CNT_TRACE_GUARD_TRIPS = 15, /* waves that hit the non-termination guard of the traversal kernels: must stay 0 */
     MI_CNT_COUNT = 16
 };
@@ -608,6 +613,11 @@ int mi_stream_read_gbps(mi_ctx *ctx, uint64_t bytes, double *gbps);
  * requests per second -- the memory-side ceiling of a BVH interior step (the traversal kernels are bound by the request rate of incoherent
  * 16-byte loads, not by HBM bandwidth: DESIGN.md s.5). */
 int mi_gather_rate(mi_ctx *ctx, uint64_t bytes, int loads_per_record, double *grequests_per_s);
+/* Stage-level check of mi_film_gather's RCCL step on a ONE-GPU box (RCCL refuses two ranks on one device, so the gather of two contexts sharing a
+ * GPU never reaches it): loads librccl.so the way the gather does, makes the communicator of {ctx's device} and moves n_pixels packed FilmTilePixels
+ * (float4) through ONE group of ncclSend / ncclRecv -- the same helper the gather calls, rank 0 to itself -- on the context's stream, then adds them into
+ * a zeroed film with the gather's own kernel.  Returns 0 when every pixel arrived bit for bit; -1 with mi_last_error otherwise. */
+int mi_rccl_probe(mi_ctx *ctx, int64_t n_pixels);
 /* Measurement aid (bench.py's `roofline.valu_issue`): the shader clock the traversal kernels really ran at during the COUNTING passes since
  * the last mi_counters_reset -- every wave stamps s_memtime (shader-clock ticks) and s_memrealtime (constant-rate ticks) when it starts and when it
  * ends.  out[0] = GHz inside the closest-hit launches, out[1] = GHz inside the any-hit launches (0: no counting pass ran), out[2], out[3] = the

@@ -4,6 +4,8 @@
 // INTEGRATION.md s.1 -- the image must equal what pbrt_ref renders for the same file (tests/test_reference_binding.py) -- and hosts three probes
 // that compare the reference's OWN classes with the checker on the flattened description:
 //   PBRT_AMD_TEX_PROBE / PBRT_AMD_HIT_PROBE / PBRT_AMD_BSDF_PROBE = <report file>
+// and PBRT_AMD_BVH_DUMP = <file>: the reference's BVHAccel (LinearBVHNode array + ordered primitives) as flattened, for the node-for-node comparison with the host
+// library's own build of every split method (tests/test_reference_binding.py)
 // Built by oracle/ref_build/Makefile into oracle/_ref/pbrt_ref_flatcheck; PBRT_AMD_BACKEND_LIB names liboracle.so.
 #include "../../integration/flatten.h"
 
@@ -202,6 +204,18 @@ class FlatCheckIntegrator : public Integrator {
         if (!lib) { Error("FlatCheckIntegrator: %s", dlerror()); return; }
         auto oracle_render = (double (*)(const mi_scene_desc *, float *, int, int, int, uint64_t *, const int32_t *))dlsym(lib, "oracle_render");
         if (!oracle_render) { Error("FlatCheckIntegrator: oracle_render not found in %s", libPath); return; }
+        if (const char *dump = std::getenv("PBRT_AMD_BVH_DUMP")) {   // the REFERENCE's own BVHAccel as it crosses the boundary: the node array and the ordered triangles (vertex positions)
+            if (FILE *f = std::fopen(dump, "wb")) {
+                const mi_scene_desc &d = flat->desc;
+                uint32_t hdr[2] = {d.n_bvh_nodes, d.n_tris};
+                std::fwrite(hdr, 4, 2, f);
+                std::fwrite(d.bvh_nodes, sizeof(mi_bvh2_node), d.n_bvh_nodes, f);
+                for (uint32_t t = 0; t < d.n_tris; ++t)
+                    for (int k = 0; k < 3; ++k) std::fwrite(d.P + 3 * (size_t)d.tri_indices[3 * t + k], 4, 3, f);
+                std::fclose(f);
+            }
+            if (std::getenv("PBRT_AMD_BVH_DUMP_ONLY")) return;
+        }
         if (const char *probe = std::getenv("PBRT_AMD_TEX_PROBE")) TextureProbe(*flat, lib, probe);
         if (const char *probe = std::getenv("PBRT_AMD_HIT_PROBE")) HitProbe(scene, *flat, lib, probe);
         if (const char *probe = std::getenv("PBRT_AMD_BSDF_PROBE")) BsdfProbe(scene, *flat, lib, probe);

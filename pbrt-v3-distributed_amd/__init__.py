@@ -21,7 +21,7 @@ DEVICE_LIB = os.environ.get("PBRT_AMD_DEVICE_LIB", os.path.join(LIB_DIR, "libpbr
 MI_CNT_COUNT = 16
 MI_K_COUNT = 8
 COUNTER_NAMES = ["camera_rays", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_any",
-                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis", "nodes_hot_closest", "nodes_hot_any", "nodes_hot_mis", "unused14",
+                 "tris_any", "path_segments", "mis_rays", "nodes_mis", "tris_mis", "nodes_hot_closest", "nodes_hot_any", "nodes_hot_mis", "film_gather_builds",
                  "trace_guard_trips"]
 KERNEL_NAMES = ["raygen", "closest", "sort", "shade", "anyhit", "mis_closest", "film", "other"]
 
@@ -48,7 +48,7 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32),
 DEVICE_SYMBOLS = [
     "mi_last_error", "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_sync",
     "mi_film_clear", "mi_film_download", "mi_film_device_ptr", "mi_film_bind", "mi_film_pixel_count", "mi_counters",
-    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_trace_clock", "mi_owned_tiles", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
+    "mi_counters_reset", "mi_timing_enable", "mi_timing_get", "mi_stream_read_gbps", "mi_gather_rate", "mi_trace_clock", "mi_owned_tiles", "mi_bvh4_validate", "mi_bvh4q_validate", "mi_trace_info", "mi_film_gather", "mi_rccl_probe", "mi_bxdf_eval", "mi_light_sample", "mi_bssrdf_eval", "mi_phase_hg", "mi_libm_eval", "mi_intersect", "mi_triangle_intersect", "mi_sphere_intersect", "mi_texture_eval", "mi_intersect_p", "mi_sobol",
     "mi_camera_rays", "mi_camera_differentials", "mi_li",
 ]
 
@@ -112,6 +112,7 @@ def device_lib():
         L.mi_bvh4q_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.mi_trace_info.argtypes = [C.c_void_p, C.c_void_p]
         L.mi_film_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mi_rccl_probe.argtypes = [C.c_void_p, C.c_int64]
         L.mi_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.mi_stream_read_gbps.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mi_trace_clock.argtypes = [C.c_void_p, C.c_void_p]
@@ -264,6 +265,10 @@ class Context:
 
     def sync(self):
         self._chk(device_lib().mi_sync(self._ctx), "mi_sync")
+
+    def rccl_probe(self, n_pixels=1 << 16):
+        """mi_rccl_probe: mi_film_gather's RCCL step (communicator, one grouped ncclSend / ncclRecv of packed pixels, the add kernel) on this context's GPU alone"""
+        self._chk(device_lib().mi_rccl_probe(self._ctx, int(n_pixels)), "mi_rccl_probe")
 
     def film_clear(self):
         self._chk(device_lib().mi_film_clear(self._ctx), "mi_film_clear")

@@ -1554,6 +1554,20 @@ struct mi_ctx {
     DevBuf film, counters, tiles;
     float4 *filmPtr = nullptr;   // c->film.p or a caller-owned buffer (mi_film_bind)
     int64_t filmPixels = 0;
+    // What the bound film holds (mi_film_gather's sparse form is exact only if it is ONE shard: zero outside that shard's reach): the sharding of the mi_render calls
+    // since the last mi_film_clear, and whether a second sharding -- or a freshly bound buffer of unknown contents -- has been mixed in (then the gather adds the whole film).
+    int filmShardRank = -1, filmShardWorld = -1;
+    bool filmMixed = false;
+    // mi_film_gather's per-sender state, kept across frames: the reach list of (rank, world) on this context's device and on the root's, the packed pixels, the root's
+    // receive buffer.  Rebuilt only when the sharding, the film size or the root's device changes (round 5 rebuilt, allocated and uploaded all of it every frame).
+    struct GatherPart {
+        int rank = -1, world = -1, rootDevice = -1;
+        int64_t pixels = 0;
+        size_t n = 0;
+        std::vector<uint32_t> idx;   // kept alive: the uploads are asynchronous
+        DevBuf dIdxSrc, dIdxRoot, packed, recv;
+    } gather;
+    uint64_t gatherBuilds = 0;   // MI_CNT_FILM_GATHER_BUILDS
     // wavefront state
     PathState ps;
     std::vector<DevBuf> stateBufs;
@@ -2988,6 +3002,8 @@ int mi_render(mi_ctx *c, const mi_render_params *rp) {
     const int tileSize = 16;
     int ex = sc.sample_max[0] - sc.sample_min[0], ey = sc.sample_max[1] - sc.sample_min[1];
     int nTx = (ex + tileSize - 1) / tileSize, nTy = (ey + tileSize - 1) / tileSize;
+    if (c->filmShardWorld < 0) { c->filmShardRank = rank; c->filmShardWorld = world; }
+    else if (c->filmShardRank != rank || c->filmShardWorld != world) c->filmMixed = true;   // a second shard accumulates into the same film
     if (c->tilesRank != rank || c->tilesWorld != world) {   // the owned-tile list changes only with the sharding: no allocation on repeated frames
         HIP_TRY(hipStreamSynchronize(c->stream));           // a pass still reading the old list / the host staging copy
         c->tilesHost.clear();
@@ -3093,11 +3109,15 @@ int mi_film_clear(mi_ctx *c) {
     if (!c || !c->haveScene) return fail("mi_film_clear: no scene");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->filmPtr, 0, (size_t)c->filmPixels * sizeof(float4), c->stream));
+    c->filmShardRank = c->filmShardWorld = -1;
+    c->filmMixed = false;
     return 0;
 }
 int mi_film_bind(mi_ctx *c, void *p) {
     if (!c || !c->haveScene) return fail("mi_film_bind: no scene");
-    c->filmPtr = p ? (float4 *)p : c->film.as<float4>();
+    float4 *q = p ? (float4 *)p : c->film.as<float4>();
+    if (q != c->filmPtr) { c->filmShardRank = c->filmShardWorld = -1; c->filmMixed = true; }   // contents unknown until the caller clears it
+    c->filmPtr = q;
     return 0;
 }
 int mi_film_download(mi_ctx *c, float *rgbw) {
@@ -3156,6 +3176,26 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
+std::mutex g_rcclMutex;   // the cached communicators are shared by every caller of this process
+// ONE group of point-to-point transfers (ncclGroupStart ... ncclSend / ncclRecv per move ... ncclGroupEnd): move m sends `count` floats from `src` (on the device and
+// stream of communicator rank `from`) into `dst` on rank `to`.  No early return inside the group: GroupEnd always runs.  Caller holds the lock on g_rccl.
+struct RcclMove { int from, to, fromDevice, toDevice; const void *src; void *dst; size_t count; hipStream_t fromStream, toStream; };
+static int rccl_group_moves(const std::vector<RcclMove> &moves, std::string *err) {
+    const int ncclFloat32_ = 7;   // ncclDataType_t value of <rccl/rccl.h>
+    int rc = g_rccl.GroupStart();
+    hipError_t he = hipSuccess;
+    for (size_t k = 0; k < moves.size() && rc == 0 && he == hipSuccess; ++k) {
+        const RcclMove &m = moves[k];
+        he = hipSetDevice(m.fromDevice);
+        if (he == hipSuccess) rc = g_rccl.Send(m.src, m.count, ncclFloat32_, m.to, g_rccl.comms[m.from], m.fromStream);
+        if (he == hipSuccess && rc == 0) he = hipSetDevice(m.toDevice);
+        if (he == hipSuccess && rc == 0) rc = g_rccl.Recv(m.dst, m.count, ncclFloat32_, m.from, g_rccl.comms[m.to], m.toStream);
+    }
+    int rc2 = g_rccl.GroupEnd();
+    if (he != hipSuccess) { *err = std::string("hipSetDevice: ") + hipGetErrorString(he); return -1; }
+    if (rc != 0 || rc2 != 0) { *err = std::string("ncclSend / ncclRecv: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"); return -1; }
+    return 0;
+}
 // the sparse film exchange (mi_film_gather): pack the FilmTilePixels a context's samples can reach / add a packed list into the root film
 __global__ void __launch_bounds__(PT_BLOCK) k_film_pack(const float4 *film, const uint32_t *idx, int64_t n, float4 *out) {
     for (int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT_BLOCK) out[i] = film[idx[i]];
@@ -3227,50 +3267,54 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root) {
     std::vector<int> devs(n);
     bool distinct = true;
     for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; ++j) distinct &= devs[j] != devs[i]; }
-    // per sender: the reach list on its own device and on the root's, the packed pixels, the root's receive buffer
-    struct Part { std::vector<uint32_t> idx; DevBuf dIdxSrc, dIdxRoot, packed, recv; bool dense = false; };
-    std::vector<Part> parts(n);
+    // per sender: the reach list on its own device and on the root's, the packed pixels, the root's receive buffer -- cached in the sender's context (mi_ctx::gather)
+    typedef mi_ctx::GatherPart Part;
+    std::vector<Part *> parts(n, nullptr);
+    std::vector<char> dense(n, 0);
+    bool built = false;
     for (int i = 0; i < n; ++i) {
         if (i == root) continue;
         mi_ctx *c = ctxs[i];
-        Part &p = parts[i];
-        p.dense = c->tilesWorld <= 1 || c->tilesRank < 0;   // (no shard rendered: the whole film may carry samples)
-        if (p.dense) continue;
-        reach_indices(c->sc, c->tilesRank, c->tilesWorld, &p.idx);
-        if (p.idx.empty()) continue;
-        HIP_TRY(hipSetDevice(c->device));
-        if (upload(c, p.dIdxSrc, p.idx.data(), p.idx.size() * sizeof(uint32_t)) || p.packed.alloc(p.idx.size() * sizeof(float4))) return -1;
-        hipLaunchKernelGGL(k_film_pack, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, (const float4 *)c->filmPtr, p.dIdxSrc.as<uint32_t>(), (int64_t)p.idx.size(), p.packed.as<float4>());
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipSetDevice(r->device));
-        if (c->device != r->device) {
-            if (upload(r, p.dIdxRoot, p.idx.data(), p.idx.size() * sizeof(uint32_t)) || p.recv.alloc(p.idx.size() * sizeof(float4))) return -1;
+        // the whole film may carry samples: no shard rendered (world 1), or more than one sharding since the last clear (the sparse form would drop them)
+        dense[i] = c->filmMixed || c->filmShardWorld <= 1 || c->filmShardRank < 0;
+        if (dense[i]) continue;
+        Part &p = c->gather;
+        parts[i] = &p;
+        if (p.rank != c->filmShardRank || p.world != c->filmShardWorld || p.pixels != c->filmPixels || p.rootDevice != r->device) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));   // nobody still reads the buffers about to be replaced
+            p.rank = -1;
+            reach_indices(c->sc, c->filmShardRank, c->filmShardWorld, &p.idx);
+            p.n = p.idx.size();
+            if (upload(c, p.dIdxSrc, p.idx.data(), p.n * sizeof(uint32_t)) || p.packed.alloc(p.n * sizeof(float4))) return -1;
+            p.dIdxRoot.release(); p.recv.release();
+            if (c->device != r->device) {
+                HIP_TRY(hipSetDevice(r->device));
+                if (upload(r, p.dIdxRoot, p.idx.data(), p.n * sizeof(uint32_t)) || p.recv.alloc(p.n * sizeof(float4))) return -1;
+            }
+            p.rank = c->filmShardRank; p.world = c->filmShardWorld; p.pixels = c->filmPixels; p.rootDevice = r->device;
+            ++c->gatherBuilds;
+            built = true;
         }
+        if (!p.n) continue;
+        HIP_TRY(hipSetDevice(c->device));
+        hipLaunchKernelGGL(k_film_pack, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, (const float4 *)c->filmPtr, p.dIdxSrc.as<uint32_t>(), (int64_t)p.n, p.packed.as<float4>());
+        HIP_TRY(hipGetLastError());
     }
-    for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }   // packed lists and index uploads are in place
+    // the packed lists (and, after a rebuild, the index uploads) are in place before the root's stream reads them
+    for (int i = 0; i < n; ++i) if (i != root || built) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
     bool viaRccl = false;
     if (distinct) {
         bool anySparse = false;
-        for (int i = 0; i < n; ++i) anySparse = anySparse || (i != root && !parts[i].dense && !parts[i].idx.empty());
+        for (int i = 0; i < n; ++i) anySparse = anySparse || (parts[i] && parts[i]->n);
         if (anySparse) {
             std::string err;
-            static std::mutex rcclMutex;   // the cached communicators (g_rccl) are shared by every caller of this process
-            std::lock_guard<std::mutex> lock(rcclMutex);
+            std::lock_guard<std::mutex> lock(g_rcclMutex);
             if (!g_rccl.load(&err) || !g_rccl.commsFor(devs, &err)) return fail("mi_film_gather: " + err);
-            const int ncclFloat32_ = 7;   // ncclDataType_t value of <rccl/rccl.h>
-            int rc = g_rccl.GroupStart();
-            hipError_t he = hipSuccess;
-            for (int i = 0; i < n && rc == 0 && he == hipSuccess; ++i) {   // no early return inside the group: GroupEnd always runs
-                if (i == root || parts[i].dense || parts[i].idx.empty()) continue;
-                const size_t count = parts[i].idx.size() * 4;
-                he = hipSetDevice(ctxs[i]->device);
-                if (he == hipSuccess) rc = g_rccl.Send(parts[i].packed.p, count, ncclFloat32_, root, g_rccl.comms[i], ctxs[i]->stream);
-                if (he == hipSuccess && rc == 0) he = hipSetDevice(r->device);
-                if (he == hipSuccess && rc == 0) rc = g_rccl.Recv(parts[i].recv.p, count, ncclFloat32_, i, g_rccl.comms[root], r->stream);
-            }
-            int rc2 = g_rccl.GroupEnd();
-            if (he != hipSuccess) return fail(std::string("mi_film_gather: hipSetDevice: ") + hipGetErrorString(he));
-            if (rc != 0 || rc2 != 0) return fail(std::string("mi_film_gather: ncclSend / ncclRecv: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error"));
+            std::vector<RcclMove> moves;
+            for (int i = 0; i < n; ++i)
+                if (parts[i] && parts[i]->n) moves.push_back({i, root, ctxs[i]->device, r->device, parts[i]->packed.p, parts[i]->recv.p, parts[i]->n * 4, ctxs[i]->stream, r->stream});
+            if (rccl_group_moves(moves, &err)) return fail("mi_film_gather: " + err);
             viaRccl = true;
         }
     }
@@ -3280,8 +3324,7 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root) {
     for (int i = 0; i < n; ++i) {   // context order: the sum is deterministic
         if (i == root) continue;
         mi_ctx *c = ctxs[i];
-        Part &p = parts[i];
-        if (p.dense) {
+        if (dense[i]) {
             const float4 *src = c->filmPtr;
             if (c->device != r->device) {
                 if (!stage.p && stage.alloc(count * sizeof(float))) return -1;
@@ -3293,20 +3336,51 @@ int mi_film_gather(mi_ctx **ctxs, int n, int root) {
             if (c->device != r->device) HIP_TRY(hipStreamSynchronize(r->stream));   // the staging buffer is reused
             continue;
         }
-        if (p.idx.empty()) continue;
+        Part &p = *parts[i];
+        if (!p.n) continue;
         const uint32_t *idx = c->device == r->device ? p.dIdxSrc.as<uint32_t>() : p.dIdxRoot.as<uint32_t>();
         const float4 *in = c->device == r->device ? p.packed.as<float4>() : p.recv.as<float4>();
-        if (c->device != r->device && !viaRccl) HIP_TRY(hipMemcpyPeerAsync(p.recv.p, r->device, p.packed.p, c->device, p.idx.size() * sizeof(float4), r->stream));
-        hipLaunchKernelGGL(k_film_add_packed, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, idx, (int64_t)p.idx.size(), in);
+        if (c->device != r->device && !viaRccl) HIP_TRY(hipMemcpyPeerAsync(p.recv.p, r->device, p.packed.p, c->device, p.n * sizeof(float4), r->stream));
+        hipLaunchKernelGGL(k_film_add_packed, dim3(r->gridBlocks), dim3(PT_BLOCK), 0, r->stream, r->filmPtr, idx, (int64_t)p.n, in);
         HIP_TRY(hipGetLastError());
     }
+    // the root's film now holds every sharding that was added: a later gather FROM it must take the dense form
+    r->filmMixed = true;
     for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
     HIP_TRY(hipSetDevice(r->device));
-    for (Part &p : parts) { p.dIdxSrc.release(); p.dIdxRoot.release(); p.packed.release(); p.recv.release(); }
     stage.release();
     return 0;
 }
 int64_t mi_film_pixel_count(mi_ctx *c) { return c ? c->filmPixels : 0; }
+
+// mi_film_gather's RCCL step on one GPU (include/pbrt_amd.h): communicator of one device, one grouped send / recv of packed pixels to itself, the gather's add kernel
+int mi_rccl_probe(mi_ctx *c, int64_t nPix) {
+    if (!c || nPix < 1 || nPix > (int64_t)1 << 28) return fail("mi_rccl_probe: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> host((size_t)nPix * 4), back((size_t)nPix * 4);
+    uint32_t st = 12345u;
+    for (float &v : host) { st = st * 1664525u + 1013904223u; v = (float)(st >> 8) * (1.0f / 16777216.0f) + 0.25f; }
+    std::vector<uint32_t> idx((size_t)nPix);
+    for (int64_t i = 0; i < nPix; ++i) idx[(size_t)i] = (uint32_t)(nPix - 1 - i);   // a permutation: the add kernel scatters
+    DevBuf packed, recv, film, dIdx;
+    if (upload(c, packed, host.data(), host.size() * sizeof(float)) || recv.alloc(host.size() * sizeof(float)) || film.alloc(host.size() * sizeof(float)) ||
+        upload(c, dIdx, idx.data(), idx.size() * sizeof(uint32_t))) return -1;
+    HIP_TRY(hipMemsetAsync(recv.p, 0, recv.bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(film.p, 0, film.bytes, c->stream));
+    {
+        std::string err;
+        std::lock_guard<std::mutex> lock(g_rcclMutex);
+        if (!g_rccl.load(&err) || !g_rccl.commsFor(std::vector<int>{c->device}, &err)) return fail("mi_rccl_probe: " + err);
+        if (rccl_group_moves({{0, 0, c->device, c->device, packed.p, recv.p, (size_t)nPix * 4, c->stream, c->stream}}, &err)) return fail("mi_rccl_probe: " + err);
+    }
+    hipLaunchKernelGGL(k_film_add_packed, dim3(c->gridBlocks), dim3(PT_BLOCK), 0, c->stream, film.as<float4>(), dIdx.as<uint32_t>(), nPix, (const float4 *)recv.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(back.data(), film.p, back.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < nPix; ++i)
+        if (std::memcmp(&back[(size_t)idx[(size_t)i] * 4], &host[(size_t)i * 4], 16) != 0) return fail("mi_rccl_probe: pixel " + std::to_string(i) + " did not arrive intact");
+    return 0;
+}
 
 int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     if (!c || !out) return fail("mi_counters: bad argument");
@@ -3323,6 +3397,7 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
     }
 #endif
     HIP_TRY(hipStreamSynchronize(c->stream));
+    out[MI_CNT_FILM_GATHER_BUILDS] = c->gatherBuilds;   // host-side: not a device counter
     return 0;
 }
 int mi_trace_clock(mi_ctx *c, double out[4]) {

@@ -34,6 +34,21 @@ PT_DEV Float sqrtf_(Float v) { return __builtin_sqrtf(v); }
 // libm calls: the reference's std::sin / cos / acos / atan2 / exp / log on floats are glibc's float routines; pt_libm.h performs
 // the same operation sequences, so the device returns the same bits (all 2^32 inputs of each routine checked against the
 // installed libm: tools/libm_check, tests/test_libm.py).
+#ifndef PT_FAST_MATH
+#define PT_FAST_MATH 0
+#endif
+#if PT_FAST_MATH
+// MEASUREMENT BUILD ONLY (`make variant NAME=fastmath FLAGS="-DPT_FAST_MATH=1 ..."`, never built by build()): the hardware's transcendental
+// instructions (v_sin / v_cos / v_exp / v_log through the __*f intrinsics, OCML's float acos / atan2) instead of the glibc-identical fp64 polynomials -- what
+// bit-identity with the reference's libm costs the shading kernels.  profiles/r06_*_fast_math_study.txt holds the result and the decision.
+PT_DEV Float sinf_(Float v) { return __sinf(v); }
+PT_DEV Float cosf_(Float v) { return __cosf(v); }
+PT_DEV void sincosf_(Float v, Float *s, Float *c) { *s = __sinf(v); *c = __cosf(v); }
+PT_DEV Float acosf_(Float v) { return acosf(v); }
+PT_DEV Float expf_(Float v) { return __expf(v); }
+PT_DEV Float logf_(Float v) { return __logf(v); }
+PT_DEV Float atan2f_(Float y, Float x) { return atan2f(y, x); }
+#else
 PT_DEV Float sinf_(Float v) { return pt_sinf(v); }
 PT_DEV Float cosf_(Float v) { return pt_cosf(v); }
 PT_DEV void sincosf_(Float v, Float *s, Float *c) { pt_sincosf(v, s, c); }
@@ -41,6 +56,7 @@ PT_DEV Float acosf_(Float v) { return pt_acosf(v); }
 PT_DEV Float expf_(Float v) { return pt_expf(v); }
 PT_DEV Float logf_(Float v) { return pt_logf(v); }
 PT_DEV Float atan2f_(Float y, Float x) { return pt_atan2f(y, x); }
+#endif
 // sin and cos of a DOUBLE (the one place the reference calls the double overloads on this path: TrowbridgeReitzSample11's first branch,
 // core/microfacet.cpp:243-248, |x| <= 2 pi): two-term Cody-Waite reduction by pi/2 and the two fdlibm kernels (error < 1 ulp of double; the
 // product with r is rounded to float afterwards, so a last-place difference from glibc's own < 1 ulp sin / cos shows in ~1e-9 of the cases).

@@ -163,6 +163,143 @@ BuildNode *Builder::build(int start, int end, std::deque<BuildNode> *pool) {
     return node;
 }
 
+// ---- SplitMethod::HLBVH (accelerators/bvh.cpp:404-638): Morton-ordered treelets under a SAH top.  Restated with the reference's arithmetic so that the
+// tree -- node bounds, split axes, leaf contents and their order -- is the one the reference builds: 10-bit Morton codes of the centroids' offsets in the centroid
+// bounds, a stable LSD radix sort (6 bits x 5), one treelet per run of equal top 12 bits, treelets split at the highest differing remaining bit (leaves below
+// maxPrimsInNode primitives or out of bits), the treelet roots joined by 12-bucket SAH with the 0.125 traversal cost and std::partition.  The reference hands out
+// a leaf's firstPrimOffset from an atomic counter inside a ParallelFor, i.e. in scheduling order; this build takes them in treelet order (the reference with one
+// thread) -- which primitives a leaf holds, and their order inside it, do not depend on that.
+struct MortonPrim { int primitiveIndex; uint32_t mortonCode; };
+
+inline uint32_t LeftShift3(uint32_t x) {   // bvh.cpp:107-131: bit i of the 10-bit value moves to bit 3 i
+    if (x == (1u << 10)) --x;
+    x = (x | (x << 16)) & 0x30000ffu;
+    x = (x | (x << 8)) & 0x300f00fu;
+    x = (x | (x << 4)) & 0x30c30c3u;
+    x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+
+struct HLBVH {
+    const std::vector<PrimInfo> &info;
+    int maxPrimsInNode;
+    std::deque<BuildNode> pool;
+    std::vector<size_t> ordered;   // orderedPrims, as primitive numbers
+    size_t orderedOffset = 0;
+    bool degenerate = false;
+
+    HLBVH(const std::vector<PrimInfo> &info, int maxPrims) : info(info), maxPrimsInNode(maxPrims) {}
+
+    BuildNode *emit(const MortonPrim *mp, int n, int bitIndex) {   // emitLBVH, bvh.cpp:472-538
+        if (bitIndex == -1 || n < maxPrimsInNode) {
+            pool.emplace_back();
+            BuildNode *node = &pool.back();
+            Bounds3 b;
+            node->firstPrimOffset = (int)orderedOffset;
+            for (int i = 0; i < n; ++i) {
+                ordered[orderedOffset + i] = (size_t)mp[i].primitiveIndex;
+                b = Union(b, info[mp[i].primitiveIndex].bounds);
+            }
+            orderedOffset += n;
+            node->nPrimitives = n;
+            node->bounds = b;
+            return node;
+        }
+        const uint32_t mask = 1u << bitIndex;
+        if ((mp[0].mortonCode & mask) == (mp[n - 1].mortonCode & mask)) return emit(mp, n, bitIndex - 1);
+        int lo = 0, hi = n - 1;   // the first primitive with the bit set (the codes are sorted)
+        while (lo + 1 != hi) {
+            int mid = (lo + hi) / 2;
+            if ((mp[lo].mortonCode & mask) == (mp[mid].mortonCode & mask)) lo = mid; else hi = mid;
+        }
+        pool.emplace_back();
+        BuildNode *node = &pool.back();   // (created before its children, like the reference: the DFS flattening does not depend on it)
+        node->children[0] = emit(mp, hi, bitIndex - 1);
+        node->children[1] = emit(mp + hi, n - hi, bitIndex - 1);
+        node->splitAxis = bitIndex % 3;
+        node->nPrimitives = 0;
+        node->bounds = Union(node->children[0]->bounds, node->children[1]->bounds);
+        return node;
+    }
+
+    BuildNode *upper(std::vector<BuildNode *> &roots, int start, int end) {   // buildUpperSAH, bvh.cpp:540-638
+        if (end - start == 1) return roots[start];
+        pool.emplace_back();
+        BuildNode *node = &pool.back();
+        Bounds3 bounds, centroidBounds;
+        for (int i = start; i < end; ++i) bounds = Union(bounds, roots[i]->bounds);
+        for (int i = start; i < end; ++i) centroidBounds = Union(centroidBounds, (roots[i]->bounds.pMin + roots[i]->bounds.pMax) * 0.5f);
+        const int dim = centroidBounds.MaximumExtent();
+        if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) { degenerate = true; return roots[start]; }   // the reference CHECK-fails here (bvh.cpp:563)
+        const int nBuckets = 12;
+        struct Bucket { int count = 0; Bounds3 bounds; } buckets[nBuckets];
+        const Float cmin = centroidBounds.pMin[dim], cmax = centroidBounds.pMax[dim];
+        auto bucketOf = [=](const BuildNode *r) {
+            Float centroid = (r->bounds.pMin[dim] + r->bounds.pMax[dim]) * 0.5f;
+            int b = nBuckets * ((centroid - cmin) / (cmax - cmin));
+            if (b == nBuckets) b = nBuckets - 1;
+            return b;
+        };
+        for (int i = start; i < end; ++i) {
+            int b = bucketOf(roots[i]);
+            buckets[b].count++;
+            buckets[b].bounds = Union(buckets[b].bounds, roots[i]->bounds);
+        }
+        Float cost[nBuckets - 1];
+        for (int i = 0; i < nBuckets - 1; ++i) {
+            Bounds3 b0, b1;
+            int count0 = 0, count1 = 0;
+            for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
+            for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
+            cost[i] = .125f + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
+        }
+        Float minCost = cost[0];
+        int minCostSplitBucket = 0;
+        for (int i = 1; i < nBuckets - 1; ++i)
+            if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+        BuildNode **pmid = std::partition(&roots[start], &roots[end - 1] + 1, [&](const BuildNode *r) { return bucketOf(r) <= minCostSplitBucket; });
+        const int mid = (int)(pmid - &roots[0]);
+        if (mid <= start || mid >= end) { degenerate = true; return roots[start]; }   // (CHECK_GT / CHECK_LT, bvh.cpp:630-631)
+        node->splitAxis = dim;
+        node->nPrimitives = 0;
+        node->children[0] = upper(roots, start, mid);
+        node->children[1] = upper(roots, mid, end);
+        node->bounds = Union(node->children[0]->bounds, node->children[1]->bounds);
+        return node;
+    }
+
+    BuildNode *build() {   // HLBVHBuild, bvh.cpp:404-470
+        Bounds3 bounds;
+        for (const PrimInfo &pi : info) bounds = Union(bounds, pi.centroid);
+        std::vector<MortonPrim> mp(info.size()), tmp(info.size());
+        for (size_t i = 0; i < info.size(); ++i) {
+            const Float mortonScale = 1 << 10;
+            Vec3 o = bounds.Offset(info[i].centroid) * mortonScale;
+            mp[i].primitiveIndex = (int)info[i].primitiveNumber;
+            mp[i].mortonCode = (LeftShift3((uint32_t)o.z) << 2) | (LeftShift3((uint32_t)o.y) << 1) | LeftShift3((uint32_t)o.x);
+        }
+        for (int pass = 0; pass < 5; ++pass) {   // RadixSort, bvh.cpp:140-179 (stable, 6 bits per pass)
+            const int lowBit = pass * 6;
+            std::vector<MortonPrim> &in = (pass & 1) ? tmp : mp, &out = (pass & 1) ? mp : tmp;
+            int count[64] = {0}, outIndex[64];
+            for (const MortonPrim &m : in) ++count[(m.mortonCode >> lowBit) & 63];
+            outIndex[0] = 0;
+            for (int i = 1; i < 64; ++i) outIndex[i] = outIndex[i - 1] + count[i - 1];
+            for (const MortonPrim &m : in) out[outIndex[(m.mortonCode >> lowBit) & 63]++] = m;
+        }
+        std::swap(mp, tmp);   // five passes: the result is in the temporary
+        ordered.resize(info.size());
+        std::vector<BuildNode *> roots;
+        const uint32_t mask = 0x3ffc0000u;   // the top 12 of the 30 bits
+        for (int start = 0, end = 1; end <= (int)mp.size(); ++end)
+            if (end == (int)mp.size() || (mp[start].mortonCode & mask) != (mp[end].mortonCode & mask)) {
+                roots.push_back(emit(&mp[start], end - start, 29 - 12));
+                start = end;
+            }
+        return upper(roots, 0, (int)roots.size());
+    }
+};
+
 size_t countNodes(const BuildNode *n) {   // iterative: trees can be deep
     size_t c = 0;
     std::vector<const BuildNode *> st{n};
@@ -179,10 +316,6 @@ size_t countNodes(const BuildNode *n) {   // iterative: trees can be deep
 
 BVHAccel::BVHAccel(const std::vector<GeometricPrimitive> &prims, int maxPrims, SplitMethod m)
     : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(m) {
-    if (m == SplitMethod::HLBVH) {
-        Warning("BVH split method \"hlbvh\" builds with \"sah\" in this implementation (same hits; different tree).");
-        splitMethod = SplitMethod::SAH;
-    }
     // one entry per triangle, in scene order (api.cpp:1365: one GeometricPrimitive per Triangle)
     std::vector<PrimRef> refs;
     size_t total = 0;
@@ -220,10 +353,23 @@ BVHAccel::BVHAccel(const std::vector<GeometricPrimitive> &prims, int maxPrims, S
         }
     }
     Builder builder(info, maxPrimsInNode, splitMethod);
-    BuildNode *root = builder.build(0, (int)total, builder.newPool());
-
+    HLBVH hl(info, maxPrimsInNode);
+    BuildNode *root;
     primitives.resize(total);
-    for (size_t i = 0; i < total; ++i) primitives[i] = refs[info[i].primitiveNumber];
+    if (splitMethod == SplitMethod::HLBVH) {
+        root = hl.build();
+        if (hl.degenerate) {   // the reference aborts on such input (CHECK_NE / CHECK_GT in buildUpperSAH): no tree to reproduce
+            Unsupported("Accelerator \"bvh\" \"string splitmethod\" \"hlbvh\": the treelet roots cannot be split (coinciding centroids); the reference's build stops with a CHECK failure on this scene");
+            splitMethod = SplitMethod::SAH;
+            root = builder.build(0, (int)total, builder.newPool());
+            for (size_t i = 0; i < total; ++i) primitives[i] = refs[info[i].primitiveNumber];
+        } else {
+            for (size_t i = 0; i < total; ++i) primitives[i] = refs[hl.ordered[i]];
+        }
+    } else {
+        root = builder.build(0, (int)total, builder.newPool());
+        for (size_t i = 0; i < total; ++i) primitives[i] = refs[info[i].primitiveNumber];
+    }
 
     // flattenBVHTree (bvh.cpp:640-658), iteratively
     nodes.resize(countNodes(root));

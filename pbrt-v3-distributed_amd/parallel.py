@@ -246,6 +246,16 @@ def _launcher_id():
         return "%d_0" % ppid
 
 
+def die_with_parent(sig=None):
+    """prctl(PR_SET_PDEATHSIG): this process gets `sig` (default SIGKILL) when its parent dies -- a rank never outlives its launcher on the GPU, whatever killed the
+    launcher.  Linux only; elsewhere a no-op."""
+    import ctypes, signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(sig if sig is not None else signal.SIGKILL), 0, 0, 0)
+    except Exception:
+        pass
+
+
 def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
     """Start `script argv` as n_ranks processes of ONE node under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1 with a free port -- the launch line the round driver uses) and return the job's exit code.  Used by
@@ -263,7 +273,10 @@ def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
     env.update(backend_env or {})
     if timeout_s is None and os.environ.get("PBRT_AMD_LAUNCH_TIMEOUT_S"):
         timeout_s = float(os.environ["PBRT_AMD_LAUNCH_TIMEOUT_S"])
-    p = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # torch.distributed.run starts every rank in a session of its own (elastic/multiprocessing/subprocess_handler), so no process-group kill from outside reaches
+    # them; the chain that does: this process dies -> the launcher gets SIGTERM (parent-death signal, below) -> it shuts its workers down; the launcher is
+    # killed outright -> every rank gets SIGKILL (die_with_parent(), called by the ranks themselves).
+    p = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=lambda: die_with_parent(signal.SIGTERM))
 
     def kill_group(sig=signal.SIGKILL):
         try:
@@ -271,8 +284,17 @@ def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
         except (ProcessLookupError, PermissionError):
             pass
 
-    def on_signal(signum, frame):
+    def stop_job():
+        if p.poll() is None:
+            kill_group(signal.SIGTERM)   # the launcher's handler ends the ranks
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                pass
         kill_group()
+
+    def on_signal(signum, frame):
+        stop_job()
         raise SystemExit(128 + signum)
 
     saved = {}
@@ -288,7 +310,7 @@ def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
             sys.stderr.write("launch_ranks: the %d-rank job did not finish within %.0f s -- killing its process group\n" % (n_ranks, timeout_s))
             return 124
     finally:
-        kill_group()   # also after a normal exit: a rank that ignored the launcher's SIGTERM does not stay on the GPU
+        stop_job()
         try:
             p.wait(timeout=10)
         except Exception:

@@ -72,7 +72,19 @@ def _gpu_session_guard():
     return "[gpu tests] device library %s sha256 %s, ABI %d, %d HIP device(s)" % (lib, build_id, want, n.value)
 
 
+# ---- the multi-rank tests need torch (torch.distributed under bench.py --gpus 2).  Its first import and first device tensor on a fresh box page in gigabytes of the
+# image -- minutes, and very variable -- which is what round 5's driver run died of.  When such tests are selected the warm-up starts NOW, in a detached process, and
+# proceeds while the two hundred in-process tests (which never touch torch) run; tests/test_zz_multirank_gpu.py waits for it before any job's limit starts counting.
+TORCH_WARMUP = None
+TORCH_WARMUP_CODE = ("import torch, torch.distributed as dist, torch.distributed.run; t = torch.zeros(1 << 20, device='cuda'); t += 1; i = torch.arange(8, device='cuda'); "
+                     "t.view(-1, 4).index_select(0, i); t.view(-1, 4).index_add_(0, i, t.view(-1, 4)[:8]); torch.cuda.synchronize(); print(float(t.sum().cpu()))")
+
+
 def pytest_collection_finish(session):
+    global TORCH_WARMUP
+    if not session.config.option.collectonly and any(it.get_closest_marker("multirank") and it.get_closest_marker("gpu") for it in session.items):
+        import subprocess
+        TORCH_WARMUP = subprocess.Popen([sys.executable, "-c", TORCH_WARMUP_CODE], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
     if not session.config.option.collectonly and any(it.get_closest_marker("gpu") for it in session.items):
         banner = _gpu_session_guard()
         tr = session.config.pluginmanager.get_plugin("terminalreporter")

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in _header_symbols() if s not in exported]
     assert not missing, missing
     L = pa.device_lib()          # loads without a GPU (libamdhip64 is present)
-    assert L.mi_abi_version() == int(re.search(r"#define MI_ABI_VERSION (\d+)", open(os.path.join(ol.ROOT, "include", "pbrt_amd.h")).read()).group(1)) == 13
+    assert L.mi_abi_version() == int(re.search(r"#define MI_ABI_VERSION (\d+)", open(os.path.join(ol.ROOT, "include", "pbrt_amd.h")).read()).group(1)) == 14
 
 
 def test_no_cpu_fallback_without_gpu():

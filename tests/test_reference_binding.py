@@ -223,3 +223,67 @@ def test_the_binding_itself_has_no_cpu_render_path(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([binding, "--quiet", "--outfile", out, scene], env=dict(env, PBRT_AMD_DEVICE_LIB=pa.DEVICE_LIB), capture_output=True, text=True, timeout=300)
         assert "no HIP device available" in (r.stderr + r.stdout) and not os.path.exists(out)
+
+
+def _host_bvh(sc):
+    """(nodes as raw bytes, ordered triangles as 9 floats each) of a scene the host library built"""
+    import ctypes as C
+    raw = (C.c_uint64 * 12).from_address(sc.desc)   # [abi|n_verts] P N UV [n_tris] idx mesh light [n_meshes] meshes [n_nodes] nodes
+    n_verts, n_tris, n_nodes = raw[0] >> 32, raw[4] & 0xffffffff, raw[10] & 0xffffffff
+    P = np.ctypeslib.as_array((C.c_float * (3 * n_verts)).from_address(raw[1])).reshape(-1, 3)
+    idx = np.ctypeslib.as_array((C.c_uint32 * (3 * n_tris)).from_address(raw[5]))
+    nodes = bytes((C.c_uint8 * (32 * n_nodes)).from_address(raw[11]))
+    return n_nodes, nodes, P[idx].reshape(n_tris, 9).copy()
+
+
+@pytest.mark.parametrize("method,maxprims", [("sah", 4), ("hlbvh", 4), ("hlbvh", 1), ("hlbvh", 9), ("middle", 4), ("equal", 2)])
+def test_host_bvh_build_equals_the_reference_build_node_for_node(method, maxprims, tmp_path):
+    """Every `Accelerator "bvh" "string splitmethod"` the reference knows (accelerators/bvh.cpp:740-760), built by the host library and by the reference's own
+    BVHAccel (one thread: HLBVH hands out leaf offsets from an atomic counter inside a ParallelFor) on the same scene -- two meshes of scattered triangles, one
+    with many coinciding centroids -- and compared as it crosses the boundary: the LinearBVHNode array byte for byte (bounds, child / primitive offsets, counts,
+    split axes) and the ordered primitive list triangle for triangle.  Round 5 built SAH for "hlbvh" with a warning: same hits except for ties, different tree."""
+    if not os.access(STUB, os.X_OK):
+        pytest.skip("oracle/_ref/pbrt_ref_flatcheck not built here (needs /root/reference)")
+    rng = np.random.default_rng(11)
+    def soup(n, spread, size):
+        c = rng.uniform(-spread, spread, (n, 1, 3)).astype(np.float32)
+        return (c + rng.uniform(-size, size, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    a = soup(3000, 4.0, 0.15)
+    b = np.concatenate([soup(400, 1.0, 0.02), np.tile(soup(1, 0.5, 0.3), (40, 1))])   # 40 identical triangles: equal Morton codes down to the last bit
+    def mesh(v):
+        return 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (" ".join(str(i) for i in range(len(v))), " ".join("%.9g" % x for x in v.reshape(-1)))
+    text = ('LookAt 0 0 -12 0 0 0 0 1 0\nCamera "perspective"\nSampler "sobol" "integer pixelsamples" [1]\nIntegrator "path"\n'
+            'Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "o.pfm"\n'
+            'Accelerator "bvh" "string splitmethod" "%s" "integer maxnodeprims" [%d]\nWorldBegin\nLightSource "point" "point from" [0 0 -10]\n%s%sWorldEnd\n'
+            % (method, maxprims, mesh(a), mesh(b)))
+    scene = tmp_path / "s.pbrt"
+    scene.write_text(text)
+    dump = str(tmp_path / "bvh.bin")
+    env = dict(os.environ, PBRT_AMD_BACKEND_LIB=ORACLE, PBRT_AMD_BVH_DUMP=dump, PBRT_AMD_BVH_DUMP_ONLY="1")
+    r = subprocess.run([STUB, "--quiet", "--nthreads", "1", "--outfile", str(tmp_path / "o.pfm"), str(scene)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.exists(dump), r.stderr[-800:]
+    blob = open(dump, "rb").read()
+    n_nodes, n_tris = np.frombuffer(blob[:8], np.uint32)
+    ref_nodes = blob[8:8 + 32 * n_nodes]
+    ref_tris = np.frombuffer(blob[8 + 32 * n_nodes:], np.float32).reshape(n_tris, 9)
+    sc = pa.Scene(str(scene), strict=True)
+    h_nodes, nodes, tris = _host_bvh(sc)
+    assert (h_nodes, len(tris)) == (n_nodes, n_tris) and n_tris == 3000 + 440
+    dt = np.dtype([("bmin", "f4", 3), ("bmax", "f4", 3), ("offset", "i4"), ("n", "u2"), ("axis", "u1"), ("pad", "u1")])
+    R, H = np.frombuffer(ref_nodes, dt), np.frombuffer(nodes, dt)
+    # the DFS layout is the same array position by position (bvh.cpp:640-658); everything but a leaf's primitivesOffset must be equal byte for byte.  The offsets
+    # themselves are handed out in construction order, which the reference leaves to the compiler (`InitInterior(dim, recursiveBuild(..), recursiveBuild(..))`:
+    # g++ evaluates the second argument first, so its ordered list fills from the right) -- what is pinned is what a leaf HOLDS, in order.
+    for f in ("bmin", "bmax", "n", "axis"):
+        assert np.ascontiguousarray(R[f]).tobytes() == np.ascontiguousarray(H[f]).tobytes(), f
+    interior = R["n"] == 0
+    assert np.array_equal(R["offset"][interior], H["offset"][interior])   # secondChildOffset
+    leaves = np.flatnonzero(~interior)
+    seen = 0
+    for i in leaves:
+        a, b, n = int(R["offset"][i]), int(H["offset"][i]), int(R["n"][i])
+        assert np.array_equal(ref_tris[a:a + n].view(np.uint32), tris[b:b + n].view(np.uint32)), (i, a, b, n)
+        seen += n
+    assert seen == n_tris
+    if method == "hlbvh":
+        assert R["n"].max() > 1 or maxprims == 1   # the treelets did produce multi-primitive leaves (40 coinciding triangles run out of Morton bits)

@@ -16,30 +16,63 @@ import oracle_lib as ol
 
 pa = ol.pa
 ROOT = ol.ROOT
-pytestmark = [pytest.mark.gpu, pytest.mark.multirank]
+pytestmark = [pytest.mark.gpu, pytest.mark.multirank, pytest.mark.timeout(1500)]
 
 BENCH = os.path.join(ROOT, "bench.py")
 SMALL = ["--steps", "1", "--warmup", "1", "--tris", "200000", "--res", "320", "192", "--spp", "4", "--cpu-seconds", "0", "--traffic", "none"]
 SCENE_KEY = "sanmiguel_synth_200k_320x192_4spp"
 
 
-def run_job(args, tmp_path, limit_s=300, extra_env=None):
-    """`python bench.py args` in its own process group, stderr to a file; (rc, stdout, stderr) -- rc None = killed at the limit"""
-    env = dict(os.environ, PBRT_AMD_BENCH_DIR=str(tmp_path), PBRT_AMD_BENCH_STACKS_S="60", PBRT_AMD_BENCH_WAIT_S="120", PBRT_AMD_PG_TIMEOUT_S="120")
-    env.update(extra_env or {})
-    err_path, out_path = str(tmp_path / "job.err"), str(tmp_path / "job.out")
-    with open(err_path, "w") as ferr, open(out_path, "w") as fout:
-        p = subprocess.Popen([sys.executable, BENCH] + args, stdout=fout, stderr=ferr, env=env, start_new_session=True)
-        try:
-            rc = p.wait(timeout=limit_s)
-        except subprocess.TimeoutExpired:
-            rc = None
-        finally:
+def _end(p, limit_s):
+    """wait for p (leader of its own process group) up to limit_s; then SIGTERM (bench.py's launcher ends its ranks), SIGKILL after 20 s.  rc or None = stopped at the limit"""
+    try:
+        return p.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 20), (signal.SIGKILL, 10)):
             try:
-                os.killpg(p.pid, signal.SIGKILL)   # launcher, torchrun and every rank: nothing stays on the GPU
+                os.killpg(p.pid, sig)
             except (ProcessLookupError, PermissionError):
                 pass
-            p.wait()
+            try:
+                p.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                pass
+        return None
+    finally:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)   # whatever is left of the group (the ranks end with their launcher: parallel.die_with_parent)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+
+@pytest.fixture(scope="module", autouse=True)
+def torch_is_warm():
+    """The first `import torch` + first device tensor on a fresh box page in gigabytes of the image and have taken anything from one to ten minutes (the stall of
+    round 5's driver run, reproduced in round 6: profiles/r06_a_*).  conftest.py starts that warm-up in the background when the session begins; here it is
+    awaited (bounded) BEFORE any job's own limit starts to count, so the limits below measure the jobs, not the box."""
+    import time
+    import conftest
+    t0 = time.time()
+    w = getattr(conftest, "TORCH_WARMUP", None)
+    if w is None:
+        w = subprocess.Popen([sys.executable, "-c", conftest.TORCH_WARMUP_CODE], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    rc = _end(w, 900)
+    print("[multirank] torch warm-up: rc %s, waited %.0f s" % (rc, time.time() - t0))
+    yield
+
+
+def run_job(args, tmp_path, limit_s=420, extra_env=None):
+    """`python bench.py args` in its own process group, stderr to a file; (rc, stdout, stderr) -- rc None = stopped at the limit"""
+    import time
+    env = dict(os.environ, PBRT_AMD_BENCH_DIR=str(tmp_path), PBRT_AMD_BENCH_STACKS_S="60", PBRT_AMD_BENCH_WAIT_S="180", PBRT_AMD_PG_TIMEOUT_S="180")
+    env.update(extra_env or {})
+    err_path, out_path = str(tmp_path / "job.err"), str(tmp_path / "job.out")
+    t0 = time.time()
+    with open(err_path, "w") as ferr, open(out_path, "w") as fout:
+        p = subprocess.Popen([sys.executable, BENCH] + args, stdout=fout, stderr=ferr, env=env, start_new_session=True)
+        rc = _end(p, limit_s)
+    print("[multirank] bench.py %s: rc %s after %.0f s" % (" ".join(args[:4]), rc, time.time() - t0))
     return rc, open(out_path).read(), open(err_path).read()
 
 
@@ -57,7 +90,7 @@ def test_bench_two_ranks_self_launch_end_to_end(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["unit"] == "Msamples/s"
     assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 - 320 * 192 * 4) <= 0.01 * 320 * 192 * 4   # all samples of the frame, once
     assert d["setup_s"]["scene_by_rank"] == ["built", "mapped"], d["setup_s"]
-    assert err.count("wrote ") and err.count("sanmiguel_synth.pbrt") and len([l for l in err.splitlines() if l.startswith("wrote ") and l.endswith(".pbrt")]) == 1, "the scene was generated more than once"
+    assert len([l for l in err.splitlines() if l.startswith("wrote ") and "sanmiguel_synth.pbrt" in l]) == 1, "the scene was generated %d times" % err.count("wrote ")
     # the image: one process, one context, the same file
     got = np.load(film2)
     sc = pa.Scene(os.path.join(str(tmp_path), SCENE_KEY, "sanmiguel_synth.pbrt"), strict=True)
@@ -105,3 +138,59 @@ def test_a_cut_off_scene_file_fails_both_ranks_loudly(tmp_path):
     assert not [l for l in out.splitlines() if l.startswith("{")]
     assert "Unable to read the contents of PLY file" in err and "strict mode" in err, err[-3000:]
     assert "Traceback" in err and "timed out" not in err
+
+
+def _run_script(code, tmp_path, limit_s=240):
+    """python -c code in its own process group with a hard limit; (rc, stdout + stderr) -- rc None = killed at the limit"""
+    out_path = str(tmp_path / "script.out")
+    env = dict(os.environ, PYTHONFAULTHANDLER="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    with open(out_path, "w") as fout:
+        p = subprocess.Popen([sys.executable, "-c", code], stdout=fout, stderr=subprocess.STDOUT, env=env, start_new_session=True, cwd=ROOT)
+        rc = _end(p, limit_s)
+    return rc, open(out_path).read()
+
+
+def test_the_librarys_rccl_step_executes_on_this_gpu(tmp_path):
+    """mi_film_gather's distinct-device branch cannot run on a one-GPU box (RCCL refuses two ranks on one device).  mi_rccl_probe runs the pieces it is made of on
+    the one GPU there is: librccl.so loaded with dlopen, ncclCommInitAll over {device 0}, ONE ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd of packed
+    FilmTilePixels on the context's stream (the helper the gather itself calls), the gather's add kernel; every pixel must arrive bit for bit."""
+    code = ("import importlib, os, sys; sys.path.insert(0, %r); pa = importlib.import_module('pbrt-v3-distributed_amd'); "
+            "sc = pa.Scene(os.path.join(%r, 'scenes', 'cornell.pbrt')); ctx = pa.Context(sc); ctx.rccl_probe(1 << 16); ctx.rccl_probe(1000003); ctx.close(); print('RCCL_PROBE_OK')" % (ROOT, ROOT))
+    rc, out = _run_script(code, tmp_path)
+    assert rc == 0 and "RCCL_PROBE_OK" in out, "rc %s\n%s" % (rc, out[-3000:])
+
+
+def test_sharded_frame_over_rccl_with_one_rank(tmp_path):
+    """parallel.ShardedFrame / FilmExchange on backend "nccl" (= RCCL) with a world of ONE rank on the real GPU: init_process_group with the device id, the film
+    tensors, the all-reduces of max_over_ranks / sum_over_ranks, the barriers of sync_all and a grouped batch_isend_irecv of packed pixels to itself all
+    execute RCCL code on hardware (the N > 1 collectives differ in peers, not in calls); the exchanged frame equals the plain render bit for bit."""
+    code = """
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+pa = importlib.import_module('pbrt-v3-distributed_amd'); par = importlib.import_module('pbrt-v3-distributed_amd.parallel')
+import torch, torch.distributed as dist
+sc = pa.Scene(os.path.join(%r, 'scenes', 'cornell.pbrt'))
+ctx = pa.Context(sc); ctx.render(); ref = ctx.film()
+torch.cuda.set_device(0)
+import datetime
+dist.init_process_group(backend='nccl', device_id=torch.device('cuda', 0), timeout=datetime.timedelta(seconds=120))
+# the collectives ShardedFrame issues with N > 1, on the one-rank communicator
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+assert t.cpu().tolist() == [1.5, 2.5]
+dist.barrier(); torch.cuda.synchronize()
+# FilmExchange's grouped point-to-point exchange, rank 0 to itself: pack -> one batch_isend_irecv group -> index_add
+film = torch.from_numpy(ref.reshape(-1)).cuda()
+idx = torch.from_numpy(par.reach_pixels(0, 1, sc.width, sc.height, sc.info['sample_bounds'], (sc.info['crop_x0'], sc.info['crop_y0']), sc.info['filter_radius'])).cuda()
+packed = film.view(-1, 4).index_select(0, idx); recv = torch.empty_like(packed)
+for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, 0), dist.P2POp(dist.irecv, recv, 0)]):
+    w.wait()
+acc = torch.zeros_like(film); acc.view(-1, 4).index_add_(0, idx, recv); torch.cuda.synchronize()
+assert np.array_equal(acc.cpu().numpy().view(np.uint32), ref.reshape(-1).view(np.uint32))
+obj = [None]; dist.all_gather_object(obj, 'built'); assert obj == ['built']
+dist.barrier(); dist.destroy_process_group(); ctx.close()
+print('RCCL_ONE_RANK_OK')
+""" % (ROOT, ROOT)
+    rc, out = _run_script(code, tmp_path)
+    assert rc == 0 and "RCCL_ONE_RANK_OK" in out, "rc %s\n%s" % (rc, out[-3000:])

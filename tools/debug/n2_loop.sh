@@ -23,7 +23,7 @@ for i in $(seq 1 $N); do
     wait $pid; rc=$?
     if [ $rc -eq 0 ] && grep -q '^{' $OUT/$i.out; then pass=$((pass+1)); else fail=$((fail+1)); fi
   fi
-    echo "iteration $i: rc $rc, $((SECONDS - t0)) s, scene generated $(grep -c '^wrote .*pbrt$' $OUT/$i.err) time(s), last line: $(tail -1 $OUT/$i.err | cut -c1-160)" | tee -a $OUT/summary.txt
+    echo "iteration $i: rc $rc, $((SECONDS - t0)) s, last line: $(tail -1 $OUT/$i.err | cut -c1-160)" | tee -a $OUT/summary.txt
   rm -rf $D
   [ "$rc" = "0" ] && [ $i -gt 3 ] && rm -f $OUT/$i.err $OUT/$i.out   # keep the first three and every failure
 done
