@@ -593,6 +593,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     typedef typename std::conditional<QN, TravTypesQ<BLOCK, TraceShape<MODE, SPHERES, ALPHA, QN>::NLDS, STEP2>, TravTypes<INST>>::type TT;
     __shared__ typename TT::Entry lds_stack[TT::LDS * BLOCK];
     __shared__ uint4 lds_hot[HOT ? 4 * HOT : 1];
+    if constexpr (ALPHA) NoiseLdsInit();   // alpha masks may be procedural (`dots`, `fbm` ...): the noise table of pt_texture.h in LDS
     if constexpr (HOT > 0) {   // the hot nodes as four word planes [word][node]; coalesced 16-byte reads of nodesq[0 .. n_hot)
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodesq);
         const uint32_t nHot = sc.n_hot < (uint32_t)HOT ? sc.n_hot : (uint32_t)HOT;
@@ -1037,6 +1038,7 @@ template <bool ENV, int SMP, bool TEX, bool INST = false>
 __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE_WAVES)) k_shade(DevScene sc, PathState ps, uint32_t qout) {
     // light-selection CDF in LDS when it fits: Distribution1D::SampleDiscrete is a chain of dependent look-ups
     __shared__ float s_cdf[PT_CDF_LDS];
+    if constexpr (TEX) NoiseLdsInit();   // procedural textures / bump maps: the noise table of pt_texture.h in LDS
 #if PT_SHADE_PROF
     __shared__ long long s_prof[PT_BLOCK / 64];
     if ((threadIdx.x & 63) == 0) s_prof[threadIdx.x >> 6] = clock64();
@@ -3733,6 +3735,7 @@ int mi_bvh4q_validate(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int
 }
 // stage-level texture evaluation: Texture<T>::Evaluate of node `node` at n recorded interactions
 __global__ void __launch_bounds__(PT_BLOCK) k_stage_texture(int node, const mi_tex_query *q, int64_t n, float *rgb) {
+    NoiseLdsInit();
     int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;
     TexCtx tc;

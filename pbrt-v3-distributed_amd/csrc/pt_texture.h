@@ -69,7 +69,17 @@ __device__ const uint8_t c_noise_perm[256] = {
     119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
     218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
     184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
-PT_DEV int NoisePerm(int i) { return c_noise_perm[i & 255]; }
+// Round 6: the table is read from LDS.  A noise value is 14 table look-ups in three DEPENDENT levels (P[P[P[x] + y] + z] for the eight corners); from global memory every
+// level is a per-lane gather at vector-memory latency, and the kernels that evaluate procedural textures run at 2-4 waves per SIMD, so a bump map (twelve noise calls) or
+// a `dots` alpha mask inside the traversal (up to three) was latency, not arithmetic.  256 bytes = one dword per LDS bank: no bank conflicts whatever the indices.
+// Every kernel that can reach a noise call copies the table at its start (NoiseLdsInit); which kernels those are is read off the compiler's own per-kernel LDS sizes
+// (tools/debug/kernel_resources.sh: exactly the instances whose group segment grew by 256 bytes).
+__shared__ uint8_t s_noise_perm[256];
+PT_DEV void NoiseLdsInit() {
+    for (uint32_t k = threadIdx.x; k < 64; k += blockDim.x) ((uint32_t *)s_noise_perm)[k] = ((const uint32_t *)c_noise_perm)[k];
+    __syncthreads();
+}
+PT_DEV int NoisePerm(int i) { return s_noise_perm[i & 255]; }
 PT_DEV Float NoiseGrad(int x, int y, int z, Float dx, Float dy, Float dz) {   // texture.cpp:186-192
     int h = NoisePerm(NoisePerm(NoisePerm(x) + y) + z);
     h &= 15;

@@ -534,6 +534,7 @@ PT_DEV void WriteNeeRecords(const PathState &ps, const DevVol &vol, uint32_t slo
 template <bool WAVE, bool INST, bool UMAT>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_shade_vol(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
     __shared__ StackEntry lds_stack[WAVE ? 1 : PT_LDS_STACK * PT_BLOCK];
+    NoiseLdsInit();
     const DevScene &sc = *scp;
     LaneTracer lt;
     lt.scp = scp;
@@ -1009,6 +1010,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_step(const DevScene *scp
 template <bool INST>
 __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_tail(const DevScene *scp, PathState ps, DevVol vol, const uint32_t *qIn, uint32_t rowIn) {
     __shared__ StackEntry lds_stack[PT_LDS_STACK * PT_BLOCK];
+    NoiseLdsInit();
     LaneTracer lt;
     lt.scp = scp;
     lt.lds = (LdsStackEntry *)&lds_stack[threadIdx.x];
@@ -1056,6 +1058,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_sss_probe_tail(const DevScene *scp
 template <bool INST>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
     __shared__ StackEntry lds_stack[1];
+    NoiseLdsInit();
     const DevScene &sc = *scp;
     LaneTracer lt;
     lt.scp = scp; lt.lds = (LdsStackEntry *)&lds_stack[0]; lt.spill = nullptr;
@@ -1167,6 +1170,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_sss_entry(cons
 // and does the rest of the loop body: phase function / BSDF sample, throughput, eta scale, Russian roulette, ++bounces.
 template <bool INST>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VOL_SHADE_WAVES) k_vol_continue(const DevScene *scp, PathState ps, DevVol vol, uint32_t qout) {
+    NoiseLdsInit();
     const DevScene &sc = *scp;
     for (SegIter it(ps.qcount, QC_CONT, ps.seg_cap); it.more(); it.next()) {
         const bool active = it.valid();

@@ -77,7 +77,7 @@ def _gpu_session_guard():
 # proceeds while the two hundred in-process tests (which never touch torch) run; tests/test_zz_multirank_gpu.py waits for it before any job's limit starts counting.
 TORCH_WARMUP = None
 TORCH_WARMUP_CODE = ("import torch, torch.distributed as dist, torch.distributed.run; t = torch.zeros(1 << 20, device='cuda'); t += 1; i = torch.arange(8, device='cuda'); "
-                     "t.view(-1, 4).index_select(0, i); t.view(-1, 4).index_add_(0, i, t.view(-1, 4)[:8]); torch.cuda.synchronize(); print(float(t.sum().cpu()))")
+                     "t.view(-1, 4).index_select(0, i); t.view(-1, 4).index_add_(0, i, t.view(-1, 4)[:8].clone()); torch.cuda.synchronize(); print(float(t.sum().cpu()))")
 
 
 def pytest_collection_finish(session):
