@@ -437,6 +437,182 @@ void bvh_study_rebuilt(const mi_scene_desc *d, const mi_ray *rays, int64_t n, in
 }
 }
 
+// ---- spatial-split study (round 6): SBVH (Stich, Friedrich, Dietrich 2009) over the same triangles.  At every node the best OBJECT split
+// (binned SAH on the reference centroids, three axes) competes with the best SPATIAL split (chopped binning: every reference is clipped, as the triangle it is, to the
+// bins it straddles); a spatial split duplicates the references that cross its plane.  Spatial splits are only tried where the children of the object split overlap
+// by more than `alpha` of the root's area.  The tree replaces bvh_nodes / the primitive list of a COPY of the description (a triangle may appear in several leaves),
+// so the counters of this file run on it unchanged.  out[4] = references / triangles, out[5] = leaves, out[6] = mean leaf size.
+namespace {
+struct SRef { float lo[3], hi[3]; uint32_t tri; };
+struct SB {
+    const mi_scene_desc *d;
+    std::vector<mi_bvh2_node> nodes;
+    std::vector<uint32_t> order;   // triangle of every leaf reference, in leaf order
+    int bins, leafMax; float cNode, cTri, alpha; double rootArea = 0;
+    static float areaOf(const float *a, const float *b) { float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2]; return (dx < 0 || dy < 0 || dz < 0) ? 0.f : 2 * (dx * dy + dx * dz + dy * dz); }
+    // box of the part of triangle t between the planes x_a = p0 and x_a = p1, intersected with the reference's own box
+    bool clipBox(const SRef &r, int a, float p0, float p1, float *lo, float *hi) const {
+        const uint32_t *v = d->tri_indices + 3 * (size_t)r.tri;
+        double poly[2][10][3]; int n = 3, cur = 0;
+        for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) poly[0][k][c] = d->P[3 * (size_t)v[k] + c];
+        for (int side = 0; side < 2; ++side) {   // keep x_a >= p0, then x_a <= p1
+            const double pl = side ? p1 : p0, sg = side ? -1 : 1;
+            int m = 0;
+            for (int k = 0; k < n; ++k) {
+                const double *A = poly[cur][k], *B = poly[cur][(k + 1) % n];
+                const double da = sg * (A[a] - pl), db = sg * (B[a] - pl);
+                if (da >= 0) { for (int c = 0; c < 3; ++c) poly[cur ^ 1][m][c] = A[c]; ++m; }
+                if ((da > 0 && db < 0) || (da < 0 && db > 0)) { const double t = da / (da - db); for (int c = 0; c < 3; ++c) poly[cur ^ 1][m][c] = A[c] + t * (B[c] - A[c]); poly[cur ^ 1][m][a] = pl; ++m; }
+            }
+            n = m; cur ^= 1;
+            if (n == 0) return false;
+        }
+        for (int c = 0; c < 3; ++c) { lo[c] = 1e30f; hi[c] = -1e30f; }
+        for (int k = 0; k < n; ++k) for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], (float)poly[cur][k][c]); hi[c] = std::max(hi[c], (float)poly[cur][k][c]); }
+        for (int c = 0; c < 3; ++c) { lo[c] = std::max(lo[c], r.lo[c]); hi[c] = std::min(hi[c], r.hi[c]); if (lo[c] > hi[c]) { if (lo[c] - hi[c] < 1e-4f * (1 + std::fabs(lo[c]))) hi[c] = lo[c]; else return false; } }
+        return true;
+    }
+    uint32_t build(std::vector<SRef> &refs, int depth) {
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        float bl[3] = {1e30f, 1e30f, 1e30f}, bh[3] = {-1e30f, -1e30f, -1e30f}, cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+        for (const SRef &r : refs) for (int a = 0; a < 3; ++a) {
+            bl[a] = std::min(bl[a], r.lo[a]); bh[a] = std::max(bh[a], r.hi[a]);
+            const float c = 0.5f * (r.lo[a] + r.hi[a]); cl[a] = std::min(cl[a], c); ch[a] = std::max(ch[a], c);
+        }
+        for (int a = 0; a < 3; ++a) { nodes[me].bmin[a] = bl[a]; nodes[me].bmax[a] = bh[a]; }
+        const uint32_t n = (uint32_t)refs.size();
+        const float A = areaOf(bl, bh);
+        if (me == 0) rootArea = A;
+        auto makeLeaf = [&]() { nodes[me].offset = (int32_t)order.size(); nodes[me].n_prims = (uint16_t)n; nodes[me].axis = 0; for (const SRef &r : refs) order.push_back(r.tri); return me; };
+        if (n == 1 || depth > 60) return makeLeaf();
+        // object split
+        float objCost = 1e38f; int objAxis = -1; float objPos = 0; float ovl = 0;
+        for (int a = 0; a < 3; ++a) {
+            if (!(ch[a] > cl[a])) continue;
+            std::vector<uint32_t> cnt(bins, 0);
+            std::vector<float> bbl(3 * bins, 1e30f), bbh(3 * bins, -1e30f);
+            const float sc = bins / (ch[a] - cl[a]);
+            for (const SRef &r : refs) {
+                int b = std::min(bins - 1, (int)((0.5f * (r.lo[a] + r.hi[a]) - cl[a]) * sc));
+                ++cnt[b];
+                for (int k = 0; k < 3; ++k) { bbl[3 * b + k] = std::min(bbl[3 * b + k], r.lo[k]); bbh[3 * b + k] = std::max(bbh[3 * b + k], r.hi[k]); }
+            }
+            std::vector<float> rA(bins, 0.f), rL(3 * bins), rH(3 * bins); std::vector<uint32_t> rN(bins, 0);
+            float rl[3] = {1e30f, 1e30f, 1e30f}, rh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t rn = 0;
+            for (int b = bins - 1; b > 0; --b) {
+                for (int k = 0; k < 3; ++k) { rl[k] = std::min(rl[k], bbl[3 * b + k]); rh[k] = std::max(rh[k], bbh[3 * b + k]); rL[3 * b + k] = rl[k]; rH[3 * b + k] = rh[k]; }
+                rn += cnt[b]; rA[b] = areaOf(rl, rh); rN[b] = rn;
+            }
+            float ll[3] = {1e30f, 1e30f, 1e30f}, lh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t ln = 0;
+            for (int b = 0; b < bins - 1; ++b) {
+                for (int k = 0; k < 3; ++k) { ll[k] = std::min(ll[k], bbl[3 * b + k]); lh[k] = std::max(lh[k], bbh[3 * b + k]); }
+                ln += cnt[b];
+                if (ln == 0 || rN[b + 1] == 0) continue;
+                float c = cNode + cTri * (areaOf(ll, lh) * ln + rA[b + 1] * rN[b + 1]) / A;
+                if (c < objCost) {
+                    objCost = c; objAxis = a; objPos = cl[a] + (b + 1) / sc;
+                    float ol[3], oh[3]; for (int k = 0; k < 3; ++k) { ol[k] = std::max(ll[k], rL[3 * (b + 1) + k]); oh[k] = std::min(lh[k], rH[3 * (b + 1) + k]); }
+                    ovl = areaOf(ol, oh);
+                }
+            }
+        }
+        // spatial split (chopped binning), only where the object split's children overlap enough
+        float spCost = 1e38f; int spAxis = -1; float spPos = 0;
+        if (alpha >= 0 && objAxis >= 0 && ovl > alpha * rootArea) {
+            for (int a = 0; a < 3; ++a) {
+                if (!(bh[a] > bl[a])) continue;
+                const float sc = bins / (bh[a] - bl[a]);
+                std::vector<uint32_t> ent(bins, 0), ext(bins, 0);
+                std::vector<float> bbl(3 * bins, 1e30f), bbh(3 * bins, -1e30f);
+                for (const SRef &r : refs) {
+                    int b0 = std::max(0, std::min(bins - 1, (int)((r.lo[a] - bl[a]) * sc))), b1 = std::max(0, std::min(bins - 1, (int)((r.hi[a] - bl[a]) * sc)));
+                    ++ent[b0]; ++ext[b1];
+                    for (int b = b0; b <= b1; ++b) {
+                        float lo[3], hi[3];
+                        if (b0 == b1) { for (int k = 0; k < 3; ++k) { lo[k] = r.lo[k]; hi[k] = r.hi[k]; } }
+                        else if (!clipBox(r, a, bl[a] + b / sc, bl[a] + (b + 1) / sc, lo, hi)) continue;
+                        for (int k = 0; k < 3; ++k) { bbl[3 * b + k] = std::min(bbl[3 * b + k], lo[k]); bbh[3 * b + k] = std::max(bbh[3 * b + k], hi[k]); }
+                    }
+                }
+                std::vector<float> rA(bins, 0.f); std::vector<uint32_t> rN(bins, 0);
+                float rl[3] = {1e30f, 1e30f, 1e30f}, rh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t rn = 0;
+                for (int b = bins - 1; b > 0; --b) {
+                    for (int k = 0; k < 3; ++k) { rl[k] = std::min(rl[k], bbl[3 * b + k]); rh[k] = std::max(rh[k], bbh[3 * b + k]); }
+                    rn += ext[b]; rA[b] = areaOf(rl, rh); rN[b] = rn;
+                }
+                float ll[3] = {1e30f, 1e30f, 1e30f}, lh[3] = {-1e30f, -1e30f, -1e30f}; uint32_t ln = 0;
+                for (int b = 0; b < bins - 1; ++b) {
+                    for (int k = 0; k < 3; ++k) { ll[k] = std::min(ll[k], bbl[3 * b + k]); lh[k] = std::max(lh[k], bbh[3 * b + k]); }
+                    ln += ent[b];
+                    if (ln == 0 || rN[b + 1] == 0 || ln == n || rN[b + 1] == n) continue;
+                    float c = cNode + cTri * (areaOf(ll, lh) * ln + rA[b + 1] * rN[b + 1]) / A;
+                    if (c < spCost) { spCost = c; spAxis = a; spPos = bl[a] + (b + 1) / sc; }
+                }
+            }
+        }
+        const float best = std::min(objCost, spCost), leafCost = cTri * n;
+        if ((int)n <= leafMax && (best >= 1e38f || leafCost <= best)) return makeLeaf();
+        std::vector<SRef> L, R;
+        int axis = 0;
+        if (spCost < objCost) {
+            axis = spAxis;
+            for (const SRef &r : refs) {
+                if (r.hi[axis] <= spPos) L.push_back(r);
+                else if (r.lo[axis] >= spPos) R.push_back(r);
+                else {
+                    SRef a = r, b = r;
+                    float lo[3], hi[3];
+                    bool okL = clipBox(r, axis, -1e30f, spPos, lo, hi);
+                    if (okL) { for (int k = 0; k < 3; ++k) { a.lo[k] = lo[k]; a.hi[k] = hi[k]; } L.push_back(a); }
+                    bool okR = clipBox(r, axis, spPos, 1e30f, lo, hi);
+                    if (okR) { for (int k = 0; k < 3; ++k) { b.lo[k] = lo[k]; b.hi[k] = hi[k]; } R.push_back(b); }
+                    if (!okL && !okR) L.push_back(r);
+                }
+            }
+            if (L.empty() || R.empty() || L.size() == n && R.size() == n) { L.clear(); R.clear(); spCost = 1e38f; }
+        }
+        if (L.empty()) {
+            if (objAxis >= 0) {
+                axis = objAxis;
+                for (const SRef &r : refs) (0.5f * (r.lo[axis] + r.hi[axis]) < objPos ? L : R).push_back(r);
+            }
+            if (L.empty() || R.empty()) { L.assign(refs.begin(), refs.begin() + n / 2); R.assign(refs.begin() + n / 2, refs.end()); }
+        }
+        std::vector<SRef>().swap(refs);
+        nodes[me].n_prims = 0; nodes[me].axis = (uint8_t)axis;
+        build(L, depth + 1);
+        const uint32_t second = build(R, depth + 1);
+        nodes[me].offset = (int32_t)second;
+        return me;
+    }
+};
+}  // namespace
+
+extern "C" void bvh_study_sbvh(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width, int cull_on_pop, int any_hit, int bins, int leafMax, float cNode, float cTri, float alpha, double *out) {
+    SB sb; sb.d = d; sb.bins = bins; sb.leafMax = std::min(leafMax, 255); sb.cNode = cNode; sb.cTri = cTri; sb.alpha = alpha;
+    const uint32_t nt = d->n_tris;
+    std::vector<SRef> refs(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t *v = d->tri_indices + 3 * (size_t)t;
+        refs[t].tri = t;
+        for (int a = 0; a < 3; ++a) {
+            float x0 = d->P[3 * (size_t)v[0] + a], x1 = d->P[3 * (size_t)v[1] + a], x2 = d->P[3 * (size_t)v[2] + a];
+            refs[t].lo[a] = std::min(x0, std::min(x1, x2)); refs[t].hi[a] = std::max(x0, std::max(x1, x2));
+        }
+    }
+    sb.nodes.reserve(3 * (size_t)nt);
+    sb.build(refs, 0);
+    std::vector<uint32_t> tri(3 * sb.order.size());
+    for (size_t i = 0; i < sb.order.size(); ++i) for (int k = 0; k < 3; ++k) tri[3 * i + k] = d->tri_indices[3 * (size_t)sb.order[i] + k];
+    mi_scene_desc d2 = *d;
+    d2.bvh_nodes = sb.nodes.data(); d2.n_bvh_nodes = (uint32_t)sb.nodes.size(); d2.tri_indices = tri.data(); d2.n_tris = (uint32_t)sb.order.size();
+    bvh_study(&d2, rays, n, width, cull_on_pop, any_hit, out);
+    out[4] = (double)sb.order.size() / nt;
+    double leaves = 0; for (auto &x : sb.nodes) leaves += x.n_prims > 0;
+    out[5] = leaves; out[6] = sb.order.size() / std::max(1.0, leaves);
+}
+
 // ---- wave-scheduling simulator (round 3): the per-lane state machine of k_trace run for 64-lane waves on the host, to count how many wave-level
 // node phases / leaf phases a policy needs and how many lanes take part in each (SIMT efficiency) -- the traversal kernels turned out to be bound by
 // VALU issue as much as by memory (profiles/r03_c_*: 47 % of the lanes active per VALU instruction), and policies can be compared here without a GPU.

@@ -114,6 +114,17 @@ def main():
                 nr, tr = out[0] / len(rays), out[1] / len(rays)
                 req = 3 + 4 * nr + 3 * tr
                 print("%-8s %-58s %9.2f %9.2f %9.1f %9.3f %9.2f   (%+.1f %% requests)" % (name, label, nr, tr, req, out[4], out[6], 100 * (req / base - 1)))
+            # round 6: spatial splits (SBVH); the "SAH rel." column shows references per triangle instead
+            L.bvh_study_sbvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+            for label, bins, leaf, cn, ct, alpha in (("own leaves, 3 x 32 bins, no spatial splits, leaves <= 4", 32, 4, 1, 1, -1), ("SBVH alpha 1e-5, leaves <= 4", 32, 4, 1, 1, 1e-5),
+                                                     ("SBVH alpha 1e-6, leaves <= 4", 32, 4, 1, 1, 1e-6), ("SBVH alpha 1e-4, leaves <= 4", 32, 4, 1, 1, 1e-4),
+                                                     ("SBVH alpha 1e-5, leaves <= 4, cTri 2", 32, 4, 1, 2, 1e-5), ("SBVH alpha 1e-5, leaves <= 2", 32, 2, 1, 1, 1e-5),
+                                                     ("SBVH alpha 0 (everywhere), leaves <= 4", 32, 4, 1, 1, 0.0)):
+                out = np.zeros(8)
+                L.bvh_study_sbvh(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), 4, 1, 0, bins, leaf, C.c_float(cn), C.c_float(ct), C.c_float(alpha), out.ctypes.data_as(C.c_void_p))
+                nr, tr = out[0] / len(rays), out[1] / len(rays)
+                req = 3 + 4 * nr + 3 * tr
+                print("%-8s %-58s %9.2f %9.2f %9.1f %9.3f %9.2f   (%+.1f %% requests; refs/tri in col 6)" % (name, label, nr, tr, req, out[4], out[6], 100 * (req / base - 1)))
         return
     print("%-8s %-36s %10s %10s %12s" % ("rays", "layout", "nodes/ray", "tris/ray", "KB/ray"))
     for name, rays in (("camera", cam), ("bounce", sec)):
