@@ -999,15 +999,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
 #endif
 #define PT_CNT_ALLOC 72
 #if PT_SHADE_PROF
-// developer instrumentation: wave time between consecutive probes (all memory drained at each probe)
+// developer instrumentation: wave time between consecutive probes (all memory drained at each probe).  Round 6: the sums are kept per wave in LDS and reach the
+// global counters once, when the block ends -- rounds 2-5 did two global atomics per probe and wave, whose contention (every wave of the chip on the same two words)
+// was most of what the profile measured: every phase cost about the same and the kernel ran 3-7 x slower than unprofiled (profiles/r06_d_*).
 #define PROBE(k)                                                                                     \
     {                                                                                                \
         __builtin_amdgcn_s_waitcnt(0);                                                               \
         unsigned long long pm_ = __ballot(1);                                                        \
         if (lane_id() == (uint32_t)(__ffsll((long long)pm_) - 1)) {                                  \
             long long now_ = clock64();                                                              \
-            atomicAdd(&ps.counters[16 + (k)], (unsigned long long)(now_ - s_prof[threadIdx.x >> 6])); \
-            atomicAdd(&ps.counters[40 + (k)], 1ull);                                                 \
+            s_pacc[threadIdx.x >> 6][(k)] += (unsigned long long)(now_ - s_prof[threadIdx.x >> 6]);  \
+            s_pcnt[threadIdx.x >> 6][(k)] += 1ull;                                                   \
             s_prof[threadIdx.x >> 6] = now_;                                                         \
         }                                                                                            \
     }
@@ -1041,6 +1043,8 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     if constexpr (TEX) NoiseLdsInit();   // procedural textures / bump maps: the noise table of pt_texture.h in LDS
 #if PT_SHADE_PROF
     __shared__ long long s_prof[PT_BLOCK / 64];
+    __shared__ unsigned long long s_pacc[PT_BLOCK / 64][24], s_pcnt[PT_BLOCK / 64][24];
+    if ((threadIdx.x & 63) < 24) { s_pacc[threadIdx.x >> 6][threadIdx.x & 63] = 0; s_pcnt[threadIdx.x >> 6][threadIdx.x & 63] = 0; }
     if ((threadIdx.x & 63) == 0) s_prof[threadIdx.x >> 6] = clock64();
 #endif
     const bool cdfInLds = sc.n_lights + 1 <= PT_CDF_LDS;
@@ -1122,6 +1126,20 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     if (hitInst && !hitInst->identity) InstanceToWorld(hitInst, &isect, &ix);
                 }
             }
+            // The light pick of a spatial table is a chain of dependent fetches (voxel -> funcInt, guide word -> cdf / func entries -> light record): its first link is
+            // issued here, as soon as the hit point is known, and flies while the emission and the BSDF set-up run -- same arithmetic on the same values (measured: k_shade
+            // 131.1 -> 128.6 ms per C3 frame, profiles/r05_aa_*; issuing the WHOLE pick here gained less, 129.7).  The guide word needs the light-pick dimension:
+            // only for the samplers that have drawn it by now (us[0]).
+            const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
+            size_t vox = 0;
+            Float funcIntE = 0;
+            uint32_t guideE = 0;
+            const bool pickEarly = spatial && found && bounces < sc.max_depth && (int)tinfo.y >= 0 && sc.n_lights > 0;
+            if (pickEarly) {
+                vox = SpatialVoxel(sc, isect.p);
+                funcIntE = sc.sp_func_int[vox];
+                if (SMP != 2 && sc.sp_guide_m) guideE = SpatialGuideWord(sc, vox, us[0]);
+            }
             PROBE(3)   // triangle reload + BuildIsect
             if (bounces == 0 || specularBounce) {
                 if (found) {
@@ -1173,20 +1191,9 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.n_lights > 0) {
                         // path.cpp:125-127 lightDistribution->Lookup(isect.p): the one table, or the voxel's (lightdistrib.cpp:139-152)
                         Float funcInt = sc.light_func_int;
-                        const bool spatial = sc.light_strategy == MI_LIGHT_STRATEGY_SPATIAL;
-                        size_t vox = 0;
                         if (spatial) {
-                            V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
-                            V3 off = isect.p - bmin;   // Bounds3::Offset geometry.h:786-792
-                            if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
-                            if (bmax.y > bmin.y) off.y /= bmax.y - bmin.y;
-                            if (bmax.z > bmin.z) off.z /= bmax.z - bmin.z;
-                            int v0 = (int)(off.x * sc.sp_nvox[0]), v1 = (int)(off.y * sc.sp_nvox[1]), v2 = (int)(off.z * sc.sp_nvox[2]);
-                            v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
-                            v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
-                            v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
-                            vox = ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
-                            funcInt = sc.sp_func_int[vox];
+                            if (!pickEarly) vox = SpatialVoxel(sc, isect.p);
+                            funcInt = pickEarly ? funcIntE : sc.sp_func_int[vox];
                         }
                         PROBE(5)   // BSDF ctor + NumComponents + voxel lookup
                         Float ul = PIX ? smp.PixGet1D(sc) : us[0];
@@ -1196,7 +1203,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                         // voxel's guide word (SpatialPick); the one power / uniform table: up to 16 independent probes per round on the LDS copy.
                         int lightNum;
                         Float funcAt;
-                        if (spatial) SpatialPick(sc, vox, ul, &lightNum, &funcAt);
+                        if (spatial) SpatialPick(sc, vox, ul, &lightNum, &funcAt, !PIX && pickEarly, guideE);
                         else {
                             const int size = (int)sc.n_lights + 1, first = CdfCountLE(cdf, size, ul);
                             lightNum = first - 1 < 0 ? 0 : (first - 1 > size - 2 ? size - 2 : first - 1);
@@ -1317,6 +1324,12 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
         PROBE(13)   // L store + queue appends
     }
     wave_count(&ps.counters[MI_CNT_PATH_SEGMENTS], nseg);
+#if PT_SHADE_PROF
+    if ((threadIdx.x & 63) < 24 && s_pcnt[threadIdx.x >> 6][threadIdx.x & 63]) {
+        atomicAdd(&ps.counters[16 + (threadIdx.x & 63)], s_pacc[threadIdx.x >> 6][threadIdx.x & 63]);
+        atomicAdd(&ps.counters[40 + (threadIdx.x & 63)], s_pcnt[threadIdx.x >> 6][threadIdx.x & 63]);
+    }
+#endif
 }
 
 #include "pt_volpath.h"   // k_shade_vol: the shading kernel of "volpath" scenes and of scenes with BSSRDF materials

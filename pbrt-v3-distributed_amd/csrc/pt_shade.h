@@ -669,15 +669,32 @@ PT_DEV int CdfCountLE(const float *cdf, int size, Float u) {
 // lies in [G, H] and only cdf[G .. H) decides it.  Round trip 1 = the guide word; round trip 2 = those (usually 0-2) cdf entries AND the candidates
 // for func[offset], which depend on G / H only -- two dependent fetches of a few words instead of the search's 24 probes in two rounds + func[offset].
 // Same comparisons on the same cdf values, so `offset` and func[offset] are the search's, bit for bit.
-PT_DEV void SpatialPick(const DevScene &sc, size_t vox, Float u, int *offset, Float *funcAt) {
+// (the voxel of a point: SpatialLightDistribution::Lookup's Bounds3::Offset + clamp, lightdistrib.cpp:139-152, geometry.h:786-792)
+PT_DEV size_t SpatialVoxel(const DevScene &sc, const V3 &p) {
+    V3 bmin = v3(sc.sp_bmin), bmax = v3(sc.sp_bmax);
+    V3 off = p - bmin;
+    if (bmax.x > bmin.x) off.x /= bmax.x - bmin.x;
+    if (bmax.y > bmin.y) off.y /= bmax.y - bmin.y;
+    if (bmax.z > bmin.z) off.z /= bmax.z - bmin.z;
+    int v0 = (int)(off.x * sc.sp_nvox[0]), v1 = (int)(off.y * sc.sp_nvox[1]), v2 = (int)(off.z * sc.sp_nvox[2]);
+    v0 = v0 < 0 ? 0 : (v0 > sc.sp_nvox[0] - 1 ? sc.sp_nvox[0] - 1 : v0);
+    v1 = v1 < 0 ? 0 : (v1 > sc.sp_nvox[1] - 1 ? sc.sp_nvox[1] - 1 : v1);
+    v2 = v2 < 0 ? 0 : (v2 > sc.sp_nvox[2] - 1 ? sc.sp_nvox[2] - 1 : v2);
+    return ((size_t)v0 * sc.sp_nvox[1] + v1) * sc.sp_nvox[2] + v2;
+}
+// the guide word of (voxel, u): the first of SpatialPick's two round trips, which k_shade issues together with the voxel's funcInt as soon as the hit point is known
+PT_DEV uint32_t SpatialGuideWord(const DevScene &sc, size_t vox, Float u) {
+    const uint32_t M = sc.sp_guide_m;
+    uint32_t j = (uint32_t)(u * (Float)M);
+    j = j < M - 1 ? j : M - 1;
+    return sc.sp_guide[vox * M + j];
+}
+PT_DEV void SpatialPick(const DevScene &sc, size_t vox, Float u, int *offset, Float *funcAt, bool haveGuide = false, uint32_t guideWord = 0) {
     const int size = (int)sc.n_lights + 1;
     const float *cdf = sc.sp_cdf + vox * (size_t)size, *func = sc.sp_func + vox * (size_t)sc.n_lights;
     int first;
     if (sc.sp_guide_m) {
-        const uint32_t M = sc.sp_guide_m;
-        uint32_t j = (uint32_t)(u * (Float)M);
-        j = j < M - 1 ? j : M - 1;
-        const uint32_t gh = sc.sp_guide[vox * M + j];
+        const uint32_t gh = haveGuide ? guideWord : SpatialGuideWord(sc, vox, u);
         const int lo = (int)(gh & 0xffffu), hi = (int)(gh >> 16);
         if (hi - lo <= 4) {
             float c[4], f[5];
