@@ -994,28 +994,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
     }
 }
 
-#ifndef PT_SHADE_PROF
-#define PT_SHADE_PROF 0
-#endif
 #define PT_CNT_ALLOC 72
-#if PT_SHADE_PROF
-// developer instrumentation: wave time between consecutive probes (all memory drained at each probe).  Round 6: the sums are kept per wave in LDS and reach the
-// global counters once, when the block ends -- rounds 2-5 did two global atomics per probe and wave, whose contention (every wave of the chip on the same two words)
-// was most of what the profile measured: every phase cost about the same and the kernel ran 3-7 x slower than unprofiled (profiles/r06_d_*).
-#define PROBE(k)                                                                                     \
-    {                                                                                                \
-        __builtin_amdgcn_s_waitcnt(0);                                                               \
-        unsigned long long pm_ = __ballot(1);                                                        \
-        if (lane_id() == (uint32_t)(__ffsll((long long)pm_) - 1)) {                                  \
-            long long now_ = clock64();                                                              \
-            s_pacc[threadIdx.x >> 6][(k)] += (unsigned long long)(now_ - s_prof[threadIdx.x >> 6]);  \
-            s_pcnt[threadIdx.x >> 6][(k)] += 1ull;                                                   \
-            s_prof[threadIdx.x >> 6] = now_;                                                         \
-        }                                                                                            \
-    }
-#else
-#define PROBE(k)
-#endif
+
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
 #ifndef PT_CDF_LDS
 #define PT_CDF_LDS 2048
@@ -1042,8 +1022,6 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     __shared__ float s_cdf[PT_CDF_LDS];
     if constexpr (TEX) NoiseLdsInit();   // procedural textures / bump maps: the noise table of pt_texture.h in LDS
 #if PT_SHADE_PROF
-    __shared__ long long s_prof[PT_BLOCK / 64];
-    __shared__ unsigned long long s_pacc[PT_BLOCK / 64][24], s_pcnt[PT_BLOCK / 64][24];
     if ((threadIdx.x & 63) < 24) { s_pacc[threadIdx.x >> 6][threadIdx.x & 63] = 0; s_pcnt[threadIdx.x >> 6][threadIdx.x & 63] = 0; }
     if ((threadIdx.x & 63) == 0) s_prof[threadIdx.x >> 6] = clock64();
 #endif

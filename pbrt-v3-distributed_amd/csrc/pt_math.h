@@ -8,6 +8,31 @@
 #include <stdint.h>
 
 #define PT_DEV __device__ __forceinline__
+// ---- developer instrumentation (PT_SHADE_PROF builds only): wave time between consecutive PROBE(k) points of k_shade, k = 0 .. 23; usable from any device routine
+// the kernel calls (round 6: the accumulators are file-scope LDS, one set per wave of the block).  All memory is drained at each probe; the sums stay per wave in LDS and
+// reach the global counters once, when the block ends -- rounds 2-5 did two global atomics per probe and wave, whose contention (every wave of the chip on the same two
+// words) was most of what the profile measured: every phase cost about the same and the kernel ran 3-7 x slower than unprofiled (profiles/r06_d_*).
+#ifndef PT_SHADE_PROF
+#define PT_SHADE_PROF 0
+#endif
+#if PT_SHADE_PROF
+__shared__ long long s_prof[4];
+__shared__ unsigned long long s_pacc[4][24], s_pcnt[4][24];
+#define PROBE(k)                                                                                     \
+    {                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                                               \
+        unsigned long long pm_ = __ballot(1);                                                        \
+        if (__lane_id() == (uint32_t)(__ffsll((long long)pm_) - 1)) {                                \
+            long long now_ = clock64();                                                              \
+            s_pacc[(threadIdx.x >> 6) & 3][(k)] += (unsigned long long)(now_ - s_prof[(threadIdx.x >> 6) & 3]);  \
+            s_pcnt[(threadIdx.x >> 6) & 3][(k)] += 1ull;                                             \
+            s_prof[(threadIdx.x >> 6) & 3] = now_;                                                   \
+        }                                                                                            \
+    }
+#else
+#define PROBE(k)
+#endif
+
 #include "pt_libm.h"
 
 typedef float Float;

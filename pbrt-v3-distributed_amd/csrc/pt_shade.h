@@ -424,6 +424,7 @@ template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const 
 template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
+    PROBE(22)   // lobe sampling: record load
     const bool needF = !(*sampledType & PT_SAMPLE_SKIP_F);
     *sampledType &= ~PT_SAMPLE_SKIP_F;
     RGB f;
@@ -439,6 +440,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR:   // BxDF::Sample_f reflection.cpp:378-385
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
+        PROBE(23)   // lobe sampling (diffuse): cosine sample
         *pdf = BxdfPdf<U>(bp, wo, *wi);
         if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
         break;
@@ -569,6 +571,7 @@ template <bool U> struct BSDF_T {
             int t = BxdfFlags(LobeType(i));
             if (Matches(t, flags) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
         }
+        PROBE(20)   // BSDF::f (NEE)
         return f;
     }
     PT_DEV Float Pdf(const V3 &woW, const V3 &wiW, int flags) const {   // reflection.cpp:770-785
@@ -596,6 +599,7 @@ template <bool U> struct BSDF_T {
         *pdf = 0;
         int bt = 0;
         RGB f(0.f);
+        PROBE(16)   // Sample_f: component choice
         // lanes may have chosen different lobes: each lobe's sampling routine runs for the lanes that picked it,
         // every time with a wave-uniform lobe pointer
         for (int i = 0; i < nb; ++i)
@@ -604,12 +608,14 @@ template <bool U> struct BSDF_T {
                 BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
+        PROBE(17)   // Sample_f: the chosen lobe's sampling routine
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
         if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
             for (int i = 0; i < nb; ++i)
                 if (i != chosen && Matches(BxdfFlags(LobeType(i)), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
         if (matchingComps > 1) *pdf /= matchingComps;
+        PROBE(18)   // Sample_f: the other lobes' pdfs
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
             f = RGB(0.f);
@@ -619,6 +625,7 @@ template <bool U> struct BSDF_T {
                 if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
             }
         }
+        PROBE(19)   // Sample_f: f over the matching lobes
         return f;
     }
 };

@@ -135,9 +135,13 @@ __device__ __noinline__ Float FBmT(const V3 p, const V3 dpdx, const V3 dpdy, Flo
         o *= omega;
     }
     Float nPartial = n - nInt;
-    Float nz = Noise3(lambda * p.x, lambda * p.y, lambda * p.z);
-    if (!turb) return sum + o * SmoothStepT(.3f, .7f, nPartial) * nz;
-    sum += o * Lerp(SmoothStepT(.3f, .7f, nPartial), (Float)0.2, absf(nz));
+    // the partial octave's weight is exactly 0 for nPartial <= .3 -- always on rays without differentials (every ray after the camera's: len2 = 0, n = maxOctaves) -- and the
+    // reference then adds o * 0 * noise = +-0 (fbm) or o * ((1 - 0) * .2 + 0 * |noise|) = o * .2 (turbulence): the same bits without the noise call (noise is finite; the sum
+    // cannot be -0), one Noise3 of five saved per evaluation, three per bump-mapped vertex
+    const Float sPartial = SmoothStepT(.3f, .7f, nPartial);
+    const Float nz = sPartial == 0 ? (Float)0 : Noise3(lambda * p.x, lambda * p.y, lambda * p.z);
+    if (!turb) return sum + o * sPartial * nz;
+    sum += o * Lerp(sPartial, (Float)0.2, absf(nz));
     for (int i = nInt; i < maxOctaves; ++i) {
         sum += o * 0.2f;
         o *= omega;

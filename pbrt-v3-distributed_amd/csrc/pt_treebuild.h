@@ -34,6 +34,11 @@ struct Box {
     }
 };
 struct Leaf { Box b; float c[3]; int32_t offset; uint16_t nPrims; };
+// joins its threads when the scope is left, also by an exception (bad_alloc in a split, a rethrown system_error): a joinable std::thread that is destroyed ends the process
+struct JoinAll {
+    std::vector<std::thread> th;
+    ~JoinAll() { for (auto &x : th) if (x.joinable()) x.join(); }
+};
 
 struct Builder {
     std::vector<Leaf> leaves;   // permuted in place by the build
@@ -47,15 +52,15 @@ struct Builder {
     template <class F> void parallelChunks(uint32_t a, uint32_t b, F f) const {
         const unsigned T = std::max(1u, nThreads);
         const uint32_t per = (b - a + T - 1) / T;
-        std::vector<std::thread> th;
+        JoinAll j;
+        j.th.reserve(T);
         for (unsigned t = 1; t < T; ++t) {
             const uint32_t c0 = std::min<uint64_t>(b, (uint64_t)a + (uint64_t)t * per), c1 = std::min<uint64_t>(b, (uint64_t)c0 + per);
             if (c0 >= c1) continue;
-            try { th.emplace_back([=]() { f(c0, c1, t); }); }
+            try { j.th.emplace_back([=]() { f(c0, c1, t); }); }
             catch (const std::system_error &) { f(c0, c1, t); }   // no thread to be had: the chunk on this one
         }
         f(a, std::min<uint64_t>(b, (uint64_t)a + per), 0u);
-        for (auto &x : th) x.join();
     }
 
     // nodes of the subtree over leaves [a, b) in DFS order (first child = this + 1): 2 (b - a) - 1 of them, starting at out[at]
@@ -82,10 +87,10 @@ struct Builder {
         bool forked = false;
         if (depthLeft > 0 && b - a > 65536) {   // the two halves in parallel near the top of the tree
             try {
-                std::thread t([=]() { build(a, mid, left, depthLeft - 1); });
+                JoinAll j;   //  joined also when the other half throws
+                j.th.emplace_back([=]() { build(a, mid, left, depthLeft - 1); });
                 forked = true;
                 build(mid, b, right, depthLeft - 1);
-                t.join();
             } catch (const std::system_error &) {   // no more threads to be had: this subtree serially
                 if (forked) throw;                  // (only the constructor throws before `forked`; anything later is not ours to swallow)
             }

@@ -459,7 +459,7 @@ void pbrtAreaLightSource(const std::string &name, const ParamSet &params) {
 void pbrtShape(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("Shape");
     if (curTransform.IsAnimated())
-        Warning("Animated shapes (TransformedPrimitive, primitive.cpp:76-96) are outside this path's scope; using the start transform");
+        Unsupported("Shape \"%s\" under an animated transformation (TransformedPrimitive with an AnimatedTransform, primitive.cpp:76-96, transform.h:412) has no counterpart on this path", name.c_str());
     std::shared_ptr<TriangleMesh> shape;
     std::shared_ptr<SphereShape> sphere;
     if (name == "sphere") {
@@ -578,10 +578,10 @@ void pbrtObjectInstance(const std::string &name) {
     if (it == renderOptions->instances.end()) { Error("Unable to find instance named \"%s\"", name.c_str()); return; }
     if (it->second.empty()) return;
     const Transform &i2w = curTransform[0];
+    if (curTransform.IsAnimated()) Unsupported("ObjectInstance \"%s\" under an animated transformation (primitive.cpp:76-96) has no counterpart on this path", name.c_str());
     if (g_twoLevelInstancing) {
         // The reference's structure (api.cpp:1555-1591): one BVHAccel per object (built at its first instantiation), one
         // TransformedPrimitive per ObjectInstance holding the CTM; bounds = PrimitiveToWorld(primitive->WorldBound()) (transform.cpp:141-153)
-        if (curTransform.IsAnimated()) Warning("Animated instance transforms are outside this path's scope; using the start transform");
         int oi;
         auto known = renderOptions->objectIndex.find(name);
         if (known == renderOptions->objectIndex.end()) {
@@ -770,7 +770,7 @@ void pbrtWorldEnd() {
         if (!film) Error("Unable to create film.");
         else if (renderOptions->CameraName == "perspective") {
             if (renderOptions->CameraToWorld.IsAnimated())
-                Warning("Animated camera transforms are outside this path's scope; using the start transform");
+                Unsupported("an animated camera transformation (camera.h:68, AnimatedTransform CameraToWorld) has no counterpart on this path");
             camera.reset(CreatePerspectiveCamera(renderOptions->CameraParams, renderOptions->CameraToWorld[0], film));
             renderOptions->CameraParams.ReportUnused();
         } else {
@@ -844,7 +844,10 @@ void pbrtWorldEnd() {
         std::shared_ptr<BVHAccel> accel;
         if (renderOptions->AcceleratorName == "bvh") accel = CreateBVHAccelerator(renderOptions->primitives, renderOptions->AcceleratorParams);
         else {
-            Warning("Accelerator \"%s\" is not on this path; using \"bvh\".", renderOptions->AcceleratorName.c_str());
+            // (the reference: "kdtree" builds a KdTreeAccel, any other name warns and falls back to "bvh", api.cpp:781-793)
+            if (renderOptions->AcceleratorName == "kdtree")
+                Unsupported("Accelerator \"kdtree\" has no counterpart on this path (another traversal order: other hits at equal distances); name \"bvh\"");
+            else Warning("Accelerator \"%s\" unknown.", renderOptions->AcceleratorName.c_str());
             accel = std::make_shared<BVHAccel>(renderOptions->primitives, 4, BVHAccel::SplitMethod::SAH);
         }
         renderOptions->AcceleratorParams.ReportUnused();

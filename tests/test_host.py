@@ -547,7 +547,10 @@ def test_spectrum_files(built, tmp_path):
 @pytest.mark.parametrize("edit", [('Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]', 'Shape "disk" "float radius" [1]'),
                                   ('WorldBegin\n', 'WorldBegin\nLightSource "projection" "rgb I" [1 1 1] "string mapname" "x.png"\n'),
                                   ('WorldBegin\n', 'Camera "orthographic"\nWorldBegin\n'),
-                                  ('WorldBegin\n', 'Integrator "bdpt"\nWorldBegin\n')])
+                                  ('WorldBegin\n', 'Integrator "bdpt"\nWorldBegin\n'),
+                                  ('WorldBegin\n', 'Accelerator "kdtree"\nWorldBegin\n'),
+                                  ('Shape "trianglemesh"', 'ActiveTransform EndTime\nTranslate 1 0 0\nActiveTransform All\nShape "trianglemesh"'),
+                                  ('WorldBegin\n', 'ActiveTransform EndTime\nTranslate 0 0 1\nActiveTransform All\nCamera "perspective"\nWorldBegin\n')])
 def test_scene_content_without_a_counterpart_is_refused_not_skipped(edit, tmp_path):
     """ADVICE r1 (plausible-but-wrong images): shapes / lights / cameras of the reference that this path does not carry used to be skipped
     with a warning, so the scene rendered without them.  Now the scene is refused: pbrt_amd_scene_load returns NULL and the command-line
