@@ -191,19 +191,32 @@ def valu_live(wl_args, pmc_steps=1):
     disp = collections.defaultdict(set)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Kernel_Name"].startswith("void k_trace<0, false"):
+            if row["Kernel_Name"].startswith("void k_trace<0, false") or row["Kernel_Name"].startswith("void k_shade<"):
                 agg[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[row["Kernel_Name"]].add(row["Dispatch_Id"])
     shutil.rmtree(d, ignore_errors=True)
-    if not agg:
+
+    def figures(prefix):
+        ks = [n for n in agg if n.startswith(prefix)]
+        if not ks:
+            return None
+        k = max(ks, key=lambda n: agg[n].get("SQ_INSTS_VALU", 0))
+        n = max(1, len(disp[k]))
+        c = {a: b / n for a, b in agg[k].items()}
+        if not c.get("SQ_ACTIVE_INST_VALU") or not c.get("SQ_WAVES"):
+            return None
+        return {"kernel": k.split("(")[0].replace("void ", ""), "launches_in_pass": n,
+                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "waves_per_launch": c["SQ_WAVES"], "lanes_active_per_valu_inst": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / c["SQ_ACTIVE_INST_VALU"], 2),
+                "valu_share_of_wave_lifetime": round(c["SQ_ACTIVE_INST_VALU"] / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4)}
+
+    res = figures("void k_trace<0, false")
+    if res is None:
         return None
-    k = max(agg, key=lambda n: agg[n].get("SQ_INSTS_VALU", 0))
-    n = max(1, len(disp[k]))
-    c = {a: b / n for a, b in agg[k].items()}
-    if not c.get("SQ_ACTIVE_INST_VALU") or not c.get("SQ_WAVES"):
-        return None
-    return {"valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "waves_per_launch": c["SQ_WAVES"], "lanes_active_per_valu_inst": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / c["SQ_ACTIVE_INST_VALU"], 2),
-            "valu_share_of_wave_lifetime": round(c["SQ_ACTIVE_INST_VALU"] / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4)}
+    res.pop("kernel"); res.pop("launches_in_pass")
+    shade = figures("void k_shade<")   # the same pass also saw the shading kernel: bench.py's roofline_shade
+    if shade:
+        res["_shade"] = shade
+    return res
 
 
 def secondary_line(extra):
@@ -567,6 +580,7 @@ def main():
         if args.max_paths:
             wl_args += ["--max-paths", str(args.max_paths)]
         traffic = None
+        roofline_shade = None
         if world == 1 and args.traffic == "live":
             traffic = traffic_live(wl_args, workload, 1 if args.config == "c5" else 2)
         if world == 1 and traffic is None and args.traffic in ("live", "file"):
@@ -632,8 +646,26 @@ def main():
                     vi["issue_frac"] = round(PROBE_MIX_CYCLES / vi["simd_cycles_per_valu_inst"], 4)
                     vi["note"] = ("SQ counters of a separate rocprofv3 --pmc pass of this workload; launch time from the unprofiled run x the clock measured inside the kernel; "
                                   "ceiling = tools/valu_probe2 kind 3 at 8 waves per SIMD (%.2f cycles per wave instruction; plain v_fma_f32 %.2f)" % (PROBE_MIX_CYCLES, PROBE_FMA_CYCLES))
+                    shade_sq = vi.pop("_shade", None)
                     roofline["valu_issue"] = vi
                     roofline["frac_valu_lane_throughput"] = round(vi["issue_frac"] * vi["lanes_active_per_valu_inst"] / 64.0, 4)
+                    # ... and the same figures for the shading kernel, from the same counter pass: k_shade has no memory roof worth the name (its
+                    # tables sit in the L2 / scalar cache); what bounds it is the rate at which its SIMDs issue VALU instructions, and how many lanes each one carries
+                    if shade_sq and timing.get("shade") and timing["shade"][1]:
+                        sh_ms = timing["shade"][0] / timing["shade"][1]          # live average launch time (HIP events on the ctx stream)
+                        sh_cycles = sh_ms * 1e-3 * clk_ghz * 1e9                  # (the clock measured inside the traversal launches of the same frame)
+                        per_simd_sh = shade_sq["valu_insts_per_launch"] / simds
+                        shade_sq["avg_launch_ms"] = round(sh_ms, 3)
+                        shade_sq["launches_per_step"] = timing["shade"][1] / args.steps
+                        shade_sq["simd_cycles_per_valu_inst"] = round(sh_cycles / per_simd_sh, 3)
+                        shade_sq["probe_cycles_per_valu_inst"] = PROBE_FMA_CYCLES   # a SIMD saturated with independent v_fma_f32 (tools/valu_probe2 kind 0): the arithmetic of shading is fma / mul / add
+                        shade_sq["issue_frac"] = round(PROBE_FMA_CYCLES / shade_sq["simd_cycles_per_valu_inst"], 4)
+                        shade_sq["frac_valu_lane_throughput"] = round(shade_sq["issue_frac"] * shade_sq["lanes_active_per_valu_inst"] / 64.0, 4)
+                        shade_sq["bound"] = "valu_issue"
+                        shade_sq["note"] = ("SQ counters of the same rocprofv3 --pmc pass as valu_issue; launch time live from this run; issue_frac = the measured issue rate of plain v_fma_f32 "
+                                            "(%.2f cycles per wave instruction per SIMD, profiles/r04_a_valu_probe2_issue_rate_and_clock.txt) / the SIMD cycles one VALU instruction of this kernel "
+                                            "costs, all stalls included; there is no HBM figure: the kernel's tables are L2 / scalar-cache resident" % PROBE_FMA_CYCLES)
+                        roofline_shade = shade_sq
             except Exception as e:   # measurement aid only
                 log("[bench] VALU issue figure not measured: %s" % e)
         # the three named fractions: SURVEY.md s.8(d)'s algorithmic bytes against the HBM peak (> 1: served by LDS / L2 / MALL, not an HBM
@@ -671,7 +703,7 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "tiles": "16x16, 2-D lattice over ranks (mi_tile_owner)", "parallelism": "tile-sharded x%d" % world},
                "mrays_per_s": round(mrays, 2), "rays_per_sample": round(samples[1] / max(1.0, samples[0]), 3),
-               "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
+               "roofline": roofline, "roofline_shade": roofline_shade, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
                "setup_s": {"parse_and_bvh_build": round(t_load, 2), "upload_and_bvh4": round(t_upload, 2),
                            "scene": "rank 0 of the node builds it once, the other ranks map the published blob" if world > 1 else "built"}}
         if world > 1:

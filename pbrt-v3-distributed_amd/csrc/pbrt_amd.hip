@@ -1202,8 +1202,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
                             PROBE(7)   // SampleLi
                             Float lightPdf = ls.pdf, scatteringPdf = 0;
                             if (lightPdf > 0 && !ls.Li.IsBlack()) {
-                                RGB f = bsdf.f(isect.wo, ls.wi, bsdfFlags) * AbsDot(ls.wi, isect.ns);
-                                scatteringPdf = bsdf.Pdf(isect.wo, ls.wi, bsdfFlags);
+                                RGB f = bsdf.fPdf(isect.wo, ls.wi, bsdfFlags, &scatteringPdf) * AbsDot(ls.wi, isect.ns);
                                 if (!f.IsBlack()) {
                                     RGB Ld;
                                     if (ls.delta) Ld = f * ls.Li / lightPdf;

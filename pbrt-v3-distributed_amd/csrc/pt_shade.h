@@ -308,9 +308,8 @@ template <bool U> PT_DEV void LoadBxdf(mi_bxdf &dst, const mi_bxdf *p) {
     else dst = *p;
 }
 PT_DEV const mi_bxdf *Generic(const mi_bxdf *b) { return b; }
-template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
-    mi_bxdf b;
-    LoadBxdf<U>(b, bp);
+// (round 6) the evaluation of a lobe whose record is already loaded: BxdfF_unscaled / BxdfPdf load and call these; BxdfFPdf loads ONCE and answers both
+template <bool U> PT_DEV RGB BxdfF_body(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     if constexpr (!U) {   // SeparableBSSRDFAdapter::f core/bssrdf.h:162-167 (TransportMode::Radiance): only per-lane lobe lists carry it (k_shade_vol)
         if (b.type == MI_BXDF_BSSRDF_ADAPTER) { RGB f(BssrdfSw(b.etaB, wi)); return f * (b.etaB * b.etaB); }
     }
@@ -373,13 +372,16 @@ template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo
     default: return RGB(0.f);   // specular lobes evaluate to zero
     }
 }
+template <bool U = true> PT_FN RGB BxdfF_unscaled(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+    mi_bxdf b;
+    LoadBxdf<U>(b, bp);
+    return BxdfF_body<U>(b, wo, wi);
+}
 template <bool U = true, class BP = BxdfConst> PT_DEV RGB BxdfF(BP b, const V3 &wo, const V3 &wi) {
     RGB f = BxdfF_unscaled<U>(Generic(b), wo, wi);
     return b->scaled ? RGB(b->scale[0], b->scale[1], b->scale[2]) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
 }
-template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
-    mi_bxdf b;
-    LoadBxdf<U>(b, bp);
+template <bool U> PT_DEV Float BxdfPdf_body(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     if constexpr (!U) { if (b.type == MI_BXDF_BSSRDF_ADAPTER) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0; }   // BxDF::Pdf reflection.cpp:387-389
     switch (b.type) {
     case MI_BXDF_LAMBERT_R: case MI_BXDF_OREN_NAYAR: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * PT_INV_PI : 0;   // :387-389
@@ -409,6 +411,27 @@ template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, con
     default: return 0;
     }
 }
+template <bool U = true> PT_FN Float BxdfPdf(const mi_bxdf *bp, const V3 wo, const V3 wi) {
+    mi_bxdf b;
+    LoadBxdf<U>(b, bp);
+    return BxdfPdf_body<U>(b, wo, wi);
+}
+// f (with the ScaledBxDF factor, as BxdfF) and / or Pdf of one lobe from ONE fetch of its record: want bit 0 = f, bit 1 = pdf.  The profile with sub-probes
+// (profiles/r06_g_*) prices every out-of-line question to a lobe -- one call + one fetch of the 100-byte record through the scalar cache -- at 2.5-6.5 k wave cycles;
+// BSDF::f + BSDF::Pdf of the light-sampling half and the pdf / f loops at the end of BSDF::Sample_f asked each lobe twice.
+struct BxdfFPdfR { RGB f; Float pdf; };
+template <bool U = true> PT_FN BxdfFPdfR BxdfFPdf(const mi_bxdf *bp, const V3 wo, const V3 wi, int want) {
+    mi_bxdf b;
+    LoadBxdf<U>(b, bp);
+    BxdfFPdfR r;
+    r.f = RGB(0.f); r.pdf = 0;
+    if (want & 2) r.pdf = BxdfPdf_body<U>(b, wo, wi);
+    if (want & 1) {
+        RGB f = BxdfF_body<U>(b, wo, wi);
+        r.f = b.scaled ? RGB(b.scale[0], b.scale[1], b.scale[2]) * f : f;   // ScaledBxDF::f reflection.cpp:97-99
+    }
+    return r;
+}
 // BxDF::Sample_f per lobe; *sampledType preset to the lobe's flags, FresnelSpecular narrows it
 struct BxdfSample { RGB f; V3 wi; Float pdf; int sampledType; };
 template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType);
@@ -418,16 +441,14 @@ template <bool U = true> PT_FN BxdfSample BxdfSample_f(const mi_bxdf *bp, const 
     r.f = BxdfSample_f_impl<U>(bp, wo, &r.wi, u0, u1, &r.pdf, &r.sampledType);
     return r;
 }
-// PT_SAMPLE_SKIP_F in *sampledType: the caller (BSDF::Sample_f) discards the f of a non-specular lobe -- it re-evaluates f over all matching
-// lobes afterwards (reflection.cpp:747-763) -- so the lobe's own f (one more D, G and Fresnel evaluation for the microfacet lobes) is not computed
-#define PT_SAMPLE_SKIP_F 0x100
 template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V3 *wi, Float u0, Float u1, Float *pdf, int *sampledType) {
     mi_bxdf b;
     LoadBxdf<U>(b, bp);
     PROBE(22)   // lobe sampling: record load
-    const bool needF = !(*sampledType & PT_SAMPLE_SKIP_F);
-    *sampledType &= ~PT_SAMPLE_SKIP_F;
     RGB f;
+    // (round 6) the lobe's generic Pdf / f are evaluated ONCE after the switch, on the record already loaded (rounds 1-5: BxdfPdf / BxdfF_unscaled calls per case, each
+    // fetching the record again)
+    bool gPdf = false, gF = false;
     if constexpr (!U) {
         if (b.type == MI_BXDF_BSSRDF_ADAPTER) {   // BxDF::Sample_f reflection.cpp:378-385
             *wi = CosineSampleHemisphere(u0, u1);
@@ -441,14 +462,12 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
         PROBE(23)   // lobe sampling (diffuse): cosine sample
-        *pdf = BxdfPdf<U>(bp, wo, *wi);
-        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
+        gPdf = true; gF = true;
         break;
     case MI_BXDF_LAMBERT_T:                            // :391-398
         *wi = CosineSampleHemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
-        *pdf = BxdfPdf<U>(bp, wo, *wi);
-        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
+        gPdf = true; gF = true;
         break;
     case MI_BXDF_SPECULAR_R:                           // :136-143
         *wi = V3(-wo.x, -wo.y, wo.z);
@@ -491,7 +510,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         *wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
-        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
+        gF = true;
         break;
     }
     case MI_BXDF_MICROFACET_T: {                       // :425-434
@@ -500,8 +519,7 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
         V3 wh = dist.Sample_wh(wo, u0, u1);
         Float eta = CosTheta(wo) > 0 ? (b.etaA / b.etaB) : (b.etaB / b.etaA);
         if (!Refract(wo, wh, eta, wi)) return RGB(0.f);
-        *pdf = BxdfPdf<U>(bp, wo, *wi);
-        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
+        gPdf = true; gF = true;
         break;
     }
     case MI_BXDF_FRESNEL_BLEND: {                      // :450-468
@@ -516,11 +534,12 @@ template <bool U> PT_DEV RGB BxdfSample_f_impl(const mi_bxdf *bp, const V3 wo, V
             *wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, *wi)) return RGB(0.f);
         }
-        *pdf = BxdfPdf<U>(bp, wo, *wi);
-        if (needF) f = BxdfF_unscaled<U>(bp, wo, *wi);
+        gPdf = true; gF = true;
         break;
     }
     }
+    if (gPdf) *pdf = BxdfPdf_body<U>(b, wo, *wi);
+    if (gF) f = BxdfF_body<U>(b, wo, *wi);
     return b.scaled ? rgb3(b.scale) * f : f;   // ScaledBxDF::Sample_f reflection.cpp:101-106
 }
 
@@ -584,6 +603,29 @@ template <bool U> struct BSDF_T {
             if (Matches(BxdfFlags(LobeType(i)), flags)) { ++matchingComps; pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi); }
         return matchingComps > 0 ? pdf / matchingComps : 0.f;
     }
+    // BSDF::f and BSDF::Pdf for the same pair of directions (the light-sampling half of EstimateDirect, integrator.cpp:134-137): the two loops above as one, every
+    // matching lobe asked once (BxdfFPdf).  Same terms added in the same (index) order.
+    PT_DEV RGB fPdf(const V3 &woW, const V3 &wiW, int flags, Float *pdfOut) const {
+        *pdfOut = 0.f;
+        V3 wi = WorldToLocal(wiW), wo = WorldToLocal(woW);
+        if (wo.z == 0) return RGB(0.f);
+        bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
+        RGB f(0.f);
+        Float pdf = 0.f;
+        int matchingComps = 0;
+        for (int i = 0; i < nb; ++i) {
+            int t = BxdfFlags(LobeType(i));
+            if (!Matches(t, flags)) continue;
+            ++matchingComps;
+            const bool wantF = (reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION));
+            BxdfFPdfR r = BxdfFPdf<U>(Generic(&m->bxdfs[i]), wo, wi, wantF ? 3 : 2);
+            pdf += r.pdf;
+            if (wantF) f = f + r.f;
+        }
+        *pdfOut = matchingComps > 0 ? pdf / matchingComps : 0.f;
+        PROBE(20)   // BSDF::f + Pdf (NEE)
+        return f;
+    }
     PT_DEV RGB Sample_f(const V3 &woWorld, V3 *wiWorld, Float u0, Float u1, Float *pdf, int type, int *sampledType) const {   // reflection.cpp:703-768
         int matchingComps = NumComponents(type);
         if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return RGB(0.f); }
@@ -605,26 +647,30 @@ template <bool U> struct BSDF_T {
         for (int i = 0; i < nb; ++i)
             if (chosen == i) {
                 bt = BxdfFlags(LobeType(i));
-                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, (bt & BSDF_SPECULAR) ? bt : (bt | PT_SAMPLE_SKIP_F));
+                BxdfSample bs = BxdfSample_f<U>(Generic(&m->bxdfs[i]), wo, ur0, u1, bt);   // with the lobe's own f: it is the chosen lobe's term of the sum below (same routine, same wo / wi)
                 f = bs.f; wi = bs.wi; *pdf = bs.pdf; *sampledType = bs.sampledType;
             }
         PROBE(17)   // Sample_f: the chosen lobe's sampling routine
         if (*pdf == 0) { *sampledType = 0; return RGB(0.f); }
         *wiWorld = LocalToWorld(wi);
-        if (!(bt & BSDF_SPECULAR) && matchingComps > 1)
-            for (int i = 0; i < nb; ++i)
-                if (i != chosen && Matches(BxdfFlags(LobeType(i)), type)) *pdf += BxdfPdf<U>(Generic(&m->bxdfs[i]), wo, wi);
-        if (matchingComps > 1) *pdf /= matchingComps;
-        PROBE(18)   // Sample_f: the other lobes' pdfs
+        // reflection.cpp:739-763: the pdfs of the other matching lobes, then f over all matching lobes -- one pass, every lobe asked once for what is wanted of it
         if (!(bt & BSDF_SPECULAR)) {
             bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
+            const RGB fChosen = f;
             f = RGB(0.f);
             for (int i = 0; i < nb; ++i) {
-                auto b = &m->bxdfs[i];
                 int t = BxdfFlags(LobeType(i));
-                if (Matches(t, type) && ((reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION)))) f = f + BxdfF<U>(b, wo, wi);
+                if (!Matches(t, type)) continue;
+                const bool wantPdf = matchingComps > 1 && i != chosen;
+                const bool wantF = (reflect && (t & BSDF_REFLECTION)) || (!reflect && (t & BSDF_TRANSMISSION));
+                if (i == chosen) { if (wantF) f = f + fChosen; continue; }   // at its place in the index order
+                if (!wantPdf && !wantF) continue;
+                BxdfFPdfR r = BxdfFPdf<U>(Generic(&m->bxdfs[i]), wo, wi, (wantF ? 1 : 0) | (wantPdf ? 2 : 0));
+                if (wantPdf) *pdf += r.pdf;
+                if (wantF) f = f + r.f;
             }
         }
+        if (matchingComps > 1) *pdf /= matchingComps;
         PROBE(19)   // Sample_f: f over the matching lobes
         return f;
     }
