@@ -304,7 +304,9 @@ template <int D, bool U> __device__ __noinline__ void MaterialEvalD<D, U>::eval(
         }
         return;
     }
+    PROBE(14)   // (profiler builds) k_shade<TEX>: up to here = differentials + the descriptor fetch
     if (md->bump >= 0) BumpT<U>(md->bump, si, x);
+    PROBE(21)   // Material::Bump (three evaluations of the displacement texture)
     const TexCtx tc = TexCtxOf(*si, *x);
     const bool remap = md->remap_roughness != 0;
     switch (md->type) {

@@ -14,7 +14,8 @@ SCENES = ["cornell.pbrt", "materials.pbrt"]
 # every traversal kernel instance the library ships runs the parity tests (the variables are read by mi_scene_upload):
 # traversal layouts that ship: bvh4q = the default (64-byte quantised BVH4 over the library's own topology of the reference's leaves, hot nodes in LDS); general = full-precision
 # 128-byte nodes; bvh4q-cold = reference node order, nothing in LDS, AND the reference's own interior nodes (PBRT_AMD_TREE=reference: the tree exactly as handed over)
-TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0", "PBRT_AMD_TREE": "reference"}}
+#  bvh4q-reftree = the reference's own interior nodes WITH hot nodes in LDS, the combination bvh4q-cold left out
+TRACE_MODES = {"bvh4q": {}, "general": {"PBRT_AMD_TRACE": "general"}, "bvh4q-cold": {"PBRT_AMD_HOT": "0", "PBRT_AMD_TREE": "reference"}, "bvh4q-reftree": {"PBRT_AMD_TREE": "reference"}}
 
 
 def _report(key, **values):
