@@ -57,12 +57,12 @@ def torch_is_warm():
     w = getattr(conftest, "TORCH_WARMUP", None)
     if w is None:
         w = subprocess.Popen([sys.executable, "-c", conftest.TORCH_WARMUP_CODE], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-    rc = _end(w, 900)
+    rc = _end(w, 480)   # (the session's limit on the driver's box is 1200 s for the whole suite: 480 s here + the warm-up's head start of the two hundred tests before it)
     print("[multirank] torch warm-up: rc %s, waited %.0f s" % (rc, time.time() - t0))
     yield
 
 
-def run_job(args, tmp_path, limit_s=420, extra_env=None):
+def run_job(args, tmp_path, limit_s=300, extra_env=None):
     """`python bench.py args` in its own process group, stderr to a file; (rc, stdout, stderr) -- rc None = stopped at the limit"""
     import time
     env = dict(os.environ, PBRT_AMD_BENCH_DIR=str(tmp_path), PBRT_AMD_BENCH_STACKS_S="60", PBRT_AMD_BENCH_WAIT_S="180", PBRT_AMD_PG_TIMEOUT_S="180")
