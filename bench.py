@@ -392,7 +392,16 @@ def main():
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
         # same launch line the driver uses) and hand their exit code back; rank 0 of the child job prints the JSON line
         par0 = importlib.import_module("pbrt-v3-distributed_amd.parallel")
-        raise SystemExit(par0.launch_ranks(args.gpus, __file__, sys.argv[1:]))
+
+        def sweep(launcher_pid):   # whatever node_scene left under this job's name (a '.failed' note for ranks that were still waiting, a blob of a job that was killed)
+            import glob
+            for d in {os.environ.get("PBRT_AMD_BLOB_DIR") or "/dev/shm", os.environ.get("PBRT_AMD_BENCH_DIR", "/tmp/pbrt_amd_bench")}:
+                for f in glob.glob(os.path.join(d, "pbrt_amd_scene_%d.blob*" % launcher_pid)):
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
+        raise SystemExit(par0.launch_ranks(args.gpus, __file__, sys.argv[1:], after=sweep))
     if args.config == "c5":   # configs[4]: the C3 scene at 4K / 512 spp
         if args.res == [1920, 1080]:
             args.res = [3840, 2160]

@@ -994,7 +994,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_spatial_guide(uint32_t nvox, uint3
     }
 }
 
-#define PT_CNT_ALLOC 72
+#define PT_CNT_ALLOC 96
 
 // ---- shading: one path vertex per lane, lanes of a wave share a material (sorted queue)
 #ifndef PT_CDF_LDS
@@ -1022,7 +1022,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     __shared__ float s_cdf[PT_CDF_LDS];
     if constexpr (TEX) NoiseLdsInit();   // procedural textures / bump maps: the noise table of pt_texture.h in LDS
 #if PT_SHADE_PROF
-    if ((threadIdx.x & 63) < 24) { s_pacc[threadIdx.x >> 6][threadIdx.x & 63] = 0; s_pcnt[threadIdx.x >> 6][threadIdx.x & 63] = 0; }
+    if ((threadIdx.x & 63) < 24) { s_pacc[threadIdx.x >> 6][threadIdx.x & 63] = 0; s_pcnt[threadIdx.x >> 6][threadIdx.x & 63] = 0; s_plan[threadIdx.x >> 6][threadIdx.x & 63] = 0; }
     if ((threadIdx.x & 63) == 0) s_prof[threadIdx.x >> 6] = clock64();
 #endif
     const bool cdfInLds = sc.n_lights + 1 <= PT_CDF_LDS;
@@ -1305,6 +1305,7 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
     if ((threadIdx.x & 63) < 24 && s_pcnt[threadIdx.x >> 6][threadIdx.x & 63]) {
         atomicAdd(&ps.counters[16 + (threadIdx.x & 63)], s_pacc[threadIdx.x >> 6][threadIdx.x & 63]);
         atomicAdd(&ps.counters[40 + (threadIdx.x & 63)], s_pcnt[threadIdx.x >> 6][threadIdx.x & 63]);
+        atomicAdd(&ps.counters[68 + (threadIdx.x & 63)], s_plan[threadIdx.x >> 6][threadIdx.x & 63]);
     }
 #endif
 }
@@ -3384,8 +3385,8 @@ int mi_counters(mi_ctx *c, uint64_t out[MI_CNT_COUNT]) {
         HIP_TRY(hipMemcpyAsync(all, c->counters.p, sizeof(all), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 24; ++k)
-            if (all[40 + k]) fprintf(stderr, "[shade-prof] phase %2d: visits %12llu  cycles/visit %10.1f  total Gcycles %8.3f\n", k,
-                                     (unsigned long long)all[40 + k], (double)all[16 + k] / (double)all[40 + k], (double)all[16 + k] * 1e-9);
+            if (all[40 + k]) fprintf(stderr, "[shade-prof] phase %2d: visits %12llu  cycles/visit %10.1f  lanes %5.1f  total Gcycles %8.3f\n", k,
+                                     (unsigned long long)all[40 + k], (double)all[16 + k] / (double)all[40 + k], (double)all[68 + k] / (double)all[40 + k], (double)all[16 + k] * 1e-9);
     }
 #endif
     HIP_TRY(hipStreamSynchronize(c->stream));

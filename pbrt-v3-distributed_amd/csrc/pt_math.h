@@ -17,7 +17,7 @@
 #endif
 #if PT_SHADE_PROF
 __shared__ long long s_prof[4];
-__shared__ unsigned long long s_pacc[4][24], s_pcnt[4][24];
+__shared__ unsigned long long s_pacc[4][24], s_pcnt[4][24], s_plan[4][24];   // cycles, visits, active lanes at the probe
 #define PROBE(k)                                                                                     \
     {                                                                                                \
         __builtin_amdgcn_s_waitcnt(0);                                                               \
@@ -26,6 +26,7 @@ __shared__ unsigned long long s_pacc[4][24], s_pcnt[4][24];
             long long now_ = clock64();                                                              \
             s_pacc[(threadIdx.x >> 6) & 3][(k)] += (unsigned long long)(now_ - s_prof[(threadIdx.x >> 6) & 3]);  \
             s_pcnt[(threadIdx.x >> 6) & 3][(k)] += 1ull;                                             \
+            s_plan[(threadIdx.x >> 6) & 3][(k)] += (unsigned long long)__popcll(pm_);                \
             s_prof[(threadIdx.x >> 6) & 3] = now_;                                                   \
         }                                                                                            \
     }

@@ -256,12 +256,13 @@ def die_with_parent(sig=None):
         pass
 
 
-def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
+def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None, after=None):
     """Start `script argv` as n_ranks processes of ONE node under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1 with a free port -- the launch line the round driver uses) and return the job's exit code.  Used by
     `python bench.py --gpus N` when it was not started by a launcher itself.  The job runs in its own session (process group): at `timeout_s`
     ($PBRT_AMD_LAUNCH_TIMEOUT_S, default none), on SIGTERM / SIGINT to this process and on any exit of this function the WHOLE group is killed, so no rank
-    outlives its launcher on the GPU (a timed-out job left two ranks behind and the next process waited 171 s for the device)."""
+    outlives its launcher on the GPU (a timed-out job left two ranks behind and the next process waited 171 s for the device).  `after(pid)` is called
+    with the launcher's pid (= the ranks' parent) once the job is gone, whatever ended it -- bench.py removes what node_scene left under that pid there."""
     import os, signal, socket, subprocess, sys
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -317,6 +318,11 @@ def launch_ranks(n_ranks, script, argv, backend_env=None, timeout_s=None):
             pass
         for sg, h in saved.items():
             signal.signal(sg, h)
+        if after is not None:
+            try:
+                after(p.pid)
+            except Exception:
+                pass
 
 
 class ShardedFrame:

@@ -138,6 +138,7 @@ def test_a_cut_off_scene_file_fails_both_ranks_loudly(tmp_path):
     assert not [l for l in out.splitlines() if l.startswith("{")]
     assert "Unable to read the contents of PLY file" in err and "strict mode" in err, err[-3000:]
     assert "Traceback" in err and "timed out" not in err
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("pbrt_amd_scene_") and f.endswith(".failed")], "the failed job left its note behind"
 
 
 def _run_script(code, tmp_path, limit_s=240):
