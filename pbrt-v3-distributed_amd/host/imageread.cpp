@@ -4,7 +4,7 @@
 // (the reference goes through lodepng_decode24_file: any colour type / bit depth -> 8-bit RGB, 16-bit samples keep
 // their high byte, alpha is dropped); TGA covers the uncompressed / RLE, true-colour / mono / colour-mapped variants
 // the reference's targa.c reads.  OpenEXR is absent from this image (and from oracle/_ref): ".exr" goes through a reader written
-// from the format specification (scan-line files, NONE / RLE / ZIPS / ZIP), unpinned against the reference (see DecodeEXR).
+// from the format specification (scan-line files, NONE / RLE / ZIPS / ZIP), pinned on one uncompressed file written by OpenEXR itself (tests/golden/openexr_written_16x16_rgba_half.exr), otherwise against files assembled from the specification (see DecodeEXR).
 #include <zlib.h>
 
 #include <cstdio>

@@ -465,9 +465,9 @@ def _exr_bytes(chans, w, h, compression, line_order=0, y_origin=3, x_origin=2):
 @pytest.mark.parametrize("compression", [0, 1, 2, 3])
 def test_exr_reader(built, tmp_path, compression):
     """scan-line OpenEXR input (radiance maps / textures of the public scenes): NONE / RLE / ZIPS / ZIP, half and float channels,
-    RGBA and luminance-only files, both line orders, a data window that does not start at (0,0).  Unpinned against the reference
-    (no OpenEXR library in this image): checked against files assembled here from the format specification and against this host's
-    own EXR writer."""
+    RGBA and luminance-only files, both line orders, a data window that does not start at (0,0).  No OpenEXR library in this image: checked
+    against files assembled here from the format specification and against this host's own EXR writer (the uncompressed layout is pinned on a file
+    OpenEXR wrote: test_exr_reader_on_a_file_written_by_openexr)."""
     rng = np.random.default_rng(compression)
     w, h = 21, 37
     R, G, B = [(rng.random((h, w)) * 4).astype(np.float32) for _ in range(3)]
@@ -623,3 +623,40 @@ def test_a_cut_off_ply_file_is_an_error_never_a_smaller_mesh(built, tmp_path, ke
     assert sc.errors >= 1 and sc.info["n_tris"] == 1   # the reference's behaviour: an Error, the shape dropped, the rest of the scene kept
     with pytest.raises(RuntimeError, match="strict mode"):
         ol.pa.Scene(text=text, strict=True)
+
+
+def test_exr_reader_on_a_file_written_by_openexr(built):
+    """The one pin of the EXR reader against the real library that this image allows: tests/golden/openexr_written_16x16_rgba_half.exr is a file WRITTEN BY OpenEXR (CPython's
+    Lib/test/imghdrdata/python.exr, 16 x 16, channels A B G R as half, no compression, increasing y; copied as data) -- its header attributes, offset table and scan-line blocks are
+    OpenEXR's own, not this repository's idea of them.  Decoded here independently with numpy (the format's uncompressed layout: per scan line the channels in alphabetical order, each
+    a row of little-endian halfs) and compared with the host reader's result, bit for bit.  PIZ / tiled files: still refused (no writer of them anywhere in the image)."""
+    import struct
+    path = os.path.join(ROOT, "tests", "golden", "openexr_written_16x16_rgba_half.exr")
+    d = open(path, "rb").read()
+    assert d[:4] == bytes([0x76, 0x2F, 0x31, 0x01])
+    i, attrs = 8, {}
+    while d[i] != 0:
+        j = d.index(b"\0", i); k = d.index(b"\0", j + 1)
+        size = struct.unpack("<i", d[k + 1:k + 5])[0]
+        attrs[d[i:j].decode()] = (d[j + 1:k].decode(), d[k + 5:k + 5 + size])
+        i = k + 5 + size
+    i += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, c = [], attrs["channels"][1]
+    p = 0
+    while c[p] != 0:
+        q = c.index(b"\0", p)
+        chans.append((c[p:q].decode(), struct.unpack("<i", c[q + 1:q + 5])[0]))
+        p = q + 17
+    assert [n for n, _ in chans] == ["A", "B", "G", "R"] and all(t == 1 for _, t in chans) and (w, h) == (16, 16)
+    offsets = struct.unpack("<%dQ" % h, d[i:i + 8 * h])
+    want = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        yy, size = struct.unpack("<ii", d[offsets[y]:offsets[y] + 8])
+        row = np.frombuffer(d[offsets[y] + 8:offsets[y] + 8 + size], "<f2").reshape(4, w).astype(np.float32)   # A, B, G, R
+        want[yy - y0] = np.stack([row[3], row[2], row[1]], -1)
+    got = pa.read_image(path)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert want.max() > 0.5 and len(np.unique(want)) > 20   # a picture, not a constant
