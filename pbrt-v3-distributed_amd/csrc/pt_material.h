@@ -246,6 +246,11 @@ PT_DEV void Set3(float *d, const RGB &c) { d[0] = c.r; d[1] = c.g; d[2] = c.b; }
 PT_DEV mi_bxdf *AddLobe(mi_material *m, int type) {
     int i = m->n_bxdfs < MI_MAX_BXDFS ? m->n_bxdfs++ : MI_MAX_BXDFS - 1;
     mi_bxdf *b = &m->bxdfs[i];
+#if defined(PT_HOST_EMU) && PT_HOST_EMU
+    //  emulator builds poison the record: a reader of a word its lobe kind never set sees a signalling pattern (NaN as a float, a huge index as an
+    // integer) instead of whatever the stack held, so the emulator's fixture tests fail on it -- the device build leaves the unread words alone
+    __builtin_memset(b, 0xff, sizeof(*b));
+#endif
     // the header words every consumer reads; the parameters a lobe kind reads are written by the code that adds it, the others are never looked at (a ScaledBxDF's
     // scale is set where `scaled` is).  Rounds 1-4 zero-filled all 25 words of the record in private memory per lobe and hit.
     b->type = type; b->fresnel = 0; b->scaled = 0; b->distrib = 0;
