@@ -4,7 +4,7 @@
 // (the reference goes through lodepng_decode24_file: any colour type / bit depth -> 8-bit RGB, 16-bit samples keep
 // their high byte, alpha is dropped); TGA covers the uncompressed / RLE, true-colour / mono / colour-mapped variants
 // the reference's targa.c reads.  OpenEXR is absent from this image (and from oracle/_ref): ".exr" goes through a reader written
-// from the format specification (scan-line files, NONE / RLE / ZIPS / ZIP), pinned on one uncompressed file written by OpenEXR itself (tests/golden/openexr_written_16x16_rgba_half.exr), otherwise against files assembled from the specification (see DecodeEXR).
+// from the format specification (scan-line and tiled files, NONE / RLE / ZIPS / ZIP / PIZ / PXR24), pinned on one uncompressed file written by OpenEXR itself (tests/golden/openexr_written_16x16_rgba_half.exr), otherwise against files assembled from the specification (see DecodeEXR).
 #include <zlib.h>
 
 #include <cstdio>
@@ -168,11 +168,11 @@ bool DecodeTGA(const std::string &name, std::vector<Float> *out, int *w, int *h)
     return true;
 }
 
-// ---- OpenEXR 2 (single-part scan-line files; compression NONE / RLE / ZIPS / ZIP; HALF / FLOAT / UINT channels R G B or Y).
+// ---- OpenEXR 2 (single-part scan-line and tiled files -- level (0, 0) of the latter; compression NONE / RLE / ZIPS / ZIP / PIZ / PXR24; HALF / FLOAT / UINT channels R G B or Y).
 // The reference reads EXR through the OpenEXR library (imageio.cpp:124-161, Imf::RgbaInputFile); that library is not in this image
 // (nor in oracle/_ref, which therefore cannot read EXR either), so this reader is written from the file-format specification and is
 // UNPINNED against the reference: tests/test_host.py checks it against files assembled independently in Python and against this
-// host's own writer.  PIZ / PXR24 / B44 / DWA compression and tiled or multi-part files are reported as unsupported.
+// host's own writer.  B44 / DWA compression and multi-part or deep files are reported as unsupported.
 float HalfToFloat(uint16_t hbits) {
     uint32_t sign = (uint32_t)(hbits >> 15) << 31, e = (hbits >> 10) & 31, m = hbits & 1023;
     uint32_t out;
@@ -189,13 +189,246 @@ float HalfToFloat(uint16_t hbits) {
     std::memcpy(&f, &out, 4);
     return f;
 }
+// ---- PIZ blocks (OpenEXR's ImfPizCompressor: a 16-bit value-range LUT, a 2-D Haar-like wavelet per channel, Huffman coding with one run-length
+// symbol), restated from the published description of the format (OpenEXR "Technical Introduction" + the layout the library documents in
+// ImfPizCompressor.cpp / ImfHuf.cpp / ImfWav.cpp's header comments).  Round 6: most published pbrt-v3 radiance maps are PIZ files.  UNPINNED against the
+// library (none here, no PIZ file in this image): tests/test_host.py checks it against blocks encoded by a Python restatement of the
+// ENCODING side (forward LUT, wenc14 / wenc16, code-table packing, run-length symbol) -- two independent restatements that must invert each other.
+// Every read is bounds-checked; malformed data is an error, never an image.
+struct PizChan { int nx, ny, size; size_t start; };   // size: 16-bit words per sample (HALF 1, FLOAT / UINT 2)
+namespace piz {
+constexpr int ENCSIZE = (1 << 16) + 1, DECBITS = 14, DECSIZE = 1 << DECBITS, DECMASK = DECSIZE - 1;
+constexpr int SHORT_ZEROCODE_RUN = 59, LONG_ZEROCODE_RUN = 63, SHORTEST_LONG_RUN = 2 + LONG_ZEROCODE_RUN - SHORT_ZEROCODE_RUN;
+struct Bits {   // most significant bit first
+    const uint8_t *in, *end;
+    uint64_t c = 0; int lc = 0; bool overrun = false;
+    void byte() { uint8_t b = 0; if (in < end) b = *in; else overrun = true; ++in; c = (c << 8) | b; lc += 8; }
+    uint32_t get(int n) { while (lc < n) byte(); lc -= n; return (uint32_t)((c >> lc) & ((1ull << n) - 1)); }
+};
+// code lengths (6 bits each; 59..62 = 2..5 zero lengths, 63 + 8 bits = 6..261 zero lengths) for symbols im..iM -> canonical codes, longest codes first
+bool UnpackTable(Bits &b, int im, int iM, std::vector<uint64_t> &h) {
+    h.assign(ENCSIZE, 0);
+    for (; im <= iM; ++im) {
+        uint32_t l = b.get(6);
+        if (b.overrun) return false;
+        h[im] = l;
+        if (l == (uint32_t)LONG_ZEROCODE_RUN || l >= (uint32_t)SHORT_ZEROCODE_RUN) {
+            int zerun = l == (uint32_t)LONG_ZEROCODE_RUN ? (int)b.get(8) + SHORTEST_LONG_RUN : (int)l - SHORT_ZEROCODE_RUN + 2;
+            if (b.overrun || im + zerun > iM + 1) return false;
+            while (zerun--) h[im++] = 0;
+            --im;
+        }
+    }
+    uint64_t n[59] = {0};
+    for (int i = 0; i < ENCSIZE; ++i) n[h[i]] += 1;
+    uint64_t c = 0;
+    for (int i = 58; i > 0; --i) { uint64_t nc = (c + n[i]) >> 1; n[i] = c; c = nc; }
+    for (int i = 0; i < ENCSIZE; ++i) { int l = (int)h[i]; if (l > 0) h[i] = (uint64_t)l | (n[l]++ << 6); }
+    return true;
+}
+struct Dec { uint8_t len = 0; uint32_t lit = 0; int longs = -1; };   // primary table entry: a short code (len, symbol) or the list of long codes that share these 14 bits
+bool Decode(const uint8_t *src, size_t nSrc, uint16_t *out, size_t nOut) {
+    if (nSrc == 0) return nOut == 0;
+    if (nSrc < 20) return false;
+    auto u32 = [&](size_t at) { return (uint32_t)src[at] | ((uint32_t)src[at + 1] << 8) | ((uint32_t)src[at + 2] << 16) | ((uint32_t)src[at + 3] << 24); };
+    const uint32_t im = u32(0), iM = u32(4), nBits = u32(12);   // (bytes 8..11: the table's packed length, 16..19: reserved)
+    if (im >= (uint32_t)ENCSIZE || iM >= (uint32_t)ENCSIZE) return false;
+    Bits tb{src + 20, src + nSrc};
+    std::vector<uint64_t> h;
+    if (!UnpackTable(tb, (int)im, (int)iM, h)) return false;
+    const uint8_t *data = tb.in;   // the table ends at a byte boundary of its own reader: what it has buffered beyond is dropped
+    if (data > src + nSrc || (uint64_t)nBits > 8ull * (uint64_t)(src + nSrc - data)) return false;
+    std::vector<Dec> dec(DECSIZE);
+    std::vector<std::vector<int>> longs;
+    for (uint32_t s = im; s <= iM; ++s) {
+        const uint64_t c = h[s] >> 6;
+        const int l = (int)(h[s] & 63);
+        if (l == 0) continue;
+        if (c >> l) return false;
+        if (l > DECBITS) {
+            Dec &d = dec[c >> (l - DECBITS)];
+            if (d.len) return false;
+            if (d.longs < 0) { d.longs = (int)longs.size(); longs.emplace_back(); }
+            longs[d.longs].push_back((int)s);
+        } else {
+            Dec *d = &dec[c << (DECBITS - l)];
+            for (uint64_t i = 1ull << (DECBITS - l); i > 0; --i, ++d) {
+                if (d->len || d->longs >= 0) return false;
+                d->len = (uint8_t)l; d->lit = s;
+            }
+        }
+    }
+    Bits b{data, data + (nBits + 7) / 8};
+    size_t o = 0;
+    const uint32_t rlc = iM;   // the run-length symbol: followed by 8 bits = how often the previous value repeats
+    auto emit = [&](uint32_t sym) -> bool {
+        if (sym == rlc) {
+            if (b.lc < 8) { if (b.in >= src + nSrc) return false; b.end = std::max(b.end, b.in + 1); b.byte(); }
+            b.lc -= 8;
+            uint32_t cs = (uint32_t)(b.c >> b.lc) & 0xff;
+            if (o == 0 || o + cs > nOut) return false;
+            const uint16_t v = out[o - 1];
+            while (cs--) out[o++] = v;
+            return true;
+        }
+        if (o >= nOut) return false;
+        out[o++] = (uint16_t)sym;
+        return true;
+    };
+    const uint8_t *ie = b.end;
+    while (b.in < ie) {
+        b.byte();
+        while (b.lc >= DECBITS) {
+            const Dec &d = dec[(b.c >> (b.lc - DECBITS)) & DECMASK];
+            if (d.len) { b.lc -= d.len; if (!emit(d.lit)) return false; }
+            else {
+                if (d.longs < 0) return false;
+                bool found = false;
+                for (int s : longs[d.longs]) {
+                    const int l = (int)(h[s] & 63);
+                    while (b.lc < l && b.in < ie) b.byte();
+                    if (b.lc >= l && (h[s] >> 6) == ((b.c >> (b.lc - l)) & ((1ull << l) - 1))) { b.lc -= l; if (!emit((uint32_t)s)) return false; found = true; break; }
+                }
+                if (!found) return false;
+            }
+        }
+    }
+    const int pad = (8 - (int)nBits) & 7;   // the bits of the last byte beyond nBits
+    b.c >>= pad; b.lc -= pad;
+    while (b.lc > 0) {
+        const Dec &d = dec[(b.c << (DECBITS - b.lc)) & DECMASK];
+        if (!d.len || d.len > b.lc) return false;
+        b.lc -= d.len;
+        if (!emit(d.lit)) return false;
+    }
+    return o == nOut;
+}
+// the inverse of the 2-D wavelet: one level = 2 x 2 butterflies, coarsest level first; 14-bit data (max value < 2^14) in plain signed arithmetic, 16-bit data modulo 2^16
+inline void wdec14(uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) {
+    const int ls = (int16_t)l, hi = (int16_t)hh;
+    const int ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t)(int16_t)ai; b = (uint16_t)(int16_t)(ai - hi);
+}
+inline void wdec16(uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) {
+    const int m = l, d = hh;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    const int aa = (d + bb - 0x8000) & 0xffff;
+    b = (uint16_t)bb; a = (uint16_t)aa;
+}
+void WavDecode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) { if (w14) wdec14(l, hh, a, b); else wdec16(l, hh, a, b); };
+    while (p >= 1) {
+        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {   // an odd column at this level: the vertical butterfly alone
+                uint16_t *p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {   // an odd row: the horizontal butterflies alone
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+}  // namespace piz
+// one PIZ block -> the block's scan lines in the uncompressed layout (per line: channel after channel); chans[] carries nx / ny / size of this block
+bool PizBlock(const uint8_t *src, size_t n, std::vector<PizChan> &chans, int nLines, uint8_t *dst, size_t raw) {
+    size_t total = 0;
+    for (PizChan &c : chans) { c.start = total; total += (size_t)c.nx * c.ny * c.size; }
+    if (total * 2 != raw || n < 4) return false;
+    const uint32_t minNonZero = src[0] | (src[1] << 8), maxNonZero = src[2] | (src[3] << 8);
+    constexpr uint32_t BITMAP = 8192;
+    if (maxNonZero >= BITMAP) return false;
+    std::vector<uint8_t> bitmap(BITMAP, 0);
+    size_t p = 4;
+    if (minNonZero <= maxNonZero) {
+        const size_t nb = maxNonZero - minNonZero + 1;
+        if (p + nb > n) return false;
+        std::memcpy(&bitmap[minNonZero], src + p, nb);
+        p += nb;
+    }
+    std::vector<uint16_t> lut(65536, 0);   // k-th value present in the block -> the value (0 is always present)
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; ++i) if (i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t maxValue = (uint16_t)(k - 1);
+    if (p + 4 > n) return false;
+    const uint32_t length = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16) | ((uint32_t)src[p + 3] << 24);
+    p += 4;
+    if (length > n - p) return false;
+    std::vector<uint16_t> tmp(total);
+    if (!piz::Decode(src + p, length, tmp.data(), total)) return false;
+    for (const PizChan &c : chans)
+        for (int j = 0; j < c.size; ++j) piz::WavDecode(tmp.data() + c.start + j, c.nx, c.size, c.ny, c.nx * c.size, maxValue);
+    for (uint16_t &v : tmp) v = lut[v];
+    std::vector<size_t> at(chans.size());
+    for (size_t c = 0; c < chans.size(); ++c) at[c] = chans[c].start;
+    size_t o = 0;
+    for (int y = 0; y < nLines; ++y)
+        for (size_t c = 0; c < chans.size(); ++c) {
+            const size_t cnt = (size_t)chans[c].nx * chans[c].size;
+            for (size_t i = 0; i < cnt; ++i) { const uint16_t v = tmp[at[c] + i]; dst[o++] = (uint8_t)(v & 0xff); dst[o++] = (uint8_t)(v >> 8); }
+            at[c] += cnt;
+        }
+    return o == raw;
+}
+// ---- PXR24 blocks (ImfPxr24Compressor): inflate, then per line and channel 2 (HALF) / 3 (FLOAT: the low 8 mantissa bits were dropped by the writer) / 4 (UINT) byte planes,
+// most significant first, each sample a running sum of differences.  types[]: 0 UINT, 1 HALF, 2 FLOAT
+bool Pxr24Block(const uint8_t *src, size_t n, const std::vector<int> &types, int width, int nLines, uint8_t *dst, size_t raw) {
+    size_t need = 0;
+    for (int t : types) need += (size_t)width * (t == 1 ? 2 : (t == 2 ? 3 : 4));
+    need *= nLines;
+    std::vector<uint8_t> tmp(need);
+    uLongf got = (uLongf)need;
+    if (uncompress(tmp.data(), &got, src, (uLong)n) != Z_OK || got != need) return false;
+    const uint8_t *t = tmp.data();
+    size_t o = 0;
+    for (int y = 0; y < nLines; ++y)
+        for (int ty : types) {
+            const int planes = ty == 1 ? 2 : (ty == 2 ? 3 : 4);
+            uint32_t pixel = 0;
+            for (int x = 0; x < width; ++x) {
+                uint32_t diff = 0;
+                for (int k = 0; k < planes; ++k) diff = (diff << 8) | t[(size_t)k * width + x];
+                if (ty == 2) diff <<= 8;
+                pixel += diff;
+                if (ty == 1) { dst[o++] = (uint8_t)(pixel & 0xff); dst[o++] = (uint8_t)((pixel >> 8) & 0xff); }
+                else { dst[o++] = (uint8_t)pixel; dst[o++] = (uint8_t)(pixel >> 8); dst[o++] = (uint8_t)(pixel >> 16); dst[o++] = (uint8_t)(pixel >> 24); }
+            }
+            t += (size_t)planes * width;
+        }
+    return o == raw;
+}
 bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h) {
     std::vector<uint8_t> f;
     if (!ReadFile(name, &f) || f.size() < 16) { Error("Unable to read image file \"%s\"", name.c_str()); return false; }
     auto rd32 = [&](size_t p) { uint32_t v; std::memcpy(&v, &f[p], 4); return v; };
     if (rd32(0) != 20000630u) { Error("\"%s\" is not an OpenEXR file", name.c_str()); return false; }
     uint32_t version = rd32(4);
-    if ((version & 0xff) != 2 || (version & 0x1a00)) { Error("EXR file \"%s\": tiled / multi-part / deep files are not supported", name.c_str()); return false; }
+    if ((version & 0xff) != 2 || (version & 0x1800)) { Error("EXR file \"%s\": multi-part / deep files are not supported", name.c_str()); return false; }
+    const bool tiled = (version & 0x200) != 0;
+    int tileW = 0, tileH = 0;
     struct Chan { std::string name; int type; };
     std::vector<Chan> chans;
     int compression = -1, lineOrder = 0;
@@ -227,38 +460,38 @@ bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h)
         } else if (an == "compression" && sz >= 1) compression = f[p];
         else if (an == "dataWindow" && sz >= 16) std::memcpy(dw, &f[p], 16);
         else if (an == "lineOrder" && sz >= 1) lineOrder = f[p];
+        else if (an == "tiles" && sz >= 9) { tileW = (int)rd32(p); tileH = (int)rd32(p + 4); }   // (the level mode byte: level (0, 0) is stored first in every mode)
         p += sz;
     }
     ++p;   // end of header
     int width = dw[2] - dw[0] + 1, height = dw[3] - dw[1] + 1;
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 28 || chans.empty()) { Error("EXR file \"%s\": bad header", name.c_str()); return false; }
-    if (compression < 0 || compression > 3) { Error("EXR file \"%s\": compression method %d is not supported (NONE, RLE, ZIPS, ZIP are)", name.c_str(), compression); return false; }
-    int linesPerBlock = compression == 3 ? 16 : 1;
-    int nBlocks = (height + linesPerBlock - 1) / linesPerBlock;
-    size_t lineBytes = 0;
-    std::vector<size_t> chanOff(chans.size());
-    for (size_t c = 0; c < chans.size(); ++c) { chanOff[c] = lineBytes; lineBytes += (size_t)width * (chans[c].type == 1 ? 2 : 4); }
+    if (compression < 0 || compression > 5) { Error("EXR file \"%s\": compression method %d is not supported (NONE, RLE, ZIPS, ZIP, PIZ, PXR24 are)", name.c_str(), compression); return false; }
+    const int linesPerBlock = compression == 4 ? 32 : (compression == 3 || compression == 5 ? 16 : 1);
+    for (const Chan &c : chans) if (c.type < 0 || c.type > 2) { Error("EXR file \"%s\": channel \"%s\" has an unknown pixel type", name.c_str(), c.name.c_str()); return false; }
+    size_t pixBytes = 0;
+    for (const Chan &c : chans) pixBytes += c.type == 1 ? 2 : 4;
     int ir = -1, ig = -1, ib = -1, iy = -1;
     for (size_t c = 0; c < chans.size(); ++c) {
         if (chans[c].name == "R") ir = (int)c; else if (chans[c].name == "G") ig = (int)c; else if (chans[c].name == "B") ib = (int)c; else if (chans[c].name == "Y") iy = (int)c;
     }
     if ((ir < 0 || ig < 0 || ib < 0) && iy < 0) { Error("EXR file \"%s\": no R, G, B (or Y) channels", name.c_str()); return false; }
     out->assign((size_t)width * height * 3, 0.f);
-    if (p + (size_t)nBlocks * 8 > f.size()) { Error("EXR file \"%s\": truncated offset table", name.c_str()); return false; }
     std::vector<uint8_t> buf, tmp;
-    for (int b = 0; b < nBlocks; ++b) {
-        uint64_t off;
-        std::memcpy(&off, &f[p + (size_t)b * 8], 8);
-        if (off + 8 > f.size()) { Error("EXR file \"%s\": bad block offset", name.c_str()); return false; }
-        int32_t y0 = (int32_t)rd32(off) - dw[1];
-        uint32_t dsz = rd32(off + 4);
-        if (off + 8 + dsz > f.size() || y0 < 0 || y0 >= height) { Error("EXR file \"%s\": bad block", name.c_str()); return false; }
-        int nl = std::min(linesPerBlock, height - y0);
-        size_t raw = lineBytes * nl;
-        const uint8_t *src = &f[off + 8];
+    // one chunk of pixel data (a block of scan lines, or one tile): bw x nl pixels at (x0, y0) of the data window, stored line after line, each line channel after channel
+    auto chunk = [&](const uint8_t *src, uint32_t dsz, int x0, int y0, int bw, int nl) -> bool {
+        const size_t lineBytes = pixBytes * (size_t)bw, raw = lineBytes * nl;
         buf.resize(raw);
-        if (compression == 0 || dsz == raw) std::memcpy(buf.data(), src, std::min<size_t>(raw, dsz));   // stored uncompressed when that is not larger
-        else {
+        if (compression == 0 || dsz >= raw) { if (dsz < raw) return false; std::memcpy(buf.data(), src, raw); }   // stored uncompressed when that is not larger
+        else if (compression == 4) {
+            std::vector<PizChan> pc(chans.size());
+            for (size_t c = 0; c < chans.size(); ++c) pc[c] = PizChan{bw, nl, chans[c].type == 1 ? 1 : 2, 0};
+            if (!PizBlock(src, dsz, pc, nl, buf.data(), raw)) { Error("EXR file \"%s\": bad PIZ data at line %d", name.c_str(), y0); return false; }
+        } else if (compression == 5) {
+            std::vector<int> types(chans.size());
+            for (size_t c = 0; c < chans.size(); ++c) types[c] = chans[c].type;
+            if (!Pxr24Block(src, dsz, types, bw, nl, buf.data(), raw)) { Error("EXR file \"%s\": bad PXR24 data at line %d", name.c_str(), y0); return false; }
+        } else {
             tmp.resize(raw);
             if (compression == 1) {   // RLE: signed run lengths
                 size_t o = 0, i = 0;
@@ -276,6 +509,9 @@ bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h)
             size_t half = (raw + 1) / 2;
             for (size_t i = 0; i < raw; ++i) buf[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];   // ... and the even / odd byte split
         }
+        std::vector<size_t> chanOff(chans.size());
+        size_t o = 0;
+        for (size_t c = 0; c < chans.size(); ++c) { chanOff[c] = o; o += (size_t)bw * (chans[c].type == 1 ? 2 : 4); }
         for (int l = 0; l < nl; ++l) {
             const uint8_t *line = &buf[lineBytes * l];
             auto value = [&](int c, int x) -> Float {
@@ -284,11 +520,39 @@ bool DecodeEXR(const std::string &name, std::vector<Float> *out, int *w, int *h)
                 if (chans[c].type == 2) { float v; std::memcpy(&v, q + 4 * (size_t)x, 4); return v; }
                 uint32_t u; std::memcpy(&u, q + 4 * (size_t)x, 4); return (Float)u;
             };
-            Float *dst = &(*out)[(size_t)(y0 + l) * width * 3];
-            for (int x = 0; x < width; ++x) {
+            Float *dst = &(*out)[((size_t)(y0 + l) * width + x0) * 3];
+            for (int x = 0; x < bw; ++x) {
                 if (ir >= 0 && ig >= 0 && ib >= 0) { dst[3 * x] = value(ir, x); dst[3 * x + 1] = value(ig, x); dst[3 * x + 2] = value(ib, x); }
                 else dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = value(iy, x);
             }
+        }
+        return true;
+    };
+    if (tiled) {   // level (0, 0) of a tiled file: the first numX x numY entries of the offset table, whatever the level mode; Imf::RgbaInputFile reads the same level
+        if (tileW <= 0 || tileH <= 0) { Error("EXR file \"%s\": tiled file without a valid \"tiles\" attribute", name.c_str()); return false; }
+        const int ntx = (width + tileW - 1) / tileW, nty = (height + tileH - 1) / tileH;
+        if (p + (size_t)ntx * nty * 8 > f.size()) { Error("EXR file \"%s\": truncated offset table", name.c_str()); return false; }
+        for (int t = 0; t < ntx * nty; ++t) {
+            uint64_t off;
+            std::memcpy(&off, &f[p + (size_t)t * 8], 8);
+            if (off > f.size() || off + 20 > f.size()) { Error("EXR file \"%s\": bad tile offset", name.c_str()); return false; }
+            const int32_t tx = (int32_t)rd32(off), ty = (int32_t)rd32(off + 4), lx = (int32_t)rd32(off + 8), ly = (int32_t)rd32(off + 12);
+            const uint32_t dsz = rd32(off + 16);
+            if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || tx >= ntx || ty >= nty || dsz > f.size() - (off + 20)) { Error("EXR file \"%s\": bad tile", name.c_str()); return false; }
+            const int x0 = tx * tileW, y0 = ty * tileH;
+            if (!chunk(&f[off + 20], dsz, x0, y0, std::min(tileW, width - x0), std::min(tileH, height - y0))) { Error("EXR file \"%s\": bad tile data", name.c_str()); return false; }
+        }
+    } else {
+        const int nBlocks = (height + linesPerBlock - 1) / linesPerBlock;
+        if (p + (size_t)nBlocks * 8 > f.size()) { Error("EXR file \"%s\": truncated offset table", name.c_str()); return false; }
+        for (int b = 0; b < nBlocks; ++b) {
+            uint64_t off;
+            std::memcpy(&off, &f[p + (size_t)b * 8], 8);
+            if (off > f.size() || off + 8 > f.size()) { Error("EXR file \"%s\": bad block offset", name.c_str()); return false; }
+            const int32_t y0 = (int32_t)rd32(off) - dw[1];
+            const uint32_t dsz = rd32(off + 4);
+            if (dsz > f.size() - (off + 8) || y0 < 0 || y0 >= height || y0 % linesPerBlock != 0) { Error("EXR file \"%s\": bad block", name.c_str()); return false; }
+            if (!chunk(&f[off + 8], dsz, 0, y0, width, std::min(linesPerBlock, height - y0))) { Error("EXR file \"%s\": bad block data", name.c_str()); return false; }
         }
     }
     (void)lineOrder;   // every block carries its own y coordinate

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rays", type=int, default=200000)
     ap.add_argument("--rebuild", action="store_true", help="tree study: the same triangles under an own SAH tree (3 axes, binned / exact sweep, leaf sizes) instead of the reference's")
     ap.add_argument("--wavesim", action="store_true", help="wave-scheduling simulator: SIMT efficiency of k_trace's node / leaf phases under different policies")
+    ap.add_argument("--ray-order", default="random", help="--wavesim: order of the bounce rays in the queue: random | morton (origin cell) | morton_oct (direction octant, then origin cell) | cellN (N^3 grid of origin cells x octant, counting-sort-like: stable inside a cell)")
     ap.add_argument("--hot", action="store_true", help="hot-node study: share of the BVH4 node visits on the K nodes a block could hold in LDS")
     args = ap.parse_args()
     import oracle_lib as ol
@@ -66,6 +67,20 @@ def main():
         L.bvh_study_wavesim.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         rng2 = np.random.RandomState(5)
         rays = np.ascontiguousarray(sec[rng2.permutation(len(sec))])
+        if args.ray_order != "random":   # round 6: what would a spatial sort of the extension rays buy the wave scheduler?
+            o = rays["o"].astype(np.float64); lo = o.min(0); ext = (o.max(0) - lo).max()
+            octant = ((rays["d"][:, 0] < 0).astype(np.int64) | ((rays["d"][:, 1] < 0).astype(np.int64) << 1) | ((rays["d"][:, 2] < 0).astype(np.int64) << 2))
+            if args.ray_order.startswith("cell"):
+                N = int(args.ray_order[4:]); c = np.minimum(N - 1, ((o - lo) / ext * N).astype(np.int64))
+                key = ((c[:, 2] * N + c[:, 1]) * N + c[:, 0]) * 8 + octant
+            else:
+                q = np.minimum(1023, ((o - lo) / ext * 1024).astype(np.int64))
+                def spread(v):
+                    v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; return (v | (v << 2)) & 0x09249249
+                key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+                if args.ray_order == "morton_oct": key = key | (octant << 30)
+            rays = np.ascontiguousarray(rays[np.argsort(key, kind="stable")])
+            print("ray order: %s (%d distinct keys)" % (args.ray_order, len(np.unique(key))))
         CN, CL = 143.0, 163.0   # VALU instructions of one node phase / one triangle phase of k_trace<0, QN> (round 4: profiles/r04_h_isa_node_step.txt)
         print("64-lane waves over %d incoherent bounce rays; cost = node phases x %.0f + triangle phases x %.0f instructions" % (len(rays), CN, CL))
         print("%-64s %9s %9s %8s %9s %9s %8s %10s" % ("policy", "nodePh/ray", "lanes/ph", "eff", "triPh/ray", "lanes/ph", "eff", "instr/ray"))
