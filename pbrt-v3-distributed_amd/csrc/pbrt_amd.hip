@@ -76,8 +76,9 @@ struct PathState {
     uint32_t *q_probe[2];      // ... and the two queues the probe walk ping-pongs between (rows QC_PROBE0 / QC_PROBE1; the direct-lighting walk keeps q_tr)
     uint32_t *q_tr[2];         // second shadow / MIS queues (the walk ping-pongs between q_shadow / q_mis and these)
     uint32_t qrow_shadow, qrow_mis;   // counter rows of the queues k_trace<2> / <1> read (QC_SHADOW / QC_MIS unless a walk swapped them)
-    uint32_t *key;             // material key per path (written when its extension ray finishes): structure-of-arrays,
-    uint2 *keyrank;            // because the sort kernels walk them in queue order, not per path
+    uint2 *keyrank;            // per QUEUE POSITION of the extension queue: .x = the path's material key, written by k_trace<0> when the ray at that position finishes (round 6:
+                               // it used to go to a per-path array that k_keycount then gathered through the queue, one 128-byte line per key: 1.2 of its 1.25 ms per launch);
+                               // k_keycount reads it in queue order, adds the rank within the block (.y), k_scatter walks the same positions
     uint32_t *q_ext[2], *q_shadow, *q_mis, *q_sorted;
     // Queues are cut into QSEG segments (one per XCD-aligned block class, blockIdx & 7), each with its own fill counter in its own
     // 128-byte line: qcount[QCI(queue, seg)].  A single counter per queue made every wave of the chip hit ONE word -- the L2 serialises
@@ -428,11 +429,21 @@ __global__ void __launch_bounds__(PT_BLOCK) k_pix_start_pixel(DevScene sc, const
     }
 }
 
+#ifndef PT_RAYGEN_LDS
+#if defined(PT_HOST_EMU) && PT_HOST_EMU
+#define PT_RAYGEN_LDS 0   /* (one-lane waves of the x86 emulator) */
+#else
+#define PT_RAYGEN_LDS 1   /* 0: every lane stores its own record's fields (rounds 1-5; the A/B partner) */
+#endif
+#endif
 // TEX: the scene has textured materials -- keep the lens sample with the path
 template <bool TEX>
 __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, PassInfo pass, uint32_t qout) {
     uint32_t n = pass.list_xy ? pass.npix : pass.npix * pass.ns;
     uint32_t ncam = 0;
+#if PT_RAYGEN_LDS
+    __shared__ float4 s_rec[PT_BLOCK / 64][7][65];   // per wave: the seven written fields of its 64 records, field-major (+1: the read-out's bank spread)
+#endif
     for (ChunkIter it(n); it.more(); it.next()) {
         uint32_t i = it.item();
         bool active = i < n;
@@ -458,10 +469,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
                          y >= sc.pixel_min[1] && y < sc.pixel_max[1];
             }
         }
-        if (i < n) {
-            ps.rec[i].L = make_float4(0, 0, 0, 0);
-            ps.rec[i].pixel = active ? ((uint32_t)(x - sc.sample_min[0]) | ((uint32_t)(y - sc.sample_min[1]) << 16)) : INACTIVE_PIXEL;
-        }
+        // The wave's 64 path records are 8 KiB of consecutive memory.  Written field by field from the lanes that own them, every store instruction touched 64
+        // different 128-byte lines with 16 bytes each (seven partial-line requests per path at the L2); through LDS the wave writes its records as whole lines
+        // (PT_RAYGEN_LDS, round 6: eight fully coalesced 1 KiB stores per wave and chunk; the record's unused words are written as zeros).
+        float4 f_o = make_float4(0, 0, 0, 0), f_d = f_o, f_beta = f_o, f_smp = f_o, f_5 = f_o, f_6 = f_o;
+        f_6.x = __uint_as_float(active ? ((uint32_t)(x - sc.sample_min[0]) | ((uint32_t)(y - sc.sample_min[1]) << 16)) : INACTIVE_PIXEL);
         if (active) {
             Sampler smp;
             if (pass.serial) smp.PixStart(tileId, s, x, y);
@@ -469,14 +481,47 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
             V3 o, d;
             Float tMax, pfx, pfy, lens0, lens1;
             GenerateCameraRay(sc, smp, &o, &d, &tMax, &pfx, &pfy, &lens0, &lens1);
-            if (TEX) ps.rec[i].lens = make_float2(lens0, lens1);
-            ps.rec[i].ray_o = make_float4(o.x, o.y, o.z, tMax);
-            ps.rec[i].ray_d = make_float4(d.x, d.y, d.z, 0);
-            ps.rec[i].beta = make_float4(1, 1, 1, 1);
-            ps.rec[i].smp = make_uint4((uint32_t)smp.index, (uint32_t)(smp.index >> 32), (uint32_t)smp.dimension, 0);
-            ps.rec[i].pfilm = make_float2(pfx, pfy);
+            if (TEX) { f_6.z = lens0; f_6.w = lens1; }
+            f_o = make_float4(o.x, o.y, o.z, tMax);
+            f_d = make_float4(d.x, d.y, d.z, 0);
+            f_beta = make_float4(1, 1, 1, 1);
+            f_smp = make_float4(__uint_as_float((uint32_t)smp.index), __uint_as_float((uint32_t)(smp.index >> 32)), __uint_as_float((uint32_t)smp.dimension), 0);
+            f_5.z = pfx; f_5.w = pfy;
             ++ncam;
         }
+#if PT_RAYGEN_LDS
+        {
+            static_assert(sizeof(PathRec) == 128, "eight 16-byte fields per record");
+            float4 (*S)[65] = s_rec[threadIdx.x >> 6];
+            const uint32_t ln = threadIdx.x & 63;
+            S[0][ln] = f_o; S[1][ln] = f_d; S[2][ln] = f_beta; S[3][ln] = make_float4(0, 0, 0, 0) /* L */; S[4][ln] = f_smp; S[5][ln] = f_5 /* hit, pfilm */; S[6][ln] = f_6 /* pixel, pad0, lens */;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t i0 = i - ln;   // the wave's first path
+            float4 *dst = reinterpret_cast<float4 *>(ps.rec + i0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t q = (uint32_t)j * 64u + ln, r = q >> 3, f = q & 7u;
+                if (i0 + r < n) dst[q] = f == 7u ? make_float4(0, 0, 0, 0) : S[f][r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the next chunk's LDS writes stay behind these reads
+        }
+#else
+        if (i < n) {
+            ps.rec[i].L = make_float4(0, 0, 0, 0);
+            ps.rec[i].pixel = __float_as_uint(f_6.x);
+        }
+        if (active) {
+            if (TEX) ps.rec[i].lens = make_float2(f_6.z, f_6.w);
+            ps.rec[i].ray_o = f_o;
+            ps.rec[i].ray_d = f_d;
+            ps.rec[i].beta = f_beta;
+            ps.rec[i].smp = make_uint4(__float_as_uint(f_smp.x), __float_as_uint(f_smp.y), __float_as_uint(f_smp.z), 0);
+            ps.rec[i].pfilm = make_float2(f_5.z, f_5.w);
+        }
+#endif
         uint32_t pos = wave_append(&ps.qcount[QCI(qout, blockIdx.x & 7)], active);   // this block class's segment of the queue
         if (active) ps.q_ext[qout][(blockIdx.x & 7) * ps.seg_cap + pos] = i;
     }
@@ -619,6 +664,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
     uint32_t poolNext = 0, poolEnd = 0;   // wave-uniform
     bool active = false;
     uint32_t slot = 0, lightNum = 0;
+    uint32_t qpos = 0;   // MODE 0: the ray's position in the queue (where its sort key goes)
     typename TT::State ts;
     ts.cur = TRAV_DONE;
     if constexpr (PEND) ts.pend = TRAV_DONE;
@@ -641,7 +687,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                     int mat = (int)sc.tri_info[ts.prim].y;
                     key = mat >= 0 ? (uint32_t)mat : sc.n_materials + 1;         // null-BSDF surfaces: own bucket
                 }
-                ps.key[slot] = key;
+                ps.keyrank[qpos].x = key;   // by queue position: k_keycount reads the keys in order
             } else if (MODE == 2) {
                 if (ts.prim == TRAV_MISS) {   // unoccluded: add the light-sampled term
                     float4 c = ps.nee[slot].sh_c, L = ps.rec[slot].L;
@@ -713,6 +759,7 @@ __global__ void __launch_bounds__((TraceShape<MODE, SPHERES, ALPHA, QN>::BLOCK),
                 uint32_t avail = poolEnd - poolNext;
                 uint32_t rank = (uint32_t)__popcll(idle & ltMask);
                 if (!active && rank < avail) {
+                    if (MODE == 0 && !TR) qpos = poolNext + rank;
                     slot = queue[poolNext + rank];
                     float4 o4 = MODE == 0 ? ps.rec[slot].ray_o : (MODE == 1 ? ps.nee[slot].mi_o : ps.nee[slot].sh_o);
                     float4 d4 = MODE == 0 ? ps.rec[slot].ray_d : (MODE == 1 ? ps.nee[slot].mi_d : ps.nee[slot].sh_d);
@@ -875,10 +922,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
     for (SegIter it(ps.qcount, qin, ps.seg_cap); it.more(); it.next()) {
         uint32_t i = it.item();
         bool active = it.valid();
-        uint32_t slot = 0, key = 0;
+        uint32_t key = 0;
         if (active) {
-            slot = ps.q_ext[qin][i];
-            key = ps.key[slot];
+            key = ps.keyrank[i].x;   // left by k_trace<0> at the ray's queue position
             if (ps.key_remap) key = ps.key_remap[key];
         }
         uint32_t rank = wave_key_rank(lhist, key, active);
@@ -2611,7 +2657,7 @@ static int ensure_state(mi_ctx *c, uint32_t cap) {
     const uint32_t chunks = (cap + PT_BLOCK - 1) / PT_BLOCK;
     ps.seg_cap = ((chunks + 7) / 8) * PT_BLOCK + PT_SHADE_PARTS_MAX * (PT_DYN_GRAIN > PT_BLOCK ? PT_DYN_GRAIN : PT_BLOCK);   // (DynIter hands a class whole grains: up to one grain beyond n_i / 8 per part)
     const size_t qcap = (size_t)QSEG * ps.seg_cap;
-    ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(key, uint32_t, cap); ALLOC(keyrank, uint2, qcap);
+    ALLOC(rec, PathRec, cap); ALLOC(nee, NeeRec, cap); ALLOC(keyrank, uint2, qcap);
     ALLOC(q_ext[0], uint32_t, qcap); ALLOC(q_ext[1], uint32_t, qcap); ALLOC(q_shadow, uint32_t, qcap); ALLOC(q_mis, uint32_t, qcap);
     ALLOC(q_sorted, uint32_t, qcap);
     ps.qrow_shadow = QC_SHADOW; ps.qrow_mis = QC_MIS;
