@@ -1365,10 +1365,64 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
 //   SPILL == true : every other footprint pixel (wide filters; with the box filter only a sample that lands
 //                   exactly on a pixel edge) through atomicAdd, in a second launch so that it cannot race
 //                   with the plain stores of the first.
+// (round 6) The second launch used to walk every sample of the pass again -- a whole 128-byte path record fetched for its 8 bytes of pFilm, to find that under the box
+// filter nothing spills: half of the film time.  Now the first launch LISTS the samples whose footprint holds other pixels (PathState::q_sorted is free once the pass
+// has been shaded; counter row QC_BINNED, zeroed at the start of the pass) and the second launch walks that list only.
+struct FilmFootprint { int p0x, p0y, p1x, p1y; Float dx, dy; };
+PT_DEV FilmFootprint FilmFoot(const DevScene &sc, float2 pf) {   // FilmTile::AddSample core/film.h:131-140, clipped to the crop window
+    FilmFootprint f;
+    f.dx = pf.x - 0.5f; f.dy = pf.y - 0.5f;
+    f.p0x = (int)__builtin_ceilf(f.dx - sc.filter_radius[0]); f.p0y = (int)__builtin_ceilf(f.dy - sc.filter_radius[1]);
+    f.p1x = (int)__builtin_floorf(f.dx + sc.filter_radius[0]) + 1; f.p1y = (int)__builtin_floorf(f.dy + sc.filter_radius[1]) + 1;
+    f.p0x = f.p0x > sc.crop_min[0] ? f.p0x : sc.crop_min[0]; f.p0y = f.p0y > sc.crop_min[1] ? f.p0y : sc.crop_min[1];
+    f.p1x = f.p1x < sc.crop_max[0] ? f.p1x : sc.crop_max[0]; f.p1y = f.p1y < sc.crop_max[1] ? f.p1y : sc.crop_max[1];
+    return f;
+}
+PT_DEV RGB FilmRadiance(const DevScene &sc, float4 L4) {   // the guards of integrator.cpp:294-315 and the maxSampleLuminance clamp (film.h:128-130)
+    RGB L(L4.x, L4.y, L4.z);
+    if (L.HasNaNs()) L = RGB(0.f);
+    else if ((double)L.y() < -1e-5) L = RGB(0.f);
+    else if (__builtin_isinf(L.y())) L = RGB(0.f);
+    if (L.y() > sc.max_sample_luminance) L = L * (sc.max_sample_luminance / L.y());
+    return L;
+}
+// the footprint pixels of one sample: OWN = only the lane's own pixel into `acc` (plain sum), else every other pixel through atomicAdd
+template <bool OWN>
+PT_DEV void FilmSplat(const DevScene &sc, const FilmFootprint &fp, const RGB &L, int ownx, int owny, float4 *film, int cw, float4 *acc) {
+    const int W = MI_FILTER_TABLE_WIDTH;
+    Float invRx = 1 / sc.filter_radius[0], invRy = 1 / sc.filter_radius[1];
+    for (int y = fp.p0y; y < fp.p1y; ++y) {
+        Float fy = absf((y - fp.dy) * invRy * W);
+        int iy = mni((int)__builtin_floorf(fy), W - 1);
+        for (int x = fp.p0x; x < fp.p1x; ++x) {
+            bool isOwn = x == ownx && y == owny;
+            if (isOwn != OWN) continue;
+            Float fx = absf((x - fp.dx) * invRx * W);
+            int ix = mni((int)__builtin_floorf(fx), W - 1);
+            Float fw = sc.filter_table[iy * W + ix];
+            RGB c = L * 1.f * fw;   // L * sampleWeight * filterWeight
+            if (OWN) { acc->x += c.r; acc->y += c.g; acc->z += c.b; acc->w += fw; }
+            else {
+                float *o = reinterpret_cast<float *>(&film[(size_t)(y - sc.crop_min[1]) * cw + (x - sc.crop_min[0])]);
+                atomicAdd(o, c.r); atomicAdd(o + 1, c.g); atomicAdd(o + 2, c.b); atomicAdd(o + 3, fw);
+            }
+        }
+    }
+}
 template <bool SPILL>
 __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, PassInfo pass, float4 *film) {
     int cw = sc.crop_max[0] - sc.crop_min[0];
-    const int W = MI_FILTER_TABLE_WIDTH;
+    if constexpr (SPILL) {   // the listed samples: every footprint pixel but the own one
+        const uint32_t count = ps.qcount[QCI(QC_BINNED, 0)];
+        for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < count; i += gridDim.x * PT_BLOCK) {
+            const uint32_t slot = ps.q_sorted[i];
+            const uint32_t pix = ps.rec[slot].pixel;
+            const int ownx = sc.sample_min[0] + (int)(pix & 0xffffu), owny = sc.sample_min[1] + (int)(pix >> 16);
+            const FilmFootprint fp = FilmFoot(sc, ps.rec[slot].pfilm);
+            FilmSplat<false>(sc, fp, FilmRadiance(sc, ps.rec[slot].L), ownx, owny, film, cw, nullptr);
+        }
+        return;
+    }
     for (ChunkIter it(pass.npix); it.more(); it.next()) {
         uint32_t p = it.item();
         if (p >= pass.npix) continue;
@@ -1377,42 +1431,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_film(DevScene sc, PathState ps, Pa
         int ownx = sc.sample_min[0] + (int)(pix & 0xffffu), owny = sc.sample_min[1] + (int)(pix >> 16);
         bool ownInside = ownx >= sc.crop_min[0] && ownx < sc.crop_max[0] && owny >= sc.crop_min[1] && owny < sc.crop_max[1];
         float4 *own = &film[(size_t)(owny - sc.crop_min[1]) * cw + (ownx - sc.crop_min[0])];
-        float4 acc = (!SPILL && ownInside) ? *own : make_float4(0, 0, 0, 0);
+        float4 acc = ownInside ? *own : make_float4(0, 0, 0, 0);
         for (uint32_t s = 0; s < pass.ns; ++s) {
             uint32_t slot = s * pass.npix + p;
-            float2 pf = ps.rec[slot].pfilm;
-            Float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
-            int p0x = (int)__builtin_ceilf(dx - sc.filter_radius[0]), p0y = (int)__builtin_ceilf(dy - sc.filter_radius[1]);
-            int p1x = (int)__builtin_floorf(dx + sc.filter_radius[0]) + 1, p1y = (int)__builtin_floorf(dy + sc.filter_radius[1]) + 1;
-            p0x = p0x > sc.crop_min[0] ? p0x : sc.crop_min[0]; p0y = p0y > sc.crop_min[1] ? p0y : sc.crop_min[1];
-            p1x = p1x < sc.crop_max[0] ? p1x : sc.crop_max[0]; p1y = p1y < sc.crop_max[1] ? p1y : sc.crop_max[1];
-            if (SPILL && p0x == ownx && p1x == ownx + 1 && p0y == owny && p1y == owny + 1) continue;   // nothing but the own pixel
-            float4 L4 = ps.rec[slot].L;
-            RGB L(L4.x, L4.y, L4.z);
-            if (L.HasNaNs()) L = RGB(0.f);
-            else if ((double)L.y() < -1e-5) L = RGB(0.f);
-            else if (__builtin_isinf(L.y())) L = RGB(0.f);
-            if (L.y() > sc.max_sample_luminance) L = L * (sc.max_sample_luminance / L.y());
-            Float invRx = 1 / sc.filter_radius[0], invRy = 1 / sc.filter_radius[1];
-            for (int y = p0y; y < p1y; ++y) {
-                Float fy = absf((y - dy) * invRy * W);
-                int iy = mni((int)__builtin_floorf(fy), W - 1);
-                for (int x = p0x; x < p1x; ++x) {
-                    bool isOwn = x == ownx && y == owny;
-                    if (isOwn == SPILL) continue;
-                    Float fx = absf((x - dx) * invRx * W);
-                    int ix = mni((int)__builtin_floorf(fx), W - 1);
-                    Float fw = sc.filter_table[iy * W + ix];
-                    RGB c = L * 1.f * fw;   // L * sampleWeight * filterWeight
-                    if (!SPILL) { acc.x += c.r; acc.y += c.g; acc.z += c.b; acc.w += fw; }
-                    else {
-                        float *o = reinterpret_cast<float *>(&film[(size_t)(y - sc.crop_min[1]) * cw + (x - sc.crop_min[0])]);
-                        atomicAdd(o, c.r); atomicAdd(o + 1, c.g); atomicAdd(o + 2, c.b); atomicAdd(o + 3, fw);
-                    }
-                }
-            }
+            const FilmFootprint fp = FilmFoot(sc, ps.rec[slot].pfilm);
+            const bool any = fp.p0x < fp.p1x && fp.p0y < fp.p1y;
+            const bool others = any && !(fp.p0x == ownx && fp.p1x == ownx + 1 && fp.p0y == owny && fp.p1y == owny + 1);   // pixels besides the own one: the second launch's
+            const uint32_t pos = wave_append(&ps.qcount[QCI(QC_BINNED, 0)], others);
+            if (others) ps.q_sorted[pos] = slot;
+            if (any) FilmSplat<true>(sc, fp, FilmRadiance(sc, ps.rec[slot].L), ownx, owny, film, cw, &acc);
         }
-        if (!SPILL && ownInside) *own = acc;
+        if (ownInside) *own = acc;
     }
 }
 
