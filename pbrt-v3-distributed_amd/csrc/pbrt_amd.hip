@@ -590,6 +590,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #ifndef PT_TRACE_MID
 #define PT_TRACE_MID 1   /* 0: round 2's shape for the masked instances (A/B) */
 #endif
+#ifndef PT_TRACE_MID_MIS
+#define PT_TRACE_MID_MIS 1   /* the MIS instance of sphere scenes takes the MID shape too (round 6, C2: k_trace<1> 36.7 -> 30.3 ms per frame, profiles/r06_q_*); 0: the 256-thread shape */
+#endif
 #ifndef PT_TRACE_MID_BLOCK
 #define PT_TRACE_MID_BLOCK 512
 #endif
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(DevScene sc, PathState ps, 
 #endif
 template <int MODE, bool SPHERES, bool ALPHA, bool QN> struct TraceShape {
     static constexpr bool BIG = QN && PT_HOT_NODES > 0 && MODE != 1 && !ALPHA && !SPHERES;
-    static constexpr bool MID = QN && PT_HOT_NODES > 0 && MODE != 1 && ALPHA && !SPHERES && PT_TRACE_MID;
+    static constexpr bool MID = QN && PT_HOT_NODES > 0 && (MODE != 1 || (PT_TRACE_MID_MIS && SPHERES)) && (ALPHA != SPHERES) && PT_TRACE_MID;   // masks, or (round 6) spheres -- not both: 128 VGPRs hold one of the two leaf extensions
     static constexpr int BLOCK = BIG ? PT_TRACEQ_BLOCK : (MID ? PT_TRACE_MID_BLOCK : PT_BLOCK);
     static constexpr int HOT = (BIG || MID) ? PT_HOT_NODES : 0;
     static constexpr int NLDS = (BIG || MID) ? PT_TRACEQ_LDS_STACK : PT_LDS_STACK;
@@ -915,6 +918,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_renumber_nodes(const BVH4QNode *sr
 //                the block; the block histogram goes to blockhist[block][key]
 //   k_scan_keys: offsets[block][key] = keyBase[key] + sum of the histograms of lower blocks (one thread per key)
 //   k_scatter  : same chunk->block mapping, so sorted[offsets[block][key] + rank] = path
+#ifndef PT_KEYRANK_ATOMIC
+#define PT_KEYRANK_ATOMIC 1   /* round 6: sort 7.7 -> 4.4 ms per C3 frame, 29.3 -> 21.2 on C4 (profiles/r06_r_*); 0: the ballot rounds of rounds 1-5 */
+#endif
 __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps, uint32_t qin, uint32_t nkeys) {
     extern __shared__ uint32_t lhist[];
     for (uint32_t k = threadIdx.x; k < nkeys; k += PT_BLOCK) lhist[k] = 0;
@@ -927,7 +933,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_keycount(DevScene sc, PathState ps
             key = ps.keyrank[i].x;   // left by k_trace<0> at the ray's queue position
             if (ps.key_remap) key = ps.key_remap[key];
         }
-        uint32_t rank = wave_key_rank(lhist, key, active);
+#if PT_KEYRANK_ATOMIC
+        uint32_t rank = active ? atomicAdd(&lhist[key], 1u) : 0u;   // one returning LDS atomic per lane: the hardware serialises equal keys (cost ~ the largest group of equal keys in the wave)
+#else
+        uint32_t rank = wave_key_rank(lhist, key, active);           // one LDS atomic per (wave, distinct key): a ballot round per distinct key
+#endif
         if (active) ps.keyrank[i] = make_uint2(key, rank);   // indexed by queue position: k_scatter walks the same chunks
     }
     __syncthreads();
@@ -2476,7 +2486,7 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
     // it only ranks nodes).
     // PBRT_AMD_HOT=0 keeps the reference order and n_hot = 0 (every step through the vector-memory path; A/B and tests).
     sc.n_hot = 0;
-    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && !c->hasSpheres && (!c->hasAlpha || PT_TRACE_MID) && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
+    if (c->useQ && qnBuf && PT_HOT_NODES > 0 && (!(c->hasSpheres || c->hasAlpha) || (PT_TRACE_MID && !(c->hasSpheres && c->hasAlpha))) && sc.n_nodes > 1 && sc.spp > 0 && sc.sample_max[0] > sc.sample_min[0] && sc.sample_max[1] > sc.sample_min[1]) {
         const char *e = std::getenv("PBRT_AMD_HOT");
         if (!(e && e[0] == '0')) {
             const uint32_t n = sc.n_nodes, K = std::min<uint32_t>(PT_HOT_NODES, n);
@@ -3288,7 +3298,7 @@ int mi_trace_info(mi_ctx *c, int64_t out[8]) {
     out[0] = mode;
     out[1] = mode == 5 ? (int64_t)sizeof(BVH4QNode) : 128;
     out[2] = c->sc.n_nodes;
-    const bool mid = mode == 5 && !c->hasSpheres && c->hasAlpha && TraceShape<0, false, true, true>::MID;
+    const bool mid = mode == 5 && (c->hasSpheres != c->hasAlpha) && TraceShape<0, false, true, true>::MID;
     const bool big = mid || (mode == 5 && !c->hasSpheres && !c->hasAlpha && TraceShape<0, false, false, true>::BIG);
     out[3] = big ? TraceShape<0, false, false, true>::NLDS : PT_LDS_STACK;
     out[4] = c->sc.n_hot;
