@@ -901,6 +901,17 @@ __global__ void __launch_bounds__(PT_BLOCK) k_hot_probe(DevScene sc, uint32_t nP
         tMax = PT_INFINITY;
     }
 }
+// the shading kernels' per-triangle line (DevScene::tri_rec) from the three per-triangle arrays
+__global__ void __launch_bounds__(PT_BLOCK) k_build_tri_rec(const float4 *verts, const TriShade *shade, const uint4 *info, float4 *rec, uint32_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < 8ull * n; i += (uint64_t)gridDim.x * PT_BLOCK) {
+        const uint32_t t = (uint32_t)(i >> 3), f = (uint32_t)(i & 7u);
+        float4 v;
+        if (f < 3) v = verts[3 * (size_t)t + f];
+        else if (f < 7) v = reinterpret_cast<const float4 *>(shade + t)[f - 3];
+        else { const uint4 u = info[t]; v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); }
+        rec[i] = v;
+    }
+}
 // dst[newIdx[i]] = src[i] with the interior child references renumbered the same way (leaf references and empty slots carry the leaf bit)
 __global__ void __launch_bounds__(PT_BLOCK) k_renumber_nodes(const BVH4QNode *src, BVH4QNode *dst, const uint32_t *newIdx, uint32_t n) {
     for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += gridDim.x * PT_BLOCK) {
@@ -1131,11 +1142,10 @@ __global__ void __launch_bounds__(PT_BLOCK, (TEX ? PT_TEX_SHADE_WAVES : PT_SHADE
             IsectX ix;
             uint4 tinfo = make_uint4(0, 0, 0, 0);
             if (found) {
-                tinfo = sc.tri_info[hr.x];
-                TriShadeRegs tsr = LoadTriShade(sc.tri_shade, hr.x);   // with the vertices: one memory round trip
+                TriShadeRegs tsr;
                 V3 p0, p1, p2;
                 uint32_t tf;
-                LoadTri(sc, hr.x, &p0, &p1, &p2, &tf);
+                LoadHitTriangle(sc, hr.x, &p0, &p1, &p2, &tf, &tsr, &tinfo);   // one 128-byte line (DevScene::tri_rec)
                 Pin(tsr.a, tsr.b, tsr.c); Pin(tsr.d); Pin(tinfo);
                 V3 iro = ro, ird = rd;   // the ray in the space the primitive lives in
                 const DevInstance *hitInst = nullptr;
@@ -2096,6 +2106,15 @@ int mi_scene_upload(mi_ctx *c, const mi_scene_desc *d) {
         if (upload(c, b, ti.data(), ti.size() * sizeof(uint4))) return -1;
         HIP_TRY(hipStreamSynchronize(c->stream));
         sc.tri_info = b.as<uint4>();
+    }
+    sc.tri_rec = nullptr;
+    if (PT_TRI_REC && d->n_tris) {   // 128 bytes per triangle on top of the 128 of the three arrays (10 M triangles: 1.3 GB of 288)
+        static_assert(sizeof(TriShade) == 64, "TriShade = four 16-byte words");
+        DevBuf &b = next();
+        if (b.alloc((size_t)d->n_tris * 128)) return -1;
+        hipLaunchKernelGGL(k_build_tri_rec, dim3(c->numCUs * 4), dim3(PT_BLOCK), 0, c->stream, sc.tri_verts, sc.tri_shade, sc.tri_info, b.as<float4>(), d->n_tris);
+        HIP_TRY(hipGetLastError());
+        sc.tri_rec = b.as<float4>();
     }
     { DevBuf &b = next(); if (upload(c, b, d->materials, (size_t)d->n_materials * sizeof(mi_material))) return -1; sc.materials = b.as<mi_material>(); }
     {   // the BSDF's lobe header per material: count + the lobe types, 4 bits each (one scalar load instead of a chain through the lobe records)

@@ -68,6 +68,8 @@ struct DevScene {
     Bvh4qGrid qgrid;
     const TriShade *tri_shade;      // per triangle: vertex normals + uvs
     const uint4 *tri_info;          // per triangle, ONE 16-byte load: x = mesh flags (MI_MESH_*), y = material (int), z = light (int), w = mesh
+    const float4 *tri_rec;          // (round 6) per triangle ONE 128-byte line for the shading kernels: [0..2] the tri_verts record, [3..6] the TriShade record, [7] tri_info --
+                                    // a vertex reloads vertices + normals / uvs + flags from one line instead of three or four (the 48-byte vertex records straddle lines)
     const mi_material *materials;
     const uint2 *mat_pack;          // per material: {n_bxdfs, the lobe types 4 bits each} -- the BSDF's lobe header (pt_shade.h, PT_LOBE_HEADER)
     const DevEnvMap *envmaps;

@@ -37,6 +37,27 @@ PT_DEV TriShadeRegs LoadTriShade(const TriShade *ts, uint32_t prim) {
     return r;
 }
 
+// (round 6) what a shading kernel reloads of the hit triangle -- vertices, normals / uvs, tri_info -- from the triangle's ONE 128-byte line (DevScene::tri_rec) when the
+// scene has it, else from the three per-triangle arrays.  Same words either way.
+#ifndef PT_TRI_REC
+#define PT_TRI_REC 1   /* 0: the three per-triangle arrays (rounds 1-5; the A/B partner) */
+#endif
+PT_DEV void LoadHitTriangle(const DevScene &sc, uint32_t prim, V3 *p0, V3 *p1, V3 *p2, uint32_t *flags, TriShadeRegs *tsr, uint4 *tinfo) {
+#if PT_TRI_REC
+    const float4 *tr = sc.tri_rec + 8 * (size_t)prim;   // eight 16-byte loads from one line
+    float4 va = tr[0], vb = tr[1], vc = tr[2], i4 = tr[7];
+    tsr->a = tr[3]; tsr->b = tr[4]; tsr->c = tr[5]; tsr->d = tr[6];
+    Pin(va, vb, vc);
+    *p0 = V3(va.x, va.y, va.z); *p1 = V3(vb.x, vb.y, vb.z); *p2 = V3(vc.x, vc.y, vc.z);
+    *flags = __float_as_uint(va.w);
+    *tinfo = make_uint4(__float_as_uint(i4.x), __float_as_uint(i4.y), __float_as_uint(i4.z), __float_as_uint(i4.w));
+#else
+    *tinfo = sc.tri_info[prim];
+    *tsr = LoadTriShade(sc.tri_shade, prim);   // with the vertices: one memory round trip
+    LoadTri(sc, prim, p0, p1, p2, flags);
+#endif
+}
+
 // Second half of Triangle::Intersect (shapes/triangle.cpp:293-421): build the interaction from the
 // barycentrics the traversal found.  rayD = direction of the ray that hit; mflags / tsr = the triangle's mesh flags
 // and shading record (loaded by the caller together with the vertices: one memory round trip).

@@ -91,11 +91,11 @@ __device__ __noinline__ void HitToIsect(const DevScene *scp, const DevVol *vol, 
         InstRay ir = InstanceRay(hitInst, o, d);
         o = ir.o; d = ir.d;
     }
-    uint4 tinfo = sc.tri_info[prim];
-    TriShadeRegs tsr = LoadTriShade(sc.tri_shade, prim);
+    uint4 tinfo;
+    TriShadeRegs tsr;
     V3 p0, p1, p2;
     uint32_t tf;
-    LoadTri(sc, prim, &p0, &p1, &p2, &tf);
+    LoadHitTriangle(sc, prim, &p0, &p1, &p2, &tf, &tsr, &tinfo);
     out->ix = IsectX();
     if (tf & TRI_FLAG_SPHERE) {
         out->is = SphereIsectToIsect(sc.spheres + __float_as_uint(p0.x), o, d, prim);
