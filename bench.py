@@ -673,7 +673,8 @@ def main():
                         shade_sq["bound"] = "valu_issue"
                         shade_sq["note"] = ("SQ counters of the same rocprofv3 --pmc pass as valu_issue; launch time live from this run; issue_frac = the measured issue rate of plain v_fma_f32 "
                                             "(%.2f cycles per wave instruction per SIMD, profiles/r04_a_valu_probe2_issue_rate_and_clock.txt) / the SIMD cycles one VALU instruction of this kernel "
-                                            "costs, all stalls included; there is no HBM figure: the kernel's tables are L2 / scalar-cache resident" % PROBE_FMA_CYCLES)
+                                            "costs, all stalls included; memory side (not measured in this run): 132.7 GB of read requests per 64 spp C3 frame = 1.03 TB/s, 0.13 of the 8 TB/s peak "
+                                            "(profiles/r06_w_kernel_traffic.txt, the same TCC_EA0_RDREQ pass as roofline.traffic, per kernel)" % PROBE_FMA_CYCLES)
                         roofline_shade = shade_sq
             except Exception as e:   # measurement aid only
                 log("[bench] VALU issue figure not measured: %s" % e)

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "pbrt_amd.h"
+#include <cstdlib>
+#include "bvh_reinsert.h"   // the product's own-topology builder (pt_treebuild.h) + the reinsertion pass studied on top of it (--reinsert)
 
 namespace {
 struct WNode { int n; float lo[8][3], hi[8][3]; uint32_t child[8]; };   // child: leaf bit 31 | first prim, count in leafCount
@@ -843,4 +845,22 @@ extern "C" void bvh_study_wavesim(const mi_scene_desc *d, const mi_ray *rays, in
     out[6] = deep13; out[7] = deep21;   // policy 3: node phases in which some stepping lane's stack holds more than 13 / 21 entries
     static bool said = false;
     if (policy == 3 && !said && (said = true)) std::fprintf(stderr, "[wavesim] policy 3: node phases with a lane deeper than 13 entries: %.1f %%, deeper than 21: %.1f %%; lane steps deeper than 13: %.2f %%\n", 100 * deep13 / std::max(1.0, phN), 100 * deep21 / std::max(1.0, phN), 100 * deepLanes / std::max(1.0, laN));
+}
+
+
+// ---- round 6, last session: the PRODUCT's topology over the reference's leaves (treebuild::RebuildOverLeaves) with and without the insertion-based
+// optimisation pass (treebuild::OptimizeByReinsertion); out[0..3] as bvh_study, out[4] = SAH relative to the tree before the pass, out[5] = subtrees moved, out[6] = seconds
+#include <chrono>
+extern "C" void bvh_study_reinsert(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int cull_on_pop, int any_hit, double frac, int passes, double *out) {
+    std::vector<mi_bvh2_node> own;
+    if (!treebuild::RebuildOverLeaves(d->bvh_nodes, d->n_bvh_nodes, &own)) { out[0] = -1; return; }
+    uint64_t moved = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double rel = treebuild::OptimizeByReinsertion(&own, frac, passes, &moved);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    mi_scene_desc d2 = *d;
+    d2.bvh_nodes = own.data();
+    d2.n_bvh_nodes = (uint32_t)own.size();
+    bvh_study(&d2, rays, n, 4, cull_on_pop, any_hit, out);
+    out[4] = rel; out[5] = (double)moved; out[6] = secs;
 }

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rebuild", action="store_true", help="tree study: the same triangles under an own SAH tree (3 axes, binned / exact sweep, leaf sizes) instead of the reference's")
     ap.add_argument("--wavesim", action="store_true", help="wave-scheduling simulator: SIMT efficiency of k_trace's node / leaf phases under different policies")
     ap.add_argument("--ray-order", default="random", help="--wavesim: order of the bounce rays in the queue: random | morton (origin cell) | morton_oct (direction octant, then origin cell) | cellN (N^3 grid of origin cells x octant, counting-sort-like: stable inside a cell)")
+    ap.add_argument("--reinsert", action="store_true", help="the product's own topology over the reference's leaves with and without the insertion-based optimisation pass (pt_treebuild.h)")
     ap.add_argument("--hot", action="store_true", help="hot-node study: share of the BVH4 node visits on the K nodes a block could hold in LDS")
     args = ap.parse_args()
     import oracle_lib as ol
@@ -50,6 +51,28 @@ def main():
     sec = np.zeros(len(p), dtype=pa.RAY_DTYPE)
     sec["o"] = (p + n * 1e-3).astype(np.float32); sec["d"] = d.astype(np.float32); sec["tmax"] = np.inf
     print("scene: %d triangles, %d BVH2 nodes; %d camera rays, %d bounce rays" % (sc.info["n_tris"], sc.info["n_bvh_nodes"], len(cam), len(sec)))
+    if args.reinsert:
+        L.bvh_study_reinsert.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.bvh_study_collapse(0, C.c_float(1), C.c_float(1), 0)
+        print("BVH4Q (greedy-area collapse, cull on pop) over the reference's leaves: the reference's tree, the product's top-down SAH topology, and that topology after reinsertion passes")
+        print("%-8s %-52s %9s %9s %9s %9s %9s %7s" % ("rays", "tree", "nodes/ray", "tris/ray", "req/ray", "SAH rel.", "moved", "s"))
+        sh = sec.copy(); sh["tmax"] = 3.0
+        for name, rays, anyhit in (("camera", cam, 0), ("bounce", sec, 0), ("shadow", sh, 1)):
+            rays = np.ascontiguousarray(rays)
+            out = np.zeros(8)
+            L.bvh_study(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), 4, 1, anyhit, out.ctypes.data_as(C.c_void_p))
+            nr, tr = out[0] / len(rays), out[1] / len(rays)
+            print("%-8s %-52s %9.2f %9.2f %9.1f" % (name, "reference", nr, tr, 3 + 4 * nr + 3 * tr))
+            base = None
+            for label, frac, passes in (("product: 3 axes x 32 bins, sweep below 2048", 0.0, 0), ("+ reinsertion: 2 % largest subtrees, 1 pass", 0.02, 1), ("+ reinsertion: 5 %, 2 passes", 0.05, 2),
+                                        ("+ reinsertion: 20 %, 2 passes", 0.2, 2), ("+ reinsertion: 100 %, 2 passes", 1.0, 2), ("+ reinsertion: 100 %, 5 passes", 1.0, 5)):
+                out = np.zeros(8)
+                L.bvh_study_reinsert(sc.desc, rays.ctypes.data_as(C.c_void_p), len(rays), 1, anyhit, frac, passes, out.ctypes.data_as(C.c_void_p))
+                nr, tr = out[0] / len(rays), out[1] / len(rays)
+                req = 3 + 4 * nr + 3 * tr
+                if base is None: base = req
+                print("%-8s %-52s %9.2f %9.2f %9.1f %9.3f %9d %7.1f   (%+.1f %% requests)" % (name, label, nr, tr, req, out[4], out[5], out[6], 100 * (req / base - 1)))
+        return
     if args.hot:
         L.bvh_study_hot.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         Ks = np.array([64, 128, 256, 512, 768, 1024, 1536, 2048, 4096], dtype=np.int32)
