@@ -338,7 +338,7 @@ class ShardedFrame:
 
     def __init__(self, ctx, scene, rank, world, device, backend="nccl", exchange="sparse", trace=None, timeout_s=None):
         """`device` = this rank's GPU ordinal (its local rank; every rank 0 only to exercise the N > 1 path on a one-GPU box, backend "gloo").  Every wait of the
-        process group is bounded by `timeout_s` ($PBRT_AMD_PG_TIMEOUT_S, default 300): a rank that never arrives fails the job instead of hanging it."""
+        process group is bounded by `timeout_s` ($PBRT_AMD_PG_TIMEOUT_S, default 600: ranks of a fresh box import torch minutes apart): a rank that never arrives fails the job instead of hanging it."""
         self.ctx, self.scene, self.rank, self.world = ctx, scene, rank, world
         self.trace = trace or (lambda s: None)
         self.torch = self.dist = self.film = None
@@ -353,7 +353,7 @@ class ShardedFrame:
             self.trace("torch imported, device %d selected" % dev)
             if not dist.is_initialized():
                 if timeout_s is None:
-                    timeout_s = float(os.environ.get("PBRT_AMD_PG_TIMEOUT_S", "300"))
+                    timeout_s = float(os.environ.get("PBRT_AMD_PG_TIMEOUT_S", "600"))
                 to = datetime.timedelta(seconds=timeout_s)
                 if backend == "nccl":
                     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev), timeout=to)
