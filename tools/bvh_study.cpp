@@ -219,7 +219,7 @@ void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width,
                     }
                     if (ok) h[nh++] = Ent{w.child[k], cnt[cur.ref][k], t0};
                 }
-                std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });   // far first: nearest ends on top
+                if (!(any_hit && std::getenv("BVH_STUDY_ANY_NOSORT"))) std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });   // far first: nearest ends on top (BVH_STUDY_ANY_NOSORT: any-hit rays take the hit children in slot order)
                 for (int k = 0; k < nh; ++k) st.push_back(h[k]);
             }
             bool got = false;
