@@ -149,6 +149,8 @@ int g_dp = 0, g_merge = 0; float g_cNode = 1, g_cTri = 1;
 extern "C" {
 void bvh_study_collapse(int dp, float cNode, float cTri, int mergeMax) { g_dp = dp; g_cNode = cNode; g_cTri = cTri; g_merge = mergeMax; }
 // out[0] = nodes visited, out[1] = triangles tested, out[2] = hits, out[3] = number of wide nodes; width 2 = the reference's BVH2 traversal
+static int g_anyOrder = 0;   // any-hit rays: 0 near-to-far (as shipped), 1 longest overlap first, 2 largest box first, 3 long-and-near first (study only)
+void bvh_study_any_order(int o) { g_anyOrder = o; }
 void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width, int cull_on_pop, int any_hit, double *out) {
     double nodes = 0, tris = 0, hits = 0;
     if (width == 2) {
@@ -217,7 +219,13 @@ void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width,
                         if (tf < t1) t1 = tf;
                         if (t0 > t1) ok = false;
                     }
-                    if (ok) h[nh++] = Ent{w.child[k], cnt[cur.ref][k], t0};
+                    if (ok) {
+                        double key = t0;
+                        if (any_hit && g_anyOrder == 1) key = -(t1 - t0);                       // longest overlap with the box first
+                        else if (any_hit && g_anyOrder == 2) { double a = 0; for (int q = 0; q < 3; ++q) { int r2 = (q + 1) % 3; a += (w.hi[k][q] - w.lo[k][q]) * (double)(w.hi[k][r2] - w.lo[k][r2]); } key = -a; }   // largest box first (SATO)
+                        else if (any_hit && g_anyOrder == 3) key = -(t1 - t0) / (1e-9 + t0 + 0.5 * (t1 - t0));   // long and near first
+                        h[nh++] = Ent{w.child[k], cnt[cur.ref][k], key};
+                    }
                 }
                 if (!(any_hit && std::getenv("BVH_STUDY_ANY_NOSORT"))) std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });   // far first: nearest ends on top (BVH_STUDY_ANY_NOSORT: any-hit rays take the hit children in slot order)
                 for (int k = 0; k < nh; ++k) st.push_back(h[k]);
@@ -225,7 +233,7 @@ void bvh_study(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int width,
             bool got = false;
             while (!st.empty()) {
                 cur = st.back(); st.pop_back();
-                if (!cull_on_pop || cur.t < tMax) { got = true; break; }
+                if (!cull_on_pop || any_hit || cur.t < tMax) { got = true; break; }
             }
             if (!got) break;
         }
@@ -270,7 +278,13 @@ void bvh_study_hot(const mi_scene_desc *d, const mi_ray *rays, int64_t n, int an
                         if (tf < t1) t1 = tf;
                         if (t0 > t1) ok = false;
                     }
-                    if (ok) h[nh++] = Ent{w.child[k], cnt[cur.ref][k], t0};
+                    if (ok) {
+                        double key = t0;
+                        if (any_hit && g_anyOrder == 1) key = -(t1 - t0);                       // longest overlap with the box first
+                        else if (any_hit && g_anyOrder == 2) { double a = 0; for (int q = 0; q < 3; ++q) { int r2 = (q + 1) % 3; a += (w.hi[k][q] - w.lo[k][q]) * (double)(w.hi[k][r2] - w.lo[k][r2]); } key = -a; }   // largest box first (SATO)
+                        else if (any_hit && g_anyOrder == 3) key = -(t1 - t0) / (1e-9 + t0 + 0.5 * (t1 - t0));   // long and near first
+                        h[nh++] = Ent{w.child[k], cnt[cur.ref][k], key};
+                    }
                 }
                 std::sort(h, h + nh, [](const Ent &a, const Ent &b) { return a.t > b.t; });
                 for (int k = 0; k < nh; ++k) st.push_back(h[k]);
