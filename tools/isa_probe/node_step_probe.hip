@@ -198,3 +198,36 @@ extern "C" __global__ void bvh4q_quad(const N4QC *nodes, const RayQ *rays, OutQ 
     if (hit && rank > 0) { const uint32_t slot = quad * 24u + (hits4 - 1u - rank); stack[slot] = child; stack_t[slot] = e; }   // far to near: rank hits4-1 at the bottom
     if (j == 0) { OutQ o; o.next = hits4 ? nxt : 0xffffffffu; o.n = hits4 ? hits4 - 1u : 0u; out[quad] = o; }
 }
+
+// ---- round 6 (last session) candidate: f16 planes in a NODE-LOCAL frame, taken straight into the slab FMAs by v_fma_mix_f32 (an f16 half of a packed word as a
+// multiplicand of an f32 FMA: no conversion instruction; hipcc emits it for fmaf((float)half, A, B) on gfx950).  A global grid does not fit f16 (11 significant
+// bits), so the node carries its own origin (3 x f32) and ONE power-of-two cell size: 80 bytes = five 16-byte words.  Per node: A = s / d (3 mul),
+// B = p / d - o / d (3 fma); the evaluation slack is a per-RAY constant folded into the entry test (e - x <= 2 delta, one subtract per child).
+// Compare with bvh4q_lane (today's shape) through the same `finish`.
+#include <hip/hip_fp16.h>
+struct RayH { float ix, iy, iz, oix, oiy, oiz, delta2, tMax; int negx, negy, negz; uint32_t cur; };
+struct N4H { float p[3], s; __half2 lo[3][2], hi[3][2]; uint32_t child[4]; };   // 80 B, plane-major, children (0,1) and (2,3) packed
+extern "C" __global__ void bvh4h_lane(const N4H *nodes, const RayH *rays, Out *out) {
+    RayH r = rays[threadIdx.x];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(nodes + r.cur);
+    uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], ch = wp[4];
+    const float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z), s = __uint_as_float(w0.w);
+    const float Ax = s * r.ix, Ay = s * r.iy, Az = s * r.iz;
+    const float Bx = __builtin_fmaf(px, r.ix, -r.oix), By = __builtin_fmaf(py, r.iy, -r.oiy), Bz = __builtin_fmaf(pz, r.iz, -r.oiz);
+    const uint32_t w[12] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+    const uint32_t nx0 = r.negx ? w[6] : w[0], nx1 = r.negx ? w[7] : w[1], fx0 = r.negx ? w[0] : w[6], fx1 = r.negx ? w[1] : w[7];
+    const uint32_t ny0 = r.negy ? w[8] : w[2], ny1 = r.negy ? w[9] : w[3], fy0 = r.negy ? w[2] : w[8], fy1 = r.negy ? w[3] : w[9];
+    const uint32_t nz0 = r.negz ? w[10] : w[4], nz1 = r.negz ? w[11] : w[5], fz0 = r.negz ? w[4] : w[10], fz1 = r.negz ? w[5] : w[11];
+    float t[4]; bool h[4]; uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+#define HALF_OF(word, hi_) ((float)((hi_) ? __high2half(*reinterpret_cast<const __half2 *>(&(word))) : __low2half(*reinterpret_cast<const __half2 *>(&(word)))))
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool hi_ = k & 1;
+        const uint32_t wnx = k < 2 ? nx0 : nx1, wny = k < 2 ? ny0 : ny1, wnz = k < 2 ? nz0 : nz1, wfx = k < 2 ? fx0 : fx1, wfy = k < 2 ? fy0 : fy1, wfz = k < 2 ? fz0 : fz1;
+        float e = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(HALF_OF(wnx, hi_), Ax, Bx), __builtin_fmaf(HALF_OF(wny, hi_), Ay, By)), __builtin_fmaf(HALF_OF(wnz, hi_), Az, Bz));
+        float x = __builtin_fminf(__builtin_fminf(__builtin_fmaf(HALF_OF(wfx, hi_), Ax, Bx), __builtin_fmaf(HALF_OF(wfy, hi_), Ay, By)), __builtin_fmaf(HALF_OF(wfz, hi_), Az, Bz));
+        h[k] = (e - x <= r.delta2) && (e < r.tMax) && (x > 0) && c[k] != 0xffffffffu; t[k] = e;
+    }
+#undef HALF_OF
+    Out o; finish<4>(t, h, c, o); out[threadIdx.x] = o;
+}

@@ -111,6 +111,10 @@ struct Stamp { unsigned long long c0, c1, r0, r1; };
 #define OP_CVTPK(i)    "v_cvt_pkrtz_f16_f32 %" #i ", %8, %9\n"
 #define OP_MAXF16PK(i) "v_pk_max_f16 %" #i ", %8, %9\n"
 #define OP_FMA_2DEP(i) "v_fma_f32 %" #i ", %" #i ", %8, %" #i "\n"
+// round 6, last session: an f16 half of a packed word as the multiplicand of an f32 FMA (the candidate node format of tools/isa_probe/node_step_probe.hip: bvh4h_lane)
+#define OP_FMAMIX_LO(i) "v_fma_mix_f32 %" #i ", %10, %8, %9 op_sel_hi:[1,0,0]\n"
+#define OP_FMAMIX_HI(i) "v_fma_mix_f32 %" #i ", %10, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define OP_FMAMIX_DEP(i) "v_fma_mix_f32 %" #i ", %10, %8, %" #i " op_sel_hi:[1,0,0]\n"
 
 #define KINDS(X) X(0, OP_MOV, "v_mov_b32") X(1, OP_FMA, "v_fma_f32") X(2, OP_CVT, "v_cvt_f32_u32 (VOP1)") X(3, OP_CVT_SDWA, "v_cvt_f32_u32_sdwa src0_sel:WORD_1") \
     X(4, OP_CVT_UB, "v_cvt_f32_ubyte1") X(5, OP_AND, "v_and_b32 (literal)") X(6, OP_LSHR, "v_lshrrev_b32") X(7, OP_CNDM_VCC, "v_cndmask_b32 (vcc)") \
@@ -131,7 +135,8 @@ struct Stamp { unsigned long long c0, c1, r0, r1; };
     X(68, OP_MAD64, "v_mad_u64_u32") X(69, OP_LSHLADD64, "v_lshl_add_u64") X(70, OP_LSHL64, "v_lshlrev_b64") X(71, OP_MULHI, "v_mul_hi_u32") X(72, OP_ADDCO, "v_add_co_u32 (-> vcc)") \
     X(73, OP_ASHR, "v_ashrrev_i32") X(74, OP_SUBF, "v_sub_f32") X(75, OP_MOV64, "v_mov_b64") X(76, OP_DIVSCALE, "v_div_scale_f32") X(77, OP_DIVFMAS, "v_div_fmas_f32") X(78, OP_DIVFIX, "v_div_fixup_f32") \
     X(79, OP_SQRT, "v_sqrt_f32") X(80, OP_CVTF64, "v_cvt_f64_f32") X(81, OP_ADDF64, "v_add_f64") X(82, OP_FMAF64, "v_fma_f64") X(83, OP_CVTF32F64, "v_cvt_f32_f64") X(84, OP_WRLANE, "v_writelane_b32") \
-    X(85, OP_BFI, "v_bfi_b32") X(86, OP_ALIGNBIT, "v_alignbit_b32") X(87, OP_CVTPK, "v_cvt_pkrtz_f16_f32") X(88, OP_MAXF16PK, "v_pk_max_f16") X(89, OP_FMA_2DEP, "v_fma_f32 (dst = src0 = src2)")
+    X(85, OP_BFI, "v_bfi_b32") X(86, OP_ALIGNBIT, "v_alignbit_b32") X(87, OP_CVTPK, "v_cvt_pkrtz_f16_f32") X(88, OP_MAXF16PK, "v_pk_max_f16") X(89, OP_FMA_2DEP, "v_fma_f32 (dst = src0 = src2)") \
+    X(90, OP_FMAMIX_LO, "v_fma_mix_f32 (f16 low half x f32 + f32, no self dependency)") X(91, OP_FMAMIX_HI, "v_fma_mix_f32 (f16 high half)") X(92, OP_FMAMIX_DEP, "v_fma_mix_f32 (dst = src2)")
 #define NKINDS 33
 
 template <int KIND>
