@@ -752,6 +752,9 @@ typedef int32_t PtLdsInt;     // an LDS address is 32 bits wide on the device (S
 #else
 typedef intptr_t PtLdsInt;    // host build of this header: the "LDS" arrays are ordinary memory
 #endif
+#ifndef PT_FIFTH_LOAD
+#define PT_FIFTH_LOAD 0   /* measurement switch, see TravNodeStepQ2 */
+#endif
 template <int STRIDE, int NLDS>
 struct TravStackB {
     enum { LDS_ENTRIES = NLDS, STRIDE_ = STRIDE, SBYTES = STRIDE * 4 };
@@ -788,6 +791,17 @@ PT_DEV void TravNodeStepQ2(const DevScene &sc, TravStateQ &ts, ST &st, TraceCoun
         w0 = w[0]; w1 = w[1]; w2 = w[2]; ch = w[3];
     }
     const uint32_t spec = *st.tp;   // what a pop would return (valid whenever the fast tail runs: nothing spilled); in flight with the node words
+#if PT_FIFTH_LOAD
+    // MEASUREMENT ONLY (never shipped; profiles/r06_w_f16_node_probe.txt): what would the fifth 16-byte request of an 80-byte node cost this step?  The first word of
+    // the NEXT node stands in for it -- the next 128-byte line for every second node, as with 80-byte nodes; one more ds_read_b128 for a hot node -- and is waited for
+    // with the node words, unused.  (Reads 16 bytes of the node after the last one: inside the allocation's granule on the scenes this is run on.)
+    {
+        uint4 w4;
+        if (isHot) { const U32x4 f = (hot + ts.cur + 1u)[0]; w4 = make_uint4(f.x, f.y, f.z, f.w); }
+        if (!isHot) w4 = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur + 1u)[0];
+        Pin(w4);
+    }
+#endif
     if (COUNT) ++cnt->nodes;
     const uint32_t wd[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, ch.x, ch.y, ch.z, ch.w};
     Float e[4], x[4];
