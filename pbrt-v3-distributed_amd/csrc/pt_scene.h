@@ -797,8 +797,9 @@ PT_DEV void TravNodeStepQ2(const DevScene &sc, TravStateQ &ts, ST &st, TraceCoun
     // with the node words, unused.  (Reads 16 bytes of the node after the last one: inside the allocation's granule on the scenes this is run on.)
     {
         uint4 w4;
-        if (isHot) { const U32x4 f = (hot + ts.cur + 1u)[0]; w4 = make_uint4(f.x, f.y, f.z, f.w); }
-        if (!isHot) w4 = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur + 1u)[0];
+        w4 = make_uint4(0, 0, 0, 0);
+        if (isHot && PT_FIFTH_LOAD != 3) { const U32x4 f = (hot + ts.cur + 1u)[0]; w4 = make_uint4(f.x, f.y, f.z, f.w); }   // (2: the LDS request only, 3: the global one only)
+        if (!isHot && PT_FIFTH_LOAD != 2) w4 = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur + 1u)[0];
         Pin(w4);
     }
 #endif
