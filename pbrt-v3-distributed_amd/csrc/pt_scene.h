@@ -799,7 +799,13 @@ PT_DEV void TravNodeStepQ2(const DevScene &sc, TravStateQ &ts, ST &st, TraceCoun
         uint4 w4;
         w4 = make_uint4(0, 0, 0, 0);
         if (isHot && PT_FIFTH_LOAD != 3) { const U32x4 f = (hot + ts.cur + 1u)[0]; w4 = make_uint4(f.x, f.y, f.z, f.w); }   // (2: the LDS request only, 3: the global one only)
-        if (!isHot && PT_FIFTH_LOAD != 2) w4 = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur + 1u)[0];
+        if (!isHot && PT_FIFTH_LOAD != 2 && PT_FIFTH_LOAD != 4) w4 = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur + 1u)[0];
+#if PT_FIFTH_LOAD == 4   // 4: the cold lanes load their OWN node's last word a second time (same 128-byte line, no new miss): is it the request or the line that costs?
+        if (!isHot) {
+            const uint4 *again = reinterpret_cast<const uint4 *>(sc.nodesq + ts.cur) + 3;
+            asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(w4) : "v"(again) : "memory");   // (the wait inside: the compiler does not count this load)
+        }
+#endif
         Pin(w4);
     }
 #endif
